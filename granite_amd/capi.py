@@ -1,0 +1,330 @@
+"""ctypes binding of the gfx950 executor's C ABI (include/granite_hip.h).
+
+This is the Python-side twin of what a Granite maintainer binds from C++: plain pointers and sizes,
+no torch types.  The library is built in-tree by ``__graft_entry__.build()`` / ``granite_amd/csrc/Makefile`` and must be
+present: there is no CPU fallback, every entry point raises if the HIP library is missing or a call fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgranite_hip.so")
+
+# gr_format (VkFormat numeric values)
+FORMAT_R8_UNORM = 9
+FORMAT_R8G8_UNORM = 16
+FORMAT_R8G8B8A8_UNORM = 37
+FORMAT_R8G8B8A8_SRGB = 43
+FORMAT_A2B10G10R10_UNORM_PACK32 = 64
+FORMAT_R16G16_SFLOAT = 83
+FORMAT_R16G16B16A16_SFLOAT = 97
+FORMAT_R32_SFLOAT = 100
+FORMAT_D16_UNORM = 124
+FORMAT_D32_SFLOAT = 126
+
+FORMAT_BPP = {
+    FORMAT_R8_UNORM: 1,
+    FORMAT_R8G8_UNORM: 2,
+    FORMAT_R8G8B8A8_UNORM: 4,
+    FORMAT_R8G8B8A8_SRGB: 4,
+    FORMAT_A2B10G10R10_UNORM_PACK32: 4,
+    FORMAT_R16G16_SFLOAT: 4,
+    FORMAT_R16G16B16A16_SFLOAT: 8,
+    FORMAT_R32_SFLOAT: 4,
+    FORMAT_D16_UNORM: 2,
+    FORMAT_D32_SFLOAT: 4,
+}
+
+LIGHTING_DIRECTIONAL_BIT = 1
+LIGHTING_CLUSTERED_BIT = 2
+LIGHTING_AMBIENT_FALLBACK_BIT = 4
+
+MAX_LIGHTS_BINDLESS = 4096
+CULL_SETUP_BYTES_PER_LIGHT = 512
+TRANSFORMED_SPOT_BYTES_PER_LIGHT = 96
+TRANSFORMS_OFFSET_LIGHTS = 0
+TRANSFORMS_OFFSET_SHADOW = 196608
+TRANSFORMS_OFFSET_MODEL = 458752
+TRANSFORMS_OFFSET_TYPE_MASK = 655360
+TRANSFORMS_OFFSET_DECALS = 655872
+TRANSFORMS_SIZE = 852480
+
+
+class Image(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("pitch_bytes", C.c_uint32),
+                ("format", C.c_uint32)]
+
+
+class TimingEntry(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("count", C.c_uint64), ("total_ms", C.c_double)]
+
+
+class PushBloomThreshold(C.Structure):
+    _fields_ = [("threads", C.c_uint32 * 2), ("inv_output_size", C.c_float * 2)]
+
+
+class PushBloomDownsample(C.Structure):
+    _fields_ = [("threads", C.c_uint32 * 2), ("inv_output_size", C.c_float * 2), ("inv_input_size", C.c_float * 2),
+                ("lerp", C.c_float)]
+
+
+class PushBloomUpsample(C.Structure):
+    _fields_ = [("threads", C.c_uint32 * 2), ("inv_output_size", C.c_float * 2), ("inv_input_size", C.c_float * 2)]
+
+
+class PushLuminance(C.Structure):
+    _fields_ = [("size", C.c_uint32 * 2), ("lerp", C.c_float), ("min_loglum", C.c_float), ("max_loglum", C.c_float)]
+
+
+class PushTonemap(C.Structure):
+    _fields_ = [("dynamic_exposure", C.c_float)]
+
+
+class ClusterParams(C.Structure):
+    _fields_ = [("transform", C.c_float * 16), ("clip_scale", C.c_float * 4), ("camera_base", C.c_float * 3),
+                ("pad0", C.c_float), ("camera_front", C.c_float * 3), ("pad1", C.c_float), ("xy_scale", C.c_float * 2),
+                ("resolution_xy", C.c_int32 * 2), ("inv_resolution_xy", C.c_float * 2), ("num_lights", C.c_int32),
+                ("num_lights_32", C.c_int32), ("num_decals", C.c_int32), ("num_decals_32", C.c_int32),
+                ("decals_texture_offset", C.c_int32), ("z_max_index", C.c_int32), ("z_scale", C.c_float),
+                ("pad2", C.c_float * 3)]
+
+
+assert C.sizeof(ClusterParams) == 176
+
+
+class PushSpotTransform(C.Structure):
+    _fields_ = [("vp", C.c_float * 16), ("camera_pos", C.c_float * 3), ("num_lights", C.c_uint32),
+                ("camera_front", C.c_float * 3), ("z_near", C.c_float), ("z_far", C.c_float)]
+
+
+assert C.sizeof(PushSpotTransform) == 100
+
+
+class PushClusterSetup(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("num_lights", C.c_uint32)]
+
+
+class PushZRange(C.Structure):
+    _fields_ = [("num_volumes", C.c_uint32), ("num_volumes_128", C.c_uint32), ("num_ranges", C.c_uint32)]
+
+
+class PushDirectional(C.Structure):
+    _fields_ = [("inv_view_proj_col2", C.c_float * 4), ("color", C.c_float * 3), ("environment_intensity", C.c_float),
+                ("camera_pos", C.c_float * 3), ("environment_mipscale", C.c_float), ("direction", C.c_float * 3),
+                ("cascade_log_bias", C.c_float), ("camera_front", C.c_float * 3), ("pad0", C.c_float),
+                ("inv_resolution", C.c_float * 2), ("pad1", C.c_float * 2)]
+
+
+class PushClustering(C.Structure):
+    _fields_ = [("inv_view_proj_col2", C.c_float * 4), ("camera_pos", C.c_float * 3), ("pad0", C.c_float),
+                ("inv_resolution", C.c_float * 2), ("pad1", C.c_float * 2)]
+
+
+class LightingArgs(C.Structure):
+    _fields_ = [("albedo", Image), ("normal", Image), ("pbr", Image), ("depth", Image), ("hdr", Image),
+                ("inv_view_projection", C.c_float * 16), ("directional", PushDirectional), ("clustering", PushClustering),
+                ("cluster", ClusterParams), ("transforms", C.c_void_p), ("bitmask", C.c_void_p), ("range", C.c_void_p),
+                ("flags", C.c_uint32)]
+
+
+class GraniteHipError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree libgranite_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GraniteHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    vp = C.c_void_p
+    sigs = {
+        "gr_abi_version": (C.c_int, []),
+        "gr_create": (vp, [C.c_int]),
+        "gr_destroy": (None, [vp]),
+        "gr_last_error": (C.c_char_p, [vp]),
+        "gr_sync": (C.c_int, [vp, vp]),
+        "gr_alloc": (C.c_int, [vp, C.c_size_t, P(vp)]),
+        "gr_free": (C.c_int, [vp, vp]),
+        "gr_upload": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
+        "gr_download": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
+        "gr_copy": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
+        "gr_fill_zero": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "gr_timing_enable": (C.c_int, [vp, C.c_int]),
+        "gr_timing_reset": (C.c_int, [vp]),
+        "gr_timing_query": (C.c_int, [vp, P(TimingEntry), C.c_int]),
+        "gr_bloom_threshold": (C.c_int, [vp, vp, P(Image), P(Image), vp, P(PushBloomThreshold)]),
+        "gr_bloom_downsample": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushBloomDownsample)]),
+        "gr_bloom_upsample": (C.c_int, [vp, vp, P(Image), P(Image), P(PushBloomUpsample)]),
+        "gr_luminance": (C.c_int, [vp, vp, P(Image), vp, P(PushLuminance)]),
+        "gr_tonemap": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushTonemap)]),
+        "gr_cluster_spot_transform": (C.c_int, [vp, vp, vp, vp, P(PushSpotTransform)]),
+        "gr_cluster_setup": (C.c_int, [vp, vp, vp, vp, vp, P(ClusterParams), P(PushClusterSetup)]),
+        "gr_cluster_binning": (C.c_int, [vp, vp, vp, vp, vp, P(ClusterParams)]),
+        "gr_cluster_z_range": (C.c_int, [vp, vp, vp, vp, P(PushZRange)]),
+        "gr_lighting": (C.c_int, [vp, vp, P(LightingArgs)]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "gr_abi_version", "gr_create", "gr_destroy", "gr_last_error", "gr_sync", "gr_alloc", "gr_free", "gr_upload",
+    "gr_download", "gr_copy", "gr_fill_zero", "gr_timing_enable", "gr_timing_reset", "gr_timing_query",
+    "gr_bloom_threshold", "gr_bloom_downsample", "gr_bloom_upsample", "gr_luminance", "gr_tonemap",
+    "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
+]
+
+
+class DeviceBuffer:
+    """A zero-initialised HBM allocation owned through gr_alloc/gr_free."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        ctx.check(ctx.lib.gr_alloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, array: np.ndarray, offset: int = 0) -> "DeviceBuffer":
+        a = np.ascontiguousarray(array)
+        assert offset + a.nbytes <= self.nbytes, (offset, a.nbytes, self.nbytes)
+        self.ctx.check(self.ctx.lib.gr_upload(self.ctx.handle, None, self.ptr + offset, a.ctypes.data, a.nbytes))
+        self.ctx.sync()
+        return self
+
+    def download(self, dtype=np.uint8, count: Optional[int] = None, offset: int = 0) -> np.ndarray:
+        dt = np.dtype(dtype)
+        n = (self.nbytes - offset) // dt.itemsize if count is None else count
+        out = np.empty(n, dtype=dt)
+        self.ctx.check(self.ctx.lib.gr_download(self.ctx.handle, None, out.ctypes.data, self.ptr + offset, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.gr_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceImage:
+    """A linear row-major attachment in HBM (tight pitch) + its gr_image descriptor."""
+
+    def __init__(self, ctx: "Context", width: int, height: int, fmt: int, ptr: Optional[int] = None):
+        self.ctx = ctx
+        self.width, self.height, self.format = int(width), int(height), int(fmt)
+        self.bpp = FORMAT_BPP[fmt]
+        self.pitch = self.width * self.bpp
+        self.buffer = None
+        if ptr is None:
+            self.buffer = DeviceBuffer(ctx, self.pitch * self.height)
+            ptr = self.buffer.ptr
+        self.ptr = ptr
+        self.desc = Image(ptr, self.width, self.height, self.pitch, self.format)
+
+    def upload(self, array: np.ndarray) -> "DeviceImage":
+        a = np.ascontiguousarray(array)
+        assert a.nbytes == self.pitch * self.height, (a.shape, a.dtype, self.width, self.height, self.bpp)
+        self.ctx.check(self.ctx.lib.gr_upload(self.ctx.handle, None, self.ptr, a.ctypes.data, a.nbytes))
+        self.ctx.sync()
+        return self
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.pitch * self.height, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.gr_download(self.ctx.handle, None, out.ctypes.data, self.ptr, out.nbytes))
+        if self.format == FORMAT_R16G16B16A16_SFLOAT:
+            return out.view(np.uint16).reshape(self.height, self.width, 4)
+        if self.format in (FORMAT_R8G8B8A8_SRGB, FORMAT_R8G8B8A8_UNORM):
+            return out.reshape(self.height, self.width, 4)
+        if self.format == FORMAT_R8G8_UNORM:
+            return out.reshape(self.height, self.width, 2)
+        if self.format in (FORMAT_D32_SFLOAT, FORMAT_R32_SFLOAT):
+            return out.view(np.float32).reshape(self.height, self.width)
+        if self.format == FORMAT_A2B10G10R10_UNORM_PACK32:
+            return out.view(np.uint32).reshape(self.height, self.width)
+        if self.format == FORMAT_R16G16_SFLOAT:
+            return out.view(np.uint16).reshape(self.height, self.width, 2)
+        return out.reshape(self.height, self.pitch)
+
+
+class Context:
+    """gr_ctx wrapper. `stream` arguments are raw hipStream_t handles (ints) or None for the default stream."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.handle = self.lib.gr_create(device)
+        if not self.handle:
+            raise GraniteHipError(f"gr_create({device}) failed: no usable HIP device")
+
+    def check(self, code: int):
+        if code < 0:
+            raise GraniteHipError(f"[{code}] {self.lib.gr_last_error(self.handle).decode()}")
+        return code
+
+    def sync(self, stream=None):
+        self.check(self.lib.gr_sync(self.handle, stream))
+
+    def close(self):
+        if self.handle:
+            self.lib.gr_destroy(self.handle)
+            self.handle = None
+
+    # ---- timing -----------------------------------------------------------------------------------------------
+    def timing_enable(self, enable: bool):
+        self.check(self.lib.gr_timing_enable(self.handle, int(enable)))
+
+    def timing_reset(self):
+        self.check(self.lib.gr_timing_reset(self.handle))
+
+    def timing_query(self):
+        arr = (TimingEntry * 64)()
+        n = self.check(self.lib.gr_timing_query(self.handle, arr, 64))
+        return {arr[i].name.decode(): (int(arr[i].count), float(arr[i].total_ms)) for i in range(n)}
+
+    # ---- post chain -------------------------------------------------------------------------------------------
+    def bloom_threshold(self, hdr: DeviceImage, out: DeviceImage, lum_ptr=None, stream=None):
+        push = PushBloomThreshold((out.width, out.height), (1.0 / out.width, 1.0 / out.height))
+        self.check(self.lib.gr_bloom_threshold(self.handle, stream, hdr.desc, out.desc, lum_ptr, push))
+
+    def bloom_downsample(self, src: DeviceImage, out: DeviceImage, history: Optional[DeviceImage] = None, lerp: float = 0.0,
+                         stream=None):
+        push = PushBloomDownsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height),
+                                   (1.0 / src.width, 1.0 / src.height), lerp)
+        self.check(self.lib.gr_bloom_downsample(self.handle, stream, src.desc, out.desc,
+                                                history.desc if history is not None else None, push))
+
+    def bloom_upsample(self, src: DeviceImage, out: DeviceImage, stream=None):
+        push = PushBloomUpsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height),
+                                 (1.0 / src.width, 1.0 / src.height))
+        self.check(self.lib.gr_bloom_upsample(self.handle, stream, src.desc, out.desc, push))
+
+    def luminance(self, d3: DeviceImage, lum_ptr, lerp: float, min_loglum: float = -3.0, max_loglum: float = 2.0, stream=None):
+        push = PushLuminance((d3.width // 2, d3.height // 2), lerp, min_loglum, max_loglum)
+        self.check(self.lib.gr_luminance(self.handle, stream, d3.desc, lum_ptr, push))
+
+    def tonemap(self, hdr: DeviceImage, bloom: DeviceImage, out: DeviceImage, lum_ptr=None, dynamic_exposure: float = 1.0,
+                stream=None):
+        push = PushTonemap(dynamic_exposure)
+        self.check(self.lib.gr_tonemap(self.handle, stream, hdr.desc, bloom.desc, out.desc, lum_ptr, push))

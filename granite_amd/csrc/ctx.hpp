@@ -1,0 +1,120 @@
+// Internal context of the C ABI (include/granite_hip.h).  Not part of the public interface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/granite_hip.h"
+
+struct gr_timing_span
+{
+	const char *name;
+	hipEvent_t start, stop;
+};
+
+struct gr_ctx
+{
+	int device = 0;
+	std::mutex lock;
+	std::string last_error;
+
+	// 256-entry sRGB8 -> linear table (assets/shaders/inc/srgb.h:4-10 semantics, what the sampler hardware does for
+	// an *_SRGB view), built on the host and resident in HBM.
+	float *srgb_decode_lut = nullptr;
+
+	// SMAA lookup tables (assets/textures/smaa/{area,search}.gtx payloads), uploaded through gr_smaa_set_luts.
+	void *smaa_area = nullptr;   // RG8, 160 x 560
+	void *smaa_search = nullptr; // R8, 64 x 16
+
+	bool timing_enabled = false;
+	std::vector<gr_timing_span> spans;
+	std::vector<hipEvent_t> event_pool;
+	struct Accum { uint64_t count = 0; double ms = 0.0; };
+	std::map<std::string, Accum> accum;
+	std::vector<std::string> accum_order;
+
+	int fail(int code, const char *fmt, ...)
+	{
+		char buf[512];
+		va_list va;
+		va_start(va, fmt);
+		vsnprintf(buf, sizeof(buf), fmt, va);
+		va_end(va);
+		std::lock_guard<std::mutex> holder{lock};
+		last_error = buf;
+		return code;
+	}
+
+	hipEvent_t get_event()
+	{
+		if (!event_pool.empty())
+		{
+			hipEvent_t e = event_pool.back();
+			event_pool.pop_back();
+			return e;
+		}
+		hipEvent_t e;
+		if (hipEventCreate(&e) != hipSuccess)
+			return nullptr;
+		return e;
+	}
+};
+
+// RAII bracket used by every launcher: records hipEvents on the launch stream around the kernel when timing is on.
+struct gr_scoped_timing
+{
+	gr_ctx *ctx;
+	hipStream_t stream;
+	gr_timing_span span{};
+	bool active = false;
+	gr_scoped_timing(gr_ctx *ctx_, hipStream_t stream_, const char *name) : ctx(ctx_), stream(stream_)
+	{
+		if (!ctx->timing_enabled)
+			return;
+		std::lock_guard<std::mutex> holder{ctx->lock};
+		span.name = name;
+		span.start = ctx->get_event();
+		span.stop = ctx->get_event();
+		if (!span.start || !span.stop)
+			return;
+		active = true;
+		(void)hipEventRecord(span.start, stream);
+	}
+	~gr_scoped_timing()
+	{
+		if (!active)
+			return;
+		(void)hipEventRecord(span.stop, stream);
+		std::lock_guard<std::mutex> holder{ctx->lock};
+		ctx->spans.push_back(span);
+	}
+};
+
+#define GR_CHECK_ARG(ctx, cond)                                                                   \
+	do                                                                                            \
+	{                                                                                             \
+		if (!(cond))                                                                              \
+			return (ctx)->fail(GR_ERR_INVALID_ARGUMENT, "%s: invalid argument: %s", __func__, #cond); \
+	} while (0)
+
+#define GR_CHECK_HIP(ctx, expr)                                                                        \
+	do                                                                                                 \
+	{                                                                                                  \
+		hipError_t err__ = (expr);                                                                     \
+		if (err__ != hipSuccess)                                                                       \
+			return (ctx)->fail(GR_ERR_HIP, "%s: %s failed: %s", __func__, #expr, hipGetErrorString(err__)); \
+	} while (0)
+
+#define GR_CHECK_LAUNCH(ctx)                                                                          \
+	do                                                                                                \
+	{                                                                                                 \
+		hipError_t err__ = hipGetLastError();                                                         \
+		if (err__ != hipSuccess)                                                                      \
+			return (ctx)->fail(GR_ERR_HIP, "%s: kernel launch failed: %s", __func__, hipGetErrorString(err__)); \
+	} while (0)
+
+static inline hipStream_t gr_to_stream(gr_stream s) { return static_cast<hipStream_t>(s); }
+static inline unsigned gr_div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }

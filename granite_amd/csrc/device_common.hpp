@@ -1,0 +1,133 @@
+// Device-side helpers shared by the gfx950 kernels: storage-format codecs and the software sampler over linear
+// HBM images.  Wavefront = 64 everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct DevImage
+{
+	const uint8_t *ptr;
+	int w, h;
+	uint32_t pitch;
+};
+
+struct DevImageRW
+{
+	uint8_t *ptr;
+	int w, h;
+	uint32_t pitch;
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// RGBA16F texel fetch: one 8-byte load, hardware cvt to fp32.
+__device__ __forceinline__ float4 load_rgba16f(const DevImage &img, int x, int y)
+{
+	const f16x4 h = *reinterpret_cast<const f16x4 *>(img.ptr + size_t(y) * img.pitch + size_t(x) * 8u);
+	return make_float4(float(h.x), float(h.y), float(h.z), float(h.w));
+}
+
+__device__ __forceinline__ float4 load_rgba16f_clamped(const DevImage &img, int x, int y)
+{
+	return load_rgba16f(img, clampi(x, 0, img.w - 1), clampi(y, 0, img.h - 1));
+}
+
+// fp32 -> fp16 with round-to-nearest-even (v_cvt_f16_f32 under the default rounding mode), as an RGBA16F attachment
+// store does.
+__device__ __forceinline__ f16x4 pack_rgba16f(float4 v)
+{
+	f16x4 h;
+	h.x = _Float16(v.x);
+	h.y = _Float16(v.y);
+	h.z = _Float16(v.z);
+	h.w = _Float16(v.w);
+	return h;
+}
+
+__device__ __forceinline__ void store_rgba16f(const DevImageRW &img, int x, int y, float4 v)
+{
+	*reinterpret_cast<f16x4 *>(img.ptr + size_t(y) * img.pitch + size_t(x) * 8u) = pack_rgba16f(v);
+}
+
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 fma4(float4 a, float s, float4 c)
+{
+	return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
+}
+
+// StockSampler::LinearClamp, LOD 0, on an RGBA16F image: unnormalised coordinate uv*size - 0.5, exact fp32 weights.
+__device__ __forceinline__ float4 sample_linear_rgba16f(const DevImage &img, float u, float v)
+{
+	const float fx = u * float(img.w) - 0.5f;
+	const float fy = v * float(img.h) - 0.5f;
+	const float flx = floorf(fx), fly = floorf(fy);
+	const float a = fx - flx, b = fy - fly;
+	const int ix = int(flx), iy = int(fly);
+	const int x0 = clampi(ix, 0, img.w - 1), x1 = clampi(ix + 1, 0, img.w - 1);
+	const int y0 = clampi(iy, 0, img.h - 1), y1 = clampi(iy + 1, 0, img.h - 1);
+	const float4 t00 = load_rgba16f(img, x0, y0), t10 = load_rgba16f(img, x1, y0);
+	const float4 t01 = load_rgba16f(img, x0, y1), t11 = load_rgba16f(img, x1, y1);
+	const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+	float4 r = t00 * w00;
+	r = fma4(t10, w10, r);
+	r = fma4(t01, w01, r);
+	r = fma4(t11, w11, r);
+	return r;
+}
+
+__device__ __forceinline__ float saturatef(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+
+// Linear -> sRGB8 as an *_SRGB attachment store: encode (assets/shaders/inc/srgb.h:12-18 formula), then UNORM8 rounding.
+__device__ __forceinline__ uint32_t encode_srgb8(float c)
+{
+	c = saturatef(c);
+	const float lo = c * 12.92f;
+	const float hi = fmaf(1.055f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(fmaxf(c, 1e-30f)) * (1.0f / 2.4f)), -0.055f);
+	const float e = saturatef(c <= 0.0031308f ? lo : hi);
+	return uint32_t(e * 255.0f + 0.5f);
+}
+
+__device__ __forceinline__ uint32_t encode_unorm8(float c)
+{
+	return uint32_t(saturatef(c) * 255.0f + 0.5f);
+}
+
+// Wave64 reductions by cross-lane shuffles (no LDS).
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v |= uint32_t(__shfl_xor(int(v), off, 64));
+	return v;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v = min(v, uint32_t(__shfl_xor(int(v), off, 64)));
+	return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v = max(v, uint32_t(__shfl_xor(int(v), off, 64)));
+	return v;
+}

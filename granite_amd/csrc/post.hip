@@ -1,0 +1,327 @@
+// HDR post chain kernels for gfx950 and their C-ABI launchers (include/granite_hip.h).
+//
+// Replaces assets/shaders/post/{bloom_threshold,bloom_downsample,bloom_upsample,luminance}.comp and tonemap.frag as
+// recorded by renderer/post/hdr.cpp:68-216,283-306.  All targets are linear row-major HBM buffers; every kernel is
+// HBM-bound (no MFMA): one pass over its declared inputs, coalesced 8/16-byte accesses per lane.
+#include "ctx.hpp"
+#include "device_common.hpp"
+
+namespace
+{
+constexpr int POST_BLOCK_X = 32;
+constexpr int POST_BLOCK_Y = 8;
+
+static inline DevImage to_dev(const gr_image *img)
+{
+	return {static_cast<const uint8_t *>(img->ptr), int(img->width), int(img->height), img->pitch_bytes};
+}
+static inline DevImageRW to_dev_rw(const gr_image *img)
+{
+	return {static_cast<uint8_t *>(img->ptr), int(img->width), int(img->height), img->pitch_bytes};
+}
+
+// ---- bloom threshold (bloom_threshold.comp:23-44) ------------------------------------------------------------------
+template <bool DYNAMIC_EXPOSURE>
+__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold(DevImage hdr, DevImageRW out,
+                                                                                const gr_luminance_data *lum,
+                                                                                gr_push_bloom_threshold push)
+{
+	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
+	const int y = blockIdx.y * POST_BLOCK_Y + threadIdx.y;
+	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= push.threads[1])
+		return;
+
+	const float u = (float(x) + 0.5f) * push.inv_output_size[0];
+	const float v = (float(y) + 0.5f) * push.inv_output_size[1];
+	const float4 c = sample_linear_rgba16f(hdr, u, v);
+
+	float luminance = fmaxf(fmaxf(c.x, c.y), c.z) + 0.0001f;
+	const float loglum = __log2f(luminance);
+	const float inv = 1.0f / luminance;
+	float r = c.x * inv, g = c.y * inv, b = c.z * inv;
+	if (DYNAMIC_EXPOSURE)
+		luminance -= 8.0f * lum->average_linear_luminance;
+	else
+		luminance -= 8.0f;
+	store_rgba16f(out, x, y,
+	              make_float4(fmaxf(r * luminance, 0.0f), fmaxf(g * luminance, 0.0f), fmaxf(b * luminance, 0.0f), loglum));
+}
+
+// ---- 9-tap tent (bloom_downsample.comp:30-38 / bloom_upsample.comp:25-33) --------------------------------------------
+__device__ __forceinline__ float4 tent9(const DevImage &in, float u, float v, float ox, float oy)
+{
+	float4 value = sample_linear_rgba16f(in, u, v) * 0.25f;
+	value = fma4(sample_linear_rgba16f(in, u - ox, v + oy), 0.0625f, value);
+	value = fma4(sample_linear_rgba16f(in, u, v + oy), 0.125f, value);
+	value = fma4(sample_linear_rgba16f(in, u + ox, v + oy), 0.0625f, value);
+	value = fma4(sample_linear_rgba16f(in, u - ox, v), 0.125f, value);
+	value = fma4(sample_linear_rgba16f(in, u + ox, v), 0.125f, value);
+	value = fma4(sample_linear_rgba16f(in, u - ox, v - oy), 0.0625f, value);
+	value = fma4(sample_linear_rgba16f(in, u, v - oy), 0.125f, value);
+	value = fma4(sample_linear_rgba16f(in, u + ox, v - oy), 0.0625f, value);
+	return value;
+}
+
+template <bool FEEDBACK>
+__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_downsample(DevImage in, DevImageRW out, DevImage history,
+                                                                                 gr_push_bloom_downsample push)
+{
+	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
+	const int y = blockIdx.y * POST_BLOCK_Y + threadIdx.y;
+	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= push.threads[1])
+		return;
+	const float u = (float(x) + 0.5f) * push.inv_output_size[0];
+	const float v = (float(y) + 0.5f) * push.inv_output_size[1];
+	float4 value = tent9(in, u, v, 1.75f * push.inv_input_size[0], 1.75f * push.inv_input_size[1]);
+	if (FEEDBACK)
+	{
+		// NearestClamp fetch of the previous frame's level at the same texel (hdr.cpp:160-166).
+		const int hx = clampi(int(floorf(u * float(history.w))), 0, history.w - 1);
+		const int hy = clampi(int(floorf(v * float(history.h))), 0, history.h - 1);
+		const float4 h = load_rgba16f(history, hx, hy);
+		const float l = push.lerp;
+		// mix(history, value, vec4(lerp, lerp, lerp, 1)) = h*(1-a) + value*a
+		value = make_float4(h.x * (1.0f - l) + value.x * l, h.y * (1.0f - l) + value.y * l, h.z * (1.0f - l) + value.z * l,
+		                    value.w);
+	}
+	store_rgba16f(out, x, y, value);
+}
+
+__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_upsample(DevImage in, DevImageRW out,
+                                                                               gr_push_bloom_upsample push)
+{
+	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
+	const int y = blockIdx.y * POST_BLOCK_Y + threadIdx.y;
+	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= push.threads[1])
+		return;
+	const float u = (float(x) + 0.5f) * push.inv_output_size[0];
+	const float v = (float(y) + 0.5f) * push.inv_output_size[1];
+	store_rgba16f(out, x, y, tent9(in, u, v, 0.875f * push.inv_input_size[0], 0.875f * push.inv_input_size[1]));
+}
+
+// ---- average luminance (luminance.comp:25-67) ---------------------------------------------------------------------
+// The reference walks the sample grid with ONE 8x8 workgroup (latency-bound serial loop).  Here a single 1024-thread
+// workgroup strides the grid, reduces each wave64 with cross-lane shuffles, then the 16 wave partials through LDS.
+// Summation order is fixed (deterministic across runs and ranks) but differs from the reference's tree: covered by the
+// stated fp32 tolerance on LuminanceData.
+constexpr int LUM_THREADS = 1024;
+__global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_luminance_data *lum, gr_push_luminance push)
+{
+	__shared__ float wave_partial[LUM_THREADS / 64];
+	const int sx = int(push.size[0]), sy = int(push.size[1]);
+	const float inv_x = 1.0f / float(sx), inv_y = 1.0f / float(sy);
+	const int total = sx * sy;
+	float sum = 0.0f;
+	for (int i = threadIdx.x; i < total; i += LUM_THREADS)
+	{
+		const int py = i / sx, px = i - py * sx;
+		sum += sample_linear_rgba16f(in, (float(px) + 0.5f) * inv_x, (float(py) + 0.5f) * inv_y).w;
+	}
+	sum = wave_sum(sum);
+	if ((threadIdx.x & 63) == 0)
+		wave_partial[threadIdx.x >> 6] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		float loglum = 0.0f;
+#pragma unroll
+		for (int i = 0; i < LUM_THREADS / 64; i++)
+			loglum += wave_partial[i];
+		loglum *= inv_x * inv_y;
+		loglum = fminf(fmaxf(loglum, push.min_loglum), push.max_loglum);
+		const float prev = lum->average_log_luminance;
+		const float new_log_luma = prev * (1.0f - push.lerp) + loglum * push.lerp;
+		lum->average_log_luminance = new_log_luma;
+		lum->average_linear_luminance = exp2f(new_log_luma);
+		lum->average_inv_linear_luminance = exp2f(-new_log_luma);
+	}
+}
+
+// ---- tonemap (tonemap.frag:30-66) -----------------------------------------------------------------------------------
+__device__ __forceinline__ float uncharted2(float x)
+{
+	const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+	return ((x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F)) - E / F;
+}
+
+constexpr int TONEMAP_PX = 4; // pixels per lane: 2 x 16 B loads, one 16 B store
+constexpr int TONEMAP_BLOCK_X = 64;
+constexpr int TONEMAP_BLOCK_Y = 4;
+
+template <bool DYNAMIC_EXPOSURE, bool SRGB>
+__global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(DevImage hdr, DevImage bloom, DevImageRW out,
+                                                                              const gr_luminance_data *lum,
+                                                                              gr_push_tonemap push)
+{
+	const int x0 = (blockIdx.x * TONEMAP_BLOCK_X + threadIdx.x) * TONEMAP_PX;
+	const int y = blockIdx.y * TONEMAP_BLOCK_Y + threadIdx.y;
+	if (x0 >= hdr.w || y >= hdr.h)
+		return;
+
+	const float inv_w = 1.0f / float(hdr.w), inv_h = 1.0f / float(hdr.h);
+	const float white_scale = 1.0f / uncharted2(11.2f);
+	float scale = push.dynamic_exposure;
+	if (DYNAMIC_EXPOSURE)
+		scale *= lum->average_inv_linear_luminance;
+	const float v = (float(y) + 0.5f) * inv_h;
+
+	const uint8_t *row = hdr.ptr + size_t(y) * hdr.pitch;
+	uint32_t packed[TONEMAP_PX];
+	const bool full = (x0 + TONEMAP_PX <= hdr.w) && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+	f16x4 texels[TONEMAP_PX];
+	if (full)
+	{
+		// 32 contiguous bytes per lane, 2 KiB per wave per row.
+		const u32x4 lo = *reinterpret_cast<const u32x4 *>(row + size_t(x0) * 8u);
+		const u32x4 hi = *reinterpret_cast<const u32x4 *>(row + size_t(x0) * 8u + 16u);
+		texels[0] = __builtin_bit_cast(f16x4, u32x2{lo.x, lo.y});
+		texels[1] = __builtin_bit_cast(f16x4, u32x2{lo.z, lo.w});
+		texels[2] = __builtin_bit_cast(f16x4, u32x2{hi.x, hi.y});
+		texels[3] = __builtin_bit_cast(f16x4, u32x2{hi.z, hi.w});
+	}
+	else
+	{
+#pragma unroll
+		for (int i = 0; i < TONEMAP_PX; i++)
+			texels[i] = *reinterpret_cast<const f16x4 *>(row + size_t(min(x0 + i, hdr.w - 1)) * 8u);
+	}
+
+#pragma unroll
+	for (int i = 0; i < TONEMAP_PX; i++)
+	{
+		const float u = (float(x0 + i) + 0.5f) * inv_w;
+		const float4 b = sample_linear_rgba16f(bloom, u, v);
+		const float r = (float(texels[i].x) + b.x) * scale;
+		const float g = (float(texels[i].y) + b.y) * scale;
+		const float bl = (float(texels[i].z) + b.z) * scale;
+		const float tr = uncharted2(r) * white_scale;
+		const float tg = uncharted2(g) * white_scale;
+		const float tb = uncharted2(bl) * white_scale;
+		if (SRGB)
+			packed[i] = encode_srgb8(tr) | (encode_srgb8(tg) << 8) | (encode_srgb8(tb) << 16) | 0xff000000u;
+		else
+			packed[i] = encode_unorm8(tr) | (encode_unorm8(tg) << 8) | (encode_unorm8(tb) << 16) | 0xff000000u;
+	}
+
+	uint8_t *orow = out.ptr + size_t(y) * out.pitch;
+	if (full && ((reinterpret_cast<uintptr_t>(orow) & 15u) == 0))
+		*reinterpret_cast<u32x4 *>(orow + size_t(x0) * 4u) = u32x4{packed[0], packed[1], packed[2], packed[3]};
+	else
+	{
+		for (int i = 0; i < TONEMAP_PX && x0 + i < hdr.w; i++)
+			*reinterpret_cast<uint32_t *>(orow + size_t(x0 + i) * 4u) = packed[i];
+	}
+}
+
+static bool is_rgba16f(const gr_image *img)
+{
+	return img && img->ptr && img->format == GR_FORMAT_R16G16B16A16_SFLOAT && img->width && img->height &&
+	       img->pitch_bytes >= img->width * 8u && (img->pitch_bytes & 7u) == 0;
+}
+} // namespace
+
+extern "C" {
+
+int gr_bloom_threshold(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *out, const gr_luminance_data *lum,
+                       const gr_push_bloom_threshold *push)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push != nullptr);
+	GR_CHECK_ARG(ctx, is_rgba16f(hdr) && is_rgba16f(out));
+	GR_CHECK_ARG(ctx, push->threads[0] <= out->width && push->threads[1] <= out->height);
+	if (push->threads[0] == 0 || push->threads[1] == 0)
+		return GR_OK;
+	dim3 block(POST_BLOCK_X, POST_BLOCK_Y);
+	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(push->threads[1], POST_BLOCK_Y));
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_threshold"};
+	if (lum)
+		hipLaunchKernelGGL(k_bloom_threshold<true>, grid, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, *push);
+	else
+		hipLaunchKernelGGL(k_bloom_threshold<false>, grid, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, *push);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_bloom_downsample(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_image *history,
+                        const gr_push_bloom_downsample *push)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push != nullptr);
+	GR_CHECK_ARG(ctx, is_rgba16f(in) && is_rgba16f(out));
+	GR_CHECK_ARG(ctx, !history || (is_rgba16f(history) && history->ptr != out->ptr));
+	GR_CHECK_ARG(ctx, push->threads[0] <= out->width && push->threads[1] <= out->height);
+	if (push->threads[0] == 0 || push->threads[1] == 0)
+		return GR_OK;
+	dim3 block(POST_BLOCK_X, POST_BLOCK_Y);
+	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(push->threads[1], POST_BLOCK_Y));
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_downsample"};
+	if (history)
+		hipLaunchKernelGGL(k_bloom_downsample<true>, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out),
+		                   to_dev(history), *push);
+	else
+		hipLaunchKernelGGL(k_bloom_downsample<false>, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out),
+		                   DevImage{}, *push);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_bloom_upsample(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_push_bloom_upsample *push)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push != nullptr);
+	GR_CHECK_ARG(ctx, is_rgba16f(in) && is_rgba16f(out));
+	GR_CHECK_ARG(ctx, push->threads[0] <= out->width && push->threads[1] <= out->height);
+	if (push->threads[0] == 0 || push->threads[1] == 0)
+		return GR_OK;
+	dim3 block(POST_BLOCK_X, POST_BLOCK_Y);
+	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(push->threads[1], POST_BLOCK_Y));
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_upsample"};
+	hipLaunchKernelGGL(k_bloom_upsample, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out), *push);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_luminance(gr_ctx *ctx, gr_stream stream, const gr_image *in, gr_luminance_data *lum, const gr_push_luminance *push)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push != nullptr && lum != nullptr);
+	GR_CHECK_ARG(ctx, is_rgba16f(in));
+	GR_CHECK_ARG(ctx, push->size[0] != 0 && push->size[1] != 0);
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "luminance"};
+	hipLaunchKernelGGL(k_luminance, dim3(1), dim3(LUM_THREADS), 0, gr_to_stream(stream), to_dev(in), lum, *push);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_tonemap(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *bloom, const gr_image *out,
+               const gr_luminance_data *lum, const gr_push_tonemap *push)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push != nullptr);
+	GR_CHECK_ARG(ctx, is_rgba16f(hdr) && is_rgba16f(bloom));
+	GR_CHECK_ARG(ctx, out && out->ptr && out->width == hdr->width && out->height == hdr->height &&
+	                       out->pitch_bytes >= out->width * 4u);
+	const bool srgb = out->format == GR_FORMAT_R8G8B8A8_SRGB;
+	if (!srgb && out->format != GR_FORMAT_R8G8B8A8_UNORM)
+		return ctx->fail(GR_ERR_UNSUPPORTED_FORMAT, "gr_tonemap: output format %u unsupported", out->format);
+	dim3 block(TONEMAP_BLOCK_X, TONEMAP_BLOCK_Y);
+	dim3 grid(gr_div_up(hdr->width, TONEMAP_BLOCK_X * TONEMAP_PX), gr_div_up(hdr->height, TONEMAP_BLOCK_Y));
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "tonemap"};
+	hipStream_t s = gr_to_stream(stream);
+	if (lum && srgb)
+		hipLaunchKernelGGL((k_tonemap<true, true>), grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push);
+	else if (lum)
+		hipLaunchKernelGGL((k_tonemap<true, false>), grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push);
+	else if (srgb)
+		hipLaunchKernelGGL((k_tonemap<false, true>), grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push);
+	else
+		hipLaunchKernelGGL((k_tonemap<false, false>), grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+}

@@ -1,0 +1,299 @@
+/* granite_hip.h — C ABI of the MI355X (gfx950) executor for Granite's image-space chain.
+ *
+ * Granite has no C plugin ABI: its operator interface for this path is the C++ RenderGraph pass API
+ * (renderer/render_graph.hpp:488-716,779-893) whose callbacks record GLSL dispatches / full-screen quads on a
+ * Vulkan::CommandBuffer.  This header is what a HIP backend for those callbacks binds instead: one entry point per
+ * shader dispatch on the hot path, taking plain pointers + sizes (no C++/torch types), with push-constant structs that
+ * are byte-identical to the reference's.  Each entry point cites the reference call site it replaces.
+ *
+ * Conventions
+ *   - All image/buffer pointers are DEVICE pointers into linear, row-major HBM buffers (origin top-left).
+ *   - Every launcher is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - Return value: 0 on success, negative gr_status on failure; gr_last_error() holds the message.
+ *     No exceptions cross this boundary.  Thread-safe per (ctx, stream).
+ */
+#ifndef GRANITE_HIP_H_
+#define GRANITE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GR_ABI_VERSION 1
+
+typedef struct gr_ctx gr_ctx;
+typedef void *gr_stream; /* hipStream_t */
+
+typedef enum gr_status
+{
+	GR_OK = 0,
+	GR_ERR_INVALID_ARGUMENT = -1,
+	GR_ERR_HIP = -2,
+	GR_ERR_UNSUPPORTED_FORMAT = -3,
+	GR_ERR_OUT_OF_MEMORY = -4
+} gr_status;
+
+/* Subset of VkFormat used on the path; numeric values are VkFormat's so reference call sites read the same. */
+typedef enum gr_format
+{
+	GR_FORMAT_UNDEFINED = 0,
+	GR_FORMAT_R8_UNORM = 9,
+	GR_FORMAT_R8G8_UNORM = 16,
+	GR_FORMAT_R8G8B8A8_UNORM = 37,
+	GR_FORMAT_R8G8B8A8_SRGB = 43,
+	GR_FORMAT_A2B10G10R10_UNORM_PACK32 = 64,
+	GR_FORMAT_R16G16_SFLOAT = 83,
+	GR_FORMAT_R16G16B16A16_SFLOAT = 97,
+	GR_FORMAT_R32_SFLOAT = 100,
+	GR_FORMAT_D16_UNORM = 124,
+	GR_FORMAT_D32_SFLOAT = 126
+} gr_format;
+
+/* A 2-D attachment as the executor sees it: what Vulkan::ImageView is to the reference's callbacks. */
+typedef struct gr_image
+{
+	void *ptr;            /* device pointer */
+	uint32_t width;
+	uint32_t height;
+	uint32_t pitch_bytes; /* row pitch; rows are tightly packed unless stated */
+	uint32_t format;      /* gr_format */
+} gr_image;
+
+/* ---- context ----------------------------------------------------------------------------------------------------- */
+gr_ctx *gr_create(int device);          /* replaces Vulkan::Context/Device creation for this path */
+void gr_destroy(gr_ctx *ctx);
+const char *gr_last_error(gr_ctx *ctx);
+int gr_abi_version(void);
+int gr_sync(gr_ctx *ctx, gr_stream stream); /* hipStreamSynchronize; Device::wait_idle analogue */
+
+/* Physical-resource allocation used by RenderGraph::setup_physical_{image,buffer} (render_graph.cpp:2577-2684).
+ * Memory is zero-initialised like the reference's (render_graph.cpp:2586-2587). */
+int gr_alloc(gr_ctx *ctx, size_t bytes, void **dptr);
+int gr_free(gr_ctx *ctx, void *dptr);
+int gr_upload(gr_ctx *ctx, gr_stream stream, void *dst, const void *src_host, size_t bytes);   /* cmd.update_buffer */
+int gr_download(gr_ctx *ctx, gr_stream stream, void *dst_host, const void *src, size_t bytes); /* readback */
+int gr_copy(gr_ctx *ctx, gr_stream stream, void *dst, const void *src, size_t bytes);
+int gr_fill_zero(gr_ctx *ctx, gr_stream stream, void *dst, size_t bytes);
+
+/* Per-kernel GPU timing (RenderGraph::enable_timestamps analogue, render_graph.cpp:2196-2310): when enabled, every
+ * launcher brackets its kernel with hipEvents on the launch stream; gr_timing_query drains {name, count, total_ms}. */
+typedef struct gr_timing_entry
+{
+	const char *name;
+	uint64_t count;
+	double total_ms;
+} gr_timing_entry;
+int gr_timing_enable(gr_ctx *ctx, int enable);
+int gr_timing_reset(gr_ctx *ctx);
+int gr_timing_query(gr_ctx *ctx, gr_timing_entry *entries, int max_entries); /* returns number of entries; syncs */
+
+/* ---- HDR post chain (renderer/post/hdr.cpp) ---------------------------------------------------------------------- */
+
+/* LuminanceData, 12 B (assets/shaders/post/luminance.comp:4-9): {log2 avg, avg, 1/avg}. */
+typedef struct gr_luminance_data
+{
+	float average_log_luminance;
+	float average_linear_luminance;
+	float average_inv_linear_luminance;
+} gr_luminance_data;
+
+/* bloom_threshold_build_compute (hdr.cpp:115-144) + bloom_threshold.comp.  lum = device LuminanceData or NULL
+ * (DYNAMIC_EXPOSURE=0).  hdr, out: R16G16B16A16_SFLOAT. */
+typedef struct gr_push_bloom_threshold
+{
+	uint32_t threads[2];
+	float inv_output_size[2];
+} gr_push_bloom_threshold;
+int gr_bloom_threshold(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *out,
+                       const gr_luminance_data *lum, const gr_push_bloom_threshold *push);
+
+/* bloom_downsample_build_compute (hdr.cpp:146-187) + bloom_downsample.comp.  history = previous frame's output
+ * (FEEDBACK=1, NearestClamp) or NULL. */
+typedef struct gr_push_bloom_downsample
+{
+	uint32_t threads[2];
+	float inv_output_size[2];
+	float inv_input_size[2];
+	float lerp;
+} gr_push_bloom_downsample;
+int gr_bloom_downsample(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out,
+                        const gr_image *history, const gr_push_bloom_downsample *push);
+
+/* bloom_upsample_build_compute (hdr.cpp:189-216) + bloom_upsample.comp. */
+typedef struct gr_push_bloom_upsample
+{
+	uint32_t threads[2];
+	float inv_output_size[2];
+	float inv_input_size[2];
+} gr_push_bloom_upsample;
+int gr_bloom_upsample(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out,
+                      const gr_push_bloom_upsample *push);
+
+/* luminance_build_compute (hdr.cpp:68-98) + luminance.comp: mean log-luminance of `in`.a over a size.x x size.y
+ * bilinear grid, clamp, temporal lerp, read-modify-write of *lum. */
+typedef struct gr_push_luminance
+{
+	uint32_t size[2];
+	float lerp;
+	float min_loglum;
+	float max_loglum;
+} gr_push_luminance;
+int gr_luminance(gr_ctx *ctx, gr_stream stream, const gr_image *in, gr_luminance_data *lum,
+                 const gr_push_luminance *push);
+
+/* tonemap_build_render_pass (hdr.cpp:283-306) + tonemap.frag (full-screen quad).  out: R8G8B8A8_SRGB (linear value
+ * is sRGB-encoded on store, as the attachment hardware does) or R8G8B8A8_UNORM.  lum NULL => DYNAMIC_EXPOSURE=0. */
+typedef struct gr_push_tonemap
+{
+	float dynamic_exposure;
+} gr_push_tonemap;
+int gr_tonemap(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *bloom, const gr_image *out,
+               const gr_luminance_data *lum, const gr_push_tonemap *push);
+
+/* ---- clustered lighting (renderer/lights/clusterer.cpp, renderer/renderer.cpp) ------------------------------------- */
+
+/* PositionalFragmentInfo (renderer/lights/light_info.hpp:35-44), 48 B. */
+typedef struct gr_light_info
+{
+	float color[3];
+	uint32_t spot_scale_bias; /* 2 x fp16: scale | bias << 16 */
+	float position[3];
+	uint32_t offset_radius;   /* 2 x fp16: offset | radius << 16 */
+	float direction[3];
+	float inv_radius;
+} gr_light_info;
+
+/* mat_affine (math/muglm/muglm.hpp:899-958): 3 rows of vec4. */
+typedef struct gr_mat_affine
+{
+	float rows[3][4];
+} gr_mat_affine;
+
+/* ClustererParametersBindless, std140, 176 B (assets/shaders/lights/clusterer_data.h:20-39; math/render_parameters.hpp:90-108). */
+typedef struct gr_cluster_params
+{
+	float transform[16];
+	float clip_scale[4];
+	float camera_base[3];
+	float pad0;
+	float camera_front[3];
+	float pad1;
+	float xy_scale[2];
+	int32_t resolution_xy[2];
+	float inv_resolution_xy[2];
+	int32_t num_lights;
+	int32_t num_lights_32;
+	int32_t num_decals;
+	int32_t num_decals_32;
+	int32_t decals_texture_offset;
+	int32_t z_max_index;
+	float z_scale;
+	float pad2[3];
+} gr_cluster_params;
+
+#define GR_MAX_LIGHTS_BINDLESS 4096
+#define GR_CULL_SETUP_BYTES_PER_LIGHT 512        /* CullSetup {vec4 data[32]}, clusterer.cpp:1601 */
+#define GR_TRANSFORMED_SPOT_BYTES_PER_LIGHT 96   /* TransformedSpot {vec4 clip[5]; vec4 z}, clusterer.cpp:1606 */
+
+/* ClustererBindlessTransforms byte offsets (clusterer_data.h:46-53), total 852480 B (clusterer.cpp:1596). */
+#define GR_TRANSFORMS_OFFSET_LIGHTS 0u
+#define GR_TRANSFORMS_OFFSET_SHADOW 196608u
+#define GR_TRANSFORMS_OFFSET_MODEL 458752u
+#define GR_TRANSFORMS_OFFSET_TYPE_MASK 655360u
+#define GR_TRANSFORMS_OFFSET_DECALS 655872u
+#define GR_TRANSFORMS_SIZE 852480u
+
+/* clusterer_bindless_spot_transform.comp; push = clusterer.cpp:1477-1493 (100 B). */
+typedef struct gr_push_spot_transform
+{
+	float vp[16];
+	float camera_pos[3];
+	uint32_t num_lights;
+	float camera_front[3];
+	float z_near;
+	float z_far;
+} gr_push_spot_transform;
+int gr_cluster_spot_transform(gr_ctx *ctx, gr_stream stream, const void *transforms, void *transformed_spots,
+                              const gr_push_spot_transform *push);
+
+/* clusterer_bindless_setup.comp; push = clusterer.cpp:1502-1509 (68 B).  params is passed by value (UBO). */
+typedef struct gr_push_cluster_setup
+{
+	float view[16];
+	uint32_t num_lights;
+} gr_push_cluster_setup;
+int gr_cluster_setup(gr_ctx *ctx, gr_stream stream, const void *transforms, const void *transformed_spots,
+                     void *cull_setup, const gr_cluster_params *params, const gr_push_cluster_setup *push);
+
+/* clusterer_bindless_binning.comp, SUBGROUPS variant at wave64 (8x8 cell tile per wave; clusterer.cpp:1516-1561).
+ * bitmask[(y*res_x + x) * num_lights_32 + chunk]. */
+int gr_cluster_binning(gr_ctx *ctx, gr_stream stream, const void *transforms, const void *cull_setup, uint32_t *bitmask,
+                       const gr_cluster_params *params);
+
+/* clusterer_bindless_z_range{,_opt}.comp; push = clusterer.cpp:1291-1300.  light_ranges: uvec2[num_volumes] slice
+ * intervals (compute_uint_range, clusterer.cpp:1265-1275); out: uvec2[num_ranges] = [first, last] light index. */
+typedef struct gr_push_z_range
+{
+	uint32_t num_volumes;
+	uint32_t num_volumes_128;
+	uint32_t num_ranges;
+} gr_push_z_range;
+int gr_cluster_z_range(gr_ctx *ctx, gr_stream stream, const uint32_t *light_ranges, uint32_t *out,
+                       const gr_push_z_range *push);
+
+/* DeferredLightRenderer::render_light (renderer.cpp:1004-1156): directional quad (directional.frag) then clustered quad
+ * (clustering.frag), both additively blended into the RGBA16F HDR target with depth test NOT_EQUAL against z = 0.
+ * One fused kernel; the intermediate blend result is rounded to fp16 exactly where the two reference draws round it. */
+typedef struct gr_push_directional /* renderer.cpp:1073-1103, 88 B used */
+{
+	float inv_view_proj_col2[4];
+	float color[3];
+	float environment_intensity;
+	float camera_pos[3];
+	float environment_mipscale;
+	float direction[3];
+	float cascade_log_bias;
+	float camera_front[3];
+	float pad0;
+	float inv_resolution[2];
+	float pad1[2];
+} gr_push_directional;
+
+typedef struct gr_push_clustering /* renderer.cpp:1110-1121 */
+{
+	float inv_view_proj_col2[4];
+	float camera_pos[3];
+	float pad0;
+	float inv_resolution[2];
+	float pad1[2];
+} gr_push_clustering;
+
+#define GR_LIGHTING_DIRECTIONAL_BIT 1u        /* draw the directional quad */
+#define GR_LIGHTING_CLUSTERED_BIT 2u          /* draw the clustered quad */
+#define GR_LIGHTING_AMBIENT_FALLBACK_BIT 4u   /* VOLUMETRIC_DIFFUSE_FALLBACK, renderer.cpp:1049-1055 */
+
+typedef struct gr_lighting_args
+{
+	gr_image albedo; /* R8G8B8A8_SRGB, a = ambient */
+	gr_image normal; /* A2B10G10R10_UNORM_PACK32 */
+	gr_image pbr;    /* R8G8_UNORM (metallic, roughness) */
+	gr_image depth;  /* D32_SFLOAT, reverse-Z */
+	gr_image hdr;    /* R16G16B16A16_SFLOAT, read-modify-write (emissive -> HDR) */
+	float inv_view_projection[16]; /* DirectionalLightUBO / clustering.vert UBO */
+	gr_push_directional directional;
+	gr_push_clustering clustering;
+	gr_cluster_params cluster;     /* UBO, by value */
+	const void *transforms;        /* cluster-transforms buffer */
+	const uint32_t *bitmask;       /* cluster-bitmask */
+	const uint32_t *range;         /* cluster-range, uvec2[res_z] */
+	uint32_t flags;
+} gr_lighting_args;
+int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

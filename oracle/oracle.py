@@ -1,0 +1,239 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end of oracle/liboracle.so, the CPU restatement of Granite's image-space chain (see oracle_common.h).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(granite_amd/) never does.  PARITY UNPINNED by the reference's own tests: pinned by analytic
+known-answer tests in tests/test_oracle_kat.py and fixtures in tests/golden/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+LIGHT_DESC_DTYPE = np.dtype([("type", "<i4"), ("color", "<f4", 3), ("inner_cone", "<f4"), ("outer_cone", "<f4"),
+                             ("cutoff_range", "<f4"), ("pad", "<f4"), ("transform", "<f4", (3, 4))])
+assert LIGHT_DESC_DTYPE.itemsize == 80
+
+LIGHT_INFO_DTYPE = np.dtype([("color", "<f4", 3), ("spot_scale_bias", "<u4"), ("position", "<f4", 3),
+                             ("offset_radius", "<u4"), ("direction", "<f4", 3), ("inv_radius", "<f4")])
+assert LIGHT_INFO_DTYPE.itemsize == 48
+
+RENDER_PARAMS_DTYPE = np.dtype([("projection", "<f4", 16), ("view", "<f4", 16), ("view_projection", "<f4", 16),
+                                ("inv_projection", "<f4", 16), ("inv_view", "<f4", 16), ("inv_view_projection", "<f4", 16),
+                                ("camera_position", "<f4", 3), ("camera_front", "<f4", 3), ("z_near", "<f4"),
+                                ("z_far", "<f4")])
+assert RENDER_PARAMS_DTYPE.itemsize == 104 * 4
+
+CLUSTER_PARAMS_DTYPE = np.dtype([("transform", "<f4", 16), ("clip_scale", "<f4", 4), ("camera_base", "<f4", 3),
+                                 ("pad0", "<f4"), ("camera_front", "<f4", 3), ("pad1", "<f4"), ("xy_scale", "<f4", 2),
+                                 ("resolution_xy", "<i4", 2), ("inv_resolution_xy", "<f4", 2), ("num_lights", "<i4"),
+                                 ("num_lights_32", "<i4"), ("num_decals", "<i4"), ("num_decals_32", "<i4"),
+                                 ("decals_texture_offset", "<i4"), ("z_max_index", "<i4"), ("z_scale", "<f4"),
+                                 ("pad2", "<f4", 3)])
+assert CLUSTER_PARAMS_DTYPE.itemsize == 176
+
+
+class LightingArgs(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("albedo", C.c_void_p), ("normal", C.c_void_p),
+                ("pbr", C.c_void_p), ("depth", C.c_void_p), ("hdr", C.c_void_p), ("rp", C.c_void_p),
+                ("cluster", C.c_void_p), ("lights", C.c_void_p), ("type_mask", C.c_void_p), ("bitmask", C.c_void_p),
+                ("range", C.c_void_p), ("dir_color", C.c_float * 3), ("dir_direction", C.c_float * 3),
+                ("enable_directional", C.c_int32), ("enable_clustered", C.c_int32), ("ambient_fallback", C.c_int32),
+                ("wave_tile", C.c_int32)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the restatement with the committed Makefile (gcc only; no GPU, no reference sources)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h"))]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_half_to_float.restype = C.c_float
+        _lib.orc_half_to_float.argtypes = [C.c_uint16]
+        _lib.orc_float_to_half.restype = C.c_uint16
+        _lib.orc_float_to_half.argtypes = [C.c_float]
+        _lib.orc_float_to_half_muglm.restype = C.c_uint16
+        _lib.orc_float_to_half_muglm.argtypes = [C.c_float]
+        _lib.orc_float_to_srgb8.restype = C.c_uint8
+        _lib.orc_float_to_srgb8.argtypes = [C.c_float]
+        _lib.orc_srgb8_to_float.restype = C.c_float
+        _lib.orc_srgb8_to_float.argtypes = [C.c_uint8]
+        _lib.orc_pack_lights.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _img16(a: np.ndarray):
+    assert a.dtype == np.uint16 and a.ndim == 3 and a.shape[2] == 4 and a.flags.c_contiguous
+    return a.shape[1], a.shape[0]
+
+
+# ---- post chain ---------------------------------------------------------------------------------------------------
+def level_size(w: int, h: int, scale: float):
+    """InputRelative size: ceil(input_dim * scale) (render_graph.cpp:3158-3170)."""
+    import math
+    return max(int(math.ceil(np.float32(w) * np.float32(scale))), 1), max(int(math.ceil(np.float32(h) * np.float32(scale))), 1)
+
+
+def bloom_threshold(hdr: np.ndarray, ow: int, oh: int, lum3=None) -> np.ndarray:
+    iw, ih = _img16(hdr)
+    out = np.zeros((oh, ow, 4), np.uint16)
+    l = None if lum3 is None else np.ascontiguousarray(lum3, np.float32)
+    lib().orc_bloom_threshold(_p(hdr), iw, ih, _p(out), ow, oh, _p(l))
+    return out
+
+
+def bloom_downsample(src: np.ndarray, ow: int, oh: int, history=None, lerp: float = 0.0) -> np.ndarray:
+    iw, ih = _img16(src)
+    out = np.zeros((oh, ow, 4), np.uint16)
+    lib().orc_bloom_downsample(_p(src), iw, ih, _p(out), ow, oh, _p(history), C.c_float(lerp))
+    return out
+
+
+def bloom_upsample(src: np.ndarray, ow: int, oh: int) -> np.ndarray:
+    iw, ih = _img16(src)
+    out = np.zeros((oh, ow, 4), np.uint16)
+    lib().orc_bloom_upsample(_p(src), iw, ih, _p(out), ow, oh)
+    return out
+
+
+def luminance(d3: np.ndarray, lum3: np.ndarray, lerp: float, lo: float = -3.0, hi: float = 2.0) -> np.ndarray:
+    w, h = _img16(d3)
+    out = np.array(lum3, np.float32, copy=True)
+    lib().orc_luminance(_p(d3), w, h, _p(out), C.c_float(lerp), C.c_float(lo), C.c_float(hi))
+    return out
+
+
+def tonemap(hdr: np.ndarray, bloom: np.ndarray, lum3=None, dynamic_exposure: float = 1.0) -> np.ndarray:
+    w, h = _img16(hdr)
+    bw, bh = _img16(bloom)
+    out = np.zeros((h, w, 4), np.uint8)
+    l = None if lum3 is None else np.ascontiguousarray(lum3, np.float32)
+    lib().orc_tonemap(_p(hdr), w, h, _p(bloom), bw, bh, _p(l), C.c_float(dynamic_exposure), _p(out))
+    return out
+
+
+def frame_lerps(frame_time: float):
+    """(luminance lerp, bloom feedback lerp) as hdr.cpp:93,181 compute them: float(1.0 - pow(0.5|0.001, frame_time))."""
+    import math
+    return float(np.float32(1.0 - math.pow(0.5, frame_time))), float(np.float32(1.0 - math.pow(0.001, frame_time)))
+
+
+def hdr_chain(hdr: np.ndarray, state: dict, frame_time: float = 0.01, dynamic_exposure: float = 1.0, use_lum: bool = True):
+    """One frame of setup_hdr_postprocess_compute's recorded order (hdr.cpp:354-379) + tonemap (:381-399).
+
+    state carries the cross-frame resources: 'lum' (LuminanceData, zero-initialised) and 'd3_history' (or None).
+    Returns dict of every level and the tonemapped RGBA8; updates state in place."""
+    w, h = _img16(hdr)
+    lum_lerp, fb_lerp = frame_lerps(frame_time)
+    lum = state.setdefault("lum", np.zeros(3, np.float32))
+    sz = [level_size(w, h, s) for s in (0.5, 0.25, 0.125, 0.0625, 0.03125)]
+    t = bloom_threshold(hdr, *sz[0], lum3=lum if use_lum else None)
+    d0 = bloom_downsample(t, *sz[1])
+    d1 = bloom_downsample(d0, *sz[2])
+    d2 = bloom_downsample(d1, *sz[3])
+    d3 = bloom_downsample(d2, *sz[4], history=state.get("d3_history"), lerp=fb_lerp)
+    if use_lum:
+        lum = luminance(d3, lum, lum_lerp)
+        state["lum"] = lum
+    u2 = bloom_upsample(d3, *sz[3])
+    u1 = bloom_upsample(u2, *sz[2])
+    u0 = bloom_upsample(u1, *sz[1])
+    out = tonemap(hdr, u0, lum if use_lum else None, dynamic_exposure)
+    state["d3_history"] = d3
+    return {"threshold": t, "d0": d0, "d1": d1, "d2": d2, "d3": d3, "u2": u2, "u1": u1, "u0": u0, "lum": lum.copy(),
+            "tonemapped": out}
+
+
+# ---- lighting -------------------------------------------------------------------------------------------------------
+def pack_lights(descs: np.ndarray, camera_front):
+    descs = np.ascontiguousarray(descs, LIGHT_DESC_DTYPE)
+    n = len(descs)
+    lights = np.zeros(4096, LIGHT_INFO_DTYPE)
+    model = np.zeros((4096, 3, 4), np.float32)
+    type_mask = np.zeros(128, np.uint32)
+    order = np.zeros(max(n, 1), np.int32)
+    cf = np.ascontiguousarray(camera_front, np.float32)
+    count = lib().orc_pack_lights(_p(descs), n, _p(cf), _p(lights), _p(model), _p(type_mask), _p(order))
+    return count, lights, model, type_mask, order[:count]
+
+
+def cluster_params(rp: np.ndarray, res_x: int, res_y: int, res_z: int, num_lights: int) -> np.ndarray:
+    out = np.zeros(1, CLUSTER_PARAMS_DTYPE)
+    lib().orc_cluster_params(_p(rp), res_x, res_y, res_z, num_lights, _p(out))
+    return out
+
+
+def light_z_ranges(rp, lights, model, type_mask, num_lights: int, res_z: int) -> np.ndarray:
+    out = np.zeros((max(num_lights, 1), 2), np.uint32)
+    if num_lights == 0:
+        out[0] = (0xFFFFFFFF, 0)  # clusterer.cpp:1341-1342
+        return out
+    lib().orc_light_z_ranges(_p(rp), _p(lights), _p(model), _p(type_mask), num_lights, res_z, _p(out))
+    return out
+
+
+def cluster_build(rp, prm, lights, model, type_mask, num_lights: int, res_z: int, subgroup_tile_h: int = 8):
+    """spot_transform -> setup -> binning -> z_range, as LightClusterer::build_cluster_bindless_gpu orders them."""
+    res_x, res_y = int(prm["resolution_xy"][0][0]), int(prm["resolution_xy"][0][1])
+    n32 = int(prm["num_lights_32"][0])
+    spots = np.zeros((4096, 24), np.float32)
+    setup = np.zeros((4096, 128), np.float32)
+    bitmask = np.zeros(res_x * res_y * max(n32, 1), np.uint32)
+    if num_lights > 0:
+        lib().orc_cluster_spot_transform(_p(rp), _p(model), num_lights, _p(spots))
+        lib().orc_cluster_setup(_p(rp), _p(prm), _p(lights), _p(type_mask), _p(spots), num_lights, _p(setup))
+        lib().orc_cluster_binning(_p(prm), _p(type_mask), _p(setup), _p(bitmask), subgroup_tile_h)
+    zr = light_z_ranges(rp, lights, model, type_mask, num_lights, res_z)
+    ranges = np.zeros((res_z, 2), np.uint32)
+    lib().orc_cluster_z_range(_p(zr), len(zr), res_z, _p(ranges))
+    return {"spots": spots, "setup": setup, "bitmask": bitmask, "light_ranges": zr, "range": ranges}
+
+
+def lighting(gbuf: dict, rp, prm, lights, type_mask, bitmask, ranges, dir_color, dir_direction, directional=True,
+             clustered=True, ambient_fallback=True, wave_tile=0, bruteforce=False) -> np.ndarray:
+    """Returns the HDR target (RGBA16F bits) after DeferredLightRenderer::render_light on gbuf['emissive']."""
+    h, w = gbuf["depth"].shape
+    hdr = np.array(gbuf["emissive"], np.uint16, copy=True)
+    a = LightingArgs()
+    a.width, a.height = w, h
+    keep = [np.ascontiguousarray(gbuf["albedo"], np.uint32), np.ascontiguousarray(gbuf["normal"], np.uint32),
+            np.ascontiguousarray(gbuf["pbr"], np.uint16), np.ascontiguousarray(gbuf["depth"], np.float32)]
+    a.albedo, a.normal, a.pbr, a.depth = [k.ctypes.data for k in keep]
+    a.hdr = hdr.ctypes.data
+    a.rp, a.cluster = rp.ctypes.data, prm.ctypes.data
+    a.lights, a.type_mask = lights.ctypes.data, type_mask.ctypes.data
+    a.bitmask, a.range = bitmask.ctypes.data, ranges.ctypes.data
+    a.dir_color = (C.c_float * 3)(*[float(v) for v in dir_color])
+    a.dir_direction = (C.c_float * 3)(*[float(v) for v in dir_direction])
+    a.enable_directional, a.enable_clustered = int(directional), int(clustered)
+    a.ambient_fallback, a.wave_tile = int(ambient_fallback), int(wave_tile)
+    if bruteforce:
+        lib().orc_lighting_bruteforce_clustered(C.byref(a))
+    else:
+        lib().orc_lighting(C.byref(a))
+    return hdr
+
+
+# ---- scalar helpers ---------------------------------------------------------------------------------------------------
+def half_to_float(bits: np.ndarray) -> np.ndarray:
+    return np.asarray(bits, np.uint16).view(np.float16).astype(np.float32)

@@ -1,0 +1,87 @@
+"""Helpers for the GPU lighting tests: device-side copies of an oracle-packed light scene."""
+import ctypes as C
+
+import numpy as np
+
+from granite_amd import capi, synth
+from oracle import oracle as orc
+
+
+class Scene:
+    def __init__(self, w, h, num_lights, res=(128, 64, 4096), seed=synth.SEED, spot_fraction=0.25):
+        self.w, self.h = w, h
+        self.cam = synth.Camera(w, h)
+        self.rp = self.cam.render_params()
+        self.gbuf = synth.make_gbuffer(self.cam, seed)
+        self.descs = synth.make_lights(self.cam, num_lights, spot_fraction, seed=seed)
+        self.res = res
+        self.n, self.lights, self.model, self.type_mask, self.order = orc.pack_lights(self.descs, self.rp[99:102])
+        self.prm = orc.cluster_params(self.rp, res[0], res[1], res[2], self.n)
+
+    def cluster_params_struct(self):
+        s = capi.ClusterParams()
+        C.memmove(C.byref(s), self.prm.ctypes.data, 176)
+        return s
+
+    def upload_transforms(self, gr):
+        buf = capi.DeviceBuffer(gr, capi.TRANSFORMS_SIZE)
+        buf.upload(self.lights.view(np.uint8), capi.TRANSFORMS_OFFSET_LIGHTS)
+        buf.upload(self.model.view(np.uint8), capi.TRANSFORMS_OFFSET_MODEL)
+        buf.upload(self.type_mask.view(np.uint8), capi.TRANSFORMS_OFFSET_TYPE_MASK)
+        return buf
+
+    def build_clusters_gpu(self, gr):
+        lib, h = gr.lib, gr.handle
+        prm = self.cluster_params_struct()
+        transforms = self.upload_transforms(gr)
+        spots = capi.DeviceBuffer(gr, capi.TRANSFORMED_SPOT_BYTES_PER_LIGHT * 4096)
+        setup = capi.DeviceBuffer(gr, capi.CULL_SETUP_BYTES_PER_LIGHT * 4096)
+        bitmask = capi.DeviceBuffer(gr, self.res[0] * self.res[1] * 512)
+        ranges = capi.DeviceBuffer(gr, self.res[2] * 8)
+        push = capi.PushSpotTransform()
+        push.vp[:] = self.rp[32:48]
+        push.camera_pos[:] = self.rp[96:99]
+        push.num_lights = self.n
+        push.camera_front[:] = self.rp[99:102]
+        push.z_near, push.z_far = self.rp[102], self.rp[103]
+        gr.check(lib.gr_cluster_spot_transform(h, None, transforms.ptr, spots.ptr, push))
+        ps = capi.PushClusterSetup()
+        ps.view[:] = self.rp[16:32]
+        ps.num_lights = self.n
+        gr.check(lib.gr_cluster_setup(h, None, transforms.ptr, spots.ptr, setup.ptr, prm, ps))
+        gr.check(lib.gr_cluster_binning(h, None, transforms.ptr, setup.ptr, bitmask.ptr, prm))
+        zr = orc.light_z_ranges(self.rp, self.lights, self.model, self.type_mask, self.n, self.res[2])
+        zr_buf = capi.DeviceBuffer(gr, zr.nbytes).upload(zr)
+        pz = capi.PushZRange(len(zr), (len(zr) + 127) // 128, self.res[2])
+        gr.check(lib.gr_cluster_z_range(h, None, zr_buf.ptr, ranges.ptr, pz))
+        gr.sync()
+        return {"transforms": transforms, "spots": spots, "setup": setup, "bitmask": bitmask, "range": ranges, "zr": zr}
+
+    def lighting_args(self, gr, dev, flags):
+        w, h = self.w, self.h
+        imgs = {
+            "albedo": capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8B8A8_SRGB).upload(self.gbuf["albedo"]),
+            "normal": capi.DeviceImage(gr, w, h, capi.FORMAT_A2B10G10R10_UNORM_PACK32).upload(self.gbuf["normal"]),
+            "pbr": capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8_UNORM).upload(self.gbuf["pbr"]),
+            "depth": capi.DeviceImage(gr, w, h, capi.FORMAT_D32_SFLOAT).upload(self.gbuf["depth"]),
+            "hdr": capi.DeviceImage(gr, w, h, capi.FORMAT_R16G16B16A16_SFLOAT).upload(self.gbuf["emissive"]),
+        }
+        a = capi.LightingArgs()
+        a.albedo, a.normal, a.pbr, a.depth, a.hdr = (imgs[k].desc for k in ("albedo", "normal", "pbr", "depth", "hdr"))
+        a.inv_view_projection[:] = self.rp[80:96]
+        col2 = self.rp[80 + 8:80 + 12]
+        a.directional.inv_view_proj_col2[:] = col2
+        a.directional.color[:] = synth.DIRECTIONAL_COLOR
+        a.directional.direction[:] = synth.DIRECTIONAL_DIRECTION
+        a.directional.camera_pos[:] = self.rp[96:99]
+        a.directional.camera_front[:] = self.rp[99:102]
+        a.directional.inv_resolution[:] = (1.0 / w, 1.0 / h)
+        a.clustering.inv_view_proj_col2[:] = col2
+        a.clustering.camera_pos[:] = self.rp[96:99]
+        a.clustering.inv_resolution[:] = (1.0 / w, 1.0 / h)
+        a.cluster = self.cluster_params_struct()
+        a.transforms = dev["transforms"].ptr
+        a.bitmask = dev["bitmask"].ptr
+        a.range = dev["range"].ptr
+        a.flags = flags
+        return a, imgs

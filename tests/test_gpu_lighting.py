@@ -1,0 +1,85 @@
+"""GPU parity: cluster build (bit-exact) and the fused lighting kernel (fp16 tolerance) vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from granite_amd import capi, synth
+from oracle import oracle as orc
+from gpu_scene import Scene
+from util import assert_rgba16f_close, rgba16f_mismatch
+
+pytestmark = pytest.mark.gpu
+
+ALL = capi.LIGHTING_DIRECTIONAL_BIT | capi.LIGHTING_CLUSTERED_BIT | capi.LIGHTING_AMBIENT_FALLBACK_BIT
+
+
+@pytest.mark.parametrize("num_lights", [0, 1, 31, 256, 1000, 4096, 5000])
+def test_cluster_build_bit_exact(gr, num_lights):
+    sc = Scene(480, 270, num_lights)
+    assert sc.n == min(num_lights, 4096)
+    ref = orc.cluster_build(sc.rp, sc.prm, sc.lights, sc.model, sc.type_mask, sc.n, sc.res[2], subgroup_tile_h=8)
+    dev = sc.build_clusters_gpu(gr)
+    got_range = dev["range"].download(np.uint32).reshape(-1, 2)
+    np.testing.assert_array_equal(got_range, ref["range"])
+    if sc.n == 0:
+        return
+    got_spots = dev["spots"].download(np.float32).reshape(4096, 24)[:sc.n]
+    np.testing.assert_array_equal(got_spots.view(np.uint32), ref["spots"][:sc.n].view(np.uint32))
+    got_setup = dev["setup"].download(np.uint32).reshape(4096, 128)[:sc.n]
+    np.testing.assert_array_equal(got_setup, ref["setup"][:sc.n].view(np.uint32))
+    n32 = (sc.n + 31) // 32
+    got_mask = dev["bitmask"].download(np.uint32)[:sc.res[0] * sc.res[1] * n32]
+    np.testing.assert_array_equal(got_mask, ref["bitmask"])
+
+
+@pytest.mark.parametrize("w,h,num_lights", [(480, 270, 256), (480, 270, 4096), (333, 77, 700), (1920, 1080, 256)])
+def test_lighting_matches_oracle(gr, w, h, num_lights):
+    sc = Scene(w, h, num_lights)
+    ref_c = orc.cluster_build(sc.rp, sc.prm, sc.lights, sc.model, sc.type_mask, sc.n, sc.res[2])
+    dev = sc.build_clusters_gpu(gr)
+    for flags, kw in ((ALL, {}), (capi.LIGHTING_CLUSTERED_BIT, dict(directional=False)),
+                      (capi.LIGHTING_DIRECTIONAL_BIT, dict(clustered=False, ambient_fallback=False))):
+        ref = orc.lighting(sc.gbuf, sc.rp, sc.prm, sc.lights, sc.type_mask, ref_c["bitmask"], ref_c["range"],
+                           synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION, **kw)
+        args, imgs = sc.lighting_args(gr, dev, flags)
+        gr.check(gr.lib.gr_lighting(gr.handle, None, args))
+        gr.sync()
+        got = imgs["hdr"].download()
+        # alpha and sky pixels must be bit-identical to the input
+        np.testing.assert_array_equal(got[..., 3], sc.gbuf["emissive"][..., 3])
+        sky = sc.gbuf["depth"] == 0.0
+        np.testing.assert_array_equal(got[sky], sc.gbuf["emissive"][sky])
+        # Two fp16 roundings (one per blended quad) => allow 2 ulp per rounding stage: 3 ulp + 1e-4.
+        assert_rgba16f_close(got, ref, ulps=3.0, abs_tol=1e-4, what=f"lighting {w}x{h} n={num_lights} flags={flags}")
+        exact = (got == ref).mean()
+        assert exact > 0.95, f"only {exact:.3f} of channels bit-identical"
+
+
+def test_lighting_equals_bruteforce_sum(gr):
+    """Size-independent property: the clustered result equals the unclustered sum over ALL lights (culling is
+    conservative), evaluated by the oracle's brute-force loop."""
+    sc = Scene(320, 180, 1500)
+    dev = sc.build_clusters_gpu(gr)
+    ref = orc.lighting(sc.gbuf, sc.rp, sc.prm, sc.lights, sc.type_mask, np.zeros(1, np.uint32), np.zeros((1, 2), np.uint32),
+                       synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION, directional=False, bruteforce=True)
+    args, imgs = sc.lighting_args(gr, dev, capi.LIGHTING_CLUSTERED_BIT)
+    gr.check(gr.lib.gr_lighting(gr.handle, None, args))
+    gr.sync()
+    assert_rgba16f_close(imgs["hdr"].download(), ref, ulps=2.0, what="clustered vs brute force")
+
+
+def test_lighting_linearity_in_light_colour(gr):
+    """Doubling every light colour doubles the added radiance (up to fp16 rounding of the sum)."""
+    sc = Scene(256, 128, 300)
+    dev = sc.build_clusters_gpu(gr)
+    sc.gbuf["emissive"][...] = 0
+    args, imgs = sc.lighting_args(gr, dev, capi.LIGHTING_CLUSTERED_BIT)
+    gr.check(gr.lib.gr_lighting(gr.handle, None, args))
+    gr.sync()
+    base = imgs["hdr"].download().view(np.float16).astype(np.float32)
+    sc.lights["color"] *= 2.0
+    dev2 = {**dev, "transforms": sc.upload_transforms(gr)}
+    args2, imgs2 = sc.lighting_args(gr, dev2, capi.LIGHTING_CLUSTERED_BIT)
+    gr.check(gr.lib.gr_lighting(gr.handle, None, args2))
+    gr.sync()
+    dbl = imgs2["hdr"].download().view(np.float16).astype(np.float32)
+    np.testing.assert_allclose(dbl[..., :3], 2.0 * base[..., :3], rtol=2e-3, atol=1e-4)

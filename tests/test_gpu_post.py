@@ -1,0 +1,138 @@
+"""GPU parity: HDR post-chain kernels through the C ABI vs the CPU oracle on identical seeded inputs.
+
+Tolerances: RGBA16F levels |a-b| <= 2 ulp_fp16 + 1e-4 per channel; RGBA8 outputs +-1 LSB;
+LuminanceData 1e-5 absolute on the log value (the HIP reduction uses a different, fixed, association order)."""
+import numpy as np
+import pytest
+
+from granite_amd import capi, synth
+from oracle import oracle as orc
+from util import assert_rgba16f_close, assert_rgba8_close
+
+pytestmark = pytest.mark.gpu
+
+F16 = capi.FORMAT_R16G16B16A16_SFLOAT
+
+SIZES = [(256, 256), (250, 130), (33, 17), (1, 1), (1920, 1080)]
+
+
+def run_chain_gpu(gr, hdr_bits, state, frame_time=0.01, use_lum=True, fmt=capi.FORMAT_R8G8B8A8_SRGB):
+    h, w = hdr_bits.shape[:2]
+    lum_lerp, fb_lerp = orc.frame_lerps(frame_time)
+    sz = [orc.level_size(w, h, s) for s in (0.5, 0.25, 0.125, 0.0625, 0.03125)]
+    hdr = capi.DeviceImage(gr, w, h, F16).upload(hdr_bits)
+    t = capi.DeviceImage(gr, *sz[0], F16)
+    d0 = capi.DeviceImage(gr, *sz[1], F16)
+    d1 = capi.DeviceImage(gr, *sz[2], F16)
+    d2 = capi.DeviceImage(gr, *sz[3], F16)
+    u2 = capi.DeviceImage(gr, *sz[3], F16)
+    u1 = capi.DeviceImage(gr, *sz[2], F16)
+    u0 = capi.DeviceImage(gr, *sz[1], F16)
+    out = capi.DeviceImage(gr, w, h, fmt)
+    if "lum_buf" not in state:
+        state["lum_buf"] = capi.DeviceBuffer(gr, 12)
+        state["d3"] = [capi.DeviceImage(gr, *sz[4], F16), capi.DeviceImage(gr, *sz[4], F16)]
+        state["frame"] = 0
+    lum = state["lum_buf"].ptr if use_lum else None
+    # history swap (render_graph.cpp:2704-2708): current <-> history each frame; no history on frame 0
+    cur = state["d3"][state["frame"] & 1]
+    hist = state["d3"][(state["frame"] & 1) ^ 1] if state["frame"] > 0 else None
+    gr.bloom_threshold(hdr, t, lum)
+    gr.bloom_downsample(t, d0)
+    gr.bloom_downsample(d0, d1)
+    gr.bloom_downsample(d1, d2)
+    gr.bloom_downsample(d2, cur, hist, fb_lerp)
+    if use_lum:
+        gr.luminance(cur, lum, lum_lerp)
+    gr.bloom_upsample(cur, u2)
+    gr.bloom_upsample(u2, u1)
+    gr.bloom_upsample(u1, u0)
+    gr.tonemap(hdr, u0, out, lum)
+    gr.sync()
+    state["frame"] += 1
+    res = {"threshold": t.download(), "d0": d0.download(), "d1": d1.download(), "d2": d2.download(), "d3": cur.download(),
+           "u2": u2.download(), "u1": u1.download(), "u0": u0.download(), "tonemapped": out.download()}
+    if use_lum:
+        res["lum"] = state["lum_buf"].download(np.float32)
+    return res
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_chain_levels_match_oracle(gr, w, h):
+    hdr = synth.make_hdr(w, h)
+    ostate, gstate = {}, {}
+    for frame in range(3):  # frame 0: no history, lum = 0; later frames exercise feedback + exposure
+        ref = orc.hdr_chain(hdr, ostate)
+        got = run_chain_gpu(gr, hdr, gstate)
+        for name in ("threshold", "d0", "d1", "d2", "d3", "u2", "u1", "u0"):
+            assert ref[name].shape == got[name].shape, name
+            assert_rgba16f_close(got[name], ref[name], what=f"{w}x{h} frame {frame} {name}")
+        np.testing.assert_allclose(got["lum"][0], ref["lum"][0], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(got["lum"][1:], ref["lum"][1:], rtol=2e-5)
+        assert_rgba8_close(got["tonemapped"], ref["tonemapped"], 1, what=f"{w}x{h} frame {frame} tonemapped")
+
+
+def test_kernels_stagewise_on_identical_inputs(gr):
+    """Each kernel against the oracle on the SAME input bits (no error carried between stages)."""
+    w, h = 250, 130
+    hdr = synth.make_hdr(w, h)
+    lum3 = np.array([0.5, 2.0 ** 0.5, 2.0 ** -0.5], np.float32)
+    lumbuf = capi.DeviceBuffer(gr, 12).upload(lum3)
+    tw, th = orc.level_size(w, h, 0.5)
+    ref_t = orc.bloom_threshold(hdr, tw, th, lum3)
+    dhdr = capi.DeviceImage(gr, w, h, F16).upload(hdr)
+    dt = capi.DeviceImage(gr, tw, th, F16)
+    gr.bloom_threshold(dhdr, dt, lumbuf.ptr)
+    assert_rgba16f_close(dt.download(), ref_t, what="threshold(dynamic)")
+    gr.bloom_threshold(dhdr, dt, None)
+    assert_rgba16f_close(dt.download(), orc.bloom_threshold(hdr, tw, th, None), what="threshold(static)")
+
+    dw, dh = orc.level_size(w, h, 0.25)
+    dt.upload(ref_t)
+    dd = capi.DeviceImage(gr, dw, dh, F16)
+    gr.bloom_downsample(dt, dd)
+    ref_d = orc.bloom_downsample(ref_t, dw, dh)
+    assert_rgba16f_close(dd.download(), ref_d, what="downsample")
+
+    hist_bits = synth.make_hdr(dw, dh, seed=99)
+    dhist = capi.DeviceImage(gr, dw, dh, F16).upload(hist_bits)
+    gr.bloom_downsample(dt, dd, dhist, 0.0667)
+    assert_rgba16f_close(dd.download(), orc.bloom_downsample(ref_t, dw, dh, hist_bits, 0.0667), what="downsample(feedback)")
+
+    du = capi.DeviceImage(gr, tw, th, F16)
+    dd.upload(ref_d)
+    gr.bloom_upsample(dd, du)
+    assert_rgba16f_close(du.download(), orc.bloom_upsample(ref_d, tw, th), what="upsample")
+
+    for fmt, check in ((capi.FORMAT_R8G8B8A8_SRGB, True),):
+        dout = capi.DeviceImage(gr, w, h, fmt)
+        gr.tonemap(dhdr, dd, dout, lumbuf.ptr, 1.3)
+        assert_rgba8_close(dout.download(), orc.tonemap(hdr, ref_d, lum3, 1.3), 1, what="tonemap(dynamic)")
+        gr.tonemap(dhdr, dd, dout, None, 0.7)
+        assert_rgba8_close(dout.download(), orc.tonemap(hdr, ref_d, None, 0.7), 1, what="tonemap(static)")
+
+
+def test_constant_image_known_answers(gr):
+    """Analytic: constant colour c with avg_lum = 0 => threshold = c/(max+1e-4)*(max+1e-4) ~ c, tent weights sum to 1 so
+    every level equals the threshold value; alpha = log2(max + 1e-4)."""
+    w, h = 128, 64
+    c = np.array([0.5, 1.5, 0.25, 1.0], np.float32)
+    hdr = np.broadcast_to(c.astype(np.float16).view(np.uint16), (h, w, 4)).copy()
+    got = run_chain_gpu(gr, hdr, {}, use_lum=True)
+    expect_alpha = np.log2(1.5 + 1e-4)
+    for name in ("threshold", "d0", "d1", "d2", "d3", "u2", "u1", "u0"):
+        v = got[name].view(np.float16).astype(np.float32)
+        np.testing.assert_allclose(v[..., :3], np.broadcast_to(c[:3], v[..., :3].shape), rtol=2e-3, err_msg=name)
+        np.testing.assert_allclose(v[..., 3], expect_alpha, rtol=2e-3, err_msg=name)
+    # luminance: mean log-lum clamp [-3,2], lerp from 0 on frame 0
+    lum_lerp, _ = orc.frame_lerps(0.01)
+    np.testing.assert_allclose(got["lum"][0], lum_lerp * expect_alpha, rtol=2e-3)
+
+
+def test_argument_validation(gr):
+    hdr = capi.DeviceImage(gr, 16, 16, F16)
+    bad = capi.DeviceImage(gr, 16, 16, capi.FORMAT_R8G8B8A8_UNORM)
+    with pytest.raises(capi.GraniteHipError):
+        gr.bloom_threshold(bad, hdr)
+    with pytest.raises(capi.GraniteHipError):
+        gr.tonemap(hdr, hdr, capi.DeviceImage(gr, 8, 8, capi.FORMAT_R8G8B8A8_SRGB))
