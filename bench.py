@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixels/s of the clustered-light + bloom + tonemap chain at 4K on MI355X (BASELINE.json metric).
+
+A "step" is one frame of the hot path over one synthetic G-buffer (config 3: 3840x2160, 4096 clustered point+spot
+lights, 5 reduced bloom levels + luminance + tonemap), run through the RenderGraph executor exactly as the reference's
+headless platform runs frames (application_headless.cpp:581-612: warm-up, then timed frames).  Inputs are resident in HBM
+before the timed region.  Prints ONE JSON line (rank 0).
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (width, height, lights, description)
+    "config3_4k_4096lights": (3840, 2160, 4096, "3840x2160, 4096 clustered point+spot lights, bloom pyramid + luminance + tonemap"),
+    "config2_1080p_256lights": (1920, 1080, 256, "1920x1080, 256 point lights, full light+post chain"),
+}
+
+# algorithmic bytes per full-resolution pixel, each pass reading its declared inputs once and writing
+# its outputs once (RGBA16F HDR; G-buffer RGBA8 + A2B10G10R10 + RG8 + D32F).
+ALGO_BYTES_PER_PX = {
+    "lighting": 22.0 + 8.0,
+    "bloom_threshold": 8.0 + 2.0,
+    "tonemap": 8.5 + 4.0,
+    "chain": 56.66,
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="config3_4k_4096lights", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cam, gbuf, descs, width, height, sample_rows):
+    """The oracle (CPU restatement of the reference GLSL, OpenMP over rows) timed on this host's cores on a bounded
+    sample of the same workload: the full cluster build + the lighting/bloom/tonemap chain on a centred horizontal band
+    of `sample_rows` rows of the same G-buffer (same lights, same camera)."""
+    from oracle import oracle as orc
+    from granite_amd import synth
+
+    cores = os.cpu_count() or 1
+    rp = cam.render_params()
+    y0 = (height - sample_rows) // 2
+    band = {k: np.ascontiguousarray(v[y0:y0 + sample_rows]) for k, v in gbuf.items()}
+
+    t0 = time.perf_counter()
+    n, lights, model, tmask, _ = orc.pack_lights(descs, rp[99:102])
+    prm = orc.cluster_params(rp, *synth.CLUSTER_RESOLUTION, n)
+    cb = orc.cluster_build(rp, prm, lights, model, tmask, n, synth.CLUSTER_RESOLUTION[2])
+    t_cluster = time.perf_counter() - t0
+
+    # The band keeps its true screen position: shade it through a full-height view of the inputs by offsetting rows.
+    # (orc.lighting works on whole images; emulate with a full-size depth that is sky outside the band.)
+    full = {k: v for k, v in gbuf.items()}
+    depth = np.zeros_like(gbuf["depth"])
+    depth[y0:y0 + sample_rows] = gbuf["depth"][y0:y0 + sample_rows]
+    full = dict(gbuf, depth=depth)
+    t0 = time.perf_counter()
+    hdr = orc.lighting(full, rp, prm, lights, tmask, cb["bitmask"], cb["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
+    t_light = time.perf_counter() - t0
+    hdr_band = np.ascontiguousarray(hdr[y0:y0 + sample_rows])
+    t0 = time.perf_counter()
+    orc.hdr_chain(hdr_band, {})
+    t_post = time.perf_counter() - t0
+    del band
+    # Extrapolate to a whole frame: the cluster build is paid once per frame, the per-pixel passes scale with rows.
+    frame_s = t_cluster + (t_light + t_post) * (height / sample_rows)
+    return {
+        "value": width * height / frame_s / 1e6,
+        "unit": "Mpixels/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"1 frame, {width}x{sample_rows} band of the same G-buffer (all {n} lights, full cluster build): "
+                  f"cluster {t_cluster:.2f}s + lighting {t_light:.2f}s + bloom/tonemap {t_post:.2f}s on {cores} OpenMP threads; "
+                  f"value = full-frame rate extrapolated as cluster + per-pixel passes x {height}/{sample_rows}",
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP executor has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from granite_amd import app as gapp, synth
+
+    width, height, num_lights, desc = WORKLOADS[args.workload]
+    cam = synth.Camera(width, height)
+    gbuf = synth.make_gbuffer(cam)
+    descs = synth.make_lights(cam, num_lights, spot_fraction=0.25 if num_lights > 256 else 0.0)
+
+    application = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True,
+                                   compute_post=True)
+    application.set_render_parameters(cam.render_params())
+    application.set_lights(descs)
+    application.upload_gbuffer(gbuf)
+    kctx = application.kernel_context()
+
+    def barrier():
+        torch.cuda.synchronize()
+        application.sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (also finds the dominant kernel with every launcher bracketed) ----
+    kctx.timing_enable(True)
+    kctx.timing_set_filter(None)
+    kctx.timing_reset()
+    application.render_frames(max(args.warmup, 1), sync=True)
+    per_kernel = kctx.timing_query()
+    dominant = max(per_kernel.items(), key=lambda kv: kv[1][1])[0] if per_kernel else "lighting"
+    warm_breakdown = {k: {"launches": c, "avg_us": 1000.0 * ms / max(c, 1)} for k, (c, ms) in per_kernel.items()}
+
+    # ---- timed region: only the dominant kernel keeps its hipEvent bracket ----
+    kctx.timing_set_filter(dominant)
+    kctx.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    application.render_frames(args.steps, sync=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timed = kctx.timing_query()
+    kctx.timing_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    pixels_per_step = width * height * world  # replicas: every rank renders its own frame
+    value = pixels_per_step * args.steps / elapsed / 1e6
+
+    dom_count, dom_ms = timed.get(dominant, (0, 0.0))
+    dom_avg_s = (dom_ms / 1000.0) / max(dom_count, 1)
+    bpp = ALGO_BYTES_PER_PX.get(dominant)
+    roofline = None
+    if bpp and dom_avg_s > 0:
+        algo_bytes = bpp * width * height
+        achieved = algo_bytes / dom_avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                    "avg_launch_us": dom_avg_s * 1e6, "launches": dom_count}
+    chain_bytes = ALGO_BYTES_PER_PX["chain"] * width * height
+    chain_gbs = chain_bytes * args.steps / elapsed / 1e9
+
+    result = {
+        "metric": "Mpixels/s for clustered-light+post chain @4K; achieved HBM GB/s vs roofline",
+        "value": value,
+        "unit": "Mpixels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": args.workload, "description": desc, "width": width, "height": height, "lights": num_lights,
+                   "cluster_grid": list(synth.CLUSTER_RESOLUTION), "parallelism": "replicas" if world > 1 else "single",
+                   "hdr_format": "R16G16B16A16_SFLOAT", "seed": synth.SEED},
+        "roofline": roofline,
+        "chain": {"algorithmic_GBps": chain_gbs, "frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS,
+                  "algorithmic_bytes_per_frame": chain_bytes},
+        "kernels_warmup": warm_breakdown,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        rows = args.cpu_sample_rows or max(64, height // 8)
+        result["cpu_baseline"] = cpu_baseline(cam, gbuf, descs, width, height, rows)
+    else:
+        result["cpu_baseline"] = None
+
+    application.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,255 @@
+"""ctypes binding of the headless harness (include/granite_app.h): composes Granite's image-space render graph on the
+HIP executor and runs frames.  One call per N frames keeps Python out of the timed loop."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import capi, synth
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgranite_host.so")
+
+POST_AA_NONE, POST_AA_FXAA = 0, 1
+POST_AA_SMAA_LOW, POST_AA_SMAA_MEDIUM, POST_AA_SMAA_HIGH, POST_AA_SMAA_ULTRA = 2, 3, 4, 5
+POST_AA_TAA_LOW, POST_AA_TAA_MEDIUM, POST_AA_TAA_HIGH = 6, 7, 8
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32), ("enable_lighting", C.c_int32),
+                ("hdr_bloom", C.c_int32), ("dynamic_exposure", C.c_int32), ("compute_post", C.c_int32),
+                ("post_aa", C.c_int32), ("pre_aa", C.c_int32), ("rmw_emissive", C.c_int32),
+                ("cluster_res", C.c_uint32 * 3), ("frame_time", C.c_float), ("directional_color", C.c_float * 3),
+                ("directional_direction", C.c_float * 3), ("enable_timestamps", C.c_int32)]
+
+
+class ResourceInfo(C.Structure):
+    _fields_ = [("device_ptr", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32),
+                ("size_bytes", C.c_uint64), ("physical_index", C.c_int32)]
+
+
+class Timestamp(C.Structure):
+    _fields_ = [("tag", C.c_char * 64), ("count", C.c_uint64), ("total_ms", C.c_double)]
+
+
+EXPORTED_SYMBOLS = [
+    "gra_create", "gra_destroy", "gra_last_error", "gra_set_camera", "gra_set_render_parameters",
+    "gra_get_render_parameters", "gra_set_lights", "gra_upload_gbuffer", "gra_render_frames", "gra_sync",
+    "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
+    "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise capi.GraniteHipError(f"{LIB_PATH} not found: run __graft_entry__.build(). There is no CPU fallback.")
+    capi.load_library()  # dependency, resolved through $ORIGIN rpath as well
+    lib = C.CDLL(LIB_PATH)
+    vp, P = C.c_void_p, C.POINTER
+    sigs = {
+        "gra_create": (vp, [P(Config), C.c_char_p, C.c_size_t]),
+        "gra_destroy": (None, [vp]),
+        "gra_last_error": (C.c_char_p, [vp]),
+        "gra_set_camera": (C.c_int, [vp, vp, vp]),
+        "gra_set_render_parameters": (C.c_int, [vp, vp]),
+        "gra_get_render_parameters": (C.c_int, [vp, vp]),
+        "gra_set_lights": (C.c_int, [vp, vp, C.c_uint32]),
+        "gra_upload_gbuffer": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
+        "gra_render_frames": (C.c_int, [vp, C.c_uint32, C.c_int32]),
+        "gra_sync": (C.c_int, [vp]),
+        "gra_get_resource": (C.c_int, [vp, C.c_char_p, P(ResourceInfo)]),
+        "gra_read_resource": (C.c_int, [vp, C.c_char_p, vp, C.c_uint64]),
+        "gra_get_backbuffer": (C.c_int, [vp, P(ResourceInfo)]),
+        "gra_read_backbuffer": (C.c_int, [vp, vp, C.c_uint64]),
+        "gra_get_cluster_state": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+        "gra_dump_graph": (C.c_size_t, [vp, C.c_char_p, C.c_size_t]),
+        "gra_collect_timestamps": (C.c_int, [vp, P(Timestamp), C.c_int]),
+        "gra_get_kernel_context": (vp, [vp]),
+        "gra_get_stream": (vp, [vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else np.ascontiguousarray(a).ctypes.data
+
+
+class Application:
+    """Headless image-space application.  device=-1 composes/bakes the graph without a GPU (CPU tests)."""
+
+    def __init__(self, width: int, height: int, *, device: int = 0, lighting: bool = True, hdr_bloom: bool = True,
+                 dynamic_exposure: bool = True, compute_post: bool = True, post_aa: int = POST_AA_NONE,
+                 pre_aa: int = POST_AA_NONE, rmw_emissive: bool = False, cluster_res=synth.CLUSTER_RESOLUTION,
+                 frame_time: float = synth.FRAME_TIME, timestamps: bool = False):
+        self.lib = load_library()
+        cfg = Config()
+        cfg.device, cfg.width, cfg.height = device, width, height
+        cfg.enable_lighting, cfg.hdr_bloom = int(lighting), int(hdr_bloom)
+        cfg.dynamic_exposure, cfg.compute_post = int(dynamic_exposure), int(compute_post)
+        cfg.post_aa, cfg.pre_aa, cfg.rmw_emissive = post_aa, pre_aa, int(rmw_emissive)
+        cfg.cluster_res[:] = cluster_res
+        cfg.frame_time = frame_time
+        cfg.directional_color[:] = synth.DIRECTIONAL_COLOR
+        cfg.directional_direction[:] = synth.DIRECTIONAL_DIRECTION
+        cfg.enable_timestamps = int(timestamps)
+        self.config = cfg
+        self.width, self.height = width, height
+        err = C.create_string_buffer(512)
+        self.handle = self.lib.gra_create(cfg, err, 512)
+        if not self.handle:
+            raise capi.GraniteHipError(f"gra_create failed: {err.value.decode()}")
+
+    def _check(self, code):
+        if code < 0:
+            raise capi.GraniteHipError(self.lib.gra_last_error(self.handle).decode())
+        return code
+
+    def close(self):
+        if self.handle:
+            self.lib.gra_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- scene ---------------------------------------------------------------------------------------------------
+    def set_render_parameters(self, params104: np.ndarray):
+        p = np.ascontiguousarray(params104, np.float32)
+        assert p.size == 104
+        self._check(self.lib.gra_set_render_parameters(self.handle, p.ctypes.data))
+
+    def set_camera(self, projection16, view16):
+        p, v = np.ascontiguousarray(projection16, np.float32), np.ascontiguousarray(view16, np.float32)
+        self._check(self.lib.gra_set_camera(self.handle, p.ctypes.data, v.ctypes.data))
+
+    def get_render_parameters(self) -> np.ndarray:
+        out = np.zeros(104, np.float32)
+        self._check(self.lib.gra_get_render_parameters(self.handle, out.ctypes.data))
+        return out
+
+    def set_lights(self, descs: np.ndarray):
+        d = np.ascontiguousarray(descs, synth.LIGHT_DESC_DTYPE)
+        self._check(self.lib.gra_set_lights(self.handle, d.ctypes.data if len(d) else None, len(d)))
+
+    def upload_gbuffer(self, gbuf: dict, motion_vectors=None):
+        keep = [np.ascontiguousarray(gbuf[k]) if k in gbuf and gbuf[k] is not None else None
+                for k in ("emissive", "albedo", "normal", "pbr", "depth")]
+        mv = None if motion_vectors is None else np.ascontiguousarray(motion_vectors)
+        self._check(self.lib.gra_upload_gbuffer(self.handle, *[_ptr(k) for k in keep], _ptr(mv)))
+
+    def upload_hdr(self, hdr_bits: np.ndarray):
+        self.upload_gbuffer({"emissive": hdr_bits})
+
+    # ---- frames --------------------------------------------------------------------------------------------------
+    def render_frames(self, count: int = 1, sync: bool = True):
+        self._check(self.lib.gra_render_frames(self.handle, count, int(sync)))
+
+    def sync(self):
+        self._check(self.lib.gra_sync(self.handle))
+
+    # ---- introspection ----------------------------------------------------------------------------------------------
+    def resource(self, name: str) -> ResourceInfo:
+        info = ResourceInfo()
+        self._check(self.lib.gra_get_resource(self.handle, name.encode(), info))
+        return info
+
+    def _shape(self, info: ResourceInfo, raw: np.ndarray):
+        f, w, h = info.format, info.width, info.height
+        if f == capi.FORMAT_R16G16B16A16_SFLOAT:
+            return raw.view(np.uint16).reshape(h, w, 4)
+        if f in (capi.FORMAT_R8G8B8A8_SRGB, capi.FORMAT_R8G8B8A8_UNORM):
+            return raw.reshape(h, w, 4)
+        if f == capi.FORMAT_R8G8_UNORM:
+            return raw.reshape(h, w, 2)
+        if f in (capi.FORMAT_D32_SFLOAT, capi.FORMAT_R32_SFLOAT):
+            return raw.view(np.float32).reshape(h, w)
+        if f == capi.FORMAT_A2B10G10R10_UNORM_PACK32:
+            return raw.view(np.uint32).reshape(h, w)
+        if f == capi.FORMAT_R16G16_SFLOAT:
+            return raw.view(np.uint16).reshape(h, w, 2)
+        return raw
+
+    def read(self, name: str) -> np.ndarray:
+        info = self.resource(name)
+        raw = np.empty(info.size_bytes, np.uint8)
+        self._check(self.lib.gra_read_resource(self.handle, name.encode(), raw.ctypes.data, raw.nbytes))
+        return self._shape(info, raw) if info.width else raw
+
+    def read_backbuffer(self) -> np.ndarray:
+        info = ResourceInfo()
+        self._check(self.lib.gra_get_backbuffer(self.handle, info))
+        raw = np.empty(info.size_bytes, np.uint8)
+        self._check(self.lib.gra_read_backbuffer(self.handle, raw.ctypes.data, raw.nbytes))
+        return self._shape(info, raw)
+
+    def backbuffer_info(self) -> ResourceInfo:
+        info = ResourceInfo()
+        self._check(self.lib.gra_get_backbuffer(self.handle, info))
+        return info
+
+    def cluster_state(self):
+        lights = np.zeros(4096 * 48, np.uint8)
+        models = np.zeros((4096, 3, 4), np.float32)
+        type_mask = np.zeros(128, np.uint32)
+        params = np.zeros(176, np.uint8)
+        ranges = np.zeros((4096, 2), np.uint32)
+        n = self._check(self.lib.gra_get_cluster_state(self.handle, lights.ctypes.data, models.ctypes.data, type_mask.ctypes.data,
+                                                       params.ctypes.data, ranges.ctypes.data))
+        return {"count": n, "lights": lights, "models": models, "type_mask": type_mask, "params": params,
+                "light_ranges": ranges[:max(n, 1)]}
+
+    def graph(self) -> dict:
+        need = self.lib.gra_dump_graph(self.handle, None, 0)
+        if need == 0:
+            raise capi.GraniteHipError(self.lib.gra_last_error(self.handle).decode())
+        buf = C.create_string_buffer(need)
+        self.lib.gra_dump_graph(self.handle, buf, need)
+        return json.loads(buf.value.decode())
+
+    def timestamps(self) -> dict:
+        arr = (Timestamp * 64)()
+        n = self._check(self.lib.gra_collect_timestamps(self.handle, arr, 64))
+        return {arr[i].tag.decode(): (int(arr[i].count), float(arr[i].total_ms)) for i in range(n)}
+
+    def kernel_context(self) -> "KernelContextView":
+        return KernelContextView(self.lib.gra_get_kernel_context(self.handle))
+
+
+class KernelContextView:
+    """Borrowed gr_ctx of a running application: per-kernel hipEvent timing (gr_timing_*)."""
+
+    def __init__(self, handle):
+        self.lib = capi.load_library()
+        self.handle = handle
+
+    def timing_enable(self, enable: bool):
+        self.lib.gr_timing_enable(self.handle, int(enable))
+
+    def timing_reset(self):
+        self.lib.gr_timing_reset(self.handle)
+
+    def timing_set_filter(self, name=None):
+        self.lib.gr_timing_set_filter(self.handle, None if name is None else name.encode())
+
+    def timing_query(self) -> dict:
+        arr = (capi.TimingEntry * 64)()
+        n = self.lib.gr_timing_query(self.handle, arr, 64)
+        if n < 0:
+            raise capi.GraniteHipError(self.lib.gr_last_error(self.handle).decode())
+        return {arr[i].name.decode(): (int(arr[i].count), float(arr[i].total_ms)) for i in range(n)}

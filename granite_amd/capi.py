@@ -126,7 +126,8 @@ class PushClustering(C.Structure):
 
 
 class LightingArgs(C.Structure):
-    _fields_ = [("albedo", Image), ("normal", Image), ("pbr", Image), ("depth", Image), ("hdr", Image),
+    _fields_ = [("albedo", Image), ("normal", Image), ("pbr", Image), ("depth", Image), ("emissive", Image),
+                ("hdr", Image),
                 ("inv_view_projection", C.c_float * 16), ("directional", PushDirectional), ("clustering", PushClustering),
                 ("cluster", ClusterParams), ("transforms", C.c_void_p), ("bitmask", C.c_void_p), ("range", C.c_void_p),
                 ("flags", C.c_uint32)]
@@ -164,6 +165,7 @@ def load_library() -> C.CDLL:
         "gr_copy": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
         "gr_fill_zero": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "gr_timing_enable": (C.c_int, [vp, C.c_int]),
+        "gr_timing_set_filter": (C.c_int, [vp, C.c_char_p]),
         "gr_timing_reset": (C.c_int, [vp]),
         "gr_timing_query": (C.c_int, [vp, P(TimingEntry), C.c_int]),
         "gr_bloom_threshold": (C.c_int, [vp, vp, P(Image), P(Image), vp, P(PushBloomThreshold)]),
@@ -187,7 +189,7 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "gr_abi_version", "gr_create", "gr_destroy", "gr_last_error", "gr_sync", "gr_alloc", "gr_free", "gr_upload",
-    "gr_download", "gr_copy", "gr_fill_zero", "gr_timing_enable", "gr_timing_reset", "gr_timing_query",
+    "gr_download", "gr_copy", "gr_fill_zero", "gr_timing_enable", "gr_timing_set_filter", "gr_timing_reset", "gr_timing_query",
     "gr_bloom_threshold", "gr_bloom_downsample", "gr_bloom_upsample", "gr_luminance", "gr_tonemap",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
 ]

@@ -140,6 +140,14 @@ int gr_timing_enable(gr_ctx *ctx, int enable)
 	return GR_OK;
 }
 
+int gr_timing_set_filter(gr_ctx *ctx, const char *name)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	ctx->timing_filter = name ? name : "";
+	return GR_OK;
+}
+
 static int drain_spans(gr_ctx *ctx)
 {
 	for (auto &s : ctx->spans)

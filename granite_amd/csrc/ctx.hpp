@@ -30,6 +30,7 @@ struct gr_ctx
 	void *smaa_search = nullptr; // R8, 64 x 16
 
 	bool timing_enabled = false;
+	std::string timing_filter; // empty = every launcher
 	std::vector<gr_timing_span> spans;
 	std::vector<hipEvent_t> event_pool;
 	struct Accum { uint64_t count = 0; double ms = 0.0; };
@@ -73,6 +74,8 @@ struct gr_scoped_timing
 	gr_scoped_timing(gr_ctx *ctx_, hipStream_t stream_, const char *name) : ctx(ctx_), stream(stream_)
 	{
 		if (!ctx->timing_enabled)
+			return;
+		if (!ctx->timing_filter.empty() && ctx->timing_filter != name)
 			return;
 		std::lock_guard<std::mutex> holder{ctx->lock};
 		span.name = name;

@@ -1,0 +1,305 @@
+// extern "C" surface of the harness (include/granite_app.h).  Exceptions from the C++ layer stop here.
+#include "image_space_app.hpp"
+#include <cstdio>
+#include <cstring>
+
+using namespace Granite;
+
+struct gra_app
+{
+	std::unique_ptr<ImageSpaceApplication> app;
+	std::string error;
+};
+
+template <typename Fn>
+static int guarded(gra_app *app, Fn &&fn)
+{
+	if (!app)
+		return -1;
+	try
+	{
+		fn();
+		return 0;
+	}
+	catch (const std::exception &e)
+	{
+		app->error = e.what();
+		return -1;
+	}
+}
+
+static void unpack_mat4(mat4 &m, const float *src)
+{
+	memcpy(m.data(), src, 16 * sizeof(float));
+}
+
+extern "C" {
+
+gra_app *gra_create(const gra_config *config, char *error, size_t error_size)
+{
+	try
+	{
+		if (!config)
+			throw std::logic_error("null config");
+		auto *handle = new gra_app;
+		handle->app = std::make_unique<ImageSpaceApplication>(*config);
+		return handle;
+	}
+	catch (const std::exception &e)
+	{
+		if (error && error_size)
+			snprintf(error, error_size, "%s", e.what());
+		return nullptr;
+	}
+}
+
+void gra_destroy(gra_app *app)
+{
+	delete app;
+}
+
+const char *gra_last_error(gra_app *app)
+{
+	return app ? app->error.c_str() : "null app";
+}
+
+int gra_set_camera(gra_app *app, const float *projection16, const float *view16)
+{
+	return guarded(app, [&]() {
+		mat4 p, v;
+		unpack_mat4(p, projection16);
+		unpack_mat4(v, view16);
+		app->app->get_context().set_camera(p, v);
+	});
+}
+
+int gra_set_render_parameters(gra_app *app, const float *f)
+{
+	return guarded(app, [&]() {
+		RenderParameters rp = app->app->get_context().get_render_parameters();
+		unpack_mat4(rp.projection, f);
+		unpack_mat4(rp.view, f + 16);
+		unpack_mat4(rp.view_projection, f + 32);
+		unpack_mat4(rp.inv_projection, f + 48);
+		unpack_mat4(rp.inv_view, f + 64);
+		unpack_mat4(rp.inv_view_projection, f + 80);
+		rp.unjittered_view_projection = rp.view_projection;
+		rp.unjittered_inv_view_projection = rp.inv_view_projection;
+		rp.camera_position = vec3(f[96], f[97], f[98]);
+		rp.camera_front = vec3(f[99], f[100], f[101]);
+		rp.z_near = f[102];
+		rp.z_far = f[103];
+		app->app->get_context().set_render_parameters(rp);
+	});
+}
+
+int gra_get_render_parameters(gra_app *app, float *f)
+{
+	return guarded(app, [&]() {
+		auto &rp = app->app->get_context().get_render_parameters();
+		const mat4 *mats[6] = {&rp.projection, &rp.view, &rp.view_projection, &rp.inv_projection, &rp.inv_view, &rp.inv_view_projection};
+		for (int i = 0; i < 6; i++)
+			memcpy(f + 16 * i, mats[i]->data(), 16 * sizeof(float));
+		for (int i = 0; i < 3; i++)
+		{
+			f[96 + i] = rp.camera_position[i];
+			f[99 + i] = rp.camera_front[i];
+		}
+		f[102] = rp.z_near;
+		f[103] = rp.z_far;
+	});
+}
+
+int gra_set_lights(gra_app *app, const gra_light_desc *lights, uint32_t count)
+{
+	return guarded(app, [&]() { app->app->set_lights(lights, count); });
+}
+
+int gra_upload_gbuffer(gra_app *app, const void *emissive, const void *albedo, const void *normal, const void *pbr, const void *depth,
+                       const void *mv)
+{
+	return guarded(app, [&]() { app->app->upload_gbuffer(emissive, albedo, normal, pbr, depth, mv); });
+}
+
+int gra_render_frames(gra_app *app, uint32_t count, int32_t sync)
+{
+	return guarded(app, [&]() {
+		for (uint32_t i = 0; i < count; i++)
+			app->app->render_frame();
+		if (sync)
+			app->app->wait_idle();
+	});
+}
+
+int gra_sync(gra_app *app)
+{
+	return guarded(app, [&]() { app->app->wait_idle(); });
+}
+
+static void fill_image_info(gra_resource_info *info, HIP::Image &img, int phys)
+{
+	info->device_ptr = img.get_device_pointer();
+	info->width = img.get_width();
+	info->height = img.get_height();
+	info->format = img.get_format();
+	info->size_bytes = img.get_size_bytes();
+	info->physical_index = phys;
+}
+
+static void lookup_resource(gra_app *app, const char *name, gra_resource_info *info)
+{
+	auto &graph = app->app->get_graph();
+	*info = {};
+	// Buffers and textures share one name table; try texture first.
+	try
+	{
+		auto &tex = graph.get_texture_resource(name);
+		if (tex.get_physical_index() == RenderResource::Unused)
+			throw std::logic_error(std::string("resource not part of the baked graph: ") + name);
+		fill_image_info(info, graph.get_physical_texture_resource(tex), int(tex.get_physical_index()));
+		return;
+	}
+	catch (const std::logic_error &)
+	{
+	}
+	auto &buf = graph.get_buffer_resource(name);
+	if (buf.get_physical_index() == RenderResource::Unused)
+		throw std::logic_error(std::string("resource not part of the baked graph: ") + name);
+	auto &phys = graph.get_physical_buffer_resource(buf);
+	info->device_ptr = phys.get_device_pointer();
+	info->size_bytes = phys.get_size();
+	info->physical_index = int(buf.get_physical_index());
+}
+
+int gra_get_resource(gra_app *app, const char *name, gra_resource_info *info)
+{
+	return guarded(app, [&]() { lookup_resource(app, name, info); });
+}
+
+int gra_read_resource(gra_app *app, const char *name, void *dst_host, uint64_t size_bytes)
+{
+	return guarded(app, [&]() {
+		gra_resource_info info;
+		lookup_resource(app, name, &info);
+		if (size_bytes > info.size_bytes)
+			throw std::logic_error("read size exceeds resource size");
+		app->app->wait_idle();
+		auto *ctx = app->app->get_device().get_context();
+		if (gr_download(ctx, nullptr, dst_host, info.device_ptr, size_bytes) < 0)
+			throw std::runtime_error(gr_last_error(ctx));
+	});
+}
+
+int gra_get_backbuffer(gra_app *app, gra_resource_info *info)
+{
+	return guarded(app, [&]() {
+		auto *bb = app->app->get_last_backbuffer();
+		if (!bb)
+			throw std::logic_error("no frame rendered yet");
+		fill_image_info(info, *bb, -1);
+	});
+}
+
+int gra_read_backbuffer(gra_app *app, void *dst_host, uint64_t size_bytes)
+{
+	return guarded(app, [&]() {
+		auto *bb = app->app->get_last_backbuffer();
+		if (!bb)
+			throw std::logic_error("no frame rendered yet");
+		if (size_bytes > bb->get_size_bytes())
+			throw std::logic_error("read size exceeds backbuffer size");
+		app->app->wait_idle();
+		auto *ctx = app->app->get_device().get_context();
+		if (gr_download(ctx, nullptr, dst_host, bb->get_device_pointer(), size_bytes) < 0)
+			throw std::runtime_error(gr_last_error(ctx));
+	});
+}
+
+int gra_get_cluster_state(gra_app *app, void *lights48, void *models48, uint32_t *type_mask128, void *params176, uint32_t *light_ranges)
+{
+	if (!app)
+		return -1;
+	try
+	{
+		auto &c = app->app->get_clusterer();
+		auto &lights = c.get_packed_lights();
+		if (lights48)
+			memcpy(lights48, lights.data(), lights.size() * sizeof(lights[0]));
+		if (models48)
+			memcpy(models48, c.get_packed_models().data(), lights.size() * sizeof(mat_affine));
+		if (type_mask128)
+			memcpy(type_mask128, c.get_type_mask(), 128 * sizeof(uint32_t));
+		if (params176)
+			memcpy(params176, &c.get_cluster_parameters_bindless(), sizeof(ClustererParametersBindless));
+		if (light_ranges)
+			memcpy(light_ranges, c.get_volume_index_range().data(), c.get_volume_index_range().size() * sizeof(uvec2));
+		return int(lights.size());
+	}
+	catch (const std::exception &e)
+	{
+		app->error = e.what();
+		return -1;
+	}
+}
+
+size_t gra_dump_graph(gra_app *app, char *buffer, size_t size)
+{
+	if (!app)
+		return 0;
+	std::string json;
+	try
+	{
+		if (app->app->get_graph().get_baked_pass_order().empty())
+			app->app->bake_only();
+		json = app->app->get_graph().dump_json();
+	}
+	catch (const std::exception &e)
+	{
+		app->error = e.what();
+		return 0;
+	}
+	if (buffer && size)
+	{
+		size_t n = std::min(size - 1, json.size());
+		memcpy(buffer, json.data(), n);
+		buffer[n] = '\0';
+	}
+	return json.size() + 1;
+}
+
+int gra_collect_timestamps(gra_app *app, gra_timestamp *entries, int max_entries)
+{
+	if (!app)
+		return -1;
+	try
+	{
+		auto reports = app->app->get_graph().collect_timestamps();
+		int n = 0;
+		for (auto &r : reports)
+		{
+			if (n >= max_entries)
+				break;
+			snprintf(entries[n].tag, sizeof(entries[n].tag), "%s", r.tag.c_str());
+			entries[n].count = r.count;
+			entries[n].total_ms = r.total_ms;
+			n++;
+		}
+		return n;
+	}
+	catch (const std::exception &e)
+	{
+		app->error = e.what();
+		return -1;
+	}
+}
+
+void *gra_get_kernel_context(gra_app *app)
+{
+	return app ? app->app->get_device().get_context() : nullptr;
+}
+
+void *gra_get_stream(gra_app *app)
+{
+	return app ? app->app->get_device().get_stream(HIP::CommandBuffer::Type::Generic) : nullptr;
+}
+}

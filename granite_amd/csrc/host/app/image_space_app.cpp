@@ -1,0 +1,256 @@
+#include "image_space_app.hpp"
+#include <cstring>
+
+namespace Granite
+{
+static std::string tagcat(const std::string &a, const std::string &b)
+{
+	return a + "-" + b;
+}
+
+ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config(config_)
+{
+	if (config.device >= 0)
+		device_holder = std::make_unique<HIP::Device>(config.device);
+	if (!config.width || !config.height)
+		throw std::logic_error("Backbuffer dimensions must be non-zero.");
+	if (!config.cluster_res[0])
+	{
+		// SceneViewerApplication: cluster->set_resolution(128, 64, 4096) (scene_viewer_application.cpp:407)
+		config.cluster_res[0] = 128;
+		config.cluster_res[1] = 64;
+		config.cluster_res[2] = 4096;
+	}
+	cluster.set_resolution(config.cluster_res[0], config.cluster_res[1], config.cluster_res[2]);
+	cluster.set_base_render_context(&context);
+	cluster.set_scene_lights(&light_list);
+
+	lighting.directional.color = vec3(config.directional_color[0], config.directional_color[1], config.directional_color[2]);
+	lighting.directional.direction = vec3(config.directional_direction[0], config.directional_direction[1], config.directional_direction[2]);
+	lighting.cluster = &cluster;
+	context.set_lighting_parameters(&lighting);
+	hdr_options.dynamic_exposure = config.dynamic_exposure != 0;
+
+	// Default camera of the survey's synthetic scene; gra_set_camera / gra_set_render_parameters override it.
+	context.set_camera(perspective(1.0471975512f, float(config.width) / float(config.height), 0.1f, 100.0f),
+	                   look_at(vec3(0.0f, 2.0f, 8.0f), vec3(0.0f, 1.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f)));
+
+	graph.enable_timestamps(config.enable_timestamps != 0);
+	if (!device_holder)
+		return;
+	auto &device = *device_holder;
+
+	// External swapchain: 4 images R8G8B8A8_SRGB, cycled per frame.
+	for (unsigned i = 0; i < 4; i++)
+		swapchain.push_back(device.create_image(config.width, config.height, VK_FORMAT_R8G8B8A8_SRGB, "swapchain-" + std::to_string(i)));
+
+	src_emissive = device.create_image(config.width, config.height, VK_FORMAT_R16G16B16A16_SFLOAT, "src-emissive");
+	if (config.enable_lighting)
+	{
+		src_albedo = device.create_image(config.width, config.height, VK_FORMAT_R8G8B8A8_SRGB, "src-albedo");
+		src_normal = device.create_image(config.width, config.height, VK_FORMAT_A2B10G10R10_UNORM_PACK32, "src-normal");
+		src_pbr = device.create_image(config.width, config.height, VK_FORMAT_R8G8_UNORM, "src-pbr");
+		src_depth = device.create_image(config.width, config.height, VK_FORMAT_D32_SFLOAT, "src-depth");
+	}
+}
+
+ImageSpaceApplication::~ImageSpaceApplication()
+{
+	wait_idle();
+}
+
+void ImageSpaceApplication::set_lights(const gra_light_desc *descs, uint32_t count)
+{
+	light_objects.clear();
+	light_transforms.resize(count);
+	light_list.clear();
+	for (uint32_t i = 0; i < count; i++)
+	{
+		auto &d = descs[i];
+		mat_affine &t = light_transforms[i];
+		for (int r = 0; r < 3; r++)
+			t[r] = vec4(d.transform[4 * r + 0], d.transform[4 * r + 1], d.transform[4 * r + 2], d.transform[4 * r + 3]);
+		std::unique_ptr<PositionalLight> light;
+		if (d.type == 0)
+		{
+			auto spot = std::make_unique<SpotLight>();
+			spot->set_spot_parameters(d.inner_cone, d.outer_cone);
+			light = std::move(spot);
+		}
+		else
+			light = std::make_unique<PointLight>();
+		light->set_color(vec3(d.color[0], d.color[1], d.color[2]));
+		light->set_maximum_range(d.cutoff_range);
+		light_list.push_back({light.get(), &light_transforms[i]});
+		light_objects.push_back(std::move(light));
+	}
+}
+
+void ImageSpaceApplication::upload_gbuffer(const void *emissive, const void *albedo, const void *normal, const void *pbr, const void *depth,
+                                           const void *mv)
+{
+	auto &device = get_device();
+	device.wait_idle();
+	auto upload = [&](HIP::ImageHandle &img, const void *src, const char *what) {
+		if (!src)
+			return;
+		if (!img)
+			throw std::logic_error(std::string("This graph has no ") + what + " attachment.");
+		if (gr_upload(device.get_context(), nullptr, img->get_device_pointer(), src, img->get_size_bytes()) < 0 ||
+		    gr_sync(device.get_context(), nullptr) < 0)
+			throw std::runtime_error(gr_last_error(device.get_context()));
+	};
+	upload(src_emissive, emissive, "emissive");
+	upload(src_albedo, albedo, "albedo");
+	upload(src_normal, normal, "normal");
+	upload(src_pbr, pbr, "pbr");
+	upload(src_depth, depth, "depth");
+	if (mv && !src_mv)
+		src_mv = device.create_image(config.width, config.height, VK_FORMAT_R16G16_SFLOAT, "src-mv");
+	upload(src_mv, mv, "motion-vector");
+	gbuffer_dirty = true;
+}
+
+// Config-1 style graph head: an "HDR-main" colour target filled from the uploaded HDR image (tools/aa_bench.cpp:80-101
+// does the same with a blit of a PNG).
+void ImageSpaceApplication::add_hdr_input_pass(const std::string &tag)
+{
+	AttachmentInfo hdr;
+	hdr.format = VK_FORMAT_R16G16B16A16_SFLOAT;
+	auto &pass = graph.add_pass(tagcat("hdr-input", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+	auto &out = pass.add_color_output(tagcat("HDR", tag), hdr);
+	pass.set_build_render_pass([this, &out](HIP::CommandBuffer &cmd) {
+		if (gbuffer_dirty)
+			cmd.copy_image(graph.get_physical_texture_resource(out), *src_emissive);
+	});
+}
+
+void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
+{
+	AttachmentInfo emissive, albedo, normal, pbr, depth;
+	emissive.format = VK_FORMAT_R16G16B16A16_SFLOAT; // renderTargetFp16 (scene_viewer_application.cpp:881-883)
+	albedo.format = VK_FORMAT_R8G8B8A8_SRGB;
+	normal.format = VK_FORMAT_A2B10G10R10_UNORM_PACK32;
+	pbr.format = VK_FORMAT_R8G8_UNORM;
+	depth.format = VK_FORMAT_D32_SFLOAT;
+
+	// The G-buffer producer: Granite rasterises the scene here; the harness copies the synthetic attachments in.
+	// Attachments persist across frames, so only what a later pass clobbers (emissive under the RMW declaration) is
+	// restored every frame.
+	auto &gbuffer = graph.add_pass(tagcat("gbuffer", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+	auto &g_emissive = gbuffer.add_color_output(tagcat("emissive", tag), emissive);
+	auto &g_albedo = gbuffer.add_color_output(tagcat("albedo", tag), albedo);
+	auto &g_normal = gbuffer.add_color_output(tagcat("normal", tag), normal);
+	auto &g_pbr = gbuffer.add_color_output(tagcat("pbr", tag), pbr);
+	auto &g_depth = gbuffer.set_depth_stencil_output(tagcat("depth-transient", tag), depth);
+	gbuffer.set_build_render_pass([this, &g_emissive, &g_albedo, &g_normal, &g_pbr, &g_depth](HIP::CommandBuffer &cmd) {
+		if (gbuffer_dirty || config.rmw_emissive)
+			cmd.copy_image(graph.get_physical_texture_resource(g_emissive), *src_emissive);
+		if (gbuffer_dirty)
+		{
+			cmd.copy_image(graph.get_physical_texture_resource(g_albedo), *src_albedo);
+			cmd.copy_image(graph.get_physical_texture_resource(g_normal), *src_normal);
+			cmd.copy_image(graph.get_physical_texture_resource(g_pbr), *src_pbr);
+			cmd.copy_image(graph.get_physical_texture_resource(g_depth), *src_depth);
+		}
+	});
+
+	auto &lighting_pass = graph.add_pass(tagcat("lighting", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+	RenderTextureResource *hdr_out;
+	RenderTextureResource *emissive_in = nullptr;
+	if (config.rmw_emissive)
+		hdr_out = &lighting_pass.add_color_output(tagcat("HDR", tag), emissive, tagcat("emissive", tag)); // reference form
+	else
+	{
+		hdr_out = &lighting_pass.add_color_output(tagcat("HDR", tag), emissive);
+		emissive_in = &lighting_pass.add_attachment_input(tagcat("emissive", tag));
+	}
+	auto &in_albedo = lighting_pass.add_attachment_input(tagcat("albedo", tag));
+	auto &in_normal = lighting_pass.add_attachment_input(tagcat("normal", tag));
+	auto &in_pbr = lighting_pass.add_attachment_input(tagcat("pbr", tag));
+	auto &in_depth = lighting_pass.add_attachment_input(tagcat("depth-transient", tag));
+	lighting_pass.set_depth_stencil_input(tagcat("depth-transient", tag));
+	lighting_pass.add_fake_resource_write_alias(tagcat("depth-transient", tag), tagcat("depth", tag));
+
+	lighting_pass.set_build_render_pass([this, hdr_out, emissive_in, &in_albedo, &in_normal, &in_pbr, &in_depth](HIP::CommandBuffer &cmd) {
+		DeferredLightAttachments att;
+		att.base_color = &graph.get_physical_texture_resource(in_albedo);
+		att.normal = &graph.get_physical_texture_resource(in_normal);
+		att.pbr = &graph.get_physical_texture_resource(in_pbr);
+		att.depth = &graph.get_physical_texture_resource(in_depth);
+		att.hdr = &graph.get_physical_texture_resource(*hdr_out);
+		att.emissive = emissive_in ? &graph.get_physical_texture_resource(*emissive_in) : att.hdr;
+		DeferredLightRenderer::render_light(cmd, context, att);
+	});
+
+	// Scene::add_render_pass_dependencies(graph, lighting_pass, LIGHTING_BIT)
+	cluster.setup_render_pass_dependencies(graph, lighting_pass, RenderPassCreator::LIGHTING_BIT);
+}
+
+void ImageSpaceApplication::bake_render_graph()
+{
+	// Keep feedback buffers (average luminance) alive across re-bakes (scene_viewer_application.cpp:1169,1315).
+	auto physical_buffers = graph.consume_physical_buffers();
+	graph.reset();
+	graph.set_device(device_holder.get());
+
+	ResourceDimensions dim;
+	dim.width = config.width;
+	dim.height = config.height;
+	dim.format = VK_FORMAT_R8G8B8A8_SRGB;
+	graph.set_backbuffer_dimensions(dim);
+
+	const std::string tag = "main";
+	if (config.enable_lighting)
+	{
+		cluster.add_render_passes(graph);
+		add_main_pass_deferred(tag);
+	}
+	else
+		add_hdr_input_pass(tag);
+
+	std::string hdr_source = tagcat("HDR", tag);
+	std::string ui_source = hdr_source;
+
+	if (config.hdr_bloom)
+	{
+		if (config.compute_post)
+			setup_hdr_postprocess_compute(graph, frame, hdr_source, "tonemapped", hdr_options);
+		else
+			setup_hdr_postprocess(graph, frame, hdr_source, "tonemapped", hdr_options);
+		ui_source = "tonemapped";
+	}
+
+	graph.set_backbuffer_source(ui_source);
+	cluster.setup_render_pass_dependencies(graph);
+	graph.bake();
+	graph.install_physical_buffers(std::move(physical_buffers));
+	need_bake = false;
+	gbuffer_dirty = true;
+}
+
+void ImageSpaceApplication::render_frame()
+{
+	auto &device = get_device();
+	if (need_bake)
+		bake_render_graph();
+
+	frame.frame_time = config.frame_time;
+	frame.elapsed_time = elapsed;
+	elapsed += config.frame_time;
+	context.set_frame_parameters(frame);
+
+	HIP::Image *backbuffer = swapchain[swapchain_index].get();
+	swapchain_index = (swapchain_index + 1) % unsigned(swapchain.size());
+
+	graph.setup_attachments(device, backbuffer);
+	if (config.enable_lighting)
+	{
+		cluster.setup_render_pass_resources(graph);
+		cluster.refresh(context, composer);
+	}
+	graph.enqueue_render_passes(device, composer);
+	gbuffer_dirty = false;
+	last_backbuffer = backbuffer;
+}
+} // namespace Granite

@@ -1,0 +1,76 @@
+// ImageSpaceApplication — headless composition + frame loop of the image-space chain on the HIP executor.
+// Graph composition follows SceneViewerApplication::bake_render_graph / add_main_pass_deferred
+// (application/scene_viewer_application.cpp:876-991,1167-1318); the frame loop follows render_frame (:1540-1611) and the
+// headless platform's external 4-image swapchain (application/platforms/application_headless.cpp:145-148,207-229).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../../../include/granite_app.h"
+#include "../lights/clusterer.hpp"
+#include "../post/hdr.hpp"
+#include "../render_context.hpp"
+#include "../render_graph.hpp"
+#include "../renderer.hpp"
+
+namespace Granite
+{
+class ImageSpaceApplication
+{
+public:
+	explicit ImageSpaceApplication(const gra_config &config);
+	~ImageSpaceApplication();
+
+	void set_lights(const gra_light_desc *descs, uint32_t count);
+	void upload_gbuffer(const void *emissive, const void *albedo, const void *normal, const void *pbr, const void *depth, const void *mv);
+	void render_frame();
+	void wait_idle()
+	{
+		if (device_holder)
+			device_holder->wait_idle();
+	}
+	// Composes and bakes the graph without touching a GPU (config.device < 0 creates no device): used by CPU tests.
+	void bake_only() { bake_render_graph(); }
+
+	HIP::Device &get_device()
+	{
+		if (!device_holder)
+			throw std::logic_error("Application was created without a device (dry mode).");
+		return *device_holder;
+	}
+	RenderGraph &get_graph() { return graph; }
+	RenderContext &get_context() { return context; }
+	LightClusterer &get_clusterer() { return cluster; }
+	HIP::Image *get_last_backbuffer() { return last_backbuffer; }
+	const gra_config &get_config() const { return config; }
+	std::string last_error;
+
+private:
+	gra_config config;
+	std::unique_ptr<HIP::Device> device_holder;
+	RenderGraph graph;
+	RenderContext context;
+	FrameParameters frame;
+	LightingParameters lighting;
+	LightClusterer cluster;
+	TaskComposer composer;
+	HDROptions hdr_options;
+
+	// "Scene": light objects + node transforms, and the synthetic G-buffer sources.
+	std::vector<std::unique_ptr<PositionalLight>> light_objects;
+	std::vector<mat_affine> light_transforms;
+	PositionalLightList light_list;
+	HIP::ImageHandle src_emissive, src_albedo, src_normal, src_pbr, src_depth, src_mv;
+	bool gbuffer_dirty = true;
+
+	std::vector<HIP::ImageHandle> swapchain;
+	unsigned swapchain_index = 0;
+	HIP::Image *last_backbuffer = nullptr;
+	bool need_bake = true;
+	double elapsed = 0.0;
+
+	void bake_render_graph();
+	void add_main_pass_deferred(const std::string &tag);
+	void add_hdr_input_pass(const std::string &tag);
+};
+} // namespace Granite

@@ -1,0 +1,182 @@
+#include "hip_device.hpp"
+#include <hip/hip_runtime_api.h>
+#include <cstring>
+#include <stdexcept>
+
+namespace HIP
+{
+static void throw_hip(hipError_t err, const char *what)
+{
+	if (err != hipSuccess)
+		throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(err));
+}
+
+Image::Image(Device &device_, unsigned width, unsigned height, VkFormat format, const std::string &name_)
+    : device(&device_), name(name_), owned(true)
+{
+	const unsigned bpp = vk_format_block_size(format);
+	if (!bpp)
+		throw std::logic_error("Unsupported image format for a linear HBM attachment: " + name);
+	view.width = width;
+	view.height = height;
+	view.pitch_bytes = width * bpp;
+	view.format = format;
+	int ret = gr_alloc(device->get_context(), get_size_bytes(), &view.ptr); // zero-initialised
+	if (ret < 0)
+		throw std::runtime_error(std::string("gr_alloc failed for ") + name + ": " + gr_last_error(device->get_context()));
+	device->account_alloc(ptrdiff_t(get_size_bytes()));
+}
+
+Image::Image(unsigned width, unsigned height, VkFormat format, void *external_ptr) : name("external"), owned(false)
+{
+	view.ptr = external_ptr;
+	view.width = width;
+	view.height = height;
+	view.pitch_bytes = width * vk_format_block_size(format);
+	view.format = format;
+}
+
+Image::~Image()
+{
+	if (owned && view.ptr)
+	{
+		gr_free(device->get_context(), view.ptr);
+		device->account_alloc(-ptrdiff_t(get_size_bytes()));
+	}
+}
+
+Buffer::Buffer(Device &device_, size_t size_, VkBufferUsageFlags usage_, const std::string &name_)
+    : device(&device_), size(size_), usage(usage_), name(name_)
+{
+	int ret = gr_alloc(device->get_context(), size, &ptr); // zero-initialised (render_graph.cpp:2586-2587)
+	if (ret < 0)
+		throw std::runtime_error(std::string("gr_alloc failed for ") + name + ": " + gr_last_error(device->get_context()));
+	device->account_alloc(ptrdiff_t(size));
+}
+
+Buffer::~Buffer()
+{
+	if (ptr)
+	{
+		gr_free(device->get_context(), ptr);
+		device->account_alloc(-ptrdiff_t(size));
+	}
+}
+
+gr_ctx *CommandBuffer::get_context() const
+{
+	return device.get_context();
+}
+
+void CommandBuffer::check(int status, const char *what)
+{
+	if (status < 0)
+		throw std::runtime_error(std::string(what) + ": " + gr_last_error(device.get_context()));
+}
+
+void CommandBuffer::update_buffer(const Buffer &dst, size_t offset, size_t size, const void *data)
+{
+	if (!size)
+		return;
+	if (offset + size > dst.get_size())
+		throw std::logic_error("update_buffer out of range");
+	void *staging = device.allocate_staging(size);
+	memcpy(staging, data, size);
+	check(gr_upload(get_context(), stream, static_cast<uint8_t *>(dst.get_device_pointer()) + offset, staging, size),
+	      "update_buffer");
+}
+
+void CommandBuffer::fill_buffer(const Buffer &dst, size_t offset, size_t size)
+{
+	check(gr_fill_zero(get_context(), stream, static_cast<uint8_t *>(dst.get_device_pointer()) + offset, size), "fill_buffer");
+}
+
+void CommandBuffer::copy_image(const Image &dst, const Image &src)
+{
+	if (dst.get_size_bytes() != src.get_size_bytes())
+		throw std::logic_error("copy_image: size mismatch");
+	check(gr_copy(get_context(), stream, dst.get_device_pointer(), src.get_device_pointer(), src.get_size_bytes()), "copy_image");
+}
+
+void CommandBuffer::clear_image(const Image &dst)
+{
+	check(gr_fill_zero(get_context(), stream, dst.get_device_pointer(), dst.get_size_bytes()), "clear_image");
+}
+
+Device::Device(int device_index) : index(device_index)
+{
+	ctx = gr_create(device_index);
+	if (!ctx)
+		throw std::runtime_error("gr_create failed: no usable HIP device " + std::to_string(device_index));
+	for (auto &s : streams)
+	{
+		hipStream_t stream;
+		throw_hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+		s = stream;
+	}
+	for (auto &frame : staging)
+	{
+		throw_hip(hipHostMalloc(reinterpret_cast<void **>(&frame.base), StagingBytes, hipHostMallocDefault), "hipHostMalloc");
+		hipEvent_t e;
+		throw_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+		frame.fence = e;
+	}
+}
+
+Device::~Device()
+{
+	(void)hipSetDevice(index);
+	(void)hipDeviceSynchronize();
+	for (auto &frame : staging)
+	{
+		if (frame.base)
+			(void)hipHostFree(frame.base);
+		if (frame.fence)
+			(void)hipEventDestroy(static_cast<hipEvent_t>(frame.fence));
+	}
+	for (auto &s : streams)
+		if (s)
+			(void)hipStreamDestroy(static_cast<hipStream_t>(s));
+	if (ctx)
+		gr_destroy(ctx);
+}
+
+ImageHandle Device::create_image(unsigned width, unsigned height, VkFormat format, const std::string &name)
+{
+	return std::make_shared<Image>(*this, width, height, format, name);
+}
+
+BufferHandle Device::create_buffer(size_t size, VkBufferUsageFlags usage, const std::string &name)
+{
+	return std::make_shared<Buffer>(*this, size, usage, name);
+}
+
+void *Device::allocate_staging(size_t size)
+{
+	auto &frame = staging[staging_index];
+	size_t aligned = (frame.offset + 63) & ~size_t(63);
+	if (aligned + size > StagingBytes)
+		throw std::runtime_error("staging ring exhausted for this frame");
+	frame.offset = aligned + size;
+	return frame.base + aligned;
+}
+
+void Device::next_frame_context()
+{
+	// Mark the copies of the frame just recorded, then make sure the slot we are about to reuse has drained.
+	auto &done = staging[staging_index];
+	for (auto &s : streams)
+		(void)s;
+	throw_hip(hipEventRecord(static_cast<hipEvent_t>(done.fence), static_cast<hipStream_t>(streams[0])), "hipEventRecord");
+	staging_index = (staging_index + 1) % StagingFrames;
+	auto &next = staging[staging_index];
+	throw_hip(hipEventSynchronize(static_cast<hipEvent_t>(next.fence)), "hipEventSynchronize");
+	next.offset = 0;
+}
+
+void Device::wait_idle()
+{
+	for (auto &s : streams)
+		throw_hip(hipStreamSynchronize(static_cast<hipStream_t>(s)), "hipStreamSynchronize");
+}
+} // namespace HIP

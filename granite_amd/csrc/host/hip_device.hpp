@@ -1,0 +1,135 @@
+// HIP:: — what Vulkan::{Device,ImageView,Buffer,CommandBuffer} are to Granite's pass callbacks
+// (vulkan/device.hpp, vulkan/command_buffer.hpp), reduced to what the image-space chain uses:
+// linear HBM images/buffers, an in-order HIP stream per queue, and the C-ABI kernel launchers.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+#include "vk_subset.hpp"
+#include "../../../include/granite_hip.h"
+
+namespace HIP
+{
+class Device;
+
+// A linear row-major 2-D image in HBM.  Owns its memory unless wrapping an external pointer (swapchain image).
+class Image
+{
+public:
+	Image(Device &device, unsigned width, unsigned height, VkFormat format, const std::string &name);
+	Image(unsigned width, unsigned height, VkFormat format, void *external_ptr);
+	~Image();
+	Image(const Image &) = delete;
+	void operator=(const Image &) = delete;
+
+	const gr_image &get_view() const { return view; }
+	gr_image &get_view() { return view; }
+	unsigned get_width() const { return view.width; }
+	unsigned get_height() const { return view.height; }
+	VkFormat get_format() const { return VkFormat(view.format); }
+	size_t get_size_bytes() const { return size_t(view.pitch_bytes) * view.height; }
+	void *get_device_pointer() const { return view.ptr; }
+	const std::string &get_name() const { return name; }
+
+private:
+	Device *device = nullptr;
+	gr_image view = {};
+	std::string name;
+	bool owned = false;
+};
+using ImageHandle = std::shared_ptr<Image>;
+using ImageView = Image; // callbacks receive HIP::ImageView& where the reference hands out Vulkan::ImageView&
+
+class Buffer
+{
+public:
+	Buffer(Device &device, size_t size, VkBufferUsageFlags usage, const std::string &name);
+	~Buffer();
+	Buffer(const Buffer &) = delete;
+	void operator=(const Buffer &) = delete;
+	void *get_device_pointer() const { return ptr; }
+	size_t get_size() const { return size; }
+	VkBufferUsageFlags get_usage() const { return usage; }
+
+private:
+	Device *device;
+	void *ptr = nullptr;
+	size_t size;
+	VkBufferUsageFlags usage;
+	std::string name;
+};
+using BufferHandle = std::shared_ptr<Buffer>;
+
+// Records work for one pass.  "Recording" is an asynchronous launch on the pass's stream; there is nothing to submit.
+class CommandBuffer
+{
+public:
+	enum class Type { Generic, AsyncCompute, Count };
+	CommandBuffer(Device &device_, void *stream_, Type type_) : device(device_), stream(stream_), type(type_) {}
+	Device &get_device() { return device; }
+	gr_ctx *get_context() const;
+	gr_stream get_stream() const { return stream; }
+	Type get_command_buffer_type() const { return type; }
+
+	// cmd.barrier(...) between dispatches of one pass (e.g. hdr.cpp:356-378): a HIP stream is in-order and kernel
+	// boundaries make writes visible, so this is a no-op kept for call-site parity.
+	void barrier(VkPipelineStageFlags2, VkAccessFlags2, VkPipelineStageFlags2, VkAccessFlags2) {}
+
+	// cmd.update_buffer analogue (clusterer.cpp:1178-1207): async H2D from a pinned staging ring owned by the device.
+	void update_buffer(const Buffer &dst, size_t offset, size_t size, const void *data);
+	void fill_buffer(const Buffer &dst, size_t offset, size_t size);
+	void copy_image(const Image &dst, const Image &src);
+	void clear_image(const Image &dst);
+
+	// Throws std::runtime_error with gr_last_error() when a launcher fails (the reference LOGEs and continues; a
+	// silently wrong frame is worse for an executor that is being validated).
+	void check(int status, const char *what);
+
+private:
+	Device &device;
+	gr_stream stream;
+	Type type;
+};
+
+class Device
+{
+public:
+	explicit Device(int device_index = 0);
+	~Device();
+	Device(const Device &) = delete;
+	void operator=(const Device &) = delete;
+
+	gr_ctx *get_context() const { return ctx; }
+	int get_device_index() const { return index; }
+	gr_stream get_stream(CommandBuffer::Type type) const { return streams[int(type)]; }
+
+	ImageHandle create_image(unsigned width, unsigned height, VkFormat format, const std::string &name);
+	BufferHandle create_buffer(size_t size, VkBufferUsageFlags usage, const std::string &name);
+
+	// Pinned-host staging for update_buffer: N frames in flight, each with its own bump allocator.
+	void *allocate_staging(size_t size);
+	void next_frame_context();
+	void wait_idle();
+
+	size_t get_allocated_bytes() const { return allocated_bytes; }
+	void account_alloc(ptrdiff_t delta) { allocated_bytes += delta; }
+
+private:
+	int index;
+	gr_ctx *ctx = nullptr;
+	gr_stream streams[int(CommandBuffer::Type::Count)] = {};
+	struct StagingFrame
+	{
+		uint8_t *base = nullptr;
+		size_t offset = 0;
+		void *fence = nullptr; // hipEvent_t recorded when the frame's copies were enqueued
+	};
+	static constexpr size_t StagingBytes = 4u << 20;
+	static constexpr unsigned StagingFrames = 4;
+	StagingFrame staging[StagingFrames];
+	unsigned staging_index = 0;
+	size_t allocated_bytes = 0;
+};
+} // namespace HIP

@@ -1,0 +1,244 @@
+#include "clusterer.hpp"
+#include <algorithm>
+#include <cstring>
+
+namespace Granite
+{
+// ---- graph wiring (clusterer.cpp:83-116,1575-1619) -------------------------------------------------------------------
+void LightClusterer::add_render_passes(RenderGraph &graph)
+{
+	BufferInfo att;
+	att.usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_TRANSFER_DST_BIT;
+	auto &pass = graph.add_pass("clustering-bindless", RENDER_GRAPH_QUEUE_COMPUTE_BIT);
+
+	// Always sized for the 4096-light maximum, one bit per light per cell.
+	att.size = resolution_x * resolution_y * (MaxLightsBindless / 8);
+	pass.add_storage_output("cluster-bitmask", att);
+	pass.add_storage_output("cluster-bitmask-decal", att);
+
+	att.size = resolution_z * sizeof(ivec2);
+	pass.add_storage_output("cluster-range", att);
+	pass.add_storage_output("cluster-range-decal", att);
+
+	att.size = GR_TRANSFORMS_SIZE; // sizeof(ClustererBindlessTransforms)
+	pass.add_transfer_output("cluster-transforms", att);
+
+	att.size = GR_CULL_SETUP_BYTES_PER_LIGHT * MaxLightsBindless;
+	pass.add_storage_output("cluster-cull-setup", att);
+
+	att.size = GR_TRANSFORMED_SPOT_BYTES_PER_LIGHT * MaxLightsBindless;
+	pass.add_storage_output("cluster-transformed-spot", att);
+
+	pass.set_build_render_pass([this](HIP::CommandBuffer &cmd) { build_cluster_bindless_gpu(cmd); });
+}
+
+void LightClusterer::setup_render_pass_dependencies(RenderGraph &, RenderPass &target, DependencyFlags dep_flags)
+{
+	if ((dep_flags & RenderPassCreator::LIGHTING_BIT) != 0)
+	{
+		target.add_storage_read_only_input("cluster-bitmask");
+		target.add_storage_read_only_input("cluster-range");
+		target.add_storage_read_only_input("cluster-transforms");
+	}
+}
+
+void LightClusterer::setup_render_pass_resources(RenderGraph &graph)
+{
+	bindless.bitmask_buffer = &graph.get_physical_buffer_resource(graph.get_buffer_resource("cluster-bitmask"));
+	bindless.range_buffer = &graph.get_physical_buffer_resource(graph.get_buffer_resource("cluster-range"));
+	bindless.transforms_buffer = &graph.get_physical_buffer_resource(graph.get_buffer_resource("cluster-transforms"));
+	bindless.transformed_spots = &graph.get_physical_buffer_resource(graph.get_buffer_resource("cluster-transformed-spot"));
+	bindless.cull_data = &graph.get_physical_buffer_resource(graph.get_buffer_resource("cluster-cull-setup"));
+	if (!bindless.light_ranges)
+		bindless.light_ranges = graph.get_device().create_buffer(MaxLightsBindless * sizeof(uvec2), VK_BUFFER_USAGE_STORAGE_BUFFER_BIT,
+		                                                         "cluster-light-ranges");
+}
+
+// ---- per-frame CPU refresh (clusterer.cpp:656-703,781-827,1133-1176; threaded_scene.cpp:141-150) -----------------------
+float LightClusterer::get_z_slice_extent(const RenderContext &ctx) const
+{
+	return std::min(0.5f, ctx.get_render_parameters().z_far / float(resolution_z));
+}
+
+void LightClusterer::refresh(const RenderContext &context_, TaskComposer &)
+{
+	// Visible positional lights, nearest first along the view direction, so that the per-slice [first, last] index
+	// window produced by the z-range kernel is tight.
+	light_sort_cache.clear();
+	if (scene_lights)
+		light_sort_cache = *scene_lights;
+	const vec3 front = context_.get_render_parameters().camera_front;
+	std::stable_sort(light_sort_cache.begin(), light_sort_cache.end(), [&front](const PositionalLightInfo &a, const PositionalLightInfo &b) {
+		return dot(a.transform->get_translation(), front) < dot(b.transform->get_translation(), front);
+	});
+	refresh_bindless_prepare(context_);
+}
+
+void LightClusterer::refresh_bindless_prepare(const RenderContext &context_)
+{
+	memset(bindless.type_mask, 0, sizeof(bindless.type_mask));
+	bindless.lights.clear();
+	bindless.model.clear();
+
+	for (auto &entry : light_sort_cache)
+	{
+		if (bindless.lights.size() >= MaxLightsBindless)
+			break; // lights beyond the bindless maximum are dropped
+		unsigned index = unsigned(bindless.lights.size());
+		if (entry.light->get_type() == PositionalLight::Type::Spot)
+		{
+			auto &spot = static_cast<SpotLight &>(*entry.light);
+			bindless.lights.push_back(spot.get_shader_info(*entry.transform));
+			bindless.model.push_back(spot.build_model_matrix(*entry.transform));
+		}
+		else
+		{
+			auto &point = static_cast<PointLight &>(*entry.light);
+			auto info = point.get_shader_info(*entry.transform);
+			bindless.lights.push_back(info);
+			mat_affine m;
+			m[0] = vec4(info.position[0], info.position[1], info.position[2], 1.0f / info.inv_radius);
+			m[1] = vec4(0.0f);
+			m[2] = vec4(0.0f);
+			bindless.model.push_back(m);
+			bindless.type_mask[index >> 5] |= 1u << (index & 31u);
+		}
+	}
+
+	auto &rp = context_.get_render_parameters();
+	auto &p = bindless.parameters;
+	p = {};
+	p.num_lights = int32_t(bindless.lights.size());
+	p.num_lights_32 = (p.num_lights + 31) / 32;
+	p.clip_scale[0] = rp.projection[0][0];
+	p.clip_scale[1] = -rp.projection[1][1];
+	p.clip_scale[2] = rp.inv_projection[0][0];
+	p.clip_scale[3] = -rp.inv_projection[1][1];
+
+	// translate(0.5, 0.5, 0) * scale(0.5, 0.5, 1) * view_projection, written out per column.
+	for (int c = 0; c < 4; c++)
+	{
+		const vec4 &col = rp.view_projection[c];
+		p.transform[4 * c + 0] = 0.5f * col.x + 0.5f * col.w;
+		p.transform[4 * c + 1] = 0.5f * col.y + 0.5f * col.w;
+		p.transform[4 * c + 2] = col.z;
+		p.transform[4 * c + 3] = col.w;
+	}
+	for (int i = 0; i < 3; i++)
+	{
+		p.camera_front[i] = rp.camera_front[i];
+		p.camera_base[i] = rp.camera_position[i];
+	}
+	p.xy_scale[0] = float(resolution_x);
+	p.xy_scale[1] = float(resolution_y);
+	p.resolution_xy[0] = int32_t(resolution_x);
+	p.resolution_xy[1] = int32_t(resolution_y);
+	p.inv_resolution_xy[0] = 1.0f / float(resolution_x);
+	p.inv_resolution_xy[1] = 1.0f / float(resolution_y);
+	p.z_scale = 1.0f / get_z_slice_extent(context_);
+	p.z_max_index = int32_t(resolution_z) - 1;
+}
+
+uvec2 LightClusterer::compute_uint_range(vec2 range) const
+{
+	float extent = get_z_slice_extent(*context);
+	range = vec2(range.x / extent, range.y / extent);
+	if (range.y < 0.0f)
+		return uvec2(0xffffffffu, 0u);
+	range.x = std::max(range.x, 0.0f);
+	uvec2 urange(uint32_t(range.x), uint32_t(range.y));
+	urange.y = std::min(urange.y, resolution_z - 1);
+	return urange;
+}
+
+// ---- GPU build (clusterer.cpp:1178-1207,1277-1346,1463-1573) ----------------------------------------------------------------
+void LightClusterer::update_bindless_data(HIP::CommandBuffer &cmd)
+{
+	uint32_t count = uint32_t(bindless.parameters.num_lights);
+	cmd.update_buffer(*bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_LIGHTS, count * sizeof(PositionalFragmentInfo), bindless.lights.data());
+	cmd.update_buffer(*bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_MODEL, count * sizeof(mat_affine), bindless.model.data());
+	cmd.update_buffer(*bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_TYPE_MASK, bindless.parameters.num_lights_32 * sizeof(uint32_t),
+	                  bindless.type_mask);
+}
+
+void LightClusterer::update_bindless_mask_buffer_gpu(HIP::CommandBuffer &cmd)
+{
+	uint32_t local_count = uint32_t(bindless.parameters.num_lights);
+	if (local_count == 0)
+		return;
+	auto &rp = context->get_render_parameters();
+	void *transforms = bindless.transforms_buffer->get_device_pointer();
+	void *spots = bindless.transformed_spots->get_device_pointer();
+	void *cull = bindless.cull_data->get_device_pointer();
+
+	gr_push_spot_transform spot_push = {};
+	memcpy(spot_push.vp, rp.view_projection.data(), sizeof(spot_push.vp));
+	for (int i = 0; i < 3; i++)
+	{
+		spot_push.camera_pos[i] = rp.camera_position[i];
+		spot_push.camera_front[i] = rp.camera_front[i];
+	}
+	spot_push.num_lights = local_count;
+	spot_push.z_near = rp.z_near;
+	spot_push.z_far = rp.z_far;
+	cmd.check(gr_cluster_spot_transform(cmd.get_context(), cmd.get_stream(), transforms, spots, &spot_push), "cluster_spot_transform");
+	cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
+	            VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
+
+	gr_push_cluster_setup setup_push = {};
+	memcpy(setup_push.view, rp.view.data(), sizeof(setup_push.view));
+	setup_push.num_lights = local_count;
+	cmd.check(gr_cluster_setup(cmd.get_context(), cmd.get_stream(), transforms, spots, cull, &bindless.parameters, &setup_push), "cluster_setup");
+	cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
+	            VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
+
+	if ((resolution_x & 7) != 0 || (resolution_y & 7) != 0)
+		throw std::logic_error("Cluster resolution must be a multiple of 8 in X and Y.");
+	// MI355X executes wave64 only: this is the SUBGROUPS path with an 8x8 cell tile per wave (clusterer.cpp:1546-1552).
+	cmd.check(gr_cluster_binning(cmd.get_context(), cmd.get_stream(), transforms, cull,
+	                             static_cast<uint32_t *>(bindless.bitmask_buffer->get_device_pointer()), &bindless.parameters),
+	          "cluster_binning");
+}
+
+void LightClusterer::update_bindless_range_buffer_gpu(HIP::CommandBuffer &cmd)
+{
+	uint32_t count = uint32_t(bindless.parameters.num_lights);
+	bindless.volume_index_range.resize(count);
+	for (unsigned i = 0; i < count; i++)
+	{
+		vec2 range;
+		if (bindless_light_is_point(i))
+		{
+			auto &l = bindless.lights[i];
+			range = point_light_z_range(*context, vec3(l.position[0], l.position[1], l.position[2]), 1.0f / l.inv_radius);
+		}
+		else
+			range = spot_light_z_range(*context, bindless.model[i]);
+		bindless.volume_index_range[i] = compute_uint_range(range);
+	}
+	// The kernel must still run with no lights so that the range buffer is cleared to "empty".
+	if (bindless.volume_index_range.empty())
+		bindless.volume_index_range.push_back(uvec2(~0u, 0u));
+
+	if ((resolution_z & 63) != 0)
+		throw std::logic_error("Cluster Z resolution must be a multiple of 64.");
+
+	auto &ranges = bindless.volume_index_range;
+	cmd.update_buffer(*bindless.light_ranges, 0, ranges.size() * sizeof(uvec2), ranges.data());
+	gr_push_z_range push = {};
+	push.num_volumes = uint32_t(ranges.size());
+	push.num_volumes_128 = (push.num_volumes + 127) / 128;
+	push.num_ranges = resolution_z;
+	cmd.check(gr_cluster_z_range(cmd.get_context(), cmd.get_stream(), static_cast<const uint32_t *>(bindless.light_ranges->get_device_pointer()),
+	                             static_cast<uint32_t *>(bindless.range_buffer->get_device_pointer()), &push),
+	          "cluster_z_range");
+}
+
+void LightClusterer::build_cluster_bindless_gpu(HIP::CommandBuffer &cmd)
+{
+	update_bindless_data(cmd);
+	cmd.barrier(VK_PIPELINE_STAGE_2_COPY_BIT, VK_ACCESS_TRANSFER_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
+	update_bindless_mask_buffer_gpu(cmd);
+	update_bindless_range_buffer_gpu(cmd);
+}
+} // namespace Granite

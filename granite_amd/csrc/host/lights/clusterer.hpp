@@ -1,0 +1,110 @@
+// LightClusterer — the bindless clustered-light path of renderer/lights/clusterer.{hpp,cpp} on the HIP executor.
+// Shadows, decals, volumetric diffuse / fog and the legacy (non-bindless) clusterer need scene geometry and are out of
+// scope; the class keeps the RenderPassCreator / PerFrameRefreshable surface used by the hot path.
+#pragma once
+#include <vector>
+#include "../render_graph.hpp"
+#include "../render_context.hpp"
+#include "lights.hpp"
+
+namespace Granite
+{
+using ClustererParametersBindless = gr_cluster_params; // math/render_parameters.hpp:90-108
+static_assert(sizeof(ClustererParametersBindless) == 176, "ClustererParametersBindless must match the std140 UBO.");
+
+struct RenderPassCreator
+{
+	enum DependencyBits
+	{
+		GEOMETRY_BIT = 1 << 0,
+		MATERIAL_BIT = 1 << 1,
+		LIGHTING_BIT = 1 << 2
+	};
+	using DependencyFlags = uint32_t;
+	virtual ~RenderPassCreator() = default;
+	virtual void add_render_passes(RenderGraph &graph) = 0;
+	virtual void set_base_render_context(const RenderContext *context) = 0;
+	virtual void setup_render_pass_dependencies(RenderGraph &graph, RenderPass &target, DependencyFlags dep_flags) = 0;
+	virtual void setup_render_pass_dependencies(RenderGraph &graph) = 0;
+	virtual void setup_render_pass_resources(RenderGraph &graph) = 0;
+};
+
+struct PerFrameRefreshable
+{
+	virtual ~PerFrameRefreshable() = default;
+	virtual void refresh(const RenderContext &context, TaskComposer &composer) = 0;
+};
+
+// One visible positional light: what Scene::gather_visible_positional_lights hands the clusterer
+// (renderer/scene.hpp PositionalLightInfo {light, transform}).
+struct PositionalLightInfo
+{
+	PositionalLight *light;
+	const mat_affine *transform;
+};
+using PositionalLightList = std::vector<PositionalLightInfo>;
+
+class LightClusterer : public RenderPassCreator, public PerFrameRefreshable
+{
+public:
+	enum { MaxLightsBindless = GR_MAX_LIGHTS_BINDLESS, MaxLightsGlobal = 32 };
+
+	void set_resolution(unsigned x, unsigned y, unsigned z)
+	{
+		resolution_x = x;
+		resolution_y = y;
+		resolution_z = z;
+	}
+	// Stand-in for set_scene(): the visible-light list the per-frame refresh gathers from.
+	void set_scene_lights(const PositionalLightList *lights_) { scene_lights = lights_; }
+
+	void add_render_passes(RenderGraph &graph) override;
+	void set_base_render_context(const RenderContext *context_) override { context = context_; }
+	void setup_render_pass_dependencies(RenderGraph &graph, RenderPass &target, DependencyFlags dep_flags) override;
+	void setup_render_pass_dependencies(RenderGraph &) override {}
+	void setup_render_pass_resources(RenderGraph &graph) override;
+	void refresh(const RenderContext &context, TaskComposer &composer) override;
+
+	const ClustererParametersBindless &get_cluster_parameters_bindless() const { return bindless.parameters; }
+	const HIP::Buffer *get_cluster_transform_buffer() const { return bindless.transforms_buffer; }
+	const HIP::Buffer *get_cluster_bitmask_buffer() const { return bindless.bitmask_buffer; }
+	const HIP::Buffer *get_cluster_range_buffer() const { return bindless.range_buffer; }
+	bool clusterer_has_volumetric_diffuse() const { return false; }
+
+	// Introspection for the parity tests: CPU-side packed state of the last refresh.
+	const std::vector<PositionalFragmentInfo> &get_packed_lights() const { return bindless.lights; }
+	const std::vector<mat_affine> &get_packed_models() const { return bindless.model; }
+	const uint32_t *get_type_mask() const { return bindless.type_mask; }
+	const std::vector<uvec2> &get_volume_index_range() const { return bindless.volume_index_range; }
+
+private:
+	const RenderContext *context = nullptr;
+	const PositionalLightList *scene_lights = nullptr;
+	unsigned resolution_x = 64, resolution_y = 32, resolution_z = 16; // clusterer.hpp:127; the viewer sets 128x64x4096
+	PositionalLightList light_sort_cache;
+
+	struct
+	{
+		ClustererParametersBindless parameters = {};
+		std::vector<PositionalFragmentInfo> lights;
+		std::vector<mat_affine> model;
+		uint32_t type_mask[MaxLightsBindless / 32] = {};
+		std::vector<uvec2> volume_index_range;
+		const HIP::Buffer *bitmask_buffer = nullptr;
+		const HIP::Buffer *range_buffer = nullptr;
+		const HIP::Buffer *transforms_buffer = nullptr;
+		const HIP::Buffer *transformed_spots = nullptr;
+		const HIP::Buffer *cull_data = nullptr;
+		HIP::BufferHandle light_ranges; // uvec2[MaxLightsBindless] upload target for the z-range kernel
+	} bindless;
+
+	float get_z_slice_extent(const RenderContext &ctx) const;
+	uvec2 compute_uint_range(vec2 range) const;
+	bool bindless_light_is_point(unsigned index) const { return (bindless.type_mask[index >> 5] & (1u << (index & 31))) != 0; }
+	void refresh_bindless_prepare(const RenderContext &context);
+	void build_cluster_bindless_gpu(HIP::CommandBuffer &cmd);
+	void update_bindless_data(HIP::CommandBuffer &cmd);
+	void update_bindless_mask_buffer_gpu(HIP::CommandBuffer &cmd);
+	void update_bindless_range_buffer_gpu(HIP::CommandBuffer &cmd);
+};
+} // namespace Granite

@@ -1,0 +1,263 @@
+// renderer/post/hdr.cpp restated on the HIP executor: identical pass / resource names, formats, size classes and push
+// constants; each recorded dispatch or full-screen quad becomes one C-ABI kernel launch.
+#include "hdr.hpp"
+#include <cmath>
+
+namespace Granite
+{
+namespace
+{
+const gr_luminance_data *luminance_ptr(RenderGraph &graph, const RenderBufferResource *res)
+{
+	return res ? static_cast<const gr_luminance_data *>(graph.get_physical_buffer_resource(*res).get_device_pointer()) : nullptr;
+}
+
+// luminance_build_compute / luminance_build_render_pass (hdr.cpp:35-98)
+void record_luminance(HIP::CommandBuffer &cmd, const FrameParameters &frame, RenderGraph &graph, const RenderBufferResource &lum,
+                      const RenderTextureResource &d3)
+{
+	auto &input = graph.get_physical_texture_resource(d3);
+	auto &output = graph.get_physical_buffer_resource(lum);
+	gr_push_luminance push = {};
+	push.size[0] = input.get_width() / 2;
+	push.size[1] = input.get_height() / 2;
+	push.lerp = float(1.0 - std::pow(0.5, frame.frame_time));
+	push.min_loglum = -3.0f;
+	push.max_loglum = 2.0f;
+	cmd.check(gr_luminance(cmd.get_context(), cmd.get_stream(), &input.get_view(),
+	                       static_cast<gr_luminance_data *>(output.get_device_pointer()), &push),
+	          "luminance");
+}
+
+// bloom_threshold_build_compute / _render_pass (hdr.cpp:100-144)
+void record_threshold(HIP::CommandBuffer &cmd, RenderGraph &graph, const RenderTextureResource &threshold, const RenderTextureResource &hdr,
+                      const RenderBufferResource *ubo)
+{
+	auto &output = graph.get_physical_texture_resource(threshold);
+	auto &input = graph.get_physical_texture_resource(hdr);
+	gr_push_bloom_threshold push = {};
+	push.threads[0] = output.get_width();
+	push.threads[1] = output.get_height();
+	push.inv_output_size[0] = 1.0f / float(push.threads[0]);
+	push.inv_output_size[1] = 1.0f / float(push.threads[1]);
+	cmd.check(gr_bloom_threshold(cmd.get_context(), cmd.get_stream(), &input.get_view(), &output.get_view(), luminance_ptr(graph, ubo), &push),
+	          "bloom_threshold");
+}
+
+// bloom_downsample_build_compute / _render_pass (hdr.cpp:146-187,218-270)
+void record_downsample(HIP::CommandBuffer &cmd, const FrameParameters &frame, RenderGraph &graph, const RenderTextureResource &output_res,
+                       const RenderTextureResource &input_res, const RenderTextureResource *feedback)
+{
+	auto &output = graph.get_physical_texture_resource(output_res);
+	auto &input = graph.get_physical_texture_resource(input_res);
+	HIP::ImageView *history = feedback ? graph.get_physical_history_texture_resource(*feedback) : nullptr; // null on frame 0
+
+	gr_push_bloom_downsample push = {};
+	push.threads[0] = output.get_width();
+	push.threads[1] = output.get_height();
+	push.inv_output_size[0] = 1.0f / float(push.threads[0]);
+	push.inv_output_size[1] = 1.0f / float(push.threads[1]);
+	push.inv_input_size[0] = 1.0f / float(input.get_width());
+	push.inv_input_size[1] = 1.0f / float(input.get_height());
+	push.lerp = float(1.0 - std::pow(0.001, frame.frame_time));
+	cmd.check(gr_bloom_downsample(cmd.get_context(), cmd.get_stream(), &input.get_view(), &output.get_view(),
+	                              history ? &history->get_view() : nullptr, &push),
+	          "bloom_downsample");
+}
+
+// bloom_upsample_build_compute / _render_pass (hdr.cpp:189-216,272-281)
+void record_upsample(HIP::CommandBuffer &cmd, RenderGraph &graph, const RenderTextureResource &output_res, const RenderTextureResource &input_res)
+{
+	auto &output = graph.get_physical_texture_resource(output_res);
+	auto &input = graph.get_physical_texture_resource(input_res);
+	gr_push_bloom_upsample push = {};
+	push.threads[0] = output.get_width();
+	push.threads[1] = output.get_height();
+	push.inv_output_size[0] = 1.0f / float(push.threads[0]);
+	push.inv_output_size[1] = 1.0f / float(push.threads[1]);
+	push.inv_input_size[0] = 1.0f / float(input.get_width());
+	push.inv_input_size[1] = 1.0f / float(input.get_height());
+	cmd.check(gr_bloom_upsample(cmd.get_context(), cmd.get_stream(), &input.get_view(), &output.get_view(), &push), "bloom_upsample");
+}
+
+// tonemap_build_render_pass (hdr.cpp:283-306)
+void record_tonemap(RenderPass &pass, HIP::CommandBuffer &cmd, const RenderTextureResource &hdr_res, const RenderTextureResource &bloom_res,
+                    const RenderBufferResource *ubo, const HDRDynamicExposureInterface *iface)
+{
+	auto &graph = pass.get_graph();
+	auto &hdr = graph.get_physical_texture_resource(hdr_res);
+	auto &bloom = graph.get_physical_texture_resource(bloom_res);
+	auto &output = graph.get_physical_texture_resource(*pass.get_color_outputs()[0]);
+	gr_push_tonemap push = {iface ? iface->get_exposure() : 1.0f};
+	cmd.check(gr_tonemap(cmd.get_context(), cmd.get_stream(), &hdr.get_view(), &bloom.get_view(), &output.get_view(), luminance_ptr(graph, ubo),
+	                     &push),
+	          "tonemap");
+}
+
+AttachmentInfo bloom_level_info(const std::string &input, float scale)
+{
+	AttachmentInfo info;
+	info.format = VK_FORMAT_R16G16B16A16_SFLOAT;
+	info.size_x = scale;
+	info.size_y = scale;
+	info.size_class = SizeClass::InputRelative;
+	info.size_relative_name = input;
+	info.aux_usage = VK_IMAGE_USAGE_SAMPLED_BIT;
+	return info;
+}
+} // namespace
+
+void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &frame, const std::string &input, const std::string &output,
+                                   const HDROptions &options, const HDRDynamicExposureInterface *iface)
+{
+	BufferInfo buffer_info;
+	buffer_info.size = 3 * sizeof(float);
+	buffer_info.usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_UNIFORM_BUFFER_BIT;
+
+	auto &bloom_pass = graph.add_pass("bloom-compute", RenderGraph::get_default_compute_queue());
+	auto &t = bloom_pass.add_storage_texture_output("threshold", bloom_level_info(input, 0.5f));
+	auto &d0 = bloom_pass.add_storage_texture_output("downsample-0", bloom_level_info(input, 0.25f));
+	auto &u0 = bloom_pass.add_storage_texture_output("upsample-0", bloom_level_info(input, 0.25f));
+	auto &d1 = bloom_pass.add_storage_texture_output("downsample-1", bloom_level_info(input, 0.125f));
+	auto &u1 = bloom_pass.add_storage_texture_output("upsample-1", bloom_level_info(input, 0.125f));
+	auto &d2 = bloom_pass.add_storage_texture_output("downsample-2", bloom_level_info(input, 0.0625f));
+	auto &u2 = bloom_pass.add_storage_texture_output("upsample-2", bloom_level_info(input, 0.0625f));
+	auto &d3 = bloom_pass.add_storage_texture_output("downsample-3", bloom_level_info(input, 0.03125f));
+
+	const RenderBufferResource *lum = nullptr;
+	if (options.dynamic_exposure)
+		lum = &bloom_pass.add_storage_output("average-luminance", buffer_info);
+
+	auto &hdr = bloom_pass.add_texture_input(input);
+	bloom_pass.add_history_input("downsample-3");
+
+	// Recorded order = hdr.cpp:354-379.  The threshold reads LAST frame's exposure (same buffer, updated later in this
+	// pass); cmd.barrier() between dispatches is stream order here.
+	bloom_pass.set_build_render_pass([&graph, &frame, &t, &d0, &d1, &d2, &d3, &u0, &u1, &u2, &hdr, ubo = lum](HIP::CommandBuffer &cmd) {
+		const auto compute_to_compute = [&cmd]() {
+			cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
+			            VK_ACCESS_2_SHADER_SAMPLED_READ_BIT);
+		};
+		record_threshold(cmd, graph, t, hdr, ubo);
+		compute_to_compute();
+		record_downsample(cmd, frame, graph, d0, t, nullptr);
+		compute_to_compute();
+		record_downsample(cmd, frame, graph, d1, d0, nullptr);
+		compute_to_compute();
+		record_downsample(cmd, frame, graph, d2, d1, nullptr);
+		compute_to_compute();
+		record_downsample(cmd, frame, graph, d3, d2, &d3);
+		compute_to_compute();
+		if (ubo)
+			record_luminance(cmd, frame, graph, *ubo, d3);
+		record_upsample(cmd, graph, u2, d3);
+		compute_to_compute();
+		record_upsample(cmd, graph, u1, u2);
+		compute_to_compute();
+		record_upsample(cmd, graph, u0, u1);
+	});
+
+	{
+		AttachmentInfo tonemap_info;
+		tonemap_info.flags |= ATTACHMENT_INFO_SUPPORTS_PREROTATE_BIT;
+		tonemap_info.size_class = SizeClass::InputRelative;
+		tonemap_info.size_relative_name = input;
+		auto &tonemap = graph.add_pass("tonemap", RenderGraph::get_default_post_graphics_queue());
+		tonemap.add_color_output(output, tonemap_info);
+		auto &hdr_res = tonemap.add_texture_input(input);
+		auto &bloom_res = tonemap.add_texture_input("upsample-0");
+		const RenderBufferResource *ubo_res = nullptr;
+		if (options.dynamic_exposure)
+			ubo_res = &tonemap.add_uniform_input("average-luminance");
+		tonemap.set_build_render_pass([&tonemap, &hdr_res, &bloom_res, iface, ubo = ubo_res](HIP::CommandBuffer &cmd) {
+			record_tonemap(tonemap, cmd, hdr_res, bloom_res, ubo, iface);
+		});
+	}
+}
+
+void setup_hdr_postprocess(RenderGraph &graph, const FrameParameters &frame, const std::string &input, const std::string &output,
+                           const HDROptions &options, const HDRDynamicExposureInterface *iface)
+{
+	BufferInfo buffer_info;
+	buffer_info.size = 3 * sizeof(float);
+	buffer_info.usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT | VK_BUFFER_USAGE_UNIFORM_BUFFER_BIT;
+
+	if (options.dynamic_exposure)
+	{
+		// "average-luminance" has no writer inside a frame: last frame's value, read by the threshold pass and then
+		// read-modify-written into its alias "average-luminance-updated" (hdr.cpp:411-431).
+		graph.get_buffer_resource("average-luminance").set_buffer_info(buffer_info);
+		auto &adapt_pass = graph.add_pass("adapt-luminance", RenderGraph::get_default_compute_queue());
+		auto &output_res = adapt_pass.add_storage_output("average-luminance-updated", buffer_info, "average-luminance");
+		auto &input_res = adapt_pass.add_texture_input("bloom-downsample-3");
+		adapt_pass.set_build_render_pass([&graph, &frame, &output_res, &input_res](HIP::CommandBuffer &cmd) {
+			record_luminance(cmd, frame, graph, output_res, input_res);
+		});
+	}
+
+	{
+		auto &threshold = graph.add_pass("bloom-threshold", RenderGraph::get_default_post_graphics_queue());
+		auto info = bloom_level_info(input, 0.5f);
+		info.aux_usage = 0;
+		auto &out = threshold.add_color_output("threshold", info);
+		auto &input_res = threshold.add_texture_input(input);
+		const RenderBufferResource *ubo_res = nullptr;
+		if (options.dynamic_exposure)
+			ubo_res = &threshold.add_uniform_input("average-luminance");
+		threshold.set_build_render_pass([&graph, &out, &input_res, ubo = ubo_res](HIP::CommandBuffer &cmd) {
+			record_threshold(cmd, graph, out, input_res, ubo);
+		});
+	}
+
+	struct Level
+	{
+		const char *pass_name;
+		const char *source;
+		float scale;
+		bool upsample;
+		bool feedback;
+	};
+	static const Level levels[] = {
+		{"bloom-downsample-0", "threshold", 0.25f, false, false},
+		{"bloom-downsample-1", "bloom-downsample-0", 0.125f, false, false},
+		{"bloom-downsample-2", "bloom-downsample-1", 0.0625f, false, false},
+		{"bloom-downsample-3", "bloom-downsample-2", 0.03125f, false, true},
+		{"bloom-upsample-0", "bloom-downsample-3", 0.0625f, true, false},
+		{"bloom-upsample-1", "bloom-upsample-0", 0.125f, true, false},
+		{"bloom-upsample-2", "bloom-upsample-1", 0.25f, true, false},
+	};
+	for (auto &level : levels)
+	{
+		auto &pass = graph.add_pass(level.pass_name, RenderGraph::get_default_post_graphics_queue());
+		auto info = bloom_level_info(input, level.scale);
+		info.aux_usage = 0;
+		auto &out = pass.add_color_output(level.pass_name, info);
+		auto &in = pass.add_texture_input(level.source);
+		RenderTextureResource *feedback = level.feedback ? &pass.add_history_input(level.pass_name) : nullptr;
+		if (level.upsample)
+			pass.set_build_render_pass([&graph, &out, &in](HIP::CommandBuffer &cmd) { record_upsample(cmd, graph, out, in); });
+		else
+			pass.set_build_render_pass([&graph, &frame, &out, &in, feedback](HIP::CommandBuffer &cmd) {
+				record_downsample(cmd, frame, graph, out, in, feedback);
+			});
+		// Colour outputs without an input are LOAD_OP_CLEAR candidates in the reference; these quads overwrite every
+		// pixel, so no clear is requested.
+	}
+
+	{
+		AttachmentInfo tonemap_info;
+		tonemap_info.size_class = SizeClass::InputRelative;
+		tonemap_info.size_relative_name = input;
+		auto &tonemap = graph.add_pass("tonemap", RenderGraph::get_default_post_graphics_queue());
+		tonemap.add_color_output(output, tonemap_info);
+		auto &hdr_res = tonemap.add_texture_input(input);
+		auto &bloom_res = tonemap.add_texture_input("bloom-upsample-2");
+		const RenderBufferResource *ubo_res = nullptr;
+		if (options.dynamic_exposure)
+			ubo_res = &tonemap.add_uniform_input("average-luminance-updated");
+		tonemap.set_build_render_pass([&tonemap, &hdr_res, &bloom_res, iface, ubo = ubo_res](HIP::CommandBuffer &cmd) {
+			record_tonemap(tonemap, cmd, hdr_res, bloom_res, ubo, iface);
+		});
+	}
+}
+} // namespace Granite

@@ -1,0 +1,1036 @@
+// Granite::RenderGraph on HIP streams — see render_graph.hpp for what is kept from / dropped against
+// renderer/render_graph.cpp.  Reference line numbers are cited per function.
+#include "render_graph.hpp"
+#include <hip/hip_runtime_api.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <sstream>
+
+namespace Granite
+{
+static constexpr RenderGraphQueueFlags compute_queues = RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT | RENDER_GRAPH_QUEUE_COMPUTE_BIT;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RenderPass declarations (render_graph.cpp:87-421).  Each call records: the resource's queue set, which passes read /
+// write it, its usage bits, and the pass-side slot it occupies.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename Res>
+static Res &declare_read(Res &res, RenderGraphQueueFlagBits queue, unsigned pass)
+{
+	res.add_queue(queue);
+	res.read_in_pass(pass);
+	return res;
+}
+
+template <typename Res>
+static Res &declare_write(Res &res, RenderGraphQueueFlagBits queue, unsigned pass)
+{
+	res.add_queue(queue);
+	res.written_in_pass(pass);
+	return res;
+}
+
+RenderTextureResource &RenderPass::add_attachment_input(const std::string &name)
+{
+	auto &res = declare_read(graph.get_texture_resource(name), queue, index);
+	res.add_image_usage(VK_IMAGE_USAGE_INPUT_ATTACHMENT_BIT);
+	attachments_inputs.push_back(&res);
+	return res;
+}
+
+RenderTextureResource &RenderPass::add_history_input(const std::string &name)
+{
+	// Not a read in this frame's dependency sense: it names LAST frame's contents (render_graph.cpp:97-105).
+	auto &res = graph.get_texture_resource(name);
+	res.add_queue(queue);
+	res.add_image_usage(VK_IMAGE_USAGE_SAMPLED_BIT);
+	history_inputs.push_back(&res);
+	return res;
+}
+
+RenderBufferResource &RenderPass::add_generic_buffer_input(const std::string &name, VkPipelineStageFlags2 stages, VkAccessFlags2 access,
+                                                           VkBufferUsageFlags usage)
+{
+	auto &res = declare_read(graph.get_buffer_resource(name), queue, index);
+	res.add_buffer_usage(usage);
+	AccessedBufferResource acc;
+	acc.buffer = &res;
+	acc.access = access;
+	acc.stages = stages;
+	generic_buffer.push_back(acc);
+	return res;
+}
+
+RenderBufferResource &RenderPass::add_vertex_buffer_input(const std::string &name)
+{
+	return add_generic_buffer_input(name, 0, 0, VK_BUFFER_USAGE_VERTEX_BUFFER_BIT);
+}
+
+RenderBufferResource &RenderPass::add_index_buffer_input(const std::string &name)
+{
+	return add_generic_buffer_input(name, 0, 0, VK_BUFFER_USAGE_INDEX_BUFFER_BIT);
+}
+
+RenderBufferResource &RenderPass::add_indirect_buffer_input(const std::string &name)
+{
+	return add_generic_buffer_input(name, 0, 0, VK_BUFFER_USAGE_INDIRECT_BUFFER_BIT);
+}
+
+static VkPipelineStageFlags2 default_stage(RenderGraphQueueFlagBits queue, VkPipelineStageFlags2 stages)
+{
+	if (stages != 0)
+		return stages;
+	return (queue & compute_queues) != 0 ? VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT : VK_PIPELINE_STAGE_FRAGMENT_SHADER_BIT;
+}
+
+RenderBufferResource &RenderPass::add_uniform_input(const std::string &name, VkPipelineStageFlags2 stages)
+{
+	return add_generic_buffer_input(name, default_stage(queue, stages), VK_ACCESS_UNIFORM_READ_BIT, VK_BUFFER_USAGE_UNIFORM_BUFFER_BIT);
+}
+
+RenderBufferResource &RenderPass::add_storage_read_only_input(const std::string &name, VkPipelineStageFlags2 stages)
+{
+	return add_generic_buffer_input(name, default_stage(queue, stages), VK_ACCESS_2_SHADER_STORAGE_READ_BIT,
+	                                VK_BUFFER_USAGE_STORAGE_BUFFER_BIT);
+}
+
+RenderBufferResource &RenderPass::add_storage_output(const std::string &name, const BufferInfo &info, const std::string &input)
+{
+	auto &res = declare_write(graph.get_buffer_resource(name), queue, index);
+	res.set_buffer_info(info);
+	res.add_buffer_usage(VK_BUFFER_USAGE_STORAGE_BUFFER_BIT);
+	storage_outputs.push_back(&res);
+	RenderBufferResource *rmw = nullptr;
+	if (!input.empty())
+	{
+		rmw = &declare_read(graph.get_buffer_resource(input), queue, index);
+		rmw->add_buffer_usage(VK_BUFFER_USAGE_STORAGE_BUFFER_BIT);
+	}
+	storage_inputs.push_back(rmw);
+	return res;
+}
+
+RenderBufferResource &RenderPass::add_transfer_output(const std::string &name, const BufferInfo &info)
+{
+	auto &res = declare_write(graph.get_buffer_resource(name), queue, index);
+	res.set_buffer_info(info);
+	res.add_buffer_usage(VK_BUFFER_USAGE_TRANSFER_DST_BIT);
+	transfer_outputs.push_back(&res);
+	return res;
+}
+
+RenderTextureResource &RenderPass::add_texture_input(const std::string &name, VkPipelineStageFlags2 stages)
+{
+	auto &res = declare_read(graph.get_texture_resource(name), queue, index);
+	res.add_image_usage(VK_IMAGE_USAGE_SAMPLED_BIT);
+	// Duplicate add_texture_input of one resource is allowed and collapses (render_graph.cpp:208-214).
+	for (auto &acc : generic_texture)
+		if (acc.texture == &res)
+			return res;
+	AccessedTextureResource acc;
+	acc.texture = &res;
+	acc.access = VK_ACCESS_2_SHADER_SAMPLED_READ_BIT;
+	acc.stages = default_stage(queue, stages);
+	generic_texture.push_back(acc);
+	return res;
+}
+
+RenderTextureResource &RenderPass::add_resolve_output(const std::string &name, const AttachmentInfo &info)
+{
+	auto &res = declare_write(graph.get_texture_resource(name), queue, index);
+	res.set_attachment_info(info);
+	res.add_image_usage(VK_IMAGE_USAGE_COLOR_ATTACHMENT_BIT);
+	resolve_outputs.push_back(&res);
+	return res;
+}
+
+RenderTextureResource &RenderPass::add_color_output(const std::string &name, const AttachmentInfo &info, const std::string &input)
+{
+	auto &res = declare_write(graph.get_texture_resource(name), queue, index);
+	res.set_attachment_info(info);
+	res.add_image_usage(VK_IMAGE_USAGE_COLOR_ATTACHMENT_BIT);
+	if (info.levels != 1)
+		res.add_image_usage(VK_IMAGE_USAGE_TRANSFER_DST_BIT | VK_IMAGE_USAGE_TRANSFER_SRC_BIT);
+	color_outputs.push_back(&res);
+	RenderTextureResource *rmw = nullptr;
+	if (!input.empty())
+	{
+		rmw = &declare_read(graph.get_texture_resource(input), queue, index);
+		rmw->add_image_usage(VK_IMAGE_USAGE_COLOR_ATTACHMENT_BIT);
+	}
+	color_inputs.push_back(rmw);
+	color_scale_inputs.push_back(nullptr);
+	return res;
+}
+
+RenderTextureResource &RenderPass::add_storage_texture_output(const std::string &name, const AttachmentInfo &info, const std::string &input)
+{
+	auto &res = declare_write(graph.get_texture_resource(name), queue, index);
+	res.set_attachment_info(info);
+	res.add_image_usage(VK_IMAGE_USAGE_STORAGE_BIT);
+	storage_texture_outputs.push_back(&res);
+	RenderTextureResource *rmw = nullptr;
+	if (!input.empty())
+	{
+		rmw = &declare_read(graph.get_texture_resource(input), queue, index);
+		rmw->add_image_usage(VK_IMAGE_USAGE_STORAGE_BIT);
+	}
+	storage_texture_inputs.push_back(rmw);
+	return res;
+}
+
+void RenderTextureResource::become_write_alias_of(const RenderTextureResource &other, unsigned writer_pass)
+{
+	info = other.info;
+	image_usage = other.image_usage;
+	reset_pass_sets(other.get_used_queues());
+	written_in_pass(writer_pass);
+}
+
+void RenderPass::add_fake_resource_write_alias(const std::string &from, const std::string &to)
+{
+	auto &from_res = graph.get_texture_resource(from);
+	auto &to_res = graph.get_texture_resource(to);
+	to_res.become_write_alias_of(from_res, index);
+	fake_resource_alias.emplace_back(&from_res, &to_res);
+}
+
+RenderTextureResource &RenderPass::set_depth_stencil_output(const std::string &name, const AttachmentInfo &info)
+{
+	auto &res = declare_write(graph.get_texture_resource(name), queue, index);
+	res.set_attachment_info(info);
+	res.add_image_usage(VK_IMAGE_USAGE_DEPTH_STENCIL_ATTACHMENT_BIT);
+	depth_stencil_output = &res;
+	return res;
+}
+
+RenderTextureResource &RenderPass::set_depth_stencil_input(const std::string &name)
+{
+	auto &res = declare_read(graph.get_texture_resource(name), queue, index);
+	res.add_image_usage(VK_IMAGE_USAGE_DEPTH_STENCIL_ATTACHMENT_BIT);
+	depth_stencil_input = &res;
+	return res;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RenderGraph: name tables (render_graph.cpp:450-546)
+// ---------------------------------------------------------------------------------------------------------------------
+RenderTextureResource &RenderGraph::get_texture_resource(const std::string &name)
+{
+	auto itr = resource_to_index.find(name);
+	if (itr != resource_to_index.end())
+	{
+		if (resources[itr->second]->get_type() != RenderResource::Type::Texture)
+			throw std::logic_error("Resource is not a texture: " + name);
+		return static_cast<RenderTextureResource &>(*resources[itr->second]);
+	}
+	unsigned index = unsigned(resources.size());
+	resources.emplace_back(new RenderTextureResource(index));
+	resources.back()->set_name(name);
+	resource_to_index[name] = index;
+	return static_cast<RenderTextureResource &>(*resources.back());
+}
+
+RenderBufferResource &RenderGraph::get_buffer_resource(const std::string &name)
+{
+	auto itr = resource_to_index.find(name);
+	if (itr != resource_to_index.end())
+	{
+		if (resources[itr->second]->get_type() != RenderResource::Type::Buffer)
+			throw std::logic_error("Resource is not a buffer: " + name);
+		return static_cast<RenderBufferResource &>(*resources[itr->second]);
+	}
+	unsigned index = unsigned(resources.size());
+	resources.emplace_back(new RenderBufferResource(index));
+	resources.back()->set_name(name);
+	resource_to_index[name] = index;
+	return static_cast<RenderBufferResource &>(*resources.back());
+}
+
+RenderPass &RenderGraph::add_pass(const std::string &name, RenderGraphQueueFlagBits queue)
+{
+	auto itr = pass_to_index.find(name);
+	if (itr != pass_to_index.end())
+		return *passes[itr->second]; // idempotent by name
+	unsigned index = unsigned(passes.size());
+	passes.emplace_back(new RenderPass(*this, index, queue));
+	passes.back()->set_name(name);
+	pass_to_index[name] = index;
+	return *passes.back();
+}
+
+RenderPass *RenderGraph::find_pass(const std::string &name)
+{
+	auto itr = pass_to_index.find(name);
+	return itr != pass_to_index.end() ? passes[itr->second].get() : nullptr;
+}
+
+void RenderGraph::set_backbuffer_source(const std::string &name)
+{
+	backbuffer_source = name;
+}
+
+HIP::BufferHandle RenderGraph::consume_persistent_physical_buffer_resource(unsigned index) const
+{
+	if (index >= physical_buffers.size())
+		return {};
+	return physical_buffers[index];
+}
+
+void RenderGraph::install_persistent_physical_buffer_resource(unsigned index, HIP::BufferHandle buffer)
+{
+	if (index >= physical_buffers.size())
+		throw std::logic_error("Out of range.");
+	physical_buffers[index] = std::move(buffer);
+}
+
+void RenderGraph::reset()
+{
+	passes.clear();
+	resources.clear();
+	pass_to_index.clear();
+	resource_to_index.clear();
+	pass_stack.clear();
+	physical_dimensions.clear();
+	physical_attachments.clear();
+	physical_buffers.clear();
+	physical_image_attachments.clear();
+	physical_history_image_attachments.clear();
+	physical_image_has_history.clear();
+	swapchain_physical_index = RenderResource::Unused;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Size resolution (render_graph.cpp:3113-3191)
+// ---------------------------------------------------------------------------------------------------------------------
+ResourceDimensions RenderGraph::get_resource_dimensions(const RenderBufferResource &resource) const
+{
+	ResourceDimensions dim;
+	auto &info = resource.get_buffer_info();
+	dim.buffer_info = info;
+	dim.buffer_info.usage |= resource.get_buffer_usage();
+	dim.flags |= info.flags;
+	dim.name = resource.get_name();
+	return dim;
+}
+
+static unsigned scaled_extent(unsigned base, float scale)
+{
+	// ceil(base * scale) in fp32 like muglm::ceil(info.size_x * dim), at least 1.
+	return std::max(unsigned(std::ceil(float(base) * scale)), 1u);
+}
+
+ResourceDimensions RenderGraph::get_resource_dimensions(const RenderTextureResource &resource) const
+{
+	ResourceDimensions dim;
+	auto &info = resource.get_attachment_info();
+	dim.layers = info.layers;
+	dim.samples = info.samples;
+	dim.format = info.format;
+	dim.queues = resource.get_used_queues();
+	dim.image_usage = info.aux_usage | resource.get_image_usage();
+	dim.name = resource.get_name();
+	dim.flags = info.flags & ~ATTACHMENT_INFO_SUPPORTS_PREROTATE_BIT; // no pre-rotation off a swapchain-less device
+
+	switch (info.size_class)
+	{
+	case SizeClass::SwapchainRelative:
+		dim.width = scaled_extent(swapchain_dimensions.width, info.size_x);
+		dim.height = scaled_extent(swapchain_dimensions.height, info.size_y);
+		dim.depth = std::max(unsigned(std::ceil(info.size_z)), 1u);
+		break;
+
+	case SizeClass::Absolute:
+		dim.width = std::max(unsigned(info.size_x), 1u);
+		dim.height = std::max(unsigned(info.size_y), 1u);
+		dim.depth = std::max(unsigned(info.size_z), 1u);
+		break;
+
+	case SizeClass::InputRelative:
+	{
+		auto itr = resource_to_index.find(info.size_relative_name);
+		if (itr == resource_to_index.end())
+			throw std::logic_error("Resource does not exist.");
+		auto &input = static_cast<RenderTextureResource &>(*resources[itr->second]);
+		auto input_dim = get_resource_dimensions(input);
+		dim.width = scaled_extent(input_dim.width, info.size_x);
+		dim.height = scaled_extent(input_dim.height, info.size_y);
+		dim.depth = std::max(unsigned(std::ceil(float(input_dim.depth) * info.size_z)), 1u);
+		break;
+	}
+	}
+
+	if (dim.format == VK_FORMAT_UNDEFINED)
+		dim.format = swapchain_dimensions.format;
+
+	unsigned max_dim = std::max(std::max(dim.width, dim.height), dim.depth);
+	unsigned full_chain = 0;
+	for (; max_dim; max_dim >>= 1)
+		full_chain++;
+	dim.levels = std::min(full_chain, info.levels == 0 ? ~0u : info.levels);
+	return dim;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Validation (render_graph.cpp:562-622)
+// ---------------------------------------------------------------------------------------------------------------------
+void RenderGraph::validate_passes()
+{
+	for (auto &pass_ptr : passes)
+	{
+		auto &pass = *pass_ptr;
+		if (pass.get_color_inputs().size() != pass.get_color_outputs().size())
+			throw std::logic_error("Size of color inputs must match color outputs.");
+		if (pass.get_storage_inputs().size() != pass.get_storage_outputs().size())
+			throw std::logic_error("Size of storage inputs must match storage outputs.");
+		if (pass.get_storage_texture_inputs().size() != pass.get_storage_texture_outputs().size())
+			throw std::logic_error("Size of storage texture inputs must match storage texture outputs.");
+		if (!pass.get_resolve_outputs().empty() && pass.get_resolve_outputs().size() != pass.get_color_outputs().size())
+			throw std::logic_error("Must have one resolve output for each color output.");
+
+		for (unsigned i = 0; i < pass.get_color_inputs().size(); i++)
+		{
+			auto *in = pass.get_color_inputs()[i];
+			if (in && get_resource_dimensions(*in) != get_resource_dimensions(*pass.get_color_outputs()[i]))
+				pass.make_color_input_scaled(i);
+		}
+
+		for (unsigned i = 0; i < pass.get_storage_outputs().size(); i++)
+		{
+			auto *in = pass.get_storage_inputs()[i];
+			if (in && pass.get_storage_outputs()[i]->get_buffer_info() != in->get_buffer_info())
+				throw std::logic_error("Doing RMW on a storage buffer, but usage and sizes do not match.");
+		}
+
+		for (unsigned i = 0; i < pass.get_storage_texture_outputs().size(); i++)
+		{
+			auto *in = pass.get_storage_texture_inputs()[i];
+			if (in && get_resource_dimensions(*pass.get_storage_texture_outputs()[i]) != get_resource_dimensions(*in))
+				throw std::logic_error("Doing RMW on a storage texture image, but sizes do not match.");
+		}
+
+		if (pass.get_depth_stencil_input() && pass.get_depth_stencil_output())
+			if (get_resource_dimensions(*pass.get_depth_stencil_input()) != get_resource_dimensions(*pass.get_depth_stencil_output()))
+				throw std::logic_error("Dimension mismatch.");
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Dependency walk (render_graph.cpp:2767-2870)
+// ---------------------------------------------------------------------------------------------------------------------
+void RenderGraph::depend_passes_recursive(const RenderPass &self, const std::unordered_set<unsigned> &written_passes, unsigned stack_count,
+                                          bool no_check, bool ignore_self, bool merge_dependency)
+{
+	if (!no_check && written_passes.empty())
+		throw std::logic_error("No pass exists which writes to resource.");
+	if (stack_count > passes.size())
+		throw std::logic_error("Cycle detected.");
+
+	for (unsigned writer : written_passes)
+	{
+		if (writer == self.get_index())
+			continue;
+		pass_dependencies[self.get_index()].insert(writer);
+		if (merge_dependency)
+			pass_merge_dependencies[self.get_index()].insert(writer);
+	}
+
+	stack_count++;
+	for (unsigned writer : written_passes)
+	{
+		if (writer == self.get_index())
+		{
+			if (ignore_self)
+				continue;
+			throw std::logic_error("Pass depends on itself.");
+		}
+		pass_stack.push_back(writer);
+		traverse_dependencies(*passes[writer], stack_count);
+	}
+}
+
+void RenderGraph::traverse_dependencies(const RenderPass &pass, unsigned stack_count)
+{
+	// Attachment-style inputs first (they were "merge" candidates in the reference; here the flag only feeds the
+	// reorder heuristic so baked orders stay comparable).
+	if (auto *ds = pass.get_depth_stencil_input())
+		depend_passes_recursive(pass, ds->get_write_passes(), stack_count, false, false, true);
+
+	for (auto *input : pass.get_attachment_inputs())
+	{
+		bool self_dependency = pass.get_depth_stencil_output() == input;
+		auto &outs = pass.get_color_outputs();
+		if (std::find(outs.begin(), outs.end(), input) != outs.end())
+			self_dependency = true;
+		if (!self_dependency)
+			depend_passes_recursive(pass, input->get_write_passes(), stack_count, false, false, true);
+	}
+
+	for (auto *input : pass.get_color_inputs())
+		if (input)
+			depend_passes_recursive(pass, input->get_write_passes(), stack_count, false, false, true);
+	for (auto *input : pass.get_color_scale_inputs())
+		if (input)
+			depend_passes_recursive(pass, input->get_write_passes(), stack_count, false, false, false);
+	for (auto &input : pass.get_generic_texture_inputs())
+		depend_passes_recursive(pass, input.texture->get_write_passes(), stack_count, false, false, false);
+
+	for (auto *input : pass.get_storage_inputs())
+	{
+		if (!input)
+			continue;
+		// Feedback buffers may have no writer; readers of the old value must run before this RMW (WAR).
+		depend_passes_recursive(pass, input->get_write_passes(), stack_count, true, false, false);
+		depend_passes_recursive(pass, input->get_read_passes(), stack_count, true, true, false);
+	}
+
+	for (auto *input : pass.get_storage_texture_inputs())
+		if (input)
+			depend_passes_recursive(pass, input->get_write_passes(), stack_count, false, false, false);
+
+	for (auto &input : pass.get_generic_buffer_inputs())
+		depend_passes_recursive(pass, input.buffer->get_write_passes(), stack_count, true, false, false);
+}
+
+bool RenderGraph::depends_on_pass(unsigned dst_pass, unsigned src_pass)
+{
+	if (dst_pass == src_pass)
+		return true;
+	for (unsigned dep : pass_dependencies[dst_pass])
+		if (depends_on_pass(dep, src_pass))
+			return true;
+	return false;
+}
+
+void RenderGraph::filter_passes(std::vector<unsigned> &list)
+{
+	std::unordered_set<unsigned> seen;
+	std::vector<unsigned> unique;
+	unique.reserve(list.size());
+	for (unsigned p : list)
+		if (seen.insert(p).second)
+			unique.push_back(p);
+	list.swap(unique);
+}
+
+// Greedy list scheduling (render_graph.cpp:2872-2977): next pass = the schedulable one that leaves the most already
+// scheduled passes between itself and its nearest dependency (maximises overlap), ties resolved by original order.
+void RenderGraph::reorder_passes(std::vector<unsigned> &flattened)
+{
+	for (unsigned pass_index = 0; pass_index < pass_merge_dependencies.size(); pass_index++)
+	{
+		auto &deps = pass_dependencies[pass_index];
+		for (unsigned merge_dep : pass_merge_dependencies[pass_index])
+			for (unsigned dependee : deps)
+				if (!depends_on_pass(dependee, merge_dep) && merge_dep != dependee)
+					pass_dependencies[merge_dep].insert(dependee);
+	}
+
+	if (flattened.size() <= 2)
+		return;
+
+	std::vector<unsigned> pending;
+	pending.swap(flattened);
+	flattened.reserve(pending.size());
+	auto take = [&](size_t i) {
+		flattened.push_back(pending[i]);
+		pending.erase(pending.begin() + ptrdiff_t(i));
+	};
+	take(0);
+
+	while (!pending.empty())
+	{
+		size_t best = 0;
+		unsigned best_overlap = 0;
+		for (size_t i = 0; i < pending.size(); i++)
+		{
+			unsigned overlap = 0;
+			if (pass_merge_dependencies[pending[i]].count(flattened.back()))
+				overlap = ~0u;
+			else
+			{
+				for (auto itr = flattened.rbegin(); itr != flattened.rend(); ++itr)
+				{
+					if (depends_on_pass(pending[i], *itr))
+						break;
+					overlap++;
+				}
+			}
+			if (overlap <= best_overlap)
+				continue;
+
+			bool blocked = false;
+			for (size_t j = 0; j < i && !blocked; j++)
+				blocked = depends_on_pass(pending[i], pending[j]);
+			if (blocked)
+				continue;
+			best = i;
+			best_overlap = overlap;
+		}
+		take(best);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Physical index assignment (render_graph.cpp:624-952): walk the baked order; first touch allocates a physical slot,
+// RMW outputs take their input's slot, later touches OR in queue/usage bits.
+// ---------------------------------------------------------------------------------------------------------------------
+void RenderGraph::build_physical_resources()
+{
+	unsigned phys_index = 0;
+	physical_dimensions.clear();
+
+	auto touch_texture = [&](RenderTextureResource *res, VkImageUsageFlags extra_usage = 0) {
+		if (res->get_physical_index() == RenderResource::Unused)
+		{
+			physical_dimensions.push_back(get_resource_dimensions(*res));
+			res->set_physical_index(phys_index++);
+		}
+		else
+		{
+			auto &dim = physical_dimensions[res->get_physical_index()];
+			dim.queues |= res->get_used_queues();
+			dim.image_usage |= res->get_image_usage();
+		}
+		physical_dimensions[res->get_physical_index()].image_usage |= extra_usage;
+	};
+	auto touch_buffer = [&](RenderBufferResource *res) {
+		if (res->get_physical_index() == RenderResource::Unused)
+		{
+			physical_dimensions.push_back(get_resource_dimensions(*res));
+			res->set_physical_index(phys_index++);
+		}
+		else
+		{
+			auto &dim = physical_dimensions[res->get_physical_index()];
+			dim.queues |= res->get_used_queues();
+			dim.buffer_info.usage |= res->get_buffer_usage();
+		}
+	};
+	auto alias_output = [&](RenderResource *output, RenderResource *input) {
+		if (output->get_physical_index() == RenderResource::Unused)
+			output->set_physical_index(input->get_physical_index());
+		else if (output->get_physical_index() != input->get_physical_index())
+			throw std::logic_error("Cannot alias resources. Index already claimed.");
+	};
+
+	for (unsigned pass_index : pass_stack)
+	{
+		auto &pass = *passes[pass_index];
+
+		for (auto &input : pass.get_generic_texture_inputs())
+			touch_texture(input.texture);
+		for (auto &input : pass.get_generic_buffer_inputs())
+			touch_buffer(input.buffer);
+		for (auto *input : pass.get_color_scale_inputs())
+			if (input)
+				touch_texture(input, VK_IMAGE_USAGE_SAMPLED_BIT);
+
+		for (unsigned i = 0; i < pass.get_color_inputs().size(); i++)
+			if (auto *input = pass.get_color_inputs()[i])
+			{
+				touch_texture(input);
+				alias_output(pass.get_color_outputs()[i], input);
+			}
+		for (unsigned i = 0; i < pass.get_storage_inputs().size(); i++)
+			if (auto *input = pass.get_storage_inputs()[i])
+			{
+				touch_buffer(input);
+				alias_output(pass.get_storage_outputs()[i], input);
+			}
+		for (unsigned i = 0; i < pass.get_storage_texture_inputs().size(); i++)
+			if (auto *input = pass.get_storage_texture_inputs()[i])
+			{
+				touch_texture(input);
+				alias_output(pass.get_storage_texture_outputs()[i], input);
+			}
+
+		for (auto *output : pass.get_color_outputs())
+			touch_texture(output);
+		for (auto *output : pass.get_resolve_outputs())
+			touch_texture(output);
+		for (auto *output : pass.get_storage_outputs())
+			touch_buffer(output);
+		for (auto *output : pass.get_transfer_outputs())
+			touch_buffer(output);
+		for (auto *output : pass.get_storage_texture_outputs())
+			touch_texture(output);
+
+		auto *ds_output = pass.get_depth_stencil_output();
+		auto *ds_input = pass.get_depth_stencil_input();
+		if (ds_input)
+		{
+			touch_texture(ds_input);
+			if (ds_output)
+			{
+				alias_output(ds_output, ds_input);
+				auto &dim = physical_dimensions[ds_output->get_physical_index()];
+				dim.queues |= ds_output->get_used_queues();
+				dim.image_usage |= ds_output->get_image_usage();
+			}
+		}
+		else if (ds_output)
+			touch_texture(ds_output);
+
+		// Input attachments last so they can pick up the slot of a colour/depth attachment of the same pass.
+		for (auto *input : pass.get_attachment_inputs())
+			touch_texture(input);
+		for (auto &alias : pass.get_fake_resource_aliases())
+			alias.second->set_physical_index(alias.first->get_physical_index());
+	}
+
+	physical_image_has_history.assign(physical_dimensions.size(), false);
+	for (unsigned pass_index : pass_stack)
+		for (auto *history : passes[pass_index]->get_history_inputs())
+		{
+			unsigned phys = history->get_physical_index();
+			if (phys == RenderResource::Unused)
+				throw std::logic_error("History input is used, but it was never written to.");
+			physical_image_has_history[phys] = true;
+		}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bake (render_graph.cpp:2993-3111)
+// ---------------------------------------------------------------------------------------------------------------------
+void RenderGraph::bake()
+{
+	for (auto &pass : passes)
+		pass->setup_dependencies();
+
+	validate_passes();
+
+	auto itr = resource_to_index.find(backbuffer_source);
+	if (itr == resource_to_index.end())
+		throw std::logic_error("Backbuffer source does not exist.");
+
+	pass_stack.clear();
+	pass_dependencies.assign(passes.size(), {});
+	pass_merge_dependencies.assign(passes.size(), {});
+	for (auto &res : resources)
+		res->set_physical_index(RenderResource::Unused);
+
+	auto &backbuffer_resource = *resources[itr->second];
+	if (backbuffer_resource.get_write_passes().empty())
+		throw std::logic_error("No pass exists which writes to resource.");
+
+	for (unsigned writer : backbuffer_resource.get_write_passes())
+		pass_stack.push_back(writer);
+	auto roots = pass_stack;
+	for (unsigned root : roots)
+		traverse_dependencies(*passes[root], 0);
+
+	std::reverse(pass_stack.begin(), pass_stack.end());
+	filter_passes(pass_stack);
+	reorder_passes(pass_stack);
+	build_physical_resources();
+
+	// Backbuffer aliasing (render_graph.cpp:3048-3098): if the resource that feeds the backbuffer has the swapchain's
+	// geometry and format it IS the externally provided swapchain image; otherwise it gets its own image and is copied
+	// (same byte size) at the end of the frame.
+	unsigned backbuffer_phys = backbuffer_resource.get_physical_index();
+	auto &backbuffer_dim = physical_dimensions[backbuffer_phys];
+	bool same_geometry = backbuffer_dim.width == swapchain_dimensions.width && backbuffer_dim.height == swapchain_dimensions.height &&
+	                     backbuffer_dim.format == swapchain_dimensions.format;
+	bool has_history = physical_image_has_history[backbuffer_phys];
+	swapchain_physical_index = (same_geometry && !has_history) ? backbuffer_phys : unsigned(RenderResource::Unused);
+
+	if (device)
+		for (unsigned pass_index : pass_stack)
+			passes[pass_index]->setup(*device);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-frame: attachments (render_graph.cpp:2577-2765)
+// ---------------------------------------------------------------------------------------------------------------------
+void RenderGraph::setup_physical_buffer(HIP::Device &device_, unsigned attachment)
+{
+	auto &att = physical_dimensions[attachment];
+	auto &slot = physical_buffers[attachment];
+	bool reuse = slot && (att.flags & ATTACHMENT_INFO_PERSISTENT_BIT) != 0 && slot->get_size() == att.buffer_info.size &&
+	             (slot->get_usage() & att.buffer_info.usage) == att.buffer_info.usage;
+	if (!reuse)
+		slot = device_.create_buffer(att.buffer_info.size, att.buffer_info.usage, att.name); // zero-initialised
+}
+
+void RenderGraph::setup_physical_image(HIP::Device &device_, unsigned attachment)
+{
+	auto &att = physical_dimensions[attachment];
+	auto &slot = physical_image_attachments[attachment];
+	bool reuse = slot && (att.flags & ATTACHMENT_INFO_PERSISTENT_BIT) != 0 && slot->get_format() == att.format &&
+	             slot->get_width() == att.width && slot->get_height() == att.height;
+	if (!reuse)
+		slot = device_.create_image(att.width, att.height, att.format, att.name);
+	physical_attachments[attachment] = slot.get();
+}
+
+void RenderGraph::setup_attachments(HIP::Device &device_, HIP::ImageView *swapchain)
+{
+	const size_t count = physical_dimensions.size();
+	physical_attachments.assign(count, nullptr);
+	physical_buffers.resize(count);
+	physical_image_attachments.resize(count);
+	physical_history_image_attachments.resize(count);
+	swapchain_attachment = swapchain;
+
+	for (unsigned i = 0; i < count; i++)
+	{
+		// What was rendered last frame becomes this frame's history; the old history image (if any) is recycled as
+		// the new render target.
+		if (physical_image_has_history[i])
+			std::swap(physical_history_image_attachments[i], physical_image_attachments[i]);
+
+		auto &att = physical_dimensions[i];
+		if (att.buffer_info.size != 0)
+			setup_physical_buffer(device_, i);
+		else if (i == swapchain_physical_index && swapchain)
+			physical_attachments[i] = swapchain;
+		else
+			setup_physical_image(device_, i);
+	}
+}
+
+HIP::ImageView &RenderGraph::get_physical_texture_resource(unsigned index)
+{
+	if (index == RenderResource::Unused || index >= physical_attachments.size() || !physical_attachments[index])
+		throw std::logic_error("Physical texture resource is not available (not baked / not set up / culled).");
+	return *physical_attachments[index];
+}
+
+HIP::ImageView *RenderGraph::get_physical_history_texture_resource(unsigned index)
+{
+	if (index == RenderResource::Unused || index >= physical_history_image_attachments.size())
+		return nullptr;
+	return physical_history_image_attachments[index].get();
+}
+
+HIP::Buffer &RenderGraph::get_physical_buffer_resource(unsigned index)
+{
+	if (index == RenderResource::Unused || index >= physical_buffers.size() || !physical_buffers[index])
+		throw std::logic_error("Physical buffer resource is not available (not baked / not set up / culled).");
+	return *physical_buffers[index];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-frame: execution (render_graph.cpp:2183-2575).  Every logical pass is a kernel sequence on the stream of its queue:
+// GRAPHICS and COMPUTE share the generic stream (the reference maps plain compute onto the graphics queue too,
+// render_graph.hpp:219-229); ASYNC_COMPUTE gets its own stream, ordered against the other by events at every switch.
+// ---------------------------------------------------------------------------------------------------------------------
+void *RenderGraph::acquire_event()
+{
+	if (!event_pool.empty())
+	{
+		void *e = event_pool.back();
+		event_pool.pop_back();
+		return e;
+	}
+	hipEvent_t e;
+	if (hipEventCreate(&e) != hipSuccess)
+		throw std::runtime_error("hipEventCreate failed");
+	return e;
+}
+
+void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &composer)
+{
+	HIP::CommandBuffer::Type last_type = HIP::CommandBuffer::Type::Count;
+	hipEvent_t cross = nullptr;
+
+	for (unsigned pass_index : pass_stack)
+	{
+		auto &pass = *passes[pass_index];
+		if (pass.may_not_need_render_pass() && !pass.need_render_pass())
+			continue;
+		pass.prepare_render_pass(composer);
+
+		auto type = (pass.get_queue() & RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT) ? HIP::CommandBuffer::Type::AsyncCompute
+		                                                                       : HIP::CommandBuffer::Type::Generic;
+		auto stream = static_cast<hipStream_t>(device_.get_stream(type));
+		if (last_type != HIP::CommandBuffer::Type::Count && last_type != type)
+		{
+			if (!cross && hipEventCreateWithFlags(&cross, hipEventDisableTiming) != hipSuccess)
+				throw std::runtime_error("hipEventCreate failed");
+			auto prev = static_cast<hipStream_t>(device_.get_stream(last_type));
+			if (hipEventRecord(cross, prev) != hipSuccess || hipStreamWaitEvent(stream, cross, 0) != hipSuccess)
+				throw std::runtime_error("cross-queue dependency failed");
+		}
+		last_type = type;
+
+		HIP::CommandBuffer cmd{device_, stream, type};
+
+		PassTimestamp ts = {pass_index, nullptr, nullptr};
+		if (enabled_timestamps)
+		{
+			ts.start = acquire_event();
+			ts.stop = acquire_event();
+			(void)hipEventRecord(static_cast<hipEvent_t>(ts.start), stream);
+		}
+
+		// LOAD_OP_CLEAR for colour outputs that have no input (render_graph.cpp:1871-1990): only on graphics passes.
+		if ((pass.get_queue() & compute_queues) == 0)
+		{
+			for (unsigned i = 0; i < pass.get_color_outputs().size(); i++)
+			{
+				VkClearColorValue value = {};
+				if (pass.get_color_inputs()[i] == nullptr && pass.get_clear_color(i, &value))
+				{
+					if (value.uint32[0] | value.uint32[1] | value.uint32[2] | value.uint32[3])
+						throw std::logic_error("Only zero clear colours are supported by the HIP executor.");
+					cmd.clear_image(get_physical_texture_resource(*pass.get_color_outputs()[i]));
+				}
+			}
+		}
+
+		pass.build_render_pass(cmd, 0);
+
+		if (enabled_timestamps)
+		{
+			(void)hipEventRecord(static_cast<hipEvent_t>(ts.stop), stream);
+			pending_timestamps.push_back(ts);
+		}
+	}
+
+	// Backbuffer could not alias the swapchain image: final blit (same geometry/format only).
+	if (swapchain_attachment && swapchain_physical_index == RenderResource::Unused)
+	{
+		auto &src = get_physical_texture_resource(resources[resource_to_index[backbuffer_source]]->get_physical_index());
+		if (src.get_size_bytes() != swapchain_attachment->get_size_bytes() || src.get_format() != swapchain_attachment->get_format())
+			throw std::logic_error("Backbuffer source does not match the swapchain; scaling blits are not implemented.");
+		HIP::CommandBuffer cmd{device_, device_.get_stream(HIP::CommandBuffer::Type::Generic), HIP::CommandBuffer::Type::Generic};
+		if (last_type == HIP::CommandBuffer::Type::AsyncCompute)
+		{
+			if (!cross && hipEventCreateWithFlags(&cross, hipEventDisableTiming) != hipSuccess)
+				throw std::runtime_error("hipEventCreate failed");
+			(void)hipEventRecord(cross, static_cast<hipStream_t>(device_.get_stream(last_type)));
+			(void)hipStreamWaitEvent(static_cast<hipStream_t>(cmd.get_stream()), cross, 0);
+		}
+		cmd.copy_image(*swapchain_attachment, src);
+	}
+
+	if (cross)
+		(void)hipEventDestroy(cross);
+	device_.next_frame_context();
+}
+
+std::vector<RenderGraph::TimestampReport> RenderGraph::collect_timestamps()
+{
+	for (auto &ts : pending_timestamps)
+	{
+		auto start = static_cast<hipEvent_t>(ts.start), stop = static_cast<hipEvent_t>(ts.stop);
+		float ms = 0.0f;
+		if (hipEventSynchronize(stop) == hipSuccess && hipEventElapsedTime(&ms, start, stop) == hipSuccess)
+		{
+			auto &name = passes[ts.pass]->get_name();
+			auto itr = timestamp_accum.find(name);
+			if (itr == timestamp_accum.end())
+			{
+				timestamp_order.push_back(name);
+				itr = timestamp_accum.emplace(name, std::make_pair(uint64_t(0), 0.0)).first;
+			}
+			itr->second.first++;
+			itr->second.second += ms;
+		}
+		event_pool.push_back(ts.start);
+		event_pool.push_back(ts.stop);
+	}
+	pending_timestamps.clear();
+
+	std::vector<TimestampReport> out;
+	for (auto &name : timestamp_order)
+	{
+		auto &acc = timestamp_accum[name];
+		out.push_back({name, acc.first, acc.second});
+	}
+	return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// log (render_graph.cpp:1394-1511)
+// ---------------------------------------------------------------------------------------------------------------------
+void RenderGraph::log()
+{
+	for (auto &dim : physical_dimensions)
+	{
+		unsigned i = unsigned(&dim - physical_dimensions.data());
+		if (dim.buffer_info.size)
+			fprintf(stderr, "Resource #%u (%s): size: %u\n", i, dim.name.c_str(), unsigned(dim.buffer_info.size));
+		else
+			fprintf(stderr, "Resource #%u (%s): %u x %u (fmt: %u), samples: %u%s\n", i, dim.name.c_str(), dim.width, dim.height,
+			        unsigned(dim.format), dim.samples, physical_image_has_history[i] ? " (history)" : "");
+	}
+	unsigned order = 0;
+	for (unsigned pass_index : pass_stack)
+	{
+		auto &pass = *passes[pass_index];
+		fprintf(stderr, "Pass #%u: %s (queue %u)\n", order++, pass.get_name().c_str(), unsigned(pass.get_queue()));
+		for (auto *o : pass.get_color_outputs())
+			fprintf(stderr, "    ColorAttachment: %u (%s)\n", o->get_physical_index(), o->get_name().c_str());
+		for (auto *o : pass.get_storage_texture_outputs())
+			fprintf(stderr, "    StorageTexture: %u (%s)\n", o->get_physical_index(), o->get_name().c_str());
+		for (auto *o : pass.get_storage_outputs())
+			fprintf(stderr, "    StorageBuffer: %u (%s)\n", o->get_physical_index(), o->get_name().c_str());
+		for (auto &in : pass.get_generic_texture_inputs())
+			fprintf(stderr, "    Texture: %u (%s)\n", in.texture->get_physical_index(), in.texture->get_name().c_str());
+		for (auto *in : pass.get_attachment_inputs())
+			fprintf(stderr, "    InputAttachment: %u (%s)\n", in->get_physical_index(), in->get_name().c_str());
+		for (auto &in : pass.get_generic_buffer_inputs())
+			fprintf(stderr, "    Buffer: %u (%s)\n", in.buffer->get_physical_index(), in.buffer->get_name().c_str());
+		for (auto *in : pass.get_history_inputs())
+			fprintf(stderr, "    History: %u (%s)\n", in->get_physical_index(), in->get_name().c_str());
+	}
+}
+
+std::string RenderGraph::dump_json() const
+{
+	std::ostringstream os;
+	os << "{\"passes\":[";
+	bool first = true;
+	for (unsigned pass_index : pass_stack)
+	{
+		auto &pass = *passes[pass_index];
+		if (!first)
+			os << ",";
+		first = false;
+		os << "{\"name\":\"" << pass.get_name() << "\",\"queue\":" << unsigned(pass.get_queue()) << ",\"writes\":[";
+		bool f2 = true;
+		auto emit = [&](const RenderResource *r) {
+			if (!r)
+				return;
+			if (!f2)
+				os << ",";
+			f2 = false;
+			os << "{\"name\":\"" << r->get_name() << "\",\"phys\":" << int(r->get_physical_index()) << "}";
+		};
+		for (auto *o : pass.get_color_outputs()) emit(o);
+		for (auto *o : pass.get_storage_texture_outputs()) emit(o);
+		for (auto *o : pass.get_storage_outputs()) emit(o);
+		for (auto *o : pass.get_transfer_outputs()) emit(o);
+		emit(pass.get_depth_stencil_output());
+		os << "],\"reads\":[";
+		f2 = true;
+		for (auto &in : pass.get_generic_texture_inputs()) emit(in.texture);
+		for (auto *in : pass.get_attachment_inputs()) emit(in);
+		for (auto &in : pass.get_generic_buffer_inputs()) emit(in.buffer);
+		for (auto *in : pass.get_color_inputs()) emit(in);
+		for (auto *in : pass.get_storage_inputs()) emit(in);
+		for (auto *in : pass.get_storage_texture_inputs()) emit(in);
+		emit(pass.get_depth_stencil_input());
+		os << "],\"history\":[";
+		f2 = true;
+		for (auto *in : pass.get_history_inputs()) emit(in);
+		os << "]}";
+	}
+	os << "],\"resources\":[";
+	for (size_t i = 0; i < physical_dimensions.size(); i++)
+	{
+		auto &d = physical_dimensions[i];
+		if (i)
+			os << ",";
+		os << "{\"phys\":" << i << ",\"name\":\"" << d.name << "\",\"width\":" << d.width << ",\"height\":" << d.height
+		   << ",\"format\":" << unsigned(d.format) << ",\"buffer_size\":" << d.buffer_info.size
+		   << ",\"history\":" << (physical_image_has_history[i] ? "true" : "false") << "}";
+	}
+	os << "],\"swapchain_phys\":" << int(swapchain_physical_index) << "}";
+	return os.str();
+}
+} // namespace Granite

@@ -5,7 +5,8 @@
 // clusterer_bindless.h + point.h + spot.h + pbr.h), both blended ONE/ONE into the RGBA16F HDR target with depth test
 // NOT_EQUAL against z = 0.
 //
-// One kernel reads the four G-buffer attachments + emissive once (22 B/px) and writes HDR once (8 B/px).  The two
+// One kernel reads the four G-buffer attachments + emissive once (22 B/px) and writes HDR once (8 B/px); emissive and
+// HDR may be the same buffer (the reference's blend read-modify-write) or distinct ones (same values, same bytes).  The two
 // blend roundings of the reference are reproduced in registers: hdr = rne16(rne16(emissive + directional) + clustered).
 //
 // Wave mapping: a wave64 owns a 16x4 pixel tile (128 B HDR / 64 B albedo row segments).  The light loop is wave-uniform
@@ -25,7 +26,7 @@ constexpr float PI_SIC = 3.1415628f; // assets/shaders/lights/pbr.h:4-6 (sic)
 
 struct KernelArgs
 {
-	DevImage albedo, normal, pbr, depth;
+	DevImage albedo, normal, pbr, depth, emissive;
 	DevImageRW hdr;
 	float inv_vp[16];
 	float camera_pos[3];
@@ -122,6 +123,12 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		depth = *reinterpret_cast<const float *>(a.depth.ptr + size_t(y) * a.depth.pitch + size_t(x) * 4u);
 	// depth test NOT_EQUAL against the quad at z = 0 (renderer.cpp:1056-1057): reverse-Z far plane untouched.
 	const bool active = inside && depth != 0.0f;
+	if (inside && !active && a.emissive.ptr != a.hdr.ptr)
+	{
+		// Far-plane pixel: the draws are depth-rejected, the target keeps the emissive value.
+		*reinterpret_cast<f16x4 *>(a.hdr.ptr + size_t(y) * a.hdr.pitch + size_t(x) * 8u) =
+		    *reinterpret_cast<const f16x4 *>(a.emissive.ptr + size_t(y) * a.emissive.pitch + size_t(x) * 8u);
+	}
 	if (!__any(active))
 		return;
 
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		alb = *reinterpret_cast<const uint32_t *>(a.albedo.ptr + size_t(y) * a.albedo.pitch + size_t(x) * 4u);
 		nrm = *reinterpret_cast<const uint32_t *>(a.normal.ptr + size_t(y) * a.normal.pitch + size_t(x) * 4u);
 		mr = *reinterpret_cast<const uint16_t *>(a.pbr.ptr + size_t(y) * a.pbr.pitch + size_t(x) * 2u);
-		dst = *reinterpret_cast<const f16x4 *>(a.hdr.ptr + size_t(y) * a.hdr.pitch + size_t(x) * 8u);
+		dst = *reinterpret_cast<const f16x4 *>(a.emissive.ptr + size_t(y) * a.emissive.pitch + size_t(x) * 8u);
 	}
 
 	// ---- G-buffer decode (clustering.frag:31-35) ----
@@ -282,6 +289,7 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	const uint32_t W = args->hdr.width, H = args->hdr.height;
 	GR_CHECK_ARG(ctx, W != 0 && H != 0);
 	GR_CHECK_ARG(ctx, check_image(args->hdr, GR_FORMAT_R16G16B16A16_SFLOAT, 8, W, H));
+	GR_CHECK_ARG(ctx, check_image(args->emissive, GR_FORMAT_R16G16B16A16_SFLOAT, 8, W, H));
 	GR_CHECK_ARG(ctx, check_image(args->albedo, GR_FORMAT_R8G8B8A8_SRGB, 4, W, H));
 	GR_CHECK_ARG(ctx, check_image(args->normal, GR_FORMAT_A2B10G10R10_UNORM_PACK32, 4, W, H));
 	GR_CHECK_ARG(ctx, check_image(args->pbr, GR_FORMAT_R8G8_UNORM, 2, W, H));
@@ -300,6 +308,7 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	k.normal = dev(args->normal);
 	k.pbr = dev(args->pbr);
 	k.depth = dev(args->depth);
+	k.emissive = dev(args->emissive);
 	k.hdr = DevImageRW{static_cast<uint8_t *>(args->hdr.ptr), int(W), int(H), args->hdr.pitch_bytes};
 	for (int i = 0; i < 16; i++)
 		k.inv_vp[i] = args->inv_view_projection[i];

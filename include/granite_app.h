@@ -1,0 +1,125 @@
+/* granite_app.h — C ABI of the headless harness that composes Granite's image-space graph on the HIP executor.
+ *
+ * Mirrors what application/scene_viewer_application.cpp:876-991,1167-1318 (graph composition) and
+ * application/platforms/application_headless.cpp:581-671 (warm-up, timed loop, readback) do for the reference, with the
+ * scene/mesh renderer replaced by synthetic G-buffer uploads.  Used by bench.py and the parity tests (ctypes); a
+ * Granite application would call the C++ classes in granite_amd/csrc/host directly.
+ */
+#ifndef GRANITE_APP_H_
+#define GRANITE_APP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gra_app gra_app;
+
+/* PostAAType (renderer/post/aa.hpp:33-47) subset that is live in the reference. */
+typedef enum gra_post_aa
+{
+	GRA_POST_AA_NONE = 0,
+	GRA_POST_AA_FXAA = 1,
+	GRA_POST_AA_SMAA_LOW = 2,
+	GRA_POST_AA_SMAA_MEDIUM = 3,
+	GRA_POST_AA_SMAA_HIGH = 4,
+	GRA_POST_AA_SMAA_ULTRA = 5,
+	GRA_POST_AA_TAA_LOW = 6,
+	GRA_POST_AA_TAA_MEDIUM = 7,
+	GRA_POST_AA_TAA_HIGH = 8
+} gra_post_aa;
+
+typedef struct gra_config
+{
+	int32_t device;            /* HIP device index */
+	uint32_t width, height;    /* backbuffer = R8G8B8A8_SRGB width x height (application_headless.cpp:207-229) */
+	int32_t enable_lighting;   /* 0: config-1 style graph (HDR input -> bloom -> tonemap); 1: gbuffer + clustering + lighting */
+	int32_t hdr_bloom;         /* viewer_config "hdrBloom" */
+	int32_t dynamic_exposure;  /* "hdrBloomDynamicExposure" */
+	int32_t compute_post;      /* ImplementationQuirks::use_async_compute_post: 1 = setup_hdr_postprocess_compute */
+	int32_t post_aa;           /* gra_post_aa applied after the post chain (fxaa / smaa) */
+	int32_t pre_aa;            /* gra_post_aa applied before the post chain (taa) */
+	int32_t rmw_emissive;      /* 1: lighting declared add_color_output("HDR", info, "emissive") exactly like the reference
+	                              (G-buffer emissive restored every frame); 0: emissive is a 5th attachment input */
+	uint32_t cluster_res[3];   /* LightClusterer::set_resolution; viewer default 128 x 64 x 4096 */
+	float frame_time;          /* FrameParameters::frame_time fed to the lerps; headless default 0.01 */
+	float directional_color[3];
+	float directional_direction[3];
+	int32_t enable_timestamps; /* RenderGraph::enable_timestamps */
+} gra_config;
+
+/* Scene-level light description (one PositionalLight + its node transform). */
+typedef struct gra_light_desc
+{
+	int32_t type;            /* 0 = spot, 1 = point */
+	float color[3];
+	float inner_cone, outer_cone;
+	float cutoff_range;      /* PositionalLight::set_maximum_range */
+	float pad;
+	float transform[12];     /* mat_affine rows */
+} gra_light_desc;
+
+/* RenderParameters subset, tightly packed: projection, view, view_projection, inv_projection, inv_view,
+ * inv_view_projection (column-major mat4 each), camera_position[3], camera_front[3], z_near, z_far = 104 floats. */
+#define GRA_RENDER_PARAMS_FLOATS 104
+
+gra_app *gra_create(const gra_config *config, char *error, size_t error_size);
+void gra_destroy(gra_app *app);
+const char *gra_last_error(gra_app *app);
+
+/* RenderContext::set_camera(projection, view): derives inverses etc. on the host like the reference. */
+int gra_set_camera(gra_app *app, const float *projection16, const float *view16);
+/* Installs precomputed parameters verbatim (so that the CPU oracle and the device see bit-identical inputs). */
+int gra_set_render_parameters(gra_app *app, const float *params104);
+int gra_get_render_parameters(gra_app *app, float *params104);
+
+int gra_set_lights(gra_app *app, const gra_light_desc *lights, uint32_t count);
+
+/* Synthetic G-buffer (host pointers, tightly packed rows, width x height of the config).  Any pointer may be NULL to
+ * leave that attachment unchanged.  Graphs without lighting take `emissive` as the HDR input. */
+int gra_upload_gbuffer(gra_app *app, const void *emissive_rgba16f, const void *albedo_rgba8, const void *normal_a2b10g10r10,
+                       const void *pbr_rg8, const void *depth_d32f, const void *motion_vectors_rg16f);
+
+/* Application::run_frame x count; asynchronous unless sync != 0. */
+int gra_render_frames(gra_app *app, uint32_t count, int32_t sync);
+int gra_sync(gra_app *app);
+
+/* Resource access by render-graph name ("HDR-main", "tonemapped", "upsample-0", "cluster-bitmask", ...). */
+typedef struct gra_resource_info
+{
+	void *device_ptr;
+	uint32_t width, height, format; /* 0 x 0 for buffers */
+	uint64_t size_bytes;
+	int32_t physical_index;
+} gra_resource_info;
+int gra_get_resource(gra_app *app, const char *name, gra_resource_info *info);
+int gra_read_resource(gra_app *app, const char *name, void *dst_host, uint64_t size_bytes);
+/* The swapchain image the last frame was rendered into (external to the graph, 4-image ring). */
+int gra_get_backbuffer(gra_app *app, gra_resource_info *info);
+int gra_read_backbuffer(gra_app *app, void *dst_host, uint64_t size_bytes);
+
+/* Clusterer CPU-side state of the last refresh, for parity tests.  Returns the number of lights. */
+int gra_get_cluster_state(gra_app *app, void *lights48, void *models48, uint32_t *type_mask128, void *params176,
+                          uint32_t *light_ranges_uvec2);
+
+/* JSON dump of the baked graph (pass order, physical resources).  Returns the length needed. */
+size_t gra_dump_graph(gra_app *app, char *buffer, size_t size);
+
+/* Per-pass GPU time accumulated since creation (enable_timestamps): fills up to max entries, returns the count. */
+typedef struct gra_timestamp
+{
+	char tag[64];
+	uint64_t count;
+	double total_ms;
+} gra_timestamp;
+int gra_collect_timestamps(gra_app *app, gra_timestamp *entries, int max_entries);
+/* Per-kernel timing lives in the kernel library: gr_timing_* on this context. */
+void *gra_get_kernel_context(gra_app *app); /* gr_ctx* */
+void *gra_get_stream(gra_app *app);         /* hipStream_t of the generic queue */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -87,6 +87,8 @@ typedef struct gr_timing_entry
 	double total_ms;
 } gr_timing_entry;
 int gr_timing_enable(gr_ctx *ctx, int enable);
+/* Restrict bracketing to launchers whose name equals `name` (NULL = all): keeps event overhead out of a timed loop. */
+int gr_timing_set_filter(gr_ctx *ctx, const char *name);
 int gr_timing_reset(gr_ctx *ctx);
 int gr_timing_query(gr_ctx *ctx, gr_timing_entry *entries, int max_entries); /* returns number of entries; syncs */
 
@@ -246,7 +248,8 @@ int gr_cluster_z_range(gr_ctx *ctx, gr_stream stream, const uint32_t *light_rang
 
 /* DeferredLightRenderer::render_light (renderer.cpp:1004-1156): directional quad (directional.frag) then clustered quad
  * (clustering.frag), both additively blended into the RGBA16F HDR target with depth test NOT_EQUAL against z = 0.
- * One fused kernel; the intermediate blend result is rounded to fp16 exactly where the two reference draws round it. */
+ * One fused kernel; the intermediate blend result is rounded to fp16 exactly where the two reference draws round it:
+ * hdr = rne16(rne16(emissive + directional) + clustered); alpha and far-plane pixels are copied through. */
 typedef struct gr_push_directional /* renderer.cpp:1073-1103, 88 B used */
 {
 	float inv_view_proj_col2[4];
@@ -281,7 +284,10 @@ typedef struct gr_lighting_args
 	gr_image normal; /* A2B10G10R10_UNORM_PACK32 */
 	gr_image pbr;    /* R8G8_UNORM (metallic, roughness) */
 	gr_image depth;  /* D32_SFLOAT, reverse-Z */
-	gr_image hdr;    /* R16G16B16A16_SFLOAT, read-modify-write (emissive -> HDR) */
+	gr_image emissive; /* R16G16B16A16_SFLOAT blend destination contents before the draws (G-buffer emissive) */
+	gr_image hdr;    /* R16G16B16A16_SFLOAT result.  May alias `emissive` (same ptr): that is the reference's
+	                    add_color_output("HDR", info, "emissive") read-modify-write; distinct buffers give the same
+	                    values and bytes without clobbering the G-buffer. */
 	float inv_view_projection[16]; /* DirectionalLightUBO / clustering.vert UBO */
 	gr_push_directional directional;
 	gr_push_clustering clustering;

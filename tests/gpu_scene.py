@@ -57,7 +57,7 @@ class Scene:
         gr.sync()
         return {"transforms": transforms, "spots": spots, "setup": setup, "bitmask": bitmask, "range": ranges, "zr": zr}
 
-    def lighting_args(self, gr, dev, flags):
+    def lighting_args(self, gr, dev, flags, alias_emissive=True):
         w, h = self.w, self.h
         imgs = {
             "albedo": capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8B8A8_SRGB).upload(self.gbuf["albedo"]),
@@ -68,6 +68,12 @@ class Scene:
         }
         a = capi.LightingArgs()
         a.albedo, a.normal, a.pbr, a.depth, a.hdr = (imgs[k].desc for k in ("albedo", "normal", "pbr", "depth", "hdr"))
+        if alias_emissive:
+            a.emissive = imgs["hdr"].desc  # reference semantics: blend read-modify-write on one attachment
+        else:
+            imgs["emissive"] = capi.DeviceImage(gr, w, h, capi.FORMAT_R16G16B16A16_SFLOAT).upload(self.gbuf["emissive"])
+            imgs["hdr"].upload(np.full_like(self.gbuf["emissive"], 0x7e00))  # NaN-fill: every pixel must be written
+            a.emissive = imgs["emissive"].desc
         a.inv_view_projection[:] = self.rp[80:96]
         col2 = self.rp[80 + 8:80 + 12]
         a.directional.inv_view_proj_col2[:] = col2

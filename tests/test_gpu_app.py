@@ -1,0 +1,122 @@
+"""GPU parity, end to end: frames rendered by the RenderGraph executor (C++ host layer + HIP kernels) vs the CPU oracle
+driven in the reference's recorded order."""
+import numpy as np
+import pytest
+
+from granite_amd import app as gapp, capi, synth
+from oracle import oracle as orc
+from util import assert_rgba16f_close, assert_rgba8_close
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_frames(cam, gbuf, descs, frames, res=synth.CLUSTER_RESOLUTION):
+    rp = cam.render_params()
+    n, lights, model, tmask, _ = orc.pack_lights(descs, rp[99:102])
+    prm = orc.cluster_params(rp, *res, n)
+    cb = orc.cluster_build(rp, prm, lights, model, tmask, n, res[2])
+    hdr = orc.lighting(gbuf, rp, prm, lights, tmask, cb["bitmask"], cb["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
+    state, out = {}, None
+    for _ in range(frames):
+        out = orc.hdr_chain(hdr, state)
+    return {"n": n, "lights": lights, "model": model, "type_mask": tmask, "prm": prm, "cluster": cb, "hdr": hdr, "chain": out}
+
+
+@pytest.fixture(scope="module")
+def scene():
+    cam = synth.Camera(480, 270)
+    return cam, synth.make_gbuffer(cam), synth.make_lights(cam, 700)
+
+
+def make_app(cam, gbuf, descs, **kw):
+    a = gapp.Application(cam.width, cam.height, **kw)
+    a.set_render_parameters(cam.render_params())
+    a.set_lights(descs)
+    a.upload_gbuffer(gbuf)
+    return a
+
+
+def test_host_light_packing_and_cluster_build_bit_exact(scene):
+    cam, gbuf, descs = scene
+    ref = oracle_frames(cam, gbuf, descs, 1)
+    a = make_app(cam, gbuf, descs)
+    a.render_frames(1)
+    st = a.cluster_state()
+    n = ref["n"]
+    assert st["count"] == n
+    np.testing.assert_array_equal(st["lights"][:n * 48], ref["lights"].view(np.uint8)[:n * 48])
+    np.testing.assert_array_equal(st["models"][:n].view(np.uint32), ref["model"][:n].view(np.uint32))
+    np.testing.assert_array_equal(st["type_mask"], ref["type_mask"])
+    np.testing.assert_array_equal(st["params"], ref["prm"].view(np.uint8).reshape(-1))
+    np.testing.assert_array_equal(st["light_ranges"], ref["cluster"]["light_ranges"])
+    n32 = (n + 31) // 32
+    bitmask = a.read("cluster-bitmask").view(np.uint32)[:128 * 64 * n32]
+    np.testing.assert_array_equal(bitmask, ref["cluster"]["bitmask"])
+    np.testing.assert_array_equal(a.read("cluster-range").view(np.uint32).reshape(-1, 2), ref["cluster"]["range"])
+    a.close()
+
+
+@pytest.mark.parametrize("compute_post", [True, False])
+def test_frames_match_oracle(scene, compute_post):
+    cam, gbuf, descs = scene
+    frames = 3
+    ref = oracle_frames(cam, gbuf, descs, frames)
+    a = make_app(cam, gbuf, descs, compute_post=compute_post)
+    a.render_frames(frames)
+    assert_rgba16f_close(a.read("HDR-main"), ref["hdr"], ulps=3.0, what="HDR-main")
+    names = ({"threshold": "threshold", "downsample-3": "d3", "upsample-0": "u0"} if compute_post else
+             {"threshold": "threshold", "bloom-downsample-3": "d3", "bloom-upsample-2": "u0"})
+    for res, key in names.items():
+        # error carried from the lighting tolerance through the pyramid: 4 ulp + 2e-4
+        assert_rgba16f_close(a.read(res), ref["chain"][key], ulps=4.0, abs_tol=2e-4, what=res)
+    lum_name = "average-luminance" if compute_post else "average-luminance-updated"
+    lum = a.read(lum_name).view(np.float32)
+    np.testing.assert_allclose(lum[0], ref["chain"]["lum"][0], atol=2e-5)
+    assert_rgba8_close(a.read_backbuffer(), ref["chain"]["tonemapped"], 1, what="backbuffer")
+    a.close()
+
+
+def test_reference_rmw_declaration_equals_attachment_input_form(scene):
+    """lighting declared add_color_output("HDR", info, "emissive") (reference form, G-buffer restored per frame) and the
+    5-attachment-input form give bit-identical frames."""
+    cam, gbuf, descs = scene
+    outs = []
+    for rmw in (True, False):
+        a = make_app(cam, gbuf, descs, rmw_emissive=rmw)
+        a.render_frames(4)
+        outs.append((a.read("HDR-main").copy(), a.read_backbuffer().copy(), a.graph()))
+        a.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    phys = {w["name"]: w["phys"] for p in outs[0][2]["passes"] for w in p["writes"]}
+    assert phys["HDR-main"] == phys["emissive-main"], "RMW output must alias its input's physical image"
+
+
+def test_config1_bloom_tonemap_only():
+    """Config 1: 256x256 bloom + tonemap, no lighting pass."""
+    hdr = synth.make_hdr(256, 256)
+    a = gapp.Application(256, 256, lighting=False)
+    a.upload_hdr(hdr)
+    state, ref = {}, None
+    for _ in range(5):
+        ref = orc.hdr_chain(hdr, state)
+    a.render_frames(5)
+    assert_rgba16f_close(a.read("upsample-0"), ref["u0"], what="upsample-0")
+    assert_rgba8_close(a.read_backbuffer(), ref["tonemapped"], 1, what="config1 backbuffer")
+    np.testing.assert_allclose(a.read("average-luminance").view(np.float32)[0], ref["lum"][0], atol=1e-5)
+    a.close()
+
+
+def test_frames_are_deterministic_and_timestamps_reported(scene):
+    cam, gbuf, descs = scene
+    a = make_app(cam, gbuf, descs, timestamps=True)
+    a.render_frames(6)
+    first = a.read_backbuffer().copy()
+    b = make_app(cam, gbuf, descs)
+    b.render_frames(6)
+    np.testing.assert_array_equal(first, b.read_backbuffer())
+    ts = a.timestamps()
+    assert {"clustering-bindless", "gbuffer-main", "lighting-main", "bloom-compute", "tonemap"} <= set(ts)
+    assert all(c == 6 and ms > 0 for c, ms in ts.values())
+    a.close()
+    b.close()

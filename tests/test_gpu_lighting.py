@@ -54,6 +54,20 @@ def test_lighting_matches_oracle(gr, w, h, num_lights):
         assert exact > 0.95, f"only {exact:.3f} of channels bit-identical"
 
 
+def test_lighting_separate_emissive_equals_aliased(gr):
+    """emissive as a distinct input attachment gives bit-identical HDR to the aliased read-modify-write form and leaves
+    the G-buffer untouched."""
+    sc = Scene(333, 77, 700)
+    dev = sc.build_clusters_gpu(gr)
+    a1, i1 = sc.lighting_args(gr, dev, ALL, alias_emissive=True)
+    gr.check(gr.lib.gr_lighting(gr.handle, None, a1))
+    a2, i2 = sc.lighting_args(gr, dev, ALL, alias_emissive=False)
+    gr.check(gr.lib.gr_lighting(gr.handle, None, a2))
+    gr.sync()
+    np.testing.assert_array_equal(i1["hdr"].download(), i2["hdr"].download())
+    np.testing.assert_array_equal(i2["emissive"].download(), sc.gbuf["emissive"])
+
+
 def test_lighting_equals_bruteforce_sum(gr):
     """Size-independent property: the clustered result equals the unclustered sum over ALL lights (culling is
     conservative), evaluated by the oracle's brute-force loop."""

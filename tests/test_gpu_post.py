@@ -13,7 +13,10 @@ pytestmark = pytest.mark.gpu
 
 F16 = capi.FORMAT_R16G16B16A16_SFLOAT
 
-SIZES = [(256, 256), (250, 130), (33, 17), (1, 1), (1920, 1080)]
+SIZES = [(256, 256), (250, 130), (70, 40), (64, 64), (1920, 1080)]
+# d3/2 has a zero dimension below 64 px: the reference's luminance pass divides by zero there (luminance.comp:31), so the
+# tiny sizes run with dynamic exposure off and the C ABI rejects a zero-sized luminance grid.
+TINY_SIZES = [(33, 17), (1, 1), (2, 3)]
 
 
 def run_chain_gpu(gr, hdr_bits, state, frame_time=0.01, use_lum=True, fmt=capi.FORMAT_R8G8B8A8_SRGB):
@@ -70,6 +73,21 @@ def test_chain_levels_match_oracle(gr, w, h):
         np.testing.assert_allclose(got["lum"][0], ref["lum"][0], atol=1e-5, rtol=0)
         np.testing.assert_allclose(got["lum"][1:], ref["lum"][1:], rtol=2e-5)
         assert_rgba8_close(got["tonemapped"], ref["tonemapped"], 1, what=f"{w}x{h} frame {frame} tonemapped")
+
+
+@pytest.mark.parametrize("w,h", TINY_SIZES)
+def test_chain_tiny_sizes_without_exposure(gr, w, h):
+    hdr = synth.make_hdr(w, h)
+    ostate, gstate = {}, {}
+    for frame in range(2):
+        ref = orc.hdr_chain(hdr, ostate, use_lum=False)
+        got = run_chain_gpu(gr, hdr, gstate, use_lum=False)
+        for name in ("threshold", "d0", "d1", "d2", "d3", "u2", "u1", "u0"):
+            assert_rgba16f_close(got[name], ref[name], what=f"{w}x{h} frame {frame} {name}")
+        assert_rgba8_close(got["tonemapped"], ref["tonemapped"], 1, what=f"{w}x{h} tonemapped")
+    d3 = capi.DeviceImage(gr, 1, 1, F16)
+    with pytest.raises(capi.GraniteHipError):
+        gr.luminance(d3, capi.DeviceBuffer(gr, 12).ptr, 0.5)
 
 
 def test_kernels_stagewise_on_identical_inputs(gr):
