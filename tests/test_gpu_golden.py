@@ -1,0 +1,41 @@
+"""GPU vs the frozen fixtures under tests/golden/ (no oracle call at run time)."""
+import os
+
+import numpy as np
+import pytest
+
+from granite_amd import app as gapp
+from golden.make_golden import FRAMES, inputs
+from util import assert_rgba16f_close, assert_rgba8_close
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "oracle_golden_v1.npz")
+
+
+def test_executor_matches_committed_fixtures():
+    ref = np.load(GOLDEN)
+    cam, gbuf, descs = inputs()
+    a = gapp.Application(cam.width, cam.height)
+    a.set_render_parameters(cam.render_params())
+    a.set_lights(descs)
+    a.upload_gbuffer(gbuf)
+    a.render_frames(FRAMES)
+    st = a.cluster_state()
+    n = st["count"]
+    np.testing.assert_array_equal(st["lights"][:n * 48], ref["lights_bytes"])
+    np.testing.assert_array_equal(st["type_mask"], ref["type_mask"])
+    np.testing.assert_array_equal(st["params"], ref["cluster_params_bytes"])
+    np.testing.assert_array_equal(st["light_ranges"], ref["light_ranges"])
+    n32 = (n + 31) // 32
+    bitmask = a.read("cluster-bitmask").view(np.uint32)[:128 * 64 * n32]
+    nz = np.flatnonzero(bitmask)
+    np.testing.assert_array_equal(nz, ref["bitmask_nonzero_index"])
+    np.testing.assert_array_equal(bitmask[nz], ref["bitmask_nonzero_value"])
+    np.testing.assert_array_equal(a.read("cluster-range").view(np.uint32).reshape(-1, 2), ref["range"])
+    assert_rgba16f_close(a.read("HDR-main"), ref["hdr"], ulps=3.0, what="HDR-main")
+    assert_rgba16f_close(a.read("threshold"), ref["threshold"], ulps=4.0, abs_tol=2e-4, what="threshold")
+    assert_rgba16f_close(a.read("downsample-3"), ref["d3"], ulps=4.0, abs_tol=2e-4, what="downsample-3")
+    assert_rgba16f_close(a.read("upsample-0"), ref["u0"], ulps=4.0, abs_tol=2e-4, what="upsample-0")
+    np.testing.assert_allclose(a.read("average-luminance").view(np.float32)[0], ref["lum"][0], atol=2e-5)
+    assert_rgba8_close(a.read_backbuffer(), ref["tonemapped"], 1, what="tonemapped")
+    a.close()
