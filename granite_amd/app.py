@@ -40,7 +40,8 @@ EXPORTED_SYMBOLS = [
     "gra_create", "gra_destroy", "gra_last_error", "gra_set_camera", "gra_set_render_parameters",
     "gra_get_render_parameters", "gra_set_lights", "gra_upload_gbuffer", "gra_render_frames", "gra_sync",
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
-    "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream",
+    "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
+    "gra_set_smaa_luts",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -75,6 +76,8 @@ def load_library() -> C.CDLL:
         "gra_collect_timestamps": (C.c_int, [vp, P(Timestamp), C.c_int]),
         "gra_get_kernel_context": (vp, [vp]),
         "gra_get_stream": (vp, [vp]),
+        "gra_get_taa_reprojection": (C.c_int, [vp, vp]),
+        "gra_set_smaa_luts": (C.c_int, [vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -111,6 +114,10 @@ class Application:
         self.handle = self.lib.gra_create(cfg, err, 512)
         if not self.handle:
             raise capi.GraniteHipError(f"gra_create failed: {err.value.decode()}")
+        if device >= 0 and POST_AA_SMAA_LOW <= post_aa <= POST_AA_SMAA_ULTRA:
+            from .data import load_smaa_luts
+            area, search = load_smaa_luts()
+            self._check(self.lib.gra_set_smaa_luts(self.handle, area.ctypes.data, search.ctypes.data))
 
     def _check(self, code):
         if code < 0:
@@ -221,6 +228,11 @@ class Application:
         buf = C.create_string_buffer(need)
         self.lib.gra_dump_graph(self.handle, buf, need)
         return json.loads(buf.value.decode())
+
+    def taa_reprojection(self) -> np.ndarray:
+        out = np.zeros(16, np.float32)
+        self._check(self.lib.gra_get_taa_reprojection(self.handle, out.ctypes.data))
+        return out
 
     def timestamps(self) -> dict:
         arr = (Timestamp * 64)()

@@ -133,6 +133,21 @@ class LightingArgs(C.Structure):
                 ("flags", C.c_uint32)]
 
 
+class PushFxaa(C.Structure):
+    _fields_ = [("inv_resolution", C.c_float * 2)]
+
+
+class PushSmaa(C.Structure):
+    _fields_ = [("rt_metrics", C.c_float * 4)]
+
+
+class PushTaa(C.Structure):
+    _fields_ = [("reproj", C.c_float * 16), ("rt_metrics", C.c_float * 4)]
+
+
+assert C.sizeof(PushTaa) == 80
+
+
 class GraniteHipError(RuntimeError):
     pass
 
@@ -178,6 +193,12 @@ def load_library() -> C.CDLL:
         "gr_cluster_binning": (C.c_int, [vp, vp, vp, vp, vp, P(ClusterParams)]),
         "gr_cluster_z_range": (C.c_int, [vp, vp, vp, vp, P(PushZRange)]),
         "gr_lighting": (C.c_int, [vp, vp, P(LightingArgs)]),
+        "gr_smaa_set_luts": (C.c_int, [vp, vp, vp]),
+        "gr_fxaa": (C.c_int, [vp, vp, P(Image), P(Image), P(PushFxaa)]),
+        "gr_smaa_edge_detection": (C.c_int, [vp, vp, P(Image), P(Image), P(PushSmaa), C.c_int]),
+        "gr_smaa_blend_weight": (C.c_int, [vp, vp, P(Image), P(Image), P(PushSmaa), C.c_int]),
+        "gr_smaa_neighbor_blend": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushSmaa)]),
+        "gr_taa_resolve": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), P(Image), P(Image), P(PushTaa), C.c_int]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here = header/library drift
@@ -192,6 +213,7 @@ EXPORTED_SYMBOLS = [
     "gr_download", "gr_copy", "gr_fill_zero", "gr_timing_enable", "gr_timing_set_filter", "gr_timing_reset", "gr_timing_query",
     "gr_bloom_threshold", "gr_bloom_downsample", "gr_bloom_upsample", "gr_luminance", "gr_tonemap",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
+    "gr_smaa_set_luts", "gr_fxaa", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
 ]
 
 
@@ -330,3 +352,36 @@ class Context:
                 stream=None):
         push = PushTonemap(dynamic_exposure)
         self.check(self.lib.gr_tonemap(self.handle, stream, hdr.desc, bloom.desc, out.desc, lum_ptr, push))
+
+
+    # ---- anti-aliasing --------------------------------------------------------------------------------------------
+    def fxaa(self, src: DeviceImage, out: DeviceImage, stream=None):
+        push = PushFxaa((1.0 / src.width, 1.0 / src.height))
+        self.check(self.lib.gr_fxaa(self.handle, stream, src.desc, out.desc, push))
+
+    def smaa_set_luts(self, area: np.ndarray, search: np.ndarray):
+        a, s = np.ascontiguousarray(area, np.uint8), np.ascontiguousarray(search, np.uint8)
+        assert a.size == 160 * 560 * 2 and s.size == 64 * 16
+        self.check(self.lib.gr_smaa_set_luts(self.handle, a.ctypes.data, s.ctypes.data))
+
+    @staticmethod
+    def _smaa_push(img: DeviceImage) -> PushSmaa:
+        return PushSmaa((1.0 / img.width, 1.0 / img.height, float(img.width), float(img.height)))
+
+    def smaa_edge_detection(self, color: DeviceImage, edges: DeviceImage, quality: int, stream=None):
+        self.check(self.lib.gr_smaa_edge_detection(self.handle, stream, color.desc, edges.desc, self._smaa_push(color), quality))
+
+    def smaa_blend_weight(self, edges: DeviceImage, weights: DeviceImage, quality: int, stream=None):
+        self.check(self.lib.gr_smaa_blend_weight(self.handle, stream, edges.desc, weights.desc, self._smaa_push(edges), quality))
+
+    def smaa_neighbor_blend(self, color: DeviceImage, weights: DeviceImage, out: DeviceImage, stream=None):
+        self.check(self.lib.gr_smaa_neighbor_blend(self.handle, stream, color.desc, weights.desc, out.desc, self._smaa_push(color)))
+
+    def taa_resolve(self, current: DeviceImage, depth: DeviceImage, mv: DeviceImage, history, out_color: DeviceImage,
+                    out_history: DeviceImage, reproj16, quality: int, stream=None):
+        push = PushTaa()
+        push.reproj[:] = [float(v) for v in reproj16]
+        push.rt_metrics[:] = (1.0 / current.width, 1.0 / current.height, float(current.width), float(current.height))
+        self.check(self.lib.gr_taa_resolve(self.handle, stream, current.desc, depth.desc, mv.desc,
+                                           history.desc if history is not None else None, out_color.desc, out_history.desc, push,
+                                           quality))

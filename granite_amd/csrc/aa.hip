@@ -1,0 +1,863 @@
+// Anti-aliasing kernels for gfx950 and their C-ABI launchers (include/granite_hip.h): FXAA, SMAA 1x (edge detection,
+// blend weights, neighbourhood blend) and the TAA resolve.
+//
+// Replaces assets/shaders/post/{fxaa.frag, smaa_*.{vert,frag} + SMAA.hlsl, taa_resolve.frag + reprojection*.h} as
+// recorded by renderer/post/{fxaa,smaa,temporal}.cpp.
+//
+// These passes take data-dependent decisions on 8-bit data (edge thresholds, search loops, LUT addresses), so the file
+// is compiled with -ffp-contract=off and every expression keeps a fixed association order; `mad` is a real fma in the
+// reference (SMAA_GLSL_4) and is written fmaf here.  Images in *_SRGB formats are read through their UNORM alias: the
+// stored bytes.
+#include "ctx.hpp"
+#include "device_common.hpp"
+#include "device_vec.hpp"
+
+namespace
+{
+constexpr int AA_BLOCK_X = 32;
+constexpr int AA_BLOCK_Y = 8;
+
+// StockSampler::LinearClamp on a UNORM8 image with CH channels; texel offsets are applied after the floor.
+template <int CH>
+struct Tex8
+{
+	const uint8_t *ptr;
+	int w, h;
+	uint32_t pitch;
+
+	__device__ __forceinline__ v4 fetch(int x, int y) const
+	{
+		x = clampi(x, 0, w - 1);
+		y = clampi(y, 0, h - 1);
+		const uint8_t *p = ptr + size_t(y) * pitch + size_t(x) * CH;
+		v4 r = mk4(0.0f, 0.0f, 0.0f, 1.0f);
+		if (CH == 4)
+		{
+			const uint32_t t = *reinterpret_cast<const uint32_t *>(p);
+			r = mk4(float(t & 255u) / 255.0f, float((t >> 8) & 255u) / 255.0f, float((t >> 16) & 255u) / 255.0f, float(t >> 24) / 255.0f);
+		}
+		else if (CH == 2)
+		{
+			const uint32_t t = *reinterpret_cast<const uint16_t *>(p);
+			r.x = float(t & 255u) / 255.0f;
+			r.y = float(t >> 8) / 255.0f;
+		}
+		else
+			r.x = float(p[0]) / 255.0f;
+		return r;
+	}
+
+	__device__ __forceinline__ v4 sample(v2 uv, int ox = 0, int oy = 0) const
+	{
+		const float fx = uv.x * float(w) - 0.5f;
+		const float fy = uv.y * float(h) - 0.5f;
+		const float flx = floorf(fx), fly = floorf(fy);
+		const float a = fx - flx, b = fy - fly;
+		const int x0 = int(flx) + ox, y0 = int(fly) + oy;
+		const v4 t00 = fetch(x0, y0), t10 = fetch(x0 + 1, y0), t01 = fetch(x0, y0 + 1), t11 = fetch(x0 + 1, y0 + 1);
+		const v4 top = t00 * (1.0f - a) + t10 * a;
+		const v4 bot = t01 * (1.0f - a) + t11 * a;
+		return top * (1.0f - b) + bot * b;
+	}
+};
+
+template <int CH>
+static Tex8<CH> make_tex8(const gr_image *img)
+{
+	return {static_cast<const uint8_t *>(img->ptr), int(img->width), int(img->height), img->pitch_bytes};
+}
+
+__device__ __forceinline__ uint32_t unorm8(float v)
+{
+	// UNORM store: NaN and negatives -> 0, >= 1 -> 255, otherwise floor(v * 255 + 0.5).
+	if (!(v > 0.0f))
+		return 0u;
+	if (v >= 1.0f)
+		return 255u;
+	return uint32_t(int(v * 255.0f + 0.5f));
+}
+
+// decode_srgb in the shader followed by the sRGB attachment store is the identity on the gamma-space value up to the
+// transcendental round trip; the kernels store the gamma-space value directly (differs from the literal path by at
+// most 1 LSB at exact .5 boundaries — inside the stated RGBA8 tolerance).
+__device__ __forceinline__ void store_rgba8(uint8_t *ptr, uint32_t pitch, int x, int y, v4 c)
+{
+	*reinterpret_cast<uint32_t *>(ptr + size_t(y) * pitch + size_t(x) * 4u) = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24);
+}
+
+// ---- FXAA (fxaa.frag:20-67) --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_fxaa(Tex8<4> tex, uint8_t *out, uint32_t out_pitch, gr_push_fxaa push)
+{
+	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
+	const int y = blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	if (x >= tex.w || y >= tex.h)
+		return;
+	const float FXAA_REDUCE_MIN = 1.0f / 128.0f, FXAA_REDUCE_MUL = 1.0f / 8.0f, FXAA_SPAN_MAX = 8.0f;
+	const v2 inv_resolution = mk2(push.inv_resolution[0], push.inv_resolution[1]);
+	const v2 uv = mk2((float(x) + 0.5f) * inv_resolution.x, (float(y) + 0.5f) * inv_resolution.y);
+	const v3 rgbNW = xyz(tex.sample(uv, -1, -1)), rgbNE = xyz(tex.sample(uv, +1, -1));
+	const v3 rgbSW = xyz(tex.sample(uv, -1, +1)), rgbSE = xyz(tex.sample(uv, +1, +1));
+	const v3 texColor = xyz(tex.sample(uv));
+	const v3 luma = mk3(0.299f, 0.587f, 0.114f);
+	const float lumaNW = dot3(rgbNW, luma), lumaNE = dot3(rgbNE, luma), lumaSW = dot3(rgbSW, luma), lumaSE = dot3(rgbSE, luma);
+	const float lumaM = dot3(texColor, luma);
+	const float lumaMin = fminf(lumaM, fminf(fminf(lumaNW, lumaNE), fminf(lumaSW, lumaSE)));
+	const float lumaMax = fmaxf(lumaM, fmaxf(fmaxf(lumaNW, lumaNE), fmaxf(lumaSW, lumaSE)));
+	v2 dir;
+	dir.x = -((lumaNW + lumaNE) - (lumaSW + lumaSE));
+	dir.y = ((lumaNW + lumaSW) - (lumaNE + lumaSE));
+	const float dirReduce = fmaxf((lumaNW + lumaNE + lumaSW + lumaSE) * (0.25f * FXAA_REDUCE_MUL), FXAA_REDUCE_MIN);
+	const float rcpDirMin = 1.0f / (fminf(fabsf(dir.x), fabsf(dir.y)) + dirReduce);
+	dir = mk2(clampfv(dir.x * rcpDirMin, -FXAA_SPAN_MAX, FXAA_SPAN_MAX), clampfv(dir.y * rcpDirMin, -FXAA_SPAN_MAX, FXAA_SPAN_MAX)) * inv_resolution;
+	const v3 rgbA = 0.5f * (xyz(tex.sample(uv + dir * (1.0f / 3.0f - 0.5f))) + xyz(tex.sample(uv + dir * (2.0f / 3.0f - 0.5f))));
+	const v3 rgbB = rgbA * 0.5f + 0.25f * (xyz(tex.sample(uv + dir * -0.5f)) + xyz(tex.sample(uv + dir * 0.5f)));
+	const float lumaB = dot3(rgbB, luma);
+	const v3 color = ((lumaB < lumaMin) || (lumaB > lumaMax)) ? rgbA : rgbB;
+	store_rgba8(out, out_pitch, x, y, mk4(color.x, color.y, color.z, 1.0f));
+}
+
+// ---- SMAA ---------------------------------------------------------------------------------------------------------------
+struct SmaaPreset
+{
+	float threshold;
+	int max_search_steps;
+	int max_search_steps_diag;
+	float corner_rounding_norm;
+	int diag;
+	int corner;
+};
+
+static SmaaPreset smaa_preset(int quality)
+{
+	switch (quality) // SMAA.hlsl:304-324
+	{
+	case 0: return {0.15f, 4, 8, 0.25f, 0, 0};
+	case 1: return {0.1f, 8, 8, 0.25f, 0, 0};
+	case 2: return {0.1f, 16, 8, 0.25f, 1, 1};
+	default: return {0.05f, 32, 16, 0.25f, 1, 1};
+	}
+}
+
+// SMAALumaEdgeDetectionPS (SMAA.hlsl:689-740).  Every pixel is written (0 = what the reference leaves as the clear value
+// when the fragment is discarded), so no separate clear pass is needed.
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_edges(Tex8<4> tex, uint8_t *edges, uint32_t edges_pitch, gr_push_smaa push,
+                                                                       SmaaPreset P)
+{
+	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
+	const int y = blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	if (x >= tex.w || y >= tex.h)
+		return;
+	const v2 rt = mk2(push.rt_metrics[0], push.rt_metrics[1]);
+	const v2 tc = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
+	const v3 weights = mk3(0.2126f, 0.7152f, 0.0722f);
+	auto luma = [&](v2 uv) { return dot3(xyz(tex.sample(uv)), weights); };
+	uint32_t result = 0u;
+	const float L = luma(tc);
+	const float Lleft = luma(fma2(rt, mk2(-1.0f, 0.0f), tc)), Ltop = luma(fma2(rt, mk2(0.0f, -1.0f), tc));
+	const v2 delta_xy = mk2(fabsf(L - Lleft), fabsf(L - Ltop));
+	v2 e = mk2(stepf(P.threshold, delta_xy.x), stepf(P.threshold, delta_xy.y));
+	if (e.x + e.y != 0.0f)
+	{
+		const float Lright = luma(fma2(rt, mk2(1.0f, 0.0f), tc)), Lbottom = luma(fma2(rt, mk2(0.0f, 1.0f), tc));
+		v2 delta_zw = mk2(fabsf(L - Lright), fabsf(L - Lbottom));
+		v2 maxDelta = mk2(fmaxf(delta_xy.x, delta_zw.x), fmaxf(delta_xy.y, delta_zw.y));
+		const float Lleftleft = luma(fma2(rt, mk2(-2.0f, 0.0f), tc)), Ltoptop = luma(fma2(rt, mk2(0.0f, -2.0f), tc));
+		delta_zw = mk2(fabsf(Lleft - Lleftleft), fabsf(Ltop - Ltoptop));
+		maxDelta = mk2(fmaxf(maxDelta.x, delta_zw.x), fmaxf(maxDelta.y, delta_zw.y));
+		const float finalDelta = fmaxf(maxDelta.x, maxDelta.y);
+		e.x *= stepf(finalDelta, 2.0f * delta_xy.x);
+		e.y *= stepf(finalDelta, 2.0f * delta_xy.y);
+		result = unorm8(e.x) | (unorm8(e.y) << 8);
+	}
+	*reinterpret_cast<uint16_t *>(edges + size_t(y) * edges_pitch + size_t(x) * 2u) = uint16_t(result);
+}
+
+struct SmaaWeights
+{
+	Tex8<2> edges;
+	Tex8<2> area;
+	Tex8<1> search;
+	v4 rt;
+	SmaaPreset P;
+
+	__device__ __forceinline__ static v2 rg(v4 v) { return mk2(v.x, v.y); }
+	__device__ __forceinline__ v2 rtxy() const { return mk2(rt.x, rt.y); }
+
+	__device__ static v2 decode_diag2(v2 e)
+	{
+		e.x = e.x * fabsf(5.0f * e.x - 5.0f * 0.75f);
+		return mk2(roundf(e.x), roundf(e.y));
+	}
+	__device__ static v4 decode_diag4(v4 e)
+	{
+		e.x = e.x * fabsf(5.0f * e.x - 5.0f * 0.75f);
+		e.z = e.z * fabsf(5.0f * e.z - 5.0f * 0.75f);
+		return mk4(roundf(e.x), roundf(e.y), roundf(e.z), roundf(e.w));
+	}
+	__device__ v2 search_diag1(v2 texcoord, v2 dir, v2 &e) const
+	{
+		v4 coord = mk4(texcoord.x, texcoord.y, -1.0f, 1.0f);
+		while (coord.z < float(P.max_search_steps_diag - 1) && coord.w > 0.9f)
+		{
+			coord.x = fmaf(rt.x, dir.x, coord.x);
+			coord.y = fmaf(rt.y, dir.y, coord.y);
+			coord.z = fmaf(1.0f, 1.0f, coord.z);
+			e = rg(edges.sample(mk2(coord.x, coord.y)));
+			coord.w = dot2(e, mk2(0.5f, 0.5f));
+		}
+		return mk2(coord.z, coord.w);
+	}
+	__device__ v2 search_diag2(v2 texcoord, v2 dir, v2 &e) const
+	{
+		v4 coord = mk4(texcoord.x, texcoord.y, -1.0f, 1.0f);
+		coord.x += 0.25f * rt.x;
+		while (coord.z < float(P.max_search_steps_diag - 1) && coord.w > 0.9f)
+		{
+			coord.x = fmaf(rt.x, dir.x, coord.x);
+			coord.y = fmaf(rt.y, dir.y, coord.y);
+			coord.z = fmaf(1.0f, 1.0f, coord.z);
+			e = decode_diag2(rg(edges.sample(mk2(coord.x, coord.y))));
+			coord.w = dot2(e, mk2(0.5f, 0.5f));
+		}
+		return mk2(coord.z, coord.w);
+	}
+	__device__ v2 area_diag(v2 dist, v2 e, float offset) const
+	{
+		v2 texcoord = fma2(mk2(20.0f, 20.0f), e, dist);
+		const v2 px = mk2(1.0f / 160.0f, 1.0f / 560.0f);
+		texcoord = fma2(px, texcoord, 0.5f * px);
+		texcoord.x += 0.5f;
+		texcoord.y += (1.0f / 7.0f) * offset;
+		return rg(area.sample(texcoord));
+	}
+	__device__ v2 diag_weights(v2 texcoord, v2 e) const
+	{
+		v2 weights = mk2(0.0f, 0.0f);
+		v4 d;
+		v2 end = mk2(0.0f, 0.0f);
+		if (e.x > 0.0f)
+		{
+			const v2 r = search_diag1(texcoord, mk2(-1.0f, 1.0f), end);
+			d.x = r.x;
+			d.z = r.y;
+			d.x += float(end.y > 0.9f);
+		}
+		else
+		{
+			d.x = 0.0f;
+			d.z = 0.0f;
+		}
+		{
+			const v2 r = search_diag1(texcoord, mk2(1.0f, -1.0f), end);
+			d.y = r.x;
+			d.w = r.y;
+		}
+		if (d.x + d.y > 2.0f)
+		{
+			const v4 coords = mk4(fmaf(-d.x + 0.25f, rt.x, texcoord.x), fmaf(d.x, rt.y, texcoord.y), fmaf(d.y, rt.x, texcoord.x),
+			                      fmaf(-d.y - 0.25f, rt.y, texcoord.y));
+			const v2 a = rg(edges.sample(mk2(coords.x, coords.y), -1, 0));
+			const v2 b = rg(edges.sample(mk2(coords.z, coords.w), 1, 0));
+			const v4 dec = decode_diag4(mk4(a.x, a.y, b.x, b.y));
+			const v4 c = mk4(dec.y, dec.x, dec.w, dec.z);
+			v2 cc = fma2(mk2(2.0f, 2.0f), mk2(c.x, c.z), mk2(c.y, c.w));
+			if (d.z >= 0.9f)
+				cc.x = 0.0f;
+			if (d.w >= 0.9f)
+				cc.y = 0.0f;
+			weights = weights + area_diag(mk2(d.x, d.y), cc, 0.0f);
+		}
+
+		{
+			const v2 r = search_diag2(texcoord, mk2(-1.0f, -1.0f), end);
+			d.x = r.x;
+			d.z = r.y;
+		}
+		if (edges.sample(texcoord, 1, 0).x > 0.0f)
+		{
+			const v2 r = search_diag2(texcoord, mk2(1.0f, 1.0f), end);
+			d.y = r.x;
+			d.w = r.y;
+			d.y += float(end.y > 0.9f);
+		}
+		else
+		{
+			d.y = 0.0f;
+			d.w = 0.0f;
+		}
+		if (d.x + d.y > 2.0f)
+		{
+			const v4 coords = mk4(fmaf(-d.x, rt.x, texcoord.x), fmaf(-d.x, rt.y, texcoord.y), fmaf(d.y, rt.x, texcoord.x), fmaf(d.y, rt.y, texcoord.y));
+			v4 c;
+			c.x = edges.sample(mk2(coords.x, coords.y), -1, 0).y;
+			c.y = edges.sample(mk2(coords.x, coords.y), 0, -1).x;
+			const v4 zw = edges.sample(mk2(coords.z, coords.w), 1, 0);
+			c.z = zw.y;
+			c.w = zw.x;
+			v2 cc = fma2(mk2(2.0f, 2.0f), mk2(c.x, c.z), mk2(c.y, c.w));
+			if (d.z >= 0.9f)
+				cc.x = 0.0f;
+			if (d.w >= 0.9f)
+				cc.y = 0.0f;
+			const v2 ar = area_diag(mk2(d.x, d.y), cc, 0.0f);
+			weights = weights + mk2(ar.y, ar.x);
+		}
+		return weights;
+	}
+
+	__device__ float search_length(v2 e, float offset) const
+	{
+		v2 scale = mk2(66.0f * 0.5f, 33.0f * -1.0f);
+		v2 bias = mk2(66.0f * offset, 33.0f * 1.0f);
+		scale = scale + mk2(-1.0f, 1.0f);
+		bias = bias + mk2(0.5f, -0.5f);
+		scale = scale * mk2(1.0f / 64.0f, 1.0f / 16.0f);
+		bias = bias * mk2(1.0f / 64.0f, 1.0f / 16.0f);
+		return search.sample(fma2(scale, e, bias)).x;
+	}
+	__device__ float search_x_left(v2 texcoord, float end) const
+	{
+		v2 e = mk2(0.0f, 1.0f);
+		while (texcoord.x > end && e.y > 0.8281f && e.x == 0.0f)
+		{
+			e = rg(edges.sample(texcoord));
+			texcoord = fma2(mk2(-2.0f, -0.0f), rtxy(), texcoord);
+		}
+		const float offset = fmaf(-(255.0f / 127.0f), search_length(e, 0.0f), 3.25f);
+		return fmaf(rt.x, offset, texcoord.x);
+	}
+	__device__ float search_x_right(v2 texcoord, float end) const
+	{
+		v2 e = mk2(0.0f, 1.0f);
+		while (texcoord.x < end && e.y > 0.8281f && e.x == 0.0f)
+		{
+			e = rg(edges.sample(texcoord));
+			texcoord = fma2(mk2(2.0f, 0.0f), rtxy(), texcoord);
+		}
+		const float offset = fmaf(-(255.0f / 127.0f), search_length(e, 0.5f), 3.25f);
+		return fmaf(-rt.x, offset, texcoord.x);
+	}
+	__device__ float search_y_up(v2 texcoord, float end) const
+	{
+		v2 e = mk2(1.0f, 0.0f);
+		while (texcoord.y > end && e.x > 0.8281f && e.y == 0.0f)
+		{
+			e = rg(edges.sample(texcoord));
+			texcoord = fma2(mk2(-0.0f, -2.0f), rtxy(), texcoord);
+		}
+		const float offset = fmaf(-(255.0f / 127.0f), search_length(mk2(e.y, e.x), 0.0f), 3.25f);
+		return fmaf(rt.y, offset, texcoord.y);
+	}
+	__device__ float search_y_down(v2 texcoord, float end) const
+	{
+		v2 e = mk2(1.0f, 0.0f);
+		while (texcoord.y < end && e.x > 0.8281f && e.y == 0.0f)
+		{
+			e = rg(edges.sample(texcoord));
+			texcoord = fma2(mk2(0.0f, 2.0f), rtxy(), texcoord);
+		}
+		const float offset = fmaf(-(255.0f / 127.0f), search_length(mk2(e.y, e.x), 0.5f), 3.25f);
+		return fmaf(-rt.y, offset, texcoord.y);
+	}
+	__device__ v2 area_lookup(v2 dist, float e1, float e2) const
+	{
+		v2 texcoord = fma2(mk2(16.0f, 16.0f), mk2(roundf(4.0f * e1), roundf(4.0f * e2)), dist);
+		const v2 px = mk2(1.0f / 160.0f, 1.0f / 560.0f);
+		texcoord = fma2(px, texcoord, 0.5f * px);
+		texcoord.y = fmaf(1.0f / 7.0f, 0.0f, texcoord.y);
+		return rg(area.sample(texcoord));
+	}
+	__device__ void corner(v2 &weights, v4 texcoord, v2 d, bool horizontal) const
+	{
+		if (!P.corner)
+			return;
+		const v2 leftRight = mk2(stepf(d.x, d.y), stepf(d.y, d.x));
+		v2 rounding = leftRight * (1.0f - P.corner_rounding_norm);
+		const float sum = leftRight.x + leftRight.y;
+		rounding = mk2(rounding.x / sum, rounding.y / sum);
+		v2 factor = mk2(1.0f, 1.0f);
+		if (horizontal)
+		{
+			factor.x -= rounding.x * edges.sample(mk2(texcoord.x, texcoord.y), 0, 1).x;
+			factor.x -= rounding.y * edges.sample(mk2(texcoord.z, texcoord.w), 1, 1).x;
+			factor.y -= rounding.x * edges.sample(mk2(texcoord.x, texcoord.y), 0, -2).x;
+			factor.y -= rounding.y * edges.sample(mk2(texcoord.z, texcoord.w), 1, -2).x;
+		}
+		else
+		{
+			factor.x -= rounding.x * edges.sample(mk2(texcoord.x, texcoord.y), 1, 0).y;
+			factor.x -= rounding.y * edges.sample(mk2(texcoord.z, texcoord.w), 1, 1).y;
+			factor.y -= rounding.x * edges.sample(mk2(texcoord.x, texcoord.y), -2, 0).y;
+			factor.y -= rounding.y * edges.sample(mk2(texcoord.z, texcoord.w), -2, 1).y;
+		}
+		weights = weights * mk2(clampfv(factor.x, 0.0f, 1.0f), clampfv(factor.y, 0.0f, 1.0f));
+	}
+
+	__device__ v4 weights_at(int x, int y) const
+	{
+		const v2 texcoord = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
+		const v2 pixcoord = mk2(texcoord.x * rt.z, texcoord.y * rt.w);
+		const v4 off0 = mk4(fmaf(rt.x, -0.25f, texcoord.x), fmaf(rt.y, -0.125f, texcoord.y), fmaf(rt.x, 1.25f, texcoord.x), fmaf(rt.y, -0.125f, texcoord.y));
+		const v4 off1 = mk4(fmaf(rt.x, -0.125f, texcoord.x), fmaf(rt.y, -0.25f, texcoord.y), fmaf(rt.x, -0.125f, texcoord.x), fmaf(rt.y, 1.25f, texcoord.y));
+		const float steps = float(P.max_search_steps);
+		const v4 off2 = mk4(fmaf(rt.x, -2.0f * steps, off0.x), fmaf(rt.x, 2.0f * steps, off0.z), fmaf(rt.y, -2.0f * steps, off1.y),
+		                    fmaf(rt.y, 2.0f * steps, off1.w));
+
+		v4 weights = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+		v2 e = rg(edges.sample(texcoord));
+		if (e.y > 0.0f)
+		{
+			bool orthogonal = true;
+			if (P.diag)
+			{
+				const v2 dw = diag_weights(texcoord, e);
+				weights.x = dw.x;
+				weights.y = dw.y;
+				orthogonal = (weights.x == -weights.y);
+			}
+			if (orthogonal)
+			{
+				v2 d;
+				v3 coords;
+				coords.x = search_x_left(mk2(off0.x, off0.y), off2.x);
+				coords.y = off1.y;
+				d.x = coords.x;
+				const float e1 = edges.sample(mk2(coords.x, coords.y)).x;
+				coords.z = search_x_right(mk2(off0.z, off0.w), off2.y);
+				d.y = coords.z;
+				d = mk2(fabsf(roundf(fmaf(rt.z, d.x, -pixcoord.x))), fabsf(roundf(fmaf(rt.z, d.y, -pixcoord.x))));
+				const v2 sqrt_d = mk2(sqrtf(d.x), sqrtf(d.y));
+				const float e2 = edges.sample(mk2(coords.z, coords.y), 1, 0).x;
+				v2 wrg = area_lookup(sqrt_d, e1, e2);
+				coords.y = texcoord.y;
+				corner(wrg, mk4(coords.x, coords.y, coords.z, coords.y), d, true);
+				weights.x = wrg.x;
+				weights.y = wrg.y;
+			}
+			else
+				e.x = 0.0f;
+		}
+		if (e.x > 0.0f)
+		{
+			v2 d;
+			v3 coords;
+			coords.y = search_y_up(mk2(off1.x, off1.y), off2.z);
+			coords.x = off0.x;
+			d.x = coords.y;
+			const float e1 = edges.sample(mk2(coords.x, coords.y)).y;
+			coords.z = search_y_down(mk2(off1.z, off1.w), off2.w);
+			d.y = coords.z;
+			d = mk2(fabsf(roundf(fmaf(rt.w, d.x, -pixcoord.y))), fabsf(roundf(fmaf(rt.w, d.y, -pixcoord.y))));
+			const v2 sqrt_d = mk2(sqrtf(d.x), sqrtf(d.y));
+			const float e2 = edges.sample(mk2(coords.x, coords.z), 0, 1).y;
+			v2 wba = area_lookup(sqrt_d, e1, e2);
+			coords.x = texcoord.x;
+			corner(wba, mk4(coords.x, coords.y, coords.x, coords.z), d, false);
+			weights.z = wba.x;
+			weights.w = wba.y;
+		}
+		return weights;
+	}
+};
+
+// SMAABlendingWeightCalculationPS.  The reference runs this quad under a depth mask EQUAL to the edge pass's
+// non-discarded pixels (smaa.cpp:101-112,170-177); the mask is the edge texel itself here: zero edge => zero weights.
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_weights(SmaaWeights S, uint8_t *out, uint32_t out_pitch)
+{
+	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
+	const int y = blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	if (x >= S.edges.w || y >= S.edges.h)
+		return;
+	const uint16_t e = *reinterpret_cast<const uint16_t *>(S.edges.ptr + size_t(y) * S.edges.pitch + size_t(x) * 2u);
+	uint32_t packed = 0u;
+	if (e != 0)
+	{
+		const v4 w = S.weights_at(x, y);
+		packed = unorm8(w.x) | (unorm8(w.y) << 8) | (unorm8(w.z) << 16) | (unorm8(w.w) << 24);
+	}
+	*reinterpret_cast<uint32_t *>(out + size_t(y) * out_pitch + size_t(x) * 4u) = packed;
+}
+
+// SMAANeighborhoodBlendingPS (SMAA.hlsl:1252-1308)
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_blend(Tex8<4> ctex, Tex8<4> btex, uint8_t *out, uint32_t out_pitch, gr_push_smaa push)
+{
+	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
+	const int y = blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	if (x >= ctex.w || y >= ctex.h)
+		return;
+	const v2 rt = mk2(push.rt_metrics[0], push.rt_metrics[1]);
+	const v2 texcoord = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
+	const v4 offset = mk4(fmaf(rt.x, 1.0f, texcoord.x), fmaf(rt.y, 0.0f, texcoord.y), fmaf(rt.x, 0.0f, texcoord.x), fmaf(rt.y, 1.0f, texcoord.y));
+	v4 a;
+	a.x = btex.sample(mk2(offset.x, offset.y)).w;
+	a.y = btex.sample(mk2(offset.z, offset.w)).y;
+	const v4 c = btex.sample(texcoord);
+	a.w = c.x;
+	a.z = c.z;
+	v4 result;
+	if (a.x + a.y + a.z + a.w < 1e-5f)
+		result = ctex.sample(texcoord);
+	else
+	{
+		const bool hz = fmaxf(a.x, a.z) > fmaxf(a.y, a.w);
+		v4 blendingOffset = mk4(0.0f, a.y, 0.0f, a.w);
+		v2 blendingWeight = mk2(a.y, a.w);
+		if (hz)
+		{
+			blendingOffset = mk4(a.x, 0.0f, a.z, 0.0f);
+			blendingWeight = mk2(a.x, a.z);
+		}
+		const float sum = blendingWeight.x + blendingWeight.y;
+		blendingWeight = mk2(blendingWeight.x / sum, blendingWeight.y / sum);
+		const v4 bc = mk4(fmaf(blendingOffset.x, rt.x, texcoord.x), fmaf(blendingOffset.y, rt.y, texcoord.y), fmaf(blendingOffset.z, -rt.x, texcoord.x),
+		                  fmaf(blendingOffset.w, -rt.y, texcoord.y));
+		result = blendingWeight.x * ctex.sample(mk2(bc.x, bc.y));
+		result = result + blendingWeight.y * ctex.sample(mk2(bc.z, bc.w));
+	}
+	store_rgba8(out, out_pitch, x, y, result);
+}
+
+// ---- TAA resolve (taa_resolve.frag + reprojection.h) -------------------------------------------------------------------------
+__device__ __forceinline__ v3 taa_tonemap(v3 c)
+{
+	c = c * 8.0f;
+	return c * (1.0f / (fmaxf(c.x, fmaxf(c.y, c.z)) + 1.0f));
+}
+__device__ __forceinline__ v3 taa_tonemap_invert(v3 c)
+{
+	return (1.0f / 8.0f) * c * (1.0f / (1.0f - fmaxf(c.x, fmaxf(c.y, c.z))));
+}
+__device__ __forceinline__ v3 rgb_to_ycgco(v3 c)
+{
+	return mk3(0.25f * c.x + 0.5f * c.y + 0.25f * c.z, 0.5f * c.y - 0.25f * c.x - 0.25f * c.z, 0.5f * c.x - 0.5f * c.z);
+}
+__device__ __forceinline__ v3 ycgco_to_rgb(v3 c)
+{
+	const float tmp = c.x - c.y;
+	return mk3(tmp + c.z, c.x + c.y, tmp - c.z);
+}
+__device__ __forceinline__ v3 hdr_to_taa(v3 c) { return rgb_to_ycgco(taa_tonemap(c)); }
+__device__ __forceinline__ v3 taa_to_hdr(v3 c)
+{
+	const v3 r = ycgco_to_rgb(c);
+	return taa_tonemap_invert(mk3(clampfv(r.x, 0.0f, 0.999f), clampfv(r.y, 0.0f, 0.999f), clampfv(r.z, 0.0f, 0.999f)));
+}
+__device__ __forceinline__ v3 clamp_box(v3 color, v3 lo, v3 hi, bool aabb)
+{
+	if (!aabb)
+		return mk3(clampfv(color.x, lo.x, hi.x), clampfv(color.y, lo.y, hi.y), clampfv(color.z, lo.z, hi.z));
+	const v3 center = 0.5f * (lo + hi);
+	const v3 radius = max3v(0.5f * (hi - lo), mk3(0.0001f, 0.0001f, 0.0001f));
+	const v3 v = color - center;
+	const v3 units = v / radius;
+	const float max_unit = fmaxf(fmaxf(fabsf(units.x), fabsf(units.y)), fabsf(units.z));
+	return max_unit > 1.0f ? center + v / max_unit : color;
+}
+
+struct TaaArgs
+{
+	DevImage current, depth, mv, history;
+	DevImageRW out_color, out_history;
+	float reproj[16];
+	float rt[4];
+	int quality;
+	int has_history;
+};
+
+__device__ __forceinline__ v3 sample_linear3(const DevImage &img, float u, float v)
+{
+	const float fx = u * float(img.w) - 0.5f;
+	const float fy = v * float(img.h) - 0.5f;
+	const float flx = floorf(fx), fly = floorf(fy);
+	const float a = fx - flx, b = fy - fly;
+	const int ix = int(flx), iy = int(fly);
+	const float4 t00 = load_rgba16f_clamped(img, ix, iy), t10 = load_rgba16f_clamped(img, ix + 1, iy);
+	const float4 t01 = load_rgba16f_clamped(img, ix, iy + 1), t11 = load_rgba16f_clamped(img, ix + 1, iy + 1);
+	const v3 top = mk3(t00.x, t00.y, t00.z) * (1.0f - a) + mk3(t10.x, t10.y, t10.z) * a;
+	const v3 bot = mk3(t01.x, t01.y, t01.z) * (1.0f - a) + mk3(t11.x, t11.y, t11.z) * a;
+	return top * (1.0f - b) + bot * b;
+}
+
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs a)
+{
+	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
+	const int y = blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	const int w = a.current.w, h = a.current.h;
+	if (x >= w || y >= h)
+		return;
+	const v4 rt = mk4(a.rt[0], a.rt[1], a.rt[2], a.rt[3]);
+	const v2 uv = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
+	auto cur_at = [&](int px, int py) {
+		const float4 t = load_rgba16f_clamped(a.current, px, py);
+		return hdr_to_taa(mk3(t.x, t.y, t.z));
+	};
+	auto depth_at = [&](int px, int py) {
+		return *reinterpret_cast<const float *>(a.depth.ptr + size_t(clampi(py, 0, h - 1)) * a.depth.pitch + size_t(clampi(px, 0, w - 1)) * 4u);
+	};
+	auto mv_at = [&](int px, int py) {
+		const f16x2 m = *reinterpret_cast<const f16x2 *>(a.mv.ptr + size_t(clampi(py, 0, h - 1)) * a.mv.pitch + size_t(clampi(px, 0, w - 1)) * 4u);
+		return mk2(float(m.x), float(m.y));
+	};
+
+	const v3 current_c = cur_at(x, y);
+	v3 out_c, hist_c;
+	if (!a.has_history)
+	{
+		out_c = taa_to_hdr(current_c);
+		hist_c = current_c;
+	}
+	else
+	{
+		v2 mv;
+		float d;
+		auto consider = [&](int ox, int oy) {
+			const float dd = depth_at(x + ox, y + oy);
+			if (dd > d)
+			{
+				mv = mv_at(x + ox, y + oy);
+				d = dd;
+			}
+		};
+		if (a.quality <= 1)
+		{
+			mv = mv_at(x - 1, y);
+			d = depth_at(x - 1, y);
+			consider(0, 0);
+			consider(0, -1);
+			consider(0, 1);
+			consider(1, 0);
+		}
+		else
+		{
+			mv = mv_at(x + 1, y + 1);
+			d = depth_at(x + 1, y + 1);
+			consider(-1, 0);
+			consider(0, 0);
+			consider(0, -1);
+			consider(-1, -1);
+			consider(1, 0);
+			consider(1, -1);
+			consider(-1, 1);
+			consider(0, 1);
+		}
+
+		v2 old_uv;
+		if (mv.x == 0.0f && mv.y == 0.0f)
+		{
+			const float cx = 2.0f * uv.x - 1.0f, cy = 2.0f * uv.y - 1.0f;
+			v4 rp = mk4(a.reproj[0], a.reproj[1], a.reproj[2], a.reproj[3]) * cx;
+			rp = rp + mk4(a.reproj[4], a.reproj[5], a.reproj[6], a.reproj[7]) * cy;
+			rp = rp + mk4(a.reproj[8], a.reproj[9], a.reproj[10], a.reproj[11]) * d;
+			rp = rp + mk4(a.reproj[12], a.reproj[13], a.reproj[14], a.reproj[15]) * 1.0f;
+			old_uv = mk2(rp.x / rp.w, rp.y / rp.w);
+			mv = uv - old_uv;
+		}
+		else
+			old_uv = uv - mv;
+
+		v3 history_color;
+		if (a.quality == 2)
+		{
+			const v2 samplePos = mk2(old_uv.x * rt.z, old_uv.y * rt.w);
+			const v2 texPos1 = mk2(floorf(samplePos.x - 0.5f) + 0.5f, floorf(samplePos.y - 0.5f) + 0.5f);
+			const v2 f = samplePos - texPos1;
+			auto W0 = [](float t) { return t * (-0.5f + t * (1.0f - 0.5f * t)); };
+			auto W1 = [](float t) { return 1.0f + t * t * (-2.5f + 1.5f * t); };
+			auto W2 = [](float t) { return t * (0.5f + t * (2.0f - 1.5f * t)); };
+			auto W3 = [](float t) { return t * t * (-0.5f + 0.5f * t); };
+			const v2 w0 = mk2(W0(f.x), W0(f.y)), w1 = mk2(W1(f.x), W1(f.y)), w2 = mk2(W2(f.x), W2(f.y)), w3 = mk2(W3(f.x), W3(f.y));
+			const v2 w12 = w1 + w2;
+			const v2 offset12 = w2 / (w1 + w2);
+			const v2 texPos0 = (texPos1 - mk2(1.0f, 1.0f)) * mk2(rt.x, rt.y);
+			const v2 texPos3 = (texPos1 + mk2(2.0f, 2.0f)) * mk2(rt.x, rt.y);
+			const v2 texPos12 = (texPos1 + offset12) * mk2(rt.x, rt.y);
+			v3 r = mk3(0.0f, 0.0f, 0.0f);
+			r = r + sample_linear3(a.history, texPos0.x, texPos0.y) * w0.x * w0.y;
+			r = r + sample_linear3(a.history, texPos12.x, texPos0.y) * w12.x * w0.y;
+			r = r + sample_linear3(a.history, texPos3.x, texPos0.y) * w3.x * w0.y;
+			r = r + sample_linear3(a.history, texPos0.x, texPos12.y) * w0.x * w12.y;
+			r = r + sample_linear3(a.history, texPos12.x, texPos12.y) * w12.x * w12.y;
+			r = r + sample_linear3(a.history, texPos3.x, texPos12.y) * w3.x * w12.y;
+			r = r + sample_linear3(a.history, texPos0.x, texPos3.y) * w0.x * w3.y;
+			r = r + sample_linear3(a.history, texPos12.x, texPos3.y) * w12.x * w3.y;
+			r = r + sample_linear3(a.history, texPos3.x, texPos3.y) * w3.x * w3.y;
+			history_color = r;
+		}
+		else
+			history_color = sample_linear3(a.history, old_uv.x, old_uv.y);
+
+		const float mv_length = len2(mv);
+		const float mv_fast = fminf(mv_length * 50.0f, 1.0f);
+		const float gamma = mixf(1.5f, 0.5f, mv_fast);
+		history_color = mk3(clampfv(history_color.x, 0.0f, 1.0f), clampfv(history_color.y, -1.0f, 1.0f), clampfv(history_color.z, -1.0f, 1.0f));
+		const float lerp_factor = (1.0f + 2.0f * mv_fast) / 16.0f;
+
+		const v3 c11 = current_c;
+		const v3 c01 = cur_at(x - 1, y), c21 = cur_at(x + 1, y), c10 = cur_at(x, y - 1), c12 = cur_at(x, y + 1);
+		v3 lo, hi;
+		if (a.quality == 0)
+		{
+			lo = min3v(min3v(min3v(min3v(c11, c01), c21), c10), c12);
+			hi = max3v(max3v(max3v(max3v(c11, c01), c21), c10), c12);
+		}
+		else
+		{
+			const v3 c00 = cur_at(x - 1, y - 1), c22 = cur_at(x + 1, y + 1), c02 = cur_at(x - 1, y + 1), c20 = cur_at(x + 1, y - 1);
+			if (a.quality == 1)
+			{
+				const v3 clo = min3v(min3v(min3v(min3v(c11, c01), c21), c10), c12);
+				const v3 chi = max3v(max3v(max3v(max3v(c11, c01), c21), c10), c12);
+				lo = min3v(min3v(min3v(min3v(clo, c00), c22), c02), c20);
+				hi = max3v(max3v(max3v(max3v(chi, c00), c22), c02), c20);
+				lo = 0.5f * (clo + lo);
+				hi = 0.5f * (chi + hi);
+			}
+			else
+			{
+				const v3 m1 = (c00 + 2.0f * c01 + c02 + 2.0f * c10 + 4.0f * c11 + 2.0f * c12 + c20 + 2.0f * c21 + c22) / 16.0f;
+				const v3 m2 = c00 * c00 + 2.0f * c01 * c01 + c02 * c02 + 2.0f * c10 * c10 + 4.0f * c11 * c11 + 2.0f * c12 * c12 + c20 * c20 +
+				              2.0f * c21 * c21 + c22 * c22;
+				const v3 variance = max3v(m2 / 16.0f - m1 * m1, mk3(0.0f, 0.0f, 0.0f));
+				const v3 sigma = mk3(sqrtf(variance.x), sqrtf(variance.y), sqrtf(variance.z));
+				lo = m1 - gamma * sigma;
+				hi = m1 + gamma * sigma;
+			}
+		}
+		history_color = clamp_box(history_color, lo, hi, a.quality >= 1);
+		const v3 mixed = mix3(history_color, current_c, lerp_factor);
+		hist_c = mixed;
+		out_c = taa_to_hdr(mixed);
+	}
+	store_rgba16f(a.out_color, x, y, make_float4(out_c.x, out_c.y, out_c.z, 1.0f));
+	store_rgba16f(a.out_history, x, y, make_float4(hist_c.x, hist_c.y, hist_c.z, 1.0f));
+}
+
+static bool check_image(const gr_image *img, uint32_t bpp, uint32_t w, uint32_t h)
+{
+	return img && img->ptr && img->width == w && img->height == h && img->pitch_bytes >= w * bpp;
+}
+static bool is_rgba8(uint32_t f) { return f == GR_FORMAT_R8G8B8A8_SRGB || f == GR_FORMAT_R8G8B8A8_UNORM; }
+static dim3 aa_grid(uint32_t w, uint32_t h) { return dim3(gr_div_up(w, AA_BLOCK_X), gr_div_up(h, AA_BLOCK_Y)); }
+} // namespace
+
+extern "C" {
+
+int gr_smaa_set_luts(gr_ctx *ctx, const void *area_rg8, const void *search_r8)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, area_rg8 && search_r8);
+	if (!ctx->smaa_area)
+		GR_CHECK_HIP(ctx, hipMalloc(&ctx->smaa_area, 160 * 560 * 2));
+	if (!ctx->smaa_search)
+		GR_CHECK_HIP(ctx, hipMalloc(&ctx->smaa_search, 64 * 16));
+	GR_CHECK_HIP(ctx, hipMemcpy(ctx->smaa_area, area_rg8, 160 * 560 * 2, hipMemcpyHostToDevice));
+	GR_CHECK_HIP(ctx, hipMemcpy(ctx->smaa_search, search_r8, 64 * 16, hipMemcpyHostToDevice));
+	return GR_OK;
+}
+
+int gr_fxaa(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_push_fxaa *push)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push && in && out && in->width && in->height);
+	GR_CHECK_ARG(ctx, check_image(in, 4, in->width, in->height) && check_image(out, 4, in->width, in->height));
+	GR_CHECK_ARG(ctx, is_rgba8(in->format) && is_rgba8(out->format) && in->ptr != out->ptr);
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "fxaa"};
+	hipLaunchKernelGGL(k_fxaa, aa_grid(in->width, in->height), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), make_tex8<4>(in),
+	                   static_cast<uint8_t *>(out->ptr), out->pitch_bytes, *push);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_smaa_edge_detection(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *edges, const gr_push_smaa *push, int quality)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push && color && edges && color->width && color->height);
+	GR_CHECK_ARG(ctx, quality >= 0 && quality <= 3);
+	GR_CHECK_ARG(ctx, check_image(color, 4, color->width, color->height) && is_rgba8(color->format));
+	GR_CHECK_ARG(ctx, check_image(edges, 2, color->width, color->height) && edges->format == GR_FORMAT_R8G8_UNORM);
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_edge_detection"};
+	hipLaunchKernelGGL(k_smaa_edges, aa_grid(color->width, color->height), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), make_tex8<4>(color),
+	                   static_cast<uint8_t *>(edges->ptr), edges->pitch_bytes, *push, smaa_preset(quality));
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push && edges && weights && edges->width && edges->height);
+	GR_CHECK_ARG(ctx, quality >= 0 && quality <= 3);
+	GR_CHECK_ARG(ctx, check_image(edges, 2, edges->width, edges->height) && edges->format == GR_FORMAT_R8G8_UNORM);
+	GR_CHECK_ARG(ctx, check_image(weights, 4, edges->width, edges->height) && weights->format == GR_FORMAT_R8G8B8A8_UNORM);
+	if (!ctx->smaa_area || !ctx->smaa_search)
+		return ctx->fail(GR_ERR_INVALID_ARGUMENT, "gr_smaa_blend_weight: SMAA lookup tables not set (gr_smaa_set_luts)");
+	SmaaWeights S;
+	S.edges = make_tex8<2>(edges);
+	S.area = {static_cast<const uint8_t *>(ctx->smaa_area), 160, 560, 320u};
+	S.search = {static_cast<const uint8_t *>(ctx->smaa_search), 64, 16, 64u};
+	S.rt = v4{push->rt_metrics[0], push->rt_metrics[1], push->rt_metrics[2], push->rt_metrics[3]};
+	S.P = smaa_preset(quality);
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_blend_weight"};
+	hipLaunchKernelGGL(k_smaa_weights, aa_grid(edges->width, edges->height), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), S,
+	                   static_cast<uint8_t *>(weights->ptr), weights->pitch_bytes);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_smaa_neighbor_blend(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *weights, const gr_image *out,
+                           const gr_push_smaa *push)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push && color && weights && out && color->width && color->height);
+	GR_CHECK_ARG(ctx, check_image(color, 4, color->width, color->height) && is_rgba8(color->format));
+	GR_CHECK_ARG(ctx, check_image(weights, 4, color->width, color->height) && weights->format == GR_FORMAT_R8G8B8A8_UNORM);
+	GR_CHECK_ARG(ctx, check_image(out, 4, color->width, color->height) && is_rgba8(out->format) && out->ptr != color->ptr);
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_neighbor_blend"};
+	hipLaunchKernelGGL(k_smaa_blend, aa_grid(color->width, color->height), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream),
+	                   make_tex8<4>(color), make_tex8<4>(weights), static_cast<uint8_t *>(out->ptr), out->pitch_bytes, *push);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_taa_resolve(gr_ctx *ctx, gr_stream stream, const gr_image *current, const gr_image *depth, const gr_image *mv, const gr_image *history,
+                   const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push && current && depth && mv && out_color && out_history);
+	GR_CHECK_ARG(ctx, quality >= 0 && quality <= 2);
+	const uint32_t w = current->width, h = current->height;
+	GR_CHECK_ARG(ctx, w && h);
+	GR_CHECK_ARG(ctx, check_image(current, 8, w, h) && current->format == GR_FORMAT_R16G16B16A16_SFLOAT);
+	GR_CHECK_ARG(ctx, check_image(depth, 4, w, h) && depth->format == GR_FORMAT_D32_SFLOAT);
+	GR_CHECK_ARG(ctx, check_image(mv, 4, w, h) && mv->format == GR_FORMAT_R16G16_SFLOAT);
+	GR_CHECK_ARG(ctx, check_image(out_color, 8, w, h) && out_color->format == GR_FORMAT_R16G16B16A16_SFLOAT);
+	GR_CHECK_ARG(ctx, check_image(out_history, 8, w, h) && out_history->format == GR_FORMAT_R16G16B16A16_SFLOAT);
+	GR_CHECK_ARG(ctx, !history || (check_image(history, 8, w, h) && history->format == GR_FORMAT_R16G16B16A16_SFLOAT && history->ptr != out_history->ptr));
+	auto dev = [](const gr_image *i) { return DevImage{static_cast<const uint8_t *>(i->ptr), int(i->width), int(i->height), i->pitch_bytes}; };
+	auto devrw = [](const gr_image *i) { return DevImageRW{static_cast<uint8_t *>(i->ptr), int(i->width), int(i->height), i->pitch_bytes}; };
+	TaaArgs a = {};
+	a.current = dev(current);
+	a.depth = dev(depth);
+	a.mv = dev(mv);
+	if (history)
+		a.history = dev(history);
+	a.out_color = devrw(out_color);
+	a.out_history = devrw(out_history);
+	for (int i = 0; i < 16; i++)
+		a.reproj[i] = push->reproj[i];
+	for (int i = 0; i < 4; i++)
+		a.rt[i] = push->rt_metrics[i];
+	a.quality = quality;
+	a.has_history = history != nullptr;
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "taa_resolve"};
+	hipLaunchKernelGGL(k_taa_resolve, aa_grid(w, h), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), a);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+}

@@ -69,7 +69,7 @@ int gra_set_camera(gra_app *app, const float *projection16, const float *view16)
 		mat4 p, v;
 		unpack_mat4(p, projection16);
 		unpack_mat4(v, view16);
-		app->app->get_context().set_camera(p, v);
+		app->app->set_base_camera(p, v);
 	});
 }
 
@@ -291,6 +291,23 @@ int gra_collect_timestamps(gra_app *app, gra_timestamp *entries, int max_entries
 		app->error = e.what();
 		return -1;
 	}
+}
+
+int gra_get_taa_reprojection(gra_app *app, float *reproj16)
+{
+	return guarded(app, [&]() {
+		mat4 m = app->app->get_taa_reprojection();
+		memcpy(reproj16, m.data(), 16 * sizeof(float));
+	});
+}
+
+int gra_set_smaa_luts(gra_app *app, const void *area_rg8, const void *search_r8)
+{
+	return guarded(app, [&]() {
+		auto *ctx = app->app->get_device().get_context();
+		if (gr_smaa_set_luts(ctx, area_rg8, search_r8) < 0)
+			throw std::runtime_error(gr_last_error(ctx));
+	});
 }
 
 void *gra_get_kernel_context(gra_app *app)

@@ -32,8 +32,8 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 	hdr_options.dynamic_exposure = config.dynamic_exposure != 0;
 
 	// Default camera of the survey's synthetic scene; gra_set_camera / gra_set_render_parameters override it.
-	context.set_camera(perspective(1.0471975512f, float(config.width) / float(config.height), 0.1f, 100.0f),
-	                   look_at(vec3(0.0f, 2.0f, 8.0f), vec3(0.0f, 1.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f)));
+	set_base_camera(perspective(1.0471975512f, float(config.width) / float(config.height), 0.1f, 100.0f),
+	                look_at(vec3(0.0f, 2.0f, 8.0f), vec3(0.0f, 1.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f)));
 
 	graph.enable_timestamps(config.enable_timestamps != 0);
 	if (!device_holder)
@@ -57,6 +57,35 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 ImageSpaceApplication::~ImageSpaceApplication()
 {
 	wait_idle();
+}
+
+void ImageSpaceApplication::set_base_camera(const mat4 &projection, const mat4 &view)
+{
+	base_projection = projection;
+	base_view = view;
+	has_base_camera = true;
+	context.set_camera(projection, view);
+}
+
+mat4 ImageSpaceApplication::get_taa_reprojection() const
+{
+	return translate(vec3(0.5f, 0.5f, 0.0f)) * scale(vec3(0.5f, 0.5f, 1.0f)) * jitter.get_history_view_proj(1) * jitter.get_history_inv_view_proj(0);
+}
+
+static PostAAType to_post_aa_type(int32_t v)
+{
+	switch (v)
+	{
+	case GRA_POST_AA_FXAA: return PostAAType::FXAA;
+	case GRA_POST_AA_SMAA_LOW: return PostAAType::SMAA_Low;
+	case GRA_POST_AA_SMAA_MEDIUM: return PostAAType::SMAA_Medium;
+	case GRA_POST_AA_SMAA_HIGH: return PostAAType::SMAA_High;
+	case GRA_POST_AA_SMAA_ULTRA: return PostAAType::SMAA_Ultra;
+	case GRA_POST_AA_TAA_LOW: return PostAAType::TAA_Low;
+	case GRA_POST_AA_TAA_MEDIUM: return PostAAType::TAA_Medium;
+	case GRA_POST_AA_TAA_HIGH: return PostAAType::TAA_High;
+	default: return PostAAType::None;
+	}
 }
 
 void ImageSpaceApplication::set_lights(const gra_light_desc *descs, uint32_t count)
@@ -122,6 +151,24 @@ void ImageSpaceApplication::add_hdr_input_pass(const std::string &tag)
 	pass.set_build_render_pass([this, &out](HIP::CommandBuffer &cmd) {
 		if (gbuffer_dirty)
 			cmd.copy_image(graph.get_physical_texture_resource(out), *src_emissive);
+	});
+}
+
+// Motion vectors come from the scene renderer in Granite (add_mv_pass, scene_viewer_application.cpp:1010-1060); here the
+// uploaded synthetic RG16F image (zeros when none was uploaded) is copied into "mv-<tag>".
+void ImageSpaceApplication::add_mv_pass(const std::string &tag)
+{
+	AttachmentInfo mv;
+	mv.format = VK_FORMAT_R16G16_SFLOAT;
+	auto &pass = graph.add_pass(tagcat("mv", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+	auto &out = pass.add_color_output(tagcat("mv", tag), mv);
+	pass.set_build_render_pass([this, &out](HIP::CommandBuffer &cmd) {
+		if (!gbuffer_dirty)
+			return;
+		if (src_mv)
+			cmd.copy_image(graph.get_physical_texture_resource(out), *src_mv);
+		else
+			cmd.clear_image(graph.get_physical_texture_resource(out));
 	});
 }
 
@@ -209,16 +256,41 @@ void ImageSpaceApplication::bake_render_graph()
 	else
 		add_hdr_input_pass(tag);
 
-	std::string hdr_source = tagcat("HDR", tag);
-	std::string ui_source = hdr_source;
+	std::string light_output = tagcat("HDR", tag);
+	std::string ui_source = light_output;
+	const PostAAType pre_aa = to_post_aa_type(config.pre_aa);
+	const PostAAType post_aa = to_post_aa_type(config.post_aa);
+	jitter.init(TemporalJitter::Type::None, vec2(0.0f));
+
+	bool temporal = pre_aa == PostAAType::TAA_Low || pre_aa == PostAAType::TAA_Medium || pre_aa == PostAAType::TAA_High;
+	if (temporal)
+	{
+		if (!config.enable_lighting)
+			throw std::logic_error("TAA needs the depth attachment of the deferred graph.");
+		add_mv_pass(tag);
+	}
 
 	if (config.hdr_bloom)
 	{
+		bool resolved = setup_before_post_chain_antialiasing(pre_aa, graph, jitter, context, 1.0f, light_output, tagcat("depth", tag),
+		                                                     tagcat("mv", tag), "HDR-resolved");
+		const std::string hdr_source = resolved ? "HDR-resolved" : light_output;
 		if (config.compute_post)
 			setup_hdr_postprocess_compute(graph, frame, hdr_source, "tonemapped", hdr_options);
 		else
 			setup_hdr_postprocess(graph, frame, hdr_source, "tonemapped", hdr_options);
 		ui_source = "tonemapped";
+	}
+
+	if (post_aa != PostAAType::None)
+	{
+		// PostAAType is a single enum in the viewer; the API composes TAA before and FXAA/SMAA after the chain, but the
+		// later jitter.init() wins (smaa.cpp:60-67), so the temporal table is restored afterwards.
+		TemporalJitter saved = jitter;
+		if (setup_after_post_chain_antialiasing(post_aa, graph, jitter, 1.0f, ui_source, tagcat("depth", tag), "post-aa-output"))
+			ui_source = "post-aa-output";
+		if (temporal)
+			jitter = saved;
 	}
 
 	graph.set_backbuffer_source(ui_source);
@@ -242,6 +314,14 @@ void ImageSpaceApplication::render_frame()
 
 	HIP::Image *backbuffer = swapchain[swapchain_index].get();
 	swapchain_index = (swapchain_index + 1) % unsigned(swapchain.size());
+
+	if (jitter.get_jitter_type() != TemporalJitter::Type::None)
+	{
+		if (!has_base_camera)
+			throw std::logic_error("Temporal AA needs gra_set_camera (projection + view), not verbatim render parameters.");
+		jitter.step(base_projection, base_view);
+		context.set_camera(jitter.get_jittered_projection(), base_view);
+	}
 
 	graph.setup_attachments(device, backbuffer);
 	if (config.enable_lighting)

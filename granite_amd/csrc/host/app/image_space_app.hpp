@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../../../include/granite_app.h"
 #include "../lights/clusterer.hpp"
+#include "../post/aa.hpp"
 #include "../post/hdr.hpp"
 #include "../render_context.hpp"
 #include "../render_graph.hpp"
@@ -40,6 +41,11 @@ public:
 	}
 	RenderGraph &get_graph() { return graph; }
 	RenderContext &get_context() { return context; }
+	TemporalJitter &get_jitter() { return jitter; }
+	// Camera as the application sees it (un-jittered); with a temporal AA active each frame renders with
+	// jitter.get_jittered_projection() like SceneViewerApplication::update_scene (scene_viewer_application.cpp:1431-1433).
+	void set_base_camera(const mat4 &projection, const mat4 &view);
+	mat4 get_taa_reprojection() const;
 	LightClusterer &get_clusterer() { return cluster; }
 	HIP::Image *get_last_backbuffer() { return last_backbuffer; }
 	const gra_config &get_config() const { return config; }
@@ -55,6 +61,9 @@ private:
 	LightClusterer cluster;
 	TaskComposer composer;
 	HDROptions hdr_options;
+	TemporalJitter jitter;
+	mat4 base_projection, base_view;
+	bool has_base_camera = false;
 
 	// "Scene": light objects + node transforms, and the synthetic G-buffer sources.
 	std::vector<std::unique_ptr<PositionalLight>> light_objects;
@@ -72,5 +81,6 @@ private:
 	void bake_render_graph();
 	void add_main_pass_deferred(const std::string &tag);
 	void add_hdr_input_pass(const std::string &tag);
+	void add_mv_pass(const std::string &tag);
 };
 } // namespace Granite

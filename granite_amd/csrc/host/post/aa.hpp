@@ -1,0 +1,78 @@
+// Anti-aliasing pass setup: renderer/post/{aa,fxaa,smaa,temporal}.hpp restated on the HIP executor.
+// Live variants only: FXAA, SMAA 1x Low..Ultra, TAA Low/Medium/High.  FXAA-2phase and SMAA-T2X do not
+// compile in the reference (missing GLSL functions), FSR2 needs an absent third_party module.
+#pragma once
+#include <string>
+#include <vector>
+#include "../render_context.hpp"
+#include "../render_graph.hpp"
+
+namespace Granite
+{
+enum class PostAAType
+{
+	FXAA,
+	FXAA_2Phase,
+	SMAA_Low,
+	SMAA_Medium,
+	SMAA_High,
+	SMAA_Ultra,
+	SMAA_Ultra_T2X,
+	TAA_Low,
+	TAA_Medium,
+	TAA_High,
+	TAA_FSR2,
+	None
+};
+
+enum class SMAAPreset { Low, Medium, High, Ultra, Ultra_T2X };
+enum class TAAQuality { Low, Medium, High };
+
+// renderer/post/temporal.{hpp,cpp}:40-197 — sub-pixel jitter tables + the ring of saved view-projections the TAA
+// reprojection matrix is built from.
+class TemporalJitter
+{
+public:
+	enum class Type { FXAA_2Phase, SMAA_T2X, TAA_8Phase, TAA_16Phase, Custom, None };
+	TemporalJitter();
+	void reset() { phase = 0; }
+	void init(Type type_, vec2 backbuffer_resolution);
+	void step(const mat4 &projection, const mat4 &view);
+	const mat4 &get_jitter_matrix() const { return jitter_table[phase]; }
+	const mat4 &get_jittered_projection() const { return saved_jittered_projection; }
+	const mat4 &get_history_view_proj(int frames) const { return saved_view_proj[get_offset_phase(frames)]; }
+	const mat4 &get_history_inv_view_proj(int frames) const { return saved_inv_view_proj[get_offset_phase(frames)]; }
+	const mat4 &get_history_jittered_view_proj(int frames) const { return saved_jittered_view_proj[get_offset_phase(frames)]; }
+	unsigned get_jitter_phase() const { return phase; }
+	unsigned get_jitter_count() const { return jitter_count; }
+	Type get_jitter_type() const { return type; }
+
+private:
+	unsigned phase = 0;
+	unsigned jitter_count = 0;
+	std::vector<mat4> jitter_table;
+	std::vector<mat4> saved_jittered_view_proj;
+	std::vector<mat4> saved_view_proj;
+	std::vector<mat4> saved_inv_view_proj;
+	mat4 saved_jittered_projection;
+	Type type = Type::None;
+	unsigned get_offset_phase(int frames) const;
+};
+
+// fxaa.cpp:28-55
+void setup_fxaa_postprocess(RenderGraph &graph, const std::string &input, const std::string &output, VkFormat output_format = VK_FORMAT_UNDEFINED);
+// smaa.cpp:32-208
+void setup_smaa_postprocess(RenderGraph &graph, TemporalJitter &jitter, float scaling_factor, const std::string &input,
+                            const std::string &input_depth, const std::string &output, SMAAPreset preset);
+// temporal.cpp:199-266
+void setup_taa_resolve(RenderGraph &graph, TemporalJitter &jitter, float scaling_factor, const std::string &input, const std::string &input_depth,
+                       const std::string &input_mv, const std::string &output, TAAQuality quality);
+
+// aa.cpp:176-253
+bool setup_before_post_chain_antialiasing(PostAAType type, RenderGraph &graph, TemporalJitter &jitter, const RenderContext &context,
+                                          float scaling_factor, const std::string &input, const std::string &input_depth,
+                                          const std::string &input_mv, const std::string &output);
+bool setup_after_post_chain_antialiasing(PostAAType type, RenderGraph &graph, TemporalJitter &jitter, float scaling_factor,
+                                         const std::string &input, const std::string &input_depth, const std::string &output);
+PostAAType string_to_post_antialiasing_type(const char *type);
+} // namespace Granite

@@ -189,3 +189,25 @@ def make_motion_vectors(width: int, height: int) -> np.ndarray:
     mv[:, x0:x1, 0] = 2.0 / width
     mv[:, x0:x1, 1] = 1.0 / height
     return _f32_to_f16_bits(mv)
+
+
+def make_ldr_pattern(width: int, height: int, seed: int = SEED) -> np.ndarray:
+    """Gamma-space RGBA8 test card for the AA passes: flat regions, axis-aligned steps, 45-degree and shallow diagonal
+    edges, circles and a noisy band, so FXAA spans, SMAA orthogonal + diagonal searches, corner rounding and LUT fetches
+    are all exercised."""
+    r = _rng(5, seed)
+    y, x = np.mgrid[0:height, 0:width].astype(np.float64)
+    img = np.zeros((height, width, 3), np.float64)
+    img[...] = (0.18, 0.22, 0.30)
+    img[(x > 0.15 * width) & (x < 0.45 * width) & (y > 0.1 * height) & (y < 0.5 * height)] = (0.85, 0.80, 0.20)  # box
+    img[(x + y) % max(width // 6, 8) < max(width // 12, 4)] *= 0.55  # 45-degree stripes
+    img[(y - 0.23 * x) > 0.62 * height] = (0.05, 0.55, 0.65)  # shallow diagonal
+    img[(y + 3.1 * x) < 0.35 * height] = (0.9, 0.9, 0.95)  # steep diagonal
+    for cx, cy, rad, col in ((0.7, 0.3, 0.12, (0.95, 0.15, 0.1)), (0.62, 0.72, 0.2, (0.1, 0.1, 0.1)), (0.3, 0.8, 0.07, (1.0, 1.0, 1.0))):
+        img[(x - cx * width) ** 2 + (y - cy * height) ** 2 < (rad * min(width, height)) ** 2] = col
+    band = (y > 0.88 * height)
+    img[band] = r.uniform(0.0, 1.0, (int(band.sum()), 3))
+    rgba = np.empty((height, width, 4), np.uint8)
+    rgba[..., :3] = np.clip(np.rint(img * 255.0), 0, 255).astype(np.uint8)
+    rgba[..., 3] = 255
+    return rgba

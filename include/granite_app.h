@@ -115,6 +115,10 @@ typedef struct gra_timestamp
 	double total_ms;
 } gra_timestamp;
 int gra_collect_timestamps(gra_app *app, gra_timestamp *entries, int max_entries);
+/* T(.5,.5,0) S(.5,.5,1) VP_prev inv(VP_cur) as pushed to the last taa-resolve (temporal.cpp:239-243). */
+int gra_get_taa_reprojection(gra_app *app, float *reproj16);
+/* SMAA AreaTex (160x560 RG8) / SearchTex (64x16 R8) payloads, host pointers; needed before a frame with an SMAA pass. */
+int gra_set_smaa_luts(gra_app *app, const void *area_rg8, const void *search_r8);
 /* Per-kernel timing lives in the kernel library: gr_timing_* on this context. */
 void *gra_get_kernel_context(gra_app *app); /* gr_ctx* */
 void *gra_get_stream(gra_app *app);         /* hipStream_t of the generic queue */

@@ -299,6 +299,45 @@ typedef struct gr_lighting_args
 } gr_lighting_args;
 int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args);
 
+/* ---- anti-aliasing (renderer/post/{fxaa,smaa,temporal}.cpp) ------------------------------------------------------------ */
+
+/* setup_fxaa_postprocess (fxaa.cpp:28-55) + fxaa.frag.  `in` is read through its UNORM alias (cmd.set_unorm_texture):
+ * the stored bytes of the tonemapped R8G8B8A8_SRGB image.  out: R8G8B8A8_SRGB or _UNORM (same bytes either way: the
+ * shader's decode_srgb and the attachment's encode cancel). */
+typedef struct gr_push_fxaa
+{
+	float inv_resolution[2];
+} gr_push_fxaa;
+int gr_fxaa(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_push_fxaa *push);
+
+/* SMAA 1x (smaa.cpp:32-208 + SMAA.hlsl).  quality 0..3 = SMAA_PRESET_LOW..ULTRA (smaa_common.h).
+ * rt_metrics = (1/w, 1/h, w, h) (smaa.cpp:129-133). */
+typedef struct gr_push_smaa
+{
+	float rt_metrics[4];
+} gr_push_smaa;
+/* AreaTex 160x560 R8G8_UNORM and SearchTex 64x16 R8_UNORM payloads (assets/textures/smaa/{area,search}.gtx), host pointers. */
+int gr_smaa_set_luts(gr_ctx *ctx, const void *area_rg8, const void *search_r8);
+/* smaa-edge pass: SMAALumaEdgeDetectionPS.  edges: R8G8_UNORM; every pixel is written (0 where the shader discards). */
+int gr_smaa_edge_detection(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *edges, const gr_push_smaa *push, int quality);
+/* smaa-weights pass: SMAABlendingWeightCalculationPS, SMAA_SUBPIXEL_MODE 0.  weights: R8G8B8A8_UNORM.  The reference's
+ * D16 "smaa-mask" depth-EQUAL test is equivalent to "edge texel != 0", which is what the kernel tests. */
+int gr_smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality);
+/* smaa-blend pass: SMAANeighborhoodBlendingPS. */
+int gr_smaa_neighbor_blend(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *weights, const gr_image *out,
+                           const gr_push_smaa *push);
+
+/* setup_taa_resolve (temporal.cpp:199-266) + taa_resolve.frag.  quality 0..2 = TAAQuality Low/Medium/High.
+ * history NULL => REPROJECTION_HISTORY = 0 (first frame).  current/out_color/history: R16G16B16A16_SFLOAT,
+ * depth D32_SFLOAT, mv R16G16_SFLOAT.  reproj = T(.5,.5,0) S(.5,.5,1) VP_prev inv(VP_cur) (temporal.cpp:239-243). */
+typedef struct gr_push_taa
+{
+	float reproj[16];
+	float rt_metrics[4];
+} gr_push_taa;
+int gr_taa_resolve(gr_ctx *ctx, gr_stream stream, const gr_image *current, const gr_image *depth, const gr_image *mv,
+                   const gr_image *history, const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality);
+
 #ifdef __cplusplus
 }
 #endif

@@ -237,3 +237,54 @@ def lighting(gbuf: dict, rp, prm, lights, type_mask, bitmask, ranges, dir_color,
 # ---- scalar helpers ---------------------------------------------------------------------------------------------------
 def half_to_float(bits: np.ndarray) -> np.ndarray:
     return np.asarray(bits, np.uint16).view(np.float16).astype(np.float32)
+
+
+# ---- anti-aliasing --------------------------------------------------------------------------------------------------------
+def fxaa(rgba8: np.ndarray, target_srgb: bool = True) -> np.ndarray:
+    h, w = rgba8.shape[:2]
+    src = np.ascontiguousarray(rgba8, np.uint8)
+    out = np.zeros((h, w, 4), np.uint8)
+    lib().orc_fxaa(_p(src), w, h, _p(out), int(target_srgb))
+    return out
+
+
+def smaa_edges(rgba8: np.ndarray, quality: int) -> np.ndarray:
+    h, w = rgba8.shape[:2]
+    src = np.ascontiguousarray(rgba8, np.uint8)
+    out = np.zeros((h, w, 2), np.uint8)
+    lib().orc_smaa_edges(_p(src), w, h, _p(out), quality)
+    return out
+
+
+def smaa_weights(edges: np.ndarray, area: np.ndarray, search: np.ndarray, quality: int) -> np.ndarray:
+    h, w = edges.shape[:2]
+    e = np.ascontiguousarray(edges, np.uint8)
+    a, s = np.ascontiguousarray(area, np.uint8), np.ascontiguousarray(search, np.uint8)
+    out = np.zeros((h, w, 4), np.uint8)
+    lib().orc_smaa_weights(_p(e), w, h, _p(a), _p(s), _p(out), quality)
+    return out
+
+
+def smaa_blend(rgba8: np.ndarray, weights: np.ndarray, target_srgb: bool = True) -> np.ndarray:
+    h, w = rgba8.shape[:2]
+    src, wt = np.ascontiguousarray(rgba8, np.uint8), np.ascontiguousarray(weights, np.uint8)
+    out = np.zeros((h, w, 4), np.uint8)
+    lib().orc_smaa_blend(_p(src), _p(wt), w, h, _p(out), int(target_srgb))
+    return out
+
+
+def smaa(rgba8: np.ndarray, area, search, quality: int, target_srgb: bool = True):
+    e = smaa_edges(rgba8, quality)
+    wt = smaa_weights(e, area, search, quality)
+    return {"edges": e, "weights": wt, "out": smaa_blend(rgba8, wt, target_srgb)}
+
+
+def taa_resolve(current: np.ndarray, depth: np.ndarray, mv: np.ndarray, history, reproj16, quality: int):
+    w, h = _img16(current)
+    d = np.ascontiguousarray(depth, np.float32)
+    m = np.ascontiguousarray(mv, np.uint16)
+    r = np.ascontiguousarray(reproj16, np.float32)
+    out_c = np.zeros((h, w, 4), np.uint16)
+    out_h = np.zeros((h, w, 4), np.uint16)
+    lib().orc_taa_resolve(_p(current), _p(d), _p(m), _p(history), w, h, _p(r), quality, _p(out_c), _p(out_h))
+    return out_c, out_h
