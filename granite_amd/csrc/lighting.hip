@@ -9,18 +9,27 @@
 // HDR may be the same buffer (the reference's blend read-modify-write) or distinct ones (same values, same bytes).  The two
 // blend roundings of the reference are reproduced in registers: hdr = rne16(rne16(emissive + directional) + clustered).
 //
-// Wave mapping: a wave64 owns a 16x4 pixel tile (128 B HDR / 64 B albedo row segments).  The light loop is wave-uniform
-// exactly like the reference's subgroup path (clusterer_bindless.h:49-81): per 32-light word the lanes' range-trimmed
-// cell masks are OR-reduced across the wave, the union is walked with scalar bit ops, and each light record is fetched
-// with scalar loads (SGPR-resident, no LDS traffic) while all 64 lanes shade it.
+// Mapping.  A wave64 owns an 8x8 pixel tile and never synchronises with another wave (no LDS, no barriers); four waves
+// side by side form a 32x8 workgroup so every row of the workgroup is one 256 B HDR / 128 B G-buffer segment.  The light
+// loop is wave-uniform like the reference's subgroup path (clusterer_bindless.h:49-81), restructured for the scalar unit:
+//   1. gather: lane l fetches bitmask word (w_lo + l) of every cluster cell the tile touches (coalesced), ORs them and
+//      trims the word by the wave's Z-slice index window [min first, max last]; this is a superset of the reference's
+//      subgroupOr of per-lane trimmed masks.  Lights it adds lie outside their radius for the pixels concerned and
+//      contribute exactly 0 (point.h:38, spot.h:45), which is also why the reference's subgroup footprint cannot matter
+//      (oracle: orc_lighting_bruteforce_clustered).
+//   2. walk: the non-zero words are pulled into SGPRs (ballot + v_readlane) and their bits iterated with scalar bit ops;
+//      each 48-byte light record is fetched with scalar loads one candidate ahead of the shading, so the 64 lanes only
+//      ever issue BRDF arithmetic with the light in SGPR operands.
+//   3. a candidate no lane of the tile is within 1.001 radius of is skipped after its distance test (wave-uniform branch).
+// The BRDF is algebraically the reference's; normalisations are folded (dot products on the unnormalised light vector,
+// H.V = |V+L|/2, one rcp for G*D) to cut the per-light VALU count, which bounds this kernel on the 4096-light config.
 #include "ctx.hpp"
 #include "device_common.hpp"
 
 namespace
 {
-constexpr int LIGHT_TILE_W = 16;
-constexpr int LIGHT_TILE_H = 4; // per wave
-constexpr int LIGHT_WAVES = 4;  // waves per workgroup, stacked vertically -> 16x16 block tile
+constexpr int LIGHT_TILE = 8;  // wave tile edge
+constexpr int LIGHT_WAVES = 4; // waves per workgroup, side by side -> 32x8 block
 
 constexpr float PI_SIC = 3.1415628f; // assets/shaders/lights/pbr.h:4-6 (sic)
 
@@ -40,12 +49,13 @@ struct KernelArgs
 	int cl_res_x, cl_res_y;
 	int cl_num_lights, cl_num_lights_32, cl_z_max_index;
 	float cl_z_scale;
-	const gr_light_info *lights;
-	const uint32_t *type_mask;
-	const uint32_t *bitmask;
-	const uint2 *range;
-	const float *srgb_lut;
+	const gr_light_info *__restrict__ lights;
+	const uint32_t *__restrict__ type_mask;
+	const uint32_t *__restrict__ bitmask;
+	const uint2 *__restrict__ range;
+	const float *__restrict__ srgb_lut;
 	uint32_t flags;
+	int blocks_x, num_blocks, blocks_per_xcd;
 };
 
 struct float3_ { float x, y, z; };
@@ -55,92 +65,170 @@ __device__ __forceinline__ float3_ operator-(float3_ a, float3_ b) { return {a.x
 __device__ __forceinline__ float3_ operator*(float3_ a, float3_ b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 __device__ __forceinline__ float3_ operator*(float3_ a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ float dot(float3_ a, float3_ b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 __device__ __forceinline__ float rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 __device__ __forceinline__ float rsq(float v) { return __builtin_amdgcn_rsqf(v); }
+__device__ __forceinline__ float med3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); } // clamp
 
 // Per-pixel material terms hoisted out of the light loop.
 struct Surface
 {
-	float3_ pos, N, V, F0, diffuse; // diffuse = base * (1 - metallic) / PI
-	float NoV, m2, k, Gv;
+	float3_ pos, N, V, F0, omF0, diffuse; // omF0 = 1 - F0; diffuse = base * (1 - metallic) / PI
+	float NdV, m2m1, c0, k, omk, Gv;     // NdV unclamped; m2m1 = m^2 - 1; c0 = m^2 / (4 PI); Gv = NoV (1-k) + k
 };
 
-// Shared BRDF tail of compute_point_light / compute_spot_light / compute_lighting
-// (point.h:119-142, spot.h:122-145, lighting.h:26-45): returns NoL * (spec + diffuse) for light direction L.
-__device__ __forceinline__ float3_ shade(const Surface &s, float3_ L)
+// Shared BRDF tail of compute_point_light / compute_spot_light / compute_lighting (point.h:119-142, spot.h:122-145,
+// lighting.h:26-45) for a unit light direction L given through NdL = dot(N, L) and hh = |V + L|^2:
+//   H = (V + L) / |V + L|,  dot(H, V) = |V + L| / 2 (unit V, L),  dot(N, H) = (NdV + NdL) / |V + L|.
+// Returns NoL and brdf = F * G * D + (1 - F) * diffuse; the caller multiplies by NoL and the light colour.
+__device__ __forceinline__ float3_ brdf(const Surface &s, float NdL, float hh, float &NoL)
 {
-	float3_ H = s.V + L;
-	H = H * rsq(dot(H, H));
-	const float NoL = clampf(dot(s.N, L), 0.001f, 1.0f);
-	const float HoV = clampf(dot(H, s.V), 0.001f, 1.0f);
-	const float NoH = clampf(dot(s.N, H), 0.0001f, 1.0f);
+	NoL = med3(NdL, 0.001f, 1.0f);
+	const float inv_h = rsq(fmaxf(hh, 1e-30f));
+	const float HoV = med3(0.5f * hh * inv_h, 0.001f, 1.0f);
+	const float NoH = med3((s.NdV + NdL) * inv_h, 0.0001f, 1.0f);
 
 	const float omh = 1.0f - HoV;
 	const float omh2 = omh * omh;
 	const float f = omh2 * omh2 * omh; // pow(1 - HoV, 5)
-	const float omf = 1.0f - f;
-	const float3_ F = f3(fmaf(s.F0.x, omf, f), fmaf(s.F0.y, omf, f), fmaf(s.F0.z, omf, f)); // mix(F0, 1, f)
 
-	const float d = fmaf(fmaf(NoH, s.m2, -NoH), NoH, 1.0f);
-	const float D = s.m2 * rcp(PI_SIC * d * d);
-	const float Gl = fmaf(NoL, 1.0f - s.k, s.k);
-	const float G = 0.25f * rcp(fmaxf(s.Gv * Gl, 0.001f));
-	const float GD = G * D;
+	const float d = fmaf(NoH * NoH, s.m2m1, 1.0f);               // (NoH m2 - NoH) NoH + 1
+	const float g = fmaxf(s.Gv * fmaf(NoL, s.omk, s.k), 0.001f); // G = 0.25 / max(Gv Gl, 0.001)
+	const float GD = s.c0 * rcp(d * d * g);                      // G * D, D = m2 / (PI d^2)
 
-	return f3(NoL * fmaf(F.x, GD, (1.0f - F.x) * s.diffuse.x), NoL * fmaf(F.y, GD, (1.0f - F.y) * s.diffuse.y),
-	          NoL * fmaf(F.z, GD, (1.0f - F.z) * s.diffuse.z));
-}
-
-__device__ __forceinline__ float smooth_falloff(float x)
-{
-	// 1 - smoothstep(0.9, 1.0, x)
-	const float t = clampf((x - 0.9f) * (1.0f / (1.0f - 0.9f)), 0.0f, 1.0f);
-	return 1.0f - t * t * (3.0f - 2.0f * t);
+	// mix(F0, 1, f) * GD + (1 - mix(F0, 1, f)) * diffuse = F * (GD - diffuse) + diffuse
+	const float Fx = fmaf(s.omF0.x, f, s.F0.x), Fy = fmaf(s.omF0.y, f, s.F0.y), Fz = fmaf(s.omF0.z, f, s.F0.z);
+	return f3(fmaf(Fx, GD - s.diffuse.x, s.diffuse.x), fmaf(Fy, GD - s.diffuse.y, s.diffuse.y),
+	          fmaf(Fz, GD - s.diffuse.z, s.diffuse.z));
 }
 
 // clusterer_bindless_buffers.h:17-27
-__device__ __forceinline__ uint32_t cluster_mask_range(uint32_t mask, uint2 range, uint32_t start_index)
+__device__ __forceinline__ uint32_t cluster_mask_range(uint32_t mask, uint32_t range_x, uint32_t range_y, uint32_t start_index)
 {
-	const uint32_t rx = min(max(range.x, start_index), start_index + 32u);
-	const uint32_t ry = min(max(range.y + 1u, rx), start_index + 32u);
+	const uint32_t rx = min(max(range_x, start_index), start_index + 32u);
+	const uint32_t ry = min(max(range_y + 1u, rx), start_index + 32u);
 	const uint32_t num_bits = ry - rx;
 	const uint32_t range_mask = num_bits == 32u ? 0xffffffffu : ((1u << num_bits) - 1u) << (rx - start_index);
 	return mask & range_mask;
 }
 
+// Wave64 min/max -> SGPR: 4 DPP steps reduce each row of 16 lanes, the 4 row results meet on the scalar unit.
+template <bool IS_MAX>
+__device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t v)
+{
+	auto op = [](uint32_t a, uint32_t b) { return IS_MAX ? max(a, b) : min(a, b); };
+	v = op(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0xB1, 0xf, 0xf, false)));  // quad_perm [1,0,3,2]
+	v = op(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x4E, 0xf, 0xf, false)));  // quad_perm [2,3,0,1]
+	v = op(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x141, 0xf, 0xf, false))); // row_half_mirror
+	v = op(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x140, 0xf, 0xf, false))); // row_mirror
+	const uint32_t r0 = uint32_t(__builtin_amdgcn_readlane(int(v), 0)), r1 = uint32_t(__builtin_amdgcn_readlane(int(v), 16));
+	const uint32_t r2 = uint32_t(__builtin_amdgcn_readlane(int(v), 32)), r3 = uint32_t(__builtin_amdgcn_readlane(int(v), 48));
+	return op(op(r0, r1), op(r2, r3));
+}
+
+// A light as fetched: the raw 48-byte PositionalFragmentInfo (3 x 16 B scalar loads) + its type_mask word.  Nothing is
+// decoded at fetch time so no scalar instruction waits on the loads before the previous light has been shaded.
+struct LightRecord
+{
+	u32x4 q0; // color.xyz, spot_scale_bias
+	u32x4 q1; // position.xyz, offset_radius
+	u32x4 q2; // direction.xyz, inv_radius
+	uint32_t type_word;
+};
+
+__device__ __forceinline__ LightRecord fetch_light(const KernelArgs &a, int index)
+{
+	// index is wave-uniform: these are scalar loads (s_load_dwordx4), the record lives in SGPRs.
+	const u32x4 *rec = reinterpret_cast<const u32x4 *>(a.lights + index);
+	LightRecord r;
+	r.q0 = rec[0];
+	r.q1 = rec[1];
+	r.q2 = rec[2];
+	r.type_word = a.type_mask[index >> 5];
+	return r;
+}
+
+__device__ __forceinline__ float u2f(uint32_t v) { return __builtin_bit_cast(float, v); }
+
+// compute_point_light / compute_spot_light (point.h:33-84, spot.h:34-93, no shadows) for one wave-uniform light.
+__device__ __forceinline__ void shade_positional(const Surface &s, const LightRecord &li, int index, float3_ &result)
+{
+	const float inv_radius = u2f(li.q2.w);
+	const float3_ Lf = f3(u2f(li.q1.x), u2f(li.q1.y), u2f(li.q1.z)) - s.pos; // light_pos - world_pos
+	const float d2 = dot(Lf, Lf);
+	// Falloff is exactly 0 once dist * inv_radius >= 1: skip the light when no pixel of the tile is inside 1.001 r.
+	const float x2 = d2 * (inv_radius * inv_radius);
+	if (!__any(x2 < 1.002f))
+		return;
+
+	const float d2c = fmaxf(d2, 1e-30f);
+	const float inv_d = rsq(d2c);
+	const float len = d2c * inv_d;       // length(light_dir_full)
+	const float dist = fmaxf(0.1f, len); // light_dist
+	const float inv_d2 = inv_d * inv_d;
+	// 1 - smoothstep(0.9, 1.0, dist * inv_radius)
+	const float t = med3(fmaf(dist * inv_radius, 10.0f, -9.0f), 0.0f, 1.0f);
+	float atten = fmaf(-(t * t), fmaf(-2.0f, t, 3.0f), 1.0f);
+	const bool is_point = ((li.type_word >> (uint32_t(index) & 31u)) & 1u) != 0u;
+	if (!is_point)
+	{
+		// spot.h:41-46: cone = dot(normalize(world_pos - light_pos), direction) = -dot(Lf, direction) / |Lf|
+		const float cone_angle = -dot(Lf, f3(u2f(li.q2.x), u2f(li.q2.y), u2f(li.q2.z))) * inv_d;
+		// The packed halves go through a VGPR: hipcc (ROCm 7.2) otherwise folds lane .w of the SGPR quad into
+		// v_fma_mix_f32 as lane .x (observed: spots shaded with colour.x as scale/bias).
+		uint32_t sb_bits;
+		asm("v_mov_b32 %0, %1" : "=v"(sb_bits) : "s"(li.q0.w));
+		const f16x2 sb = __builtin_bit_cast(f16x2, sb_bits);
+		const float cone = med3(fmaf(cone_angle, float(sb.x), float(sb.y)), 0.0f, 1.0f);
+		atten *= cone * cone;
+		// Most of a spot's bounding sphere is outside its cone: spot_color == 0 for the whole tile -> returns 0.
+		if (!__any(atten > 0.0f))
+			return;
+	}
+	// colour = light colour * atten / dist^2; dist^2 = max(len, 0.1)^2
+	const float a2 = atten * fminf(inv_d2, 1.0f / (0.1f * 0.1f));
+
+	const float NdL = dot(s.N, Lf) * inv_d;
+	// |V + L|^2 with L = Lf / len: |len V + Lf|^2 / len^2
+	const float3_ Hs = f3(fmaf(s.V.x, len, Lf.x), fmaf(s.V.y, len, Lf.y), fmaf(s.V.z, len, Lf.z));
+	const float hh = dot(Hs, Hs) * inv_d2;
+	float NoL;
+	const float3_ b = brdf(s, NdL, hh, NoL);
+	const float w = NoL * a2;
+	result.x = fmaf(u2f(li.q0.x) * w, b.x, result.x);
+	result.y = fmaf(u2f(li.q0.y) * w, b.y, result.y);
+	result.z = fmaf(u2f(li.q0.z) * w, b.z, result.z);
+}
+
 __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 {
+	// XCD-aware tile order: block b runs on XCD b % 8; give each XCD one contiguous band of the screen so the cluster
+	// words and light records a band needs stay in that XCD's L2.
+	const int logical = int(blockIdx.x & 7u) * a.blocks_per_xcd + int(blockIdx.x >> 3);
+	if (logical >= a.num_blocks)
+		return;
+	const int block_x = logical % a.blocks_x, block_y = logical / a.blocks_x;
 	const int wave = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
-	const int x = blockIdx.x * LIGHT_TILE_W + (lane & (LIGHT_TILE_W - 1));
-	const int y = (blockIdx.y * LIGHT_WAVES + wave) * LIGHT_TILE_H + (lane / LIGHT_TILE_W);
+	const int tile_x0 = (block_x * LIGHT_WAVES + wave) * LIGHT_TILE, tile_y0 = block_y * LIGHT_TILE;
+	const int x = tile_x0 + (lane & (LIGHT_TILE - 1));
+	const int y = tile_y0 + (lane >> 3);
 	const int W = a.hdr.w, H = a.hdr.h;
 	const bool inside = x < W && y < H;
 
 	float depth = 0.0f;
-	if (inside)
-		depth = *reinterpret_cast<const float *>(a.depth.ptr + size_t(y) * a.depth.pitch + size_t(x) * 4u);
-	// depth test NOT_EQUAL against the quad at z = 0 (renderer.cpp:1056-1057): reverse-Z far plane untouched.
-	const bool active = inside && depth != 0.0f;
-	if (inside && !active && a.emissive.ptr != a.hdr.ptr)
-	{
-		// Far-plane pixel: the draws are depth-rejected, the target keeps the emissive value.
-		*reinterpret_cast<f16x4 *>(a.hdr.ptr + size_t(y) * a.hdr.pitch + size_t(x) * 8u) =
-		    *reinterpret_cast<const f16x4 *>(a.emissive.ptr + size_t(y) * a.emissive.pitch + size_t(x) * 8u);
-	}
-	if (!__any(active))
-		return;
-
 	uint32_t alb = 0, nrm = 0, mr = 0;
 	f16x4 dst = {0, 0, 0, 0};
-	if (active)
+	if (inside)
 	{
+		depth = *reinterpret_cast<const float *>(a.depth.ptr + size_t(y) * a.depth.pitch + size_t(x) * 4u);
 		alb = *reinterpret_cast<const uint32_t *>(a.albedo.ptr + size_t(y) * a.albedo.pitch + size_t(x) * 4u);
 		nrm = *reinterpret_cast<const uint32_t *>(a.normal.ptr + size_t(y) * a.normal.pitch + size_t(x) * 4u);
 		mr = *reinterpret_cast<const uint16_t *>(a.pbr.ptr + size_t(y) * a.pbr.pitch + size_t(x) * 2u);
 		dst = *reinterpret_cast<const f16x4 *>(a.emissive.ptr + size_t(y) * a.emissive.pitch + size_t(x) * 8u);
 	}
+	// depth test NOT_EQUAL against the quad at z = 0 (renderer.cpp:1056-1057): reverse-Z far-plane pixels keep the
+	// emissive value (both draws are depth-rejected).
+	const bool active = inside && depth != 0.0f;
 
 	// ---- G-buffer decode (clustering.frag:31-35) ----
 	const float3_ base = f3(a.srgb_lut[alb & 255u], a.srgb_lut[(alb >> 8) & 255u], a.srgb_lut[(alb >> 16) & 255u]);
@@ -173,16 +261,20 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 	float3_ V = cam - pos;
 	V = V * rsq(fmaxf(dot(V, V), 1e-30f));
 	s.V = V;
-	s.NoV = clampf(dot(N, V), 0.001f, 1.0f);
+	s.NdV = dot(N, V);
+	const float NoV = med3(s.NdV, 0.001f, 1.0f);
 	s.F0 = f3(fmaf(base.x - 0.04f, metallic, 0.04f), fmaf(base.y - 0.04f, metallic, 0.04f), fmaf(base.z - 0.04f, metallic, 0.04f));
+	s.omF0 = f3(1.0f - s.F0.x, 1.0f - s.F0.y, 1.0f - s.F0.z);
 	const float roughness = fmaf(mat_roughness, 0.75f, 0.25f);
 	const float m = roughness * roughness;
-	s.m2 = m * m;
+	const float m2 = m * m;
+	s.m2m1 = m2 - 1.0f;
+	s.c0 = m2 * (0.25f / PI_SIC);
 	const float r1 = roughness + 1.0f;
 	s.k = r1 * r1 * (1.0f / 8.0f);
-	s.Gv = fmaf(s.NoV, 1.0f - s.k, s.k);
-	const float dscale = (1.0f - metallic) * (1.0f / PI_SIC);
-	s.diffuse = base * dscale;
+	s.omk = 1.0f - s.k;
+	s.Gv = fmaf(NoV, s.omk, s.k);
+	s.diffuse = base * ((1.0f - metallic) * (1.0f / PI_SIC));
 
 	float3_ accum = f3(float(dst.x), float(dst.y), float(dst.z));
 
@@ -190,7 +282,10 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 	if (a.flags & GR_LIGHTING_DIRECTIONAL_BIT)
 	{
 		const float3_ L = f3(a.dir_direction[0], a.dir_direction[1], a.dir_direction[2]);
-		float3_ lit = f3(a.dir_color[0], a.dir_color[1], a.dir_color[2]) * shade(s, L);
+		const float3_ Hv = V + L;
+		float NoL;
+		const float3_ b = brdf(s, dot(N, L), dot(Hv, Hv), NoL);
+		float3_ lit = f3(a.dir_color[0] * NoL * b.x, a.dir_color[1] * NoL * b.y, a.dir_color[2] * NoL * b.z);
 		if (a.flags & GR_LIGHTING_AMBIENT_FALLBACK_BIT)
 			lit = lit + base * 0.05f;
 		// blend ONE/ONE, attachment store rounds to fp16
@@ -202,12 +297,7 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 	{
 		float3_ result = f3(0.0f, 0.0f, 0.0f);
 
-		int ccx = int(__fmul_rn(__fmul_rn(float(x) + 0.5f, a.inv_resolution[0]), a.cl_xy_scale[0]));
-		int ccy = int(__fmul_rn(__fmul_rn(float(y) + 0.5f, a.inv_resolution[1]), a.cl_xy_scale[1]));
-		ccx = clampi(ccx, 0, a.cl_res_x - 1);
-		ccy = clampi(ccy, 0, a.cl_res_y - 1);
-		const int cluster_base = (ccy * a.cl_res_x + ccx) * a.cl_num_lights_32;
-
+		// Slice lookup (clusterer_bindless.h:43-47) and the wave's light-index window.
 		const float dzx = __fsub_rn(pos.x, a.cl_camera_base[0]), dzy = __fsub_rn(pos.y, a.cl_camera_base[1]),
 		            dzz = __fsub_rn(pos.z, a.cl_camera_base[2]);
 		const float z = __fadd_rn(__fadd_rn(__fmul_rn(dzx, a.cl_camera_front[0]), __fmul_rn(dzy, a.cl_camera_front[1])),
@@ -217,58 +307,90 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		uint2 z_range = make_uint2(0xffffffffu, 0u);
 		if (active)
 			z_range = a.range[z_index];
+		const uint32_t win_lo = wave_minmax_u32<false>(z_range.x);
+		const uint32_t win_hi = wave_minmax_u32<true>(z_range.y);
 
-		const int z_start = __builtin_amdgcn_readfirstlane(int(wave_min_u32(z_range.x) >> 5u));
-		const int z_end = __builtin_amdgcn_readfirstlane(min(int(wave_max_u32(z_range.y) >> 5u), a.cl_num_lights_32 - 1));
-
-		for (int i = z_start; i <= z_end; i++)
+		if (win_lo <= win_hi)
 		{
-			uint32_t mask = 0u;
-			if (active)
-				mask = cluster_mask_range(a.bitmask[cluster_base + i], z_range, 32u * uint32_t(i));
-			uint32_t uni = __builtin_amdgcn_readfirstlane(wave_or(mask));
-			const uint32_t type_mask = a.type_mask[i];
+			// Cluster cells the tile touches (clusterer_bindless.h:39-42 evaluated at the tile corners; the per-pixel
+			// formula is monotonic, so every lane's cell lies in this rectangle).
+			const int xe = min(tile_x0 + LIGHT_TILE - 1, W - 1), ye = min(tile_y0 + LIGHT_TILE - 1, H - 1);
+			auto cell = [](int p, float inv_res, float scale, int res) {
+				return clampi(int(__fmul_rn(__fmul_rn(float(p) + 0.5f, inv_res), scale)), 0, res - 1);
+			};
+			const int cx0 = __builtin_amdgcn_readfirstlane(cell(tile_x0, a.inv_resolution[0], a.cl_xy_scale[0], a.cl_res_x));
+			const int cx1 = __builtin_amdgcn_readfirstlane(cell(xe, a.inv_resolution[0], a.cl_xy_scale[0], a.cl_res_x));
+			const int cy0 = __builtin_amdgcn_readfirstlane(cell(tile_y0, a.inv_resolution[1], a.cl_xy_scale[1], a.cl_res_y));
+			const int cy1 = __builtin_amdgcn_readfirstlane(cell(ye, a.inv_resolution[1], a.cl_xy_scale[1], a.cl_res_y));
 
-			while (uni != 0u)
+			const int word_lo = int(win_lo >> 5u);
+			const int word_hi = min(int(win_hi >> 5u), a.cl_num_lights_32 - 1);
+
+			for (int word_base = word_lo; word_base <= word_hi; word_base += 64)
 			{
-				const int bit = __builtin_ctz(uni);
-				uni &= uni - 1u;
-				const gr_light_info &li = a.lights[32 * i + bit]; // wave-uniform address -> scalar loads
-				const float3_ lpos = f3(li.position[0], li.position[1], li.position[2]);
-				float3_ Lf = lpos - pos;
-				const float d2 = dot(Lf, Lf);
-				const float inv_d = rsq(fmaxf(d2, 1e-30f));
-				const float3_ L = Lf * inv_d;
-				const float dist = fmaxf(0.1f, d2 * inv_d);
-				float atten = smooth_falloff(dist * li.inv_radius);
-				if (!((type_mask >> bit) & 1u))
+				// ---- gather: one candidate word per lane ----
+				const int my_word = word_base + lane;
+				uint32_t cand = 0u;
+				if (my_word <= word_hi)
 				{
-					// spot.h:41-46: cone = dot(normalize(world_pos - light_pos), direction) = -dot(L, direction)
-					const float cone_angle = -dot(L, f3(li.direction[0], li.direction[1], li.direction[2]));
-					const f16x2 sb = __builtin_bit_cast(f16x2, li.spot_scale_bias);
-					float cone = clampf(fmaf(cone_angle, float(sb.x), float(sb.y)), 0.0f, 1.0f);
-					atten *= cone * cone;
+					for (int cy = cy0; cy <= cy1; cy++)
+					{
+#pragma clang loop vectorize(disable) unroll(disable)
+						for (int cx = cx0; cx <= cx1; cx++)
+							cand |= a.bitmask[(cy * a.cl_res_x + cx) * a.cl_num_lights_32 + my_word];
+					}
+					cand = cluster_mask_range(cand, win_lo, win_hi, 32u * uint32_t(my_word));
 				}
-				if (atten > 0.0f)
+				uint64_t live_words = __ballot(cand != 0u);
+
+				// ---- walk: scalar iteration over set bits, light records prefetched one candidate ahead ----
+				uint32_t word = 0u;
+				int word_index = 0;
+				auto next_candidate = [&]() -> int {
+					while (word == 0u)
+					{
+						if (live_words == 0ull)
+							return -1;
+						const int j = __builtin_ctzll(live_words);
+						live_words &= live_words - 1ull;
+						word = uint32_t(__builtin_amdgcn_readlane(int(cand), j));
+						word_index = word_base + j;
+					}
+					const int bit = __builtin_ctz(word);
+					word &= word - 1u;
+					return 32 * word_index + bit;
+				};
+
+				int current = next_candidate();
+				LightRecord li{};
+				if (current >= 0)
+					li = fetch_light(a, current);
+				while (current >= 0)
 				{
-					const float a2 = atten * rcp(dist * dist);
-					const float3_ color = f3(li.color[0] * a2, li.color[1] * a2, li.color[2] * a2);
-					if (color.x != 0.0f || color.y != 0.0f || color.z != 0.0f)
-						result = result + color * shade(s, L);
+					const int upcoming = next_candidate();
+					LightRecord li_next = li;
+					if (upcoming >= 0)
+						li_next = fetch_light(a, upcoming);
+					shade_positional(s, li, current, result);
+					li = li_next;
+					current = upcoming;
 				}
 			}
 		}
 		accum = f3(float(_Float16(accum.x + result.x)), float(_Float16(accum.y + result.y)), float(_Float16(accum.z + result.z)));
 	}
 
-	if (active)
+	if (inside)
 	{
-		f16x4 o;
-		o.x = _Float16(accum.x);
-		o.y = _Float16(accum.y);
-		o.z = _Float16(accum.z);
-		o.w = dst.w;
-		*reinterpret_cast<f16x4 *>(a.hdr.ptr + size_t(y) * a.hdr.pitch + size_t(x) * 8u) = o;
+		f16x4 o = dst;
+		if (active)
+		{
+			o.x = _Float16(accum.x);
+			o.y = _Float16(accum.y);
+			o.z = _Float16(accum.z);
+		}
+		if (active || a.emissive.ptr != a.hdr.ptr)
+			*reinterpret_cast<f16x4 *>(a.hdr.ptr + size_t(y) * a.hdr.pitch + size_t(x) * 8u) = o;
 	}
 }
 
@@ -341,7 +463,10 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	k.srgb_lut = ctx->srgb_decode_lut;
 	k.flags = args->flags;
 
-	dim3 grid(gr_div_up(W, LIGHT_TILE_W), gr_div_up(H, LIGHT_TILE_H * LIGHT_WAVES));
+	k.blocks_x = int(gr_div_up(W, LIGHT_TILE * LIGHT_WAVES));
+	k.num_blocks = k.blocks_x * int(gr_div_up(H, LIGHT_TILE));
+	k.blocks_per_xcd = (k.num_blocks + 7) / 8;
+	dim3 grid(unsigned(k.blocks_per_xcd) * 8u);
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "lighting"};
 	hipLaunchKernelGGL(k_lighting, grid, dim3(64 * LIGHT_WAVES), 0, gr_to_stream(stream), k);
 	GR_CHECK_LAUNCH(ctx);
