@@ -145,7 +145,11 @@ def main():
     kctx.timing_reset()
     barrier()
     t0 = time.perf_counter()
-    application.render_frames(args.steps, sync=True)
+    hs0 = application.host_stats()
+    application.render_frames(args.steps, sync=False)
+    hs1 = application.host_stats()
+    # host side of the frame loop (light sort/pack + launches), excluding time blocked on GPU back-pressure
+    host_busy = (hs1["seconds"] - hs0["seconds"]) - (hs1["blocked_seconds"] - hs0["blocked_seconds"])
     barrier()
     elapsed = time.perf_counter() - t0
     timed = kctx.timing_query()
@@ -192,6 +196,7 @@ def main():
         "chain": {"algorithmic_GBps": chain_gbs, "frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS,
                   "algorithmic_bytes_per_frame": chain_bytes},
         "kernels_warmup": warm_breakdown,
+        "host_busy_ms_per_step": 1000.0 * host_busy / args.steps,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

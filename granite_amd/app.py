@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "gra_get_render_parameters", "gra_set_lights", "gra_upload_gbuffer", "gra_render_frames", "gra_sync",
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
-    "gra_set_smaa_luts",
+    "gra_set_smaa_luts", "gra_get_host_stats",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
         "gra_get_stream": (vp, [vp]),
         "gra_get_taa_reprojection": (C.c_int, [vp, vp]),
         "gra_set_smaa_luts": (C.c_int, [vp, vp, vp]),
+        "gra_get_host_stats": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -238,6 +239,11 @@ class Application:
         arr = (Timestamp * 64)()
         n = self._check(self.lib.gra_collect_timestamps(self.handle, arr, 64))
         return {arr[i].tag.decode(): (int(arr[i].count), float(arr[i].total_ms)) for i in range(n)}
+
+    def host_stats(self) -> dict:
+        out = np.zeros(3, np.float64)
+        self._check(self.lib.gra_get_host_stats(self.handle, out.ctypes.data))
+        return {"frames": int(out[0]), "seconds": float(out[1]), "blocked_seconds": float(out[2])}
 
     def kernel_context(self) -> "KernelContextView":
         return KernelContextView(self.lib.gra_get_kernel_context(self.handle))

@@ -131,6 +131,15 @@ int gra_render_frames(gra_app *app, uint32_t count, int32_t sync)
 	});
 }
 
+int gra_get_host_stats(gra_app *app, double *out3)
+{
+	return guarded(app, [&]() {
+		if (!out3)
+			throw std::logic_error("gra_get_host_stats: null output");
+		app->app->get_host_stats(out3);
+	});
+}
+
 int gra_sync(gra_app *app)
 {
 	return guarded(app, [&]() { app->app->wait_idle(); });

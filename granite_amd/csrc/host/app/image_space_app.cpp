@@ -1,4 +1,5 @@
 #include "image_space_app.hpp"
+#include <chrono>
 #include <cstring>
 
 namespace Granite
@@ -304,6 +305,7 @@ void ImageSpaceApplication::bake_render_graph()
 void ImageSpaceApplication::render_frame()
 {
 	auto &device = get_device();
+	const auto host_t0 = std::chrono::steady_clock::now();
 	if (need_bake)
 		bake_render_graph();
 
@@ -332,5 +334,7 @@ void ImageSpaceApplication::render_frame()
 	graph.enqueue_render_passes(device, composer);
 	gbuffer_dirty = false;
 	last_backbuffer = backbuffer;
+	host_frames++;
+	host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - host_t0).count();
 }
 } // namespace Granite

@@ -49,6 +49,13 @@ public:
 	LightClusterer &get_clusterer() { return cluster; }
 	HIP::Image *get_last_backbuffer() { return last_backbuffer; }
 	const gra_config &get_config() const { return config; }
+	// Host-side cost of the frame loop: frames rendered, wall seconds inside render_frame(), of which blocked on the GPU.
+	void get_host_stats(double out[3]) const
+	{
+		out[0] = double(host_frames);
+		out[1] = host_seconds;
+		out[2] = device_holder ? device_holder->get_blocked_seconds() : 0.0;
+	}
 	std::string last_error;
 
 private:
@@ -77,6 +84,8 @@ private:
 	HIP::Image *last_backbuffer = nullptr;
 	bool need_bake = true;
 	double elapsed = 0.0;
+	uint64_t host_frames = 0;
+	double host_seconds = 0.0;
 
 	void bake_render_graph();
 	void add_main_pass_deferred(const std::string &tag);

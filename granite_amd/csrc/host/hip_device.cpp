@@ -1,5 +1,6 @@
 #include "hip_device.hpp"
 #include <hip/hip_runtime_api.h>
+#include <chrono>
 #include <cstring>
 #include <stdexcept>
 
@@ -170,7 +171,12 @@ void Device::next_frame_context()
 	throw_hip(hipEventRecord(static_cast<hipEvent_t>(done.fence), static_cast<hipStream_t>(streams[0])), "hipEventRecord");
 	staging_index = (staging_index + 1) % StagingFrames;
 	auto &next = staging[staging_index];
-	throw_hip(hipEventSynchronize(static_cast<hipEvent_t>(next.fence)), "hipEventSynchronize");
+	if (hipEventQuery(static_cast<hipEvent_t>(next.fence)) != hipSuccess)
+	{
+		auto t0 = std::chrono::steady_clock::now();
+		throw_hip(hipEventSynchronize(static_cast<hipEvent_t>(next.fence)), "hipEventSynchronize");
+		blocked_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	}
 	next.offset = 0;
 }
 

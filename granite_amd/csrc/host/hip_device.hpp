@@ -114,6 +114,8 @@ public:
 	void wait_idle();
 
 	size_t get_allocated_bytes() const { return allocated_bytes; }
+	// Seconds the host has spent blocked waiting for the GPU to release a staging slot (frame pacing back-pressure).
+	double get_blocked_seconds() const { return blocked_seconds; }
 	void account_alloc(ptrdiff_t delta) { allocated_bytes += delta; }
 
 private:
@@ -131,5 +133,6 @@ private:
 	StagingFrame staging[StagingFrames];
 	unsigned staging_index = 0;
 	size_t allocated_bytes = 0;
+	double blocked_seconds = 0.0;
 };
 } // namespace HIP

@@ -63,14 +63,58 @@ float LightClusterer::get_z_slice_extent(const RenderContext &ctx) const
 void LightClusterer::refresh(const RenderContext &context_, TaskComposer &)
 {
 	// Visible positional lights, nearest first along the view direction, so that the per-slice [first, last] index
-	// window produced by the z-range kernel is tight.
-	light_sort_cache.clear();
-	if (scene_lights)
-		light_sort_cache = *scene_lights;
+	// window produced by the z-range kernel is tight.  Same result as a stable sort of the scene list by
+	// dot(translation, front) (the reference sorts the list with that comparator), done as: one key per light, then
+	// either "last frame's order is still sorted" (static lights + camera: O(n) check) or a stable LSD radix sort.
+	const size_t count = scene_lights ? scene_lights->size() : 0;
 	const vec3 front = context_.get_render_parameters().camera_front;
-	std::stable_sort(light_sort_cache.begin(), light_sort_cache.end(), [&front](const PositionalLightInfo &a, const PositionalLightInfo &b) {
-		return dot(a.transform->get_translation(), front) < dot(b.transform->get_translation(), front);
-	});
+	sort_keys.resize(count);
+	for (size_t i = 0; i < count; i++)
+	{
+		float key = dot((*scene_lights)[i].transform->get_translation(), front);
+		uint32_t bits;
+		memcpy(&bits, &key, sizeof(bits));
+		// order-preserving map of IEEE floats onto unsigned integers (-0 and +0 stay distinct but adjacent)
+		sort_keys[i] = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+	}
+
+	bool sorted = sort_order.size() == count;
+	for (size_t i = 1; sorted && i < count; i++)
+	{
+		const uint32_t a = sort_order[i - 1], b = sort_order[i];
+		sorted = sort_keys[a] < sort_keys[b] || (sort_keys[a] == sort_keys[b] && a < b);
+	}
+	if (!sorted)
+	{
+		sort_order.resize(count);
+		sort_scratch.resize(count);
+		for (size_t i = 0; i < count; i++)
+			sort_order[i] = uint32_t(i);
+		// 3 passes of 11 bits, least significant first; each pass is stable, ties keep scene order.
+		uint32_t *src = sort_order.data(), *dst = sort_scratch.data();
+		for (unsigned shift = 0; shift < 33; shift += 11)
+		{
+			uint32_t histogram[2048] = {};
+			for (size_t i = 0; i < count; i++)
+				histogram[(sort_keys[src[i]] >> shift) & 2047u]++;
+			uint32_t sum = 0;
+			for (auto &h : histogram)
+			{
+				uint32_t c = h;
+				h = sum;
+				sum += c;
+			}
+			for (size_t i = 0; i < count; i++)
+				dst[histogram[(sort_keys[src[i]] >> shift) & 2047u]++] = src[i];
+			std::swap(src, dst);
+		}
+		if (src != sort_order.data())
+			sort_order.swap(sort_scratch);
+	}
+
+	light_sort_cache.resize(count);
+	for (size_t i = 0; i < count; i++)
+		light_sort_cache[i] = (*scene_lights)[sort_order[i]];
 	refresh_bindless_prepare(context_);
 }
 

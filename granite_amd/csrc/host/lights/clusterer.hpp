@@ -82,6 +82,7 @@ private:
 	const PositionalLightList *scene_lights = nullptr;
 	unsigned resolution_x = 64, resolution_y = 32, resolution_z = 16; // clusterer.hpp:127; the viewer sets 128x64x4096
 	PositionalLightList light_sort_cache;
+	std::vector<uint32_t> sort_keys, sort_order, sort_scratch;
 
 	struct
 	{

@@ -285,6 +285,16 @@ void RenderGraph::install_persistent_physical_buffer_resource(unsigned index, HI
 	physical_buffers[index] = std::move(buffer);
 }
 
+RenderGraph::~RenderGraph()
+{
+	for (void *e : pass_done_event)
+		if (e)
+			(void)hipEventDestroy(static_cast<hipEvent_t>(e));
+	for (void *e : event_pool)
+		if (e)
+			(void)hipEventDestroy(static_cast<hipEvent_t>(e));
+}
+
 void RenderGraph::reset()
 {
 	passes.clear();
@@ -735,6 +745,7 @@ void RenderGraph::bake()
 	                     backbuffer_dim.format == swapchain_dimensions.format;
 	bool has_history = physical_image_has_history[backbuffer_phys];
 	swapchain_physical_index = (same_geometry && !has_history) ? backbuffer_phys : unsigned(RenderResource::Unused);
+	build_stream_assignment();
 
 	if (device)
 		for (unsigned pass_index : pass_stack)
@@ -772,6 +783,12 @@ void RenderGraph::setup_attachments(HIP::Device &device_, HIP::ImageView *swapch
 	physical_buffers.resize(count);
 	physical_image_attachments.resize(count);
 	physical_history_image_attachments.resize(count);
+	physical_buffers_alternate.resize(count);
+	if (physical_sync.size() != count)
+	{
+		physical_sync.assign(count, {});
+		physical_sync_alternate.assign(count, {});
+	}
 	swapchain_attachment = swapchain;
 
 	for (unsigned i = 0; i < count; i++)
@@ -782,6 +799,11 @@ void RenderGraph::setup_attachments(HIP::Device &device_, HIP::ImageView *swapch
 			std::swap(physical_history_image_attachments[i], physical_image_attachments[i]);
 
 		auto &att = physical_dimensions[i];
+		if (att.buffer_info.size != 0 && physical_buffer_is_double_buffered(i))
+		{
+			std::swap(physical_buffers[i], physical_buffers_alternate[i]);
+			std::swap(physical_sync[i], physical_sync_alternate[i]);
+		}
 		if (att.buffer_info.size != 0)
 			setup_physical_buffer(device_, i);
 		else if (i == swapchain_physical_index && swapchain)
@@ -831,10 +853,162 @@ void *RenderGraph::acquire_event()
 	return e;
 }
 
+void RenderGraph::build_stream_assignment()
+{
+	pass_async.assign(passes.size(), false);
+	pass_reads_physical.assign(passes.size(), {});
+	pass_writes_physical.assign(passes.size(), {});
+	uses_async_stream = false;
+
+	auto add = [](std::vector<unsigned> &list, const RenderResource *res) {
+		if (!res || res->get_physical_index() == RenderResource::Unused)
+			return;
+		if (std::find(list.begin(), list.end(), res->get_physical_index()) == list.end())
+			list.push_back(res->get_physical_index());
+	};
+
+	for (unsigned pass_index : pass_stack)
+	{
+		auto &pass = *passes[pass_index];
+		auto &reads = pass_reads_physical[pass_index];
+		auto &writes = pass_writes_physical[pass_index];
+		for (auto *r : pass.get_color_inputs()) add(reads, r);
+		for (auto *r : pass.get_color_scale_inputs()) add(reads, r);
+		for (auto *r : pass.get_storage_texture_inputs()) add(reads, r);
+		for (auto *r : pass.get_attachment_inputs()) add(reads, r);
+		for (auto *r : pass.get_history_inputs()) add(reads, r);
+		for (auto *r : pass.get_storage_inputs()) add(reads, r);
+		for (auto &r : pass.get_generic_texture_inputs()) add(reads, r.texture);
+		for (auto &r : pass.get_generic_buffer_inputs()) add(reads, r.buffer);
+		add(reads, pass.get_depth_stencil_input());
+		for (auto *r : pass.get_color_outputs()) add(writes, r);
+		for (auto *r : pass.get_resolve_outputs()) add(writes, r);
+		for (auto *r : pass.get_storage_texture_outputs()) add(writes, r);
+		for (auto *r : pass.get_storage_outputs()) add(writes, r);
+		for (auto *r : pass.get_transfer_outputs()) add(writes, r);
+		add(writes, pass.get_depth_stencil_output());
+
+		bool async = (pass.get_queue() & RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT) != 0;
+		if (!async && hoist_independent_compute && (pass.get_queue() & RENDER_GRAPH_QUEUE_COMPUTE_BIT) != 0 && reads.empty() &&
+		    !writes.empty())
+		{
+			// Nothing it reads is produced by the graph.  It must not feed the swapchain image directly either.
+			async = std::find(writes.begin(), writes.end(), swapchain_physical_index) == writes.end();
+		}
+		pass_async[pass_index] = async;
+		uses_async_stream = uses_async_stream || async;
+	}
+	physical_sync.assign(physical_dimensions.size(), {});
+	physical_sync_alternate.assign(physical_dimensions.size(), {});
+
+	// Only passes that touch a resource which is also touched from the other stream take part in event ordering; every
+	// other pass is ordered by its in-order stream alone and records nothing (event / barrier packets are not free:
+	// each one is a command-processor round trip between two kernels).
+	pass_needs_sync.assign(passes.size(), false);
+	blit_needs_sync = false;
+	if (uses_async_stream)
+	{
+		std::vector<uint8_t> touched(physical_dimensions.size(), 0); // bit 0: generic stream, bit 1: async stream
+		for (unsigned pass_index : pass_stack)
+		{
+			const uint8_t bit = pass_async[pass_index] ? 2 : 1;
+			for (unsigned r : pass_reads_physical[pass_index])
+				touched[r] |= bit;
+			for (unsigned w : pass_writes_physical[pass_index])
+				touched[w] |= bit;
+		}
+		if (swapchain_physical_index == RenderResource::Unused)
+		{
+			auto itr = resource_to_index.find(backbuffer_source);
+			if (itr != resource_to_index.end() && resources[itr->second]->get_physical_index() != RenderResource::Unused)
+			{
+				touched[resources[itr->second]->get_physical_index()] |= 1; // final blit runs on the generic stream
+				blit_needs_sync = touched[resources[itr->second]->get_physical_index()] == 3;
+			}
+		}
+		for (unsigned pass_index : pass_stack)
+		{
+			bool shared = false;
+			for (unsigned r : pass_reads_physical[pass_index])
+				shared = shared || touched[r] == 3;
+			for (unsigned w : pass_writes_physical[pass_index])
+				shared = shared || touched[w] == 3;
+			pass_needs_sync[pass_index] = shared;
+		}
+	}
+
+	// Double-buffer what hoisted passes write, provided every byte a consumer reads is rewritten each frame by the
+	// hoisted pass itself: no read-modify-write input and no other writer.
+	physical_buffer_double.assign(physical_dimensions.size(), false);
+	if (hoist_independent_compute)
+	{
+		std::vector<unsigned> writers(physical_dimensions.size(), 0);
+		for (unsigned pass_index : pass_stack)
+			for (unsigned w : pass_writes_physical[pass_index])
+				writers[w]++;
+		for (unsigned pass_index : pass_stack)
+		{
+			if (!pass_async[pass_index] || (passes[pass_index]->get_queue() & RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT) != 0)
+				continue;
+			for (unsigned w : pass_writes_physical[pass_index])
+				if (physical_dimensions[w].buffer_info.size != 0 && writers[w] == 1)
+					physical_buffer_double[w] = true;
+		}
+	}
+}
+
 void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &composer)
 {
-	HIP::CommandBuffer::Type last_type = HIP::CommandBuffer::Type::Count;
-	hipEvent_t cross = nullptr;
+	const size_t ring_slot = size_t(frame_counter++ % EventRing);
+	if (pass_done_event.size() < (passes.size() + 1) * EventRing)
+		pass_done_event.resize((passes.size() + 1) * EventRing, nullptr);
+	if (physical_sync.size() != physical_dimensions.size())
+	{
+		physical_sync.assign(physical_dimensions.size(), {});
+		physical_sync_alternate.assign(physical_dimensions.size(), {});
+	}
+
+	std::vector<void *> waited;
+	auto wait_for = [&](hipStream_t stream, void *event) {
+		if (!event || std::find(waited.begin(), waited.end(), event) != waited.end())
+			return;
+		waited.push_back(event);
+		if (hipStreamWaitEvent(stream, static_cast<hipEvent_t>(event), 0) != hipSuccess)
+			throw std::runtime_error("cross-queue dependency failed");
+	};
+	// RAW / WAW / WAR against accesses recorded on the other stream.
+	auto acquire = [&](hipStream_t stream, int stream_index, const std::vector<unsigned> &reads, const std::vector<unsigned> &writes) {
+		waited.clear();
+		for (unsigned r : reads)
+			if (physical_sync[r].last_write && physical_sync[r].write_stream != stream_index)
+				wait_for(stream, physical_sync[r].last_write);
+		for (unsigned w : writes)
+		{
+			if (physical_sync[w].last_write && physical_sync[w].write_stream != stream_index)
+				wait_for(stream, physical_sync[w].last_write);
+			wait_for(stream, physical_sync[w].last_read[1 - stream_index]);
+		}
+	};
+	auto release = [&](hipStream_t stream, int stream_index, void *&event, const std::vector<unsigned> &reads,
+	                   const std::vector<unsigned> &writes) {
+		if (!event)
+		{
+			hipEvent_t e;
+			if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+				throw std::runtime_error("hipEventCreate failed");
+			event = e;
+		}
+		if (hipEventRecord(static_cast<hipEvent_t>(event), stream) != hipSuccess)
+			throw std::runtime_error("hipEventRecord failed");
+		for (unsigned r : reads)
+			physical_sync[r].last_read[stream_index] = event;
+		for (unsigned w : writes)
+		{
+			physical_sync[w].last_write = event;
+			physical_sync[w].write_stream = stream_index;
+			physical_sync[w].last_read[0] = physical_sync[w].last_read[1] = nullptr;
+		}
+	};
 
 	for (unsigned pass_index : pass_stack)
 	{
@@ -843,18 +1017,12 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 			continue;
 		pass.prepare_render_pass(composer);
 
-		auto type = (pass.get_queue() & RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT) ? HIP::CommandBuffer::Type::AsyncCompute
-		                                                                       : HIP::CommandBuffer::Type::Generic;
+		const bool async = pass_runs_async(pass_index);
+		auto type = async ? HIP::CommandBuffer::Type::AsyncCompute : HIP::CommandBuffer::Type::Generic;
 		auto stream = static_cast<hipStream_t>(device_.get_stream(type));
-		if (last_type != HIP::CommandBuffer::Type::Count && last_type != type)
-		{
-			if (!cross && hipEventCreateWithFlags(&cross, hipEventDisableTiming) != hipSuccess)
-				throw std::runtime_error("hipEventCreate failed");
-			auto prev = static_cast<hipStream_t>(device_.get_stream(last_type));
-			if (hipEventRecord(cross, prev) != hipSuccess || hipStreamWaitEvent(stream, cross, 0) != hipSuccess)
-				throw std::runtime_error("cross-queue dependency failed");
-		}
-		last_type = type;
+		const bool sync = uses_async_stream && pass_needs_sync[pass_index];
+		if (sync)
+			acquire(stream, int(type), pass_reads_physical[pass_index], pass_writes_physical[pass_index]);
 
 		HIP::CommandBuffer cmd{device_, stream, type};
 
@@ -888,27 +1056,29 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 			(void)hipEventRecord(static_cast<hipEvent_t>(ts.stop), stream);
 			pending_timestamps.push_back(ts);
 		}
+		if (sync)
+			release(stream, int(type), pass_done_event[pass_index * EventRing + ring_slot], pass_reads_physical[pass_index],
+			        pass_writes_physical[pass_index]);
 	}
 
 	// Backbuffer could not alias the swapchain image: final blit (same geometry/format only).
 	if (swapchain_attachment && swapchain_physical_index == RenderResource::Unused)
 	{
-		auto &src = get_physical_texture_resource(resources[resource_to_index[backbuffer_source]]->get_physical_index());
+		const unsigned src_index = resources[resource_to_index[backbuffer_source]]->get_physical_index();
+		auto &src = get_physical_texture_resource(src_index);
 		if (src.get_size_bytes() != swapchain_attachment->get_size_bytes() || src.get_format() != swapchain_attachment->get_format())
 			throw std::logic_error("Backbuffer source does not match the swapchain; scaling blits are not implemented.");
 		HIP::CommandBuffer cmd{device_, device_.get_stream(HIP::CommandBuffer::Type::Generic), HIP::CommandBuffer::Type::Generic};
-		if (last_type == HIP::CommandBuffer::Type::AsyncCompute)
-		{
-			if (!cross && hipEventCreateWithFlags(&cross, hipEventDisableTiming) != hipSuccess)
-				throw std::runtime_error("hipEventCreate failed");
-			(void)hipEventRecord(cross, static_cast<hipStream_t>(device_.get_stream(last_type)));
-			(void)hipStreamWaitEvent(static_cast<hipStream_t>(cmd.get_stream()), cross, 0);
-		}
+		auto stream = static_cast<hipStream_t>(cmd.get_stream());
+		const std::vector<unsigned> reads = {src_index}, none;
+		const bool sync = uses_async_stream && blit_needs_sync;
+		if (sync)
+			acquire(stream, int(HIP::CommandBuffer::Type::Generic), reads, none);
 		cmd.copy_image(*swapchain_attachment, src);
+		if (sync)
+			release(stream, int(HIP::CommandBuffer::Type::Generic), pass_done_event[passes.size() * EventRing + ring_slot], reads, none);
 	}
 
-	if (cross)
-		(void)hipEventDestroy(cross);
 	device_.next_frame_context();
 }
 
@@ -991,7 +1161,8 @@ std::string RenderGraph::dump_json() const
 		if (!first)
 			os << ",";
 		first = false;
-		os << "{\"name\":\"" << pass.get_name() << "\",\"queue\":" << unsigned(pass.get_queue()) << ",\"writes\":[";
+		os << "{\"name\":\"" << pass.get_name() << "\",\"queue\":" << unsigned(pass.get_queue())
+		   << ",\"stream\":" << (pass_runs_async(pass_index) ? "\"async\"" : "\"generic\"") << ",\"writes\":[";
 		bool f2 = true;
 		auto emit = [&](const RenderResource *r) {
 			if (!r)
@@ -1028,7 +1199,8 @@ std::string RenderGraph::dump_json() const
 			os << ",";
 		os << "{\"phys\":" << i << ",\"name\":\"" << d.name << "\",\"width\":" << d.width << ",\"height\":" << d.height
 		   << ",\"format\":" << unsigned(d.format) << ",\"buffer_size\":" << d.buffer_info.size
-		   << ",\"history\":" << (physical_image_has_history[i] ? "true" : "false") << "}";
+		   << ",\"history\":" << (physical_image_has_history[i] ? "true" : "false")
+		   << ",\"double_buffered\":" << (physical_buffer_is_double_buffered(unsigned(i)) ? "true" : "false") << "}";
 	}
 	os << "],\"swapchain_phys\":" << int(swapchain_physical_index) << "}";
 	return os.str();

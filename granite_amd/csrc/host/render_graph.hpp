@@ -352,6 +352,7 @@ class RenderGraph
 {
 public:
 	RenderGraph() = default;
+	~RenderGraph();
 	RenderGraph(const RenderGraph &) = delete;
 	void operator=(const RenderGraph &) = delete;
 
@@ -373,6 +374,12 @@ public:
 	ResourceDimensions get_resource_dimensions(const RenderTextureResource &resource) const;
 
 	void enable_timestamps(bool enable) { enabled_timestamps = enable; }
+	// HIP executor policy (no reference analogue; Granite decides queues at declaration time only): a COMPUTE pass that
+	// reads nothing produced inside the graph (e.g. "clustering-bindless") is run on the async-compute stream, ordered
+	// by per-resource events, so that frame N+1's instance overlaps frame N's tail.  Default on.
+	void set_hoist_independent_compute(bool enable) { hoist_independent_compute = enable; }
+	bool pass_runs_async(unsigned pass_index) const { return pass_index < pass_async.size() && pass_async[pass_index]; }
+	bool physical_buffer_is_double_buffered(unsigned index) const { return index < physical_buffer_double.size() && physical_buffer_double[index]; }
 	void bake();
 	void reset();
 	void log();
@@ -468,6 +475,36 @@ private:
 	};
 	std::vector<PassTimestamp> pending_timestamps;
 	std::vector<void *> event_pool;
+
+	// Cross-stream ordering.  Filled by bake(): the physical resources each pass reads / writes and the stream it runs
+	// on.  At execution every pass that shares a resource with a pass on the OTHER stream waits on that pass's "done"
+	// event (RAW, WAW and WAR); the state survives across frames, which is what lets frame N+1's hoisted passes start
+	// as soon as frame N's readers of their outputs have finished.  With a single stream in use nothing is recorded.
+	bool hoist_independent_compute = true;
+	bool uses_async_stream = false;
+	std::vector<bool> pass_async;
+	std::vector<bool> pass_needs_sync; // touches a physical resource that the other stream also touches
+	bool blit_needs_sync = false;
+	std::vector<std::vector<unsigned>> pass_reads_physical, pass_writes_physical;
+	// hipEvent_t ring per pass: a sync entry must keep naming the record of the frame it was made in (the alternate copy
+	// of a double-buffered buffer was last read two frames ago), so the event of frame f is slot f % EventRing.  The
+	// host never runs more than Device::StagingFrames - 1 frames ahead, so a slot is complete long before its reuse.
+	enum { EventRing = 4 };
+	std::vector<void *> pass_done_event;
+	uint64_t frame_counter = 0;
+	struct PhysicalSync
+	{
+		void *last_write = nullptr;
+		int write_stream = -1;
+		void *last_read[2] = {nullptr, nullptr};
+	};
+	std::vector<PhysicalSync> physical_sync;
+	// Buffers written by a hoisted pass exist twice and alternate per frame (like an image with history), so the
+	// hoisted pass of frame N+1 never waits for frame N's consumers: write-after-read across frames disappears.
+	std::vector<bool> physical_buffer_double;
+	std::vector<HIP::BufferHandle> physical_buffers_alternate;
+	std::vector<PhysicalSync> physical_sync_alternate;
+	void build_stream_assignment();
 	std::unordered_map<std::string, std::pair<uint64_t, double>> timestamp_accum;
 	std::vector<std::string> timestamp_order;
 

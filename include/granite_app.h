@@ -119,6 +119,9 @@ int gra_collect_timestamps(gra_app *app, gra_timestamp *entries, int max_entries
 int gra_get_taa_reprojection(gra_app *app, float *reproj16);
 /* SMAA AreaTex (160x560 RG8) / SearchTex (64x16 R8) payloads, host pointers; needed before a frame with an SMAA pass. */
 int gra_set_smaa_luts(gra_app *app, const void *area_rg8, const void *search_r8);
+/* Host-side frame-loop cost since creation: out[0] = frames, out[1] = seconds spent inside the frame loop (light
+ * refresh + graph execution = launches), out[2] = seconds of those spent blocked on GPU back-pressure. */
+int gra_get_host_stats(gra_app *app, double *out3);
 /* Per-kernel timing lives in the kernel library: gr_timing_* on this context. */
 void *gra_get_kernel_context(gra_app *app); /* gr_ctx* */
 void *gra_get_stream(gra_app *app);         /* hipStream_t of the generic queue */

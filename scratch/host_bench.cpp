@@ -1,0 +1,38 @@
+// Host-side per-frame cost of the clusterer refresh (sort + pack + z ranges), no GPU.
+#include "../granite_amd/csrc/host/app/image_space_app.hpp"
+#include <chrono>
+#include <cstdio>
+#include <random>
+using namespace Granite;
+int main()
+{
+	gra_config cfg = {};
+	cfg.device = -1; cfg.width = 3840; cfg.height = 2160; cfg.enable_lighting = 1; cfg.hdr_bloom = 1; cfg.dynamic_exposure = 1; cfg.compute_post = 1;
+	cfg.frame_time = 0.01f;
+	ImageSpaceApplication app(cfg);
+	std::mt19937 rng(1);
+	std::uniform_real_distribution<float> u(-1.f, 1.f);
+	std::vector<gra_light_desc> d(4096);
+	for (auto &l : d)
+	{
+		l = {};
+		l.type = (rng() & 3) ? 1 : 0;
+		l.color[0] = 5 + u(rng); l.color[1] = 4; l.color[2] = 3;
+		l.inner_cone = 0.94f; l.outer_cone = 0.87f; l.cutoff_range = 4.0f;
+		float t[12] = {1, 0, 0, 10 * u(rng), 0, 1, 0, 5 * u(rng), 0, 0, 1, -20 + 19 * u(rng)};
+		memcpy(l.transform, t, sizeof(t));
+	}
+	app.set_lights(d.data(), 4096);
+	app.bake_only();
+	TaskComposer composer;
+	auto &cl = app.get_clusterer();
+	for (int rep = 0; rep < 3; rep++)
+	{
+		auto t0 = std::chrono::steady_clock::now();
+		for (int i = 0; i < 100; i++)
+			cl.refresh(app.get_context(), composer);
+		auto t1 = std::chrono::steady_clock::now();
+		printf("refresh: %.1f us/frame\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / 100);
+	}
+	return 0;
+}

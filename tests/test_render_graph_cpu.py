@@ -67,3 +67,19 @@ def test_dry_application_refuses_to_render():
     with pytest.raises(capi.GraniteHipError):
         a.render_frames(1)
     a.close()
+
+
+def test_independent_compute_pass_is_hoisted_to_async_stream():
+    """Executor policy: a COMPUTE pass that reads nothing produced in the graph (the cluster build) runs on the async
+    stream; passes that consume graph resources stay on the generic stream."""
+    g = graph_of(3840, 2160)
+    streams = {p["name"]: p["stream"] for p in g["passes"]}
+    assert streams["clustering-bindless"] == "async"
+    assert streams["lighting-main"] == "generic" and streams["bloom-compute"] == "generic" and streams["tonemap"] == "generic"
+    # what the hoisted pass writes alternates between two copies, so frame N+1's build never waits for frame N's lighting
+    dbl = {r["name"] for r in g["resources"] if r["double_buffered"]}
+    assert {"cluster-bitmask", "cluster-range", "cluster-transforms", "cluster-cull-setup", "cluster-transformed-spot"} <= dbl
+    assert "average-luminance" not in dbl and "HDR-main" not in dbl
+    # no lighting => no cluster pass => single stream
+    g1 = graph_of(256, 256, lighting=False)
+    assert {p["stream"] for p in g1["passes"]} == {"generic"}
