@@ -9,20 +9,24 @@
 // HDR may be the same buffer (the reference's blend read-modify-write) or distinct ones (same values, same bytes).  The two
 // blend roundings of the reference are reproduced in registers: hdr = rne16(rne16(emissive + directional) + clustered).
 //
-// Mapping.  A wave64 owns an 8x8 pixel tile and never synchronises with another wave (no LDS, no barriers); four waves
-// side by side form a 32x8 workgroup so every row of the workgroup is one 256 B HDR / 128 B G-buffer segment.  The light
-// loop is wave-uniform like the reference's subgroup path (clusterer_bindless.h:49-81), restructured for the scalar unit:
-//   1. gather: lane l fetches bitmask word (w_lo + l) of every cluster cell the tile touches (coalesced), ORs them and
-//      trims the word by the wave's Z-slice index window [min first, max last]; this is a superset of the reference's
-//      subgroupOr of per-lane trimmed masks.  Lights it adds lie outside their radius for the pixels concerned and
-//      contribute exactly 0 (point.h:38, spot.h:45), which is also why the reference's subgroup footprint cannot matter
-//      (oracle: orc_lighting_bruteforce_clustered).
-//   2. walk: the non-zero words are pulled into SGPRs (ballot + v_readlane) and their bits iterated with scalar bit ops;
-//      each 48-byte light record is fetched with scalar loads one candidate ahead of the shading, so the 64 lanes only
-//      ever issue BRDF arithmetic with the light in SGPR operands.
-//   3. a candidate no lane of the tile is within 1.001 radius of is skipped after its distance test (wave-uniform branch).
+// Mapping.  A wave64 owns an 8x8 pixel tile and never synchronises with another wave (wave-private LDS, no barriers);
+// four waves side by side form a 32x8 workgroup so every row of the workgroup is one 256 B HDR / 128 B G-buffer segment.
+// The light loop is wave-uniform like the reference's subgroup path (clusterer_bindless.h:49-81), in three steps per
+// 64-light chunk of the tile's light-index window:
+//   1. gather (one LIGHT per lane): lane l owns light 64*chunk + l.  Its bit is the OR of that bit over every cluster
+//      cell the tile touches, trimmed to the wave's Z-slice index window [min first, max last] - a superset of the
+//      reference's subgroupOr of per-lane trimmed masks.  What the superset adds lies outside its radius for the pixels
+//      concerned and contributes exactly 0 (point.h:38, spot.h:45); the reference's subgroup footprint cannot matter
+//      for the same reason (oracle: orc_lighting_bruteforce_clustered).
+//   2. cull + stage: each lane tests its light's sphere (1.001 r) against the tile's bounding sphere, survivors are
+//      compacted in index order (ballot + mbcnt) into a wave-private LDS list together with per-light constants
+//      (10 / r, (1.001 r)^2, fp32 spot scale / bias) computed once per light instead of once per pixel.
+//   3. shade (one PIXEL per lane): the list is walked with broadcast ds_read_b128; every BRDF operand is a VGPR.
+//      On gfx950 fp32 fma / mul / add issue at full rate only with VGPR / literal / inline operands (measured: 1.2 ns per
+//      wave-instruction per SIMD vs 1.9 ns with an SGPR operand, 2.0 ns for min / max / med3 / cmp / cvt, 3.6 ns for
+//      rcp / rsq), which is what bounds this kernel on the 4096-light config, not HBM.
 // The BRDF is algebraically the reference's; normalisations are folded (dot products on the unnormalised light vector,
-// H.V = |V+L|/2, one rcp for G*D) to cut the per-light VALU count, which bounds this kernel on the 4096-light config.
+// H.V = |V+L|/2, one rcp for G*D) to cut the per-light VALU count.
 #include "ctx.hpp"
 #include "device_common.hpp"
 
@@ -30,8 +34,12 @@ namespace
 {
 constexpr int LIGHT_TILE = 8;  // wave tile edge
 constexpr int LIGHT_WAVES = 4; // waves per workgroup, side by side -> 32x8 block
+constexpr int LIGHT_SLOT_BYTES = 64;
 
 constexpr float PI_SIC = 3.1415628f; // assets/shaders/lights/pbr.h:4-6 (sic)
+// Sphere culling margins: the shader's falloff is exactly 0 once dist * inv_radius >= 1.
+constexpr float CULL_RADIUS_SCALE = 1.001f;
+constexpr float CULL_SLACK = 1e-3f;
 
 struct KernelArgs
 {
@@ -62,12 +70,12 @@ struct float3_ { float x, y, z; };
 __device__ __forceinline__ float3_ f3(float x, float y, float z) { return {x, y, z}; }
 __device__ __forceinline__ float3_ operator+(float3_ a, float3_ b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ float3_ operator-(float3_ a, float3_ b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ float3_ operator*(float3_ a, float3_ b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 __device__ __forceinline__ float3_ operator*(float3_ a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ float dot(float3_ a, float3_ b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 __device__ __forceinline__ float rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 __device__ __forceinline__ float rsq(float v) { return __builtin_amdgcn_rsqf(v); }
 __device__ __forceinline__ float med3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); } // clamp
+__device__ __forceinline__ float sat(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); } // folds into a clamp modifier
 
 // Per-pixel material terms hoisted out of the light loop.
 struct Surface
@@ -77,13 +85,13 @@ struct Surface
 };
 
 // Shared BRDF tail of compute_point_light / compute_spot_light / compute_lighting (point.h:119-142, spot.h:122-145,
-// lighting.h:26-45) for a unit light direction L given through NdL = dot(N, L) and hh = |V + L|^2:
+// lighting.h:26-45) for a unit light direction L given through NdL = dot(N, L) and hh = |V + L|^2 (> 0):
 //   H = (V + L) / |V + L|,  dot(H, V) = |V + L| / 2 (unit V, L),  dot(N, H) = (NdV + NdL) / |V + L|.
 // Returns NoL and brdf = F * G * D + (1 - F) * diffuse; the caller multiplies by NoL and the light colour.
 __device__ __forceinline__ float3_ brdf(const Surface &s, float NdL, float hh, float &NoL)
 {
 	NoL = med3(NdL, 0.001f, 1.0f);
-	const float inv_h = rsq(fmaxf(hh, 1e-30f));
+	const float inv_h = rsq(hh);
 	const float HoV = med3(0.5f * hh * inv_h, 0.001f, 1.0f);
 	const float NoH = med3((s.NdV + NdL) * inv_h, 0.0001f, 1.0f);
 
@@ -101,14 +109,10 @@ __device__ __forceinline__ float3_ brdf(const Surface &s, float NdL, float hh, f
 	          fmaf(Fz, GD - s.diffuse.z, s.diffuse.z));
 }
 
-// clusterer_bindless_buffers.h:17-27
-__device__ __forceinline__ uint32_t cluster_mask_range(uint32_t mask, uint32_t range_x, uint32_t range_y, uint32_t start_index)
+// clusterer_bindless_buffers.h:17-27 for one light index instead of one 32-bit word.
+__device__ __forceinline__ bool index_in_range(uint32_t index, uint32_t range_x, uint32_t range_y)
 {
-	const uint32_t rx = min(max(range_x, start_index), start_index + 32u);
-	const uint32_t ry = min(max(range_y + 1u, rx), start_index + 32u);
-	const uint32_t num_bits = ry - rx;
-	const uint32_t range_mask = num_bits == 32u ? 0xffffffffu : ((1u << num_bits) - 1u) << (rx - start_index);
-	return mask & range_mask;
+	return index >= range_x && index <= range_y;
 }
 
 // Wave64 min/max -> SGPR: 4 DPP steps reduce each row of 16 lanes, the 4 row results meet on the scalar unit.
@@ -125,60 +129,31 @@ __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t v)
 	return op(op(r0, r1), op(r2, r3));
 }
 
-// A light as fetched: the raw 48-byte PositionalFragmentInfo (3 x 16 B scalar loads) + its type_mask word.  Nothing is
-// decoded at fetch time so no scalar instruction waits on the loads before the previous light has been shaded.
-struct LightRecord
+// One staged light = 4 x 16 B in wave-private LDS.
+//   q0: position.xyz, (1.001 r)^2        q1: colour.xyz, 10 / r
+//   q2: direction.xyz, -                 q3: spot scale, spot bias (fp32), -, -          (q2, q3 read for spots only)
+__device__ __forceinline__ void shade_positional(const Surface &s, f32x4 q0, f32x4 q1, const f32x4 *slot, bool is_spot,
+                                                 float3_ &result)
 {
-	u32x4 q0; // color.xyz, spot_scale_bias
-	u32x4 q1; // position.xyz, offset_radius
-	u32x4 q2; // direction.xyz, inv_radius
-	uint32_t type_word;
-};
-
-__device__ __forceinline__ LightRecord fetch_light(const KernelArgs &a, int index)
-{
-	// index is wave-uniform: these are scalar loads (s_load_dwordx4), the record lives in SGPRs.
-	const u32x4 *rec = reinterpret_cast<const u32x4 *>(a.lights + index);
-	LightRecord r;
-	r.q0 = rec[0];
-	r.q1 = rec[1];
-	r.q2 = rec[2];
-	r.type_word = a.type_mask[index >> 5];
-	return r;
-}
-
-__device__ __forceinline__ float u2f(uint32_t v) { return __builtin_bit_cast(float, v); }
-
-// compute_point_light / compute_spot_light (point.h:33-84, spot.h:34-93, no shadows) for one wave-uniform light.
-__device__ __forceinline__ void shade_positional(const Surface &s, const LightRecord &li, int index, float3_ &result)
-{
-	const float inv_radius = u2f(li.q2.w);
-	const float3_ Lf = f3(u2f(li.q1.x), u2f(li.q1.y), u2f(li.q1.z)) - s.pos; // light_pos - world_pos
-	const float d2 = dot(Lf, Lf);
+	const float3_ Lf = f3(q0.x, q0.y, q0.z) - s.pos;                 // light_pos - world_pos
+	const float d2 = fmaf(Lf.z, Lf.z, fmaf(Lf.y, Lf.y, fmaf(Lf.x, Lf.x, 1e-30f))); // > 0: no inf / nan downstream
 	// Falloff is exactly 0 once dist * inv_radius >= 1: skip the light when no pixel of the tile is inside 1.001 r.
-	const float x2 = d2 * (inv_radius * inv_radius);
-	if (!__any(x2 < 1.002f))
+	if (!__any(d2 < q0.w))
 		return;
 
-	const float d2c = fmaxf(d2, 1e-30f);
-	const float inv_d = rsq(d2c);
-	const float len = d2c * inv_d;       // length(light_dir_full)
+	const float inv_d = rsq(d2);
+	const float len = d2 * inv_d;        // length(light_dir_full)
 	const float dist = fmaxf(0.1f, len); // light_dist
 	const float inv_d2 = inv_d * inv_d;
 	// 1 - smoothstep(0.9, 1.0, dist * inv_radius)
-	const float t = med3(fmaf(dist * inv_radius, 10.0f, -9.0f), 0.0f, 1.0f);
+	const float t = sat(fmaf(dist, q1.w, -9.0f));
 	float atten = fmaf(-(t * t), fmaf(-2.0f, t, 3.0f), 1.0f);
-	const bool is_point = ((li.type_word >> (uint32_t(index) & 31u)) & 1u) != 0u;
-	if (!is_point)
+	if (is_spot)
 	{
 		// spot.h:41-46: cone = dot(normalize(world_pos - light_pos), direction) = -dot(Lf, direction) / |Lf|
-		const float cone_angle = -dot(Lf, f3(u2f(li.q2.x), u2f(li.q2.y), u2f(li.q2.z))) * inv_d;
-		// The packed halves go through a VGPR: hipcc (ROCm 7.2) otherwise folds lane .w of the SGPR quad into
-		// v_fma_mix_f32 as lane .x (observed: spots shaded with colour.x as scale/bias).
-		uint32_t sb_bits;
-		asm("v_mov_b32 %0, %1" : "=v"(sb_bits) : "s"(li.q0.w));
-		const f16x2 sb = __builtin_bit_cast(f16x2, sb_bits);
-		const float cone = med3(fmaf(cone_angle, float(sb.x), float(sb.y)), 0.0f, 1.0f);
+		const f32x4 q2 = slot[2], q3 = slot[3];
+		const float cone_angle = -dot(Lf, f3(q2.x, q2.y, q2.z)) * inv_d;
+		const float cone = sat(fmaf(cone_angle, q3.x, q3.y));
 		atten *= cone * cone;
 		// Most of a spot's bounding sphere is outside its cone: spot_color == 0 for the whole tile -> returns 0.
 		if (!__any(atten > 0.0f))
@@ -190,17 +165,19 @@ __device__ __forceinline__ void shade_positional(const Surface &s, const LightRe
 	const float NdL = dot(s.N, Lf) * inv_d;
 	// |V + L|^2 with L = Lf / len: |len V + Lf|^2 / len^2
 	const float3_ Hs = f3(fmaf(s.V.x, len, Lf.x), fmaf(s.V.y, len, Lf.y), fmaf(s.V.z, len, Lf.z));
-	const float hh = dot(Hs, Hs) * inv_d2;
+	const float hh = fmaf(Hs.z, Hs.z, fmaf(Hs.y, Hs.y, fmaf(Hs.x, Hs.x, 1e-30f))) * inv_d2;
 	float NoL;
 	const float3_ b = brdf(s, NdL, hh, NoL);
 	const float w = NoL * a2;
-	result.x = fmaf(u2f(li.q0.x) * w, b.x, result.x);
-	result.y = fmaf(u2f(li.q0.y) * w, b.y, result.y);
-	result.z = fmaf(u2f(li.q0.z) * w, b.z, result.z);
+	result.x = fmaf(q1.x * w, b.x, result.x);
+	result.y = fmaf(q1.y * w, b.y, result.y);
+	result.z = fmaf(q1.z * w, b.z, result.z);
 }
 
 __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 {
+	__shared__ __attribute__((aligned(16))) f32x4 s_lights[LIGHT_WAVES][64 * (LIGHT_SLOT_BYTES / 16)];
+
 	// XCD-aware tile order: block b runs on XCD b % 8; give each XCD one contiguous band of the screen so the cluster
 	// words and light records a band needs stay in that XCD's L2.
 	const int logical = int(blockIdx.x & 7u) * a.blocks_per_xcd + int(blockIdx.x >> 3);
@@ -237,22 +214,20 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 	const float metallic = float(mr & 255u) * (1.0f / 255.0f);
 	const float mat_roughness = float(mr >> 8) * (1.0f / 255.0f);
 
-	// ---- position reconstruction (clustering.vert:10-13, clustering.frag:37-39); plain mul/add, no contraction,
-	// so the cell / slice selection below is reproducible. ----
-	const float ndc_x = __fsub_rn(__fmul_rn(2.0f, __fmul_rn(float(x) + 0.5f, a.inv_resolution[0])), 1.0f);
-	const float ndc_y = __fsub_rn(__fmul_rn(2.0f, __fmul_rn(float(y) + 0.5f, a.inv_resolution[1])), 1.0f);
+	// ---- position reconstruction (clustering.vert:10-13, clustering.frag:37-39): clip = invVP * (ndc.xy, depth, 1),
+	// pos = clip.xyz / clip.w.  Evaluated with fused multiply-adds and a Newton-refined reciprocal; a pixel that lands in
+	// the neighbouring Z slice because of the last-bit difference sees the same lights up to ones at the very edge of
+	// their radius (falloff -> 0), cf. the conservative slice ranges of clusterer.cpp:1265-1275. ----
+	const float ndc_x = fmaf(2.0f * (float(x) + 0.5f), a.inv_resolution[0], -1.0f);
+	const float ndc_y = fmaf(2.0f * (float(y) + 0.5f), a.inv_resolution[1], -1.0f);
 	float clip[4];
 #pragma unroll
 	for (int i = 0; i < 4; i++)
-	{
-		float v = __fmul_rn(a.inv_vp[i], ndc_x);
-		v = __fadd_rn(v, __fmul_rn(a.inv_vp[4 + i], ndc_y));
-		v = __fadd_rn(v, __fmul_rn(a.inv_vp[8 + i], 0.0f));
-		v = __fadd_rn(v, a.inv_vp[12 + i]);
-		clip[i] = __fadd_rn(v, __fmul_rn(depth, a.inv_vp[8 + i]));
-	}
+		clip[i] = fmaf(depth, a.inv_vp[8 + i], fmaf(a.inv_vp[4 + i], ndc_y, fmaf(a.inv_vp[i], ndc_x, a.inv_vp[12 + i])));
 	const float clip_w = active ? clip[3] : 1.0f;
-	const float3_ pos = f3(__fdiv_rn(clip[0], clip_w), __fdiv_rn(clip[1], clip_w), __fdiv_rn(clip[2], clip_w));
+	float inv_w = rcp(clip_w);
+	inv_w = inv_w * fmaf(-clip_w, inv_w, 2.0f);
+	const float3_ pos = f3(clip[0] * inv_w, clip[1] * inv_w, clip[2] * inv_w);
 
 	Surface s;
 	s.pos = pos;
@@ -284,7 +259,7 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		const float3_ L = f3(a.dir_direction[0], a.dir_direction[1], a.dir_direction[2]);
 		const float3_ Hv = V + L;
 		float NoL;
-		const float3_ b = brdf(s, dot(N, L), dot(Hv, Hv), NoL);
+		const float3_ b = brdf(s, dot(N, L), fmaxf(dot(Hv, Hv), 1e-30f), NoL);
 		float3_ lit = f3(a.dir_color[0] * NoL * b.x, a.dir_color[1] * NoL * b.y, a.dir_color[2] * NoL * b.z);
 		if (a.flags & GR_LIGHTING_AMBIENT_FALLBACK_BIT)
 			lit = lit + base * 0.05f;
@@ -298,17 +273,14 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		float3_ result = f3(0.0f, 0.0f, 0.0f);
 
 		// Slice lookup (clusterer_bindless.h:43-47) and the wave's light-index window.
-		const float dzx = __fsub_rn(pos.x, a.cl_camera_base[0]), dzy = __fsub_rn(pos.y, a.cl_camera_base[1]),
-		            dzz = __fsub_rn(pos.z, a.cl_camera_base[2]);
-		const float z = __fadd_rn(__fadd_rn(__fmul_rn(dzx, a.cl_camera_front[0]), __fmul_rn(dzy, a.cl_camera_front[1])),
-		                          __fmul_rn(dzz, a.cl_camera_front[2]));
-		int z_index = int(__fmul_rn(z, a.cl_z_scale));
-		z_index = clampi(z_index, 0, a.cl_z_max_index);
+		const float z = dot(pos - f3(a.cl_camera_base[0], a.cl_camera_base[1], a.cl_camera_base[2]),
+		                    f3(a.cl_camera_front[0], a.cl_camera_front[1], a.cl_camera_front[2]));
+		const int z_index = clampi(int(z * a.cl_z_scale), 0, a.cl_z_max_index);
 		uint2 z_range = make_uint2(0xffffffffu, 0u);
 		if (active)
 			z_range = a.range[z_index];
 		const uint32_t win_lo = wave_minmax_u32<false>(z_range.x);
-		const uint32_t win_hi = wave_minmax_u32<true>(z_range.y);
+		const uint32_t win_hi = min(wave_minmax_u32<true>(z_range.y), uint32_t(a.cl_num_lights - 1));
 
 		if (win_lo <= win_hi)
 		{
@@ -323,58 +295,85 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 			const int cy0 = __builtin_amdgcn_readfirstlane(cell(tile_y0, a.inv_resolution[1], a.cl_xy_scale[1], a.cl_res_y));
 			const int cy1 = __builtin_amdgcn_readfirstlane(cell(ye, a.inv_resolution[1], a.cl_xy_scale[1], a.cl_res_y));
 
-			const int word_lo = int(win_lo >> 5u);
-			const int word_hi = min(int(win_hi >> 5u), a.cl_num_lights_32 - 1);
+			// Bounding sphere of the tile's surface points: centre = first lit pixel, radius = farthest lit pixel from it.
+			const uint64_t lit = __ballot(active);
+			const int first = __builtin_ctzll(lit);
+			const float3_ centre = f3(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pos.x), first)),
+			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pos.y), first)),
+			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pos.z), first)));
+			const float3_ off = pos - centre;
+			const float off2 = active ? dot(off, off) : 0.0f;
+			const float tile_radius =
+			    __builtin_sqrtf(__builtin_bit_cast(float, wave_minmax_u32<true>(__builtin_bit_cast(uint32_t, off2)))) * 1.0001f + CULL_SLACK;
 
-			for (int word_base = word_lo; word_base <= word_hi; word_base += 64)
+			f32x4 *const slots = s_lights[wave];
+			const int chunk_lo = int(win_lo >> 6u), chunk_hi = int(win_hi >> 6u);
+			for (int chunk = chunk_lo; chunk <= chunk_hi; chunk++)
 			{
-				// ---- gather: one candidate word per lane ----
-				const int my_word = word_base + lane;
-				uint32_t cand = 0u;
-				if (my_word <= word_hi)
+				// ---- gather + cull: one light per lane ----
+				const uint32_t light_index = uint32_t(chunk) * 64u + uint32_t(lane);
+				const int my_word = chunk * 2 + (lane >> 5);
+				bool keep = false;
+				bool is_spot = false;
+				f32x4 r0 = {0, 0, 0, 0}, r1q = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
+				if (index_in_range(light_index, win_lo, win_hi))
 				{
+					uint32_t word = 0u;
 					for (int cy = cy0; cy <= cy1; cy++)
 					{
 #pragma clang loop vectorize(disable) unroll(disable)
 						for (int cx = cx0; cx <= cx1; cx++)
-							cand |= a.bitmask[(cy * a.cl_res_x + cx) * a.cl_num_lights_32 + my_word];
+							word |= a.bitmask[(cy * a.cl_res_x + cx) * a.cl_num_lights_32 + my_word];
 					}
-					cand = cluster_mask_range(cand, win_lo, win_hi, 32u * uint32_t(my_word));
-				}
-				uint64_t live_words = __ballot(cand != 0u);
-
-				// ---- walk: scalar iteration over set bits, light records prefetched one candidate ahead ----
-				uint32_t word = 0u;
-				int word_index = 0;
-				auto next_candidate = [&]() -> int {
-					while (word == 0u)
+					if ((word >> (uint32_t(lane) & 31u)) & 1u)
 					{
-						if (live_words == 0ull)
-							return -1;
-						const int j = __builtin_ctzll(live_words);
-						live_words &= live_words - 1ull;
-						word = uint32_t(__builtin_amdgcn_readlane(int(cand), j));
-						word_index = word_base + j;
+						const f32x4 *rec = reinterpret_cast<const f32x4 *>(a.lights + light_index);
+						const f32x4 c = rec[0], p = rec[1], d = rec[2]; // colour|scale_bias, position|offset_radius, direction|inv_radius
+						const float radius = CULL_RADIUS_SCALE * rcp(d.w);
+						const float3_ to_light = f3(p.x, p.y, p.z) - centre;
+						const float reach = radius + tile_radius;
+						keep = dot(to_light, to_light) <= reach * reach;
+						is_spot = ((a.type_mask[light_index >> 5] >> (light_index & 31u)) & 1u) == 0u;
+						// unpackHalf2x16(spot_scale_bias).  The lane is copied to a scalar first: clang (ROCm 7.2) evaluates
+						// __builtin_bit_cast on a vector-component lvalue (v.w) at the address of the whole vector, i.e. as
+						// lane .x (observed: spots shaded with colour.x as scale | bias).
+						const float sb_lane = c.w;
+						const uint32_t sb_bits = __builtin_bit_cast(uint32_t, sb_lane);
+						const float spot_scale = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits & 0xffffu)));
+						const float spot_bias = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits >> 16)));
+						r0 = f32x4{p.x, p.y, p.z, radius * radius};
+						r1q = f32x4{c.x, c.y, c.z, 10.0f * d.w};
+						r2 = f32x4{d.x, d.y, d.z, 0.0f};
+						r3 = f32x4{spot_scale, spot_bias, 0.0f, 0.0f};
 					}
-					const int bit = __builtin_ctz(word);
-					word &= word - 1u;
-					return 32 * word_index + bit;
-				};
-
-				int current = next_candidate();
-				LightRecord li{};
-				if (current >= 0)
-					li = fetch_light(a, current);
-				while (current >= 0)
-				{
-					const int upcoming = next_candidate();
-					LightRecord li_next = li;
-					if (upcoming >= 0)
-						li_next = fetch_light(a, upcoming);
-					shade_positional(s, li, current, result);
-					li = li_next;
-					current = upcoming;
 				}
+				uint64_t kept = __ballot(keep);
+				const uint64_t spots = __ballot(keep && is_spot);
+				if (keep)
+				{
+					const int slot = __builtin_amdgcn_mbcnt_hi(uint32_t(kept >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(kept), 0u));
+					f32x4 *dst_slot = slots + slot * (LIGHT_SLOT_BYTES / 16);
+					dst_slot[0] = r0;
+					dst_slot[1] = r1q;
+					if (is_spot)
+					{
+						dst_slot[2] = r2;
+						dst_slot[3] = r3;
+					}
+				}
+				__builtin_amdgcn_wave_barrier(); // LDS is wave-private: in-order DS execution is the only ordering needed
+
+				// ---- shade: one pixel per lane, lights broadcast from LDS ----
+				const f32x4 *slot = slots;
+				while (kept != 0ull)
+				{
+					const int src_lane = __builtin_ctzll(kept);
+					kept &= kept - 1ull;
+					const bool spot = ((spots >> src_lane) & 1ull) != 0ull;
+					shade_positional(s, slot[0], slot[1], slot, spot, result);
+					slot += LIGHT_SLOT_BYTES / 16;
+				}
+				__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
 			}
 		}
 		accum = f3(float(_Float16(accum.x + result.x)), float(_Float16(accum.y + result.y)), float(_Float16(accum.z + result.z)));

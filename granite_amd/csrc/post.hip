@@ -138,17 +138,23 @@ __global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_lumin
 }
 
 // ---- tonemap (tonemap.frag:30-66) -----------------------------------------------------------------------------------
+// Per pixel this pass is 12.5 B of traffic but three filmic curves + three sRGB encodes, i.e. VALU-heavy; the arithmetic is
+// kept lean so that the kernel stays on the HBM side of its roofline: the filmic division is num * v_rcp_f32(den) (1 ulp),
+// and when the bloom level is exactly 1/4 resolution (the InputRelative 0.25 level of even-sized targets) the four pixels of
+// a lane share one 3x2 bloom footprint that is lerped separably instead of four independent 4-tap fetches.
 __device__ __forceinline__ float uncharted2(float x)
 {
 	const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
-	return ((x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F)) - E / F;
+	const float num = fmaf(x, fmaf(A, x, C * B), D * E);
+	const float den = fmaf(x, fmaf(A, x, B), D * F);
+	return fmaf(num, __builtin_amdgcn_rcpf(den), -(E / F));
 }
 
 constexpr int TONEMAP_PX = 4; // pixels per lane: 2 x 16 B loads, one 16 B store
 constexpr int TONEMAP_BLOCK_X = 64;
 constexpr int TONEMAP_BLOCK_Y = 4;
 
-template <bool DYNAMIC_EXPOSURE, bool SRGB>
+template <bool DYNAMIC_EXPOSURE, bool SRGB, bool QUARTER_BLOOM>
 __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(DevImage hdr, DevImage bloom, DevImageRW out,
                                                                               const gr_luminance_data *lum,
                                                                               gr_push_tonemap push)
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 		return;
 
 	const float inv_w = 1.0f / float(hdr.w), inv_h = 1.0f / float(hdr.h);
-	const float white_scale = 1.0f / uncharted2(11.2f);
+	const float white_scale = 1.0f / (((11.2f * (0.15f * 11.2f + 0.10f * 0.50f) + 0.20f * 0.02f) /
+	                                   (11.2f * (0.15f * 11.2f + 0.50f) + 0.20f * 0.30f)) - 0.02f / 0.30f);
 	float scale = push.dynamic_exposure;
 	if (DYNAMIC_EXPOSURE)
 		scale *= lum->average_inv_linear_luminance;
@@ -186,14 +193,55 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 			texels[i] = *reinterpret_cast<const f16x4 *>(row + size_t(min(x0 + i, hdr.w - 1)) * 8u);
 	}
 
+	float bloom_rgb[TONEMAP_PX][3];
+	if (QUARTER_BLOOM)
+	{
+		// hdr = 4 x bloom in both axes and x0 = 4k: the unnormalised bloom coordinate of pixel x0 + i is
+		// k + (i + 0.5)/4 - 0.5, i.e. texel pairs (k-1,k),(k-1,k),(k,k+1),(k,k+1) with weights .625,.875,.125,.375;
+		// rows likewise from y.  Same StockSampler::LinearClamp result, evaluated separably (rows first).
+		const int k = x0 >> 2;
+		const int j = (y >> 2) - (((y & 3) < 2) ? 1 : 0);
+		const float wy = 0.125f + 0.25f * float((y + 2) & 3);
+		const int r0 = clampi(j, 0, bloom.h - 1), r1 = clampi(j + 1, 0, bloom.h - 1);
+		float col[3][3];
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+		{
+			const int cx = clampi(k - 1 + c, 0, bloom.w - 1);
+			const f16x4 t0 = *reinterpret_cast<const f16x4 *>(bloom.ptr + size_t(r0) * bloom.pitch + size_t(cx) * 8u);
+			const f16x4 t1 = *reinterpret_cast<const f16x4 *>(bloom.ptr + size_t(r1) * bloom.pitch + size_t(cx) * 8u);
+			col[c][0] = fmaf(float(t1.x) - float(t0.x), wy, float(t0.x));
+			col[c][1] = fmaf(float(t1.y) - float(t0.y), wy, float(t0.y));
+			col[c][2] = fmaf(float(t1.z) - float(t0.z), wy, float(t0.z));
+		}
+#pragma unroll
+		for (int ch = 0; ch < 3; ch++)
+		{
+			bloom_rgb[0][ch] = fmaf(col[1][ch] - col[0][ch], 0.625f, col[0][ch]);
+			bloom_rgb[1][ch] = fmaf(col[1][ch] - col[0][ch], 0.875f, col[0][ch]);
+			bloom_rgb[2][ch] = fmaf(col[2][ch] - col[1][ch], 0.125f, col[1][ch]);
+			bloom_rgb[3][ch] = fmaf(col[2][ch] - col[1][ch], 0.375f, col[1][ch]);
+		}
+	}
+	else
+	{
+#pragma unroll
+		for (int i = 0; i < TONEMAP_PX; i++)
+		{
+			const float u = (float(x0 + i) + 0.5f) * inv_w;
+			const float4 b = sample_linear_rgba16f(bloom, u, v);
+			bloom_rgb[i][0] = b.x;
+			bloom_rgb[i][1] = b.y;
+			bloom_rgb[i][2] = b.z;
+		}
+	}
+
 #pragma unroll
 	for (int i = 0; i < TONEMAP_PX; i++)
 	{
-		const float u = (float(x0 + i) + 0.5f) * inv_w;
-		const float4 b = sample_linear_rgba16f(bloom, u, v);
-		const float r = (float(texels[i].x) + b.x) * scale;
-		const float g = (float(texels[i].y) + b.y) * scale;
-		const float bl = (float(texels[i].z) + b.z) * scale;
+		const float r = (float(texels[i].x) + bloom_rgb[i][0]) * scale;
+		const float g = (float(texels[i].y) + bloom_rgb[i][1]) * scale;
+		const float bl = (float(texels[i].z) + bloom_rgb[i][2]) * scale;
 		const float tr = uncharted2(r) * white_scale;
 		const float tg = uncharted2(g) * white_scale;
 		const float tb = uncharted2(bl) * white_scale;
@@ -313,14 +361,24 @@ int gr_tonemap(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_imag
 	dim3 grid(gr_div_up(hdr->width, TONEMAP_BLOCK_X * TONEMAP_PX), gr_div_up(hdr->height, TONEMAP_BLOCK_Y));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "tonemap"};
 	hipStream_t s = gr_to_stream(stream);
-	if (lum && srgb)
-		hipLaunchKernelGGL((k_tonemap<true, true>), grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push);
-	else if (lum)
-		hipLaunchKernelGGL((k_tonemap<true, false>), grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push);
-	else if (srgb)
-		hipLaunchKernelGGL((k_tonemap<false, true>), grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push);
+	const bool quarter = hdr->width == 4u * bloom->width && hdr->height == 4u * bloom->height;
+	auto launch = [&](auto kernel) {
+		hipLaunchKernelGGL(kernel, grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push);
+	};
+	if (quarter)
+	{
+		if (lum && srgb) launch(k_tonemap<true, true, true>);
+		else if (lum) launch(k_tonemap<true, false, true>);
+		else if (srgb) launch(k_tonemap<false, true, true>);
+		else launch(k_tonemap<false, false, true>);
+	}
 	else
-		hipLaunchKernelGGL((k_tonemap<false, false>), grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push);
+	{
+		if (lum && srgb) launch(k_tonemap<true, true, false>);
+		else if (lum) launch(k_tonemap<true, false, false>);
+		else if (srgb) launch(k_tonemap<false, true, false>);
+		else launch(k_tonemap<false, false, false>);
+	}
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

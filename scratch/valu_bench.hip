@@ -27,6 +27,22 @@ template <int OP> __global__ __launch_bounds__(256) void k(float *out, float a, 
 			if (OP == 11) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,1]" : "+v"(p[i]) : "v"(pa), "v"(pb));
 			if (OP == 12) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(r[i]));
 			if (OP == 13) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pa));
+			if (OP == 14) asm volatile("v_fmaak_f32 %0, %0, %1, 0x41200000" : "+v"(r[i]) : "v"(a));
+			if (OP == 15) asm volatile("v_fma_f32 %0, %0, %1, 2.0" : "+v"(r[i]) : "v"(a));
+			if (OP == 16) asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(r[i]) : "v"(a), "v"(b));
+			if (OP == 17) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(r[i]) : "s"(a));
+			if (OP == 18) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r[i]) : "s"(a));
+			if (OP == 19) asm volatile("v_max_f32 %0, 1.0, %0" : "+v"(r[i]));
+			if (OP == 20) asm volatile("v_min_f32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+			if (OP == 21) asm volatile("v_mov_b32 %0, %1" : "=v"(r[i]) : "s"(a));
+			if (OP == 22) asm volatile("v_fma_f32 %0, -%0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+			if (OP == 23) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+			if (OP == 24) asm volatile("v_fma_f32 %0, %0, %1, %2 mul:2" : "+v"(r[i]) : "v"(a), "v"(b));
+			if (OP == 25) asm volatile("v_mul_f32 %0, 0.5, %0" : "+v"(r[i]));
+			if (OP == 26) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(r[i]));
+			if (OP == 27) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+			if (OP == 28) asm volatile("v_fma_mix_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+			if (OP == 29) asm volatile("v_mul_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r[i]) : "v"(a));
 		}
 	}
 	float s = 0; for (int i = 0; i < 8; i++) s += r[i] + p[i].x + p[i].y;
@@ -51,5 +67,9 @@ int main()
 	run<0>("v_fma_f32", d); run<1>("v_pk_fma_f32", d); run<11>("v_pk_fma_f32 op_sel bcast", d); run<2>("v_max_f32", d); run<3>("v_med3_f32", d);
 	run<4>("v_rsq_f32", d); run<9>("v_rcp_f32", d); run<5>("v_mul_f32", d); run<6>("v_pk_mul_f32", d); run<13>("v_pk_add_f32", d); run<7>("v_add_f32", d);
 	run<8>("v_cmp_lt_f32", d); run<10>("v_fma_f32 sgpr src", d); run<12>("v_cvt_f16_f32", d);
+	run<14>("v_fmaak_f32 literal", d); run<15>("v_fma_f32 inline const", d); run<16>("v_fma_f32 clamp", d); run<17>("v_mul_f32 sgpr", d);
+	run<18>("v_sub_f32 sgpr", d); run<19>("v_max_f32 inline", d); run<20>("v_min_f32", d); run<21>("v_mov_b32 sgpr", d);
+	run<22>("v_fma_f32 neg mod", d); run<23>("v_fmac_f32", d); run<24>("v_fma_f32 omod", d); run<25>("v_mul_f32 inline 0.5", d);
+	run<26>("v_cvt_f32_f16", d); run<27>("v_and_b32", d); run<28>("v_fma_mix_f32", d); run<29>("v_mul_f32_dpp", d);
 	return 0;
 }
