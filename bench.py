@@ -107,21 +107,35 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
+        # Control plane only (barriers, the max-over-ranks reduction, shipping the RCCL id): gloo on the host.  The data
+        # path's collectives are RCCL all-gathers issued by the executor itself on its own stream (gra_comm_init).
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
 
-    from granite_amd import app as gapp, synth
+    from granite_amd import app as gapp, multigpu, synth
 
     width, height, num_lights, desc = WORKLOADS[args.workload]
+    workload_name = args.workload
+    if world > 1:
+        # Weak scaling: one base frame's worth of pixels per rank, the frame tiled into `world` row bands
+        # (7680x4320 at 4 ranks is BASELINE config 5's frame); same camera, same 4096 lights, same cluster grid.
+        width, height = multigpu.weak_scaled_frame(world, (width, height))
+        workload_name = f"{args.workload}_x{world}_rowbands_{width}x{height}"
+        desc = f"{width}x{height} tiled into {world} row bands (one per GPU), {num_lights} clustered lights, bloom pyramid + luminance + tonemap"
     cam = synth.Camera(width, height)
     gbuf = synth.make_gbuffer(cam)
     descs = synth.make_lights(cam, num_lights, spot_fraction=0.25 if num_lights > 256 else 0.0)
 
     application = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True,
-                                   compute_post=True)
+                                   compute_post=True, strip_index=rank if world > 1 else 0, strip_count=world)
     application.set_render_parameters(cam.render_params())
     application.set_lights(descs)
     application.upload_gbuffer(gbuf)
+    if world > 1:
+        ids = [gapp.Application.comm_create_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        application.comm_init(ids[0], rank, world)
+    plan = application.strip_plan()
     kctx = application.kernel_context()
 
     def barrier():
@@ -156,11 +170,11 @@ def main():
     kctx.timing_enable(False)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    pixels_per_step = width * height * world  # replicas: every rank renders its own frame
+    pixels_per_step = width * height  # one frame per step; at N > 1 its row bands are spread over the ranks
     value = pixels_per_step * args.steps / elapsed / 1e6
 
     dom_count, dom_ms = timed.get(dominant, (0, 0.0))
@@ -168,7 +182,10 @@ def main():
     bpp = ALGO_BYTES_PER_PX.get(dominant)
     roofline = None
     if bpp and dom_avg_s > 0:
-        algo_bytes = bpp * width * height
+        # rank 0's launch of the dominant kernel covers its own band only
+        band = {"lighting": plan["lighting"], "tonemap": plan["tonemap"], "bloom_threshold": plan["threshold"]}.get(dominant)
+        rows = height if band is None else band[1] * (2 if dominant == "bloom_threshold" else 1)
+        algo_bytes = bpp * width * rows
         achieved = algo_bytes / dom_avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
@@ -189,8 +206,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": args.workload, "description": desc, "width": width, "height": height, "lights": num_lights,
-                   "cluster_grid": list(synth.CLUSTER_RESOLUTION), "parallelism": "replicas" if world > 1 else "single",
+        "config": {"workload": workload_name, "description": desc, "width": width, "height": height, "lights": num_lights,
+                   "cluster_grid": list(synth.CLUSTER_RESOLUTION),
+                   "parallelism": f"{world} row bands, RCCL all-gather of the 1/8 bloom level and of the tonemapped bands" if world > 1 else "single",
                    "hdr_format": "R16G16B16A16_SFLOAT", "seed": synth.SEED},
         "roofline": roofline,
         "chain": {"algorithmic_GBps": chain_gbs, "frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS,

@@ -24,7 +24,12 @@ class Config(C.Structure):
                 ("hdr_bloom", C.c_int32), ("dynamic_exposure", C.c_int32), ("compute_post", C.c_int32),
                 ("post_aa", C.c_int32), ("pre_aa", C.c_int32), ("rmw_emissive", C.c_int32),
                 ("cluster_res", C.c_uint32 * 3), ("frame_time", C.c_float), ("directional_color", C.c_float * 3),
-                ("directional_direction", C.c_float * 3), ("enable_timestamps", C.c_int32)]
+                ("directional_direction", C.c_float * 3), ("enable_timestamps", C.c_int32),
+                ("strip_index", C.c_uint32), ("strip_count", C.c_uint32)]
+
+
+# void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream)
+EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p)
 
 
 class ResourceInfo(C.Structure):
@@ -41,7 +46,8 @@ EXPORTED_SYMBOLS = [
     "gra_get_render_parameters", "gra_set_lights", "gra_upload_gbuffer", "gra_render_frames", "gra_sync",
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
-    "gra_set_smaa_luts", "gra_get_host_stats",
+    "gra_set_smaa_luts", "gra_get_host_stats", "gra_set_exchange_callback", "gra_get_strip_plan",
+    "gra_comm_create_unique_id", "gra_comm_init",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -79,6 +85,10 @@ def load_library() -> C.CDLL:
         "gra_get_taa_reprojection": (C.c_int, [vp, vp]),
         "gra_set_smaa_luts": (C.c_int, [vp, vp, vp]),
         "gra_get_host_stats": (C.c_int, [vp, vp]),
+        "gra_set_exchange_callback": (C.c_int, [vp, EXCHANGE_FN, vp]),
+        "gra_get_strip_plan": (C.c_int, [vp, vp]),
+        "gra_comm_create_unique_id": (C.c_int, [vp]),
+        "gra_comm_init": (C.c_int, [vp, vp, C.c_int32, C.c_int32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -97,7 +107,7 @@ class Application:
     def __init__(self, width: int, height: int, *, device: int = 0, lighting: bool = True, hdr_bloom: bool = True,
                  dynamic_exposure: bool = True, compute_post: bool = True, post_aa: int = POST_AA_NONE,
                  pre_aa: int = POST_AA_NONE, rmw_emissive: bool = False, cluster_res=synth.CLUSTER_RESOLUTION,
-                 frame_time: float = synth.FRAME_TIME, timestamps: bool = False):
+                 frame_time: float = synth.FRAME_TIME, timestamps: bool = False, strip_index: int = 0, strip_count: int = 1):
         self.lib = load_library()
         cfg = Config()
         cfg.device, cfg.width, cfg.height = device, width, height
@@ -109,6 +119,8 @@ class Application:
         cfg.directional_color[:] = synth.DIRECTIONAL_COLOR
         cfg.directional_direction[:] = synth.DIRECTIONAL_DIRECTION
         cfg.enable_timestamps = int(timestamps)
+        cfg.strip_index, cfg.strip_count = strip_index, strip_count
+        self._exchange_ref = None
         self.config = cfg
         self.width, self.height = width, height
         err = C.create_string_buffer(512)
@@ -239,6 +251,44 @@ class Application:
         arr = (Timestamp * 64)()
         n = self._check(self.lib.gra_collect_timestamps(self.handle, arr, 64))
         return {arr[i].tag.decode(): (int(arr[i].count), float(arr[i].total_ms)) for i in range(n)}
+
+    # ---- row-band tiling ---------------------------------------------------------------------------------------------
+    def set_exchange_callback(self, fn):
+        """fn(tag: str, device_ptr: int, chunk_bytes: int, rank_count: int, stream: int) is called by the executor where
+        the bands of all ranks meet; None removes it."""
+        if fn is None:
+            self._exchange_ref = None
+            self._check(self.lib.gra_set_exchange_callback(self.handle, C.cast(None, EXCHANGE_FN), None))
+            return
+
+        def trampoline(_user, tag, ptr, chunk_bytes, ranks, stream):
+            fn(tag.decode(), int(ptr or 0), int(chunk_bytes), int(ranks), int(stream or 0))
+
+        self._exchange_ref = EXCHANGE_FN(trampoline)  # keep alive
+        self._check(self.lib.gra_set_exchange_callback(self.handle, self._exchange_ref, None))
+
+    @staticmethod
+    def comm_create_unique_id() -> bytes:
+        """Rank 0: the 128-byte RCCL id every rank passes to comm_init."""
+        buf = (C.c_uint8 * 128)()
+        if load_library().gra_comm_create_unique_id(buf) != 0:
+            raise capi.GraniteHipError("gra_comm_create_unique_id failed (librccl.so.1 not loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, ranks: int):
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.gra_comm_init(self.handle, buf, rank, ranks))
+
+    def strip_plan(self) -> dict:
+        out = np.zeros(24, np.uint32)
+        self._check(self.lib.gra_get_strip_plan(self.handle, out.ctypes.data))
+        plan = {"index": int(out[0]), "count": int(out[1]), "width": int(out[2]), "height": int(out[3])}
+        for i, name in enumerate(("lighting", "threshold", "d0", "d1", "u0", "tonemap")):
+            whole, first, count = (int(v) for v in out[4 + 3 * i:7 + 3 * i])
+            plan[name] = None if whole else (first, count)
+        plan["d1_chunk_rows"], plan["out_chunk_rows"] = int(out[22]), int(out[23])
+        return plan
 
     def host_stats(self) -> dict:
         out = np.zeros(3, np.float64)

@@ -131,6 +131,55 @@ int gra_render_frames(gra_app *app, uint32_t count, int32_t sync)
 	});
 }
 
+int gra_set_exchange_callback(gra_app *app, gra_exchange_fn fn, void *user)
+{
+	return guarded(app, [&]() { app->app->set_exchange_callback(fn, user); });
+}
+
+int gra_comm_create_unique_id(uint8_t *id128)
+{
+	if (!id128)
+		return -1;
+	try
+	{
+		HIP::Collective::create_unique_id(id128);
+		return 0;
+	}
+	catch (const std::exception &e)
+	{
+		fprintf(stderr, "gra_comm_create_unique_id: %s\n", e.what());
+		return -1;
+	}
+}
+
+int gra_comm_init(gra_app *app, const uint8_t *id128, int32_t rank, int32_t ranks)
+{
+	return guarded(app, [&]() {
+		if (!id128)
+			throw std::logic_error("gra_comm_init: null id");
+		app->app->init_collective(id128, rank, ranks);
+	});
+}
+
+int gra_get_strip_plan(gra_app *app, uint32_t *out24)
+{
+	return guarded(app, [&]() {
+		if (!out24)
+			throw std::logic_error("gra_get_strip_plan: null output");
+		auto &p = app->app->get_strip_plan();
+		uint32_t *o = out24;
+		*o++ = p.index; *o++ = p.count; *o++ = p.width; *o++ = p.height;
+		for (const Granite::RowRange *r : {&p.lighting, &p.threshold, &p.d0, &p.d1, &p.u0, &p.tonemap})
+		{
+			*o++ = r->whole ? 1u : 0u;
+			*o++ = r->first;
+			*o++ = r->count;
+		}
+		*o++ = p.d1_chunk_rows;
+		*o++ = p.out_chunk_rows;
+	});
+}
+
 int gra_get_host_stats(gra_app *app, double *out3)
 {
 	return guarded(app, [&]() {

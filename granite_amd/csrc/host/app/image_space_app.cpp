@@ -32,6 +32,19 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 	context.set_lighting_parameters(&lighting);
 	hdr_options.dynamic_exposure = config.dynamic_exposure != 0;
 
+	if (config.strip_count == 0)
+		config.strip_count = 1;
+	if (config.strip_count > 1)
+	{
+		if (config.strip_index >= config.strip_count)
+			throw std::logic_error("strip_index must be below strip_count.");
+		if (!config.enable_lighting || !config.hdr_bloom || !config.compute_post || config.post_aa != GRA_POST_AA_NONE ||
+		    config.pre_aa != GRA_POST_AA_NONE || config.rmw_emissive)
+			throw std::logic_error("Row-band tiling needs the deferred compute-post graph without AA and without the RMW emissive declaration.");
+	}
+	strip_plan = StripPlan::build(config.strip_index, config.strip_count, config.width, config.height);
+	hdr_options.strip = &strip_plan;
+
 	// Default camera of the survey's synthetic scene; gra_set_camera / gra_set_render_parameters override it.
 	set_base_camera(perspective(1.0471975512f, float(config.width) / float(config.height), 0.1f, 100.0f),
 	                look_at(vec3(0.0f, 2.0f, 8.0f), vec3(0.0f, 1.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f)));
@@ -40,6 +53,7 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 	if (!device_holder)
 		return;
 	auto &device = *device_holder;
+	device.set_image_row_granularity(config.strip_count);
 
 	// External swapchain: 4 images R8G8B8A8_SRGB, cycled per frame.
 	for (unsigned i = 0; i < 4; i++)
@@ -58,6 +72,30 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 ImageSpaceApplication::~ImageSpaceApplication()
 {
 	wait_idle();
+}
+
+void ImageSpaceApplication::set_exchange_callback(gra_exchange_fn fn, void *user)
+{
+	if (!fn)
+	{
+		strip_plan.exchange = nullptr;
+		return;
+	}
+	const uint32_t ranks = strip_plan.count;
+	strip_plan.exchange = [fn, user, ranks](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *tag) {
+		fn(user, tag, image.get_device_pointer(), uint64_t(chunk_rows) * image.get_view().pitch_bytes, ranks, cmd.get_stream());
+	};
+}
+
+void ImageSpaceApplication::init_collective(const uint8_t *id128, int rank, int ranks)
+{
+	if (unsigned(ranks) != strip_plan.count || unsigned(rank) != strip_plan.index)
+		throw std::logic_error("Collective rank / size must match the strip plan of this instance.");
+	get_device().make_current(); // the communicator binds to the calling thread's current device
+	collective.init(id128, rank, ranks);
+	strip_plan.exchange = [this](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *) {
+		collective.all_gather_in_place(image.get_device_pointer(), size_t(chunk_rows) * image.get_view().pitch_bytes, cmd.get_stream());
+	};
 }
 
 void ImageSpaceApplication::set_base_camera(const mat4 &projection, const mat4 &view)
@@ -228,6 +266,7 @@ void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
 		att.depth = &graph.get_physical_texture_resource(in_depth);
 		att.hdr = &graph.get_physical_texture_resource(*hdr_out);
 		att.emissive = emissive_in ? &graph.get_physical_texture_resource(*emissive_in) : att.hdr;
+		att.rows = strip_plan.active() ? &strip_plan.lighting : nullptr;
 		DeferredLightRenderer::render_light(cmd, context, att);
 	});
 

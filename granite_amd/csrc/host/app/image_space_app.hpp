@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include "../../../../include/granite_app.h"
+#include "../collective.hpp"
 #include "../lights/clusterer.hpp"
 #include "../post/aa.hpp"
 #include "../post/hdr.hpp"
@@ -49,6 +50,9 @@ public:
 	LightClusterer &get_clusterer() { return cluster; }
 	HIP::Image *get_last_backbuffer() { return last_backbuffer; }
 	const gra_config &get_config() const { return config; }
+	const StripPlan &get_strip_plan() const { return strip_plan; }
+	void set_exchange_callback(gra_exchange_fn fn, void *user);
+	void init_collective(const uint8_t *id128, int rank, int ranks);
 	// Host-side cost of the frame loop: frames rendered, wall seconds inside render_frame(), of which blocked on the GPU.
 	void get_host_stats(double out[3]) const
 	{
@@ -68,6 +72,8 @@ private:
 	LightClusterer cluster;
 	TaskComposer composer;
 	HDROptions hdr_options;
+	StripPlan strip_plan;
+	HIP::Collective collective;
 	TemporalJitter jitter;
 	mat4 base_projection, base_view;
 	bool has_base_camera = false;

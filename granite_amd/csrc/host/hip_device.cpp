@@ -22,7 +22,9 @@ Image::Image(Device &device_, unsigned width, unsigned height, VkFormat format, 
 	view.height = height;
 	view.pitch_bytes = width * bpp;
 	view.format = format;
-	int ret = gr_alloc(device->get_context(), get_size_bytes(), &view.ptr); // zero-initialised
+	const unsigned gran = device->get_image_row_granularity();
+	const size_t padded_rows = (size_t(height) + gran - 1) / gran * gran;
+	int ret = gr_alloc(device->get_context(), size_t(view.pitch_bytes) * padded_rows, &view.ptr); // zero-initialised
 	if (ret < 0)
 		throw std::runtime_error(std::string("gr_alloc failed for ") + name + ": " + gr_last_error(device->get_context()));
 	device->account_alloc(ptrdiff_t(get_size_bytes()));
@@ -140,6 +142,11 @@ Device::~Device()
 			(void)hipStreamDestroy(static_cast<hipStream_t>(s));
 	if (ctx)
 		gr_destroy(ctx);
+}
+
+void Device::make_current() const
+{
+	throw_hip(hipSetDevice(index), "hipSetDevice");
 }
 
 ImageHandle Device::create_image(unsigned width, unsigned height, VkFormat format, const std::string &name)

@@ -103,10 +103,16 @@ public:
 
 	gr_ctx *get_context() const { return ctx; }
 	int get_device_index() const { return index; }
+	void make_current() const; // hipSetDevice for the calling thread
 	gr_stream get_stream(CommandBuffer::Type type) const { return streams[int(type)]; }
 
 	ImageHandle create_image(unsigned width, unsigned height, VkFormat format, const std::string &name);
 	BufferHandle create_buffer(size_t size, VkBufferUsageFlags usage, const std::string &name);
+
+	// Images are allocated with their row count rounded up to a multiple of this (row-band all-gathers write
+	// rank_count * ceil(height / rank_count) rows).  The logical height is unchanged.
+	void set_image_row_granularity(unsigned rows) { image_row_granularity = rows ? rows : 1; }
+	unsigned get_image_row_granularity() const { return image_row_granularity; }
 
 	// Pinned-host staging for update_buffer: N frames in flight, each with its own bump allocator.
 	void *allocate_staging(size_t size);
@@ -134,5 +140,6 @@ private:
 	unsigned staging_index = 0;
 	size_t allocated_bytes = 0;
 	double blocked_seconds = 0.0;
+	unsigned image_row_granularity = 1;
 };
 } // namespace HIP

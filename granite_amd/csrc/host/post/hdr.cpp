@@ -7,6 +7,19 @@ namespace Granite
 {
 namespace
 {
+// RowRange -> the C ABI's render area.  Returns false when the band is empty (nothing to launch on this rank).
+bool to_rows(const RowRange *range, gr_rows &rows)
+{
+	rows = {0, 0};
+	if (!range || range->whole)
+		return true;
+	if (range->count == 0)
+		return false;
+	rows.first = range->first;
+	rows.count = range->count;
+	return true;
+}
+
 const gr_luminance_data *luminance_ptr(RenderGraph &graph, const RenderBufferResource *res)
 {
 	return res ? static_cast<const gr_luminance_data *>(graph.get_physical_buffer_resource(*res).get_device_pointer()) : nullptr;
@@ -31,8 +44,11 @@ void record_luminance(HIP::CommandBuffer &cmd, const FrameParameters &frame, Ren
 
 // bloom_threshold_build_compute / _render_pass (hdr.cpp:100-144)
 void record_threshold(HIP::CommandBuffer &cmd, RenderGraph &graph, const RenderTextureResource &threshold, const RenderTextureResource &hdr,
-                      const RenderBufferResource *ubo)
+                      const RenderBufferResource *ubo, const RowRange *range = nullptr)
 {
+	gr_rows rows;
+	if (!to_rows(range, rows))
+		return;
 	auto &output = graph.get_physical_texture_resource(threshold);
 	auto &input = graph.get_physical_texture_resource(hdr);
 	gr_push_bloom_threshold push = {};
@@ -40,14 +56,18 @@ void record_threshold(HIP::CommandBuffer &cmd, RenderGraph &graph, const RenderT
 	push.threads[1] = output.get_height();
 	push.inv_output_size[0] = 1.0f / float(push.threads[0]);
 	push.inv_output_size[1] = 1.0f / float(push.threads[1]);
-	cmd.check(gr_bloom_threshold(cmd.get_context(), cmd.get_stream(), &input.get_view(), &output.get_view(), luminance_ptr(graph, ubo), &push),
+	cmd.check(gr_bloom_threshold_rows(cmd.get_context(), cmd.get_stream(), &input.get_view(), &output.get_view(), luminance_ptr(graph, ubo),
+	                                  &push, &rows),
 	          "bloom_threshold");
 }
 
 // bloom_downsample_build_compute / _render_pass (hdr.cpp:146-187,218-270)
 void record_downsample(HIP::CommandBuffer &cmd, const FrameParameters &frame, RenderGraph &graph, const RenderTextureResource &output_res,
-                       const RenderTextureResource &input_res, const RenderTextureResource *feedback)
+                       const RenderTextureResource &input_res, const RenderTextureResource *feedback, const RowRange *range = nullptr)
 {
+	gr_rows rows;
+	if (!to_rows(range, rows))
+		return;
 	auto &output = graph.get_physical_texture_resource(output_res);
 	auto &input = graph.get_physical_texture_resource(input_res);
 	HIP::ImageView *history = feedback ? graph.get_physical_history_texture_resource(*feedback) : nullptr; // null on frame 0
@@ -60,14 +80,18 @@ void record_downsample(HIP::CommandBuffer &cmd, const FrameParameters &frame, Re
 	push.inv_input_size[0] = 1.0f / float(input.get_width());
 	push.inv_input_size[1] = 1.0f / float(input.get_height());
 	push.lerp = float(1.0 - std::pow(0.001, frame.frame_time));
-	cmd.check(gr_bloom_downsample(cmd.get_context(), cmd.get_stream(), &input.get_view(), &output.get_view(),
-	                              history ? &history->get_view() : nullptr, &push),
+	cmd.check(gr_bloom_downsample_rows(cmd.get_context(), cmd.get_stream(), &input.get_view(), &output.get_view(),
+	                                   history ? &history->get_view() : nullptr, &push, &rows),
 	          "bloom_downsample");
 }
 
 // bloom_upsample_build_compute / _render_pass (hdr.cpp:189-216,272-281)
-void record_upsample(HIP::CommandBuffer &cmd, RenderGraph &graph, const RenderTextureResource &output_res, const RenderTextureResource &input_res)
+void record_upsample(HIP::CommandBuffer &cmd, RenderGraph &graph, const RenderTextureResource &output_res, const RenderTextureResource &input_res,
+                     const RowRange *range = nullptr)
 {
+	gr_rows rows;
+	if (!to_rows(range, rows))
+		return;
 	auto &output = graph.get_physical_texture_resource(output_res);
 	auto &input = graph.get_physical_texture_resource(input_res);
 	gr_push_bloom_upsample push = {};
@@ -77,21 +101,27 @@ void record_upsample(HIP::CommandBuffer &cmd, RenderGraph &graph, const RenderTe
 	push.inv_output_size[1] = 1.0f / float(push.threads[1]);
 	push.inv_input_size[0] = 1.0f / float(input.get_width());
 	push.inv_input_size[1] = 1.0f / float(input.get_height());
-	cmd.check(gr_bloom_upsample(cmd.get_context(), cmd.get_stream(), &input.get_view(), &output.get_view(), &push), "bloom_upsample");
+	cmd.check(gr_bloom_upsample_rows(cmd.get_context(), cmd.get_stream(), &input.get_view(), &output.get_view(), &push, &rows),
+	          "bloom_upsample");
 }
 
 // tonemap_build_render_pass (hdr.cpp:283-306)
 void record_tonemap(RenderPass &pass, HIP::CommandBuffer &cmd, const RenderTextureResource &hdr_res, const RenderTextureResource &bloom_res,
-                    const RenderBufferResource *ubo, const HDRDynamicExposureInterface *iface)
+                    const RenderBufferResource *ubo, const HDRDynamicExposureInterface *iface, const StripPlan *strip = nullptr)
 {
 	auto &graph = pass.get_graph();
 	auto &hdr = graph.get_physical_texture_resource(hdr_res);
 	auto &bloom = graph.get_physical_texture_resource(bloom_res);
 	auto &output = graph.get_physical_texture_resource(*pass.get_color_outputs()[0]);
 	gr_push_tonemap push = {iface ? iface->get_exposure() : 1.0f};
-	cmd.check(gr_tonemap(cmd.get_context(), cmd.get_stream(), &hdr.get_view(), &bloom.get_view(), &output.get_view(), luminance_ptr(graph, ubo),
-	                     &push),
-	          "tonemap");
+	gr_rows rows;
+	if (to_rows(strip ? &strip->tonemap : nullptr, rows))
+		cmd.check(gr_tonemap_rows(cmd.get_context(), cmd.get_stream(), &hdr.get_view(), &bloom.get_view(), &output.get_view(),
+		                          luminance_ptr(graph, ubo), &push, &rows),
+		          "tonemap");
+	// Row-band tiling: the tonemapped bands of all ranks meet in every rank's output image.
+	if (strip && strip->exchange)
+		strip->exchange(cmd, output, strip->out_chunk_rows, "tonemapped");
 }
 
 AttachmentInfo bloom_level_info(const std::string &input, float scale)
@@ -133,16 +163,23 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 
 	// Recorded order = hdr.cpp:354-379.  The threshold reads LAST frame's exposure (same buffer, updated later in this
 	// pass); cmd.barrier() between dispatches is stream order here.
-	bloom_pass.set_build_render_pass([&graph, &frame, &t, &d0, &d1, &d2, &d3, &u0, &u1, &u2, &hdr, ubo = lum](HIP::CommandBuffer &cmd) {
+	// Row-band tiling (options.strip): the band-limited dispatches compute this rank's part of threshold / d0 / d1, the
+	// 1/8 level is all-gathered, everything coarser is replicated, u0 is computed where the tonemap band samples it.
+	// (A one-rank plan with an exchange installed still runs the exchange points: that is how the transport is tested.)
+	const StripPlan *plan = options.strip;
+	bloom_pass.set_build_render_pass([&graph, &frame, &t, &d0, &d1, &d2, &d3, &u0, &u1, &u2, &hdr, ubo = lum, plan](HIP::CommandBuffer &cmd) {
+		const StripPlan *strip = plan && (plan->active() || plan->exchange) ? plan : nullptr;
 		const auto compute_to_compute = [&cmd]() {
 			cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
 			            VK_ACCESS_2_SHADER_SAMPLED_READ_BIT);
 		};
-		record_threshold(cmd, graph, t, hdr, ubo);
+		record_threshold(cmd, graph, t, hdr, ubo, strip ? &strip->threshold : nullptr);
 		compute_to_compute();
-		record_downsample(cmd, frame, graph, d0, t, nullptr);
+		record_downsample(cmd, frame, graph, d0, t, nullptr, strip ? &strip->d0 : nullptr);
 		compute_to_compute();
-		record_downsample(cmd, frame, graph, d1, d0, nullptr);
+		record_downsample(cmd, frame, graph, d1, d0, nullptr, strip ? &strip->d1 : nullptr);
+		if (strip && strip->exchange)
+			strip->exchange(cmd, graph.get_physical_texture_resource(d1), strip->d1_chunk_rows, "downsample-1");
 		compute_to_compute();
 		record_downsample(cmd, frame, graph, d2, d1, nullptr);
 		compute_to_compute();
@@ -154,7 +191,7 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 		compute_to_compute();
 		record_upsample(cmd, graph, u1, u2);
 		compute_to_compute();
-		record_upsample(cmd, graph, u0, u1);
+		record_upsample(cmd, graph, u0, u1, strip ? &strip->u0 : nullptr);
 	});
 
 	{
@@ -169,8 +206,9 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 		const RenderBufferResource *ubo_res = nullptr;
 		if (options.dynamic_exposure)
 			ubo_res = &tonemap.add_uniform_input("average-luminance");
-		tonemap.set_build_render_pass([&tonemap, &hdr_res, &bloom_res, iface, ubo = ubo_res](HIP::CommandBuffer &cmd) {
-			record_tonemap(tonemap, cmd, hdr_res, bloom_res, ubo, iface);
+		tonemap.set_build_render_pass([&tonemap, &hdr_res, &bloom_res, iface, ubo = ubo_res, plan](HIP::CommandBuffer &cmd) {
+			const StripPlan *strip = plan && (plan->active() || plan->exchange) ? plan : nullptr;
+			record_tonemap(tonemap, cmd, hdr_res, bloom_res, ubo, iface, strip);
 		});
 	}
 }

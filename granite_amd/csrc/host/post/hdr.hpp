@@ -3,6 +3,7 @@
 #include <string>
 #include "../render_graph.hpp"
 #include "../render_context.hpp"
+#include "../strip_plan.hpp"
 
 namespace Granite
 {
@@ -15,6 +16,9 @@ struct HDRDynamicExposureInterface
 struct HDROptions
 {
 	bool dynamic_exposure = true;
+	// HIP executor extension: row-band tiling of the frame across devices (strip_plan.hpp).  nullptr or an inactive plan
+	// = the whole frame on this device.  Honoured by setup_hdr_postprocess_compute only.
+	const StripPlan *strip = nullptr;
 };
 
 // Ten separate passes (hdr.cpp:402-561).

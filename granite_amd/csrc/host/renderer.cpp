@@ -72,6 +72,13 @@ void DeferredLightRenderer::render_light(HIP::CommandBuffer &cmd, const RenderCo
 		args.clustering.inv_resolution[1] = inv_h;
 	}
 
+	if (att.rows && !att.rows->whole)
+	{
+		if (att.rows->count == 0)
+			return; // empty band on this rank
+		args.rows.first = att.rows->first;
+		args.rows.count = att.rows->count;
+	}
 	cmd.check(gr_lighting(cmd.get_context(), cmd.get_stream(), &args), "lighting");
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include "render_context.hpp"
 #include "render_graph.hpp"
+#include "strip_plan.hpp"
 
 namespace Granite
 {
@@ -15,6 +16,7 @@ struct DeferredLightAttachments
 	const HIP::ImageView *depth = nullptr;      // depth-main, D32F
 	const HIP::ImageView *emissive = nullptr;   // blend destination contents before the draws
 	HIP::ImageView *hdr = nullptr;              // HDR-main; may be the same image as emissive (reference RMW)
+	const RowRange *rows = nullptr;             // render area (row-band tiling); nullptr = whole target
 };
 
 class DeferredLightRenderer

@@ -1,0 +1,104 @@
+#include "strip_plan.hpp"
+#include <algorithm>
+#include <cmath>
+#include <stdexcept>
+
+namespace Granite
+{
+namespace
+{
+uint32_t level_size(uint32_t full, float scale)
+{
+	return uint32_t(std::ceil(float(full) * scale)); // get_resource_dimensions: ceil(input * size)
+}
+
+struct Span
+{
+	int64_t lo, hi; // inclusive
+};
+
+// Input rows a band of output rows reads through a LinearClamp fetch at v = (r + 0.5) / out_h displaced by up to
+// `reach` input texels (tent taps: 1.75 down, 0.875 up; 0 for a plain bilinear fetch), one row of safety either side
+// for the fp32 coordinate arithmetic of the kernels.
+Span footprint(Span out_rows, uint32_t out_h, uint32_t in_h, double reach)
+{
+	const double scale = double(in_h) / double(out_h);
+	const double lo = (double(out_rows.lo) + 0.5) * scale - 0.5 - reach;
+	const double hi = (double(out_rows.hi) + 0.5) * scale - 0.5 + reach;
+	Span s;
+	s.lo = std::max<int64_t>(int64_t(std::floor(lo)) - 1, 0);
+	s.hi = std::min<int64_t>(int64_t(std::floor(hi)) + 2, int64_t(in_h) - 1);
+	return s;
+}
+
+RowRange to_range(Span s)
+{
+	RowRange r;
+	r.whole = false;
+	if (s.hi < s.lo)
+	{
+		r.first = 0;
+		r.count = 0;
+	}
+	else
+	{
+		r.first = uint32_t(s.lo);
+		r.count = uint32_t(s.hi - s.lo + 1);
+	}
+	return r;
+}
+
+Span chunk_of(unsigned index, uint32_t chunk, uint32_t height)
+{
+	const int64_t lo = int64_t(index) * chunk;
+	const int64_t hi = std::min<int64_t>(lo + chunk, height) - 1;
+	return {lo, hi};
+}
+} // namespace
+
+StripPlan StripPlan::build(unsigned index, unsigned count, uint32_t width, uint32_t height)
+{
+	if (count == 0 || index >= count)
+		throw std::logic_error("StripPlan: rank index out of range.");
+	StripPlan plan;
+	plan.index = index;
+	plan.count = count;
+	plan.width = width;
+	plan.height = height;
+	plan.h_threshold = level_size(height, 0.5f);
+	plan.h_d0 = level_size(height, 0.25f);
+	plan.h_d1 = level_size(height, 0.125f);
+	plan.h_u0 = plan.h_d0;
+	plan.out_chunk_rows = (height + count - 1) / count;
+	plan.d1_chunk_rows = (plan.h_d1 + count - 1) / count;
+	if (count == 1)
+		return plan; // every range stays "whole"; one chunk = the whole level
+
+	const Span out = chunk_of(index, plan.out_chunk_rows, height);
+	const Span d1 = chunk_of(index, plan.d1_chunk_rows, plan.h_d1);
+	plan.tonemap = to_range(out);
+	plan.d1 = to_range(d1);
+
+	Span hdr_rows = out;
+	if (d1.hi >= d1.lo)
+	{
+		const Span d0 = footprint(d1, plan.h_d1, plan.h_d0, 1.75);
+		const Span thr = footprint(d0, plan.h_d0, plan.h_threshold, 1.75);
+		const Span hdr_for_threshold = footprint(thr, plan.h_threshold, height, 0.0);
+		plan.d0 = to_range(d0);
+		plan.threshold = to_range(thr);
+		if (out.hi >= out.lo)
+			hdr_rows = {std::min(out.lo, hdr_for_threshold.lo), std::max(out.hi, hdr_for_threshold.hi)};
+		else
+			hdr_rows = hdr_for_threshold;
+	}
+	else
+	{
+		plan.d0 = to_range({0, -1});
+		plan.threshold = to_range({0, -1});
+	}
+	plan.lighting = to_range(hdr_rows);
+	plan.u0 = out.hi >= out.lo ? to_range(footprint(out, height, plan.h_u0, 0.0)) : to_range({0, -1});
+	return plan;
+}
+} // namespace Granite

@@ -1,0 +1,52 @@
+// Row-band tiling of one frame across N executors.  No reference analogue: Granite renders a frame on one
+// device.  Rank g owns a band of full-resolution rows; per-pixel passes (lighting, threshold, tonemap) and the fine bloom
+// levels run on the band plus the halo their consumers reach into, the 1/8-resolution level is all-gathered, the coarse
+// levels (1/16, 1/32, luminance, the first two upsamples) are computed redundantly and identically on every rank, and the
+// tonemapped bands are all-gathered into the swapchain image.  Every kernel keeps full-image coordinates, so a band holds
+// bit-identical values to the same rows of a single-device frame.
+#pragma once
+#include <cstdint>
+#include <functional>
+
+namespace HIP
+{
+class CommandBuffer;
+class Image;
+}
+
+namespace Granite
+{
+// Rows [first, first + count) of one render target.  whole == true: no restriction (count is ignored).
+struct RowRange
+{
+	bool whole = true;
+	uint32_t first = 0;
+	uint32_t count = 0;
+	bool empty() const { return !whole && count == 0; }
+};
+
+struct StripPlan
+{
+	unsigned index = 0, count = 1;
+	uint32_t width = 0, height = 0;
+	// heights of the InputRelative levels (render_graph.cpp:3158-3170: ceil(input * scale))
+	uint32_t h_threshold = 0, h_d0 = 0, h_d1 = 0, h_u0 = 0;
+
+	RowRange lighting;  // HDR rows: own output band + what the own 1/8 chunk needs through threshold / d0 / d1
+	RowRange threshold; // 1/2 level
+	RowRange d0;        // 1/4 level
+	RowRange d1;        // 1/8 level: exactly this rank's all-gather chunk
+	RowRange u0;        // 1/4 level rows the tonemap band samples
+	RowRange tonemap;   // full-res rows: exactly this rank's all-gather chunk
+	uint32_t d1_chunk_rows = 0;  // rows per rank in the 1/8-level all-gather (last ranks may own fewer real rows)
+	uint32_t out_chunk_rows = 0; // rows per rank in the final all-gather
+
+	bool active() const { return count > 1; }
+	static StripPlan build(unsigned index, unsigned count, uint32_t width, uint32_t height);
+
+	// All-gather of `chunk_rows` rows per rank inside `image` (rank r's rows start at r * chunk_rows; the image's memory
+	// is padded to count * chunk_rows rows).  Installed by the application; runs on the command buffer's stream.
+	using ExchangeHook = std::function<void(HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *tag)>;
+	ExchangeHook exchange;
+};
+} // namespace Granite

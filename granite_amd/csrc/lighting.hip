@@ -64,6 +64,7 @@ struct KernelArgs
 	const float *__restrict__ srgb_lut;
 	uint32_t flags;
 	int blocks_x, num_blocks, blocks_per_xcd;
+	int row_first, row_end, block_row0; // render area rows [row_first, row_end); first block row = row_first / 8
 };
 
 struct float3_ { float x, y, z; };
@@ -183,14 +184,14 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 	const int logical = int(blockIdx.x & 7u) * a.blocks_per_xcd + int(blockIdx.x >> 3);
 	if (logical >= a.num_blocks)
 		return;
-	const int block_x = logical % a.blocks_x, block_y = logical / a.blocks_x;
+	const int block_x = logical % a.blocks_x, block_y = a.block_row0 + logical / a.blocks_x;
 	const int wave = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
 	const int tile_x0 = (block_x * LIGHT_WAVES + wave) * LIGHT_TILE, tile_y0 = block_y * LIGHT_TILE;
 	const int x = tile_x0 + (lane & (LIGHT_TILE - 1));
 	const int y = tile_y0 + (lane >> 3);
 	const int W = a.hdr.w, H = a.hdr.h;
-	const bool inside = x < W && y < H;
+	const bool inside = x < W && y >= a.row_first && y < a.row_end; // row_end <= H
 
 	float depth = 0.0f;
 	uint32_t alb = 0, nrm = 0, mr = 0;
@@ -462,8 +463,21 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	k.srgb_lut = ctx->srgb_decode_lut;
 	k.flags = args->flags;
 
+	// Render area: tiles stay aligned to multiples of 8 rows of the full target, rows outside the band are masked.
+	uint32_t row_first = 0, row_end = H;
+	if (args->rows.count != 0)
+	{
+		row_first = args->rows.first < H ? args->rows.first : H;
+		const uint64_t end = uint64_t(args->rows.first) + args->rows.count;
+		row_end = end < H ? uint32_t(end) : H;
+	}
+	if (row_first >= row_end)
+		return GR_OK;
+	k.row_first = int(row_first);
+	k.row_end = int(row_end);
+	k.block_row0 = int(row_first / LIGHT_TILE);
 	k.blocks_x = int(gr_div_up(W, LIGHT_TILE * LIGHT_WAVES));
-	k.num_blocks = k.blocks_x * int(gr_div_up(H, LIGHT_TILE));
+	k.num_blocks = k.blocks_x * (int(gr_div_up(row_end, LIGHT_TILE)) - k.block_row0);
 	k.blocks_per_xcd = (k.num_blocks + 7) / 8;
 	dim3 grid(unsigned(k.blocks_per_xcd) * 8u);
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "lighting"};

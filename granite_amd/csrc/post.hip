@@ -24,11 +24,12 @@ static inline DevImageRW to_dev_rw(const gr_image *img)
 template <bool DYNAMIC_EXPOSURE>
 __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold(DevImage hdr, DevImageRW out,
                                                                                 const gr_luminance_data *lum,
-                                                                                gr_push_bloom_threshold push)
+                                                                                gr_push_bloom_threshold push, uint32_t y_first,
+                                                                                uint32_t y_end)
 {
 	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
-	const int y = blockIdx.y * POST_BLOCK_Y + threadIdx.y;
-	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= push.threads[1])
+	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
+	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
 		return;
 
 	const float u = (float(x) + 0.5f) * push.inv_output_size[0];
@@ -64,11 +65,12 @@ __device__ __forceinline__ float4 tent9(const DevImage &in, float u, float v, fl
 
 template <bool FEEDBACK>
 __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_downsample(DevImage in, DevImageRW out, DevImage history,
-                                                                                 gr_push_bloom_downsample push)
+                                                                                 gr_push_bloom_downsample push, uint32_t y_first,
+                                                                                 uint32_t y_end)
 {
 	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
-	const int y = blockIdx.y * POST_BLOCK_Y + threadIdx.y;
-	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= push.threads[1])
+	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
+	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
 		return;
 	const float u = (float(x) + 0.5f) * push.inv_output_size[0];
 	const float v = (float(y) + 0.5f) * push.inv_output_size[1];
@@ -88,11 +90,12 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_downsample
 }
 
 __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_upsample(DevImage in, DevImageRW out,
-                                                                               gr_push_bloom_upsample push)
+                                                                               gr_push_bloom_upsample push, uint32_t y_first,
+                                                                               uint32_t y_end)
 {
 	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
-	const int y = blockIdx.y * POST_BLOCK_Y + threadIdx.y;
-	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= push.threads[1])
+	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
+	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
 		return;
 	const float u = (float(x) + 0.5f) * push.inv_output_size[0];
 	const float v = (float(y) + 0.5f) * push.inv_output_size[1];
@@ -157,11 +160,11 @@ constexpr int TONEMAP_BLOCK_Y = 4;
 template <bool DYNAMIC_EXPOSURE, bool SRGB, bool QUARTER_BLOOM>
 __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(DevImage hdr, DevImage bloom, DevImageRW out,
                                                                               const gr_luminance_data *lum,
-                                                                              gr_push_tonemap push)
+                                                                              gr_push_tonemap push, uint32_t y_first, uint32_t y_end)
 {
 	const int x0 = (blockIdx.x * TONEMAP_BLOCK_X + threadIdx.x) * TONEMAP_PX;
-	const int y = blockIdx.y * TONEMAP_BLOCK_Y + threadIdx.y;
-	if (x0 >= hdr.w || y >= hdr.h)
+	const int y = int(y_first) + blockIdx.y * TONEMAP_BLOCK_Y + threadIdx.y;
+	if (x0 >= hdr.w || uint32_t(y) >= y_end)
 		return;
 
 	const float inv_w = 1.0f / float(hdr.w), inv_h = 1.0f / float(hdr.h);
@@ -261,6 +264,21 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 	}
 }
 
+// Resolves a render area against `height` output rows: [first, end), empty when the band lies outside the image.
+struct RowSpan
+{
+	uint32_t first, end;
+	uint32_t count() const { return end - first; }
+};
+static RowSpan resolve_rows(const gr_rows *rows, uint32_t height)
+{
+	if (!rows || rows->count == 0)
+		return {0, height};
+	const uint32_t first = rows->first < height ? rows->first : height;
+	const uint64_t end = uint64_t(rows->first) + rows->count;
+	return {first, end < height ? uint32_t(end) : height};
+}
+
 static bool is_rgba16f(const gr_image *img)
 {
 	return img && img->ptr && img->format == GR_FORMAT_R16G16B16A16_SFLOAT && img->width && img->height &&
@@ -273,6 +291,12 @@ extern "C" {
 int gr_bloom_threshold(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *out, const gr_luminance_data *lum,
                        const gr_push_bloom_threshold *push)
 {
+	return gr_bloom_threshold_rows(ctx, stream, hdr, out, lum, push, nullptr);
+}
+
+int gr_bloom_threshold_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *out, const gr_luminance_data *lum,
+                            const gr_push_bloom_threshold *push, const gr_rows *rows)
+{
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, push != nullptr);
@@ -280,19 +304,30 @@ int gr_bloom_threshold(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const
 	GR_CHECK_ARG(ctx, push->threads[0] <= out->width && push->threads[1] <= out->height);
 	if (push->threads[0] == 0 || push->threads[1] == 0)
 		return GR_OK;
+	const RowSpan span = resolve_rows(rows, push->threads[1]);
+	if (span.count() == 0)
+		return GR_OK;
 	dim3 block(POST_BLOCK_X, POST_BLOCK_Y);
-	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(push->threads[1], POST_BLOCK_Y));
+	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_threshold"};
 	if (lum)
-		hipLaunchKernelGGL(k_bloom_threshold<true>, grid, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, *push);
+		hipLaunchKernelGGL(k_bloom_threshold<true>, grid, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, *push,
+		                   span.first, span.end);
 	else
-		hipLaunchKernelGGL(k_bloom_threshold<false>, grid, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, *push);
+		hipLaunchKernelGGL(k_bloom_threshold<false>, grid, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, *push,
+		                   span.first, span.end);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
 
 int gr_bloom_downsample(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_image *history,
                         const gr_push_bloom_downsample *push)
+{
+	return gr_bloom_downsample_rows(ctx, stream, in, out, history, push, nullptr);
+}
+
+int gr_bloom_downsample_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_image *history,
+                             const gr_push_bloom_downsample *push, const gr_rows *rows)
 {
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
@@ -302,20 +337,29 @@ int gr_bloom_downsample(gr_ctx *ctx, gr_stream stream, const gr_image *in, const
 	GR_CHECK_ARG(ctx, push->threads[0] <= out->width && push->threads[1] <= out->height);
 	if (push->threads[0] == 0 || push->threads[1] == 0)
 		return GR_OK;
+	const RowSpan span = resolve_rows(rows, push->threads[1]);
+	if (span.count() == 0)
+		return GR_OK;
 	dim3 block(POST_BLOCK_X, POST_BLOCK_Y);
-	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(push->threads[1], POST_BLOCK_Y));
+	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_downsample"};
 	if (history)
 		hipLaunchKernelGGL(k_bloom_downsample<true>, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out),
-		                   to_dev(history), *push);
+		                   to_dev(history), *push, span.first, span.end);
 	else
 		hipLaunchKernelGGL(k_bloom_downsample<false>, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out),
-		                   DevImage{}, *push);
+		                   DevImage{}, *push, span.first, span.end);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
 
 int gr_bloom_upsample(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_push_bloom_upsample *push)
+{
+	return gr_bloom_upsample_rows(ctx, stream, in, out, push, nullptr);
+}
+
+int gr_bloom_upsample_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_push_bloom_upsample *push,
+                           const gr_rows *rows)
 {
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
@@ -324,10 +368,13 @@ int gr_bloom_upsample(gr_ctx *ctx, gr_stream stream, const gr_image *in, const g
 	GR_CHECK_ARG(ctx, push->threads[0] <= out->width && push->threads[1] <= out->height);
 	if (push->threads[0] == 0 || push->threads[1] == 0)
 		return GR_OK;
+	const RowSpan span = resolve_rows(rows, push->threads[1]);
+	if (span.count() == 0)
+		return GR_OK;
 	dim3 block(POST_BLOCK_X, POST_BLOCK_Y);
-	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(push->threads[1], POST_BLOCK_Y));
+	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_upsample"};
-	hipLaunchKernelGGL(k_bloom_upsample, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out), *push);
+	hipLaunchKernelGGL(k_bloom_upsample, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out), *push, span.first, span.end);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
@@ -348,6 +395,12 @@ int gr_luminance(gr_ctx *ctx, gr_stream stream, const gr_image *in, gr_luminance
 int gr_tonemap(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *bloom, const gr_image *out,
                const gr_luminance_data *lum, const gr_push_tonemap *push)
 {
+	return gr_tonemap_rows(ctx, stream, hdr, bloom, out, lum, push, nullptr);
+}
+
+int gr_tonemap_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *bloom, const gr_image *out,
+                    const gr_luminance_data *lum, const gr_push_tonemap *push, const gr_rows *rows)
+{
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, push != nullptr);
@@ -357,13 +410,16 @@ int gr_tonemap(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_imag
 	const bool srgb = out->format == GR_FORMAT_R8G8B8A8_SRGB;
 	if (!srgb && out->format != GR_FORMAT_R8G8B8A8_UNORM)
 		return ctx->fail(GR_ERR_UNSUPPORTED_FORMAT, "gr_tonemap: output format %u unsupported", out->format);
+	const RowSpan span = resolve_rows(rows, hdr->height);
+	if (span.count() == 0)
+		return GR_OK;
 	dim3 block(TONEMAP_BLOCK_X, TONEMAP_BLOCK_Y);
-	dim3 grid(gr_div_up(hdr->width, TONEMAP_BLOCK_X * TONEMAP_PX), gr_div_up(hdr->height, TONEMAP_BLOCK_Y));
+	dim3 grid(gr_div_up(hdr->width, TONEMAP_BLOCK_X * TONEMAP_PX), gr_div_up(span.count(), TONEMAP_BLOCK_Y));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "tonemap"};
 	hipStream_t s = gr_to_stream(stream);
 	const bool quarter = hdr->width == 4u * bloom->width && hdr->height == 4u * bloom->height;
 	auto launch = [&](auto kernel) {
-		hipLaunchKernelGGL(kernel, grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push);
+		hipLaunchKernelGGL(kernel, grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push, span.first, span.end);
 	};
 	if (quarter)
 	{

@@ -1,0 +1,115 @@
+"""Row-band tiling of one frame across ranks: the collectives behind gra_set_exchange_callback.
+
+The executor (C++) decides WHAT each rank computes (StripPlan) and WHERE bands must meet; this module supplies HOW they
+meet: one in-place all-gather per meeting point on torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  Nothing here touches pixel values.
+"""
+from __future__ import annotations
+
+import threading
+from typing import Callable, Dict, Tuple
+
+import numpy as np
+
+
+def all_gather_chunks_inplace(full, rank: int, chunk_elems: int, group=None):
+    """In-place all-gather on a flat torch tensor `full` of world * chunk_elems elements: rank r's chunk lives at
+    [r * chunk_elems, (r + 1) * chunk_elems)."""
+    import torch.distributed as dist
+    mine = full[rank * chunk_elems:(rank + 1) * chunk_elems]
+    dist.all_gather_into_tensor(full, mine, group=group)
+
+
+class _DevicePointer:
+    """Just enough of the CUDA array interface for torch.as_tensor to wrap a raw HBM pointer without copying."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3, "strides": None}
+
+
+class TorchDistExchange:
+    """gra_exchange_fn on torch.distributed.  One all-gather per call, enqueued on the executor's own HIP stream (wrapped
+    as a torch ExternalStream) so it is ordered after the band kernels and before their consumers without any host sync."""
+
+    def __init__(self, rank: int, world: int, device_index: int, group=None):
+        import torch
+        self.torch = torch
+        self.rank, self.world, self.group = rank, world, group
+        self.device = torch.device("cuda", device_index)
+        self._tensors: Dict[Tuple[int, int], object] = {}
+        self._streams: Dict[int, object] = {}
+        self.calls = 0
+        self.bytes_gathered = 0
+
+    def __call__(self, tag: str, ptr: int, chunk_bytes: int, ranks: int, stream: int):
+        torch = self.torch
+        assert ranks == self.world, f"plan built for {ranks} ranks, process group has {self.world}"
+        key = (ptr, chunk_bytes * ranks)
+        full = self._tensors.get(key)
+        if full is None:
+            full = torch.as_tensor(_DevicePointer(ptr, chunk_bytes * ranks), device=self.device)
+            self._tensors[key] = full
+        ext = self._streams.get(stream)
+        if ext is None:
+            ext = torch.cuda.ExternalStream(stream, device=self.device)
+            self._streams[stream] = ext
+        with torch.cuda.stream(ext):
+            all_gather_chunks_inplace(full, self.rank, chunk_bytes, self.group)
+        self.calls += 1
+        self.bytes_gathered += chunk_bytes * (ranks - 1)
+
+
+class LocalExchange:
+    """The same meeting points for N executor instances living in ONE process on ONE GPU (one Python thread per rank):
+    used by the GPU parity test that emulates an N-rank frame on the single device available to it.  copy(dst, src, nbytes,
+    stream) enqueues a device-to-device copy, sync(stream) waits for a stream."""
+
+    def __init__(self, world: int, copy: Callable[[int, int, int, int], None], sync: Callable[[int], None]):
+        self.world = world
+        self.copy, self.sync = copy, sync
+        self.barrier = threading.Barrier(world)
+        self.posted: Dict[int, Tuple[int, int]] = {}
+        self.lock = threading.Lock()
+
+    def for_rank(self, rank: int):
+        def exchange(tag: str, ptr: int, chunk_bytes: int, ranks: int, stream: int):
+            assert ranks == self.world
+            self.sync(stream)  # my chunk is complete
+            with self.lock:
+                self.posted[rank] = (ptr, chunk_bytes)
+            self.barrier.wait()
+            for other in range(self.world):
+                if other != rank:
+                    src_ptr, nbytes = self.posted[other]
+                    assert nbytes == chunk_bytes
+                    self.copy(ptr + other * chunk_bytes, src_ptr + other * chunk_bytes, chunk_bytes, stream)
+            self.sync(stream)
+            self.barrier.wait()  # nobody moves on (and rewrites its chunk) while someone still reads it
+        return exchange
+
+
+def weak_scaled_frame(world: int, base=(3840, 2160)) -> Tuple[int, int]:
+    """bench.py's frame for `world` ranks: one base frame's worth of pixels per rank, grown alternately in height and
+    width (1: 3840x2160, 2: 3840x4320, 4: 7680x4320 = BASELINE config 5's frame, 8: 7680x8640)."""
+    w, h = base
+    n, grow_h = world, True
+    while n > 1:
+        if n % 2:
+            raise ValueError("world size must be a power of two")
+        if grow_h:
+            h *= 2
+        else:
+            w *= 2
+        grow_h = not grow_h
+        n //= 2
+    return w, h
+
+
+def plan_numpy(index: int, count: int, width: int, height: int) -> dict:
+    """StripPlan::build through the C ABI without a GPU (dry application)."""
+    from . import app as gapp
+    a = gapp.Application(width, height, device=-1, strip_index=index, strip_count=count)
+    try:
+        return a.strip_plan()
+    finally:
+        a.close()

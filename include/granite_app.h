@@ -48,6 +48,10 @@ typedef struct gra_config
 	float directional_color[3];
 	float directional_direction[3];
 	int32_t enable_timestamps; /* RenderGraph::enable_timestamps */
+	/* Row-band tiling of the frame across executors: this instance is rank strip_index of strip_count.
+	 * 0 / 1 = the whole frame here.  Needs enable_lighting, hdr_bloom, compute_post and no AA; the band exchanges go
+	 * through gra_set_exchange_callback. */
+	uint32_t strip_index, strip_count;
 } gra_config;
 
 /* Scene-level light description (one PositionalLight + its node transform). */
@@ -119,6 +123,22 @@ int gra_collect_timestamps(gra_app *app, gra_timestamp *entries, int max_entries
 int gra_get_taa_reprojection(gra_app *app, float *reproj16);
 /* SMAA AreaTex (160x560 RG8) / SearchTex (64x16 R8) payloads, host pointers; needed before a frame with an SMAA pass. */
 int gra_set_smaa_luts(gra_app *app, const void *area_rg8, const void *search_r8);
+/* Row-band tiling.  The executor calls `fn` where the bands of all ranks must meet (after the 1/8 bloom level, after
+ * tonemap): an in-place all-gather of `rank_count` chunks of `chunk_bytes` bytes laid out back to back from `device_ptr`
+ * (this rank's chunk already sits at device_ptr + strip_index * chunk_bytes), to be enqueued on `stream` (hipStream_t).
+ * bench.py implements it with torch.distributed (RCCL); tests with local copies. */
+typedef void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream);
+int gra_set_exchange_callback(gra_app *app, gra_exchange_fn fn, void *user);
+/* RCCL transport for the band exchanges: rank 0 creates a 128-byte id (gra_comm_create_unique_id), the launcher ships it
+ * to every rank (bench.py: torch.distributed broadcast), every rank calls gra_comm_init; from then on the exchange points
+ * are in-place ncclAllGather calls on the executor's stream (xGMI between the GPUs of one node).  ranks must equal the
+ * config's strip_count and rank its strip_index. */
+int gra_comm_create_unique_id(uint8_t *id128);
+int gra_comm_init(gra_app *app, const uint8_t *id128, int32_t rank, int32_t ranks);
+/* The band plan of this instance: out[0..3] = index, count, width, height; then {whole, first, count} for lighting,
+ * threshold, downsample-0, downsample-1, upsample-0, tonemap; then d1_chunk_rows, out_chunk_rows (24 values). */
+int gra_get_strip_plan(gra_app *app, uint32_t *out24);
+
 /* Host-side frame-loop cost since creation: out[0] = frames, out[1] = seconds spent inside the frame loop (light
  * refresh + graph execution = launches), out[2] = seconds of those spent blocked on GPU back-pressure. */
 int gra_get_host_stats(gra_app *app, double *out3);

@@ -92,6 +92,16 @@ int gr_timing_set_filter(gr_ctx *ctx, const char *name);
 int gr_timing_reset(gr_ctx *ctx);
 int gr_timing_query(gr_ctx *ctx, gr_timing_entry *entries, int max_entries); /* returns number of entries; syncs */
 
+/* Render area of one launch: output rows [first, first + count) only; count == 0 (or a NULL pointer) = the whole image.
+ * The reference restricts draws with VkRect2D render areas / scissors (vulkan/command_buffer.cpp set_scissor); the
+ * executor uses row bands to tile one frame across GPUs.  Coordinates stay those of the full image, so a
+ * band computes bit-identical values to the same rows of a whole-image launch. */
+typedef struct gr_rows
+{
+	uint32_t first;
+	uint32_t count;
+} gr_rows;
+
 /* ---- HDR post chain (renderer/post/hdr.cpp) ---------------------------------------------------------------------- */
 
 /* LuminanceData, 12 B (assets/shaders/post/luminance.comp:4-9): {log2 avg, avg, 1/avg}. */
@@ -111,6 +121,8 @@ typedef struct gr_push_bloom_threshold
 } gr_push_bloom_threshold;
 int gr_bloom_threshold(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *out,
                        const gr_luminance_data *lum, const gr_push_bloom_threshold *push);
+int gr_bloom_threshold_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *out,
+                            const gr_luminance_data *lum, const gr_push_bloom_threshold *push, const gr_rows *rows);
 
 /* bloom_downsample_build_compute (hdr.cpp:146-187) + bloom_downsample.comp.  history = previous frame's output
  * (FEEDBACK=1, NearestClamp) or NULL. */
@@ -123,6 +135,8 @@ typedef struct gr_push_bloom_downsample
 } gr_push_bloom_downsample;
 int gr_bloom_downsample(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out,
                         const gr_image *history, const gr_push_bloom_downsample *push);
+int gr_bloom_downsample_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out,
+                             const gr_image *history, const gr_push_bloom_downsample *push, const gr_rows *rows);
 
 /* bloom_upsample_build_compute (hdr.cpp:189-216) + bloom_upsample.comp. */
 typedef struct gr_push_bloom_upsample
@@ -133,6 +147,8 @@ typedef struct gr_push_bloom_upsample
 } gr_push_bloom_upsample;
 int gr_bloom_upsample(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out,
                       const gr_push_bloom_upsample *push);
+int gr_bloom_upsample_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out,
+                           const gr_push_bloom_upsample *push, const gr_rows *rows);
 
 /* luminance_build_compute (hdr.cpp:68-98) + luminance.comp: mean log-luminance of `in`.a over a size.x x size.y
  * bilinear grid, clamp, temporal lerp, read-modify-write of *lum. */
@@ -154,6 +170,8 @@ typedef struct gr_push_tonemap
 } gr_push_tonemap;
 int gr_tonemap(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *bloom, const gr_image *out,
                const gr_luminance_data *lum, const gr_push_tonemap *push);
+int gr_tonemap_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *bloom, const gr_image *out,
+                    const gr_luminance_data *lum, const gr_push_tonemap *push, const gr_rows *rows);
 
 /* ---- clustered lighting (renderer/lights/clusterer.cpp, renderer/renderer.cpp) ------------------------------------- */
 
@@ -296,6 +314,7 @@ typedef struct gr_lighting_args
 	const uint32_t *bitmask;       /* cluster-bitmask */
 	const uint32_t *range;         /* cluster-range, uvec2[res_z] */
 	uint32_t flags;
+	gr_rows rows;                  /* render area; {0, 0} = whole target */
 } gr_lighting_args;
 int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args);
 

@@ -1,0 +1,79 @@
+"""One rank of the CPU row-band test (launched by test_strips_cpu.py, world_size 2, gloo).
+
+Each rank runs the CPU oracle's post chain but only trusts the rows its StripPlan says it computes: everything outside is
+overwritten with a poison value before the next stage reads it, so a halo that is too small, or an all-gather that lands a
+chunk in the wrong place, changes the rank's output.  Bands meet through granite_amd.multigpu.all_gather_chunks_inplace on
+torch.distributed -- the same call the GPU path makes, on the gloo backend."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+POISON16 = np.float16(60000.0).view(np.uint16)
+
+
+def keep_rows(img: np.ndarray, rng, poison):
+    """Rows outside the plan's range were never computed on this rank."""
+    out = np.full_like(img, poison)
+    if rng is None:
+        return img
+    first, count = rng
+    out[first:first + count] = img[first:first + count]
+    return out
+
+
+def gather_rows(img: np.ndarray, rank: int, world: int, chunk_rows: int) -> np.ndarray:
+    import torch
+    from granite_amd import multigpu
+    h = img.shape[0]
+    row_bytes = int(np.prod(img.shape[1:])) * img.dtype.itemsize
+    padded = np.zeros((world * chunk_rows,) + img.shape[1:], img.dtype)
+    padded[:h] = img
+    flat = torch.from_numpy(padded.reshape(-1).view(np.uint8))  # bytes, exactly what the GPU path gathers
+    multigpu.all_gather_chunks_inplace(flat, rank, chunk_rows * row_bytes)
+    return padded[:h]
+
+
+def main():
+    import torch.distributed as dist
+    from granite_amd import multigpu, synth
+    from oracle import oracle as orc
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    width, height, frames, out_path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = multigpu.plan_numpy(rank, world, width, height)
+    assert plan["count"] == world and plan["index"] == rank
+
+    hdr = synth.make_hdr(width, height)
+    sz = [orc.level_size(width, height, s) for s in (0.5, 0.25, 0.125, 0.0625, 0.03125)]
+    lum_lerp, fb_lerp = orc.frame_lerps(0.01)
+    lum, d3_history = np.zeros(3, np.float32), None
+    results = []
+    for _ in range(frames):
+        lit = keep_rows(hdr, plan["lighting"], POISON16)
+        t = keep_rows(orc.bloom_threshold(lit, *sz[0], lum3=lum), plan["threshold"], POISON16)
+        d0 = keep_rows(orc.bloom_downsample(t, *sz[1]), plan["d0"], POISON16)
+        d1 = keep_rows(orc.bloom_downsample(d0, *sz[2]), plan["d1"], POISON16)
+        d1 = gather_rows(d1, rank, world, plan["d1_chunk_rows"])
+        d2 = orc.bloom_downsample(d1, *sz[3])
+        d3 = orc.bloom_downsample(d2, *sz[4], history=d3_history, lerp=fb_lerp)
+        lum = orc.luminance(d3, lum, lum_lerp)
+        u2 = orc.bloom_upsample(d3, *sz[3])
+        u1 = orc.bloom_upsample(u2, *sz[2])
+        u0 = keep_rows(orc.bloom_upsample(u1, *sz[1]), plan["u0"], POISON16)
+        tm = keep_rows(orc.tonemap(lit, u0, lum), plan["tonemap"], 0x5A)
+        tm = gather_rows(tm, rank, world, plan["out_chunk_rows"])
+        d3_history = d3
+        results.append((d1.copy(), tm.copy(), lum.copy()))
+    np.savez(out_path.format(rank=rank), d1=np.stack([r[0] for r in results]), tm=np.stack([r[1] for r in results]),
+             lum=np.stack([r[2] for r in results]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

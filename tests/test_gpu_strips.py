@@ -1,0 +1,101 @@
+"""GPU parity for row-band tiling: N executor instances on the one available device, one thread per rank,
+bands meeting through multigpu.LocalExchange, must reproduce the single-instance frame bit for bit -- every kernel keeps
+full-image coordinates, so a band holds the very values of the same rows of a whole-frame launch."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from granite_amd import app as gapp, capi, multigpu, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make_app(w, h, cam, gbuf, descs, **kw):
+    a = gapp.Application(w, h, **kw)
+    a.set_render_parameters(cam.render_params())
+    a.set_lights(descs)
+    a.upload_gbuffer(gbuf)
+    return a
+
+
+@pytest.mark.parametrize("world,w,h,lights", [(2, 480, 272, 300), (3, 333, 250, 200), (4, 512, 512, 64)])
+def test_emulated_ranks_reproduce_the_single_device_frame(world, w, h, lights):
+    frames = 3
+    cam = synth.Camera(w, h)
+    gbuf = synth.make_gbuffer(cam)
+    descs = synth.make_lights(cam, lights)
+
+    ref = make_app(w, h, cam, gbuf, descs)
+    ref_frames = []
+    for _ in range(frames):
+        ref.render_frames(1)
+        ref_frames.append((ref.read_backbuffer().copy(), ref.read("downsample-1").copy(), ref.read("average-luminance").copy()))
+    ref.close()
+
+    lib = capi.load_library()
+    lib.gr_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.gr_sync.argtypes = [C.c_void_p, C.c_void_p]
+    apps = [make_app(w, h, cam, gbuf, descs, strip_index=r, strip_count=world) for r in range(world)]
+    ctx = apps[0].lib.gra_get_kernel_context(apps[0].handle)
+
+    def copy(dst, src, nbytes, stream):
+        assert lib.gr_copy(ctx, stream, dst, src, nbytes) == 0
+
+    def sync(stream):
+        assert lib.gr_sync(ctx, stream) == 0
+
+    local = multigpu.LocalExchange(world, copy, sync)
+    got = [[] for _ in range(world)]
+    errors = []
+
+    def run(rank):
+        try:
+            a = apps[rank]
+            a.set_exchange_callback(local.for_rank(rank))
+            for _ in range(frames):
+                a.render_frames(1)
+                got[rank].append((a.read_backbuffer().copy(), a.read("downsample-1").copy(), a.read("average-luminance").copy()))
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            local.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for rank in range(world):
+        plan = apps[rank].strip_plan()
+        assert plan["count"] == world and plan["tonemap"] is not None
+        for f in range(frames):
+            np.testing.assert_array_equal(got[rank][f][1], ref_frames[f][1], err_msg=f"rank {rank} frame {f}: downsample-1")
+            np.testing.assert_array_equal(got[rank][f][2], ref_frames[f][2], err_msg=f"rank {rank} frame {f}: average-luminance")
+            np.testing.assert_array_equal(got[rank][f][0], ref_frames[f][0], err_msg=f"rank {rank} frame {f}: backbuffer")
+    for a in apps:
+        a.close()
+
+
+def test_single_rank_rccl_exchange_is_identity():
+    """ranks = 1 through the real transport: dlopen(librccl), ncclCommInitRank, the in-place ncclAllGather on the
+    executor's stream at both exchange points of a (degenerate) band plan.  The frame must equal the plain frame."""
+    w, h = 256, 144
+    cam = synth.Camera(w, h)
+    gbuf = synth.make_gbuffer(cam)
+    descs = synth.make_lights(cam, 64)
+    ref = make_app(w, h, cam, gbuf, descs)
+    ref.render_frames(2)
+    want = ref.read_backbuffer().copy()
+    ref.close()
+
+    a = make_app(w, h, cam, gbuf, descs)
+    uid = gapp.Application.comm_create_unique_id()
+    assert len(uid) == 128 and any(uid)
+    a.comm_init(uid, 0, 1)
+    a.render_frames(2)
+    np.testing.assert_array_equal(a.read_backbuffer(), want)
+    with pytest.raises(capi.GraniteHipError):
+        a.comm_init(uid, 0, 1)  # already initialised
+    a.close()
