@@ -210,7 +210,7 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "gr_abi_version", "gr_create", "gr_destroy", "gr_last_error", "gr_sync", "gr_alloc", "gr_free", "gr_upload",
-    "gr_download", "gr_copy", "gr_fill_zero", "gr_timing_enable", "gr_timing_set_filter", "gr_timing_reset", "gr_timing_query",
+    "gr_download", "gr_copy", "gr_fill_zero", "gr_upload_batch", "gr_timing_enable", "gr_timing_set_filter", "gr_timing_reset", "gr_timing_query",
     "gr_bloom_threshold", "gr_bloom_downsample", "gr_bloom_upsample", "gr_luminance", "gr_tonemap",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
     "gr_smaa_set_luts", "gr_fxaa", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",

@@ -103,6 +103,72 @@ int gr_upload(gr_ctx *ctx, gr_stream stream, void *dst, const void *src_host, si
 	return GR_OK;
 }
 
+namespace
+{
+struct UploadBatch
+{
+	uint32_t *dst[GR_MAX_UPLOAD_RANGES];
+	const uint32_t *src[GR_MAX_UPLOAD_RANGES];
+	uint32_t dwords[GR_MAX_UPLOAD_RANGES];
+	uint32_t count;
+};
+
+// blockIdx.y selects the range; 16-byte accesses where both pointers allow it.
+__global__ __launch_bounds__(256) void k_upload_batch(UploadBatch b)
+{
+	const uint32_t r = blockIdx.y;
+	if (r >= b.count)
+		return;
+	uint32_t *dst = b.dst[r];
+	const uint32_t *src = b.src[r];
+	const uint32_t n = b.dwords[r];
+	const uint32_t stride = gridDim.x * blockDim.x;
+	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0)
+	{
+		const uint32_t n4 = n / 4;
+		for (uint32_t i = tid; i < n4; i += stride)
+			reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+		for (uint32_t i = n4 * 4 + tid; i < n; i += stride)
+			dst[i] = src[i];
+	}
+	else
+		for (uint32_t i = tid; i < n; i += stride)
+			dst[i] = src[i];
+}
+} // namespace
+
+int gr_upload_batch(gr_ctx *ctx, gr_stream stream, const gr_upload_range *ranges, uint32_t count)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, ranges != nullptr || count == 0);
+	GR_CHECK_ARG(ctx, count <= GR_MAX_UPLOAD_RANGES);
+	UploadBatch b = {};
+	uint32_t max_dwords = 0;
+	for (uint32_t i = 0; i < count; i++)
+	{
+		if (ranges[i].bytes == 0)
+			continue;
+		GR_CHECK_ARG(ctx, ranges[i].dst && ranges[i].src_pinned && (ranges[i].bytes & 3u) == 0 && ranges[i].bytes < (size_t(1) << 33));
+		GR_CHECK_ARG(ctx, (reinterpret_cast<uintptr_t>(ranges[i].dst) & 3u) == 0 && (reinterpret_cast<uintptr_t>(ranges[i].src_pinned) & 3u) == 0);
+		void *mapped = nullptr;
+		GR_CHECK_HIP(ctx, hipHostGetDevicePointer(&mapped, const_cast<void *>(ranges[i].src_pinned), 0));
+		b.dst[b.count] = static_cast<uint32_t *>(ranges[i].dst);
+		b.src[b.count] = static_cast<const uint32_t *>(mapped);
+		b.dwords[b.count] = uint32_t(ranges[i].bytes / 4);
+		max_dwords = max_dwords > b.dwords[b.count] ? max_dwords : b.dwords[b.count];
+		b.count++;
+	}
+	if (b.count == 0)
+		return GR_OK;
+	const unsigned blocks_x = gr_div_up(gr_div_up(max_dwords, 4u), 256u) < 64u ? gr_div_up(gr_div_up(max_dwords, 4u), 256u) : 64u;
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "upload_batch"};
+	hipLaunchKernelGGL(k_upload_batch, dim3(blocks_x ? blocks_x : 1, b.count), dim3(256), 0, gr_to_stream(stream), b);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
 int gr_download(gr_ctx *ctx, gr_stream stream, void *dst_host, const void *src, size_t bytes)
 {
 	if (!ctx)
@@ -150,8 +216,23 @@ int gr_timing_set_filter(gr_ctx *ctx, const char *name)
 
 static int drain_spans(gr_ctx *ctx)
 {
+	// GR_TIMING_DUMP=<file>: also append every span as "name start_us stop_us" relative to the first span drained in this
+	// process -- a GPU-side timeline across streams that, unlike a profiler's API interception, does not slow the host.
+	static FILE *dump = getenv("GR_TIMING_DUMP") ? fopen(getenv("GR_TIMING_DUMP"), "w") : nullptr;
+	static hipEvent_t origin = nullptr;
 	for (auto &s : ctx->spans)
 	{
+		if (dump)
+		{
+			(void)hipEventSynchronize(s.stop);
+			if (!origin)
+			{
+				origin = s.start; // first span's start event is kept (never recycled) as the time origin
+			}
+			float a = 0.0f, b = 0.0f;
+			if (hipEventElapsedTime(&a, origin, s.start) == hipSuccess && hipEventElapsedTime(&b, origin, s.stop) == hipSuccess)
+				fprintf(dump, "%s %.1f %.1f\n", s.name, a * 1000.0f, b * 1000.0f);
+		}
 		GR_CHECK_HIP(ctx, hipEventSynchronize(s.stop));
 		float ms = 0.0f;
 		GR_CHECK_HIP(ctx, hipEventElapsedTime(&ms, s.start, s.stop));
@@ -163,9 +244,12 @@ static int drain_spans(gr_ctx *ctx)
 		}
 		itr->second.count++;
 		itr->second.ms += ms;
-		ctx->event_pool.push_back(s.start);
+		if (s.start != origin)
+			ctx->event_pool.push_back(s.start);
 		ctx->event_pool.push_back(s.stop);
 	}
+	if (dump)
+		fflush(dump);
 	ctx->spans.clear();
 	return GR_OK;
 }

@@ -177,6 +177,7 @@ void ImageSpaceApplication::upload_gbuffer(const void *emissive, const void *alb
 		src_mv = device.create_image(config.width, config.height, VK_FORMAT_R16G16_SFLOAT, "src-mv");
 	upload(src_mv, mv, "motion-vector");
 	gbuffer_dirty = true;
+	filled_targets.clear();
 }
 
 // Config-1 style graph head: an "HDR-main" colour target filled from the uploaded HDR image (tools/aa_bench.cpp:80-101
@@ -188,8 +189,9 @@ void ImageSpaceApplication::add_hdr_input_pass(const std::string &tag)
 	auto &pass = graph.add_pass(tagcat("hdr-input", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
 	auto &out = pass.add_color_output(tagcat("HDR", tag), hdr);
 	pass.set_build_render_pass([this, &out](HIP::CommandBuffer &cmd) {
-		if (gbuffer_dirty)
-			cmd.copy_image(graph.get_physical_texture_resource(out), *src_emissive);
+		auto &target = graph.get_physical_texture_resource(out);
+		if (needs_fill(target))
+			cmd.copy_image(target, *src_emissive);
 	});
 }
 
@@ -202,12 +204,13 @@ void ImageSpaceApplication::add_mv_pass(const std::string &tag)
 	auto &pass = graph.add_pass(tagcat("mv", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
 	auto &out = pass.add_color_output(tagcat("mv", tag), mv);
 	pass.set_build_render_pass([this, &out](HIP::CommandBuffer &cmd) {
-		if (!gbuffer_dirty)
+		auto &target = graph.get_physical_texture_resource(out);
+		if (!needs_fill(target))
 			return;
 		if (src_mv)
-			cmd.copy_image(graph.get_physical_texture_resource(out), *src_mv);
+			cmd.copy_image(target, *src_mv);
 		else
-			cmd.clear_image(graph.get_physical_texture_resource(out));
+			cmd.clear_image(target);
 	});
 }
 
@@ -230,15 +233,16 @@ void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
 	auto &g_pbr = gbuffer.add_color_output(tagcat("pbr", tag), pbr);
 	auto &g_depth = gbuffer.set_depth_stencil_output(tagcat("depth-transient", tag), depth);
 	gbuffer.set_build_render_pass([this, &g_emissive, &g_albedo, &g_normal, &g_pbr, &g_depth](HIP::CommandBuffer &cmd) {
-		if (gbuffer_dirty || config.rmw_emissive)
-			cmd.copy_image(graph.get_physical_texture_resource(g_emissive), *src_emissive);
-		if (gbuffer_dirty)
-		{
-			cmd.copy_image(graph.get_physical_texture_resource(g_albedo), *src_albedo);
-			cmd.copy_image(graph.get_physical_texture_resource(g_normal), *src_normal);
-			cmd.copy_image(graph.get_physical_texture_resource(g_pbr), *src_pbr);
-			cmd.copy_image(graph.get_physical_texture_resource(g_depth), *src_depth);
-		}
+		auto fill = [&](RenderTextureResource &res, HIP::ImageHandle &src, bool always) {
+			auto &target = graph.get_physical_texture_resource(res);
+			if (needs_fill(target) || always)
+				cmd.copy_image(target, *src);
+		};
+		fill(g_emissive, src_emissive, config.rmw_emissive != 0);
+		fill(g_albedo, src_albedo, false);
+		fill(g_normal, src_normal, false);
+		fill(g_pbr, src_pbr, false);
+		fill(g_depth, src_depth, false);
 	});
 
 	auto &lighting_pass = graph.add_pass(tagcat("lighting", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);

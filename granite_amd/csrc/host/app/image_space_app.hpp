@@ -4,6 +4,7 @@
 // headless platform's external 4-image swapchain (application/platforms/application_headless.cpp:145-148,207-229).
 #pragma once
 #include <memory>
+#include <unordered_set>
 #include <string>
 #include <vector>
 #include "../../../../include/granite_app.h"
@@ -84,6 +85,9 @@ private:
 	PositionalLightList light_list;
 	HIP::ImageHandle src_emissive, src_albedo, src_normal, src_pbr, src_depth, src_mv;
 	bool gbuffer_dirty = true;
+	// Physical targets that already hold the current synthetic upload (an attachment the executor double-buffers has two).
+	std::unordered_set<const void *> filled_targets;
+	bool needs_fill(const HIP::Image &target) { return filled_targets.insert(target.get_device_pointer()).second; }
 
 	std::vector<HIP::ImageHandle> swapchain;
 	unsigned swapchain_index = 0;

@@ -89,6 +89,30 @@ void CommandBuffer::update_buffer(const Buffer &dst, size_t offset, size_t size,
 	      "update_buffer");
 }
 
+void CommandBuffer::update_buffers(const BufferUpdate *updates, unsigned count)
+{
+	gr_upload_range ranges[GR_MAX_UPLOAD_RANGES];
+	unsigned n = 0;
+	for (unsigned i = 0; i < count; i++)
+	{
+		auto &u = updates[i];
+		if (!u.size)
+			continue;
+		if (u.offset + u.size > u.dst->get_size())
+			throw std::logic_error("update_buffers out of range");
+		if ((u.size & 3u) || (u.offset & 3u) || n == GR_MAX_UPLOAD_RANGES)
+		{
+			update_buffer(*u.dst, u.offset, u.size, u.data); // odd sizes take the copy-engine path
+			continue;
+		}
+		void *staging = device.allocate_staging(u.size);
+		memcpy(staging, u.data, u.size);
+		ranges[n++] = {static_cast<uint8_t *>(u.dst->get_device_pointer()) + u.offset, staging, u.size};
+	}
+	if (n)
+		check(gr_upload_batch(get_context(), stream, ranges, n), "update_buffers");
+}
+
 void CommandBuffer::fill_buffer(const Buffer &dst, size_t offset, size_t size)
 {
 	check(gr_fill_zero(get_context(), stream, static_cast<uint8_t *>(dst.get_device_pointer()) + offset, size), "fill_buffer");
@@ -111,11 +135,18 @@ Device::Device(int device_index) : index(device_index)
 	ctx = gr_create(device_index);
 	if (!ctx)
 		throw std::runtime_error("gr_create failed: no usable HIP device " + std::to_string(device_index));
-	for (auto &s : streams)
+	// Queue priorities for the executor's frame pipelining: the back of a frame (bloom pyramid, tonemap: short, dependent,
+	// bandwidth-bound launches) and the cluster build must not queue behind the next frame's lighting kernel, which fills
+	// every wave slot of the chip for ~200 us; lighting is throughput work and runs at the lowest priority.
+	int least = 0, greatest = 0;
+	throw_hip(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+	const int middle = (least + greatest) / 2;
+	const int priorities[int(CommandBuffer::Type::Count)] = {greatest, middle, least}; // Generic, AsyncCompute, Front
+	for (int i = 0; i < int(CommandBuffer::Type::Count); i++)
 	{
 		hipStream_t stream;
-		throw_hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
-		s = stream;
+		throw_hip(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, priorities[i]), "hipStreamCreateWithPriority");
+		streams[i] = stream;
 	}
 	for (auto &frame : staging)
 	{

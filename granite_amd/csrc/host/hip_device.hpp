@@ -66,7 +66,9 @@ using BufferHandle = std::shared_ptr<Buffer>;
 class CommandBuffer
 {
 public:
-	enum class Type { Generic, AsyncCompute, Count };
+	// Generic: graphics + compute queue of the reference; AsyncCompute: its async compute queue; Front: the executor's
+	// frame-pipelining stream (render_graph.hpp, set_hoist_independent_compute).
+	enum class Type { Generic, AsyncCompute, Front, Count };
 	CommandBuffer(Device &device_, void *stream_, Type type_) : device(device_), stream(stream_), type(type_) {}
 	Device &get_device() { return device; }
 	gr_ctx *get_context() const;
@@ -79,6 +81,15 @@ public:
 
 	// cmd.update_buffer analogue (clusterer.cpp:1178-1207): async H2D from a pinned staging ring owned by the device.
 	void update_buffer(const Buffer &dst, size_t offset, size_t size, const void *data);
+	// Several update_buffer calls as one launch: stage every range in the pinned ring, then one gr_upload_batch kernel
+	// (no copy engine, no cross-engine signalling in the middle of a short pass).
+	struct BufferUpdate
+	{
+		const Buffer *dst;
+		size_t offset, size;
+		const void *data;
+	};
+	void update_buffers(const BufferUpdate *updates, unsigned count);
 	void fill_buffer(const Buffer &dst, size_t offset, size_t size);
 	void copy_image(const Image &dst, const Image &src);
 	void clear_image(const Image &dst);

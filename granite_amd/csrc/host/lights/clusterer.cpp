@@ -198,11 +198,19 @@ uvec2 LightClusterer::compute_uint_range(vec2 range) const
 // ---- GPU build (clusterer.cpp:1178-1207,1277-1346,1463-1573) ----------------------------------------------------------------
 void LightClusterer::update_bindless_data(HIP::CommandBuffer &cmd)
 {
+	// The reference records three cmd.update_buffer here and a fourth (the per-light slice intervals) before the z-range
+	// dispatch (clusterer.cpp:1178-1207,1302).  All four are staged now and uploaded by ONE kernel: nothing on the GPU
+	// reads any of them before this point, and a copy-engine transfer in the middle of the pass costs more than the pass.
+	compute_volume_index_ranges();
 	uint32_t count = uint32_t(bindless.parameters.num_lights);
-	cmd.update_buffer(*bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_LIGHTS, count * sizeof(PositionalFragmentInfo), bindless.lights.data());
-	cmd.update_buffer(*bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_MODEL, count * sizeof(mat_affine), bindless.model.data());
-	cmd.update_buffer(*bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_TYPE_MASK, bindless.parameters.num_lights_32 * sizeof(uint32_t),
-	                  bindless.type_mask);
+	auto &ranges = bindless.volume_index_range;
+	const HIP::CommandBuffer::BufferUpdate updates[] = {
+		{bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_LIGHTS, count * sizeof(PositionalFragmentInfo), bindless.lights.data()},
+		{bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_MODEL, count * sizeof(mat_affine), bindless.model.data()},
+		{bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_TYPE_MASK, bindless.parameters.num_lights_32 * sizeof(uint32_t), bindless.type_mask},
+		{bindless.light_ranges.get(), 0, ranges.size() * sizeof(uvec2), ranges.data()},
+	};
+	cmd.update_buffers(updates, 4);
 }
 
 void LightClusterer::update_bindless_mask_buffer_gpu(HIP::CommandBuffer &cmd)
@@ -244,7 +252,7 @@ void LightClusterer::update_bindless_mask_buffer_gpu(HIP::CommandBuffer &cmd)
 	          "cluster_binning");
 }
 
-void LightClusterer::update_bindless_range_buffer_gpu(HIP::CommandBuffer &cmd)
+void LightClusterer::compute_volume_index_ranges()
 {
 	uint32_t count = uint32_t(bindless.parameters.num_lights);
 	bindless.volume_index_range.resize(count);
@@ -263,12 +271,14 @@ void LightClusterer::update_bindless_range_buffer_gpu(HIP::CommandBuffer &cmd)
 	// The kernel must still run with no lights so that the range buffer is cleared to "empty".
 	if (bindless.volume_index_range.empty())
 		bindless.volume_index_range.push_back(uvec2(~0u, 0u));
+}
 
+void LightClusterer::update_bindless_range_buffer_gpu(HIP::CommandBuffer &cmd)
+{
 	if ((resolution_z & 63) != 0)
 		throw std::logic_error("Cluster Z resolution must be a multiple of 64.");
 
-	auto &ranges = bindless.volume_index_range;
-	cmd.update_buffer(*bindless.light_ranges, 0, ranges.size() * sizeof(uvec2), ranges.data());
+	auto &ranges = bindless.volume_index_range; // uploaded by update_bindless_data
 	gr_push_z_range push = {};
 	push.num_volumes = uint32_t(ranges.size());
 	push.num_volumes_128 = (push.num_volumes + 127) / 128;

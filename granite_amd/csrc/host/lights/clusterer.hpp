@@ -105,6 +105,7 @@ private:
 	void refresh_bindless_prepare(const RenderContext &context);
 	void build_cluster_bindless_gpu(HIP::CommandBuffer &cmd);
 	void update_bindless_data(HIP::CommandBuffer &cmd);
+	void compute_volume_index_ranges();
 	void update_bindless_mask_buffer_gpu(HIP::CommandBuffer &cmd);
 	void update_bindless_range_buffer_gpu(HIP::CommandBuffer &cmd);
 };

@@ -308,6 +308,8 @@ void RenderGraph::reset()
 	physical_image_attachments.clear();
 	physical_history_image_attachments.clear();
 	physical_image_has_history.clear();
+	physical_images_alternate.clear();
+	physical_buffers_alternate.clear();
 	swapchain_physical_index = RenderResource::Unused;
 }
 
@@ -784,6 +786,7 @@ void RenderGraph::setup_attachments(HIP::Device &device_, HIP::ImageView *swapch
 	physical_image_attachments.resize(count);
 	physical_history_image_attachments.resize(count);
 	physical_buffers_alternate.resize(count);
+	physical_images_alternate.resize(count);
 	if (physical_sync.size() != count)
 	{
 		physical_sync.assign(count, {});
@@ -799,9 +802,12 @@ void RenderGraph::setup_attachments(HIP::Device &device_, HIP::ImageView *swapch
 			std::swap(physical_history_image_attachments[i], physical_image_attachments[i]);
 
 		auto &att = physical_dimensions[i];
-		if (att.buffer_info.size != 0 && physical_buffer_is_double_buffered(i))
+		if (physical_buffer_is_double_buffered(i))
 		{
-			std::swap(physical_buffers[i], physical_buffers_alternate[i]);
+			if (att.buffer_info.size != 0)
+				std::swap(physical_buffers[i], physical_buffers_alternate[i]);
+			else
+				std::swap(physical_image_attachments[i], physical_images_alternate[i]);
 			std::swap(physical_sync[i], physical_sync_alternate[i]);
 		}
 		if (att.buffer_info.size != 0)
@@ -855,7 +861,7 @@ void *RenderGraph::acquire_event()
 
 void RenderGraph::build_stream_assignment()
 {
-	pass_async.assign(passes.size(), false);
+	pass_stream.assign(passes.size(), 0);
 	pass_reads_physical.assign(passes.size(), {});
 	pass_writes_physical.assign(passes.size(), {});
 	uses_async_stream = false;
@@ -888,15 +894,62 @@ void RenderGraph::build_stream_assignment()
 		for (auto *r : pass.get_transfer_outputs()) add(writes, r);
 		add(writes, pass.get_depth_stencil_output());
 
-		bool async = (pass.get_queue() & RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT) != 0;
-		if (!async && hoist_independent_compute && (pass.get_queue() & RENDER_GRAPH_QUEUE_COMPUTE_BIT) != 0 && reads.empty() &&
-		    !writes.empty())
+		pass_stream[pass_index] = (pass.get_queue() & RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT) != 0 ? 1 : 0;
+	}
+
+	// Frame pipelining (HIP executor policy, set_hoist_independent_compute): the "front" of a frame is every pass that
+	// does not depend, directly or through other passes, on anything carried over from the previous frame (history
+	// inputs, buffers that are read before they are written within the frame) -- cluster build, G-buffer, lighting.  The
+	// front runs on the second stream, so the front of frame N+1 executes while the back of frame N (bloom pyramid with
+	// its feedback, exposure, tonemap, AA) is still in flight on the first stream.
+	std::vector<bool> front(passes.size(), false);
+	if (hoist_independent_compute)
+	{
+		std::vector<int> first_writer(physical_dimensions.size(), -1), any_writer(physical_dimensions.size(), 0);
+		std::vector<int> order(passes.size(), -1);
+		int position = 0;
+		for (unsigned pass_index : pass_stack)
 		{
-			// Nothing it reads is produced by the graph.  It must not feed the swapchain image directly either.
-			async = std::find(writes.begin(), writes.end(), swapchain_physical_index) == writes.end();
+			order[pass_index] = position++;
+			for (unsigned w : pass_writes_physical[pass_index])
+			{
+				if (first_writer[w] < 0)
+					first_writer[w] = int(pass_index);
+				any_writer[w]++;
+			}
 		}
-		pass_async[pass_index] = async;
-		uses_async_stream = uses_async_stream || async;
+		std::vector<bool> written_by_back(physical_dimensions.size(), false);
+		bool any_back = false;
+		for (unsigned pass_index : pass_stack)
+		{
+			auto &pass = *passes[pass_index];
+			bool ok = pass_stream[pass_index] == 0 && pass.get_history_inputs().empty() && !pass_writes_physical[pass_index].empty();
+			for (unsigned w : pass_writes_physical[pass_index])
+				ok = ok && w != swapchain_physical_index && !physical_image_has_history[w];
+			for (unsigned r : pass_reads_physical[pass_index])
+			{
+				// Every producer of what it reads must already have run in this frame, on the front.
+				const bool produced_before = first_writer[r] >= 0 && order[first_writer[r]] < order[pass_index];
+				const bool rmw_of_own_output = std::find(pass_writes_physical[pass_index].begin(), pass_writes_physical[pass_index].end(), r) !=
+				                               pass_writes_physical[pass_index].end();
+				ok = ok && !written_by_back[r] && (produced_before || (any_writer[r] == 0)) && !(rmw_of_own_output && first_writer[r] == int(pass_index));
+			}
+			front[pass_index] = ok;
+			if (!ok)
+			{
+				any_back = true;
+				for (unsigned w : pass_writes_physical[pass_index])
+					written_by_back[w] = true;
+			}
+		}
+		if (!any_back) // nothing to overlap with: keep the whole frame on one stream
+			front.assign(passes.size(), false);
+	}
+	for (unsigned pass_index : pass_stack)
+	{
+		if (front[pass_index])
+			pass_stream[pass_index] = pass_reads_physical[pass_index].empty() ? 1 : 2;
+		uses_async_stream = uses_async_stream || pass_stream[pass_index] != 0;
 	}
 	physical_sync.assign(physical_dimensions.size(), {});
 	physical_sync_alternate.assign(physical_dimensions.size(), {});
@@ -908,10 +961,11 @@ void RenderGraph::build_stream_assignment()
 	blit_needs_sync = false;
 	if (uses_async_stream)
 	{
-		std::vector<uint8_t> touched(physical_dimensions.size(), 0); // bit 0: generic stream, bit 1: async stream
+		std::vector<uint8_t> touched(physical_dimensions.size(), 0); // bit s: touched from stream s
+		auto several = [](uint8_t bits) { return (bits & (bits - 1)) != 0; };
 		for (unsigned pass_index : pass_stack)
 		{
-			const uint8_t bit = pass_async[pass_index] ? 2 : 1;
+			const uint8_t bit = uint8_t(1u << pass_stream[pass_index]);
 			for (unsigned r : pass_reads_physical[pass_index])
 				touched[r] |= bit;
 			for (unsigned w : pass_writes_physical[pass_index])
@@ -923,37 +977,45 @@ void RenderGraph::build_stream_assignment()
 			if (itr != resource_to_index.end() && resources[itr->second]->get_physical_index() != RenderResource::Unused)
 			{
 				touched[resources[itr->second]->get_physical_index()] |= 1; // final blit runs on the generic stream
-				blit_needs_sync = touched[resources[itr->second]->get_physical_index()] == 3;
+				blit_needs_sync = several(touched[resources[itr->second]->get_physical_index()]);
 			}
 		}
 		for (unsigned pass_index : pass_stack)
 		{
 			bool shared = false;
 			for (unsigned r : pass_reads_physical[pass_index])
-				shared = shared || touched[r] == 3;
+				shared = shared || several(touched[r]);
 			for (unsigned w : pass_writes_physical[pass_index])
-				shared = shared || touched[w] == 3;
+				shared = shared || several(touched[w]);
 			pass_needs_sync[pass_index] = shared;
 		}
 	}
 
-	// Double-buffer what hoisted passes write, provided every byte a consumer reads is rewritten each frame by the
-	// hoisted pass itself: no read-modify-write input and no other writer.
+	// What the front writes and the back reads exists twice and alternates per frame (like an image with history), so the
+	// front of frame N+1 never waits for the back of frame N to finish reading: write-after-read across frames disappears.
+	// Only resources with a single writer qualify (every byte the back reads is rewritten by the front each frame).
 	physical_buffer_double.assign(physical_dimensions.size(), false);
-	if (hoist_independent_compute)
 	{
 		std::vector<unsigned> writers(physical_dimensions.size(), 0);
-		for (unsigned pass_index : pass_stack)
-			for (unsigned w : pass_writes_physical[pass_index])
-				writers[w]++;
+		std::vector<uint8_t> reader_streams(physical_dimensions.size(), 0);
 		for (unsigned pass_index : pass_stack)
 		{
-			if (!pass_async[pass_index] || (passes[pass_index]->get_queue() & RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT) != 0)
-				continue;
 			for (unsigned w : pass_writes_physical[pass_index])
-				if (physical_dimensions[w].buffer_info.size != 0 && writers[w] == 1)
-					physical_buffer_double[w] = true;
+				writers[w]++;
+			for (unsigned r : pass_reads_physical[pass_index])
+				reader_streams[r] |= uint8_t(1u << pass_stream[pass_index]);
 		}
+		if (swapchain_physical_index == RenderResource::Unused)
+		{
+			auto itr = resource_to_index.find(backbuffer_source);
+			if (itr != resource_to_index.end() && resources[itr->second]->get_physical_index() != RenderResource::Unused)
+				reader_streams[resources[itr->second]->get_physical_index()] |= 1;
+		}
+		for (unsigned pass_index : pass_stack)
+			if (front[pass_index])
+				for (unsigned w : pass_writes_physical[pass_index])
+					if (writers[w] == 1 && (reader_streams[w] & ~uint8_t(1u << pass_stream[pass_index])) != 0)
+						physical_buffer_double[w] = true;
 	}
 }
 
@@ -968,11 +1030,18 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		physical_sync_alternate.assign(physical_dimensions.size(), {});
 	}
 
+	static const bool sync_debug = getenv("GRANITE_SYNC_DEBUG") != nullptr;
+	const uint64_t this_frame = frame_counter - 1;
+	int current_pass = -1;
 	std::vector<void *> waited;
-	auto wait_for = [&](hipStream_t stream, void *event) {
+	auto wait_for = [&](hipStream_t stream, void *event, const char *kind = "", unsigned resource = 0, int src_pass = -1, uint64_t src_frame = 0) {
 		if (!event || std::find(waited.begin(), waited.end(), event) != waited.end())
 			return;
 		waited.push_back(event);
+		if (sync_debug)
+			fprintf(stderr, "[sync] frame %llu pass %s waits %s on %s: pass %s of frame %llu\n", (unsigned long long)this_frame,
+			        current_pass >= 0 ? passes[current_pass]->get_name().c_str() : "blit", kind, physical_dimensions[resource].name.c_str(),
+			        src_pass >= 0 && src_pass < int(passes.size()) ? passes[src_pass]->get_name().c_str() : "?", (unsigned long long)src_frame);
 		if (hipStreamWaitEvent(stream, static_cast<hipEvent_t>(event), 0) != hipSuccess)
 			throw std::runtime_error("cross-queue dependency failed");
 	};
@@ -981,12 +1050,14 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		waited.clear();
 		for (unsigned r : reads)
 			if (physical_sync[r].last_write && physical_sync[r].write_stream != stream_index)
-				wait_for(stream, physical_sync[r].last_write);
+				wait_for(stream, physical_sync[r].last_write, "RAW", r, physical_sync[r].write_pass, physical_sync[r].write_frame);
 		for (unsigned w : writes)
 		{
 			if (physical_sync[w].last_write && physical_sync[w].write_stream != stream_index)
-				wait_for(stream, physical_sync[w].last_write);
-			wait_for(stream, physical_sync[w].last_read[1 - stream_index]);
+				wait_for(stream, physical_sync[w].last_write, "WAW", w, physical_sync[w].write_pass, physical_sync[w].write_frame);
+			for (int other = 0; other < 3; other++)
+				if (other != stream_index)
+					wait_for(stream, physical_sync[w].last_read[other], "WAR", w, physical_sync[w].read_pass[other], physical_sync[w].read_frame[other]);
 		}
 	};
 	auto release = [&](hipStream_t stream, int stream_index, void *&event, const std::vector<unsigned> &reads,
@@ -1001,12 +1072,18 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		if (hipEventRecord(static_cast<hipEvent_t>(event), stream) != hipSuccess)
 			throw std::runtime_error("hipEventRecord failed");
 		for (unsigned r : reads)
+		{
 			physical_sync[r].last_read[stream_index] = event;
+			physical_sync[r].read_pass[stream_index] = current_pass;
+			physical_sync[r].read_frame[stream_index] = this_frame;
+		}
 		for (unsigned w : writes)
 		{
 			physical_sync[w].last_write = event;
 			physical_sync[w].write_stream = stream_index;
-			physical_sync[w].last_read[0] = physical_sync[w].last_read[1] = nullptr;
+			physical_sync[w].write_pass = current_pass;
+			physical_sync[w].write_frame = this_frame;
+			physical_sync[w].last_read[0] = physical_sync[w].last_read[1] = physical_sync[w].last_read[2] = nullptr;
 		}
 	};
 
@@ -1017,10 +1094,12 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 			continue;
 		pass.prepare_render_pass(composer);
 
-		const bool async = pass_runs_async(pass_index);
-		auto type = async ? HIP::CommandBuffer::Type::AsyncCompute : HIP::CommandBuffer::Type::Generic;
+		static const HIP::CommandBuffer::Type stream_types[3] = {HIP::CommandBuffer::Type::Generic, HIP::CommandBuffer::Type::AsyncCompute,
+		                                                          HIP::CommandBuffer::Type::Front};
+		auto type = stream_types[get_pass_stream(pass_index)];
 		auto stream = static_cast<hipStream_t>(device_.get_stream(type));
 		const bool sync = uses_async_stream && pass_needs_sync[pass_index];
+		current_pass = int(pass_index);
 		if (sync)
 			acquire(stream, int(type), pass_reads_physical[pass_index], pass_writes_physical[pass_index]);
 
@@ -1072,6 +1151,7 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		auto stream = static_cast<hipStream_t>(cmd.get_stream());
 		const std::vector<unsigned> reads = {src_index}, none;
 		const bool sync = uses_async_stream && blit_needs_sync;
+		current_pass = -1;
 		if (sync)
 			acquire(stream, int(HIP::CommandBuffer::Type::Generic), reads, none);
 		cmd.copy_image(*swapchain_attachment, src);
@@ -1162,7 +1242,7 @@ std::string RenderGraph::dump_json() const
 			os << ",";
 		first = false;
 		os << "{\"name\":\"" << pass.get_name() << "\",\"queue\":" << unsigned(pass.get_queue())
-		   << ",\"stream\":" << (pass_runs_async(pass_index) ? "\"async\"" : "\"generic\"") << ",\"writes\":[";
+		   << ",\"stream\":" << (get_pass_stream(pass_index) == 0 ? "\"generic\"" : get_pass_stream(pass_index) == 1 ? "\"async\"" : "\"front\"") << ",\"writes\":[";
 		bool f2 = true;
 		auto emit = [&](const RenderResource *r) {
 			if (!r)

@@ -374,11 +374,16 @@ public:
 	ResourceDimensions get_resource_dimensions(const RenderTextureResource &resource) const;
 
 	void enable_timestamps(bool enable) { enabled_timestamps = enable; }
-	// HIP executor policy (no reference analogue; Granite decides queues at declaration time only): a COMPUTE pass that
-	// reads nothing produced inside the graph (e.g. "clustering-bindless") is run on the async-compute stream, ordered
-	// by per-resource events, so that frame N+1's instance overlaps frame N's tail.  Default on.
+	// HIP executor policy (no reference analogue; Granite decides queues at declaration time only): frame pipelining.
+	// Passes that do not depend on anything carried over from the previous frame (the "front": cluster build, G-buffer,
+	// lighting) leave the generic stream: input-free ones (cluster build) go to the async-compute stream, the others to a
+	// third "front" stream.  Streams are ordered by per-resource events and whatever crosses from one stream to another
+	// is double-buffered, so frame N+1's cluster build overlaps frame N's lighting and frame N+1's lighting overlaps
+	// frame N's bloom / tonemap.  Default on.
 	void set_hoist_independent_compute(bool enable) { hoist_independent_compute = enable; }
-	bool pass_runs_async(unsigned pass_index) const { return pass_index < pass_async.size() && pass_async[pass_index]; }
+	// 0 = generic stream (the back of the frame), 1 = async compute (passes the front does not wait for within a frame:
+	// explicit ASYNC_COMPUTE passes and input-free front passes such as the cluster build), 2 = the rest of the front.
+	unsigned get_pass_stream(unsigned pass_index) const { return pass_index < pass_stream.size() ? pass_stream[pass_index] : 0u; }
 	bool physical_buffer_is_double_buffered(unsigned index) const { return index < physical_buffer_double.size() && physical_buffer_double[index]; }
 	void bake();
 	void reset();
@@ -482,7 +487,7 @@ private:
 	// as soon as frame N's readers of their outputs have finished.  With a single stream in use nothing is recorded.
 	bool hoist_independent_compute = true;
 	bool uses_async_stream = false;
-	std::vector<bool> pass_async;
+	std::vector<uint8_t> pass_stream;
 	std::vector<bool> pass_needs_sync; // touches a physical resource that the other stream also touches
 	bool blit_needs_sync = false;
 	std::vector<std::vector<unsigned>> pass_reads_physical, pass_writes_physical;
@@ -496,13 +501,17 @@ private:
 	{
 		void *last_write = nullptr;
 		int write_stream = -1;
-		void *last_read[2] = {nullptr, nullptr};
+		void *last_read[3] = {nullptr, nullptr, nullptr};
+		// who recorded those events (pass index, frame), for GRANITE_SYNC_DEBUG=1 traces
+		int write_pass = -1, read_pass[3] = {-1, -1, -1};
+		uint64_t write_frame = 0, read_frame[3] = {0, 0, 0};
 	};
 	std::vector<PhysicalSync> physical_sync;
 	// Buffers written by a hoisted pass exist twice and alternate per frame (like an image with history), so the
 	// hoisted pass of frame N+1 never waits for frame N's consumers: write-after-read across frames disappears.
 	std::vector<bool> physical_buffer_double;
 	std::vector<HIP::BufferHandle> physical_buffers_alternate;
+	std::vector<HIP::ImageHandle> physical_images_alternate;
 	std::vector<PhysicalSync> physical_sync_alternate;
 	void build_stream_assignment();
 	std::unordered_map<std::string, std::pair<uint64_t, double>> timestamp_accum;

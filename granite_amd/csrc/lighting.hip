@@ -27,6 +27,7 @@
 //      rcp / rsq), which is what bounds this kernel on the 4096-light config, not HBM.
 // The BRDF is algebraically the reference's; normalisations are folded (dot products on the unnormalised light vector,
 // H.V = |V+L|/2, one rcp for G*D) to cut the per-light VALU count.
+#include <cstdlib>
 #include "ctx.hpp"
 #include "device_common.hpp"
 
@@ -480,8 +481,20 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	k.num_blocks = k.blocks_x * (int(gr_div_up(row_end, LIGHT_TILE)) - k.block_row0);
 	k.blocks_per_xcd = (k.num_blocks + 7) / 8;
 	dim3 grid(unsigned(k.blocks_per_xcd) * 8u);
+	// Residency cap.  The kernel is VALU-bound and needs no more than ~6 waves per SIMD to hide its latencies, but at full
+	// occupancy it owns every wave slot of the chip for the whole launch and the executor's other streams (the previous
+	// frame's bloom / tonemap, the next frame's cluster build) cannot get a single wave in.  Padding the workgroup's LDS
+	// footprint so that only `max_wgs` workgroups fit per CU leaves the remaining slots to them.
+	static const int max_wgs = []() {
+		const char *env = getenv("GR_LIGHTING_WGS_PER_CU");
+		const int v = env ? atoi(env) : 7;
+		return v >= 1 && v <= 8 ? v : 7;
+	}();
+	const size_t static_lds = sizeof(f32x4) * LIGHT_WAVES * 64 * (LIGHT_SLOT_BYTES / 16);
+	const size_t per_wg = (160u * 1024u / unsigned(max_wgs)) & ~size_t(1023);
+	const size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "lighting"};
-	hipLaunchKernelGGL(k_lighting, grid, dim3(64 * LIGHT_WAVES), 0, gr_to_stream(stream), k);
+	hipLaunchKernelGGL(k_lighting, grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

@@ -75,6 +75,17 @@ int gr_alloc(gr_ctx *ctx, size_t bytes, void **dptr);
 int gr_free(gr_ctx *ctx, void *dptr);
 int gr_upload(gr_ctx *ctx, gr_stream stream, void *dst, const void *src_host, size_t bytes);   /* cmd.update_buffer */
 int gr_download(gr_ctx *ctx, gr_stream stream, void *dst_host, const void *src, size_t bytes); /* readback */
+/* Several cmd.update_buffer calls of one pass (clusterer.cpp:1178-1207,1302) as ONE kernel that reads pinned host memory
+ * (hipHostMalloc'd, device-mapped) and writes HBM: no copy engine, no cross-engine signalling, ordered like any other
+ * kernel on `stream`.  Sizes and offsets must be multiples of 4 bytes; at most GR_MAX_UPLOAD_RANGES ranges. */
+#define GR_MAX_UPLOAD_RANGES 8
+typedef struct gr_upload_range
+{
+	void *dst;             /* device */
+	const void *src_pinned; /* pinned host */
+	size_t bytes;
+} gr_upload_range;
+int gr_upload_batch(gr_ctx *ctx, gr_stream stream, const gr_upload_range *ranges, uint32_t count);
 int gr_copy(gr_ctx *ctx, gr_stream stream, void *dst, const void *src, size_t bytes);
 int gr_fill_zero(gr_ctx *ctx, gr_stream stream, void *dst, size_t bytes);
 

@@ -120,3 +120,33 @@ def test_frames_are_deterministic_and_timestamps_reported(scene):
     assert all(c == 6 and ms > 0 for c, ms in ts.values())
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(pre_aa=gapp.POST_AA_TAA_HIGH, post_aa=gapp.POST_AA_FXAA)])
+def test_pipelined_frames_equal_synchronised_frames(kw):
+    """Frame pipelining (front of frame N+1 on the second stream while the back of frame N is in flight, double-buffered
+    hand-over) must not change a single byte: 16 frames enqueued back to back vs the same frames with a full device sync
+    after each one."""
+    w, h = 960, 540
+    cam = synth.Camera(w, h)
+    gbuf = synth.make_gbuffer(cam)
+    descs = synth.make_lights(cam, 1024)
+    mv = synth.make_motion_vectors(w, h)
+    P, V = np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16)
+    results = []
+    for sync_every_frame in (True, False):
+        a = gapp.Application(w, h, **kw)
+        a.set_camera(P, V)
+        a.set_lights(descs)
+        a.upload_gbuffer(gbuf, mv)
+        if sync_every_frame:
+            for _ in range(16):
+                a.render_frames(1, sync=True)
+        else:
+            a.render_frames(16, sync=False)
+            a.sync()
+        results.append((a.read_backbuffer().copy(), a.read("average-luminance").copy(), a.read("HDR-main").copy(),
+                        a.read("downsample-3").copy()))
+        a.close()
+    for got, want in zip(results[1], results[0]):
+        np.testing.assert_array_equal(got, want)

@@ -69,17 +69,25 @@ def test_dry_application_refuses_to_render():
     a.close()
 
 
-def test_independent_compute_pass_is_hoisted_to_async_stream():
-    """Executor policy: a COMPUTE pass that reads nothing produced in the graph (the cluster build) runs on the async
-    stream; passes that consume graph resources stay on the generic stream."""
+def test_frame_front_is_pipelined_on_the_second_stream():
+    """Executor policy: passes that depend on nothing carried over from the previous frame (cluster build, G-buffer,
+    lighting) form the front of the frame and run on the second stream; passes with cross-frame feedback (the bloom
+    pyramid's history + exposure) and everything after them stay on the first.  What crosses from front to back
+    (HDR-main) is double-buffered, so frame N+1's front never waits for frame N's back."""
     g = graph_of(3840, 2160)
     streams = {p["name"]: p["stream"] for p in g["passes"]}
-    assert streams["clustering-bindless"] == "async"
-    assert streams["lighting-main"] == "generic" and streams["bloom-compute"] == "generic" and streams["tonemap"] == "generic"
-    # what the hoisted pass writes alternates between two copies, so frame N+1's build never waits for frame N's lighting
+    assert streams == {"clustering-bindless": "async", "gbuffer-main": "async", "lighting-main": "front",
+                       "bloom-compute": "generic", "tonemap": "generic"}
     dbl = {r["name"] for r in g["resources"] if r["double_buffered"]}
-    assert {"cluster-bitmask", "cluster-range", "cluster-transforms", "cluster-cull-setup", "cluster-transformed-spot"} <= dbl
-    assert "average-luminance" not in dbl and "HDR-main" not in dbl
-    # no lighting => no cluster pass => single stream
+    # cluster build -> lighting and lighting -> bloom / tonemap cross streams
+    assert {"HDR-main", "cluster-bitmask", "cluster-range", "cluster-transforms"} <= dbl
+    assert "average-luminance" not in dbl and "downsample-3" not in dbl
+    # TAA reads the depth and motion vectors the front produces: they cross to the back as well
+    g2 = graph_of(1280, 720, pre_aa=gapp.POST_AA_TAA_HIGH)
+    s2 = {p["name"]: p["stream"] for p in g2["passes"]}
+    assert s2["lighting-main"] == "front" and s2["taa-resolve"] == "generic" and s2["tonemap"] == "generic"
+    dbl2 = {r["name"] for r in g2["resources"] if r["double_buffered"]}
+    assert "HDR-main" in dbl2 and "HDR-resolved" not in dbl2
+    # no lighting: the frame starts at the HDR upload; nothing but the upload pass is independent of feedback
     g1 = graph_of(256, 256, lighting=False)
-    assert {p["stream"] for p in g1["passes"]} == {"generic"}
+    assert {p["name"]: p["stream"] for p in g1["passes"]}["bloom-compute"] == "generic"
