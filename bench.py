@@ -190,6 +190,19 @@ def main():
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
                     "avg_launch_us": dom_avg_s * 1e6, "launches": dom_count}
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes of this very
+        # command, corrected as MI355X_MICROARCH.md prescribes; scripts/pmc_passes.sh -> profiles/pmc_traffic.json).  Only
+        # quoted for the workload it was collected on.
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            entry = pmc["kernels"].get(dominant)
+            if entry and args.workload == "config3_4k_4096lights" and world == 1:
+                roofline["traffic"] = entry["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/pmc_traffic.json (" + pmc["source"] + "; " + entry["correction"] + ")"
+                roofline["valu_instructions_per_launch"] = entry.get("SQ_INSTS_VALU")
+        except (OSError, KeyError, ValueError):
+            pass
     chain_bytes = ALGO_BYTES_PER_PX["chain"] * width * height
     chain_gbs = chain_bytes * args.steps / elapsed / 1e9
 
