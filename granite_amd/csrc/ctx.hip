@@ -81,7 +81,10 @@ int gr_alloc(gr_ctx *ctx, size_t bytes, void **dptr)
 	hipError_t err = hipMalloc(dptr, bytes);
 	if (err != hipSuccess)
 		return ctx->fail(GR_ERR_OUT_OF_MEMORY, "gr_alloc: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+	// hipMemset on device memory is asynchronous with respect to the host and runs on the null stream, which the executor's
+	// non-blocking streams do not synchronise with: wait for it, or the zeros can land on top of a kernel's first writes.
 	GR_CHECK_HIP(ctx, hipMemset(*dptr, 0, bytes));
+	GR_CHECK_HIP(ctx, hipStreamSynchronize(nullptr));
 	return GR_OK;
 }
 

@@ -3,6 +3,7 @@
 // Replaces assets/shaders/post/{bloom_threshold,bloom_downsample,bloom_upsample,luminance}.comp and tonemap.frag as
 // recorded by renderer/post/hdr.cpp:68-216,283-306.  All targets are linear row-major HBM buffers; every kernel is
 // HBM-bound (no MFMA): one pass over its declared inputs, coalesced 8/16-byte accesses per lane.
+#include <cstdlib>
 #include "ctx.hpp"
 #include "device_common.hpp"
 
@@ -100,6 +101,119 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_upsample(D
 	const float u = (float(x) + 0.5f) * push.inv_output_size[0];
 	const float v = (float(y) + 0.5f) * push.inv_output_size[1];
 	store_rgba16f(out, x, y, tent9(in, u, v, 0.875f * push.inv_input_size[0], 0.875f * push.inv_input_size[1]));
+}
+
+// ---- exact 2:1 / 1:2 forms of the tent filters -----------------------------------------------------------------------------
+// When a level is exactly half (twice) its input in both axes -- every level of an even-sized pyramid, e.g. all of 4K down to
+// 240x135 -- the nine LinearClamp taps of bloom_downsample.comp / bloom_upsample.comp land on fixed sub-texel phases, so the
+// filter is a separable stencil with constant weights over clamped texel indices:
+//   downsample: taps at 2i+0.5 and 2i+0.5 +- 1.75 input texels  ->  texels 2i-2 .. 2i+3, weights (1 3 4 4 3 1) / 16 per axis
+//   upsample:   taps at i/2-0.25 and +- 0.875 input texels      ->  4 texels from k-2 (i = 2k) or k-1 (i = 2k+1),
+//               weights (1 11 15 5) / 32 for even i, mirrored for odd i
+// Same clamping as the sampler (each texel index clamped on its own); the products differ from the tap-by-tap evaluation only
+// in fp32 summation order (covered by the per-level fp16 tolerance).  A 9-tap kernel spends ~60 VALU per tap on coordinates,
+// weights and conversions; the stencils need 36 (16) texel fetches and one fma per texel and channel.
+__device__ __forceinline__ float4 cvt4(f16x4 t) { return make_float4(float(t.x), float(t.y), float(t.z), float(t.w)); }
+__device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+template <bool FEEDBACK>
+__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_downsample_2to1(DevImage in, DevImageRW out, DevImage history,
+                                                                                      gr_push_bloom_downsample push, uint32_t y_first,
+                                                                                      uint32_t y_end)
+{
+	// Two horizontally adjacent outputs per thread: their stencils share 4 of 8 texel columns, fetched as 4 x 16 B per row.
+	const int x0 = (blockIdx.x * POST_BLOCK_X + threadIdx.x) * 2;
+	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
+	if (uint32_t(x0) >= push.threads[0] || uint32_t(y) >= y_end)
+		return;
+	const float wt[6] = {0.0625f, 0.1875f, 0.25f, 0.25f, 0.1875f, 0.0625f};
+	const int col0 = 2 * x0 - 2; // first of 8 input columns; even, so 16-byte aligned when inside the image
+	const bool interior = col0 >= 0 && col0 + 7 < in.w;
+	float4 acc0 = make_float4(0, 0, 0, 0), acc1 = make_float4(0, 0, 0, 0);
+#pragma unroll
+	for (int r = 0; r < 6; r++)
+	{
+		const int iy = clampi(2 * y - 2 + r, 0, in.h - 1);
+		const uint8_t *row = in.ptr + size_t(iy) * in.pitch;
+		float4 t[8];
+		if (interior)
+		{
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+			{
+				const u32x4 v = *reinterpret_cast<const u32x4 *>(row + size_t(col0 + 2 * q) * 8u);
+				t[2 * q] = cvt4(__builtin_bit_cast(f16x4, u32x2{v.x, v.y}));
+				t[2 * q + 1] = cvt4(__builtin_bit_cast(f16x4, u32x2{v.z, v.w}));
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int c = 0; c < 8; c++)
+				t[c] = cvt4(*reinterpret_cast<const f16x4 *>(row + size_t(clampi(col0 + c, 0, in.w - 1)) * 8u));
+		}
+		float4 h0 = mul4(t[0], wt[0]), h1 = mul4(t[2], wt[0]);
+#pragma unroll
+		for (int c = 1; c < 6; c++)
+		{
+			h0 = fma4(t[c], wt[c], h0);
+			h1 = fma4(t[c + 2], wt[c], h1);
+		}
+		acc0 = fma4(h0, wt[r], acc0);
+		acc1 = fma4(h1, wt[r], acc1);
+	}
+#pragma unroll
+	for (int k = 0; k < 2; k++)
+	{
+		const int x = x0 + k;
+		if (uint32_t(x) >= push.threads[0])
+			break;
+		float4 value = k ? acc1 : acc0;
+		if (FEEDBACK)
+		{
+			// NearestClamp fetch of the previous frame's level at the same texel (hdr.cpp:160-166).
+			const float u = (float(x) + 0.5f) * push.inv_output_size[0];
+			const float v = (float(y) + 0.5f) * push.inv_output_size[1];
+			const int hx = clampi(int(floorf(u * float(history.w))), 0, history.w - 1);
+			const int hy = clampi(int(floorf(v * float(history.h))), 0, history.h - 1);
+			const float4 h = load_rgba16f(history, hx, hy);
+			const float l = push.lerp;
+			value = make_float4(h.x * (1.0f - l) + value.x * l, h.y * (1.0f - l) + value.y * l, h.z * (1.0f - l) + value.z * l,
+			                    value.w);
+		}
+		store_rgba16f(out, x, y, value);
+	}
+}
+
+__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_upsample_1to2(DevImage in, DevImageRW out,
+                                                                                    gr_push_bloom_upsample push, uint32_t y_first,
+                                                                                    uint32_t y_end)
+{
+	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
+	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
+	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
+		return;
+	// even output: texels k-2..k+1, weights (1 11 15 5)/32; odd output: texels k-1..k+2, weights (5 15 11 1)/32
+	const bool odd_x = (x & 1) != 0, odd_y = (y & 1) != 0;
+	const int sx = (x >> 1) - 2 + (odd_x ? 1 : 0), sy = (y >> 1) - 2 + (odd_y ? 1 : 0);
+	const float wx[4] = {odd_x ? 0.15625f : 0.03125f, odd_x ? 0.46875f : 0.34375f, odd_x ? 0.34375f : 0.46875f, odd_x ? 0.03125f : 0.15625f};
+	const float wy[4] = {odd_y ? 0.15625f : 0.03125f, odd_y ? 0.46875f : 0.34375f, odd_y ? 0.34375f : 0.46875f, odd_y ? 0.03125f : 0.15625f};
+	int cx[4];
+#pragma unroll
+	for (int c = 0; c < 4; c++)
+		cx[c] = clampi(sx + c, 0, in.w - 1);
+	float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+	for (int r = 0; r < 4; r++)
+	{
+		const uint8_t *row = in.ptr + size_t(clampi(sy + r, 0, in.h - 1)) * in.pitch;
+		float4 h = mul4(cvt4(*reinterpret_cast<const f16x4 *>(row + size_t(cx[0]) * 8u)), wx[0]);
+#pragma unroll
+		for (int c = 1; c < 4; c++)
+			h = fma4(cvt4(*reinterpret_cast<const f16x4 *>(row + size_t(cx[c]) * 8u)), wx[c], h);
+		acc = fma4(h, wy[r], acc);
+	}
+	store_rgba16f(out, x, y, acc);
 }
 
 // ---- average luminance (luminance.comp:25-67) ---------------------------------------------------------------------
@@ -343,7 +457,23 @@ int gr_bloom_downsample_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, 
 	dim3 block(POST_BLOCK_X, POST_BLOCK_Y);
 	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_downsample"};
-	if (history)
+	// Exact 2:1 level (and push constants that say so): constant-weight stencil, two outputs per thread.
+	static const bool allow_stencil = getenv("GR_NO_STENCIL") == nullptr; // A/B switch for measurements
+	const bool exact = allow_stencil && in->width == 2u * push->threads[0] && in->height == 2u * push->threads[1] && (in->pitch_bytes & 15u) == 0 &&
+	                   (reinterpret_cast<uintptr_t>(in->ptr) & 15u) == 0 && push->inv_output_size[0] == 1.0f / float(push->threads[0]) &&
+	                   push->inv_output_size[1] == 1.0f / float(push->threads[1]) && push->inv_input_size[0] == 1.0f / float(in->width) &&
+	                   push->inv_input_size[1] == 1.0f / float(in->height);
+	if (exact)
+	{
+		dim3 grid2(gr_div_up(gr_div_up(push->threads[0], 2u), POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
+		if (history)
+			hipLaunchKernelGGL(k_bloom_downsample_2to1<true>, grid2, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out),
+			                   to_dev(history), *push, span.first, span.end);
+		else
+			hipLaunchKernelGGL(k_bloom_downsample_2to1<false>, grid2, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out),
+			                   DevImage{}, *push, span.first, span.end);
+	}
+	else if (history)
 		hipLaunchKernelGGL(k_bloom_downsample<true>, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out),
 		                   to_dev(history), *push, span.first, span.end);
 	else
@@ -374,7 +504,15 @@ int gr_bloom_upsample_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, co
 	dim3 block(POST_BLOCK_X, POST_BLOCK_Y);
 	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_upsample"};
-	hipLaunchKernelGGL(k_bloom_upsample, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out), *push, span.first, span.end);
+	static const bool allow_stencil = getenv("GR_NO_STENCIL") == nullptr;
+	const bool exact = allow_stencil && push->threads[0] == 2u * in->width && push->threads[1] == 2u * in->height &&
+	                   push->inv_output_size[0] == 1.0f / float(push->threads[0]) && push->inv_output_size[1] == 1.0f / float(push->threads[1]) &&
+	                   push->inv_input_size[0] == 1.0f / float(in->width) && push->inv_input_size[1] == 1.0f / float(in->height);
+	if (exact)
+		hipLaunchKernelGGL(k_bloom_upsample_1to2, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out), *push, span.first,
+		                   span.end);
+	else
+		hipLaunchKernelGGL(k_bloom_upsample, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out), *push, span.first, span.end);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
