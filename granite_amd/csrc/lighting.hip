@@ -134,51 +134,81 @@ __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t v)
 // One staged light = 4 x 16 B in wave-private LDS.
 //   q0: position.xyz, (1.001 r)^2        q1: colour.xyz, 10 / r
 //   q2: direction.xyz, -                 q3: spot scale, spot bias (fp32), -, -          (q2, q3 read for spots only)
-__device__ __forceinline__ void shade_positional(const Surface &s, f32x4 q0, f32x4 q1, const f32x4 *slot, bool is_spot,
-                                                 float3_ &result)
+//
+// PX pixels per lane (horizontally adjacent): the light record, the tile-level early-outs and all of the wave-level
+// bookkeeping are shared by 64 * PX pixels, and the PX independent BRDF chains give the wave enough instruction-level
+// parallelism to saturate the VALU at half the resident waves -- which is what leaves wave slots to the executor's other
+// streams while this kernel runs (see gr_lighting).
+template <int PX>
+__device__ __forceinline__ void shade_positional(const Surface (&s)[PX], f32x4 q0, f32x4 q1, const f32x4 *slot, bool is_spot,
+                                                 float3_ (&result)[PX])
 {
-	const float3_ Lf = f3(q0.x, q0.y, q0.z) - s.pos;                 // light_pos - world_pos
-	const float d2 = fmaf(Lf.z, Lf.z, fmaf(Lf.y, Lf.y, fmaf(Lf.x, Lf.x, 1e-30f))); // > 0: no inf / nan downstream
+	float3_ Lf[PX];
+	float d2[PX];
+	bool near_any = false;
+#pragma unroll
+	for (int p = 0; p < PX; p++)
+	{
+		Lf[p] = f3(q0.x, q0.y, q0.z) - s[p].pos;                                               // light_pos - world_pos
+		d2[p] = fmaf(Lf[p].z, Lf[p].z, fmaf(Lf[p].y, Lf[p].y, fmaf(Lf[p].x, Lf[p].x, 1e-30f))); // > 0: no inf / nan downstream
+		near_any = near_any || d2[p] < q0.w;
+	}
 	// Falloff is exactly 0 once dist * inv_radius >= 1: skip the light when no pixel of the tile is inside 1.001 r.
-	if (!__any(d2 < q0.w))
+	if (!__any(near_any))
 		return;
 
-	const float inv_d = rsq(d2);
-	const float len = d2 * inv_d;        // length(light_dir_full)
-	const float dist = fmaxf(0.1f, len); // light_dist
-	const float inv_d2 = inv_d * inv_d;
-	// 1 - smoothstep(0.9, 1.0, dist * inv_radius)
-	const float t = sat(fmaf(dist, q1.w, -9.0f));
-	float atten = fmaf(-(t * t), fmaf(-2.0f, t, 3.0f), 1.0f);
+	float inv_d[PX], len[PX], inv_d2[PX], atten[PX];
+#pragma unroll
+	for (int p = 0; p < PX; p++)
+	{
+		inv_d[p] = rsq(d2[p]);
+		len[p] = d2[p] * inv_d[p];                // length(light_dir_full)
+		const float dist = fmaxf(0.1f, len[p]); // light_dist
+		inv_d2[p] = inv_d[p] * inv_d[p];
+		// 1 - smoothstep(0.9, 1.0, dist * inv_radius)
+		const float t = sat(fmaf(dist, q1.w, -9.0f));
+		atten[p] = fmaf(-(t * t), fmaf(-2.0f, t, 3.0f), 1.0f);
+	}
 	if (is_spot)
 	{
 		// spot.h:41-46: cone = dot(normalize(world_pos - light_pos), direction) = -dot(Lf, direction) / |Lf|
 		const f32x4 q2 = slot[2], q3 = slot[3];
-		const float cone_angle = -dot(Lf, f3(q2.x, q2.y, q2.z)) * inv_d;
-		const float cone = sat(fmaf(cone_angle, q3.x, q3.y));
-		atten *= cone * cone;
+		bool lit_any = false;
+#pragma unroll
+		for (int p = 0; p < PX; p++)
+		{
+			const float cone_angle = -dot(Lf[p], f3(q2.x, q2.y, q2.z)) * inv_d[p];
+			const float cone = sat(fmaf(cone_angle, q3.x, q3.y));
+			atten[p] *= cone * cone;
+			lit_any = lit_any || atten[p] > 0.0f;
+		}
 		// Most of a spot's bounding sphere is outside its cone: spot_color == 0 for the whole tile -> returns 0.
-		if (!__any(atten > 0.0f))
+		if (!__any(lit_any))
 			return;
 	}
-	// colour = light colour * atten / dist^2; dist^2 = max(len, 0.1)^2
-	const float a2 = atten * fminf(inv_d2, 1.0f / (0.1f * 0.1f));
-
-	const float NdL = dot(s.N, Lf) * inv_d;
-	// |V + L|^2 with L = Lf / len: |len V + Lf|^2 / len^2
-	const float3_ Hs = f3(fmaf(s.V.x, len, Lf.x), fmaf(s.V.y, len, Lf.y), fmaf(s.V.z, len, Lf.z));
-	const float hh = fmaf(Hs.z, Hs.z, fmaf(Hs.y, Hs.y, fmaf(Hs.x, Hs.x, 1e-30f))) * inv_d2;
-	float NoL;
-	const float3_ b = brdf(s, NdL, hh, NoL);
-	const float w = NoL * a2;
-	result.x = fmaf(q1.x * w, b.x, result.x);
-	result.y = fmaf(q1.y * w, b.y, result.y);
-	result.z = fmaf(q1.z * w, b.z, result.z);
+#pragma unroll
+	for (int p = 0; p < PX; p++)
+	{
+		// colour = light colour * atten / dist^2; dist^2 = max(len, 0.1)^2
+		const float a2 = atten[p] * fminf(inv_d2[p], 1.0f / (0.1f * 0.1f));
+		const float NdL = dot(s[p].N, Lf[p]) * inv_d[p];
+		// |V + L|^2 with L = Lf / len: |len V + Lf|^2 / len^2
+		const float3_ Hs = f3(fmaf(s[p].V.x, len[p], Lf[p].x), fmaf(s[p].V.y, len[p], Lf[p].y), fmaf(s[p].V.z, len[p], Lf[p].z));
+		const float hh = fmaf(Hs.z, Hs.z, fmaf(Hs.y, Hs.y, fmaf(Hs.x, Hs.x, 1e-30f))) * inv_d2[p];
+		float NoL;
+		const float3_ b = brdf(s[p], NdL, hh, NoL);
+		const float w = NoL * a2;
+		result[p].x = fmaf(q1.x * w, b.x, result[p].x);
+		result[p].y = fmaf(q1.y * w, b.y, result[p].y);
+		result[p].z = fmaf(q1.z * w, b.z, result[p].z);
+	}
 }
 
+template <int PX>
 __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 {
 	__shared__ __attribute__((aligned(16))) f32x4 s_lights[LIGHT_WAVES][64 * (LIGHT_SLOT_BYTES / 16)];
+	constexpr int TILE_W = LIGHT_TILE * PX;
 
 	// XCD-aware tile order: block b runs on XCD b % 8; give each XCD one contiguous band of the screen so the cluster
 	// words and light records a band needs stay in that XCD's L2.
@@ -188,107 +218,128 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 	const int block_x = logical % a.blocks_x, block_y = a.block_row0 + logical / a.blocks_x;
 	const int wave = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
-	const int tile_x0 = (block_x * LIGHT_WAVES + wave) * LIGHT_TILE, tile_y0 = block_y * LIGHT_TILE;
-	const int x = tile_x0 + (lane & (LIGHT_TILE - 1));
+	const int tile_x0 = (block_x * LIGHT_WAVES + wave) * TILE_W, tile_y0 = block_y * LIGHT_TILE;
+	const int x0 = tile_x0 + (lane & (LIGHT_TILE - 1)) * PX;
 	const int y = tile_y0 + (lane >> 3);
 	const int W = a.hdr.w, H = a.hdr.h;
-	const bool inside = x < W && y >= a.row_first && y < a.row_end; // row_end <= H
+	const bool row_inside = y >= a.row_first && y < a.row_end; // row_end <= H
 
-	float depth = 0.0f;
-	uint32_t alb = 0, nrm = 0, mr = 0;
-	f16x4 dst = {0, 0, 0, 0};
-	if (inside)
-	{
-		depth = *reinterpret_cast<const float *>(a.depth.ptr + size_t(y) * a.depth.pitch + size_t(x) * 4u);
-		alb = *reinterpret_cast<const uint32_t *>(a.albedo.ptr + size_t(y) * a.albedo.pitch + size_t(x) * 4u);
-		nrm = *reinterpret_cast<const uint32_t *>(a.normal.ptr + size_t(y) * a.normal.pitch + size_t(x) * 4u);
-		mr = *reinterpret_cast<const uint16_t *>(a.pbr.ptr + size_t(y) * a.pbr.pitch + size_t(x) * 2u);
-		dst = *reinterpret_cast<const f16x4 *>(a.emissive.ptr + size_t(y) * a.emissive.pitch + size_t(x) * 8u);
-	}
-	// depth test NOT_EQUAL against the quad at z = 0 (renderer.cpp:1056-1057): reverse-Z far-plane pixels keep the
-	// emissive value (both draws are depth-rejected).
-	const bool active = inside && depth != 0.0f;
-
-	// ---- G-buffer decode (clustering.frag:31-35) ----
-	const float3_ base = f3(a.srgb_lut[alb & 255u], a.srgb_lut[(alb >> 8) & 255u], a.srgb_lut[(alb >> 16) & 255u]);
-	const float3_ N = f3(float(nrm & 1023u) * (2.0f / 1023.0f) - 1.0f, float((nrm >> 10) & 1023u) * (2.0f / 1023.0f) - 1.0f,
-	                     float((nrm >> 20) & 1023u) * (2.0f / 1023.0f) - 1.0f);
-	const float metallic = float(mr & 255u) * (1.0f / 255.0f);
-	const float mat_roughness = float(mr >> 8) * (1.0f / 255.0f);
-
-	// ---- position reconstruction (clustering.vert:10-13, clustering.frag:37-39): clip = invVP * (ndc.xy, depth, 1),
-	// pos = clip.xyz / clip.w.  Evaluated with fused multiply-adds and a Newton-refined reciprocal; a pixel that lands in
-	// the neighbouring Z slice because of the last-bit difference sees the same lights up to ones at the very edge of
-	// their radius (falloff -> 0), cf. the conservative slice ranges of clusterer.cpp:1265-1275. ----
-	const float ndc_x = fmaf(2.0f * (float(x) + 0.5f), a.inv_resolution[0], -1.0f);
-	const float ndc_y = fmaf(2.0f * (float(y) + 0.5f), a.inv_resolution[1], -1.0f);
-	float clip[4];
+	bool inside[PX], active[PX];
+	f16x4 dst[PX];
+	Surface s[PX];
+	float3_ base[PX], accum[PX];
+	bool any_active = false;
 #pragma unroll
-	for (int i = 0; i < 4; i++)
-		clip[i] = fmaf(depth, a.inv_vp[8 + i], fmaf(a.inv_vp[4 + i], ndc_y, fmaf(a.inv_vp[i], ndc_x, a.inv_vp[12 + i])));
-	const float clip_w = active ? clip[3] : 1.0f;
-	float inv_w = rcp(clip_w);
-	inv_w = inv_w * fmaf(-clip_w, inv_w, 2.0f);
-	const float3_ pos = f3(clip[0] * inv_w, clip[1] * inv_w, clip[2] * inv_w);
-
-	Surface s;
-	s.pos = pos;
-	s.N = N;
-	const float3_ cam = f3(a.camera_pos[0], a.camera_pos[1], a.camera_pos[2]);
-	float3_ V = cam - pos;
-	V = V * rsq(fmaxf(dot(V, V), 1e-30f));
-	s.V = V;
-	s.NdV = dot(N, V);
-	const float NoV = med3(s.NdV, 0.001f, 1.0f);
-	s.F0 = f3(fmaf(base.x - 0.04f, metallic, 0.04f), fmaf(base.y - 0.04f, metallic, 0.04f), fmaf(base.z - 0.04f, metallic, 0.04f));
-	s.omF0 = f3(1.0f - s.F0.x, 1.0f - s.F0.y, 1.0f - s.F0.z);
-	const float roughness = fmaf(mat_roughness, 0.75f, 0.25f);
-	const float m = roughness * roughness;
-	const float m2 = m * m;
-	s.m2m1 = m2 - 1.0f;
-	s.c0 = m2 * (0.25f / PI_SIC);
-	const float r1 = roughness + 1.0f;
-	s.k = r1 * r1 * (1.0f / 8.0f);
-	s.omk = 1.0f - s.k;
-	s.Gv = fmaf(NoV, s.omk, s.k);
-	s.diffuse = base * ((1.0f - metallic) * (1.0f / PI_SIC));
-
-	float3_ accum = f3(float(dst.x), float(dst.y), float(dst.z));
-
-	// ---- directional quad (directional.frag:41-65) ----
-	if (a.flags & GR_LIGHTING_DIRECTIONAL_BIT)
+	for (int p = 0; p < PX; p++)
 	{
-		const float3_ L = f3(a.dir_direction[0], a.dir_direction[1], a.dir_direction[2]);
-		const float3_ Hv = V + L;
-		float NoL;
-		const float3_ b = brdf(s, dot(N, L), fmaxf(dot(Hv, Hv), 1e-30f), NoL);
-		float3_ lit = f3(a.dir_color[0] * NoL * b.x, a.dir_color[1] * NoL * b.y, a.dir_color[2] * NoL * b.z);
-		if (a.flags & GR_LIGHTING_AMBIENT_FALLBACK_BIT)
-			lit = lit + base * 0.05f;
-		// blend ONE/ONE, attachment store rounds to fp16
-		accum = f3(float(_Float16(accum.x + lit.x)), float(_Float16(accum.y + lit.y)), float(_Float16(accum.z + lit.z)));
+		const int x = x0 + p;
+		inside[p] = row_inside && x < W;
+		float depth = 0.0f;
+		uint32_t alb = 0, nrm = 0, mr = 0;
+		dst[p] = f16x4{0, 0, 0, 0};
+		if (inside[p])
+		{
+			depth = *reinterpret_cast<const float *>(a.depth.ptr + size_t(y) * a.depth.pitch + size_t(x) * 4u);
+			alb = *reinterpret_cast<const uint32_t *>(a.albedo.ptr + size_t(y) * a.albedo.pitch + size_t(x) * 4u);
+			nrm = *reinterpret_cast<const uint32_t *>(a.normal.ptr + size_t(y) * a.normal.pitch + size_t(x) * 4u);
+			mr = *reinterpret_cast<const uint16_t *>(a.pbr.ptr + size_t(y) * a.pbr.pitch + size_t(x) * 2u);
+			dst[p] = *reinterpret_cast<const f16x4 *>(a.emissive.ptr + size_t(y) * a.emissive.pitch + size_t(x) * 8u);
+		}
+		// depth test NOT_EQUAL against the quad at z = 0 (renderer.cpp:1056-1057): reverse-Z far-plane pixels keep the
+		// emissive value (both draws are depth-rejected).
+		active[p] = inside[p] && depth != 0.0f;
+		any_active = any_active || active[p];
+
+		// ---- G-buffer decode (clustering.frag:31-35) ----
+		base[p] = f3(a.srgb_lut[alb & 255u], a.srgb_lut[(alb >> 8) & 255u], a.srgb_lut[(alb >> 16) & 255u]);
+		const float3_ N = f3(float(nrm & 1023u) * (2.0f / 1023.0f) - 1.0f, float((nrm >> 10) & 1023u) * (2.0f / 1023.0f) - 1.0f,
+		                     float((nrm >> 20) & 1023u) * (2.0f / 1023.0f) - 1.0f);
+		const float metallic = float(mr & 255u) * (1.0f / 255.0f);
+		const float mat_roughness = float(mr >> 8) * (1.0f / 255.0f);
+
+		// ---- position reconstruction (clustering.vert:10-13, clustering.frag:37-39): clip = invVP * (ndc.xy, depth, 1),
+		// pos = clip.xyz / clip.w.  Evaluated with fused multiply-adds and a Newton-refined reciprocal; a pixel that lands
+		// in the neighbouring Z slice because of the last-bit difference sees the same lights up to ones at the very edge
+		// of their radius (falloff -> 0), cf. the conservative slice ranges of clusterer.cpp:1265-1275. ----
+		const float ndc_x = fmaf(2.0f * (float(x) + 0.5f), a.inv_resolution[0], -1.0f);
+		const float ndc_y = fmaf(2.0f * (float(y) + 0.5f), a.inv_resolution[1], -1.0f);
+		float clip[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			clip[i] = fmaf(depth, a.inv_vp[8 + i], fmaf(a.inv_vp[4 + i], ndc_y, fmaf(a.inv_vp[i], ndc_x, a.inv_vp[12 + i])));
+		const float clip_w = active[p] ? clip[3] : 1.0f;
+		float inv_w = rcp(clip_w);
+		inv_w = inv_w * fmaf(-clip_w, inv_w, 2.0f);
+		const float3_ pos = f3(clip[0] * inv_w, clip[1] * inv_w, clip[2] * inv_w);
+
+		s[p].pos = pos;
+		s[p].N = N;
+		const float3_ cam = f3(a.camera_pos[0], a.camera_pos[1], a.camera_pos[2]);
+		float3_ V = cam - pos;
+		V = V * rsq(fmaxf(dot(V, V), 1e-30f));
+		s[p].V = V;
+		s[p].NdV = dot(N, V);
+		const float NoV = med3(s[p].NdV, 0.001f, 1.0f);
+		s[p].F0 = f3(fmaf(base[p].x - 0.04f, metallic, 0.04f), fmaf(base[p].y - 0.04f, metallic, 0.04f),
+		             fmaf(base[p].z - 0.04f, metallic, 0.04f));
+		s[p].omF0 = f3(1.0f - s[p].F0.x, 1.0f - s[p].F0.y, 1.0f - s[p].F0.z);
+		const float roughness = fmaf(mat_roughness, 0.75f, 0.25f);
+		const float m = roughness * roughness;
+		const float m2 = m * m;
+		s[p].m2m1 = m2 - 1.0f;
+		s[p].c0 = m2 * (0.25f / PI_SIC);
+		const float r1 = roughness + 1.0f;
+		s[p].k = r1 * r1 * (1.0f / 8.0f);
+		s[p].omk = 1.0f - s[p].k;
+		s[p].Gv = fmaf(NoV, s[p].omk, s[p].k);
+		s[p].diffuse = base[p] * ((1.0f - metallic) * (1.0f / PI_SIC));
+
+		accum[p] = f3(float(dst[p].x), float(dst[p].y), float(dst[p].z));
+
+		// ---- directional quad (directional.frag:41-65) ----
+		if (a.flags & GR_LIGHTING_DIRECTIONAL_BIT)
+		{
+			const float3_ L = f3(a.dir_direction[0], a.dir_direction[1], a.dir_direction[2]);
+			const float3_ Hv = V + L;
+			float NoL;
+			const float3_ b = brdf(s[p], dot(N, L), fmaxf(dot(Hv, Hv), 1e-30f), NoL);
+			float3_ lit = f3(a.dir_color[0] * NoL * b.x, a.dir_color[1] * NoL * b.y, a.dir_color[2] * NoL * b.z);
+			if (a.flags & GR_LIGHTING_AMBIENT_FALLBACK_BIT)
+				lit = lit + base[p] * 0.05f;
+			// blend ONE/ONE, attachment store rounds to fp16
+			accum[p] = f3(float(_Float16(accum[p].x + lit.x)), float(_Float16(accum[p].y + lit.y)), float(_Float16(accum[p].z + lit.z)));
+		}
 	}
 
 	// ---- clustered quad (clusterer_bindless.h:29-84) ----
 	if ((a.flags & GR_LIGHTING_CLUSTERED_BIT) && a.cl_num_lights > 0)
 	{
-		float3_ result = f3(0.0f, 0.0f, 0.0f);
-
-		// Slice lookup (clusterer_bindless.h:43-47) and the wave's light-index window.
-		const float z = dot(pos - f3(a.cl_camera_base[0], a.cl_camera_base[1], a.cl_camera_base[2]),
-		                    f3(a.cl_camera_front[0], a.cl_camera_front[1], a.cl_camera_front[2]));
-		const int z_index = clampi(int(z * a.cl_z_scale), 0, a.cl_z_max_index);
-		uint2 z_range = make_uint2(0xffffffffu, 0u);
-		if (active)
-			z_range = a.range[z_index];
-		const uint32_t win_lo = wave_minmax_u32<false>(z_range.x);
-		const uint32_t win_hi = min(wave_minmax_u32<true>(z_range.y), uint32_t(a.cl_num_lights - 1));
+		float3_ result[PX];
+		uint32_t lane_lo = 0xffffffffu, lane_hi = 0u;
+#pragma unroll
+		for (int p = 0; p < PX; p++)
+		{
+			result[p] = f3(0.0f, 0.0f, 0.0f);
+			// Slice lookup (clusterer_bindless.h:43-47).
+			const float z = dot(s[p].pos - f3(a.cl_camera_base[0], a.cl_camera_base[1], a.cl_camera_base[2]),
+			                    f3(a.cl_camera_front[0], a.cl_camera_front[1], a.cl_camera_front[2]));
+			const int z_index = clampi(int(z * a.cl_z_scale), 0, a.cl_z_max_index);
+			if (active[p])
+			{
+				const uint2 z_range = a.range[z_index];
+				lane_lo = min(lane_lo, z_range.x);
+				lane_hi = max(lane_hi, z_range.y);
+			}
+		}
+		// The wave's light-index window.
+		const uint32_t win_lo = wave_minmax_u32<false>(lane_lo);
+		const uint32_t win_hi = min(wave_minmax_u32<true>(lane_hi), uint32_t(a.cl_num_lights - 1));
 
 		if (win_lo <= win_hi)
 		{
 			// Cluster cells the tile touches (clusterer_bindless.h:39-42 evaluated at the tile corners; the per-pixel
 			// formula is monotonic, so every lane's cell lies in this rectangle).
-			const int xe = min(tile_x0 + LIGHT_TILE - 1, W - 1), ye = min(tile_y0 + LIGHT_TILE - 1, H - 1);
+			const int xe = min(tile_x0 + TILE_W - 1, W - 1), ye = min(tile_y0 + LIGHT_TILE - 1, H - 1);
 			auto cell = [](int p, float inv_res, float scale, int res) {
 				return clampi(int(__fmul_rn(__fmul_rn(float(p) + 0.5f, inv_res), scale)), 0, res - 1);
 			};
@@ -298,13 +349,23 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 			const int cy1 = __builtin_amdgcn_readfirstlane(cell(ye, a.inv_resolution[1], a.cl_xy_scale[1], a.cl_res_y));
 
 			// Bounding sphere of the tile's surface points: centre = first lit pixel, radius = farthest lit pixel from it.
-			const uint64_t lit = __ballot(active);
+			const uint64_t lit = __ballot(any_active);
 			const int first = __builtin_ctzll(lit);
-			const float3_ centre = f3(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pos.x), first)),
-			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pos.y), first)),
-			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pos.z), first)));
-			const float3_ off = pos - centre;
-			const float off2 = active ? dot(off, off) : 0.0f;
+			float3_ mine = s[0].pos;
+#pragma unroll
+			for (int p = PX - 1; p >= 0; p--)
+				if (active[p])
+					mine = s[p].pos;
+			const float3_ centre = f3(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), first)),
+			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), first)),
+			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), first)));
+			float off2 = 0.0f;
+#pragma unroll
+			for (int p = 0; p < PX; p++)
+			{
+				const float3_ off = s[p].pos - centre;
+				off2 = fmaxf(off2, active[p] ? dot(off, off) : 0.0f);
+			}
 			const float tile_radius =
 			    __builtin_sqrtf(__builtin_bit_cast(float, wave_minmax_u32<true>(__builtin_bit_cast(uint32_t, off2)))) * 1.0001f + CULL_SLACK;
 
@@ -330,9 +391,9 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 					if ((word >> (uint32_t(lane) & 31u)) & 1u)
 					{
 						const f32x4 *rec = reinterpret_cast<const f32x4 *>(a.lights + light_index);
-						const f32x4 c = rec[0], p = rec[1], d = rec[2]; // colour|scale_bias, position|offset_radius, direction|inv_radius
+						const f32x4 c = rec[0], pq = rec[1], d = rec[2]; // colour|scale_bias, position|offset_radius, direction|inv_radius
 						const float radius = CULL_RADIUS_SCALE * rcp(d.w);
-						const float3_ to_light = f3(p.x, p.y, p.z) - centre;
+						const float3_ to_light = f3(pq.x, pq.y, pq.z) - centre;
 						const float reach = radius + tile_radius;
 						keep = dot(to_light, to_light) <= reach * reach;
 						is_spot = ((a.type_mask[light_index >> 5] >> (light_index & 31u)) & 1u) == 0u;
@@ -343,7 +404,7 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 						const uint32_t sb_bits = __builtin_bit_cast(uint32_t, sb_lane);
 						const float spot_scale = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits & 0xffffu)));
 						const float spot_bias = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits >> 16)));
-						r0 = f32x4{p.x, p.y, p.z, radius * radius};
+						r0 = f32x4{pq.x, pq.y, pq.z, radius * radius};
 						r1q = f32x4{c.x, c.y, c.z, 10.0f * d.w};
 						r2 = f32x4{d.x, d.y, d.z, 0.0f};
 						r3 = f32x4{spot_scale, spot_bias, 0.0f, 0.0f};
@@ -365,33 +426,39 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 				}
 				__builtin_amdgcn_wave_barrier(); // LDS is wave-private: in-order DS execution is the only ordering needed
 
-				// ---- shade: one pixel per lane, lights broadcast from LDS ----
+				// ---- shade: PX pixels per lane, lights broadcast from LDS ----
 				const f32x4 *slot = slots;
 				while (kept != 0ull)
 				{
 					const int src_lane = __builtin_ctzll(kept);
 					kept &= kept - 1ull;
 					const bool spot = ((spots >> src_lane) & 1ull) != 0ull;
-					shade_positional(s, slot[0], slot[1], slot, spot, result);
+					shade_positional<PX>(s, slot[0], slot[1], slot, spot, result);
 					slot += LIGHT_SLOT_BYTES / 16;
 				}
 				__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
 			}
 		}
-		accum = f3(float(_Float16(accum.x + result.x)), float(_Float16(accum.y + result.y)), float(_Float16(accum.z + result.z)));
+#pragma unroll
+		for (int p = 0; p < PX; p++)
+			accum[p] = f3(float(_Float16(accum[p].x + result[p].x)), float(_Float16(accum[p].y + result[p].y)),
+			              float(_Float16(accum[p].z + result[p].z)));
 	}
 
-	if (inside)
+#pragma unroll
+	for (int p = 0; p < PX; p++)
 	{
-		f16x4 o = dst;
-		if (active)
+		if (!inside[p])
+			continue;
+		f16x4 o = dst[p];
+		if (active[p])
 		{
-			o.x = _Float16(accum.x);
-			o.y = _Float16(accum.y);
-			o.z = _Float16(accum.z);
+			o.x = _Float16(accum[p].x);
+			o.y = _Float16(accum[p].y);
+			o.z = _Float16(accum[p].z);
 		}
-		if (active || a.emissive.ptr != a.hdr.ptr)
-			*reinterpret_cast<f16x4 *>(a.hdr.ptr + size_t(y) * a.hdr.pitch + size_t(x) * 8u) = o;
+		if (active[p] || a.emissive.ptr != a.hdr.ptr)
+			*reinterpret_cast<f16x4 *>(a.hdr.ptr + size_t(y) * a.hdr.pitch + size_t(x0 + p) * 8u) = o;
 	}
 }
 
@@ -477,24 +544,34 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	k.row_first = int(row_first);
 	k.row_end = int(row_end);
 	k.block_row0 = int(row_first / LIGHT_TILE);
-	k.blocks_x = int(gr_div_up(W, LIGHT_TILE * LIGHT_WAVES));
+	// Pixels per lane: 2 by default (GR_LIGHTING_PX=1 selects the one-pixel form, kept for A/B measurements).
+	static const int px = []() {
+		const char *env = getenv("GR_LIGHTING_PX");
+		return env && atoi(env) == 1 ? 1 : 2;
+	}();
+	k.blocks_x = int(gr_div_up(W, LIGHT_TILE * px * LIGHT_WAVES));
 	k.num_blocks = k.blocks_x * (int(gr_div_up(row_end, LIGHT_TILE)) - k.block_row0);
 	k.blocks_per_xcd = (k.num_blocks + 7) / 8;
 	dim3 grid(unsigned(k.blocks_per_xcd) * 8u);
-	// Residency cap.  The kernel is VALU-bound and needs no more than ~6 waves per SIMD to hide its latencies, but at full
-	// occupancy it owns every wave slot of the chip for the whole launch and the executor's other streams (the previous
-	// frame's bloom / tonemap, the next frame's cluster build) cannot get a single wave in.  Padding the workgroup's LDS
-	// footprint so that only `max_wgs` workgroups fit per CU leaves the remaining slots to them.
-	static const int max_wgs = []() {
+	// Residency cap.  The kernel is VALU-bound; at full occupancy it owns every wave slot of the chip for the whole launch
+	// and the executor's other streams (the previous frame's bloom / tonemap, the next frame's cluster build) cannot get
+	// a single wave in.  Padding the workgroup's LDS footprint so that only `max_wgs` workgroups fit per CU leaves the
+	// remaining slots to them.  With two pixels per lane the wave has two independent BRDF chains in flight, so four
+	// workgroups (16 waves) per CU already keep the VALU busy.
+	static const int max_wgs = [&]() {
 		const char *env = getenv("GR_LIGHTING_WGS_PER_CU");
-		const int v = env ? atoi(env) : 7;
-		return v >= 1 && v <= 8 ? v : 7;
+		const int fallback = px == 2 ? 4 : 7;
+		const int v = env ? atoi(env) : fallback;
+		return v >= 1 && v <= 8 ? v : fallback;
 	}();
 	const size_t static_lds = sizeof(f32x4) * LIGHT_WAVES * 64 * (LIGHT_SLOT_BYTES / 16);
 	const size_t per_wg = (160u * 1024u / unsigned(max_wgs)) & ~size_t(1023);
 	const size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "lighting"};
-	hipLaunchKernelGGL(k_lighting, grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+	if (px == 2)
+		hipLaunchKernelGGL(k_lighting<2>, grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+	else
+		hipLaunchKernelGGL(k_lighting<1>, grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
