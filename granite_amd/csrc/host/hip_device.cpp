@@ -1,6 +1,7 @@
 #include "hip_device.hpp"
 #include <hip/hip_runtime_api.h>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -141,7 +142,10 @@ Device::Device(int device_index) : index(device_index)
 	int least = 0, greatest = 0;
 	throw_hip(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
 	const int middle = (least + greatest) / 2;
-	const int priorities[int(CommandBuffer::Type::Count)] = {greatest, middle, least}; // Generic, AsyncCompute, Front
+	int priorities[int(CommandBuffer::Type::Count)] = {greatest, middle, least}; // Generic, AsyncCompute, Front
+	if (const char *env = getenv("GRANITE_STREAM_PRIORITIES")) // experiment: three letters from {h, m, l}, e.g. "lmh"
+		for (int i = 0; i < 3 && env[i]; i++)
+			priorities[i] = env[i] == 'h' ? greatest : env[i] == 'm' ? middle : least;
 	for (int i = 0; i < int(CommandBuffer::Type::Count); i++)
 	{
 		hipStream_t stream;

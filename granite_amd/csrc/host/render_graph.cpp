@@ -308,8 +308,10 @@ void RenderGraph::reset()
 	physical_image_attachments.clear();
 	physical_history_image_attachments.clear();
 	physical_image_has_history.clear();
-	physical_images_alternate.clear();
-	physical_buffers_alternate.clear();
+	for (auto &v : physical_images_alternate)
+		v.clear();
+	for (auto &v : physical_buffers_alternate)
+		v.clear();
 	swapchain_physical_index = RenderResource::Unused;
 }
 
@@ -785,12 +787,15 @@ void RenderGraph::setup_attachments(HIP::Device &device_, HIP::ImageView *swapch
 	physical_buffers.resize(count);
 	physical_image_attachments.resize(count);
 	physical_history_image_attachments.resize(count);
-	physical_buffers_alternate.resize(count);
-	physical_images_alternate.resize(count);
+	for (auto &v : physical_buffers_alternate)
+		v.resize(count);
+	for (auto &v : physical_images_alternate)
+		v.resize(count);
 	if (physical_sync.size() != count)
 	{
 		physical_sync.assign(count, {});
-		physical_sync_alternate.assign(count, {});
+		for (auto &v : physical_sync_alternate)
+			v.assign(count, {});
 	}
 	swapchain_attachment = swapchain;
 
@@ -804,11 +809,29 @@ void RenderGraph::setup_attachments(HIP::Device &device_, HIP::ImageView *swapch
 		auto &att = physical_dimensions[i];
 		if (physical_buffer_is_double_buffered(i))
 		{
+			// rotate: current -> newest spare, oldest spare -> current
+			constexpr int spares = HandOverCopies - 1;
 			if (att.buffer_info.size != 0)
-				std::swap(physical_buffers[i], physical_buffers_alternate[i]);
+			{
+				auto current = physical_buffers[i];
+				physical_buffers[i] = physical_buffers_alternate[0][i];
+				for (int k = 0; k + 1 < spares; k++)
+					physical_buffers_alternate[k][i] = physical_buffers_alternate[k + 1][i];
+				physical_buffers_alternate[spares - 1][i] = current;
+			}
 			else
-				std::swap(physical_image_attachments[i], physical_images_alternate[i]);
-			std::swap(physical_sync[i], physical_sync_alternate[i]);
+			{
+				auto current = physical_image_attachments[i];
+				physical_image_attachments[i] = physical_images_alternate[0][i];
+				for (int k = 0; k + 1 < spares; k++)
+					physical_images_alternate[k][i] = physical_images_alternate[k + 1][i];
+				physical_images_alternate[spares - 1][i] = current;
+			}
+			auto current_sync = physical_sync[i];
+			physical_sync[i] = physical_sync_alternate[0][i];
+			for (int k = 0; k + 1 < spares; k++)
+				physical_sync_alternate[k][i] = physical_sync_alternate[k + 1][i];
+			physical_sync_alternate[spares - 1][i] = current_sync;
 		}
 		if (att.buffer_info.size != 0)
 			setup_physical_buffer(device_, i);
@@ -952,7 +975,8 @@ void RenderGraph::build_stream_assignment()
 		uses_async_stream = uses_async_stream || pass_stream[pass_index] != 0;
 	}
 	physical_sync.assign(physical_dimensions.size(), {});
-	physical_sync_alternate.assign(physical_dimensions.size(), {});
+	for (auto &v : physical_sync_alternate)
+		v.assign(physical_dimensions.size(), {});
 
 	// Only passes that touch a resource which is also touched from the other stream take part in event ordering; every
 	// other pass is ordered by its in-order stream alone and records nothing (event / barrier packets are not free:
@@ -1027,7 +1051,8 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 	if (physical_sync.size() != physical_dimensions.size())
 	{
 		physical_sync.assign(physical_dimensions.size(), {});
-		physical_sync_alternate.assign(physical_dimensions.size(), {});
+		for (auto &v : physical_sync_alternate)
+			v.assign(physical_dimensions.size(), {});
 	}
 
 	static const bool sync_debug = getenv("GRANITE_SYNC_DEBUG") != nullptr;
@@ -1038,6 +1063,11 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		if (!event || std::find(waited.begin(), waited.end(), event) != waited.end())
 			return;
 		waited.push_back(event);
+		// The host runs one to three frames ahead of the GPU, so most cross-stream dependencies (anything on work of two
+		// frames ago, usually the cluster build as well) are already complete when they are looked at: no barrier packet
+		// is needed then, and each one costs the command processor several microseconds between two kernels.
+		if (hipEventQuery(static_cast<hipEvent_t>(event)) == hipSuccess)
+			return;
 		if (sync_debug)
 			fprintf(stderr, "[sync] frame %llu pass %s waits %s on %s: pass %s of frame %llu\n", (unsigned long long)this_frame,
 			        current_pass >= 0 ? passes[current_pass]->get_name().c_str() : "blit", kind, physical_dimensions[resource].name.c_str(),
@@ -1047,7 +1077,6 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 	};
 	// RAW / WAW / WAR against accesses recorded on the other stream.
 	auto acquire = [&](hipStream_t stream, int stream_index, const std::vector<unsigned> &reads, const std::vector<unsigned> &writes) {
-		waited.clear();
 		for (unsigned r : reads)
 			if (physical_sync[r].last_write && physical_sync[r].write_stream != stream_index)
 				wait_for(stream, physical_sync[r].last_write, "RAW", r, physical_sync[r].write_pass, physical_sync[r].write_frame);
@@ -1060,8 +1089,11 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 					wait_for(stream, physical_sync[w].last_read[other], "WAR", w, physical_sync[w].read_pass[other], physical_sync[w].read_frame[other]);
 		}
 	};
-	auto release = [&](hipStream_t stream, int stream_index, void *&event, const std::vector<unsigned> &reads,
-	                   const std::vector<unsigned> &writes) {
+	// One event per RUN of consecutive passes on the same stream (not per pass): the accesses of every pass of the run are
+	// published under the run's event, which is recorded once, after the run's last pass and before any pass of another
+	// stream is enqueued.  Fewer packets between kernels: each event record / wait costs the command processor several
+	// microseconds (measured: 23 us of a 283 us frame with one record per pass).
+	auto ensure_event = [&](void *&event) {
 		if (!event)
 		{
 			hipEvent_t e;
@@ -1069,8 +1101,8 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 				throw std::runtime_error("hipEventCreate failed");
 			event = e;
 		}
-		if (hipEventRecord(static_cast<hipEvent_t>(event), stream) != hipSuccess)
-			throw std::runtime_error("hipEventRecord failed");
+	};
+	auto release = [&](int stream_index, void *event, const std::vector<unsigned> &reads, const std::vector<unsigned> &writes) {
 		for (unsigned r : reads)
 		{
 			physical_sync[r].last_read[stream_index] = event;
@@ -1087,6 +1119,21 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		}
 	};
 
+	static const HIP::CommandBuffer::Type stream_types[3] = {HIP::CommandBuffer::Type::Generic, HIP::CommandBuffer::Type::AsyncCompute,
+	                                                          HIP::CommandBuffer::Type::Front};
+	int run_stream = -1;        // stream of the run being enqueued
+	unsigned run_slot = 0;      // index of the run within the frame (event ring row)
+	bool run_published = false; // a pass of the run published accesses under the run's event
+	auto close_run = [&]() {
+		if (run_stream >= 0 && run_published)
+		{
+			void *event = pass_done_event[run_slot * EventRing + ring_slot];
+			if (hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(device_.get_stream(stream_types[run_stream]))) != hipSuccess)
+				throw std::runtime_error("hipEventRecord failed");
+		}
+		run_published = false;
+	};
+
 	for (unsigned pass_index : pass_stack)
 	{
 		auto &pass = *passes[pass_index];
@@ -1094,11 +1141,17 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 			continue;
 		pass.prepare_render_pass(composer);
 
-		static const HIP::CommandBuffer::Type stream_types[3] = {HIP::CommandBuffer::Type::Generic, HIP::CommandBuffer::Type::AsyncCompute,
-		                                                          HIP::CommandBuffer::Type::Front};
 		auto type = stream_types[get_pass_stream(pass_index)];
 		auto stream = static_cast<hipStream_t>(device_.get_stream(type));
-		const bool sync = uses_async_stream && pass_needs_sync[pass_index];
+		if (int(get_pass_stream(pass_index)) != run_stream)
+		{
+			close_run();
+			run_stream = int(get_pass_stream(pass_index));
+			run_slot++; // rows 1 .. (number of runs <= number of passes); row 0 belongs to the final blit
+			waited.clear();
+		}
+		static const bool no_cross_sync = getenv("GRANITE_UNSAFE_NO_CROSS_SYNC") != nullptr; // measurement only: frames are wrong
+		const bool sync = uses_async_stream && pass_needs_sync[pass_index] && !no_cross_sync;
 		current_pass = int(pass_index);
 		if (sync)
 			acquire(stream, int(type), pass_reads_physical[pass_index], pass_writes_physical[pass_index]);
@@ -1136,9 +1189,14 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 			pending_timestamps.push_back(ts);
 		}
 		if (sync)
-			release(stream, int(type), pass_done_event[pass_index * EventRing + ring_slot], pass_reads_physical[pass_index],
+		{
+			ensure_event(pass_done_event[run_slot * EventRing + ring_slot]);
+			release(int(type), pass_done_event[run_slot * EventRing + ring_slot], pass_reads_physical[pass_index],
 			        pass_writes_physical[pass_index]);
+			run_published = true;
+		}
 	}
+	close_run();
 
 	// Backbuffer could not alias the swapchain image: final blit (same geometry/format only).
 	if (swapchain_attachment && swapchain_physical_index == RenderResource::Unused)
@@ -1153,10 +1211,19 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		const bool sync = uses_async_stream && blit_needs_sync;
 		current_pass = -1;
 		if (sync)
+		{
+			waited.clear();
 			acquire(stream, int(HIP::CommandBuffer::Type::Generic), reads, none);
+		}
 		cmd.copy_image(*swapchain_attachment, src);
 		if (sync)
-			release(stream, int(HIP::CommandBuffer::Type::Generic), pass_done_event[passes.size() * EventRing + ring_slot], reads, none);
+		{
+			void *&event = pass_done_event[0 * EventRing + ring_slot]; // row 0 is reserved for the blit
+			ensure_event(event);
+			release(int(HIP::CommandBuffer::Type::Generic), event, reads, none);
+			if (hipEventRecord(static_cast<hipEvent_t>(event), stream) != hipSuccess)
+				throw std::runtime_error("hipEventRecord failed");
+		}
 	}
 
 	device_.next_frame_context();

@@ -510,9 +510,13 @@ private:
 	// Buffers written by a hoisted pass exist twice and alternate per frame (like an image with history), so the
 	// hoisted pass of frame N+1 never waits for frame N's consumers: write-after-read across frames disappears.
 	std::vector<bool> physical_buffer_double;
-	std::vector<HIP::BufferHandle> physical_buffers_alternate;
-	std::vector<HIP::ImageHandle> physical_images_alternate;
-	std::vector<PhysicalSync> physical_sync_alternate;
+	// HandOverCopies - 1 spare copies per resource; every frame the current copy goes to the back of the ring and the oldest
+	// spare becomes current.  Three copies: the producer of frame N+1 writes what the consumers of frame N-2 read last, so
+	// a back-of-frame that runs late (it shares the chip with the next frame's lighting) never stalls the front.
+	enum { HandOverCopies = 3 };
+	std::vector<HIP::BufferHandle> physical_buffers_alternate[HandOverCopies - 1];
+	std::vector<HIP::ImageHandle> physical_images_alternate[HandOverCopies - 1];
+	std::vector<PhysicalSync> physical_sync_alternate[HandOverCopies - 1];
 	void build_stream_assignment();
 	std::unordered_map<std::string, std::pair<uint64_t, double>> timestamp_accum;
 	std::vector<std::string> timestamp_order;

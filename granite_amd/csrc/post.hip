@@ -116,76 +116,70 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_upsample(D
 __device__ __forceinline__ float4 cvt4(f16x4 t) { return make_float4(float(t.x), float(t.y), float(t.z), float(t.w)); }
 __device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 
+// Register budget of the back-of-frame kernels.  They run on the executor's generic stream WHILE the next frame's lighting
+// kernel is resident with 4 waves x 104 VGPRs per SIMD, i.e. they live in the 96 registers per lane that are left: a kernel
+// above that cannot co-reside at all and is served only between lighting workgroups (observed: a 140-VGPR downsample took
+// 72 us instead of 8 us).  Under 56 registers one wave per SIMD always fits, under 48 two.
+#define POST_VGPR_BUDGET /* documentation only: clang (ROCm 7.2) ignores amdgpu_num_vgpr below the 64-register occupancy step; the kernels are written to stay under 56 */
+
 template <bool FEEDBACK>
-__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_downsample_2to1(DevImage in, DevImageRW out, DevImage history,
+__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k_bloom_downsample_2to1(DevImage in, DevImageRW out, DevImage history,
                                                                                       gr_push_bloom_downsample push, uint32_t y_first,
                                                                                       uint32_t y_end)
 {
-	// Two horizontally adjacent outputs per thread: their stencils share 4 of 8 texel columns, fetched as 4 x 16 B per row.
-	const int x0 = (blockIdx.x * POST_BLOCK_X + threadIdx.x) * 2;
+	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
 	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
-	if (uint32_t(x0) >= push.threads[0] || uint32_t(y) >= y_end)
+	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
 		return;
 	const float wt[6] = {0.0625f, 0.1875f, 0.25f, 0.25f, 0.1875f, 0.0625f};
-	const int col0 = 2 * x0 - 2; // first of 8 input columns; even, so 16-byte aligned when inside the image
-	const bool interior = col0 >= 0 && col0 + 7 < in.w;
-	float4 acc0 = make_float4(0, 0, 0, 0), acc1 = make_float4(0, 0, 0, 0);
-#pragma unroll
+	const int col0 = 2 * x - 2; // first of 6 input columns; even, so 16-byte aligned when inside the image
+	const bool interior = col0 >= 0 && col0 + 5 < in.w;
+	float4 acc = make_float4(0, 0, 0, 0);
+	// Row by row (not unrolled across rows): one row of six texels is live at a time.
+#pragma unroll 1
 	for (int r = 0; r < 6; r++)
 	{
 		const int iy = clampi(2 * y - 2 + r, 0, in.h - 1);
 		const uint8_t *row = in.ptr + size_t(iy) * in.pitch;
-		float4 t[8];
+		float4 h;
 		if (interior)
 		{
-#pragma unroll
-			for (int q = 0; q < 4; q++)
-			{
-				const u32x4 v = *reinterpret_cast<const u32x4 *>(row + size_t(col0 + 2 * q) * 8u);
-				t[2 * q] = cvt4(__builtin_bit_cast(f16x4, u32x2{v.x, v.y}));
-				t[2 * q + 1] = cvt4(__builtin_bit_cast(f16x4, u32x2{v.z, v.w}));
-			}
+			const u32x4 v0 = *reinterpret_cast<const u32x4 *>(row + size_t(col0) * 8u);
+			const u32x4 v1 = *reinterpret_cast<const u32x4 *>(row + size_t(col0 + 2) * 8u);
+			const u32x4 v2 = *reinterpret_cast<const u32x4 *>(row + size_t(col0 + 4) * 8u);
+			h = mul4(cvt4(__builtin_bit_cast(f16x4, u32x2{v0.x, v0.y})), wt[0]);
+			h = fma4(cvt4(__builtin_bit_cast(f16x4, u32x2{v0.z, v0.w})), wt[1], h);
+			h = fma4(cvt4(__builtin_bit_cast(f16x4, u32x2{v1.x, v1.y})), wt[2], h);
+			h = fma4(cvt4(__builtin_bit_cast(f16x4, u32x2{v1.z, v1.w})), wt[3], h);
+			h = fma4(cvt4(__builtin_bit_cast(f16x4, u32x2{v2.x, v2.y})), wt[4], h);
+			h = fma4(cvt4(__builtin_bit_cast(f16x4, u32x2{v2.z, v2.w})), wt[5], h);
 		}
 		else
 		{
+			h = mul4(cvt4(*reinterpret_cast<const f16x4 *>(row + size_t(clampi(col0, 0, in.w - 1)) * 8u)), wt[0]);
 #pragma unroll
-			for (int c = 0; c < 8; c++)
-				t[c] = cvt4(*reinterpret_cast<const f16x4 *>(row + size_t(clampi(col0 + c, 0, in.w - 1)) * 8u));
+			for (int c = 1; c < 6; c++)
+				h = fma4(cvt4(*reinterpret_cast<const f16x4 *>(row + size_t(clampi(col0 + c, 0, in.w - 1)) * 8u)), wt[c], h);
 		}
-		float4 h0 = mul4(t[0], wt[0]), h1 = mul4(t[2], wt[0]);
-#pragma unroll
-		for (int c = 1; c < 6; c++)
-		{
-			h0 = fma4(t[c], wt[c], h0);
-			h1 = fma4(t[c + 2], wt[c], h1);
-		}
-		acc0 = fma4(h0, wt[r], acc0);
-		acc1 = fma4(h1, wt[r], acc1);
+		const float wr = r == 0 || r == 5 ? 0.0625f : (r == 1 || r == 4 ? 0.1875f : 0.25f);
+		acc = fma4(h, wr, acc);
 	}
-#pragma unroll
-	for (int k = 0; k < 2; k++)
+	float4 value = acc;
+	if (FEEDBACK)
 	{
-		const int x = x0 + k;
-		if (uint32_t(x) >= push.threads[0])
-			break;
-		float4 value = k ? acc1 : acc0;
-		if (FEEDBACK)
-		{
-			// NearestClamp fetch of the previous frame's level at the same texel (hdr.cpp:160-166).
-			const float u = (float(x) + 0.5f) * push.inv_output_size[0];
-			const float v = (float(y) + 0.5f) * push.inv_output_size[1];
-			const int hx = clampi(int(floorf(u * float(history.w))), 0, history.w - 1);
-			const int hy = clampi(int(floorf(v * float(history.h))), 0, history.h - 1);
-			const float4 h = load_rgba16f(history, hx, hy);
-			const float l = push.lerp;
-			value = make_float4(h.x * (1.0f - l) + value.x * l, h.y * (1.0f - l) + value.y * l, h.z * (1.0f - l) + value.z * l,
-			                    value.w);
-		}
-		store_rgba16f(out, x, y, value);
+		// NearestClamp fetch of the previous frame's level at the same texel (hdr.cpp:160-166).
+		const float u = (float(x) + 0.5f) * push.inv_output_size[0];
+		const float v = (float(y) + 0.5f) * push.inv_output_size[1];
+		const int hx = clampi(int(floorf(u * float(history.w))), 0, history.w - 1);
+		const int hy = clampi(int(floorf(v * float(history.h))), 0, history.h - 1);
+		const float4 hv = load_rgba16f(history, hx, hy);
+		const float l = push.lerp;
+		value = make_float4(hv.x * (1.0f - l) + value.x * l, hv.y * (1.0f - l) + value.y * l, hv.z * (1.0f - l) + value.z * l, value.w);
 	}
+	store_rgba16f(out, x, y, value);
 }
 
-__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_upsample_1to2(DevImage in, DevImageRW out,
+__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k_bloom_upsample_1to2(DevImage in, DevImageRW out,
                                                                                     gr_push_bloom_upsample push, uint32_t y_first,
                                                                                     uint32_t y_end)
 {
@@ -465,12 +459,11 @@ int gr_bloom_downsample_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, 
 	                   push->inv_input_size[1] == 1.0f / float(in->height);
 	if (exact)
 	{
-		dim3 grid2(gr_div_up(gr_div_up(push->threads[0], 2u), POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
 		if (history)
-			hipLaunchKernelGGL(k_bloom_downsample_2to1<true>, grid2, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out),
+			hipLaunchKernelGGL(k_bloom_downsample_2to1<true>, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out),
 			                   to_dev(history), *push, span.first, span.end);
 		else
-			hipLaunchKernelGGL(k_bloom_downsample_2to1<false>, grid2, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out),
+			hipLaunchKernelGGL(k_bloom_downsample_2to1<false>, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out),
 			                   DevImage{}, *push, span.first, span.end);
 	}
 	else if (history)
