@@ -378,41 +378,97 @@ __global__ __launch_bounds__(64) void k_cluster_binning(const void *transforms, 
 
 // ---- z_range.comp ----------------------------------------------------------------------------------------------------------
 // out[z] = (first light whose [lo,hi] slice interval covers z, last such light); empty = (0xffffffff, 0).
-// 64 slices per workgroup x 16 sub-threads per slice; each sub-thread scans a strided subset of the LDS-staged light
-// intervals for min/max covering index, then a 16-lane shuffle reduction (lanes of one slice are adjacent).
-constexpr int ZR_SLICES = 64;
-constexpr int ZR_SUB = 16;
-__global__ __launch_bounds__(ZR_SLICES *ZR_SUB) void k_cluster_z_range(const uint2 *light_ranges, uint2 *out, gr_push_z_range push)
+// The reference scans every interval for every slice (O(slices x lights)).  Same result with pruning: intervals are staged in
+// LDS together with the union interval of each group of 64 consecutive lights; for a slice, one ballot over the group
+// bounds says which groups can contain a covering light, and the first (last) covering light is found by walking those
+// groups from the front (back) with one ballot per group -- lights arrive sorted by depth, so it is almost always the
+// first group tried.  Exact for any input order (the group bounds only prune), integer-only.
+constexpr int ZR_THREADS = 256;
+constexpr int ZR_SLICES_PER_WAVE = 4;
+constexpr int ZR_SLICES = (ZR_THREADS / 64) * ZR_SLICES_PER_WAVE;
+
+__device__ __forceinline__ uint32_t zr_wave_min(uint32_t v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v = min(v, uint32_t(__shfl_xor(int(v), off, 64)));
+	return v;
+}
+__device__ __forceinline__ uint32_t zr_wave_max(uint32_t v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v = max(v, uint32_t(__shfl_xor(int(v), off, 64)));
+	return v;
+}
+
+__global__ __launch_bounds__(ZR_THREADS) void k_cluster_z_range(const uint2 *light_ranges, uint2 *out, gr_push_z_range push)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	uint2 *ranges = reinterpret_cast<uint2 *>(smem);
-	for (uint32_t i = threadIdx.x; i < push.num_volumes; i += ZR_SLICES * ZR_SUB)
-		ranges[i] = light_ranges[i];
+	const uint32_t num_groups = (push.num_volumes + 63u) / 64u;
+	uint2 *ranges = reinterpret_cast<uint2 *>(smem);        // num_groups * 64 entries, padded with empty intervals
+	uint2 *group_bounds = ranges + size_t(num_groups) * 64u; // num_groups entries
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6u;
+
+	for (uint32_t g = wave; g < num_groups; g += ZR_THREADS / 64)
+	{
+		const uint32_t i = g * 64u + lane;
+		const uint2 r = i < push.num_volumes ? light_ranges[i] : make_uint2(0xffffffffu, 0u);
+		ranges[i] = r;
+		// an empty interval (lo > hi) must not widen the group's bounds
+		const bool valid = r.x <= r.y;
+		const uint32_t glo = zr_wave_min(valid ? r.x : 0xffffffffu), ghi = zr_wave_max(valid ? r.y : 0u);
+		if (lane == 0)
+			group_bounds[g] = make_uint2(glo, ghi);
+	}
 	__syncthreads();
 
-	const uint32_t sub = threadIdx.x & (ZR_SUB - 1);
-	const uint32_t z = blockIdx.x * ZR_SLICES + (threadIdx.x / ZR_SUB);
-	uint32_t lo = 0xffffffffu, hi = 0u;
-	bool any = false;
-	for (uint32_t i = sub; i < push.num_volumes; i += ZR_SUB)
+	for (uint32_t s = 0; s < ZR_SLICES_PER_WAVE; s++)
 	{
-		const uint2 r = ranges[i];
-		if (z >= r.x && z <= r.y)
+		const uint32_t z = blockIdx.x * ZR_SLICES + wave * ZR_SLICES_PER_WAVE + s;
+		if (z >= push.num_ranges)
+			break;
+		uint32_t first = 0xffffffffu, last = 0u;
+		// up to 64 groups per round (4096 lights = one round)
+		for (uint32_t base = 0; base < num_groups; base += 64u)
 		{
-			lo = min(lo, i);
-			hi = max(hi, i);
-			any = true;
+			const uint32_t g = base + lane;
+			const uint2 gb = g < num_groups ? group_bounds[g] : make_uint2(0xffffffffu, 0u);
+			const uint64_t candidates = __ballot(gb.x <= z && z <= gb.y);
+			if (first == 0xffffffffu)
+			{
+				uint64_t walk = candidates;
+				while (walk != 0ull)
+				{
+					const uint32_t gg = base + uint32_t(__builtin_ctzll(walk));
+					walk &= walk - 1ull;
+					const uint2 r = ranges[gg * 64u + lane];
+					const uint64_t m = __ballot(r.x <= z && z <= r.y);
+					if (m != 0ull)
+					{
+						first = gg * 64u + uint32_t(__builtin_ctzll(m));
+						break;
+					}
+				}
+			}
+			uint64_t walk = candidates;
+			while (walk != 0ull)
+			{
+				const uint32_t top = 63u - uint32_t(__builtin_clzll(walk));
+				walk &= ~(1ull << top);
+				const uint32_t gg = base + top;
+				const uint2 r = ranges[gg * 64u + lane];
+				const uint64_t m = __ballot(r.x <= z && z <= r.y);
+				if (m != 0ull)
+				{
+					last = max(last, gg * 64u + 63u - uint32_t(__builtin_clzll(m)));
+					break;
+				}
+			}
 		}
+		if (lane == 0)
+			out[z] = make_uint2(first, last);
 	}
-	(void)any;
-#pragma unroll
-	for (int off = ZR_SUB / 2; off > 0; off >>= 1)
-	{
-		lo = min(lo, uint32_t(__shfl_xor(int(lo), off, 64)));
-		hi = max(hi, uint32_t(__shfl_xor(int(hi), off, 64)));
-	}
-	if (sub == 0 && z < push.num_ranges)
-		out[z] = make_uint2(lo, hi);
 }
 } // namespace
 
@@ -480,8 +536,9 @@ int gr_cluster_z_range(gr_ctx *ctx, gr_stream stream, const uint32_t *light_rang
 	GR_CHECK_ARG(ctx, push->num_volumes >= 1 && push->num_volumes <= GR_MAX_LIGHTS_BINDLESS);
 	GR_CHECK_ARG(ctx, push->num_ranges > 0);
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "cluster_z_range"};
-	hipLaunchKernelGGL(k_cluster_z_range, dim3(gr_div_up(push->num_ranges, ZR_SLICES)), dim3(ZR_SLICES * ZR_SUB),
-	                   push->num_volumes * sizeof(uint2), gr_to_stream(stream), reinterpret_cast<const uint2 *>(light_ranges),
+	const uint32_t num_groups = (push->num_volumes + 63u) / 64u;
+	hipLaunchKernelGGL(k_cluster_z_range, dim3(gr_div_up(push->num_ranges, ZR_SLICES)), dim3(ZR_THREADS),
+	                   size_t(num_groups) * 65u * sizeof(uint2), gr_to_stream(stream), reinterpret_cast<const uint2 *>(light_ranges),
 	                   reinterpret_cast<uint2 *>(out), *push);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
