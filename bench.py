@@ -200,7 +200,7 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
                     "avg_launch_us": dom_avg_s * 1e6, "launches": dom_count}
         # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes of this very
-        # command, corrected as MI355X_MICROARCH.md prescribes; scripts/pmc_passes.sh -> profiles/pmc_traffic.json).  Only
+        # command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_passes.sh -> profiles/pmc_traffic.json).  Only
         # quoted for the workload it was collected on.
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 PMC passes over a short bench.py run (separate passes: SQ issue counters, FETCH_SIZE, WRITE_SIZE), as
-# MI355X_MICROARCH.md's HBM/rocprofv3 section prescribes.  Usage (on the GPU box): scripts/pmc_passes.sh <tag> [bench args]
+# MI355X_MICROARCH.md's HBM/rocprofv3 section prescribes.  Usage (on the GPU box): tools/pmc_passes.sh <tag> [bench args]
 set -u
 TAG=${1:-pmc}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -17,5 +17,5 @@ run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACT
 run sq2 SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-python "$ROOT/scripts/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
+python "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
