@@ -120,32 +120,57 @@ def main():
 
     from granite_amd import app as gapp, multigpu, synth
 
-    width, height, num_lights, desc = WORKLOADS[args.workload]
-    workload_name = args.workload
-    if world > 1:
-        # Weak scaling: one base frame's worth of pixels per rank, the frame tiled into `world` row bands
-        # (7680x4320 at 4 ranks is BASELINE config 5's frame); same camera, same 4096 lights, same cluster grid.
-        width, height = multigpu.weak_scaled_frame(world, (width, height))
-        workload_name = f"{args.workload}_x{world}_rowbands_{width}x{height}"
-        desc = f"{width}x{height} tiled into {world} row bands (one per GPU), {num_lights} clustered lights, bloom pyramid + luminance + tonemap"
-    cam = synth.Camera(width, height)
-    gbuf = synth.make_gbuffer(cam)
-    descs = synth.make_lights(cam, num_lights, spot_fraction=0.25 if num_lights > 256 else 0.0)
+    base_width, base_height, num_lights, base_desc = WORKLOADS[args.workload]
 
-    application = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True,
-                                   compute_post=True, strip_index=rank if world > 1 else 0, strip_count=world)
-    application.set_render_parameters(cam.render_params())
-    application.set_lights(descs)
-    application.upload_gbuffer(gbuf)
-    if world > 1:
-        ids = [gapp.Application.comm_create_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        application.comm_init(ids[0], rank, world)
+    def build(bands: bool):
+        """One frame tiled into `world` row bands (bands=True) or this rank's own base frame (single GPU / fallback)."""
+        width, height, desc, name = base_width, base_height, base_desc, args.workload
+        if bands:
+            # Weak scaling: one base frame's worth of pixels per rank, the frame tiled into `world` row bands
+            # (7680x4320 at 4 ranks is BASELINE config 5's frame); same camera, same 4096 lights, same cluster grid.
+            width, height = multigpu.weak_scaled_frame(world, (width, height))
+            name = f"{args.workload}_x{world}_rowbands_{width}x{height}"
+            desc = f"{width}x{height} tiled into {world} row bands (one per GPU), {num_lights} clustered lights, bloom pyramid + luminance + tonemap"
+        cam = synth.Camera(width, height)
+        gbuf = synth.make_gbuffer(cam)
+        descs = synth.make_lights(cam, num_lights, spot_fraction=0.25 if num_lights > 256 else 0.0)
+        app = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True,
+                               compute_post=True, strip_index=rank if bands else 0, strip_count=world if bands else 1)
+        app.set_render_parameters(cam.render_params())
+        app.set_lights(descs)
+        app.upload_gbuffer(gbuf)
+        if bands:
+            ids = [gapp.Application.comm_create_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            app.comm_init(ids[0], rank, world)
+        # Set-up, not a step: bake the graph and let the executor allocate what it creates lazily (physical images, the
+        # spare copies of hand-over resources, its event rings) so that no hipMalloc lands in a counted frame.  With bands
+        # this also runs the first all-gathers.
+        app.render_frames(4, sync=True)
+        return app, cam, gbuf, descs, width, height, desc, name
+
+    bands = world > 1 and os.environ.get("GRANITE_BENCH_MULTI", "bands") != "replicas"
+    fallback_reason = None
+    if bands:
+        # Every rank must end up in the same mode: agree on success through the control plane.
+        try:
+            built = build(True)
+            ok = 1
+        except Exception as e:  # noqa: BLE001 - any failure of the RCCL transport or the band set-up
+            built, ok, fallback_reason = None, 0, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if built is not None:
+                built[0].close()
+            bands = False
+            fallback_reason = fallback_reason or "another rank failed to set up the row-band transport"
+            built = build(False)
+    else:
+        built = build(False)
+    application, cam, gbuf, descs, width, height, desc, workload_name = built
     plan = application.strip_plan()
     kctx = application.kernel_context()
-    # Set-up, not a step: bake the graph and let the executor allocate what it creates lazily (physical images, the
-    # second copies of double-buffered hand-over resources, its event rings) so that no hipMalloc lands in a counted frame.
-    application.render_frames(4, sync=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -183,7 +208,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    pixels_per_step = width * height  # one frame per step; at N > 1 its row bands are spread over the ranks
+    # one frame per step: at N > 1 its row bands are spread over the ranks; in the replicas fallback every rank renders its own
+    pixels_per_step = width * height * (1 if bands or world == 1 else world)
     value = pixels_per_step * args.steps / elapsed / 1e6
 
     dom_count, dom_ms = timed.get(dominant, (0, 0.0))
@@ -230,7 +256,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": workload_name, "description": desc, "width": width, "height": height, "lights": num_lights,
                    "cluster_grid": list(synth.CLUSTER_RESOLUTION),
-                   "parallelism": f"{world} row bands, RCCL all-gather of the 1/8 bloom level and of the tonemapped bands" if world > 1 else "single",
+                   "parallelism": ("single" if world == 1 else
+                                   f"{world} row bands, RCCL all-gather of the 1/8 bloom level and of the tonemapped bands" if bands else
+                                   f"{world} independent replicas (row-band set-up failed: {fallback_reason})"),
                    "hdr_format": "R16G16B16A16_SFLOAT", "seed": synth.SEED},
         "roofline": roofline,
         "chain": {"algorithmic_GBps": chain_gbs, "frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS,
