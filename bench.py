@@ -103,6 +103,8 @@ def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "GRANITE_BENCH_DEVICE" in os.environ:  # test hook: several ranks on one GPU (exercises the replicas fallback)
+        local_rank = int(os.environ["GRANITE_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
