@@ -133,6 +133,15 @@ class LightingArgs(C.Structure):
                 ("flags", C.c_uint32), ("rows", C.c_uint32 * 2)]
 
 
+class Rows(C.Structure):
+    """gr_rows: render area of one launch, output rows [first, first + count); count == 0 = whole image."""
+    _fields_ = [("first", C.c_uint32), ("count", C.c_uint32)]
+
+
+class UploadRange(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src_pinned", C.c_void_p), ("bytes", C.c_size_t)]
+
+
 class PushFxaa(C.Structure):
     _fields_ = [("inv_resolution", C.c_float * 2)]
 
@@ -188,6 +197,13 @@ def load_library() -> C.CDLL:
         "gr_bloom_upsample": (C.c_int, [vp, vp, P(Image), P(Image), P(PushBloomUpsample)]),
         "gr_luminance": (C.c_int, [vp, vp, P(Image), vp, P(PushLuminance)]),
         "gr_tonemap": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushTonemap)]),
+        "gr_bloom_threshold_rows": (C.c_int, [vp, vp, P(Image), P(Image), vp, P(PushBloomThreshold), P(Rows)]),
+        "gr_bloom_downsample_rows": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushBloomDownsample), P(Rows)]),
+        "gr_bloom_upsample_rows": (C.c_int, [vp, vp, P(Image), P(Image), P(PushBloomUpsample), P(Rows)]),
+        "gr_tonemap_rows": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushTonemap), P(Rows)]),
+        "gr_upload_batch": (C.c_int, [vp, vp, P(UploadRange), C.c_uint32]),
+        "gr_alloc_host": (C.c_int, [vp, C.c_size_t, P(vp)]),
+        "gr_free_host": (C.c_int, [vp, vp]),
         "gr_cluster_spot_transform": (C.c_int, [vp, vp, vp, vp, P(PushSpotTransform)]),
         "gr_cluster_setup": (C.c_int, [vp, vp, vp, vp, vp, P(ClusterParams), P(PushClusterSetup)]),
         "gr_cluster_binning": (C.c_int, [vp, vp, vp, vp, vp, P(ClusterParams)]),
@@ -210,8 +226,9 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "gr_abi_version", "gr_create", "gr_destroy", "gr_last_error", "gr_sync", "gr_alloc", "gr_free", "gr_upload",
-    "gr_download", "gr_copy", "gr_fill_zero", "gr_upload_batch", "gr_timing_enable", "gr_timing_set_filter", "gr_timing_reset", "gr_timing_query",
+    "gr_download", "gr_copy", "gr_fill_zero", "gr_upload_batch", "gr_alloc_host", "gr_free_host", "gr_timing_enable", "gr_timing_set_filter", "gr_timing_reset", "gr_timing_query",
     "gr_bloom_threshold", "gr_bloom_downsample", "gr_bloom_upsample", "gr_luminance", "gr_tonemap",
+    "gr_bloom_threshold_rows", "gr_bloom_downsample_rows", "gr_bloom_upsample_rows", "gr_tonemap_rows",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
     "gr_smaa_set_luts", "gr_fxaa", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
 ]
@@ -328,30 +345,34 @@ class Context:
         return {arr[i].name.decode(): (int(arr[i].count), float(arr[i].total_ms)) for i in range(n)}
 
     # ---- post chain -------------------------------------------------------------------------------------------
-    def bloom_threshold(self, hdr: DeviceImage, out: DeviceImage, lum_ptr=None, stream=None):
+    @staticmethod
+    def _rows(rows):
+        return None if rows is None else C.byref(Rows(int(rows[0]), int(rows[1])))
+
+    def bloom_threshold(self, hdr: DeviceImage, out: DeviceImage, lum_ptr=None, stream=None, rows=None):
         push = PushBloomThreshold((out.width, out.height), (1.0 / out.width, 1.0 / out.height))
-        self.check(self.lib.gr_bloom_threshold(self.handle, stream, hdr.desc, out.desc, lum_ptr, push))
+        self.check(self.lib.gr_bloom_threshold_rows(self.handle, stream, hdr.desc, out.desc, lum_ptr, push, self._rows(rows)))
 
     def bloom_downsample(self, src: DeviceImage, out: DeviceImage, history: Optional[DeviceImage] = None, lerp: float = 0.0,
-                         stream=None):
+                         stream=None, rows=None):
         push = PushBloomDownsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height),
                                    (1.0 / src.width, 1.0 / src.height), lerp)
-        self.check(self.lib.gr_bloom_downsample(self.handle, stream, src.desc, out.desc,
-                                                history.desc if history is not None else None, push))
+        self.check(self.lib.gr_bloom_downsample_rows(self.handle, stream, src.desc, out.desc,
+                                                     history.desc if history is not None else None, push, self._rows(rows)))
 
-    def bloom_upsample(self, src: DeviceImage, out: DeviceImage, stream=None):
+    def bloom_upsample(self, src: DeviceImage, out: DeviceImage, stream=None, rows=None):
         push = PushBloomUpsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height),
                                  (1.0 / src.width, 1.0 / src.height))
-        self.check(self.lib.gr_bloom_upsample(self.handle, stream, src.desc, out.desc, push))
+        self.check(self.lib.gr_bloom_upsample_rows(self.handle, stream, src.desc, out.desc, push, self._rows(rows)))
 
     def luminance(self, d3: DeviceImage, lum_ptr, lerp: float, min_loglum: float = -3.0, max_loglum: float = 2.0, stream=None):
         push = PushLuminance((d3.width // 2, d3.height // 2), lerp, min_loglum, max_loglum)
         self.check(self.lib.gr_luminance(self.handle, stream, d3.desc, lum_ptr, push))
 
     def tonemap(self, hdr: DeviceImage, bloom: DeviceImage, out: DeviceImage, lum_ptr=None, dynamic_exposure: float = 1.0,
-                stream=None):
+                stream=None, rows=None):
         push = PushTonemap(dynamic_exposure)
-        self.check(self.lib.gr_tonemap(self.handle, stream, hdr.desc, bloom.desc, out.desc, lum_ptr, push))
+        self.check(self.lib.gr_tonemap_rows(self.handle, stream, hdr.desc, bloom.desc, out.desc, lum_ptr, push, self._rows(rows)))
 
 
     # ---- anti-aliasing --------------------------------------------------------------------------------------------

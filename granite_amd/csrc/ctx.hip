@@ -172,6 +172,26 @@ int gr_upload_batch(gr_ctx *ctx, gr_stream stream, const gr_upload_range *ranges
 	return GR_OK;
 }
 
+int gr_alloc_host(gr_ctx *ctx, size_t bytes, void **hptr)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, hptr != nullptr && bytes != 0);
+	hipError_t err = hipHostMalloc(hptr, bytes, hipHostMallocDefault);
+	if (err != hipSuccess)
+		return ctx->fail(GR_ERR_OUT_OF_MEMORY, "gr_alloc_host: hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+	return GR_OK;
+}
+
+int gr_free_host(gr_ctx *ctx, void *hptr)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	if (hptr)
+		GR_CHECK_HIP(ctx, hipHostFree(hptr));
+	return GR_OK;
+}
+
 int gr_download(gr_ctx *ctx, gr_stream stream, void *dst_host, const void *src, size_t bytes)
 {
 	if (!ctx)

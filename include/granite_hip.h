@@ -86,6 +86,9 @@ typedef struct gr_upload_range
 	size_t bytes;
 } gr_upload_range;
 int gr_upload_batch(gr_ctx *ctx, gr_stream stream, const gr_upload_range *ranges, uint32_t count);
+/* Pinned, device-mapped host memory for gr_upload_batch sources (hipHostMalloc / hipHostFree). */
+int gr_alloc_host(gr_ctx *ctx, size_t bytes, void **hptr);
+int gr_free_host(gr_ctx *ctx, void *hptr);
 int gr_copy(gr_ctx *ctx, gr_stream stream, void *dst, const void *src, size_t bytes);
 int gr_fill_zero(gr_ctx *ctx, gr_stream stream, void *dst, size_t bytes);
 

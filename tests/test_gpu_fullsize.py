@@ -79,3 +79,67 @@ def test_4k_frames_are_reproducible():
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     assert len(np.unique(outs[0][0][::16, ::16, :3])) > 8  # a real (if bright: exposure has not adapted in 8 frames) image
+
+
+def test_4k_post_launchers_in_row_bands_equal_whole_image(gr):
+    """Render areas of the post launchers (gr_*_rows): threshold, 2:1 and generic downsample, 1:2 upsample and tonemap run
+    in uneven row bands must write the very bytes of the whole-image launch, at 3840x2160 (all levels exact 2x) and at an
+    odd size (generic tent path)."""
+    from test_gpu_post import F16
+    for w, h in ((W, H), (1366, 769)):
+        hdr_bits = synth.make_hdr(w, h)
+        hdr = capi.DeviceImage(gr, w, h, F16).upload(hdr_bits)
+        sz = [orc_level(w, h, s) for s in (0.5, 0.25, 0.125)]
+
+        def bands(height):
+            cuts = [0, 1, height // 3 + 1, (2 * height) // 3 - 2, height]
+            return [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(4) if cuts[i + 1] > cuts[i]]
+
+        def both(launch, out_w, out_h, fmt=F16):
+            whole = capi.DeviceImage(gr, out_w, out_h, fmt)
+            launch(whole, None)
+            split = capi.DeviceImage(gr, out_w, out_h, fmt)
+            for b in bands(out_h):
+                launch(split, b)
+            gr.sync()
+            np.testing.assert_array_equal(split.download(), whole.download())
+            return whole
+
+        t = both(lambda out, rows: gr.bloom_threshold(hdr, out, None, rows=rows), *sz[0])
+        d0 = both(lambda out, rows: gr.bloom_downsample(t, out, rows=rows), *sz[1])
+        d1 = both(lambda out, rows: gr.bloom_downsample(d0, out, rows=rows), *sz[2])
+        u0 = both(lambda out, rows: gr.bloom_upsample(d1, out, rows=rows), *sz[1])
+        both(lambda out, rows: gr.tonemap(hdr, u0, out, None, rows=rows), w, h, capi.FORMAT_R8G8B8A8_SRGB)
+
+
+def orc_level(w, h, scale):
+    from oracle import oracle as orc
+    return orc.level_size(w, h, scale)
+
+
+def test_upload_batch_writes_every_range(gr):
+    """gr_upload_batch: several pinned-host -> HBM ranges in one kernel (aligned and unaligned to 16 bytes, odd dword
+    counts) land byte for byte; other bytes of the destination stay untouched."""
+    import ctypes as C
+
+    lib = gr.lib
+    rng = np.random.default_rng(7)
+    sizes = [196608, 4 * 1021, 512, 32768, 4]
+    dst = capi.DeviceBuffer(gr, sum(sizes) + 64 * len(sizes))
+    dst.upload(np.full(dst.nbytes, 0xEE, np.uint8))
+    ranges = (capi.UploadRange * len(sizes))()
+    keep, expect, off = [], np.full(dst.nbytes, 0xEE, np.uint8), 4
+    for i, n in enumerate(sizes):
+        hptr = C.c_void_p()
+        gr.check(lib.gr_alloc_host(gr.handle, n, C.byref(hptr)))
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        C.memmove(hptr.value, data.ctypes.data, n)
+        keep.append(hptr)
+        ranges[i] = capi.UploadRange(dst.ptr + off, hptr.value, n)
+        expect[off:off + n] = data
+        off += n + 60  # keeps dword alignment, breaks 16-byte alignment
+    gr.check(lib.gr_upload_batch(gr.handle, None, ranges, len(sizes)))
+    gr.sync()
+    np.testing.assert_array_equal(dst.download(np.uint8), expect)
+    for hptr in keep:
+        gr.check(lib.gr_free_host(gr.handle, hptr))
