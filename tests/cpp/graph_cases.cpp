@@ -1,0 +1,168 @@
+// CPU-only exercise of the restated RenderGraph declaration / bake API (no device): prints one JSON object per case on
+// stdout, consumed by tests/test_render_graph_cases_cpu.py.  The first case declares the topology of the reference's
+// tests/render_graph_sandbox.cpp (depth -> first -> async compute -> final, backbuffer "back") with this repo's own code.
+#include "../../granite_amd/csrc/host/render_graph.hpp"
+#include <cstdio>
+#include <functional>
+#include <string>
+
+using namespace Granite;
+
+static ResourceDimensions backbuffer(unsigned w, unsigned h)
+{
+	ResourceDimensions dim;
+	dim.width = w;
+	dim.height = h;
+	dim.format = VK_FORMAT_R8G8B8A8_SRGB;
+	return dim;
+}
+
+static void print_case(const char *name, const std::string &json)
+{
+	printf("{\"case\":\"%s\",\"graph\":%s}\n", name, json.c_str());
+}
+
+static void print_error(const char *name, const std::function<void()> &fn)
+{
+	try
+	{
+		fn();
+		printf("{\"case\":\"%s\",\"error\":null}\n", name);
+	}
+	catch (const std::logic_error &e)
+	{
+		printf("{\"case\":\"%s\",\"error\":\"%s\"}\n", name, e.what());
+	}
+}
+
+int main()
+{
+	{
+		RenderGraph graph;
+		graph.set_backbuffer_dimensions(backbuffer(1920, 1080));
+		AttachmentInfo back; // swapchain relative, swapchain format
+		AttachmentInfo im;
+		im.format = VK_FORMAT_R8G8B8A8_UNORM;
+		im.size_x = 1280.0f;
+		im.size_y = 720.0f;
+		im.size_class = SizeClass::Absolute;
+
+		auto &depth = graph.add_pass("depth", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		depth.add_color_output("depth", back);
+		auto &graphics = graph.add_pass("first", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		auto &first = graphics.add_color_output("first", back);
+		graphics.add_texture_input("depth");
+		auto &compute = graph.add_pass("compute", RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT);
+		auto &image = compute.add_storage_texture_output("image", im);
+		compute.add_texture_input("first");
+		auto &swap = graph.add_pass("final", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		swap.add_color_output("back", back);
+		swap.add_texture_input("image");
+		swap.add_texture_input("first");
+		// add_pass is idempotent by name; resource references stay valid
+		if (&graph.add_pass("first", RENDER_GRAPH_QUEUE_GRAPHICS_BIT) != &graphics)
+			return 2;
+		if (&graph.get_texture_resource("first") != &first || &graph.get_texture_resource("image") != &image)
+			return 3;
+		graph.set_backbuffer_source("back");
+		graph.bake();
+		print_case("sandbox", graph.dump_json());
+	}
+	{
+		// A pass nobody needs is culled; an unused branch does not survive the back-to-front walk.
+		RenderGraph graph;
+		graph.set_backbuffer_dimensions(backbuffer(640, 360));
+		AttachmentInfo info;
+		auto &a = graph.add_pass("a", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		a.add_color_output("a-out", info);
+		auto &dead = graph.add_pass("dead", RENDER_GRAPH_QUEUE_COMPUTE_BIT);
+		AttachmentInfo half;
+		half.size_x = half.size_y = 0.5f;
+		half.format = VK_FORMAT_R16G16B16A16_SFLOAT;
+		dead.add_storage_texture_output("dead-out", half);
+		dead.add_texture_input("a-out");
+		auto &b = graph.add_pass("b", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		b.add_color_output("b-out", info);
+		b.add_texture_input("a-out");
+		graph.set_backbuffer_source("b-out");
+		graph.bake();
+		print_case("culling", graph.dump_json());
+	}
+	{
+		// Read-modify-write chain: both names share one physical image; InputRelative sizes follow ceil(input * scale).
+		RenderGraph graph;
+		graph.set_backbuffer_dimensions(backbuffer(1001, 333));
+		AttachmentInfo hdr;
+		hdr.format = VK_FORMAT_R16G16B16A16_SFLOAT;
+		auto &fill = graph.add_pass("fill", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		fill.add_color_output("base", hdr);
+		auto &add = graph.add_pass("add", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		add.add_color_output("sum", hdr, "base");
+		AttachmentInfo quarter;
+		quarter.format = VK_FORMAT_R16G16B16A16_SFLOAT;
+		quarter.size_class = SizeClass::InputRelative;
+		quarter.size_relative_name = "sum";
+		quarter.size_x = quarter.size_y = 0.25f;
+		auto &down = graph.add_pass("down", RENDER_GRAPH_QUEUE_COMPUTE_BIT);
+		down.add_storage_texture_output("small", quarter);
+		down.add_texture_input("sum");
+		AttachmentInfo out;
+		auto &present = graph.add_pass("present", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		present.add_color_output("screen", out);
+		present.add_texture_input("small");
+		present.add_texture_input("sum");
+		graph.set_backbuffer_source("screen");
+		graph.bake();
+		print_case("rmw", graph.dump_json());
+	}
+	print_error("no-writer", []() {
+		RenderGraph graph;
+		graph.set_backbuffer_dimensions(backbuffer(64, 64));
+		auto &p = graph.add_pass("p", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		AttachmentInfo info;
+		p.add_color_output("out", info);
+		p.add_texture_input("never-written");
+		graph.set_backbuffer_source("out");
+		graph.bake();
+	});
+	print_error("missing-backbuffer", []() {
+		RenderGraph graph;
+		graph.set_backbuffer_dimensions(backbuffer(64, 64));
+		auto &p = graph.add_pass("p", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		AttachmentInfo info;
+		p.add_color_output("out", info);
+		graph.set_backbuffer_source("nope");
+		graph.bake();
+	});
+	print_error("cycle", []() {
+		RenderGraph graph;
+		graph.set_backbuffer_dimensions(backbuffer(64, 64));
+		AttachmentInfo info;
+		auto &a = graph.add_pass("a", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		a.add_color_output("a-out", info);
+		a.add_texture_input("b-out");
+		auto &b = graph.add_pass("b", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		b.add_color_output("b-out", info);
+		b.add_texture_input("a-out");
+		graph.set_backbuffer_source("b-out");
+		graph.bake();
+	});
+	print_error("rmw-size-mismatch", []() {
+		RenderGraph graph;
+		graph.set_backbuffer_dimensions(backbuffer(64, 64));
+		AttachmentInfo full, half;
+		half.size_x = half.size_y = 0.5f;
+		auto &a = graph.add_pass("a", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		a.add_color_output("a-out", half);
+		auto &b = graph.add_pass("b", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		b.add_color_output("b-out", full, "a-out");
+		graph.set_backbuffer_source("b-out");
+		graph.bake();
+	});
+	print_error("texture-as-buffer", []() {
+		RenderGraph graph;
+		graph.get_texture_resource("x");
+		graph.get_buffer_resource("x");
+	});
+	return 0;
+}
