@@ -25,7 +25,8 @@ class Config(C.Structure):
                 ("post_aa", C.c_int32), ("pre_aa", C.c_int32), ("rmw_emissive", C.c_int32),
                 ("cluster_res", C.c_uint32 * 3), ("frame_time", C.c_float), ("directional_color", C.c_float * 3),
                 ("directional_direction", C.c_float * 3), ("enable_timestamps", C.c_int32),
-                ("strip_index", C.c_uint32), ("strip_count", C.c_uint32)]
+                ("strip_index", C.c_uint32), ("strip_count", C.c_uint32),
+                ("disable_image_aliasing", C.c_int32)]
 
 
 # void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream)
@@ -46,7 +47,7 @@ EXPORTED_SYMBOLS = [
     "gra_get_render_parameters", "gra_set_lights", "gra_upload_gbuffer", "gra_render_frames", "gra_sync",
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
-    "gra_set_smaa_luts", "gra_get_host_stats", "gra_set_exchange_callback", "gra_get_strip_plan",
+    "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_allocated_bytes", "gra_set_exchange_callback", "gra_get_strip_plan",
     "gra_comm_create_unique_id", "gra_comm_init",
 ]
 
@@ -85,6 +86,7 @@ def load_library() -> C.CDLL:
         "gra_get_taa_reprojection": (C.c_int, [vp, vp]),
         "gra_set_smaa_luts": (C.c_int, [vp, vp, vp]),
         "gra_get_host_stats": (C.c_int, [vp, vp]),
+        "gra_get_allocated_bytes": (C.c_int, [vp, vp]),
         "gra_set_exchange_callback": (C.c_int, [vp, EXCHANGE_FN, vp]),
         "gra_get_strip_plan": (C.c_int, [vp, vp]),
         "gra_comm_create_unique_id": (C.c_int, [vp]),
@@ -107,7 +109,8 @@ class Application:
     def __init__(self, width: int, height: int, *, device: int = 0, lighting: bool = True, hdr_bloom: bool = True,
                  dynamic_exposure: bool = True, compute_post: bool = True, post_aa: int = POST_AA_NONE,
                  pre_aa: int = POST_AA_NONE, rmw_emissive: bool = False, cluster_res=synth.CLUSTER_RESOLUTION,
-                 frame_time: float = synth.FRAME_TIME, timestamps: bool = False, strip_index: int = 0, strip_count: int = 1):
+                 frame_time: float = synth.FRAME_TIME, timestamps: bool = False, strip_index: int = 0, strip_count: int = 1,
+                 alias_images: bool = True):
         self.lib = load_library()
         cfg = Config()
         cfg.device, cfg.width, cfg.height = device, width, height
@@ -120,6 +123,7 @@ class Application:
         cfg.directional_direction[:] = synth.DIRECTIONAL_DIRECTION
         cfg.enable_timestamps = int(timestamps)
         cfg.strip_index, cfg.strip_count = strip_index, strip_count
+        cfg.disable_image_aliasing = int(not alias_images)
         self._exchange_ref = None
         self.config = cfg
         self.width, self.height = width, height
@@ -294,6 +298,11 @@ class Application:
         out = np.zeros(3, np.float64)
         self._check(self.lib.gra_get_host_stats(self.handle, out.ctypes.data))
         return {"frames": int(out[0]), "seconds": float(out[1]), "blocked_seconds": float(out[2])}
+
+    def allocated_bytes(self) -> int:
+        out = C.c_uint64(0)
+        self._check(self.lib.gra_get_allocated_bytes(self.handle, C.byref(out)))
+        return int(out.value)
 
     def kernel_context(self) -> "KernelContextView":
         return KernelContextView(self.lib.gra_get_kernel_context(self.handle))

@@ -189,6 +189,15 @@ int gra_get_host_stats(gra_app *app, double *out3)
 	});
 }
 
+int gra_get_allocated_bytes(gra_app *app, uint64_t *out)
+{
+	return guarded(app, [&]() {
+		if (!out)
+			throw std::logic_error("gra_get_allocated_bytes: null output");
+		*out = app->app->get_allocated_bytes();
+	});
+}
+
 int gra_sync(gra_app *app)
 {
 	return guarded(app, [&]() { app->app->wait_idle(); });

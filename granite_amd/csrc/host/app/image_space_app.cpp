@@ -284,6 +284,7 @@ void ImageSpaceApplication::bake_render_graph()
 	auto physical_buffers = graph.consume_physical_buffers();
 	graph.reset();
 	graph.set_device(device_holder.get());
+	graph.set_alias_disjoint_images(!config.disable_image_aliasing);
 
 	ResourceDimensions dim;
 	dim.width = config.width;

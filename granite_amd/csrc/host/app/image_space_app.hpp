@@ -55,6 +55,7 @@ public:
 	void set_exchange_callback(gra_exchange_fn fn, void *user);
 	void init_collective(const uint8_t *id128, int rank, int ranks);
 	// Host-side cost of the frame loop: frames rendered, wall seconds inside render_frame(), of which blocked on the GPU.
+	size_t get_allocated_bytes() const { return device_holder ? device_holder->get_allocated_bytes() : 0; }
 	void get_host_stats(double out[3]) const
 	{
 		out[0] = double(host_frames);

@@ -749,7 +749,9 @@ void RenderGraph::bake()
 	                     backbuffer_dim.format == swapchain_dimensions.format;
 	bool has_history = physical_image_has_history[backbuffer_phys];
 	swapchain_physical_index = (same_geometry && !has_history) ? backbuffer_phys : unsigned(RenderResource::Unused);
+	build_physical_passes();
 	build_stream_assignment();
+	build_aliases();
 
 	if (device)
 		for (unsigned pass_index : pass_stack)
@@ -773,6 +775,13 @@ void RenderGraph::setup_physical_image(HIP::Device &device_, unsigned attachment
 {
 	auto &att = physical_dimensions[attachment];
 	auto &slot = physical_image_attachments[attachment];
+	if (physical_aliases[attachment] != RenderResource::Unused)
+	{
+		// lower index => already set up this frame (render_graph.cpp:2612-2618)
+		slot = physical_image_attachments[physical_aliases[attachment]];
+		physical_attachments[attachment] = slot.get();
+		return;
+	}
 	bool reuse = slot && (att.flags & ATTACHMENT_INFO_PERSISTENT_BIT) != 0 && slot->get_format() == att.format &&
 	             slot->get_width() == att.width && slot->get_height() == att.height;
 	if (!reuse)
@@ -1043,6 +1052,234 @@ void RenderGraph::build_stream_assignment()
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Physical passes (render_graph.cpp:1221-1392): consecutive graphics passes on one queue become subpasses of one render
+// pass when the later one consumes the earlier one's attachments "on tile" (colour RMW, shared depth, input attachments)
+// and needs nothing from it through memory (sampled textures, storage images / buffers, scaled colour inputs), has no
+// conflicting depth attachment and no mip generation in between.  A run grows while the candidate can join EVERY pass
+// already in it.  Compute passes never merge.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace
+{
+template <typename List, typename Res>
+bool holds_physical(const List &list, const Res *res)
+{
+	if (!res)
+		return false;
+	for (auto *entry : list)
+		if (entry && entry->get_physical_index() == res->get_physical_index())
+			return true;
+	return false;
+}
+} // namespace
+
+void RenderGraph::build_physical_passes()
+{
+	constexpr RenderGraphQueueFlags compute_mask = RENDER_GRAPH_QUEUE_COMPUTE_BIT | RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT;
+
+	auto through_memory = [&](const RenderPass &early, const RenderPass &late) {
+		// anything `late` fetches that `early` produced other than as an attachment of the same pixel
+		for (auto &in : late.get_generic_texture_inputs())
+			if (holds_physical(early.get_color_outputs(), in.texture) || holds_physical(early.get_resolve_outputs(), in.texture) ||
+			    holds_physical(early.get_storage_texture_outputs(), in.texture) || (in.texture && in.texture == early.get_depth_stencil_output()))
+				return true;
+		for (auto &in : late.get_generic_buffer_inputs())
+			if (holds_physical(early.get_storage_outputs(), in.buffer))
+				return true;
+		for (auto *in : late.get_storage_inputs())
+			if (holds_physical(early.get_storage_outputs(), in))
+				return true;
+		for (auto *in : late.get_storage_texture_inputs())
+			if (holds_physical(early.get_storage_texture_outputs(), in))
+				return true;
+		for (auto *in : late.get_color_scale_inputs())
+			if (holds_physical(early.get_storage_texture_outputs(), in) || holds_physical(early.get_color_outputs(), in) ||
+			    holds_physical(early.get_resolve_outputs(), in))
+				return true;
+		for (auto *in : late.get_color_inputs())
+			if (holds_physical(early.get_storage_texture_outputs(), in))
+				return true;
+		return false;
+	};
+	auto differs = [](const RenderResource *a, const RenderResource *b) { return a && b && a->get_physical_index() != b->get_physical_index(); };
+	auto same = [](const RenderResource *a, const RenderResource *b) { return a && b && a->get_physical_index() == b->get_physical_index(); };
+
+	auto joins = [&](const RenderPass &early, const RenderPass &late) {
+		if ((early.get_queue() & compute_mask) != 0 || late.get_queue() != early.get_queue())
+			return false;
+		for (auto *out : early.get_color_outputs())
+		{
+			auto &dim = physical_dimensions[out->get_physical_index()];
+			if (dim.levels > 1 && (dim.flags & ATTACHMENT_INFO_MIPGEN_BIT) != 0)
+				return false; // mips are generated between the two
+		}
+		if (through_memory(early, late))
+			return false;
+		const RenderResource *early_ds[2] = {early.get_depth_stencil_input(), early.get_depth_stencil_output()};
+		const RenderResource *late_ds[2] = {late.get_depth_stencil_input(), late.get_depth_stencil_output()};
+		for (auto *a : late_ds)
+			for (auto *b : early_ds)
+				if (differs(a, b))
+					return false;
+
+		// Allowed; is there anything to gain?
+		for (auto *in : late.get_color_inputs())
+			if (holds_physical(early.get_color_outputs(), in) || holds_physical(early.get_resolve_outputs(), in))
+				return true;
+		if (same(late_ds[0], early_ds[0]) || same(late_ds[0], early_ds[1]))
+			return true;
+		for (auto *in : late.get_attachment_inputs())
+			if (holds_physical(early.get_color_outputs(), in) || holds_physical(early.get_resolve_outputs(), in) ||
+			    (in && in == early.get_depth_stencil_output()))
+				return true;
+		return false;
+	};
+
+	pass_physical_pass.assign(passes.size(), unsigned(RenderResource::Unused));
+	physical_pass_count = 0;
+	for (size_t begin = 0; begin < pass_stack.size();)
+	{
+		size_t end = begin + 1;
+		while (end < pass_stack.size())
+		{
+			bool ok = true;
+			for (size_t member = begin; member < end && ok; member++)
+				ok = joins(*passes[pass_stack[member]], *passes[pass_stack[end]]);
+			if (!ok)
+				break;
+			end++;
+		}
+		for (size_t member = begin; member < end; member++)
+			pass_physical_pass[pass_stack[member]] = physical_pass_count;
+		physical_pass_count++;
+		begin = end;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Aliasing of attachment images (render_graph.cpp:1548-1746).  Two images of identical geometry whose uses within the
+// frame do not overlap share one allocation.  As in the reference: buffers, images with history and storage images
+// (implicitly preserved) never alias, nor does the output of a pass that may be skipped, nor an image that is read
+// before it is completely written.  Lifetimes are measured in physical passes, as in the reference.
+//
+// The reference restricts aliasing to images used on one and the same single queue ("we can only use events to pass
+// aliasing barriers").  The HIP executor's form of that rule: both images are touched from one and the same in-order
+// stream only, where program order is the aliasing barrier -- within the frame and across frames -- and neither is a
+// front-to-back hand-over ring, the swapchain image or the source of the final blit.
+//
+// One deliberate difference: the reference tests a candidate against one lower-indexed image only, so an image can
+// join a chain through a member it is disjoint with while overlapping another member.  Here a candidate must be
+// disjoint with every image already sharing the allocation.
+// ---------------------------------------------------------------------------------------------------------------------
+void RenderGraph::build_aliases()
+{
+	struct Range
+	{
+		unsigned first_write = ~0u, last_write = 0, first_read = ~0u, last_read = 0;
+		bool block_alias = false;
+		uint8_t streams = 0;
+		bool has_writer() const { return first_write <= last_write; }
+		bool has_reader() const { return first_read <= last_read; }
+		bool is_used() const { return has_writer() || has_reader(); }
+		bool can_alias() const
+		{
+			if (has_reader() && has_writer() && first_read <= first_write)
+				return false; // read before completely written: contents must be preserved
+			return !block_alias;
+		}
+		unsigned last_used() const { return std::max(has_writer() ? last_write : 0u, has_reader() ? last_read : 0u); }
+		unsigned first_used() const { return std::min(has_writer() ? first_write : ~0u, has_reader() ? first_read : ~0u); }
+		bool disjoint_lifetime(const Range &other) const
+		{
+			if (!is_used() || !other.is_used() || !can_alias() || !other.can_alias())
+				return false;
+			return last_used() < other.first_used() || other.last_used() < first_used();
+		}
+	};
+
+	const size_t count = physical_dimensions.size();
+	physical_aliases.assign(count, unsigned(RenderResource::Unused));
+	if (!alias_disjoint_images)
+		return;
+
+	std::vector<Range> ranges(count);
+	auto reader = [&](const RenderTextureResource *res, unsigned position, unsigned stream) {
+		if (!res || res->get_physical_index() == RenderResource::Unused)
+			return;
+		auto &r = ranges[res->get_physical_index()];
+		r.first_read = std::min(r.first_read, position);
+		r.last_read = std::max(r.last_read, position);
+		r.streams |= uint8_t(1u << stream);
+	};
+	auto writer = [&](const RenderTextureResource *res, unsigned position, unsigned stream, bool block) {
+		if (!res || res->get_physical_index() == RenderResource::Unused)
+			return;
+		auto &r = ranges[res->get_physical_index()];
+		r.first_write = std::min(r.first_write, position);
+		r.last_write = std::max(r.last_write, position);
+		r.block_alias = r.block_alias || block;
+		r.streams |= uint8_t(1u << stream);
+	};
+
+	for (unsigned pass_index : pass_stack)
+	{
+		auto &pass = *passes[pass_index];
+		const unsigned stream = pass_stream[pass_index];
+		const unsigned position = pass_physical_pass[pass_index];
+		for (auto *in : pass.get_color_inputs()) reader(in, position, stream);
+		for (auto *in : pass.get_color_scale_inputs()) reader(in, position, stream);
+		for (auto *in : pass.get_attachment_inputs()) reader(in, position, stream);
+		for (auto &in : pass.get_generic_texture_inputs()) reader(in.texture, position, stream);
+		for (auto *in : pass.get_storage_texture_inputs()) reader(in, position, stream);
+		reader(pass.get_depth_stencil_input(), position, stream);
+
+		const bool conditional = pass.may_not_need_render_pass();
+		writer(pass.get_depth_stencil_output(), position, stream, conditional);
+		for (auto *out : pass.get_color_outputs()) writer(out, position, stream, conditional);
+		for (auto *out : pass.get_resolve_outputs()) writer(out, position, stream, conditional);
+		for (auto *out : pass.get_storage_texture_outputs()) writer(out, position, stream, true);
+	}
+
+	unsigned blit_source = RenderResource::Unused;
+	if (swapchain_physical_index == RenderResource::Unused)
+	{
+		auto itr = resource_to_index.find(backbuffer_source);
+		if (itr != resource_to_index.end())
+			blit_source = resources[itr->second]->get_physical_index();
+	}
+	auto eligible = [&](unsigned i) {
+		const uint8_t s = ranges[i].streams;
+		return physical_dimensions[i].buffer_info.size == 0 && !physical_image_has_history[i] && i != swapchain_physical_index &&
+		       i != blit_source && !physical_buffer_double[i] && s != 0 && (s & (s - 1)) == 0;
+	};
+
+	std::vector<std::vector<unsigned>> sharing(count); // owner -> images living in its allocation (owner first)
+	for (unsigned i = 0; i < count; i++)
+	{
+		if (!eligible(i))
+			continue;
+		for (unsigned j = 0; j < i; j++)
+		{
+			if (!eligible(j) || physical_aliases[j] != RenderResource::Unused)
+				continue;
+			if (physical_dimensions[i] != physical_dimensions[j] || ranges[i].streams != ranges[j].streams)
+				continue;
+			bool disjoint = ranges[i].disjoint_lifetime(ranges[j]);
+			for (unsigned other : sharing[j])
+				disjoint = disjoint && ranges[i].disjoint_lifetime(ranges[other]);
+			if (!disjoint)
+				continue;
+			physical_aliases[i] = j;
+			if (sharing[j].empty())
+				sharing[j].push_back(j);
+			sharing[j].push_back(i);
+			auto usage = physical_dimensions[j].image_usage | physical_dimensions[i].image_usage;
+			physical_dimensions[i].image_usage = physical_dimensions[j].image_usage = usage;
+			break;
+		}
+	}
+}
+
 void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &composer)
 {
 	const size_t ring_slot = size_t(frame_counter++ % EventRing);
@@ -1309,6 +1546,7 @@ std::string RenderGraph::dump_json() const
 			os << ",";
 		first = false;
 		os << "{\"name\":\"" << pass.get_name() << "\",\"queue\":" << unsigned(pass.get_queue())
+		   << ",\"physical_pass\":" << int(get_physical_pass_index(pass_index))
 		   << ",\"stream\":" << (get_pass_stream(pass_index) == 0 ? "\"generic\"" : get_pass_stream(pass_index) == 1 ? "\"async\"" : "\"front\"") << ",\"writes\":[";
 		bool f2 = true;
 		auto emit = [&](const RenderResource *r) {
@@ -1347,7 +1585,8 @@ std::string RenderGraph::dump_json() const
 		os << "{\"phys\":" << i << ",\"name\":\"" << d.name << "\",\"width\":" << d.width << ",\"height\":" << d.height
 		   << ",\"format\":" << unsigned(d.format) << ",\"buffer_size\":" << d.buffer_info.size
 		   << ",\"history\":" << (physical_image_has_history[i] ? "true" : "false")
-		   << ",\"double_buffered\":" << (physical_buffer_is_double_buffered(unsigned(i)) ? "true" : "false") << "}";
+		   << ",\"double_buffered\":" << (physical_buffer_is_double_buffered(unsigned(i)) ? "true" : "false")
+		   << ",\"alias_of\":" << int(get_physical_alias(unsigned(i))) << "}";
 	}
 	os << "],\"swapchain_phys\":" << int(swapchain_physical_index) << "}";
 	return os.str();

@@ -5,9 +5,10 @@
 //
 // Kept: names, argument meaning, idempotent add_pass, resource read/write bookkeeping, validation + std::logic_error
 // messages, back-to-front dependency walk, pass reordering, physical index assignment (RMW outputs alias inputs),
-// history swap, InputRelative/SwapchainRelative size resolution (ceil(in * scale)), persistent-resource reuse.
-// Dropped (no HIP analogue): image layouts, barriers/semaphores, subpass merging, transient attachments, aliasing of
-// disjoint-lifetime images.  A pass is a sequence of kernel launches on an in-order stream.
+// history swap, InputRelative/SwapchainRelative size resolution (ceil(in * scale)), persistent-resource reuse, aliasing
+// of attachment images with disjoint lifetimes (build_aliases).
+// Dropped (no HIP analogue): image layouts, barriers/semaphores, subpass merging, transient attachments.  A pass is a
+// sequence of kernel launches on an in-order stream, and every logical pass is its own physical pass.
 #pragma once
 #include <functional>
 #include <memory>
@@ -381,6 +382,12 @@ public:
 	// is double-buffered, so frame N+1's cluster build overlaps frame N's lighting and frame N+1's lighting overlaps
 	// frame N's bloom / tonemap.  Default on.
 	void set_hoist_independent_compute(bool enable) { hoist_independent_compute = enable; }
+	// Share one allocation between attachment images of identical geometry whose lifetimes within the frame do not
+	// overlap (build_aliases, render_graph.cpp:1548-1746).  On by default like the reference; off is for A/B tests.
+	void set_alias_disjoint_images(bool enable) { alias_disjoint_images = enable; }
+	unsigned get_physical_pass_index(unsigned pass_index) const { return pass_index < pass_physical_pass.size() ? pass_physical_pass[pass_index] : unsigned(RenderResource::Unused); }
+	unsigned get_physical_pass_count() const { return physical_pass_count; }
+	unsigned get_physical_alias(unsigned index) const { return index < physical_aliases.size() ? physical_aliases[index] : unsigned(RenderResource::Unused); }
 	// 0 = generic stream (the back of the frame), 1 = async compute (passes the front does not wait for within a frame:
 	// explicit ASYNC_COMPUTE passes and input-free front passes such as the cluster build), 2 = the rest of the front.
 	unsigned get_pass_stream(unsigned pass_index) const { return pass_index < pass_stream.size() ? pass_stream[pass_index] : 0u; }
@@ -518,6 +525,15 @@ private:
 	std::vector<HIP::ImageHandle> physical_images_alternate[HandOverCopies - 1];
 	std::vector<PhysicalSync> physical_sync_alternate[HandOverCopies - 1];
 	void build_stream_assignment();
+	void build_physical_passes();
+	void build_aliases();
+	// Which baked passes the reference would fold into one VkRenderPass as subpasses (build_physical_passes,
+	// render_graph.cpp:1221-1392).  The HIP executor launches every pass on its own; the grouping is kept because the
+	// reference measures attachment lifetimes for aliasing in physical passes, and for graph dumps.
+	std::vector<unsigned> pass_physical_pass;
+	unsigned physical_pass_count = 0;
+	bool alias_disjoint_images = true;
+	std::vector<unsigned> physical_aliases; // physical index whose image this one shares, or Unused
 	std::unordered_map<std::string, std::pair<uint64_t, double>> timestamp_accum;
 	std::vector<std::string> timestamp_order;
 

@@ -52,6 +52,9 @@ typedef struct gra_config
 	 * 0 / 1 = the whole frame here.  Needs enable_lighting, hdr_bloom, compute_post and no AA; the band exchanges go
 	 * through gra_set_exchange_callback. */
 	uint32_t strip_index, strip_count;
+	/* 0 (reference behaviour): attachment images of identical geometry with disjoint lifetimes inside the frame share
+	 * one allocation (RenderGraph::build_aliases, render_graph.cpp:1548-1746); 1: every image gets its own. */
+	int32_t disable_image_aliasing;
 } gra_config;
 
 /* Scene-level light description (one PositionalLight + its node transform). */
@@ -142,6 +145,8 @@ int gra_get_strip_plan(gra_app *app, uint32_t *out24);
 /* Host-side frame-loop cost since creation: out[0] = frames, out[1] = seconds spent inside the frame loop (light
  * refresh + graph execution = launches), out[2] = seconds of those spent blocked on GPU back-pressure. */
 int gra_get_host_stats(gra_app *app, double *out3);
+/* Bytes of HBM currently held by the executor's images and buffers (graph attachments, hand-over rings, uploads). */
+int gra_get_allocated_bytes(gra_app *app, uint64_t *out);
 /* Per-kernel timing lives in the kernel library: gr_timing_* on this context. */
 void *gra_get_kernel_context(gra_app *app); /* gr_ctx* */
 void *gra_get_stream(gra_app *app);         /* hipStream_t of the generic queue */

@@ -115,6 +115,40 @@ int main()
 		graph.bake();
 		print_case("rmw", graph.dump_json());
 	}
+	{
+		// Attachment images of identical geometry with disjoint lifetimes share one allocation (build_aliases); storage
+		// images never do.  "c" moves into a's allocation; "d" overlaps c (pass p3 reads c while writing d), so it must
+		// not follow it there even though it is disjoint with a itself -- it lands in b's.
+		RenderGraph graph;
+		graph.set_backbuffer_dimensions(backbuffer(512, 256));
+		AttachmentInfo half;
+		half.format = VK_FORMAT_R16G16B16A16_SFLOAT;
+		half.size_x = half.size_y = 0.5f;
+		const char *names[] = {"a", "b", "c", "d"};
+		for (unsigned i = 0; i < 4; i++)
+		{
+			auto &pass = graph.add_pass(std::string("p") + std::to_string(i), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+			pass.add_color_output(names[i], half);
+			if (i)
+				pass.add_texture_input(names[i - 1]);
+		}
+		auto &store = graph.add_pass("p4", RENDER_GRAPH_QUEUE_COMPUTE_BIT);
+		store.add_storage_texture_output("s", half);
+		store.add_texture_input("d");
+		auto &present = graph.add_pass("p5", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		AttachmentInfo out;
+		present.add_color_output("screen", out);
+		present.add_texture_input("s");
+		graph.set_backbuffer_source("screen");
+		graph.bake();
+		print_case("aliasing-pipelined", graph.dump_json());
+		graph.set_hoist_independent_compute(false); // whole frame on one stream
+		graph.bake();
+		print_case("aliasing", graph.dump_json());
+		graph.set_alias_disjoint_images(false);
+		graph.bake();
+		print_case("aliasing-off", graph.dump_json());
+	}
 	print_error("no-writer", []() {
 		RenderGraph graph;
 		graph.set_backbuffer_dimensions(backbuffer(64, 64));

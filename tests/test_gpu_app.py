@@ -150,3 +150,35 @@ def test_pipelined_frames_equal_synchronised_frames(kw):
         a.close()
     for got, want in zip(results[1], results[0]):
         np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("lighting", [False, True])
+def test_aliased_attachments_do_not_change_a_byte(scene, lighting):
+    """Graphics form of the chain: the upsample levels live in the allocations of the dead downsample levels
+    (RenderGraph::build_aliases, render_graph.cpp:1548-1746).  Frames must equal those of a graph where every image has
+    its own allocation -- across several frames, pipelined -- while the executor holds less HBM."""
+    cam, gbuf, descs = scene
+    results, held = [], []
+    for alias in (False, True):
+        if lighting:
+            a = make_app(cam, gbuf, descs, compute_post=False, alias_images=alias)
+        else:
+            a = gapp.Application(480, 270, lighting=False, compute_post=False, alias_images=alias)
+            a.upload_hdr(synth.make_hdr(480, 270))
+        g = {r["name"]: r for r in a.graph()["resources"]}
+        assert (g["bloom-upsample-2"]["alias_of"] == g["bloom-downsample-0"]["phys"]) == alias
+        a.render_frames(8)
+        a.sync()
+        if alias:
+            up, down = a.resource("bloom-upsample-2"), a.resource("bloom-downsample-0")
+            assert up.device_ptr == down.device_ptr
+        results.append((a.read_backbuffer().copy(), a.read("average-luminance").copy(), a.read("bloom-upsample-2").copy(),
+                        a.read("bloom-downsample-3").copy()))
+        held.append(a.allocated_bytes())
+        a.close()
+    for got, want in zip(results[1], results[0]):
+        np.testing.assert_array_equal(got, want)
+    saved = held[0] - held[1]
+    w, h = 480, 270
+    levels = [((w + 3) // 4) * ((h + 3) // 4), ((w + 7) // 8) * ((h + 7) // 8), ((w + 15) // 16) * ((h + 15) // 16)]
+    assert saved == 8 * sum(levels), (held, levels)

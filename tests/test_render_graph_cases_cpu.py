@@ -57,6 +57,25 @@ def test_rmw_aliases_and_input_relative_sizes(cases):
     assert res[phys["sum"]]["double_buffered"] is False
 
 
+def test_disjoint_lifetime_attachments_share_an_allocation(cases):
+    """build_aliases (render_graph.cpp:1548-1746): same geometry + disjoint lifetimes => one allocation; storage images,
+    history images and the swapchain never alias; nothing joins an allocation it overlaps any member of."""
+    g = cases["aliasing"]["graph"]
+    res = {r["name"]: r for r in g["resources"]}
+    assert res["a"]["alias_of"] == -1 and res["b"]["alias_of"] == -1
+    assert res["c"]["alias_of"] == res["a"]["phys"]
+    assert res["d"]["alias_of"] == res["b"]["phys"]      # not a's: c lives there and p3 reads c while writing d
+    assert res["s"]["alias_of"] == -1 and res["screen"]["alias_of"] == -1
+    # With the frame front pipelined on other streams (p0 on the async stream, p1..p4 on the front stream), "a" crosses
+    # streams as a hand-over ring and stays out of it; b/d live on the front stream alone and still share.
+    gp = cases["aliasing-pipelined"]["graph"]
+    rp = {r["name"]: r for r in gp["resources"]}
+    assert {p["name"]: p["stream"] for p in gp["passes"]}["p0"] == "async" and rp["a"]["double_buffered"]
+    assert rp["c"]["alias_of"] == -1 and rp["d"]["alias_of"] == rp["b"]["phys"]
+    off = {r["name"]: r["alias_of"] for r in cases["aliasing-off"]["graph"]["resources"]}
+    assert set(off.values()) == {-1}
+
+
 def test_validation_errors_are_logic_errors_with_the_reference_messages(cases):
     assert cases["no-writer"]["error"] == "No pass exists which writes to resource."
     assert cases["missing-backbuffer"]["error"] == "Backbuffer source does not exist."

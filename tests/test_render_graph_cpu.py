@@ -91,3 +91,32 @@ def test_frame_front_is_pipelined_on_the_second_stream():
     # no lighting: the frame starts at the HDR upload; nothing but the upload pass is independent of feedback
     g1 = graph_of(256, 256, lighting=False)
     assert {p["name"]: p["stream"] for p in g1["passes"]}["bloom-compute"] == "generic"
+
+
+def test_graphics_bloom_chain_reuses_downsample_levels_for_the_upsample_chain():
+    """The 10-pass graphics form of the HDR chain (hdr.cpp:402-561) writes colour attachments: once downsample-(k+1) exists,
+    downsample-k is dead, so the upsample level of the same size moves into its allocation (build_aliases).  The compute
+    form writes storage images, which are implicitly preserved and never alias (render_graph.cpp:1671-1673)."""
+    g = graph_of(1280, 720, lighting=False, compute_post=False)
+    res = {r["name"]: r for r in g["resources"]}
+    for up, down in (("bloom-upsample-0", "bloom-downsample-2"), ("bloom-upsample-1", "bloom-downsample-1"),
+                     ("bloom-upsample-2", "bloom-downsample-0")):
+        assert res[up]["alias_of"] == res[down]["phys"], up
+    assert res["bloom-downsample-3"]["alias_of"] == -1 and res["bloom-downsample-3"]["history"]
+    assert res["tonemapped"]["alias_of"] == -1 and res["HDR-main"]["alias_of"] == -1
+    g2 = graph_of(1280, 720)
+    assert {r["alias_of"] for r in g2["resources"]} == {-1}
+    g3 = graph_of(1280, 720, lighting=False, compute_post=False, alias_images=False)
+    assert {r["alias_of"] for r in g3["resources"]} == {-1}
+
+
+def test_gbuffer_and_lighting_form_one_physical_pass_like_the_reference():
+    """build_physical_passes (render_graph.cpp:1221-1392): lighting consumes the G-buffer as input attachments of the same
+    pixel, so the reference folds both into one VkRenderPass (two subpasses); everything that samples a texture another pass
+    wrote, and every compute pass, starts a new physical pass."""
+    g = graph_of(1280, 720, compute_post=False, post_aa=gapp.POST_AA_FXAA)
+    pp = {p["name"]: p["physical_pass"] for p in g["passes"]}
+    assert pp["gbuffer-main"] == pp["lighting-main"]
+    others = [v for k, v in pp.items() if k not in ("gbuffer-main", "lighting-main")]
+    assert len(set(others)) == len(others) and pp["gbuffer-main"] not in others
+    assert [p["physical_pass"] for p in g["passes"]] == sorted(p["physical_pass"] for p in g["passes"])
