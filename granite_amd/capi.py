@@ -157,6 +157,12 @@ class PushTaa(C.Structure):
 assert C.sizeof(PushTaa) == 80
 
 
+class HizArgs(C.Structure):
+    _fields_ = [("depth", Image), ("chain", C.c_void_p), ("chain_width", C.c_uint32), ("chain_height", C.c_uint32),
+                ("chain_levels", C.c_uint32), ("output_downsample", C.c_uint32), ("z_transform", C.c_float * 4),
+                ("counter", C.c_void_p)]
+
+
 class GraniteHipError(RuntimeError):
     pass
 
@@ -215,6 +221,9 @@ def load_library() -> C.CDLL:
         "gr_smaa_blend_weight": (C.c_int, [vp, vp, P(Image), P(Image), P(PushSmaa), C.c_int]),
         "gr_smaa_neighbor_blend": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushSmaa)]),
         "gr_taa_resolve": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), P(Image), P(Image), P(PushTaa), C.c_int]),
+        "gr_hiz": (C.c_int, [vp, vp, P(HizArgs)]),
+        "gr_mip_chain_offset": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "gr_mip_chain_size": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here = header/library drift
@@ -231,6 +240,7 @@ EXPORTED_SYMBOLS = [
     "gr_bloom_threshold_rows", "gr_bloom_downsample_rows", "gr_bloom_upsample_rows", "gr_tonemap_rows",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
     "gr_smaa_set_luts", "gr_fxaa", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
+    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size",
 ]
 
 
@@ -406,3 +416,32 @@ class Context:
         self.check(self.lib.gr_taa_resolve(self.handle, stream, current.desc, depth.desc, mv.desc,
                                            history.desc if history is not None else None, out_color.desc, out_history.desc, push,
                                            quality))
+
+    def hiz(self, depth: DeviceImage, z_transform, output_downsample: bool = False, chain: Optional[DeviceBuffer] = None,
+            counter: Optional[DeviceBuffer] = None, stream=None):
+        """Depth hierarchy of `depth` sized as setup_depth_hierarchy_pass sizes it (spd.cpp:207-218).  Returns
+        (chain buffer, counter buffer, layout dict); chain / counter can be passed back in to reuse them."""
+        ds = int(output_downsample)
+        levels = max(1, max(depth.width, depth.height).bit_length() - 1 - ds)
+        cw, ch = ((depth.width + 63) & ~63) >> ds, ((depth.height + 63) & ~63) >> ds
+        if chain is None:
+            chain = DeviceBuffer(self, self.lib.gr_mip_chain_size(cw, ch, 4, levels))
+        if counter is None:
+            counter = DeviceBuffer(self, 4)
+        args = HizArgs()
+        args.depth = depth.desc
+        args.chain, args.chain_width, args.chain_height, args.chain_levels = chain.ptr, cw, ch, levels
+        args.output_downsample = ds
+        args.z_transform[:] = [float(v) for v in z_transform]
+        args.counter = counter.ptr
+        self.check(self.lib.gr_hiz(self.handle, stream, args))
+        return chain, counter, {"chain_w": cw, "chain_h": ch, "levels": levels}
+
+    def read_mip_chain(self, chain: DeviceBuffer, layout: dict):
+        raw = chain.download(np.float32)
+        out = []
+        for l in range(layout["levels"]):
+            w, h = max(layout["chain_w"] >> l, 1), max(layout["chain_h"] >> l, 1)
+            o = self.lib.gr_mip_chain_offset(layout["chain_w"], layout["chain_h"], 4, l) // 4
+            out.append(raw[o:o + w * h].reshape(h, w))
+        return out

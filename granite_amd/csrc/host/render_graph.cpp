@@ -31,6 +31,26 @@ static Res &declare_write(Res &res, RenderGraphQueueFlagBits queue, unsigned pas
 	return res;
 }
 
+void RenderPass::add_proxy_output(const std::string &name, VkPipelineStageFlags2 stages, VkAccessFlags2 access, const std::string &input)
+{
+	AccessedProxyResource acc;
+	acc.proxy = &declare_write(graph.get_proxy_resource(name), queue, index);
+	acc.stages = stages;
+	acc.access = access;
+	if (!input.empty())
+		acc.alias_input = &declare_read(graph.get_proxy_resource(input), queue, index);
+	proxy_outputs.push_back(acc);
+}
+
+void RenderPass::add_proxy_input(const std::string &name, VkPipelineStageFlags2 stages, VkAccessFlags2 access)
+{
+	AccessedProxyResource acc;
+	acc.proxy = &declare_read(graph.get_proxy_resource(name), queue, index);
+	acc.stages = stages;
+	acc.access = access;
+	proxy_inputs.push_back(acc);
+}
+
 RenderTextureResource &RenderPass::add_attachment_input(const std::string &name)
 {
 	auto &res = declare_read(graph.get_texture_resource(name), queue, index);
@@ -246,6 +266,22 @@ RenderBufferResource &RenderGraph::get_buffer_resource(const std::string &name)
 	resources.back()->set_name(name);
 	resource_to_index[name] = index;
 	return static_cast<RenderBufferResource &>(*resources.back());
+}
+
+RenderResource &RenderGraph::get_proxy_resource(const std::string &name)
+{
+	auto itr = resource_to_index.find(name);
+	if (itr != resource_to_index.end())
+	{
+		if (resources[itr->second]->get_type() != RenderResource::Type::Proxy)
+			throw std::logic_error("Resource is not a proxy: " + name);
+		return *resources[itr->second];
+	}
+	unsigned index = unsigned(resources.size());
+	resources.emplace_back(new RenderResource(RenderResource::Type::Proxy, index));
+	resources.back()->set_name(name);
+	resource_to_index[name] = index;
+	return *resources.back();
 }
 
 RenderPass &RenderGraph::add_pass(const std::string &name, RenderGraphQueueFlagBits queue)
@@ -505,6 +541,16 @@ void RenderGraph::traverse_dependencies(const RenderPass &pass, unsigned stack_c
 
 	for (auto &input : pass.get_generic_buffer_inputs())
 		depend_passes_recursive(pass, input.buffer->get_write_passes(), stack_count, true, false, false);
+
+	// Proxies: ordering edges only (render_graph.cpp:2802-2812); a proxy RMW is ordered like a storage-buffer RMW.
+	for (auto &input : pass.get_proxy_inputs())
+		depend_passes_recursive(pass, input.proxy->get_write_passes(), stack_count, false, false, false);
+	for (auto &output : pass.get_proxy_outputs())
+		if (output.alias_input)
+		{
+			depend_passes_recursive(pass, output.alias_input->get_write_passes(), stack_count, true, false, false);
+			depend_passes_recursive(pass, output.alias_input->get_read_passes(), stack_count, true, true, false);
+		}
 }
 
 bool RenderGraph::depends_on_pass(unsigned dst_pass, unsigned src_pass)
@@ -622,6 +668,19 @@ void RenderGraph::build_physical_resources()
 			dim.buffer_info.usage |= res->get_buffer_usage();
 		}
 	};
+	auto touch_proxy = [&](RenderResource *res) {
+		if (res->get_physical_index() == RenderResource::Unused)
+		{
+			ResourceDimensions dim;
+			dim.flags |= ATTACHMENT_INFO_INTERNAL_PROXY_BIT; // no memory behind it (render_graph.cpp:758-767)
+			dim.name = res->get_name();
+			dim.queues = res->get_used_queues();
+			physical_dimensions.push_back(dim);
+			res->set_physical_index(phys_index++);
+		}
+		else
+			physical_dimensions[res->get_physical_index()].queues |= res->get_used_queues();
+	};
 	auto alias_output = [&](RenderResource *output, RenderResource *input) {
 		if (output->get_physical_index() == RenderResource::Unused)
 			output->set_physical_index(input->get_physical_index());
@@ -660,10 +719,21 @@ void RenderGraph::build_physical_resources()
 				alias_output(pass.get_storage_texture_outputs()[i], input);
 			}
 
+		for (auto &input : pass.get_proxy_inputs())
+			touch_proxy(input.proxy);
+		for (auto &output : pass.get_proxy_outputs())
+			if (output.alias_input)
+			{
+				touch_proxy(output.alias_input);
+				alias_output(output.proxy, output.alias_input);
+			}
+
 		for (auto *output : pass.get_color_outputs())
 			touch_texture(output);
 		for (auto *output : pass.get_resolve_outputs())
 			touch_texture(output);
+		for (auto &output : pass.get_proxy_outputs())
+			touch_proxy(output.proxy);
 		for (auto *output : pass.get_storage_outputs())
 			touch_buffer(output);
 		for (auto *output : pass.get_transfer_outputs())
@@ -842,6 +912,8 @@ void RenderGraph::setup_attachments(HIP::Device &device_, HIP::ImageView *swapch
 				physical_sync_alternate[k][i] = physical_sync_alternate[k + 1][i];
 			physical_sync_alternate[spares - 1][i] = current_sync;
 		}
+		if ((att.flags & ATTACHMENT_INFO_INTERNAL_PROXY_BIT) != 0)
+			continue;
 		if (att.buffer_info.size != 0)
 			setup_physical_buffer(device_, i);
 		else if (i == swapchain_physical_index && swapchain)
@@ -918,6 +990,9 @@ void RenderGraph::build_stream_assignment()
 		for (auto *r : pass.get_storage_inputs()) add(reads, r);
 		for (auto &r : pass.get_generic_texture_inputs()) add(reads, r.texture);
 		for (auto &r : pass.get_generic_buffer_inputs()) add(reads, r.buffer);
+		for (auto &r : pass.get_proxy_inputs()) add(reads, r.proxy);
+		for (auto &r : pass.get_proxy_outputs()) add(reads, r.alias_input);
+		for (auto &r : pass.get_proxy_outputs()) add(writes, r.proxy);
 		add(reads, pass.get_depth_stencil_input());
 		for (auto *r : pass.get_color_outputs()) add(writes, r);
 		for (auto *r : pass.get_resolve_outputs()) add(writes, r);

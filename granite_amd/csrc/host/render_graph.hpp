@@ -78,7 +78,9 @@ enum AttachmentInfoFlagBits
 	ATTACHMENT_INFO_PERSISTENT_BIT = 1 << 0,
 	ATTACHMENT_INFO_UNORM_SRGB_ALIAS_BIT = 1 << 1,
 	ATTACHMENT_INFO_SUPPORTS_PREROTATE_BIT = 1 << 2,
-	ATTACHMENT_INFO_MIPGEN_BIT = 1 << 3
+	ATTACHMENT_INFO_MIPGEN_BIT = 1 << 3,
+	ATTACHMENT_INFO_INTERNAL_TRANSIENT_BIT = 1 << 16,
+	ATTACHMENT_INFO_INTERNAL_PROXY_BIT = 1 << 17
 };
 using AttachmentInfoFlags = uint32_t;
 
@@ -219,6 +221,13 @@ public:
 		VkAccessFlags2 access = 0;
 		RenderBufferResource *buffer = nullptr;
 	};
+	struct AccessedProxyResource
+	{
+		VkPipelineStageFlags2 stages = 0;
+		VkAccessFlags2 access = 0;
+		RenderResource *proxy = nullptr;
+		RenderResource *alias_input = nullptr;
+	};
 
 	RenderGraphQueueFlagBits get_queue() const { return queue; }
 	RenderGraph &get_graph() { return graph; }
@@ -236,6 +245,10 @@ public:
 	RenderBufferResource &add_storage_output(const std::string &name, const BufferInfo &info, const std::string &input = "");
 	RenderBufferResource &add_transfer_output(const std::string &name, const BufferInfo &info);
 	RenderTextureResource &add_storage_texture_output(const std::string &name, const AttachmentInfo &info, const std::string &input = "");
+	// Proxies carry no memory: a pure ordering edge between a writer and its readers (render_graph.hpp:513-514), e.g.
+	// to keep alive and order a pass whose output is consumed outside the graph or by the next frame.
+	void add_proxy_output(const std::string &name, VkPipelineStageFlags2 stages, VkAccessFlags2 access, const std::string &input = "");
+	void add_proxy_input(const std::string &name, VkPipelineStageFlags2 stages, VkAccessFlags2 access);
 	RenderBufferResource &add_vertex_buffer_input(const std::string &name);
 	RenderBufferResource &add_index_buffer_input(const std::string &name);
 	RenderBufferResource &add_indirect_buffer_input(const std::string &name);
@@ -258,6 +271,8 @@ public:
 	const std::vector<RenderBufferResource *> &get_transfer_outputs() const { return transfer_outputs; }
 	const std::vector<AccessedTextureResource> &get_generic_texture_inputs() const { return generic_texture; }
 	const std::vector<AccessedBufferResource> &get_generic_buffer_inputs() const { return generic_buffer; }
+	const std::vector<AccessedProxyResource> &get_proxy_inputs() const { return proxy_inputs; }
+	const std::vector<AccessedProxyResource> &get_proxy_outputs() const { return proxy_outputs; }
 	const std::vector<std::pair<RenderTextureResource *, RenderTextureResource *>> &get_fake_resource_aliases() const
 	{
 		return fake_resource_alias;
@@ -340,6 +355,7 @@ private:
 	std::vector<RenderBufferResource *> transfer_outputs;
 	std::vector<AccessedTextureResource> generic_texture;
 	std::vector<AccessedBufferResource> generic_buffer;
+	std::vector<AccessedProxyResource> proxy_inputs, proxy_outputs;
 	RenderTextureResource *depth_stencil_input = nullptr;
 	RenderTextureResource *depth_stencil_output = nullptr;
 	std::vector<std::pair<RenderTextureResource *, RenderTextureResource *>> fake_resource_alias;
@@ -402,6 +418,7 @@ public:
 
 	RenderTextureResource &get_texture_resource(const std::string &name);
 	RenderBufferResource &get_buffer_resource(const std::string &name);
+	RenderResource &get_proxy_resource(const std::string &name);
 
 	HIP::ImageView &get_physical_texture_resource(unsigned index);
 	HIP::ImageView *get_physical_history_texture_resource(unsigned index);

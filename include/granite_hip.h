@@ -371,6 +371,30 @@ typedef struct gr_push_taa
 int gr_taa_resolve(gr_ctx *ctx, gr_stream stream, const gr_image *current, const gr_image *depth, const gr_image *mv,
                    const gr_image *history, const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality);
 
+/* ---- depth hierarchy ---------------------------------------------------------------------------------------------------
+ * HiZPassState::build_render_pass (renderer/post/spd.cpp:141-194) + assets/shaders/post/hiz.comp: one launch turns the
+ * depth attachment into a full max-reduction mip chain of linearised depth.  Workgroups reduce 64 x 64 tiles down to one
+ * texel (mips 0..6); the last workgroup to finish (atomic counter, hiz.comp:355-365) reduces what is left, folding in the
+ * odd row / column of non-power-of-two levels.
+ *
+ * Mip chains live in one allocation, level after level, each level tightly packed; level l of a w x h chain is
+ * max(w >> l, 1) x max(h >> l, 1) texels (gr_mip_chain_offset / gr_mip_chain_size, in bytes). */
+size_t gr_mip_chain_offset(uint32_t width, uint32_t height, uint32_t bytes_per_texel, uint32_t level);
+size_t gr_mip_chain_size(uint32_t width, uint32_t height, uint32_t bytes_per_texel, uint32_t levels);
+
+typedef struct gr_hiz_args
+{
+	gr_image depth;            /* D32_SFLOAT / R32_SFLOAT; texels past its edge repeat the edge (NearestClamp) */
+	void *chain;               /* R32_SFLOAT mip chain */
+	uint32_t chain_width;      /* level 0 of the chain: the input size rounded up to multiples of 64 (spd.cpp:214-215), */
+	uint32_t chain_height;     /* halved when output_downsample */
+	uint32_t chain_levels;     /* spd.cpp:212: max(1, floor_log2(max(w, h)) - output_downsample) */
+	uint32_t output_downsample; /* 1: the transformed full-resolution level is not stored; chain level 0 is mip 1 */
+	float z_transform[4];      /* column-major mat2, spd.cpp:164-165: depth -> (num, den), stored value min(num / den, 1e30) */
+	uint32_t *counter;         /* one zero-initialised uint32 (the pass's "-counter" buffer); left at zero */
+} gr_hiz_args;
+int gr_hiz(gr_ctx *ctx, gr_stream stream, const gr_hiz_args *args);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@ known-answer tests in tests/test_oracle_kat.py and fixtures in tests/golden/.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -288,3 +289,37 @@ def taa_resolve(current: np.ndarray, depth: np.ndarray, mv: np.ndarray, history,
     out_h = np.zeros((h, w, 4), np.uint16)
     lib().orc_taa_resolve(_p(current), _p(d), _p(m), _p(history), w, h, _p(r), quality, _p(out_c), _p(out_h))
     return out_c, out_h
+
+
+# ---- depth hierarchy (renderer/post/spd.cpp:196-232 + assets/shaders/post/hiz.comp) ----------------------------------------
+def hiz_layout(iw: int, ih: int, output_downsample: bool = False):
+    """setup_depth_hierarchy_pass (spd.cpp:207-218): chain level-0 size, level count; plus push.resolution / push.mips."""
+    ds = int(output_downsample)
+    levels = max(1, int(math.floor(math.log2(max(iw, ih)))) - ds)
+    cw, ch = ((iw + 63) & ~63) >> ds, ((ih + 63) & ~63) >> ds
+    return {"chain_w": cw, "chain_h": ch, "levels": levels, "res_w": cw << ds, "res_h": ch << ds, "mips": levels + ds}
+
+
+def hiz_z_transform(inv_projection16) -> np.ndarray:
+    """mat2(inv_projection[2].zw * vec2(-1, 1), inv_projection[3].zw * vec2(-1, 1)), column-major (spd.cpp:164-165)."""
+    m = np.asarray(inv_projection16, np.float32).reshape(4, 4)  # m[c] = column c
+    return np.array([-m[2][2], m[2][3], -m[3][2], m[3][3]], np.float32)
+
+
+def hiz(depth: np.ndarray, z_transform, output_downsample: bool = False):
+    """Returns the list of chain levels (2-D float32 arrays)."""
+    d = np.ascontiguousarray(depth, np.float32)
+    ih, iw = d.shape
+    lay = hiz_layout(iw, ih, output_downsample)
+    fn = lib().orc_mip_chain_offset
+    fn.restype = C.c_size_t
+    total = fn(lay["chain_w"], lay["chain_h"], lay["levels"])
+    out = np.zeros(total, np.float32)
+    zt = np.ascontiguousarray(z_transform, np.float32)
+    lib().orc_hiz(_p(d), iw, ih, lay["res_w"], lay["res_h"], lay["mips"], _p(zt), int(not output_downsample), _p(out))
+    levels = []
+    for l in range(lay["levels"]):
+        w, h = max(lay["chain_w"] >> l, 1), max(lay["chain_h"] >> l, 1)
+        o = fn(lay["chain_w"], lay["chain_h"], l)
+        levels.append(out[o:o + w * h].reshape(h, w))
+    return levels
