@@ -26,7 +26,7 @@ class Config(C.Structure):
                 ("cluster_res", C.c_uint32 * 3), ("frame_time", C.c_float), ("directional_color", C.c_float * 3),
                 ("directional_direction", C.c_float * 3), ("enable_timestamps", C.c_int32),
                 ("strip_index", C.c_uint32), ("strip_count", C.c_uint32),
-                ("disable_image_aliasing", C.c_int32)]
+                ("disable_image_aliasing", C.c_int32), ("depth_hierarchy", C.c_int32)]
 
 
 # void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream)
@@ -35,7 +35,7 @@ EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, 
 
 class ResourceInfo(C.Structure):
     _fields_ = [("device_ptr", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32),
-                ("size_bytes", C.c_uint64), ("physical_index", C.c_int32)]
+                ("size_bytes", C.c_uint64), ("physical_index", C.c_int32), ("levels", C.c_uint32)]
 
 
 class Timestamp(C.Structure):
@@ -110,7 +110,7 @@ class Application:
                  dynamic_exposure: bool = True, compute_post: bool = True, post_aa: int = POST_AA_NONE,
                  pre_aa: int = POST_AA_NONE, rmw_emissive: bool = False, cluster_res=synth.CLUSTER_RESOLUTION,
                  frame_time: float = synth.FRAME_TIME, timestamps: bool = False, strip_index: int = 0, strip_count: int = 1,
-                 alias_images: bool = True):
+                 alias_images: bool = True, depth_hierarchy: int = 0):
         self.lib = load_library()
         cfg = Config()
         cfg.device, cfg.width, cfg.height = device, width, height
@@ -124,6 +124,7 @@ class Application:
         cfg.enable_timestamps = int(timestamps)
         cfg.strip_index, cfg.strip_count = strip_index, strip_count
         cfg.disable_image_aliasing = int(not alias_images)
+        cfg.depth_hierarchy = int(depth_hierarchy)
         self._exchange_ref = None
         self.config = cfg
         self.width, self.height = width, height
@@ -213,7 +214,21 @@ class Application:
         info = self.resource(name)
         raw = np.empty(info.size_bytes, np.uint8)
         self._check(self.lib.gra_read_resource(self.handle, name.encode(), raw.ctypes.data, raw.nbytes))
+        if info.levels > 1:
+            return raw
         return self._shape(info, raw) if info.width else raw
+
+    def read_mip_chain(self, name: str):
+        """Levels of a mip-chain attachment (R32_SFLOAT), finest first."""
+        info = self.resource(name)
+        raw = self.read(name).view(np.float32)
+        lib = capi.load_library()
+        out = []
+        for l in range(info.levels):
+            w, h = max(info.width >> l, 1), max(info.height >> l, 1)
+            o = lib.gr_mip_chain_offset(info.width, info.height, 4, l) // 4
+            out.append(raw[o:o + w * h].reshape(h, w))
+        return out
 
     def read_backbuffer(self) -> np.ndarray:
         info = ResourceInfo()

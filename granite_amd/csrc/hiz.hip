@@ -1,12 +1,13 @@
-// Depth hierarchy for gfx950: HiZPassState::build_render_pass (renderer/post/spd.cpp:141-194) + assets/shaders/post/hiz.comp
-// as ONE launch.  The work is a stream: 4 B read per texel, 4 B (+1/3) written, nothing re-read from HBM.
+// Depth hierarchy for gfx950: HiZPassState::build_render_pass (renderer/post/spd.cpp:141-194) + assets/shaders/post/hiz.comp.
+// The work is a stream: 4 B read per texel, 4 B (+1/3) written, nothing re-read from HBM.
 //
 // Mapping (own design, not the shader's): a workgroup of four waves owns a 64 x 64 texel tile, a wave a 32 x 32 quadrant, a
 // lane a 4 x 4 block (four 16-byte loads; eight lanes cover a 128-byte line of every row).  Lanes are numbered along a
 // Morton curve inside the quadrant, so mips 1 and 2 are per-lane register work, mips 3 / 4 / 5 are xor-shuffles over lane
-// bits (0,1) / (2,3) / (4,5) -- no LDS, no barrier -- and mip 6 is one LDS exchange between the four waves.  The last
-// workgroup to arrive at the atomic counter (release / acquire at agent scope: the tiles were written through eight
-// different L2s) reduces mip 6 to the end of the chain in LDS, folding the odd row / column of non-power-of-two levels.
+// bits (0,1) / (2,3) / (4,5) -- no LDS, no barrier -- and mip 6 is one LDS exchange between the four waves.  A one-workgroup
+// tail launch reduces mip 6 to the end of the chain in LDS (k_hiz_tail).
+//
+// (Non-temporal loads / stores were tried: +9 % at 8K with the full-resolution level, -10..15 % elsewhere; not kept.)
 //
 // Max-reductions are exact in any order; the depth transform is fp32 with IEEE division and no contraction
 // (-ffp-contract=off for this file), so the chain is bit-identical to the oracle.
@@ -28,8 +29,6 @@ struct HizParams
 	int mips;         // push.mips
 	int top;          // WRITE_TOP_LEVEL
 	float m0, m1, m2, m3;
-	uint32_t *counter;
-	uint32_t target;
 	uint32_t offset[HIZ_MAX_MIPS]; // float offset of mip m inside the chain
 };
 
@@ -58,11 +57,9 @@ __device__ __forceinline__ float reduce_folded(Fetch fetch, int x, int y, int w,
 	return r;
 }
 
-__global__ __launch_bounds__(256) void k_hiz(HizParams p)
+__global__ __launch_bounds__(256) void k_hiz_tiles(HizParams p)
 {
-	extern __shared__ float tail_lds[];
 	__shared__ float wave_top[4];
-	__shared__ uint32_t is_last;
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
@@ -79,7 +76,7 @@ __global__ __launch_bounds__(256) void k_hiz(HizParams p)
 		const uint8_t *row = p.depth + size_t(min(y0 + j, p.ih - 1)) * p.pitch;
 		if (vector_rows)
 		{
-			const float4 t = *reinterpret_cast<const float4 *>(row + size_t(x0) * 4u);
+			const f32x4 t = *reinterpret_cast<const f32x4 *>(row + size_t(x0) * 4u);
 			v[j][0] = t.x, v[j][1] = t.y, v[j][2] = t.z, v[j][3] = t.w;
 		}
 		else
@@ -98,7 +95,7 @@ __global__ __launch_bounds__(256) void k_hiz(HizParams p)
 		float *l0 = p.chain + p.offset[0];
 #pragma unroll
 		for (int j = 0; j < 4; j++)
-			*reinterpret_cast<float4 *>(l0 + size_t(y0 + j) * p.res_w + x0) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+			*reinterpret_cast<f32x4 *>(l0 + size_t(y0 + j) * p.res_w + x0) = f32x4{v[j][0], v[j][1], v[j][2], v[j][3]};
 	}
 	if (p.mips <= 1)
 		return;
@@ -151,26 +148,18 @@ __global__ __launch_bounds__(256) void k_hiz(HizParams p)
 
 	__syncthreads();
 	if (threadIdx.x == 0)
-	{
-		const int w6 = p.res_w >> 6;
-		p.chain[p.offset[6] + size_t(by) * w6 + bx] = max4(wave_top[0], wave_top[1], wave_top[2], wave_top[3]);
-		if (p.mips > 7)
-		{
-			// Release the tile's mip-6 texel to the other XCDs, then take a ticket.
-			__threadfence();
-			const uint32_t ticket = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-			is_last = (ticket + 1u == p.target) ? 1u : 0u;
-		}
-	}
-	if (p.mips <= 7)
-		return;
-	__syncthreads();
-	if (!is_last)
-		return;
-	if (threadIdx.x == 0)
-		__hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next frame
-	__threadfence(); // acquire every tile's mip 6
+		p.chain[p.offset[6] + size_t(by) * (p.res_w >> 6) + bx] = max4(wave_top[0], wave_top[1], wave_top[2], wave_top[3]);
+}
 
+// Mips 7 and up: what is left after the tiles (at most 128 x 128 texels of mip 6 for a 8192 x 8192 target) is reduced by one
+// workgroup through LDS, folding the odd row / column of non-power-of-two levels.  A second launch on the same stream rather
+// than the shader's "last workgroup takes a ticket" (hiz.comp:355-365): the tiles are written through eight XCD-private L2s,
+// so handing mip 6 to one workgroup inside the launch costs every workgroup an agent-scope release (an L2 write-back) plus a
+// memory-side atomic on one address -- measured ~80 ns per workgroup, serialised: 155 us at 4K against 20 us of streaming.
+// The kernel boundary does the same hand-over once.
+__global__ __launch_bounds__(256) void k_hiz_tail(HizParams p)
+{
+	extern __shared__ float tail_lds[];
 	const int w6 = p.res_w >> 6, h6 = p.res_h >> 6;
 	int pw = max(p.res_w >> 7, 1), ph = max(p.res_h >> 7, 1);
 	float *cur = tail_lds;
@@ -178,9 +167,7 @@ __global__ __launch_bounds__(256) void k_hiz(HizParams p)
 	{
 		const float *l6 = p.chain + p.offset[6];
 		float *l7 = p.chain + p.offset[7];
-		auto fetch6 = [&](int x, int y) {
-			return __hip_atomic_load(l6 + size_t(y) * w6 + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		};
+		auto fetch6 = [&](int x, int y) { return l6[size_t(y) * w6 + x]; };
 		for (int i = threadIdx.x; i < pw * ph; i += 256)
 		{
 			const int y = i / pw, x = i - y * pw;
@@ -259,8 +246,6 @@ int gr_hiz(gr_ctx *ctx, gr_stream stream, const gr_hiz_args *args)
 	p.m1 = args->z_transform[1];
 	p.m2 = args->z_transform[2];
 	p.m3 = args->z_transform[3];
-	p.counter = args->counter;
-	p.target = (res_w / 64u) * (res_h / 64u);
 	for (uint32_t m = ds; m < mips; m++)
 		p.offset[m] = uint32_t(gr_mip_chain_offset(args->chain_width, args->chain_height, 1, m - ds));
 
@@ -274,8 +259,13 @@ int gr_hiz(gr_ctx *ctx, gr_stream stream, const gr_hiz_args *args)
 			return ctx->fail(GR_ERR_INVALID_ARGUMENT, "gr_hiz: %u x %u is beyond the single-launch tail (mip 7 must fit LDS)", res_w, res_h);
 	}
 	gr_scoped_timing timing(ctx, gr_to_stream(stream), "hiz");
-	hipLaunchKernelGGL(k_hiz, dim3(res_w / 64u, res_h / 64u), dim3(256), lds, gr_to_stream(stream), p);
+	hipLaunchKernelGGL(k_hiz_tiles, dim3(res_w / 64u, res_h / 64u), dim3(256), 0, gr_to_stream(stream), p);
 	GR_CHECK_LAUNCH(ctx);
+	if (mips > 7)
+	{
+		hipLaunchKernelGGL(k_hiz_tail, dim3(1), dim3(256), lds, gr_to_stream(stream), p);
+		GR_CHECK_LAUNCH(ctx);
+	}
 	return GR_OK;
 }
 

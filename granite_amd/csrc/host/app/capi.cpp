@@ -211,6 +211,7 @@ static void fill_image_info(gra_resource_info *info, HIP::Image &img, int phys)
 	info->format = img.get_format();
 	info->size_bytes = img.get_size_bytes();
 	info->physical_index = phys;
+	info->levels = img.get_levels();
 }
 
 static void lookup_resource(gra_app *app, const char *name, gra_resource_info *info)

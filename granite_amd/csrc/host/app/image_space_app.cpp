@@ -1,4 +1,5 @@
 #include "image_space_app.hpp"
+#include "../post/spd.hpp"
 #include <chrono>
 #include <cstring>
 
@@ -336,6 +337,18 @@ void ImageSpaceApplication::bake_render_graph()
 			ui_source = "post-aa-output";
 		if (temporal)
 			jitter = saved;
+	}
+
+	if (config.depth_hierarchy)
+	{
+		if (!config.enable_lighting)
+			throw std::logic_error("The depth hierarchy needs the depth attachment of the deferred graph.");
+		setup_depth_hierarchy_pass(graph, tagcat("depth", tag), "depth-hiz", &context, config.depth_hierarchy == 2);
+		// Its consumers are outside the graph: a proxy keeps the pass alive and orders it before the end of the frame.
+		constexpr VkPipelineStageFlags2 compute_stage = VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT;
+		graph.find_pass("depth-hiz")->add_proxy_output("depth-hiz-ready", compute_stage, 0);
+		for (unsigned writer : graph.get_texture_resource(ui_source).get_write_passes())
+			graph.get_pass(writer).add_proxy_input("depth-hiz-ready", compute_stage, 0);
 	}
 
 	graph.set_backbuffer_source(ui_source);

@@ -1,5 +1,6 @@
 #include "hip_device.hpp"
 #include <hip/hip_runtime_api.h>
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -13,8 +14,8 @@ static void throw_hip(hipError_t err, const char *what)
 		throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(err));
 }
 
-Image::Image(Device &device_, unsigned width, unsigned height, VkFormat format, const std::string &name_)
-    : device(&device_), name(name_), owned(true)
+Image::Image(Device &device_, unsigned width, unsigned height, VkFormat format, const std::string &name_, unsigned levels_)
+    : device(&device_), name(name_), owned(true), levels(levels_ ? levels_ : 1)
 {
 	const unsigned bpp = vk_format_block_size(format);
 	if (!bpp)
@@ -25,7 +26,10 @@ Image::Image(Device &device_, unsigned width, unsigned height, VkFormat format, 
 	view.format = format;
 	const unsigned gran = device->get_image_row_granularity();
 	const size_t padded_rows = (size_t(height) + gran - 1) / gran * gran;
-	int ret = gr_alloc(device->get_context(), size_t(view.pitch_bytes) * padded_rows, &view.ptr); // zero-initialised
+	size_t bytes = size_t(view.pitch_bytes) * padded_rows;
+	if (levels > 1)
+		bytes = chain_bytes = gr_mip_chain_size(width, height, bpp, levels);
+	int ret = gr_alloc(device->get_context(), bytes, &view.ptr); // zero-initialised
 	if (ret < 0)
 		throw std::runtime_error(std::string("gr_alloc failed for ") + name + ": " + gr_last_error(device->get_context()));
 	device->account_alloc(ptrdiff_t(get_size_bytes()));
@@ -38,6 +42,19 @@ Image::Image(unsigned width, unsigned height, VkFormat format, void *external_pt
 	view.height = height;
 	view.pitch_bytes = width * vk_format_block_size(format);
 	view.format = format;
+}
+
+gr_image Image::get_level_view(unsigned level) const
+{
+	if (level >= levels)
+		throw std::logic_error("Image level out of range: " + name);
+	const unsigned bpp = vk_format_block_size(VkFormat(view.format));
+	gr_image v = view;
+	v.width = std::max(view.width >> level, 1u);
+	v.height = std::max(view.height >> level, 1u);
+	v.pitch_bytes = v.width * bpp;
+	v.ptr = static_cast<uint8_t *>(view.ptr) + gr_mip_chain_offset(view.width, view.height, bpp, level);
+	return v;
 }
 
 Image::~Image()
@@ -184,9 +201,9 @@ void Device::make_current() const
 	throw_hip(hipSetDevice(index), "hipSetDevice");
 }
 
-ImageHandle Device::create_image(unsigned width, unsigned height, VkFormat format, const std::string &name)
+ImageHandle Device::create_image(unsigned width, unsigned height, VkFormat format, const std::string &name, unsigned levels)
 {
-	return std::make_shared<Image>(*this, width, height, format, name);
+	return std::make_shared<Image>(*this, width, height, format, name, levels);
 }
 
 BufferHandle Device::create_buffer(size_t size, VkBufferUsageFlags usage, const std::string &name)

@@ -15,10 +15,12 @@ namespace HIP
 class Device;
 
 // A linear row-major 2-D image in HBM.  Owns its memory unless wrapping an external pointer (swapchain image).
+// With levels > 1 the allocation holds a mip chain, level after level, each level tightly packed
+// (gr_mip_chain_offset); get_view() is level 0.
 class Image
 {
 public:
-	Image(Device &device, unsigned width, unsigned height, VkFormat format, const std::string &name);
+	Image(Device &device, unsigned width, unsigned height, VkFormat format, const std::string &name, unsigned levels = 1);
 	Image(unsigned width, unsigned height, VkFormat format, void *external_ptr);
 	~Image();
 	Image(const Image &) = delete;
@@ -29,7 +31,9 @@ public:
 	unsigned get_width() const { return view.width; }
 	unsigned get_height() const { return view.height; }
 	VkFormat get_format() const { return VkFormat(view.format); }
-	size_t get_size_bytes() const { return size_t(view.pitch_bytes) * view.height; }
+	size_t get_size_bytes() const { return levels > 1 ? chain_bytes : size_t(view.pitch_bytes) * view.height; }
+	unsigned get_levels() const { return levels; }
+	gr_image get_level_view(unsigned level) const; // Vulkan::ImageView with base_level = level, levels = 1
 	void *get_device_pointer() const { return view.ptr; }
 	const std::string &get_name() const { return name; }
 
@@ -38,6 +42,8 @@ private:
 	gr_image view = {};
 	std::string name;
 	bool owned = false;
+	unsigned levels = 1;
+	size_t chain_bytes = 0;
 };
 using ImageHandle = std::shared_ptr<Image>;
 using ImageView = Image; // callbacks receive HIP::ImageView& where the reference hands out Vulkan::ImageView&
@@ -117,7 +123,7 @@ public:
 	void make_current() const; // hipSetDevice for the calling thread
 	gr_stream get_stream(CommandBuffer::Type type) const { return streams[int(type)]; }
 
-	ImageHandle create_image(unsigned width, unsigned height, VkFormat format, const std::string &name);
+	ImageHandle create_image(unsigned width, unsigned height, VkFormat format, const std::string &name, unsigned levels = 1);
 	BufferHandle create_buffer(size_t size, VkBufferUsageFlags usage, const std::string &name);
 
 	// Images are allocated with their row count rounded up to a multiple of this (row-band all-gathers write

@@ -853,9 +853,9 @@ void RenderGraph::setup_physical_image(HIP::Device &device_, unsigned attachment
 		return;
 	}
 	bool reuse = slot && (att.flags & ATTACHMENT_INFO_PERSISTENT_BIT) != 0 && slot->get_format() == att.format &&
-	             slot->get_width() == att.width && slot->get_height() == att.height;
+	             slot->get_width() == att.width && slot->get_height() == att.height && slot->get_levels() == att.levels;
 	if (!reuse)
-		slot = device_.create_image(att.width, att.height, att.format, att.name);
+		slot = device_.create_image(att.width, att.height, att.format, att.name, att.levels);
 	physical_attachments[attachment] = slot.get();
 }
 

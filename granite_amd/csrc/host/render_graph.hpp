@@ -460,6 +460,7 @@ public:
 	// Introspection used by the tests and by log().
 	const std::vector<unsigned> &get_baked_pass_order() const { return pass_stack; }
 	const RenderPass &get_pass(unsigned index) const { return *passes[index]; }
+	RenderPass &get_pass(unsigned index) { return *passes[index]; }
 	const std::vector<ResourceDimensions> &get_physical_dimensions() const { return physical_dimensions; }
 	bool physical_resource_has_history(unsigned index) const { return physical_image_has_history[index]; }
 	unsigned get_swapchain_physical_index() const { return swapchain_physical_index; }

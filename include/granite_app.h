@@ -55,6 +55,11 @@ typedef struct gra_config
 	/* 0 (reference behaviour): attachment images of identical geometry with disjoint lifetimes inside the frame share
 	 * one allocation (RenderGraph::build_aliases, render_graph.cpp:1548-1746); 1: every image gets its own. */
 	int32_t disable_image_aliasing;
+	/* Depth hierarchy of the frame's depth attachment (setup_depth_hierarchy_pass, renderer/post/spd.cpp:196-232), resource
+	 * "depth-hiz": 0 = none, 1 = full chain, 2 = output_downsample (no full-resolution level).  Needs enable_lighting.
+	 * The pass is tied to the end of the frame through a proxy resource, as its consumers (occlusion culling, SSR) live
+	 * outside this build. */
+	int32_t depth_hierarchy;
 } gra_config;
 
 /* Scene-level light description (one PositionalLight + its node transform). */
@@ -98,8 +103,9 @@ typedef struct gra_resource_info
 {
 	void *device_ptr;
 	uint32_t width, height, format; /* 0 x 0 for buffers */
-	uint64_t size_bytes;
+	uint64_t size_bytes;            /* whole mip chain when levels > 1 (gr_mip_chain_size) */
 	int32_t physical_index;
+	uint32_t levels;                /* 1 unless the attachment was declared with a mip chain; 0 for buffers */
 } gra_resource_info;
 int gra_get_resource(gra_app *app, const char *name, gra_resource_info *info);
 int gra_read_resource(gra_app *app, const char *name, void *dst_host, uint64_t size_bytes);

@@ -372,10 +372,12 @@ int gr_taa_resolve(gr_ctx *ctx, gr_stream stream, const gr_image *current, const
                    const gr_image *history, const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality);
 
 /* ---- depth hierarchy ---------------------------------------------------------------------------------------------------
- * HiZPassState::build_render_pass (renderer/post/spd.cpp:141-194) + assets/shaders/post/hiz.comp: one launch turns the
- * depth attachment into a full max-reduction mip chain of linearised depth.  Workgroups reduce 64 x 64 tiles down to one
- * texel (mips 0..6); the last workgroup to finish (atomic counter, hiz.comp:355-365) reduces what is left, folding in the
- * odd row / column of non-power-of-two levels.
+ * HiZPassState::build_render_pass (renderer/post/spd.cpp:141-194) + assets/shaders/post/hiz.comp: turns the depth
+ * attachment into a full max-reduction mip chain of linearised depth.  Workgroups reduce 64 x 64 tiles down to one texel
+ * (mips 0..6); one more workgroup reduces what is left, folding in the odd row / column of non-power-of-two levels.  The
+ * shader hands over inside one dispatch through an atomic counter (hiz.comp:355-365); with eight XCD-private L2s that
+ * hand-over is cheaper as a second, one-workgroup launch on the same stream, so the counter is accepted for interface
+ * parity but not touched.
  *
  * Mip chains live in one allocation, level after level, each level tightly packed; level l of a w x h chain is
  * max(w >> l, 1) x max(h >> l, 1) texels (gr_mip_chain_offset / gr_mip_chain_size, in bytes). */
@@ -391,7 +393,7 @@ typedef struct gr_hiz_args
 	uint32_t chain_levels;     /* spd.cpp:212: max(1, floor_log2(max(w, h)) - output_downsample) */
 	uint32_t output_downsample; /* 1: the transformed full-resolution level is not stored; chain level 0 is mip 1 */
 	float z_transform[4];      /* column-major mat2, spd.cpp:164-165: depth -> (num, den), stored value min(num / den, 1e30) */
-	uint32_t *counter;         /* one zero-initialised uint32 (the pass's "-counter" buffer); left at zero */
+	uint32_t *counter;         /* the pass's "-counter" buffer (one uint32); never written, stays zero */
 } gr_hiz_args;
 int gr_hiz(gr_ctx *ctx, gr_stream stream, const gr_hiz_args *args);
 

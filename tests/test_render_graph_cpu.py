@@ -120,3 +120,23 @@ def test_gbuffer_and_lighting_form_one_physical_pass_like_the_reference():
     others = [v for k, v in pp.items() if k not in ("gbuffer-main", "lighting-main")]
     assert len(set(others)) == len(others) and pp["gbuffer-main"] not in others
     assert [p["physical_pass"] for p in g["passes"]] == sorted(p["physical_pass"] for p in g["passes"])
+
+
+def test_depth_hierarchy_pass_is_kept_alive_by_a_proxy_and_sized_in_whole_tiles():
+    """setup_depth_hierarchy_pass (spd.cpp:196-232): chain = input rounded up to multiples of 64 (halved with
+    output_downsample), plus a 4-byte counter; a proxy resource (render_graph.hpp:513-514) ties the otherwise unconsumed
+    pass to the end of the frame.  It reads "depth-main", which the lighting pass publishes, and joins the frame front."""
+    g = graph_of(1280, 720, depth_hierarchy=1)
+    order = [p["name"] for p in g["passes"]]
+    assert order == ["clustering-bindless", "gbuffer-main", "lighting-main", "depth-hiz", "bloom-compute", "tonemap"]
+    res = {r["name"]: r for r in g["resources"]}
+    assert (res["depth-hiz"]["width"], res["depth-hiz"]["height"], res["depth-hiz"]["format"]) == (1280, 768, 100)
+    assert res["depth-hiz-counter"]["buffer_size"] == 4
+    assert res["depth-hiz-ready"]["width"] == 0 and res["depth-hiz-ready"]["buffer_size"] == 0  # proxy: no memory
+    assert {p["name"]: p["stream"] for p in g["passes"]}["depth-hiz"] == "front"
+    g2 = graph_of(1280, 720, depth_hierarchy=2)
+    res2 = {r["name"]: r for r in g2["resources"]}
+    assert (res2["depth-hiz"]["width"], res2["depth-hiz"]["height"]) == (640, 384)
+    assert "depth-hiz" not in {p["name"] for p in graph_of(1280, 720)["passes"]}
+    with pytest.raises(capi.GraniteHipError):
+        graph_of(256, 256, lighting=False, depth_hierarchy=1)
