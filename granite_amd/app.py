@@ -47,7 +47,8 @@ EXPORTED_SYMBOLS = [
     "gra_get_render_parameters", "gra_set_lights", "gra_upload_gbuffer", "gra_render_frames", "gra_sync",
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
-    "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_allocated_bytes", "gra_set_exchange_callback", "gra_get_strip_plan",
+    "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
+    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_set_exchange_callback", "gra_get_strip_plan",
     "gra_comm_create_unique_id", "gra_comm_init",
 ]
 
@@ -87,6 +88,11 @@ def load_library() -> C.CDLL:
         "gra_set_smaa_luts": (C.c_int, [vp, vp, vp]),
         "gra_get_host_stats": (C.c_int, [vp, vp]),
         "gra_get_allocated_bytes": (C.c_int, [vp, vp]),
+        "gra_gtx_probe": (C.c_int, [C.c_char_p, vp, vp, C.c_size_t]),
+        "gra_gtx_read": (C.c_int, [C.c_char_p, vp, C.c_uint64, vp, C.c_size_t]),
+        "gra_gtx_write": (C.c_int, [C.c_char_p, vp, vp, vp, C.c_size_t]),
+        "gra_upload_gbuffer_gtx": (C.c_int, [vp] + [C.c_char_p] * 6),
+        "gra_save_resource_gtx": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
         "gra_set_exchange_callback": (C.c_int, [vp, EXCHANGE_FN, vp]),
         "gra_get_strip_plan": (C.c_int, [vp, vp]),
         "gra_comm_create_unique_id": (C.c_int, [vp]),
@@ -177,6 +183,15 @@ class Application:
                 for k in ("emissive", "albedo", "normal", "pbr", "depth")]
         mv = None if motion_vectors is None else np.ascontiguousarray(motion_vectors)
         self._check(self.lib.gra_upload_gbuffer(self.handle, *[_ptr(k) for k in keep], _ptr(mv)))
+
+    def upload_gbuffer_gtx(self, emissive=None, albedo=None, normal=None, pbr=None, depth=None, motion_vectors=None):
+        """G-buffer attachments from .gtx files (paths; None = unchanged)."""
+        paths = [None if p is None else str(p).encode() for p in (emissive, albedo, normal, pbr, depth, motion_vectors)]
+        self._check(self.lib.gra_upload_gbuffer_gtx(self.handle, *paths))
+
+    def save_gtx(self, path: str, name: Optional[str] = None):
+        """Write graph texture `name` (None = the last backbuffer) as .gtx."""
+        self._check(self.lib.gra_save_resource_gtx(self.handle, None if name is None else name.encode(), str(path).encode()))
 
     def upload_hdr(self, hdr_bits: np.ndarray):
         self.upload_gbuffer({"emissive": hdr_bits})

@@ -1,5 +1,6 @@
 // extern "C" surface of the harness (include/granite_app.h).  Exceptions from the C++ layer stop here.
 #include "image_space_app.hpp"
+#include "../gtx.hpp"
 #include <cstdio>
 #include <cstring>
 
@@ -31,6 +32,35 @@ static int guarded(gra_app *app, Fn &&fn)
 static void unpack_mat4(mat4 &m, const float *src)
 {
 	memcpy(m.data(), src, 16 * sizeof(float));
+}
+
+template <typename Fn>
+static int guarded_message(char *error, size_t error_size, Fn &&fn)
+{
+	try
+	{
+		fn();
+		return 0;
+	}
+	catch (const std::exception &e)
+	{
+		if (error && error_size)
+			snprintf(error, error_size, "%s", e.what());
+		return -1;
+	}
+}
+
+static void fill_gtx_info(gra_gtx_info *info, const GtxImage &img)
+{
+	info->type = img.type;
+	info->format = uint32_t(img.format);
+	info->width = img.width;
+	info->height = img.height;
+	info->depth = img.depth;
+	info->layers = img.layers;
+	info->levels = img.levels;
+	info->flags = img.flags;
+	info->payload_size = img.payload.size();
 }
 
 extern "C" {
@@ -119,6 +149,57 @@ int gra_upload_gbuffer(gra_app *app, const void *emissive, const void *albedo, c
                        const void *mv)
 {
 	return guarded(app, [&]() { app->app->upload_gbuffer(emissive, albedo, normal, pbr, depth, mv); });
+}
+
+int gra_gtx_probe(const char *path, gra_gtx_info *info, char *error, size_t error_size)
+{
+	return guarded_message(error, error_size, [&]() {
+		if (!path || !info)
+			throw std::logic_error("gra_gtx_probe: null argument");
+		fill_gtx_info(info, gtx_load(path));
+	});
+}
+
+int gra_gtx_read(const char *path, void *payload, uint64_t payload_capacity, char *error, size_t error_size)
+{
+	return guarded_message(error, error_size, [&]() {
+		if (!path || !payload)
+			throw std::logic_error("gra_gtx_read: null argument");
+		auto img = gtx_load(path);
+		if (img.payload.size() > payload_capacity)
+			throw std::logic_error("gra_gtx_read: destination is smaller than the payload");
+		memcpy(payload, img.payload.data(), img.payload.size());
+	});
+}
+
+int gra_gtx_write(const char *path, const gra_gtx_info *info, const void *payload, char *error, size_t error_size)
+{
+	return guarded_message(error, error_size, [&]() {
+		if (!path || !info || !payload)
+			throw std::logic_error("gra_gtx_write: null argument");
+		GtxImage img;
+		img.type = info->type;
+		img.format = VkFormat(info->format);
+		img.width = info->width;
+		img.height = info->height;
+		img.depth = info->depth;
+		img.layers = info->layers;
+		img.levels = info->levels;
+		img.flags = info->flags;
+		if (info->payload_size != img.required_payload_size())
+			throw std::logic_error("gra_gtx_write: payload_size does not match the layout of the described image");
+		img.payload.assign(static_cast<const uint8_t *>(payload), static_cast<const uint8_t *>(payload) + info->payload_size);
+		gtx_save(img, path);
+	});
+}
+
+int gra_upload_gbuffer_gtx(gra_app *app, const char *emissive, const char *albedo, const char *normal, const char *pbr,
+                           const char *depth, const char *motion_vectors)
+{
+	return guarded(app, [&]() {
+		const char *paths[6] = {emissive, albedo, normal, pbr, depth, motion_vectors};
+		app->app->upload_gbuffer_gtx(paths);
+	});
 }
 
 int gra_render_frames(gra_app *app, uint32_t count, int32_t sync)
@@ -255,6 +336,25 @@ int gra_read_resource(gra_app *app, const char *name, void *dst_host, uint64_t s
 		auto *ctx = app->app->get_device().get_context();
 		if (gr_download(ctx, nullptr, dst_host, info.device_ptr, size_bytes) < 0)
 			throw std::runtime_error(gr_last_error(ctx));
+	});
+}
+
+int gra_save_resource_gtx(gra_app *app, const char *name, const char *path)
+{
+	return guarded(app, [&]() {
+		if (!path)
+			throw std::logic_error("gra_save_resource_gtx: null path");
+		if (!name)
+		{
+			auto *bb = app->app->get_last_backbuffer();
+			if (!bb)
+				throw std::logic_error("no frame rendered yet");
+			app->app->save_image_gtx(*bb, path);
+			return;
+		}
+		auto &graph = app->app->get_graph();
+		auto &tex = graph.get_texture_resource(name);
+		app->app->save_image_gtx(graph.get_physical_texture_resource(tex), path);
 	});
 }
 

@@ -1,4 +1,5 @@
 #include "image_space_app.hpp"
+#include "../gtx.hpp"
 #include "../post/spd.hpp"
 #include <chrono>
 #include <cstring>
@@ -179,6 +180,61 @@ void ImageSpaceApplication::upload_gbuffer(const void *emissive, const void *alb
 	upload(src_mv, mv, "motion-vector");
 	gbuffer_dirty = true;
 	filled_targets.clear();
+}
+
+void ImageSpaceApplication::upload_gbuffer_gtx(const char *const paths[6])
+{
+	struct Slot
+	{
+		const char *what;
+		VkFormat formats[2];
+	};
+	static const Slot slots[6] = {
+		{"emissive", {VK_FORMAT_R16G16B16A16_SFLOAT, VK_FORMAT_R16G16B16A16_SFLOAT}},
+		{"albedo", {VK_FORMAT_R8G8B8A8_SRGB, VK_FORMAT_R8G8B8A8_UNORM}},
+		{"normal", {VK_FORMAT_A2B10G10R10_UNORM_PACK32, VK_FORMAT_A2B10G10R10_UNORM_PACK32}},
+		{"pbr", {VK_FORMAT_R8G8_UNORM, VK_FORMAT_R8G8_UNORM}},
+		{"depth", {VK_FORMAT_D32_SFLOAT, VK_FORMAT_R32_SFLOAT}},
+		{"motion-vector", {VK_FORMAT_R16G16_SFLOAT, VK_FORMAT_R16G16_SFLOAT}},
+	};
+	GtxImage images[6];
+	const void *level0[6] = {};
+	for (int i = 0; i < 6; i++)
+	{
+		if (!paths[i])
+			continue;
+		images[i] = gtx_load(paths[i]);
+		auto &img = images[i];
+		if (img.type != 1 || img.layers != 1 || img.depth != 1)
+			throw std::runtime_error(std::string(paths[i]) + ": a 2-D single-layer image is expected for " + slots[i].what + ".");
+		if (img.format != slots[i].formats[0] && img.format != slots[i].formats[1])
+			throw std::runtime_error(std::string(paths[i]) + ": wrong format for the " + slots[i].what + " attachment.");
+		if (img.width != config.width || img.height != config.height)
+			throw std::runtime_error(std::string(paths[i]) + ": " + std::to_string(img.width) + " x " + std::to_string(img.height) +
+			                         " does not match the configured frame.");
+		level0[i] = img.payload.data() + img.level_offset(0);
+	}
+	upload_gbuffer(level0[0], level0[1], level0[2], level0[3], level0[4], level0[5]);
+}
+
+void ImageSpaceApplication::save_image_gtx(HIP::Image &image, const std::string &path)
+{
+	auto &device = get_device();
+	device.wait_idle();
+	GtxImage out;
+	out.format = image.get_format();
+	out.width = image.get_width();
+	out.height = image.get_height();
+	out.levels = image.get_levels();
+	out.payload.assign(out.required_payload_size(), 0);
+	// The executor packs mip levels back to back; GTX starts each one on a 16-byte boundary.
+	for (unsigned level = 0; level < out.levels; level++)
+	{
+		const gr_image view = image.get_level_view(level);
+		if (gr_download(device.get_context(), nullptr, out.payload.data() + out.level_offset(level), view.ptr, out.level_size(level)) < 0)
+			throw std::runtime_error(gr_last_error(device.get_context()));
+	}
+	gtx_save(out, path);
 }
 
 // Config-1 style graph head: an "HDR-main" colour target filled from the uploaded HDR image (tools/aa_bench.cpp:80-101

@@ -62,6 +62,9 @@ public:
 		out[1] = host_seconds;
 		out[2] = device_holder ? device_holder->get_blocked_seconds() : 0.0;
 	}
+	// G-buffer attachments from .gtx files (any may be null); the frame written back as .gtx.
+	void upload_gbuffer_gtx(const char *const paths[6]);
+	void save_image_gtx(HIP::Image &image, const std::string &path);
 	std::string last_error;
 
 private:

@@ -94,6 +94,25 @@ int gra_set_lights(gra_app *app, const gra_light_desc *lights, uint32_t count);
 int gra_upload_gbuffer(gra_app *app, const void *emissive_rgba16f, const void *albedo_rgba8, const void *normal_a2b10g10r10,
                        const void *pbr_rg8, const void *depth_d32f, const void *motion_vectors_rg16f);
 
+/* ---- GTX ("GRANITE TEXFMT1", vulkan/texture/memory_mapped_texture.cpp:29-44): the container Granite keeps textures and
+ * image dumps in -- the wire format on either side of this path.  Header fields as stored; payload = mip levels in order,
+ * each at a 16-byte aligned offset (vulkan/texture/texture_format.cpp:349-387). */
+typedef struct gra_gtx_info
+{
+	uint32_t type, format, width, height, depth, layers, levels, flags;
+	uint64_t payload_size;
+} gra_gtx_info;
+int gra_gtx_probe(const char *path, gra_gtx_info *info, char *error, size_t error_size);
+int gra_gtx_read(const char *path, void *payload, uint64_t payload_capacity, char *error, size_t error_size);
+int gra_gtx_write(const char *path, const gra_gtx_info *info, const void *payload, char *error, size_t error_size);
+/* gra_upload_gbuffer from .gtx files (2-D, one layer, level 0 is used).  Formats must be the attachment's own:
+ * emissive / HDR R16G16B16A16_SFLOAT, albedo R8G8B8A8_SRGB or _UNORM, normal A2B10G10R10_UNORM_PACK32, pbr R8G8_UNORM,
+ * depth D32_SFLOAT or R32_SFLOAT, motion vectors R16G16_SFLOAT; sizes must equal the configured frame.  NULL = unchanged. */
+int gra_upload_gbuffer_gtx(gra_app *app, const char *emissive, const char *albedo, const char *normal, const char *pbr,
+                           const char *depth, const char *motion_vectors);
+/* Writes a graph texture (all its mip levels) or, with name == NULL, the last rendered backbuffer as .gtx. */
+int gra_save_resource_gtx(gra_app *app, const char *name, const char *path);
+
 /* Application::run_frame x count; asynchronous unless sync != 0. */
 int gra_render_frames(gra_app *app, uint32_t count, int32_t sync);
 int gra_sync(gra_app *app);
