@@ -26,7 +26,8 @@ class Config(C.Structure):
                 ("cluster_res", C.c_uint32 * 3), ("frame_time", C.c_float), ("directional_color", C.c_float * 3),
                 ("directional_direction", C.c_float * 3), ("enable_timestamps", C.c_int32),
                 ("strip_index", C.c_uint32), ("strip_count", C.c_uint32),
-                ("disable_image_aliasing", C.c_int32), ("depth_hierarchy", C.c_int32)]
+                ("disable_image_aliasing", C.c_int32), ("depth_hierarchy", C.c_int32),
+                ("resolution_scale", C.c_float), ("resolution_scale_sharpen", C.c_int32), ("fsr_fp32", C.c_int32)]
 
 
 # void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream)
@@ -48,7 +49,7 @@ EXPORTED_SYMBOLS = [
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
     "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
-    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_set_exchange_callback", "gra_get_strip_plan",
+    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_set_exchange_callback", "gra_get_strip_plan",
     "gra_comm_create_unique_id", "gra_comm_init",
 ]
 
@@ -88,6 +89,7 @@ def load_library() -> C.CDLL:
         "gra_set_smaa_luts": (C.c_int, [vp, vp, vp]),
         "gra_get_host_stats": (C.c_int, [vp, vp]),
         "gra_get_allocated_bytes": (C.c_int, [vp, vp]),
+        "gra_get_render_size": (C.c_int, [vp, vp, vp]),
         "gra_gtx_probe": (C.c_int, [C.c_char_p, vp, vp, C.c_size_t]),
         "gra_gtx_read": (C.c_int, [C.c_char_p, vp, C.c_uint64, vp, C.c_size_t]),
         "gra_gtx_write": (C.c_int, [C.c_char_p, vp, vp, vp, C.c_size_t]),
@@ -116,7 +118,8 @@ class Application:
                  dynamic_exposure: bool = True, compute_post: bool = True, post_aa: int = POST_AA_NONE,
                  pre_aa: int = POST_AA_NONE, rmw_emissive: bool = False, cluster_res=synth.CLUSTER_RESOLUTION,
                  frame_time: float = synth.FRAME_TIME, timestamps: bool = False, strip_index: int = 0, strip_count: int = 1,
-                 alias_images: bool = True, depth_hierarchy: int = 0):
+                 alias_images: bool = True, depth_hierarchy: int = 0,
+                 resolution_scale: float = 1.0, resolution_scale_sharpen: bool = True, fsr_fp16: bool = True):
         self.lib = load_library()
         cfg = Config()
         cfg.device, cfg.width, cfg.height = device, width, height
@@ -131,6 +134,8 @@ class Application:
         cfg.strip_index, cfg.strip_count = strip_index, strip_count
         cfg.disable_image_aliasing = int(not alias_images)
         cfg.depth_hierarchy = int(depth_hierarchy)
+        cfg.resolution_scale = float(resolution_scale)
+        cfg.resolution_scale_sharpen, cfg.fsr_fp32 = int(resolution_scale_sharpen), int(not fsr_fp16)
         self._exchange_ref = None
         self.config = cfg
         self.width, self.height = width, height
@@ -328,6 +333,12 @@ class Application:
         out = np.zeros(3, np.float64)
         self._check(self.lib.gra_get_host_stats(self.handle, out.ctypes.data))
         return {"frames": int(out[0]), "seconds": float(out[1]), "blocked_seconds": float(out[2])}
+
+    def render_size(self):
+        """(width, height) the G-buffer is rendered and uploaded at (backbuffer size x resolution_scale)."""
+        w, h = C.c_uint32(0), C.c_uint32(0)
+        self._check(self.lib.gra_get_render_size(self.handle, C.byref(w), C.byref(h)))
+        return int(w.value), int(h.value)
 
     def allocated_bytes(self) -> int:
         out = C.c_uint64(0)

@@ -222,6 +222,8 @@ def load_library() -> C.CDLL:
         "gr_smaa_neighbor_blend": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushSmaa)]),
         "gr_taa_resolve": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), P(Image), P(Image), P(PushTaa), C.c_int]),
         "gr_hiz": (C.c_int, [vp, vp, P(HizArgs)]),
+        "gr_fsr_upscale": (C.c_int, [vp, vp, P(Image), P(Image), C.c_int]),
+        "gr_fsr_sharpen": (C.c_int, [vp, vp, P(Image), P(Image), C.c_float]),
         "gr_mip_chain_offset": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
         "gr_mip_chain_size": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     }
@@ -240,7 +242,7 @@ EXPORTED_SYMBOLS = [
     "gr_bloom_threshold_rows", "gr_bloom_downsample_rows", "gr_bloom_upsample_rows", "gr_tonemap_rows",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
     "gr_smaa_set_luts", "gr_fxaa", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
-    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size",
+    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen",
 ]
 
 
@@ -416,6 +418,12 @@ class Context:
         self.check(self.lib.gr_taa_resolve(self.handle, stream, current.desc, depth.desc, mv.desc,
                                            history.desc if history is not None else None, out_color.desc, out_history.desc, push,
                                            quality))
+
+    def fsr_upscale(self, src: DeviceImage, out: DeviceImage, fp16: bool = True, stream=None):
+        self.check(self.lib.gr_fsr_upscale(self.handle, stream, src.desc, out.desc, int(fp16)))
+
+    def fsr_sharpen(self, src: DeviceImage, out: DeviceImage, sharpness: float, stream=None):
+        self.check(self.lib.gr_fsr_sharpen(self.handle, stream, src.desc, out.desc, C.c_float(sharpness)))
 
     def hiz(self, depth: DeviceImage, z_transform, output_downsample: bool = False, chain: Optional[DeviceBuffer] = None,
             counter: Optional[DeviceBuffer] = None, stream=None):

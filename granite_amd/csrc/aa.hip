@@ -34,16 +34,16 @@ struct Tex8
 		if (CH == 4)
 		{
 			const uint32_t t = *reinterpret_cast<const uint32_t *>(p);
-			r = mk4(float(t & 255u) / 255.0f, float((t >> 8) & 255u) / 255.0f, float((t >> 16) & 255u) / 255.0f, float(t >> 24) / 255.0f);
+			r = mk4(unorm8_to_float(t & 255u), unorm8_to_float((t >> 8) & 255u), unorm8_to_float((t >> 16) & 255u), unorm8_to_float(t >> 24));
 		}
 		else if (CH == 2)
 		{
 			const uint32_t t = *reinterpret_cast<const uint16_t *>(p);
-			r.x = float(t & 255u) / 255.0f;
-			r.y = float(t >> 8) / 255.0f;
+			r.x = unorm8_to_float(t & 255u);
+			r.y = unorm8_to_float(t >> 8);
 		}
 		else
-			r.x = float(p[0]) / 255.0f;
+			r.x = unorm8_to_float(p[0]);
 		return r;
 	}
 

@@ -26,6 +26,16 @@ struct DevImageRW
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
+// UNORM8 -> float: v / 255 for an integer v in [0, 255], bit-identical to the IEEE quotient for all 256 inputs
+// (tests/test_oracle_kat.py) at three VALU operations instead of a full division: one Newton step on v * (1 / 255).
+__device__ __forceinline__ float unorm8_to_float(uint32_t v)
+{
+	const float f = float(v);
+	const float r = 1.0f / 255.0f;
+	const float q = f * r;
+	return fmaf(fmaf(-q, 255.0f, f), r, q);
+}
+
 // RGBA16F texel fetch: one 8-byte load, hardware cvt to fp32.
 __device__ __forceinline__ float4 load_rgba16f(const DevImage &img, int x, int y)
 {

@@ -202,6 +202,16 @@ int gra_upload_gbuffer_gtx(gra_app *app, const char *emissive, const char *albed
 	});
 }
 
+int gra_get_render_size(gra_app *app, uint32_t *width, uint32_t *height)
+{
+	return guarded(app, [&]() {
+		if (!width || !height)
+			throw std::logic_error("gra_get_render_size: null output");
+		*width = app->app->get_render_width();
+		*height = app->app->get_render_height();
+	});
+}
+
 int gra_render_frames(gra_app *app, uint32_t count, int32_t sync)
 {
 	return guarded(app, [&]() {

@@ -2,6 +2,7 @@
 #include "../gtx.hpp"
 #include "../post/spd.hpp"
 #include <chrono>
+#include <cmath>
 #include <cstring>
 
 namespace Granite
@@ -17,6 +18,18 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 		device_holder = std::make_unique<HIP::Device>(config.device);
 	if (!config.width || !config.height)
 		throw std::logic_error("Backbuffer dimensions must be non-zero.");
+	if (config.resolution_scale < 0.0f || config.resolution_scale > 1.0f)
+		throw std::logic_error("resolution_scale must be in (0, 1].");
+	render_width = config.width;
+	render_height = config.height;
+	if (scaled())
+	{
+		// ceil(size * scale), as the graph resolves SwapchainRelative sizes (render_graph.cpp:3158-3170)
+		render_width = std::max(unsigned(std::ceil(float(config.width) * config.resolution_scale)), 1u);
+		render_height = std::max(unsigned(std::ceil(float(config.height) * config.resolution_scale)), 1u);
+		if (config.strip_count > 1)
+			throw std::logic_error("Row-band tiling and resolution scaling cannot be combined.");
+	}
 	if (!config.cluster_res[0])
 	{
 		// SceneViewerApplication: cluster->set_resolution(128, 64, 4096) (scene_viewer_application.cpp:407)
@@ -61,13 +74,13 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 	for (unsigned i = 0; i < 4; i++)
 		swapchain.push_back(device.create_image(config.width, config.height, VK_FORMAT_R8G8B8A8_SRGB, "swapchain-" + std::to_string(i)));
 
-	src_emissive = device.create_image(config.width, config.height, VK_FORMAT_R16G16B16A16_SFLOAT, "src-emissive");
+	src_emissive = device.create_image(render_width, render_height, VK_FORMAT_R16G16B16A16_SFLOAT, "src-emissive");
 	if (config.enable_lighting)
 	{
-		src_albedo = device.create_image(config.width, config.height, VK_FORMAT_R8G8B8A8_SRGB, "src-albedo");
-		src_normal = device.create_image(config.width, config.height, VK_FORMAT_A2B10G10R10_UNORM_PACK32, "src-normal");
-		src_pbr = device.create_image(config.width, config.height, VK_FORMAT_R8G8_UNORM, "src-pbr");
-		src_depth = device.create_image(config.width, config.height, VK_FORMAT_D32_SFLOAT, "src-depth");
+		src_albedo = device.create_image(render_width, render_height, VK_FORMAT_R8G8B8A8_SRGB, "src-albedo");
+		src_normal = device.create_image(render_width, render_height, VK_FORMAT_A2B10G10R10_UNORM_PACK32, "src-normal");
+		src_pbr = device.create_image(render_width, render_height, VK_FORMAT_R8G8_UNORM, "src-pbr");
+		src_depth = device.create_image(render_width, render_height, VK_FORMAT_D32_SFLOAT, "src-depth");
 	}
 }
 
@@ -176,7 +189,7 @@ void ImageSpaceApplication::upload_gbuffer(const void *emissive, const void *alb
 	upload(src_pbr, pbr, "pbr");
 	upload(src_depth, depth, "depth");
 	if (mv && !src_mv)
-		src_mv = device.create_image(config.width, config.height, VK_FORMAT_R16G16_SFLOAT, "src-mv");
+		src_mv = device.create_image(render_width, render_height, VK_FORMAT_R16G16_SFLOAT, "src-mv");
 	upload(src_mv, mv, "motion-vector");
 	gbuffer_dirty = true;
 	filled_targets.clear();
@@ -209,7 +222,7 @@ void ImageSpaceApplication::upload_gbuffer_gtx(const char *const paths[6])
 			throw std::runtime_error(std::string(paths[i]) + ": a 2-D single-layer image is expected for " + slots[i].what + ".");
 		if (img.format != slots[i].formats[0] && img.format != slots[i].formats[1])
 			throw std::runtime_error(std::string(paths[i]) + ": wrong format for the " + slots[i].what + " attachment.");
-		if (img.width != config.width || img.height != config.height)
+		if (img.width != render_width || img.height != render_height)
 			throw std::runtime_error(std::string(paths[i]) + ": " + std::to_string(img.width) + " x " + std::to_string(img.height) +
 			                         " does not match the configured frame.");
 		level0[i] = img.payload.data() + img.level_offset(0);
@@ -243,6 +256,8 @@ void ImageSpaceApplication::add_hdr_input_pass(const std::string &tag)
 {
 	AttachmentInfo hdr;
 	hdr.format = VK_FORMAT_R16G16B16A16_SFLOAT;
+	if (scaled())
+		hdr.size_x = hdr.size_y = config.resolution_scale;
 	auto &pass = graph.add_pass(tagcat("hdr-input", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
 	auto &out = pass.add_color_output(tagcat("HDR", tag), hdr);
 	pass.set_build_render_pass([this, &out](HIP::CommandBuffer &cmd) {
@@ -258,6 +273,8 @@ void ImageSpaceApplication::add_mv_pass(const std::string &tag)
 {
 	AttachmentInfo mv;
 	mv.format = VK_FORMAT_R16G16_SFLOAT;
+	if (scaled())
+		mv.size_x = mv.size_y = config.resolution_scale;
 	auto &pass = graph.add_pass(tagcat("mv", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
 	auto &out = pass.add_color_output(tagcat("mv", tag), mv);
 	pass.set_build_render_pass([this, &out](HIP::CommandBuffer &cmd) {
@@ -279,6 +296,9 @@ void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
 	normal.format = VK_FORMAT_A2B10G10R10_UNORM_PACK32;
 	pbr.format = VK_FORMAT_R8G8_UNORM;
 	depth.format = VK_FORMAT_D32_SFLOAT;
+	if (scaled()) // scene_viewer_application.cpp:758-761,888-889
+		for (auto *info : {&emissive, &albedo, &normal, &pbr, &depth})
+			info->size_x = info->size_y = config.resolution_scale;
 
 	// The G-buffer producer: Granite rasterises the scene here; the harness copies the synthetic attachments in.
 	// Attachments persist across frames, so only what a later pass clobbers (emissive under the RMW declaration) is
@@ -393,6 +413,12 @@ void ImageSpaceApplication::bake_render_graph()
 			ui_source = "post-aa-output";
 		if (temporal)
 			jitter = saved;
+	}
+
+	if (scaled()) // scene_viewer_application.cpp:1263-1268
+	{
+		if (setup_after_post_chain_upscaling(graph, ui_source, "post-scale-output", config.resolution_scale_sharpen != 0, config.fsr_fp32 == 0))
+			ui_source = "post-scale-output";
 	}
 
 	if (config.depth_hierarchy)

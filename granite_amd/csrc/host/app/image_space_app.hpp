@@ -51,6 +51,8 @@ public:
 	LightClusterer &get_clusterer() { return cluster; }
 	HIP::Image *get_last_backbuffer() { return last_backbuffer; }
 	const gra_config &get_config() const { return config; }
+	unsigned get_render_width() const { return render_width; }
+	unsigned get_render_height() const { return render_height; }
 	const StripPlan &get_strip_plan() const { return strip_plan; }
 	void set_exchange_callback(gra_exchange_fn fn, void *user);
 	void init_collective(const uint8_t *id128, int rank, int ranks);
@@ -69,6 +71,8 @@ public:
 
 private:
 	gra_config config;
+	unsigned render_width = 0, render_height = 0; // backbuffer size x resolution_scale
+	bool scaled() const { return config.resolution_scale > 0.0f && config.resolution_scale < 1.0f; }
 	std::unique_ptr<HIP::Device> device_holder;
 	RenderGraph graph;
 	RenderContext context;

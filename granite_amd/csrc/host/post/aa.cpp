@@ -1,4 +1,5 @@
 #include "aa.hpp"
+#include <cmath>
 #include <cstring>
 
 namespace Granite
@@ -223,6 +224,43 @@ bool setup_before_post_chain_antialiasing(PostAAType type, RenderGraph &graph, T
 	default: return false;
 	}
 	setup_taa_resolve(graph, jitter, scaling_factor, input, input_depth, input_mv, output, taa_quality);
+	return true;
+}
+
+// ---- spatial upscaling (aa.cpp:64-174) ------------------------------------------------------------------------------------
+bool setup_after_post_chain_upscaling(RenderGraph &graph, const std::string &input, const std::string &output, bool use_sharpen, bool fp16)
+{
+	auto &upscale = graph.add_pass(output + "-scale", RenderGraph::get_default_post_graphics_queue());
+	AttachmentInfo upscale_info; // swapchain sized
+	upscale_info.format = VK_FORMAT_R8G8B8A8_UNORM;
+	if (use_sharpen)
+		upscale_info.flags |= ATTACHMENT_INFO_UNORM_SRGB_ALIAS_BIT; // the sharpen pass reads it through an sRGB view
+	else
+		upscale_info.flags |= ATTACHMENT_INFO_SUPPORTS_PREROTATE_BIT;
+	auto &upscaled = upscale.add_color_output(use_sharpen ? output + "-scale" : output, upscale_info);
+	auto &source = upscale.add_texture_input(input);
+	graph.get_texture_resource(input).get_attachment_info().flags |= ATTACHMENT_INFO_UNORM_SRGB_ALIAS_BIT; // read as stored bytes
+
+	upscale.set_build_render_pass([&graph, &upscaled, &source, fp16](HIP::CommandBuffer &cmd) {
+		auto &in = graph.get_physical_texture_resource(source);
+		auto &out = graph.get_physical_texture_resource(upscaled);
+		cmd.check(gr_fsr_upscale(cmd.get_context(), cmd.get_stream(), &in.get_view(), &out.get_view(), fp16 ? 1 : 0), "fsr upscale");
+	});
+
+	if (use_sharpen)
+	{
+		auto &sharpen = graph.add_pass(output + "-sharpen", RenderGraph::get_default_post_graphics_queue());
+		AttachmentInfo sharpen_info; // swapchain size and format
+		sharpen_info.flags |= ATTACHMENT_INFO_SUPPORTS_PREROTATE_BIT;
+		auto &sharpened = sharpen.add_color_output(output, sharpen_info);
+		auto &scaled = sharpen.add_texture_input(output + "-scale");
+		sharpen.set_build_render_pass([&graph, &sharpened, &scaled](HIP::CommandBuffer &cmd) {
+			auto &in = graph.get_physical_texture_resource(scaled);
+			auto &out = graph.get_physical_texture_resource(sharpened);
+			const float sharpness = exp2f(-0.5f); // FsrRcasCon(constants.params, 0.5f), aa.cpp:64-74,157
+			cmd.check(gr_fsr_sharpen(cmd.get_context(), cmd.get_stream(), &in.get_view(), &out.get_view(), sharpness), "fsr sharpen");
+		});
+	}
 	return true;
 }
 

@@ -72,6 +72,10 @@ void setup_taa_resolve(RenderGraph &graph, TemporalJitter &jitter, float scaling
 bool setup_before_post_chain_antialiasing(PostAAType type, RenderGraph &graph, TemporalJitter &jitter, const RenderContext &context,
                                           float scaling_factor, const std::string &input, const std::string &input_depth,
                                           const std::string &input_mv, const std::string &output);
+// aa.cpp:75-174: `output + "-scale"` (FSR 1.0 EASU from `input` to the swapchain size) and, with use_sharpen,
+// `output + "-sharpen"` (RCAS, 0.5 stops).  fp16 = the FP16 shader variant (the reference picks it from the device's
+// shaderFloat16 / FIDELITYFX_FSR_FP16, aa.cpp:118-119; on MI355X that is true).
+bool setup_after_post_chain_upscaling(RenderGraph &graph, const std::string &input, const std::string &output, bool use_sharpen, bool fp16 = true);
 bool setup_after_post_chain_antialiasing(PostAAType type, RenderGraph &graph, TemporalJitter &jitter, float scaling_factor,
                                          const std::string &input, const std::string &input_depth, const std::string &output);
 PostAAType string_to_post_antialiasing_type(const char *type);

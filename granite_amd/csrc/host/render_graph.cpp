@@ -1510,12 +1510,16 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 	}
 	close_run();
 
-	// Backbuffer could not alias the swapchain image: final blit (same geometry/format only).
+	// Backbuffer could not alias the swapchain image: final blit.  Same geometry only; R8G8B8A8 UNORM <-> SRGB is a byte
+	// copy (the stored bytes are the gamma-space colour either way -- e.g. the un-sharpened FSR output, aa.cpp:80-84.  The
+	// reference's scale pass, render_graph.cpp:2557-2566, would sample the UNORM view and let the sRGB store encode again).
 	if (swapchain_attachment && swapchain_physical_index == RenderResource::Unused)
 	{
 		const unsigned src_index = resources[resource_to_index[backbuffer_source]]->get_physical_index();
 		auto &src = get_physical_texture_resource(src_index);
-		if (src.get_size_bytes() != swapchain_attachment->get_size_bytes() || src.get_format() != swapchain_attachment->get_format())
+		auto rgba8 = [](VkFormat f) { return f == VK_FORMAT_R8G8B8A8_UNORM || f == VK_FORMAT_R8G8B8A8_SRGB; };
+		const bool same_texels = src.get_format() == swapchain_attachment->get_format() || (rgba8(src.get_format()) && rgba8(swapchain_attachment->get_format()));
+		if (src.get_width() != swapchain_attachment->get_width() || src.get_height() != swapchain_attachment->get_height() || !same_texels)
 			throw std::logic_error("Backbuffer source does not match the swapchain; scaling blits are not implemented.");
 		HIP::CommandBuffer cmd{device_, device_.get_stream(HIP::CommandBuffer::Type::Generic), HIP::CommandBuffer::Type::Generic};
 		auto stream = static_cast<hipStream_t>(cmd.get_stream());

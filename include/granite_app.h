@@ -60,6 +60,13 @@ typedef struct gra_config
 	 * The pass is tied to the end of the frame through a proxy resource, as its consumers (occlusion culling, SSR) live
 	 * outside this build. */
 	int32_t depth_hierarchy;
+	/* viewer_config "resolutionScale" / "resolutionScaleSharpen" (scene_viewer_application.cpp:248-250,758-761,1263-1268):
+	 * with 0 < resolution_scale < 1 the G-buffer, lighting, post chain and AA run at ceil(size * scale) and
+	 * setup_after_post_chain_upscaling (FSR 1.0 EASU, + RCAS when resolution_scale_sharpen) brings the result to the
+	 * backbuffer size; uploads are then render-sized.  0 or 1 = off.  fsr_fp32 = 1 forces the FP16 = 0 shader variant. */
+	float resolution_scale;
+	int32_t resolution_scale_sharpen;
+	int32_t fsr_fp32;
 } gra_config;
 
 /* Scene-level light description (one PositionalLight + its node transform). */
@@ -86,6 +93,8 @@ int gra_set_camera(gra_app *app, const float *projection16, const float *view16)
 /* Installs precomputed parameters verbatim (so that the CPU oracle and the device see bit-identical inputs). */
 int gra_set_render_parameters(gra_app *app, const float *params104);
 int gra_get_render_parameters(gra_app *app, float *params104);
+/* Size the G-buffer is rendered (and uploaded) at: the backbuffer size unless resolution_scale is in use. */
+int gra_get_render_size(gra_app *app, uint32_t *width, uint32_t *height);
 
 int gra_set_lights(gra_app *app, const gra_light_desc *lights, uint32_t count);
 

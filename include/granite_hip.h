@@ -397,6 +397,18 @@ typedef struct gr_hiz_args
 } gr_hiz_args;
 int gr_hiz(gr_ctx *ctx, gr_stream stream, const gr_hiz_args *args);
 
+/* ---- spatial upscaling after the post chain ---------------------------------------------------------------------------
+ * setup_after_post_chain_upscaling (renderer/post/aa.cpp:75-174).  Both images R8G8B8A8_{UNORM,SRGB}.
+ * gr_fsr_upscale: the "-scale" pass, upscale.{vert,frag} + FsrEasu{F,H} with the constants of FsrEasuCon (viewport = input
+ * size): reads the stored (gamma-space) bytes of `in`, writes out->width x out->height.  fp16 != 0 selects the FP16 shader
+ * variant (the reference's choice on hardware with fp16 arithmetic, aa.cpp:118-119).  The value written is the gamma-space
+ * result for either output format (TARGET_SRGB decodes and the *_SRGB store re-encodes).
+ * gr_fsr_sharpen: the "-sharpen" pass, sharpen.{vert,frag} + FsrRcasF; sharpness = exp2(-stops), FsrRcasCon (aa.cpp:64-74,
+ * 0.5 stops at :157).  With an *_SRGB output the input is read through its sRGB view (linear) and the store encodes
+ * (aa.cpp:147-151); with a UNORM output bytes go straight through. */
+int gr_fsr_upscale(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, int fp16);
+int gr_fsr_sharpen(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, float sharpness);
+
 #ifdef __cplusplus
 }
 #endif

@@ -323,3 +323,26 @@ def hiz(depth: np.ndarray, z_transform, output_downsample: bool = False):
         o = fn(lay["chain_w"], lay["chain_h"], l)
         levels.append(out[o:o + w * h].reshape(h, w))
     return levels
+
+
+# ---- spatial upscaling (renderer/post/aa.cpp:75-174 + assets/shaders/post/ffx-fsr) -----------------------------------------
+def fsr_easu(rgba8: np.ndarray, ow: int, oh: int, fp16: bool = True, target_srgb: bool = False) -> np.ndarray:
+    ih, iw = rgba8.shape[:2]
+    src = np.ascontiguousarray(rgba8, np.uint8)
+    out = np.zeros((oh, ow, 4), np.uint8)
+    lib().orc_fsr_easu(_p(src), iw, ih, _p(out), ow, oh, int(fp16), int(target_srgb))
+    return out
+
+
+def fsr_rcas_sharpness(stops: float = 0.5) -> float:
+    """FsrRcasCon (aa.cpp:64-74): the linear sharpness, exp2(-stops) in fp32."""
+    return float(np.exp2(np.float32(-stops), dtype=np.float32))
+
+
+def fsr_rcas(rgba8: np.ndarray, sharpness: float = None, srgb: bool = True) -> np.ndarray:
+    h, w = rgba8.shape[:2]
+    src = np.ascontiguousarray(rgba8, np.uint8)
+    out = np.zeros((h, w, 4), np.uint8)
+    s = fsr_rcas_sharpness() if sharpness is None else sharpness
+    lib().orc_fsr_rcas(_p(src), w, h, _p(out), C.c_float(s), int(srgb))
+    return out

@@ -311,3 +311,16 @@ def test_oracle_reproduces_committed_fixtures():
             np.testing.assert_allclose(now[k], ref[k], rtol=1e-5, atol=1e-6, err_msg=k)
         else:
             np.testing.assert_array_equal(now[k], ref[k], err_msg=k)
+
+
+def test_unorm8_decode_without_a_division_is_exact():
+    """device_common.hpp unorm8_to_float: v * (1/255) followed by one Newton step equals the IEEE quotient v / 255 for every
+    byte, so kernels may use it where the oracle divides."""
+    f32 = np.float32
+    r = f32(1.0) / f32(255.0)
+    for v in range(256):
+        f = f32(v)
+        q = f32(f * r)
+        e = f32(np.float64(-q) * 255.0 + np.float64(f))      # fma: one rounding
+        got = f32(np.float64(e) * np.float64(r) + np.float64(q))
+        assert got == f32(f / f32(255.0)), v

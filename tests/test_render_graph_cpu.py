@@ -140,3 +140,24 @@ def test_depth_hierarchy_pass_is_kept_alive_by_a_proxy_and_sized_in_whole_tiles(
     assert "depth-hiz" not in {p["name"] for p in graph_of(1280, 720)["passes"]}
     with pytest.raises(capi.GraniteHipError):
         graph_of(256, 256, lighting=False, depth_hierarchy=1)
+
+
+def test_resolution_scale_adds_the_upscale_passes_at_backbuffer_size():
+    """scene_viewer_application.cpp:758-761,1263-1268 + aa.cpp:75-174: everything up to the AA output runs at
+    ceil(size * scale); "<out>-scale" (EASU, R8G8B8A8_UNORM) and "<out>-sharpen" (RCAS, swapchain format) are swapchain
+    sized, and the sharpened output is the swapchain image itself."""
+    g = graph_of(1920, 1080, resolution_scale=2.0 / 3.0, post_aa=gapp.POST_AA_FXAA)
+    order = [p["name"] for p in g["passes"]]
+    assert order[-3:] == ["fxaa", "post-scale-output-scale", "post-scale-output-sharpen"]
+    res = {r["name"]: r for r in g["resources"]}
+    for name in ("HDR-main", "tonemapped", "post-aa-output", "albedo-main"):
+        assert (res[name]["width"], res[name]["height"]) == (1280, 720), name
+    assert (res["threshold"]["width"], res["threshold"]["height"]) == (640, 360)
+    assert (res["post-scale-output-scale"]["width"], res["post-scale-output-scale"]["height"], res["post-scale-output-scale"]["format"]) == (1920, 1080, 37)
+    assert g["swapchain_phys"] == res["post-scale-output"]["phys"]
+    # without the sharpener the EASU output is UNORM: not the swapchain's format, so it is blitted
+    g2 = graph_of(1920, 1080, resolution_scale=0.5, resolution_scale_sharpen=False)
+    assert [p["name"] for p in g2["passes"]][-1] == "post-scale-output-scale" and g2["swapchain_phys"] == -1
+    assert {r["name"]: (r["width"], r["height"]) for r in g2["resources"]}["HDR-main"] == (960, 540)
+    with pytest.raises(capi.GraniteHipError):
+        graph_of(1920, 1080, resolution_scale=1.5)
