@@ -27,7 +27,8 @@ class Config(C.Structure):
                 ("directional_direction", C.c_float * 3), ("enable_timestamps", C.c_int32),
                 ("strip_index", C.c_uint32), ("strip_count", C.c_uint32),
                 ("disable_image_aliasing", C.c_int32), ("depth_hierarchy", C.c_int32),
-                ("resolution_scale", C.c_float), ("resolution_scale_sharpen", C.c_int32), ("fsr_fp32", C.c_int32)]
+                ("resolution_scale", C.c_float), ("resolution_scale_sharpen", C.c_int32), ("fsr_fp32", C.c_int32),
+                ("ambient_occlusion", C.c_int32)]
 
 
 # void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream)
@@ -49,7 +50,7 @@ EXPORTED_SYMBOLS = [
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
     "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
-    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_set_exchange_callback", "gra_get_strip_plan",
+    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_set_exchange_callback", "gra_get_strip_plan",
     "gra_comm_create_unique_id", "gra_comm_init",
 ]
 
@@ -90,6 +91,7 @@ def load_library() -> C.CDLL:
         "gra_get_host_stats": (C.c_int, [vp, vp]),
         "gra_get_allocated_bytes": (C.c_int, [vp, vp]),
         "gra_get_render_size": (C.c_int, [vp, vp, vp]),
+        "gra_upload_ambient_occlusion": (C.c_int, [vp, vp]),
         "gra_gtx_probe": (C.c_int, [C.c_char_p, vp, vp, C.c_size_t]),
         "gra_gtx_read": (C.c_int, [C.c_char_p, vp, C.c_uint64, vp, C.c_size_t]),
         "gra_gtx_write": (C.c_int, [C.c_char_p, vp, vp, vp, C.c_size_t]),
@@ -119,7 +121,8 @@ class Application:
                  pre_aa: int = POST_AA_NONE, rmw_emissive: bool = False, cluster_res=synth.CLUSTER_RESOLUTION,
                  frame_time: float = synth.FRAME_TIME, timestamps: bool = False, strip_index: int = 0, strip_count: int = 1,
                  alias_images: bool = True, depth_hierarchy: int = 0,
-                 resolution_scale: float = 1.0, resolution_scale_sharpen: bool = True, fsr_fp16: bool = True):
+                 resolution_scale: float = 1.0, resolution_scale_sharpen: bool = True, fsr_fp16: bool = True,
+                 ambient_occlusion: bool = False):
         self.lib = load_library()
         cfg = Config()
         cfg.device, cfg.width, cfg.height = device, width, height
@@ -136,6 +139,7 @@ class Application:
         cfg.depth_hierarchy = int(depth_hierarchy)
         cfg.resolution_scale = float(resolution_scale)
         cfg.resolution_scale_sharpen, cfg.fsr_fp32 = int(resolution_scale_sharpen), int(not fsr_fp16)
+        cfg.ambient_occlusion = int(ambient_occlusion)
         self._exchange_ref = None
         self.config = cfg
         self.width, self.height = width, height
@@ -188,6 +192,11 @@ class Application:
                 for k in ("emissive", "albedo", "normal", "pbr", "depth")]
         mv = None if motion_vectors is None else np.ascontiguousarray(motion_vectors)
         self._check(self.lib.gra_upload_gbuffer(self.handle, *[_ptr(k) for k in keep], _ptr(mv)))
+
+    def upload_ambient_occlusion(self, ao: np.ndarray):
+        """Render-sized uint8 image for "ssao-output-main" (needs ambient_occlusion=True)."""
+        a = np.ascontiguousarray(ao, np.uint8)
+        self._check(self.lib.gra_upload_ambient_occlusion(self.handle, a.ctypes.data))
 
     def upload_gbuffer_gtx(self, emissive=None, albedo=None, normal=None, pbr=None, depth=None, motion_vectors=None):
         """G-buffer attachments from .gtx files (paths; None = unchanged)."""

@@ -43,6 +43,7 @@ FORMAT_BPP = {
 LIGHTING_DIRECTIONAL_BIT = 1
 LIGHTING_CLUSTERED_BIT = 2
 LIGHTING_AMBIENT_FALLBACK_BIT = 4
+LIGHTING_AMBIENT_OCCLUSION_BIT = 8
 
 MAX_LIGHTS_BINDLESS = 4096
 CULL_SETUP_BYTES_PER_LIGHT = 512
@@ -130,7 +131,7 @@ class LightingArgs(C.Structure):
                 ("hdr", Image),
                 ("inv_view_projection", C.c_float * 16), ("directional", PushDirectional), ("clustering", PushClustering),
                 ("cluster", ClusterParams), ("transforms", C.c_void_p), ("bitmask", C.c_void_p), ("range", C.c_void_p),
-                ("flags", C.c_uint32), ("rows", C.c_uint32 * 2)]
+                ("flags", C.c_uint32), ("rows", C.c_uint32 * 2), ("ambient_occlusion", Image)]
 
 
 class Rows(C.Structure):
@@ -222,6 +223,7 @@ def load_library() -> C.CDLL:
         "gr_smaa_neighbor_blend": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushSmaa)]),
         "gr_taa_resolve": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), P(Image), P(Image), P(PushTaa), C.c_int]),
         "gr_hiz": (C.c_int, [vp, vp, P(HizArgs)]),
+        "gr_fill_byte": (C.c_int, [vp, vp, vp, C.c_int, C.c_size_t]),
         "gr_fsr_upscale": (C.c_int, [vp, vp, P(Image), P(Image), C.c_int]),
         "gr_fsr_sharpen": (C.c_int, [vp, vp, P(Image), P(Image), C.c_float]),
         "gr_mip_chain_offset": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -242,7 +244,7 @@ EXPORTED_SYMBOLS = [
     "gr_bloom_threshold_rows", "gr_bloom_downsample_rows", "gr_bloom_upsample_rows", "gr_tonemap_rows",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
     "gr_smaa_set_luts", "gr_fxaa", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
-    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen",
+    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen", "gr_fill_byte",
 ]
 
 

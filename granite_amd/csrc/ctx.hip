@@ -221,6 +221,15 @@ int gr_fill_zero(gr_ctx *ctx, gr_stream stream, void *dst, size_t bytes)
 	return GR_OK;
 }
 
+int gr_fill_byte(gr_ctx *ctx, gr_stream stream, void *dst, int value, size_t bytes)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, dst);
+	GR_CHECK_HIP(ctx, hipMemsetAsync(dst, value & 0xff, bytes, gr_to_stream(stream)));
+	return GR_OK;
+}
+
 int gr_timing_enable(gr_ctx *ctx, int enable)
 {
 	if (!ctx)

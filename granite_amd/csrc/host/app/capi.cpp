@@ -193,6 +193,11 @@ int gra_gtx_write(const char *path, const gra_gtx_info *info, const void *payloa
 	});
 }
 
+int gra_upload_ambient_occlusion(gra_app *app, const void *ao_r8)
+{
+	return guarded(app, [&]() { app->app->upload_ambient_occlusion(ao_r8); });
+}
+
 int gra_upload_gbuffer_gtx(gra_app *app, const char *emissive, const char *albedo, const char *normal, const char *pbr,
                            const char *depth, const char *motion_vectors)
 {

@@ -195,6 +195,22 @@ void ImageSpaceApplication::upload_gbuffer(const void *emissive, const void *alb
 	filled_targets.clear();
 }
 
+void ImageSpaceApplication::upload_ambient_occlusion(const void *ao_r8)
+{
+	if (!config.ambient_occlusion || !config.enable_lighting)
+		throw std::logic_error("This graph has no ambient-occlusion input (config.ambient_occlusion).");
+	if (!ao_r8)
+		throw std::logic_error("upload_ambient_occlusion: null image");
+	auto &device = get_device();
+	device.wait_idle();
+	if (!src_ao)
+		src_ao = device.create_image(render_width, render_height, VK_FORMAT_R8_UNORM, "src-ssao");
+	if (gr_upload(device.get_context(), nullptr, src_ao->get_device_pointer(), ao_r8, src_ao->get_size_bytes()) < 0 ||
+	    gr_sync(device.get_context(), nullptr) < 0)
+		throw std::runtime_error(gr_last_error(device.get_context()));
+	filled_targets.clear();
+}
+
 void ImageSpaceApplication::upload_gbuffer_gtx(const char *const paths[6])
 {
 	struct Slot
@@ -322,6 +338,31 @@ void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
 		fill(g_depth, src_depth, false);
 	});
 
+	ssao_output = nullptr;
+	if (config.ambient_occlusion)
+	{
+		// setup_ffx_cacao(graph, context, "ssao-output-<tag>", depth, normal) (scene_viewer_application.cpp:950-954; output
+		// declared at ssao.cpp:48-58: R8_UNORM storage image the size of the depth input).  CACAO itself exists only as
+		// SPIR-V blobs in the reference; the pass here copies the uploaded image in (white = unoccluded until one arrives).
+		auto &ssao = graph.add_pass(tagcat("ssao", tag), RENDER_GRAPH_QUEUE_COMPUTE_BIT);
+		AttachmentInfo ao;
+		ao.format = VK_FORMAT_R8_UNORM;
+		ao.size_class = SizeClass::InputRelative;
+		ao.size_relative_name = tagcat("depth-transient", tag);
+		auto &ao_out = ssao.add_storage_texture_output(tagcat("ssao-output", tag), ao);
+		ssao.add_texture_input(tagcat("depth-transient", tag));
+		ssao.add_texture_input(tagcat("normal", tag));
+		ssao.set_build_render_pass([this, &ao_out](HIP::CommandBuffer &cmd) {
+			auto &target = graph.get_physical_texture_resource(ao_out);
+			if (!needs_fill(target))
+				return;
+			if (src_ao)
+				cmd.copy_image(target, *src_ao);
+			else
+				cmd.check(gr_fill_byte(cmd.get_context(), cmd.get_stream(), target.get_device_pointer(), 0xff, target.get_size_bytes()), "ssao fill");
+		});
+	}
+
 	auto &lighting_pass = graph.add_pass(tagcat("lighting", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
 	RenderTextureResource *hdr_out;
 	RenderTextureResource *emissive_in = nullptr;
@@ -339,7 +380,12 @@ void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
 	lighting_pass.set_depth_stencil_input(tagcat("depth-transient", tag));
 	lighting_pass.add_fake_resource_write_alias(tagcat("depth-transient", tag), tagcat("depth", tag));
 
+	if (config.ambient_occlusion)
+		ssao_output = &lighting_pass.add_texture_input(tagcat("ssao-output", tag));
+
 	lighting_pass.set_build_render_pass([this, hdr_out, emissive_in, &in_albedo, &in_normal, &in_pbr, &in_depth](HIP::CommandBuffer &cmd) {
+		// lighting.ambient_occlusion = graph.maybe_get_physical_texture_resource(ssao_output) (scene_viewer_application.cpp:1571)
+		lighting.ambient_occlusion = ssao_output ? &graph.get_physical_texture_resource(*ssao_output) : nullptr;
 		DeferredLightAttachments att;
 		att.base_color = &graph.get_physical_texture_resource(in_albedo);
 		att.normal = &graph.get_physical_texture_resource(in_normal);

@@ -66,6 +66,7 @@ public:
 	}
 	// G-buffer attachments from .gtx files (any may be null); the frame written back as .gtx.
 	void upload_gbuffer_gtx(const char *const paths[6]);
+	void upload_ambient_occlusion(const void *ao_r8);
 	void save_image_gtx(HIP::Image &image, const std::string &path);
 	std::string last_error;
 
@@ -91,7 +92,8 @@ private:
 	std::vector<std::unique_ptr<PositionalLight>> light_objects;
 	std::vector<mat_affine> light_transforms;
 	PositionalLightList light_list;
-	HIP::ImageHandle src_emissive, src_albedo, src_normal, src_pbr, src_depth, src_mv;
+	HIP::ImageHandle src_emissive, src_albedo, src_normal, src_pbr, src_depth, src_mv, src_ao;
+	RenderTextureResource *ssao_output = nullptr;
 	bool gbuffer_dirty = true;
 	// Physical targets that already hold the current synthetic upload (an attachment the executor double-buffers has two).
 	std::unordered_set<const void *> filled_targets;

@@ -1,6 +1,7 @@
 // FrameParameters / RenderParameters / RenderContext / LightingParameters — the slices of
 // renderer/render_context.{hpp,cpp} and math/render_parameters.hpp:37-59,155-162 the image-space passes read.
 #pragma once
+#include "hip_device.hpp"
 #include "math.hpp"
 
 namespace Granite
@@ -50,6 +51,9 @@ struct LightingParameters
 	FogParameters fog;
 	DirectionalParameters directional;
 	LightClusterer *cluster = nullptr;
+	// LightingParameters::ambient_occlusion (renderer/lights/lights.hpp): the SSAO result the deferred lighting pass
+	// samples, or null.  Set every frame from the graph's physical resource (scene_viewer_application.cpp:1571).
+	const HIP::ImageView *ambient_occlusion = nullptr;
 };
 
 class RenderContext

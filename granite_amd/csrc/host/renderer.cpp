@@ -43,7 +43,14 @@ void DeferredLightRenderer::render_light(HIP::CommandBuffer &cmd, const RenderCo
 	args.flags = GR_LIGHTING_DIRECTIONAL_BIT;
 	bool cluster_volumetric_diffuse = light->cluster && light->cluster->clusterer_has_volumetric_diffuse();
 	if (!cluster_volumetric_diffuse)
+	{
 		args.flags |= GR_LIGHTING_AMBIENT_FALLBACK_BIT;
+		if (light->ambient_occlusion) // AMBIENT_OCCLUSION define + BINDING_GLOBAL_AMBIENT_OCCLUSION (renderer.cpp:611-612,1050-1051)
+		{
+			args.flags |= GR_LIGHTING_AMBIENT_OCCLUSION_BIT;
+			args.ambient_occlusion = light->ambient_occlusion->get_view();
+		}
+	}
 
 	// Clustered lighting (renderer.cpp:1107-1156)
 	if (light->cluster && light->cluster->get_cluster_bitmask_buffer())

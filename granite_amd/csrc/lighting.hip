@@ -44,7 +44,7 @@ constexpr float CULL_SLACK = 1e-3f;
 
 struct KernelArgs
 {
-	DevImage albedo, normal, pbr, depth, emissive;
+	DevImage albedo, normal, pbr, depth, emissive, ao;
 	DevImageRW hdr;
 	float inv_vp[16];
 	float camera_pos[3];
@@ -78,6 +78,20 @@ __device__ __forceinline__ float rcp(float v) { return __builtin_amdgcn_rcpf(v);
 __device__ __forceinline__ float rsq(float v) { return __builtin_amdgcn_rsqf(v); }
 __device__ __forceinline__ float med3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); } // clamp
 __device__ __forceinline__ float sat(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); } // folds into a clamp modifier
+
+// StockSampler::LinearClamp on an R8_UNORM image (the ambient-occlusion input).
+__device__ __forceinline__ float sample_linear_r8(const DevImage &img, float u, float v)
+{
+	const float fx = u * float(img.w) - 0.5f, fy = v * float(img.h) - 0.5f;
+	const float flx = floorf(fx), fly = floorf(fy);
+	const float wx = fx - flx, wy = fy - fly;
+	const int x0 = clampi(int(flx), 0, img.w - 1), x1 = clampi(int(flx) + 1, 0, img.w - 1);
+	const int y0 = clampi(int(fly), 0, img.h - 1), y1 = clampi(int(fly) + 1, 0, img.h - 1);
+	const uint8_t *r0 = img.ptr + size_t(y0) * img.pitch, *r1 = img.ptr + size_t(y1) * img.pitch;
+	const float t00 = unorm8_to_float(r0[x0]), t10 = unorm8_to_float(r0[x1]), t01 = unorm8_to_float(r1[x0]), t11 = unorm8_to_float(r1[x1]);
+	const float top = t00 * (1.0f - wx) + t10 * wx, bottom = t01 * (1.0f - wx) + t11 * wx;
+	return top * (1.0f - wy) + bottom * wy;
+}
 
 // Per-pixel material terms hoisted out of the light loop.
 struct Surface
@@ -204,7 +218,9 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], f32x4 q
 	}
 }
 
-template <int PX>
+// AO: the AMBIENT_OCCLUSION shader variant (renderer.cpp:1050-1051), a separate instantiation so that the default kernel keeps
+// its register budget.
+template <int PX, bool AO>
 __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 {
 	__shared__ __attribute__((aligned(16))) f32x4 s_lights[LIGHT_WAVES][64 * (LIGHT_SLOT_BYTES / 16)];
@@ -305,7 +321,12 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 			const float3_ b = brdf(s[p], dot(N, L), fmaxf(dot(Hv, Hv), 1e-30f), NoL);
 			float3_ lit = f3(a.dir_color[0] * NoL * b.x, a.dir_color[1] * NoL * b.y, a.dir_color[2] * NoL * b.z);
 			if (a.flags & GR_LIGHTING_AMBIENT_FALLBACK_BIT)
-				lit = lit + base[p] * 0.05f;
+			{
+				if (AO) // base_ambient * base_color * 0.05 (directional.frag:52-64)
+					lit = lit + (base[p] * sample_linear_r8(a.ao, (float(x) + 0.5f) * a.inv_resolution[0], (float(y) + 0.5f) * a.inv_resolution[1])) * 0.05f;
+				else
+					lit = lit + base[p] * 0.05f;
+			}
 			// blend ONE/ONE, attachment store rounds to fp16
 			accum[p] = f3(float(_Float16(accum[p].x + lit.x)), float(_Float16(accum[p].y + lit.y)), float(_Float16(accum[p].z + lit.z)));
 		}
@@ -499,6 +520,13 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	k.pbr = dev(args->pbr);
 	k.depth = dev(args->depth);
 	k.emissive = dev(args->emissive);
+	if (args->flags & GR_LIGHTING_AMBIENT_OCCLUSION_BIT)
+	{
+		GR_CHECK_ARG(ctx, (args->flags & GR_LIGHTING_AMBIENT_FALLBACK_BIT) != 0);
+		GR_CHECK_ARG(ctx, args->ambient_occlusion.ptr && args->ambient_occlusion.format == GR_FORMAT_R8_UNORM && args->ambient_occlusion.width &&
+		                      args->ambient_occlusion.height && args->ambient_occlusion.pitch_bytes >= args->ambient_occlusion.width);
+		k.ao = dev(args->ambient_occlusion);
+	}
 	k.hdr = DevImageRW{static_cast<uint8_t *>(args->hdr.ptr), int(W), int(H), args->hdr.pitch_bytes};
 	for (int i = 0; i < 16; i++)
 		k.inv_vp[i] = args->inv_view_projection[i];
@@ -568,10 +596,15 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	const size_t per_wg = (160u * 1024u / unsigned(max_wgs)) & ~size_t(1023);
 	const size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "lighting"};
-	if (px == 2)
-		hipLaunchKernelGGL(k_lighting<2>, grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+	const bool ao = (args->flags & GR_LIGHTING_AMBIENT_OCCLUSION_BIT) != 0;
+	if (px == 2 && ao)
+		hipLaunchKernelGGL((k_lighting<2, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+	else if (px == 2)
+		hipLaunchKernelGGL((k_lighting<2, false>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+	else if (ao)
+		hipLaunchKernelGGL((k_lighting<1, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
 	else
-		hipLaunchKernelGGL(k_lighting<1>, grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+		hipLaunchKernelGGL((k_lighting<1, false>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

@@ -67,6 +67,10 @@ typedef struct gra_config
 	float resolution_scale;
 	int32_t resolution_scale_sharpen;
 	int32_t fsr_fp32;
+	/* viewer_config "ssao" on the deferred path (scene_viewer_application.cpp:950-980,1571): the lighting pass takes the
+	 * R8_UNORM texture "ssao-output-main" as LightingParameters::ambient_occlusion.  Its producer in Granite is FFX CACAO,
+	 * shipped as SPIR-V blobs only; the harness fills the texture from gra_upload_ambient_occlusion like the G-buffer. */
+	int32_t ambient_occlusion;
 } gra_config;
 
 /* Scene-level light description (one PositionalLight + its node transform). */
@@ -102,6 +106,9 @@ int gra_set_lights(gra_app *app, const gra_light_desc *lights, uint32_t count);
  * leave that attachment unchanged.  Graphs without lighting take `emissive` as the HDR input. */
 int gra_upload_gbuffer(gra_app *app, const void *emissive_rgba16f, const void *albedo_rgba8, const void *normal_a2b10g10r10,
                        const void *pbr_rg8, const void *depth_d32f, const void *motion_vectors_rg16f);
+
+/* Render-sized R8_UNORM ambient-occlusion image (host pointer, tightly packed); needs config.ambient_occlusion. */
+int gra_upload_ambient_occlusion(gra_app *app, const void *ao_r8);
 
 /* ---- GTX ("GRANITE TEXFMT1", vulkan/texture/memory_mapped_texture.cpp:29-44): the container Granite keeps textures and
  * image dumps in -- the wire format on either side of this path.  Header fields as stored; payload = mip levels in order,

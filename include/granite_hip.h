@@ -91,6 +91,7 @@ int gr_alloc_host(gr_ctx *ctx, size_t bytes, void **hptr);
 int gr_free_host(gr_ctx *ctx, void *hptr);
 int gr_copy(gr_ctx *ctx, gr_stream stream, void *dst, const void *src, size_t bytes);
 int gr_fill_zero(gr_ctx *ctx, gr_stream stream, void *dst, size_t bytes);
+int gr_fill_byte(gr_ctx *ctx, gr_stream stream, void *dst, int value, size_t bytes); /* clear to a UNORM8 constant */
 
 /* Per-kernel GPU timing (RenderGraph::enable_timestamps analogue, render_graph.cpp:2196-2310): when enabled, every
  * launcher brackets its kernel with hipEvents on the launch stream; gr_timing_query drains {name, count, total_ms}. */
@@ -309,6 +310,8 @@ typedef struct gr_push_clustering /* renderer.cpp:1110-1121 */
 #define GR_LIGHTING_DIRECTIONAL_BIT 1u        /* draw the directional quad */
 #define GR_LIGHTING_CLUSTERED_BIT 2u          /* draw the clustered quad */
 #define GR_LIGHTING_AMBIENT_FALLBACK_BIT 4u   /* VOLUMETRIC_DIFFUSE_FALLBACK, renderer.cpp:1049-1055 */
+#define GR_LIGHTING_AMBIENT_OCCLUSION_BIT 8u  /* AMBIENT_OCCLUSION (renderer.cpp:1050-1051): `ambient_occlusion` scales the
+                                                 fallback ambient term, directional.frag:52-64.  Needs the fallback bit. */
 
 typedef struct gr_lighting_args
 {
@@ -329,6 +332,8 @@ typedef struct gr_lighting_args
 	const uint32_t *range;         /* cluster-range, uvec2[res_z] */
 	uint32_t flags;
 	gr_rows rows;                  /* render area; {0, 0} = whole target */
+	gr_image ambient_occlusion;    /* R8_UNORM, any size, sampled LinearClamp at the pixel centre (LightingParameters::
+	                                  ambient_occlusion, renderer.cpp:611-612); read only with the AMBIENT_OCCLUSION bit */
 } gr_lighting_args;
 int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args);
 

@@ -46,7 +46,7 @@ class LightingArgs(C.Structure):
                 ("cluster", C.c_void_p), ("lights", C.c_void_p), ("type_mask", C.c_void_p), ("bitmask", C.c_void_p),
                 ("range", C.c_void_p), ("dir_color", C.c_float * 3), ("dir_direction", C.c_float * 3),
                 ("enable_directional", C.c_int32), ("enable_clustered", C.c_int32), ("ambient_fallback", C.c_int32),
-                ("wave_tile", C.c_int32)]
+                ("wave_tile", C.c_int32), ("ambient_occlusion", C.c_void_p), ("ao_width", C.c_int32), ("ao_height", C.c_int32)]
 
 
 def build(force: bool = False) -> str:
@@ -211,7 +211,7 @@ def cluster_build(rp, prm, lights, model, type_mask, num_lights: int, res_z: int
 
 
 def lighting(gbuf: dict, rp, prm, lights, type_mask, bitmask, ranges, dir_color, dir_direction, directional=True,
-             clustered=True, ambient_fallback=True, wave_tile=0, bruteforce=False) -> np.ndarray:
+             clustered=True, ambient_fallback=True, wave_tile=0, bruteforce=False, ambient_occlusion=None) -> np.ndarray:
     """Returns the HDR target (RGBA16F bits) after DeferredLightRenderer::render_light on gbuf['emissive']."""
     h, w = gbuf["depth"].shape
     hdr = np.array(gbuf["emissive"], np.uint16, copy=True)
@@ -228,6 +228,10 @@ def lighting(gbuf: dict, rp, prm, lights, type_mask, bitmask, ranges, dir_color,
     a.dir_direction = (C.c_float * 3)(*[float(v) for v in dir_direction])
     a.enable_directional, a.enable_clustered = int(directional), int(clustered)
     a.ambient_fallback, a.wave_tile = int(ambient_fallback), int(wave_tile)
+    if ambient_occlusion is not None:  # AMBIENT_OCCLUSION variant: R8_UNORM image of any size
+        ao = np.ascontiguousarray(ambient_occlusion, np.uint8)
+        keep.append(ao)
+        a.ambient_occlusion, a.ao_height, a.ao_width = ao.ctypes.data, ao.shape[0], ao.shape[1]
     if bruteforce:
         lib().orc_lighting_bruteforce_clustered(C.byref(a))
     else:

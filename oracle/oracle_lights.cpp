@@ -774,7 +774,23 @@ struct OrcLightingArgs
 	int32_t enable_clustered;
 	int32_t ambient_fallback; // VOLUMETRIC_DIFFUSE_FALLBACK (renderer.cpp:1049-1055, directional.frag:62-64)
 	int32_t wave_tile;        // 0/1: exact per-pixel light set; N>1: N x N pixel tile emulating the subgroup union (clusterer_bindless.h:49-56)
+	const uint8_t *ambient_occlusion; // AMBIENT_OCCLUSION (renderer.cpp:1050-1051, directional.frag:52-64): R8_UNORM or NULL
+	int32_t ao_width, ao_height;
 };
+
+// textureLod(uAmbientOcclusion, gl_FragCoord.xy * inv_resolution, 0).x with StockSampler::LinearClamp (renderer.cpp:611-612).
+static float sample_ambient_occlusion(const OrcLightingArgs *a, float u, float v)
+{
+	const int w = a->ao_width, h = a->ao_height;
+	const float fx = u * float(w) - 0.5f, fy = v * float(h) - 0.5f;
+	const float flx = floorf(fx), fly = floorf(fy);
+	const float wx = fx - flx, wy = fy - fly;
+	auto texel = [&](int x, int y) { return float(a->ambient_occlusion[size_t(clampi(y, 0, h - 1)) * w + clampi(x, 0, w - 1)]) / 255.0f; };
+	const int x0 = int(flx), y0 = int(fly);
+	const float top = texel(x0, y0) * (1.0f - wx) + texel(x0 + 1, y0) * wx;
+	const float bottom = texel(x0, y0 + 1) * (1.0f - wx) + texel(x0 + 1, y0 + 1) * wx;
+	return top * (1.0f - wy) + bottom * wy;
+}
 
 // DeferredLightRenderer::render_light (renderer.cpp:1004-1156): directional quad then clustered quad, each blended
 // ONE/ONE into the RGBA16F target (two separate fp16 roundings), depth test NOT_EQUAL against the quad at z = 0 so
@@ -861,7 +877,12 @@ void orc_lighting(const OrcLightingArgs *a)
 					// light_color * NoL * shadow_term * (...) — light_color multiplies from the left in lighting.h:41-42.
 					vec3 lit = dcol * brdf(m, ddir, poss[li], camera_pos);
 					if (a->ambient_fallback)
-						lit = lit + 1.0f * m.base * V3(0.05f);
+					{
+						const float base_ambient = a->ambient_occlusion
+						                               ? sample_ambient_occlusion(a, (float(x) + 0.5f) * inv_resolution.x, (float(y) + 0.5f) * inv_resolution.y)
+						                               : 1.0f;
+						lit = lit + base_ambient * m.base * V3(0.05f);
+					}
 					vec4 dst = load_rgba16f(a->hdr, W, x, y);
 					store_rgba16f(a->hdr, W, x, y, V4(dst.x + lit.x, dst.y + lit.y, dst.z + lit.z, dst.w));
 				}

@@ -182,3 +182,26 @@ def test_aliased_attachments_do_not_change_a_byte(scene, lighting):
     w, h = 480, 270
     levels = [((w + 3) // 4) * ((h + 3) // 4), ((w + 7) // 8) * ((h + 7) // 8), ((w + 15) // 16) * ((h + 15) // 16)]
     assert saved == 8 * sum(levels), (held, levels)
+
+
+def test_ambient_occlusion_input_of_the_lighting_pass(scene):
+    """viewer_config "ssao" on the deferred path: "ssao-output-main" (R8_UNORM, filled from an upload in place of FFX CACAO)
+    reaches the lighting kernel as LightingParameters::ambient_occlusion.  White until an image is uploaded."""
+    cam, gbuf, descs = scene
+    plain = make_app(cam, gbuf, descs)
+    plain.render_frames(3)
+    a = make_app(cam, gbuf, descs, ambient_occlusion=True)
+    a.render_frames(3)
+    np.testing.assert_array_equal(a.read("HDR-main"), plain.read("HDR-main"))
+    np.testing.assert_array_equal(a.read_backbuffer(), plain.read_backbuffer())
+    plain.close()
+    rng = np.random.default_rng(4)
+    ao = rng.integers(0, 256, (cam.height, cam.width), dtype=np.uint8)
+    a.upload_ambient_occlusion(ao)
+    a.render_frames(3)
+    np.testing.assert_array_equal(a.read("ssao-output-main").reshape(cam.height, cam.width), ao)
+    o = oracle_frames(cam, gbuf, descs, 0)
+    want = orc.lighting(gbuf, cam.render_params(), o["prm"], o["lights"], o["type_mask"], o["cluster"]["bitmask"], o["cluster"]["range"],
+                        synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION, ambient_occlusion=ao)
+    assert_rgba16f_close(a.read("HDR-main"), want, ulps=3.0, abs_tol=1e-4, what="HDR with ambient occlusion")
+    a.close()

@@ -97,3 +97,46 @@ def test_lighting_linearity_in_light_colour(gr):
     gr.sync()
     dbl = imgs2["hdr"].download().view(np.float16).astype(np.float32)
     np.testing.assert_allclose(dbl[..., :3], 2.0 * base[..., :3], rtol=2e-3, atol=1e-4)
+
+
+def ambient_occlusion_image(w, h, seed=5):
+    r = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    ao = 128 + 100 * np.sin(x * 0.11) * np.cos(y * 0.07) + r.integers(-20, 21, (h, w))
+    return np.clip(ao, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("ao_size", ["full", "half"])
+def test_lighting_ambient_occlusion_variant(gr, ao_size):
+    """AMBIENT_OCCLUSION (renderer.cpp:1050-1051, directional.frag:52-64): the SSAO texture, sampled LinearClamp at the pixel
+    centre, scales the 0.05 fallback ambient term.  Full-size and half-size (bilinear weights in play) inputs."""
+    w, h = 480, 270
+    sc = Scene(w, h, 700)
+    ref_c = orc.cluster_build(sc.rp, sc.prm, sc.lights, sc.model, sc.type_mask, sc.n, sc.res[2])
+    dev = sc.build_clusters_gpu(gr)
+    aw, ah = (w, h) if ao_size == "full" else (w // 2, h // 2)
+    ao = ambient_occlusion_image(aw, ah)
+    ref = orc.lighting(sc.gbuf, sc.rp, sc.prm, sc.lights, sc.type_mask, ref_c["bitmask"], ref_c["range"],
+                       synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION, ambient_occlusion=ao)
+    args, imgs = sc.lighting_args(gr, dev, ALL | capi.LIGHTING_AMBIENT_OCCLUSION_BIT)
+    ao_img = capi.DeviceImage(gr, aw, ah, capi.FORMAT_R8_UNORM).upload(ao)
+    args.ambient_occlusion = ao_img.desc
+    gr.check(gr.lib.gr_lighting(gr.handle, None, args))
+    gr.sync()
+    got = imgs["hdr"].download()
+    assert_rgba16f_close(got, ref, ulps=3.0, abs_tol=1e-4, what=f"lighting with {ao_size}-size AO")
+    # it matters: the result differs from the un-occluded one, and white AO reproduces it exactly
+    args2, imgs2 = sc.lighting_args(gr, dev, ALL)
+    gr.check(gr.lib.gr_lighting(gr.handle, None, args2))
+    white = capi.DeviceImage(gr, aw, ah, capi.FORMAT_R8_UNORM).upload(np.full((ah, aw), 255, np.uint8))
+    args3, imgs3 = sc.lighting_args(gr, dev, ALL | capi.LIGHTING_AMBIENT_OCCLUSION_BIT)
+    args3.ambient_occlusion = white.desc
+    gr.check(gr.lib.gr_lighting(gr.handle, None, args3))
+    gr.sync()
+    plain = imgs2["hdr"].download()
+    assert (plain != got).mean() > 0.2
+    np.testing.assert_array_equal(imgs3["hdr"].download(), plain)
+    # the bit without an image, or without the fallback term it scales, is refused
+    bad, _ = sc.lighting_args(gr, dev, ALL | capi.LIGHTING_AMBIENT_OCCLUSION_BIT)
+    with pytest.raises(capi.GraniteHipError):
+        gr.check(gr.lib.gr_lighting(gr.handle, None, bad))

@@ -324,3 +324,28 @@ def test_unorm8_decode_without_a_division_is_exact():
         e = f32(np.float64(-q) * 255.0 + np.float64(f))      # fma: one rounding
         got = f32(np.float64(e) * np.float64(r) + np.float64(q))
         assert got == f32(f / f32(255.0)), v
+
+
+def test_ambient_occlusion_scales_only_the_fallback_ambient_term():
+    """directional.frag:52-64 under LIGHTING_NO_AMBIENT + VOLUMETRIC_DIFFUSE_FALLBACK: FragColor += ao * base_color * 0.05.
+    White AO = the plain variant; black AO = the variant without the fallback term; grey is linear in between (before the
+    fp16 store)."""
+    cam = synth.Camera(96, 54)
+    gbuf = synth.make_gbuffer(cam)
+    rp = cam.render_params()
+    n, lights, model, tmask, _ = orc.pack_lights(synth.make_lights(cam, 40), rp[99:102])
+    prm = orc.cluster_params(rp, *synth.CLUSTER_RESOLUTION, n)
+    cb = orc.cluster_build(rp, prm, lights, model, tmask, n, synth.CLUSTER_RESOLUTION[2])
+
+    def run(**kw):
+        return orc.lighting(gbuf, rp, prm, lights, tmask, cb["bitmask"], cb["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION,
+                            clustered=False, **kw)
+
+    plain, none = run(), run(ambient_fallback=False)
+    np.testing.assert_array_equal(run(ambient_occlusion=np.full((54, 96), 255, np.uint8)), plain)
+    np.testing.assert_array_equal(run(ambient_occlusion=np.zeros((54, 96), np.uint8)), none)
+    half = f32(run(ambient_occlusion=np.full((27, 48), 51, np.uint8)))  # 51 / 255 = 0.2, any size: constant image
+    lit = gbuf["depth"] != 0.0
+    want = f32(none)[lit] + 0.2 * (f32(plain)[lit] - f32(none)[lit])
+    np.testing.assert_allclose(half[lit][:, :3], want[:, :3], rtol=4e-3, atol=2e-4)
+    assert np.abs(f32(plain)[lit][:, :3] - f32(none)[lit][:, :3]).max() > 1e-3

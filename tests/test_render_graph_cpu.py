@@ -161,3 +161,17 @@ def test_resolution_scale_adds_the_upscale_passes_at_backbuffer_size():
     assert {r["name"]: (r["width"], r["height"]) for r in g2["resources"]}["HDR-main"] == (960, 540)
     with pytest.raises(capi.GraniteHipError):
         graph_of(1920, 1080, resolution_scale=1.5)
+
+
+def test_ambient_occlusion_pass_sits_between_gbuffer_and_lighting():
+    """scene_viewer_application.cpp:950-980: the SSAO pass (compute, R8_UNORM the size of the depth input) reads depth and
+    normals; lighting takes its output as a texture.  A compute pass between them ends the G-buffer + lighting subpass merge."""
+    g = graph_of(1280, 720, ambient_occlusion=True)
+    order = [p["name"] for p in g["passes"]]
+    assert order.index("gbuffer-main") < order.index("ssao-main") < order.index("lighting-main")
+    res = {r["name"]: r for r in g["resources"]}
+    assert (res["ssao-output-main"]["width"], res["ssao-output-main"]["height"], res["ssao-output-main"]["format"]) == (1280, 720, 9)
+    lighting = next(p for p in g["passes"] if p["name"] == "lighting-main")
+    assert "ssao-output-main" in {r["name"] for r in lighting["reads"]}
+    pp = {p["name"]: p["physical_pass"] for p in g["passes"]}
+    assert len({pp["gbuffer-main"], pp["ssao-main"], pp["lighting-main"]}) == 3
