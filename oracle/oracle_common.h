@@ -8,7 +8,9 @@
 // PARITY UNPINNED: the reference holds no golden vectors / known-answer tests for this path
 //  and cannot be built here (no Vulkan/GLSL toolchain).  The oracle is pinned
 // instead by analytic known-answer cases derived from the shader math (tests/test_oracle_kat.py)
-// and by fixtures under tests/golden/.
+// and by fixtures under tests/golden/.  The host-side math that the reference keeps in buildable C++
+// (math/muglm: half packing, matrix inverse / product) is checked against the real reference code
+// built into oracle/_ref/ by oracle/ref_build/Makefile (tests/test_reference_math_cpu.py).
 //
 // Conventions
 //   * Images are tightly packed row-major linear buffers, origin top-left (Vulkan framebuffer

@@ -172,6 +172,11 @@ void orc_tonemap(const uint16_t *hdr, int w, int h, const uint16_t *bloom, int b
 uint16_t orc_float_to_half(float f) { return float_to_half_rne(f); }
 float orc_half_to_float(uint16_t h) { return half_to_float(h); }
 uint16_t orc_float_to_half_muglm(float f) { return float_to_half_muglm(f); }
+void orc_float_to_half_muglm_array(const float *in, uint16_t *out, uint64_t count)
+{
+	for (uint64_t i = 0; i < count; i++)
+		out[i] = float_to_half_muglm(in[i]);
+}
 uint8_t orc_float_to_srgb8(float f) { return float_to_srgb8(f); }
 float orc_srgb8_to_float(uint8_t v) { return srgb8_to_float(v); }
 void orc_sample_linear_rgba16f(const uint16_t *img, int w, int h, float u, float v, float *out4)
