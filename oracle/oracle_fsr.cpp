@@ -298,6 +298,14 @@ void easu_pixel_f16(const Rgba8 &in, const EasuConstants &con, int x, int y, flo
 
 extern "C" {
 
+// {scale_x, scale_y, offset_x, offset_y} as the upscale pass uses them (checked against the vendored FsrEasuCon in CPU mode,
+// tests/test_reference_math_cpu.py).
+void orc_fsr_easu_constants(int iw, int ih, int ow, int oh, float *out4)
+{
+	const EasuConstants c = easu_constants(iw, ih, ow, oh);
+	out4[0] = c.scale_x, out4[1] = c.scale_y, out4[2] = c.offset_x, out4[3] = c.offset_y;
+}
+
 // upscale pass.  in: RGBA8 bytes (gamma space, iw x ih); out: RGBA8 ow x oh.  fp16: the FP16 shader variant.
 // target_srgb: the output attachment is *_SRGB (upscale.frag:43-45 decodes, the store re-encodes).
 void orc_fsr_easu(const uint8_t *in, int iw, int ih, uint8_t *out, int ow, int oh, int fp16, int target_srgb)

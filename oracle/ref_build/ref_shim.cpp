@@ -7,8 +7,15 @@
 // the real reference code; it never ships and is absent on the GPU box unless built here first.
 #include "muglm/muglm_impl.hpp"
 #include "muglm/matrix_helper.hpp"
+#include <cmath>
 #include <cstdint>
 #include <cstring>
+
+// The FidelityFX headers the reference vendors, in their CPU mode: only the constant set-up functions exist there
+// (FsrEasuCon / FsrRcasCon); the filters themselves are GPU-only code.
+#define A_CPU 1
+#include "ffx-a/ffx_a.h"
+#include "ffx-fsr/ffx_fsr1.h"
 
 using namespace muglm;
 
@@ -72,5 +79,13 @@ void ref_taa_reprojection(const float *prev_view_proj, const float *inv_view_pro
 {
 	store(out, translate(vec3(0.5f, 0.5f, 0.0f)) * scale(vec3(0.5f, 0.5f, 1.0f)) * load(prev_view_proj) * load(inv_view_proj));
 }
+
+// FsrEasuCon as setup_after_post_chain_upscaling calls it (renderer/post/aa.cpp:106-108: viewport = input size) and
+// FsrRcasCon (aa.cpp:157): the 16 + 4 constant words.
+void ref_fsr_easu_constants(float iw, float ih, float ow, float oh, uint32_t *out16)
+{
+	FsrEasuCon(out16, out16 + 4, out16 + 8, out16 + 12, iw, ih, iw, ih, ow, oh);
+}
+void ref_fsr_rcas_constants(float stops, uint32_t *out4) { FsrRcasCon(out4, stops); }
 
 } // extern "C"

@@ -95,3 +95,24 @@ def test_default_harness_projection_is_muglm_perspective(ref):
     ref.ref_perspective(1.0471975512, 1280.0 / 720.0, 0.1, 100.0, want.ctypes.data)
     np.testing.assert_allclose(a.get_render_parameters()[0:16], want, rtol=2e-6, atol=1e-7)
     a.close()
+
+
+def test_fsr_constants_equal_the_vendored_header_in_cpu_mode(ref):
+    """FsrEasuCon / FsrRcasCon compiled from assets/shaders/post/ffx-fsr/ffx_fsr1.h (A_CPU): the resolve-position scale and
+    offset the EASU restatement uses, and the linear sharpness of RCAS."""
+    ref.ref_fsr_easu_constants.argtypes = [C.c_float] * 4 + [C.c_void_p]
+    ref.ref_fsr_rcas_constants.argtypes = [C.c_float, C.c_void_p]
+    orc.lib().orc_fsr_easu_constants.argtypes = [C.c_int] * 4 + [C.c_void_p]
+    for iw, ih, ow, oh in ((1280, 720, 1920, 1080), (2560, 1440, 3840, 2160), (480, 270, 720, 405), (7, 5, 30, 22), (1001, 333, 1920, 1080)):
+        want = np.zeros(16, np.uint32)
+        ref.ref_fsr_easu_constants(iw, ih, ow, oh, want.ctypes.data)
+        got = np.zeros(4, np.float32)
+        orc.lib().orc_fsr_easu_constants(iw, ih, ow, oh, got.ctypes.data)
+        np.testing.assert_array_equal(got.view(np.uint32), want[0:4])
+        # the gather positions are texel corners: con1 = (1/iw, 1/ih, 1/iw, -1/ih), i.e. taps at integer offsets from floor(pp)
+        f = want.view(np.float32)
+        assert f[4] == np.float32(1) / np.float32(iw) and f[5] == np.float32(1) / np.float32(ih)
+        assert f[6] == f[4] and f[7] == -f[5]
+    con = np.zeros(4, np.uint32)
+    ref.ref_fsr_rcas_constants(0.5, con.ctypes.data)
+    assert con.view(np.float32)[0] == np.float32(orc.fsr_rcas_sharpness(0.5))
