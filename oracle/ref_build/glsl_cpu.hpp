@@ -1,0 +1,471 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+//
+// A small GLSL execution environment for the CPU: enough of the language's vector types (with swizzles), built-in functions
+// and resource types that the REFERENCE's own shader sources -- lightly re-spelled by glsl2cpp.py into oracle/_ref/gen/ at
+// build time, never committed -- compile as C++ and run one invocation per call.  Everything here is this repository's own
+// code; it defines what the hardware defines for a shader (texture filtering, format conversion on image stores, fp32
+// arithmetic with no contraction), in exactly the terms the oracle states them, so that what is compared against the oracle
+// is the shader TEXT: its expressions, association order and constants.
+//
+//   * float is IEEE fp32; compile with -ffp-contract=off.  "mediump" is fp32 (desktop / lavapipe behaviour).
+//   * min / max / clamp: IEEE minNum / maxNum.
+//   * textureLod: LinearClamp or NearestClamp on a tightly packed image; texel weights (1 - a, a) from
+//     a = fract(u * w - 0.5), lerp horizontally then vertically -- the oracle's sampler.
+//   * imageStore / fragment outputs convert to the attachment format: RGBA16F round-to-nearest-even, UNORM8
+//     floor(v * 255 + 0.5) after clamping, sRGB8 encode then UNORM8.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include "../oracle_common.h"
+
+namespace glsl
+{
+using uint = uint32_t;
+
+// ---- vectors ------------------------------------------------------------------------------------------------------------
+template <typename T> struct tvec2;
+template <typename T> struct tvec3;
+template <typename T> struct tvec4;
+
+// Swizzle proxies: plain arrays that sit in a union with the components and convert to the selected vector.
+template <typename T, int N, int A, int B>
+struct swz2
+{
+	T d[N];
+	operator tvec2<T>() const;
+	swz2 &operator=(const tvec2<T> &v);
+};
+template <typename T, int N, int A, int B, int C>
+struct swz3
+{
+	T d[N];
+	operator tvec3<T>() const;
+	swz3 &operator=(const tvec3<T> &v);
+};
+template <typename T, int N, int A, int B, int C, int D>
+struct swz4
+{
+	T d[N];
+	operator tvec4<T>() const;
+};
+
+template <typename T>
+struct tvec2
+{
+	using scalar = T;
+	union
+	{
+		struct { T x, y; };
+		struct { T r, g; };
+		T d[2];
+		swz2<T, 2, 0, 1> xy;
+		swz2<T, 2, 1, 0> yx;
+		swz2<T, 2, 0, 0> xx;
+		swz2<T, 2, 1, 1> yy;
+		swz2<T, 2, 0, 1> rg;
+	};
+	tvec2() : x(0), y(0) {}
+	explicit tvec2(T s) : x(s), y(s) {}
+	tvec2(T x_, T y_) : x(x_), y(y_) {}
+	template <typename U> explicit tvec2(const tvec2<U> &o) : x(T(o.x)), y(T(o.y)) {}
+	template <typename U, int N, int A, int B> explicit tvec2(const swz2<U, N, A, B> &o) : x(T(o.d[A])), y(T(o.d[B])) {}
+	tvec2(const tvec2 &o) : x(o.x), y(o.y) {}
+	tvec2 &operator=(const tvec2 &o) { x = o.x; y = o.y; return *this; }
+	T &operator[](int i) { return d[i]; }
+	const T &operator[](int i) const { return d[i]; }
+};
+
+template <typename T>
+struct tvec3
+{
+	using scalar = T;
+	union
+	{
+		struct { T x, y, z; };
+		struct { T r, g, b; };
+		T d[3];
+		swz2<T, 3, 0, 1> xy;
+		swz2<T, 3, 0, 2> xz;
+		swz2<T, 3, 1, 2> yz;
+		swz2<T, 3, 0, 1> rg;
+		swz3<T, 3, 0, 1, 2> xyz;
+		swz3<T, 3, 0, 1, 2> rgb;
+		swz3<T, 3, 2, 1, 0> zyx;
+		swz3<T, 3, 2, 1, 0> bgr;
+	};
+	tvec3() : x(0), y(0), z(0) {}
+	explicit tvec3(T s) : x(s), y(s), z(s) {}
+	tvec3(T x_, T y_, T z_) : x(x_), y(y_), z(z_) {}
+	tvec3(const tvec2<T> &v, T z_) : x(v.x), y(v.y), z(z_) {}
+	tvec3(T x_, const tvec2<T> &v) : x(x_), y(v.x), z(v.y) {}
+	template <typename U> explicit tvec3(const tvec3<U> &o) : x(T(o.x)), y(T(o.y)), z(T(o.z)) {}
+	explicit tvec3(const tvec4<T> &o);
+	tvec3(const tvec3 &o) : x(o.x), y(o.y), z(o.z) {}
+	tvec3 &operator=(const tvec3 &o) { x = o.x; y = o.y; z = o.z; return *this; }
+	T &operator[](int i) { return d[i]; }
+	const T &operator[](int i) const { return d[i]; }
+};
+
+template <typename T>
+struct tvec4
+{
+	using scalar = T;
+	union
+	{
+		struct { T x, y, z, w; };
+		struct { T r, g, b, a; };
+		T d[4];
+		swz2<T, 4, 0, 1> xy;
+		swz2<T, 4, 2, 3> zw;
+		swz2<T, 4, 0, 2> xz;
+		swz2<T, 4, 1, 3> yw;
+		swz2<T, 4, 0, 3> xw;
+		swz2<T, 4, 1, 2> yz;
+		swz2<T, 4, 0, 1> rg;
+		swz2<T, 4, 2, 3> ba;
+		swz2<T, 4, 0, 3> ra;
+		swz3<T, 4, 0, 1, 2> xyz;
+		swz3<T, 4, 0, 1, 2> rgb;
+		swz3<T, 4, 0, 1, 3> xyw;
+		swz3<T, 4, 1, 2, 3> yzw;
+		swz4<T, 4, 0, 1, 2, 3> xyzw;
+		swz4<T, 4, 0, 1, 2, 3> rgba;
+		swz4<T, 4, 3, 2, 0, 1> wzxy;
+		swz4<T, 4, 0, 2, 0, 2> xzxz;
+		swz4<T, 4, 1, 3, 1, 3> ywyw;
+		swz4<T, 4, 0, 0, 1, 1> xxyy;
+		swz4<T, 4, 2, 2, 3, 3> zzww;
+		swz4<T, 4, 0, 1, 0, 1> xyxy;
+		swz4<T, 4, 2, 3, 2, 3> zwzw;
+	};
+	tvec4() : x(0), y(0), z(0), w(0) {}
+	explicit tvec4(T s) : x(s), y(s), z(s), w(s) {}
+	tvec4(T x_, T y_, T z_, T w_) : x(x_), y(y_), z(z_), w(w_) {}
+	tvec4(const tvec3<T> &v, T w_) : x(v.x), y(v.y), z(v.z), w(w_) {}
+	tvec4(const tvec2<T> &v, T z_, T w_) : x(v.x), y(v.y), z(z_), w(w_) {}
+	tvec4(const tvec2<T> &a_, const tvec2<T> &b_) : x(a_.x), y(a_.y), z(b_.x), w(b_.y) {}
+	tvec4(T x_, const tvec3<T> &v) : x(x_), y(v.x), z(v.y), w(v.z) {}
+	template <typename U> explicit tvec4(const tvec4<U> &o) : x(T(o.x)), y(T(o.y)), z(T(o.z)), w(T(o.w)) {}
+	tvec4(const tvec4 &o) : x(o.x), y(o.y), z(o.z), w(o.w) {}
+	tvec4 &operator=(const tvec4 &o) { x = o.x; y = o.y; z = o.z; w = o.w; return *this; }
+	T &operator[](int i) { return d[i]; }
+	const T &operator[](int i) const { return d[i]; }
+};
+
+template <typename T> tvec3<T>::tvec3(const tvec4<T> &o) : x(o.x), y(o.y), z(o.z) {}
+
+template <typename T, int N, int A, int B> swz2<T, N, A, B>::operator tvec2<T>() const { return tvec2<T>(d[A], d[B]); }
+template <typename T, int N, int A, int B> swz2<T, N, A, B> &swz2<T, N, A, B>::operator=(const tvec2<T> &v) { d[A] = v.x; d[B] = v.y; return *this; }
+template <typename T, int N, int A, int B, int C> swz3<T, N, A, B, C>::operator tvec3<T>() const { return tvec3<T>(d[A], d[B], d[C]); }
+template <typename T, int N, int A, int B, int C> swz3<T, N, A, B, C> &swz3<T, N, A, B, C>::operator=(const tvec3<T> &v) { d[A] = v.x; d[B] = v.y; d[C] = v.z; return *this; }
+template <typename T, int N, int A, int B, int C, int D> swz4<T, N, A, B, C, D>::operator tvec4<T>() const { return tvec4<T>(d[A], d[B], d[C], d[D]); }
+
+using vec2 = tvec2<float>;
+using vec3 = tvec3<float>;
+using vec4 = tvec4<float>;
+using ivec2 = tvec2<int>;
+using ivec3 = tvec3<int>;
+using ivec4 = tvec4<int>;
+using uvec2 = tvec2<uint>;
+using uvec3 = tvec3<uint>;
+using uvec4 = tvec4<uint>;
+using bvec2 = tvec2<bool>;
+using bvec3 = tvec3<bool>;
+using bvec4 = tvec4<bool>;
+
+// ---- scalar built-ins (fp32, IEEE minNum / maxNum) -----------------------------------------------------------------------
+inline float min(float a, float b) { return fminf(a, b); }
+inline float max(float a, float b) { return fmaxf(a, b); }
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }
+inline uint min(uint a, uint b) { return a < b ? a : b; }
+inline uint max(uint a, uint b) { return a > b ? a : b; }
+inline float clamp(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+inline int clamp(int v, int lo, int hi) { return min(max(v, lo), hi); }
+inline float mix(float a, float b, float t) { return a * (1.0f - t) + b * t; } // GLSL: x * (1 - a) + y * a
+inline float abs(float v) { return fabsf(v); }
+inline int abs(int v) { return v < 0 ? -v : v; }
+inline float floor(float v) { return floorf(v); }
+inline float ceil(float v) { return ceilf(v); }
+inline float fract(float v) { return v - floorf(v); }
+inline float sqrt(float v) { return sqrtf(v); }
+inline float inversesqrt(float v) { return 1.0f / sqrtf(v); }
+inline float exp2(float v) { return exp2f(v); }
+inline float log2(float v) { return log2f(v); }
+inline float pow(float a, float b) { return powf(a, b); }
+inline float exp(float v) { return expf(v); }
+inline float log(float v) { return logf(v); }
+inline float sin(float v) { return sinf(v); }
+inline float cos(float v) { return cosf(v); }
+inline float sign(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+inline float step(float edge, float v) { return v < edge ? 0.0f : 1.0f; }
+inline float smoothstep(float e0, float e1, float v)
+{
+	const float t = clamp((v - e0) / (e1 - e0), 0.0f, 1.0f);
+	return t * t * (3.0f - 2.0f * t);
+}
+inline float fma(float a, float b, float c) { return fmaf(a, b, c); }
+inline uint floatBitsToUint(float v) { return orc::f2u(v); }
+inline int floatBitsToInt(float v) { return int(orc::f2u(v)); }
+inline float uintBitsToFloat(uint v) { return orc::u2f(v); }
+inline float intBitsToFloat(int v) { return orc::u2f(uint(v)); }
+inline bool isnan(float v) { return v != v; }
+
+// ---- component-wise operators and functions -------------------------------------------------------------------------------
+#define GLSL_VEC_BINOP(V, N, op)                                                                                                    \
+	inline V operator op(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] op b.d[i]; return r; }       \
+	inline V operator op(const V &a, V::scalar s) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] op s; return r; }     \
+	inline V operator op(V::scalar s, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = s op b.d[i]; return r; }     \
+	inline V &operator op##=(V &a, const V &b) { for (int i = 0; i < N; i++) a.d[i] = a.d[i] op b.d[i]; return a; }               \
+	inline V &operator op##=(V &a, V::scalar s) { for (int i = 0; i < N; i++) a.d[i] = a.d[i] op s; return a; }
+
+#define GLSL_VEC_ARITH(V, N)                                                                                  \
+	GLSL_VEC_BINOP(V, N, +)                                                                                     \
+	GLSL_VEC_BINOP(V, N, -)                                                                                     \
+	GLSL_VEC_BINOP(V, N, *)                                                                                     \
+	GLSL_VEC_BINOP(V, N, /)                                                                                     \
+	inline V operator-(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = -a.d[i]; return r; }
+
+GLSL_VEC_ARITH(vec2, 2)
+GLSL_VEC_ARITH(vec3, 3)
+GLSL_VEC_ARITH(vec4, 4)
+GLSL_VEC_ARITH(ivec2, 2)
+GLSL_VEC_ARITH(ivec3, 3)
+GLSL_VEC_ARITH(ivec4, 4)
+GLSL_VEC_ARITH(uvec2, 2)
+GLSL_VEC_ARITH(uvec3, 3)
+GLSL_VEC_ARITH(uvec4, 4)
+
+#define GLSL_INT_OPS(V, N)                                                                                                         \
+	inline V operator>>(const V &a, int s) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] >> s; return r; }                   \
+	inline V operator<<(const V &a, int s) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] << s; return r; }                   \
+	inline V operator&(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] & b.d[i]; return r; }          \
+	inline V operator|(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] | b.d[i]; return r; }          \
+	inline V min(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = min(a.d[i], b.d[i]); return r; }             \
+	inline V max(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = max(a.d[i], b.d[i]); return r; }             \
+	inline V clamp(const V &v, const V &lo, const V &hi) { return min(max(v, lo), hi); }
+GLSL_INT_OPS(ivec2, 2)
+GLSL_INT_OPS(ivec3, 3)
+GLSL_INT_OPS(ivec4, 4)
+GLSL_INT_OPS(uvec2, 2)
+GLSL_INT_OPS(uvec3, 3)
+GLSL_INT_OPS(uvec4, 4)
+
+#define GLSL_MAP1(V, N, fn) \
+	inline V fn(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = fn(a.d[i]); return r; }
+#define GLSL_MAP2(V, N, fn)                                                                               \
+	inline V fn(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = fn(a.d[i], b.d[i]); return r; } \
+	inline V fn(const V &a, float s) { V r; for (int i = 0; i < N; i++) r.d[i] = fn(a.d[i], s); return r; }
+
+#define GLSL_FLOAT_FUNCS(V, N)                                                                                                     \
+	GLSL_MAP1(V, N, abs) GLSL_MAP1(V, N, floor) GLSL_MAP1(V, N, ceil) GLSL_MAP1(V, N, fract) GLSL_MAP1(V, N, sqrt)                 \
+	GLSL_MAP1(V, N, inversesqrt) GLSL_MAP1(V, N, exp2) GLSL_MAP1(V, N, log2) GLSL_MAP1(V, N, sign) GLSL_MAP1(V, N, exp)            \
+	GLSL_MAP1(V, N, log)                                                                                                          \
+	GLSL_MAP2(V, N, min) GLSL_MAP2(V, N, max) GLSL_MAP2(V, N, pow)                                                                \
+	inline V clamp(const V &v, const V &lo, const V &hi) { return min(max(v, lo), hi); }                                          \
+	inline V clamp(const V &v, float lo, float hi) { return min(max(v, lo), hi); }                                                \
+	inline V mix(const V &a, const V &b, const V &t) { V r; for (int i = 0; i < N; i++) r.d[i] = mix(a.d[i], b.d[i], t.d[i]); return r; } \
+	inline V mix(const V &a, const V &b, float t) { V r; for (int i = 0; i < N; i++) r.d[i] = mix(a.d[i], b.d[i], t); return r; } \
+	inline V step(const V &e, const V &v) { V r; for (int i = 0; i < N; i++) r.d[i] = step(e.d[i], v.d[i]); return r; }          \
+	inline V step(float e, const V &v) { V r; for (int i = 0; i < N; i++) r.d[i] = step(e, v.d[i]); return r; }                  \
+	inline float dot(const V &a, const V &b) { float s = a.d[0] * b.d[0]; for (int i = 1; i < N; i++) s = s + a.d[i] * b.d[i]; return s; } \
+	inline float length(const V &a) { return sqrtf(dot(a, a)); }                                                                  \
+	inline float distance(const V &a, const V &b) { return length(a - b); }                                                       \
+	inline V normalize(const V &a) { return a * inversesqrt(dot(a, a)); }
+GLSL_FLOAT_FUNCS(vec2, 2)
+GLSL_FLOAT_FUNCS(vec3, 3)
+GLSL_FLOAT_FUNCS(vec4, 4)
+
+inline vec3 cross(const vec3 &a, const vec3 &b) { return vec3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+
+// mix with a boolean selector picks a side (GLSL 4.5 mix(x, y, bvec)).
+inline vec3 mix(const vec3 &a, const vec3 &b, const bvec3 &t) { return vec3(t.x ? b.x : a.x, t.y ? b.y : a.y, t.z ? b.z : a.z); }
+inline vec2 mix(const vec2 &a, const vec2 &b, const bvec2 &t) { return vec2(t.x ? b.x : a.x, t.y ? b.y : a.y); }
+
+#define GLSL_COMPARE(V, B, N)                                                                                                        \
+	inline B lessThan(const V &a, const V &b) { B r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] < b.d[i]; return r; }             \
+	inline B lessThanEqual(const V &a, const V &b) { B r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] <= b.d[i]; return r; }       \
+	inline B greaterThan(const V &a, const V &b) { B r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] > b.d[i]; return r; }          \
+	inline B greaterThanEqual(const V &a, const V &b) { B r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] >= b.d[i]; return r; }    \
+	inline B equal(const V &a, const V &b) { B r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] == b.d[i]; return r; }               \
+	inline B notEqual(const V &a, const V &b) { B r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] != b.d[i]; return r; }
+GLSL_COMPARE(vec2, bvec2, 2)
+GLSL_COMPARE(vec3, bvec3, 3)
+GLSL_COMPARE(vec4, bvec4, 4)
+GLSL_COMPARE(ivec2, bvec2, 2)
+GLSL_COMPARE(ivec3, bvec3, 3)
+GLSL_COMPARE(uvec2, bvec2, 2)
+GLSL_COMPARE(uvec3, bvec3, 3)
+inline bool any(const bvec2 &v) { return v.x || v.y; }
+inline bool any(const bvec3 &v) { return v.x || v.y || v.z; }
+inline bool any(const bvec4 &v) { return v.x || v.y || v.z || v.w; }
+inline bool all(const bvec2 &v) { return v.x && v.y; }
+inline bool all(const bvec3 &v) { return v.x && v.y && v.z; }
+inline bool all(const bvec4 &v) { return v.x && v.y && v.z && v.w; }
+inline bvec2 operator!(const bvec2 &v) { bvec2 r; r.x = !v.x; r.y = !v.y; return r; }
+
+// ---- matrices (column major) ----------------------------------------------------------------------------------------------
+struct mat2
+{
+	vec2 c[2];
+	mat2() {}
+	mat2(const vec2 &a, const vec2 &b) { c[0] = a; c[1] = b; }
+	vec2 &operator[](int i) { return c[i]; }
+	const vec2 &operator[](int i) const { return c[i]; }
+};
+inline vec2 operator*(const mat2 &m, const vec2 &v) { return m.c[0] * v.x + m.c[1] * v.y; }
+struct mat4
+{
+	vec4 c[4];
+	vec4 &operator[](int i) { return c[i]; }
+	const vec4 &operator[](int i) const { return c[i]; }
+};
+inline vec4 operator*(const mat4 &m, const vec4 &v) { return m.c[0] * v.x + m.c[1] * v.y + m.c[2] * v.z + m.c[3] * v.w; }
+struct mat3
+{
+	vec3 c[3];
+	mat3() {}
+	explicit mat3(const mat4 &m) { for (int i = 0; i < 3; i++) c[i] = vec3(m.c[i]); }
+	vec3 &operator[](int i) { return c[i]; }
+	const vec3 &operator[](int i) const { return c[i]; }
+};
+inline vec3 operator*(const mat3 &m, const vec3 &v) { return m.c[0] * v.x + m.c[1] * v.y + m.c[2] * v.z; }
+
+// ---- resources ------------------------------------------------------------------------------------------------------------
+enum class Format { RGBA16F, RGBA8_UNORM, RGBA8_SRGB, R32F, RG16F, RG8_UNORM, R8_UNORM };
+enum class Filter { Linear, Nearest };
+
+struct Texture
+{
+	const void *data = nullptr;
+	int w = 0, h = 0;
+	Format format = Format::RGBA16F;
+	Filter filter = Filter::Linear;
+
+	vec4 texel(int x, int y) const
+	{
+		x = orc::clampi(x, 0, w - 1);
+		y = orc::clampi(y, 0, h - 1);
+		const size_t i = size_t(y) * w + x;
+		switch (format)
+		{
+		case Format::RGBA16F:
+		{
+			const uint16_t *p = static_cast<const uint16_t *>(data) + i * 4;
+			return vec4(orc::half_to_float(p[0]), orc::half_to_float(p[1]), orc::half_to_float(p[2]), orc::half_to_float(p[3]));
+		}
+		case Format::RGBA8_UNORM:
+		{
+			const uint8_t *p = static_cast<const uint8_t *>(data) + i * 4;
+			return vec4(float(p[0]) / 255.0f, float(p[1]) / 255.0f, float(p[2]) / 255.0f, float(p[3]) / 255.0f);
+		}
+		case Format::RGBA8_SRGB:
+		{
+			const uint8_t *p = static_cast<const uint8_t *>(data) + i * 4;
+			return vec4(orc::srgb8_to_float(p[0]), orc::srgb8_to_float(p[1]), orc::srgb8_to_float(p[2]), float(p[3]) / 255.0f);
+		}
+		case Format::R32F:
+			return vec4(static_cast<const float *>(data)[i], 0.0f, 0.0f, 1.0f);
+		case Format::RG16F:
+		{
+			const uint16_t *p = static_cast<const uint16_t *>(data) + i * 2;
+			return vec4(orc::half_to_float(p[0]), orc::half_to_float(p[1]), 0.0f, 1.0f);
+		}
+		case Format::RG8_UNORM:
+		{
+			const uint8_t *p = static_cast<const uint8_t *>(data) + i * 2;
+			return vec4(float(p[0]) / 255.0f, float(p[1]) / 255.0f, 0.0f, 1.0f);
+		}
+		case Format::R8_UNORM:
+			return vec4(float(static_cast<const uint8_t *>(data)[i]) / 255.0f, 0.0f, 0.0f, 1.0f);
+		}
+		return vec4();
+	}
+
+	vec4 sample(const vec2 &uv, int ox = 0, int oy = 0) const
+	{
+		const float fx = uv.x * float(w) - 0.5f, fy = uv.y * float(h) - 0.5f;
+		const float flx = floorf(fx), fly = floorf(fy);
+		if (filter == Filter::Nearest)
+			return texel(int(floorf(uv.x * float(w))) + ox, int(floorf(uv.y * float(h))) + oy);
+		const float a = fx - flx, b = fy - fly;
+		const int x0 = int(flx) + ox, y0 = int(fly) + oy;
+		const vec4 top = texel(x0, y0) * (1.0f - a) + texel(x0 + 1, y0) * a;
+		const vec4 bottom = texel(x0, y0 + 1) * (1.0f - a) + texel(x0 + 1, y0 + 1) * a;
+		return top * (1.0f - b) + bottom * b;
+	}
+};
+using sampler2D = Texture;
+using texture2D = Texture;
+
+inline vec4 textureLod(const Texture &t, const vec2 &uv, float) { return t.sample(uv); }
+inline vec4 texture(const Texture &t, const vec2 &uv) { return t.sample(uv); }
+inline vec4 textureLodOffset(const Texture &t, const vec2 &uv, float, const ivec2 &o) { return t.sample(uv, o.x, o.y); }
+inline vec4 texelFetch(const Texture &t, const ivec2 &p, int) { return t.texel(p.x, p.y); }
+inline ivec2 textureSize(const Texture &t, int) { return ivec2(t.w, t.h); }
+
+struct Image
+{
+	void *data = nullptr;
+	int w = 0, h = 0;
+	Format format = Format::RGBA16F;
+};
+using image2D = Image;
+
+inline void imageStore(Image &img, const ivec2 &p, const vec4 &v)
+{
+	if (p.x < 0 || p.y < 0 || p.x >= img.w || p.y >= img.h)
+		return;
+	const size_t i = size_t(p.y) * img.w + p.x;
+	switch (img.format)
+	{
+	case Format::RGBA16F:
+	{
+		uint16_t *o = static_cast<uint16_t *>(img.data) + i * 4;
+		for (int c = 0; c < 4; c++)
+			o[c] = orc::float_to_half_rne(v.d[c]);
+		break;
+	}
+	case Format::RGBA8_UNORM:
+	{
+		uint8_t *o = static_cast<uint8_t *>(img.data) + i * 4;
+		for (int c = 0; c < 4; c++)
+			o[c] = orc::float_to_unorm8(v.d[c]);
+		break;
+	}
+	case Format::RGBA8_SRGB:
+	{
+		uint8_t *o = static_cast<uint8_t *>(img.data) + i * 4;
+		for (int c = 0; c < 3; c++)
+			o[c] = orc::float_to_srgb8(v.d[c]);
+		o[3] = orc::float_to_unorm8(v.d[3]);
+		break;
+	}
+	case Format::R32F:
+		static_cast<float *>(img.data)[i] = v.x;
+		break;
+	default:
+		break;
+	}
+}
+
+// ---- per-invocation built-in variables --------------------------------------------------------------------------------------
+inline thread_local uvec3 gl_GlobalInvocationID, gl_LocalInvocationID, gl_WorkGroupID;
+inline thread_local uint gl_LocalInvocationIndex;
+inline thread_local vec4 gl_FragCoord;
+} // namespace glsl
+
+// Qualifiers that mean nothing on the CPU.
+#define mediump
+#define highp
+#define lowp
+#define uniform
+#define writeonly
+#define readonly
+#define coherent
+#define restrict
+#define shared
+#define buffer
+#define precise

@@ -1,0 +1,104 @@
+"""CPU: the oracle against the REFERENCE's OWN SHADER SOURCES, executed.
+
+oracle/ref_build/ re-spells the GLSL of /root/reference/assets/shaders (glsl2cpp.py: strips layout()/precision/interface-block
+syntax, suffixes float literals -- statements, expressions and constants untouched) into oracle/_ref/gen/ and compiles it
+as C++ against a small GLSL environment (glsl_cpu.hpp: vectors with swizzles, built-ins, texture / image types).  The shader
+text that runs here is the reference's; the environment (bilinear filtering, format conversion of stores, fp32 without
+contraction) is stated once and shared with the oracle.  Equality below is therefore a statement about the oracle's reading
+of every expression, association order and constant of these shaders -- it is required BIT FOR BIT."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from granite_amd import synth
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libref_shaders.so")
+P = C.c_void_p
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if os.path.isdir("/root/reference/assets/shaders"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "ref_build")])
+    if not os.path.exists(REF_LIB):
+        pytest.skip("oracle/_ref/libref_shaders.so not built (needs /root/reference)")
+    lib = C.CDLL(REF_LIB)
+    lib.ref_bloom_threshold.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int, P]
+    lib.ref_bloom_downsample.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int, P, C.c_float]
+    lib.ref_bloom_upsample.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int]
+    lib.ref_luminance.argtypes = [P, C.c_int, C.c_int, P, C.c_float, C.c_float, C.c_float]
+    lib.ref_tonemap.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int, P, C.c_float, P]
+    return lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+SIZES = [(256, 256), (200, 120), (333, 77), (65, 129), (16, 16)]
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_post_chain_shaders_bit_for_bit(ref, w, h):
+    """bloom_threshold.comp (both DYNAMIC_EXPOSURE variants), bloom_downsample.comp (plain + FEEDBACK), bloom_upsample.comp,
+    luminance.comp (one 8x8 workgroup of 64 real threads with barriers: the shader's own reduction tree) and tonemap.frag,
+    chained over the pyramid exactly as hdr.cpp records them, two frames so that the feedback paths carry state."""
+    hdr = synth.make_hdr(w, h)
+    lum_lerp, fb_lerp = orc.frame_lerps(0.01)
+    sz = [orc.level_size(w, h, s) for s in (0.5, 0.25, 0.125, 0.0625, 0.03125)]
+    lum = np.array([0.2, 1.1, 0.9], np.float32)
+    history = None
+    for frame in range(2):
+        for l in (None, lum):
+            want = orc.bloom_threshold(hdr, *sz[0], lum3=l)
+            got = np.zeros_like(want)
+            ref.ref_bloom_threshold(ptr(hdr), w, h, ptr(got), sz[0][0], sz[0][1], ptr(l))
+            np.testing.assert_array_equal(got, want, err_msg="bloom_threshold")
+        levels = [want]
+        for i in range(1, 5):
+            hist = history if i == 4 else None
+            want = orc.bloom_downsample(levels[-1], *sz[i], history=hist, lerp=fb_lerp if hist is not None else 0.0)
+            got = np.zeros_like(want)
+            src = levels[-1]
+            ref.ref_bloom_downsample(ptr(src), src.shape[1], src.shape[0], ptr(got), sz[i][0], sz[i][1], ptr(hist), fb_lerp)
+            np.testing.assert_array_equal(got, want, err_msg=f"bloom_downsample level {i} frame {frame}")
+            levels.append(want)
+        history = levels[-1]
+        d3 = levels[-1]
+        if d3.shape[0] >= 2 and d3.shape[1] >= 2:
+            want_lum = orc.luminance(d3, lum.copy(), lum_lerp)
+            got_lum = lum.copy()
+            ref.ref_luminance(ptr(d3), d3.shape[1], d3.shape[0], ptr(got_lum), lum_lerp, -3.0, 2.0)
+            np.testing.assert_array_equal(got_lum.view(np.uint32), want_lum.view(np.uint32), err_msg="luminance")
+            lum = want_lum
+        up = d3
+        for i in (3, 2, 1):
+            want = orc.bloom_upsample(up, *sz[i])
+            got = np.zeros_like(want)
+            ref.ref_bloom_upsample(ptr(up), up.shape[1], up.shape[0], ptr(got), sz[i][0], sz[i][1])
+            np.testing.assert_array_equal(got, want, err_msg=f"bloom_upsample to level {i}")
+            up = want
+        for l, exposure in ((None, 1.0), (lum, 1.0), (lum, 1.7)):
+            want = orc.tonemap(hdr, up, l, exposure)
+            got = np.zeros((h, w, 4), np.uint8)
+            ref.ref_tonemap(ptr(hdr), w, h, ptr(up), up.shape[1], up.shape[0], ptr(l), exposure, ptr(got))
+            np.testing.assert_array_equal(got, want, err_msg="tonemap")
+
+
+def test_whole_chain_equals_hdr_chain_helper(ref):
+    """The same shaders driven in orc.hdr_chain's order reproduce its outputs: the recorded order is part of the contract."""
+    w, h = 192, 108
+    hdr = synth.make_hdr(w, h)
+    state = {}
+    out = None
+    for _ in range(3):
+        out = orc.hdr_chain(hdr, state)
+    got = np.zeros((h, w, 4), np.uint8)
+    u0 = out["u0"]
+    ref.ref_tonemap(ptr(hdr), w, h, ptr(u0), u0.shape[1], u0.shape[0], ptr(out["lum"]), 1.0, ptr(got))
+    np.testing.assert_array_equal(got, out["tonemapped"])
