@@ -211,8 +211,9 @@ def cluster_build(rp, prm, lights, model, type_mask, num_lights: int, res_z: int
 
 
 def lighting(gbuf: dict, rp, prm, lights, type_mask, bitmask, ranges, dir_color, dir_direction, directional=True,
-             clustered=True, ambient_fallback=True, wave_tile=0, bruteforce=False, ambient_occlusion=None) -> np.ndarray:
-    """Returns the HDR target (RGBA16F bits) after DeferredLightRenderer::render_light on gbuf['emissive']."""
+             clustered=True, ambient_fallback=True, wave_tile=0, bruteforce=False, ambient_occlusion=None, entry=None) -> np.ndarray:
+    """Returns the HDR target (RGBA16F bits) after DeferredLightRenderer::render_light on gbuf['emissive'].
+    entry: another implementation taking the same OrcLightingArgs (oracle/_ref's ref_lighting: the reference's own shaders)."""
     h, w = gbuf["depth"].shape
     hdr = np.array(gbuf["emissive"], np.uint16, copy=True)
     a = LightingArgs()
@@ -232,7 +233,9 @@ def lighting(gbuf: dict, rp, prm, lights, type_mask, bitmask, ranges, dir_color,
         ao = np.ascontiguousarray(ambient_occlusion, np.uint8)
         keep.append(ao)
         a.ambient_occlusion, a.ao_height, a.ao_width = ao.ctypes.data, ao.shape[0], ao.shape[1]
-    if bruteforce:
+    if entry is not None:
+        entry(C.byref(a))
+    elif bruteforce:
         lib().orc_lighting_bruteforce_clustered(C.byref(a))
     else:
         lib().orc_lighting(C.byref(a))

@@ -706,6 +706,29 @@ static inline vec3 brdf(const Material &m, vec3 L, vec3 world_pos, vec3 camera_p
 	return specref + diffuse_light;
 }
 
+// compute_lighting (lighting.h:26-47) for the directional quad: the same terms as brdf(), but the light colour multiplies
+// from the left -- light_color * NoL * shadow_term * (...) -- which rounds differently from colour * (NoL * (...)).  Found by
+// running the reference's own directional.frag on the CPU (oracle/ref_build): one fp32 ulp, visible after the fp16 store in
+// about 1 texel in 20 000.
+static inline vec3 directional_lighting(const Material &m, vec3 light_color, vec3 L, vec3 world_pos, vec3 camera_pos)
+{
+	const float shadow_term = 1.0f;
+	float roughness = m.roughness * 0.75f + 0.25f;
+	vec3 V = normalize(camera_pos - world_pos);
+	vec3 H = normalize(V + L);
+	vec3 N = m.N;
+	float NoV = clampf(dot(N, V), 0.001f, 1.0f);
+	float NoL = clampf(dot(N, L), 0.001f, 1.0f);
+	float HoV = clampf(dot(H, V), 0.001f, 1.0f);
+	vec3 F0 = compute_F0(m.base, m.metallic);
+	vec3 specular_fresnel = fresnel(F0, HoV);
+	vec3 cook_torrance = specular_fresnel * G_schlick(roughness, NoV, NoL) * D_GGX(roughness, N, H);
+	vec3 specref = light_color * NoL * shadow_term * cook_torrance;
+	vec3 diffref = light_color * NoL * shadow_term * (V3(1.0f) - specular_fresnel) * (1.0f / PI_SIC);
+	vec3 diffuse_light = diffref * m.base * (1.0f - m.metallic);
+	return specref + diffuse_light;
+}
+
 // point.h:33-84 (no shadows)
 static inline vec3 compute_point_light(const LightInfo &pt, const Material &m, vec3 world_pos, vec3 camera_pos)
 {
@@ -875,7 +898,7 @@ void orc_lighting(const OrcLightingArgs *a)
 						continue;
 					const Material &m = mats[li];
 					// light_color * NoL * shadow_term * (...) — light_color multiplies from the left in lighting.h:41-42.
-					vec3 lit = dcol * brdf(m, ddir, poss[li], camera_pos);
+					vec3 lit = directional_lighting(m, dcol, ddir, poss[li], camera_pos);
 					if (a->ambient_fallback)
 					{
 						const float base_ambient = a->ambient_occlusion

@@ -18,17 +18,17 @@ PARAM_OUT = re.compile(r"\b(?:inout|out)\s+((?:(?:mediump|highp|lowp)\s+)?)(\w+)
 PARAM_IN = re.compile(r"(?<=[(,])\s*in\s+(?=(?:(?:mediump|highp|lowp)\s+)?\w+\s+\w+\s*[,)])")
 
 
-def expand_includes(path: str, seen=None) -> str:
-    seen = seen if seen is not None else set()
+def expand_includes(path: str, stack=()) -> str:
+    """Textual #include expansion.  Every inclusion is expanded -- a header may first appear inside a conditional block that
+    ends up disabled -- and the headers' own #ifndef guards do the de-duplication when the C++ preprocessor runs."""
     real = os.path.realpath(path)
-    if real in seen:  # include guards of the reference headers are #ifndef based; this only stops cycles
+    if real in stack:
         return ""
-    seen.add(real)
     out = []
     for line in open(path, encoding="utf-8", errors="replace").read().splitlines():
         m = re.match(r'\s*#\s*include\s+"([^"]+)"', line)
         if m:
-            out.append(expand_includes(os.path.join(os.path.dirname(path), m.group(1)), seen))
+            out.append(expand_includes(os.path.join(os.path.dirname(path), m.group(1)), stack + (real,)))
         else:
             out.append(line)
     return "\n".join(out)
@@ -47,6 +47,7 @@ def respell(text: str) -> str:
 
     def block(m):
         name, body, instance = m.group(1), m.group(2), m.group(3)
+        body = re.sub(r"(\w+)\s+(\w+)\s*\[\s*\]\s*;", r"const \1 *\2;", body)  # run-time sized array: a pointer
         if instance:
             return "struct %s_block {%s} %s;" % (name, body, instance)
         return body  # no instance name: the members are globals
@@ -66,8 +67,12 @@ def main():
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     with open(dst, "w") as f:
         f.write("// GENERATED from %s by oracle/ref_build/glsl2cpp.py -- reference text, do not commit.\n" % src)
-        f.write(respell(expand_includes(src)))
+        text = respell(expand_includes(src))
+        f.write(text)
         f.write("\n")
+        # Include guards are macros: forget them, so that another variant of the shader can be compiled in another namespace.
+        for guard in sorted(set(re.findall(r"^\s*#\s*ifndef\s+(\w+)\s*\n\s*#\s*define\s+\1\b", text, flags=re.M))):
+            f.write("#undef %s\n" % guard)
 
 
 if __name__ == "__main__":

@@ -184,6 +184,7 @@ inline uint min(uint a, uint b) { return a < b ? a : b; }
 inline uint max(uint a, uint b) { return a > b ? a : b; }
 inline float clamp(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 inline int clamp(int v, int lo, int hi) { return min(max(v, lo), hi); }
+inline uint clamp(uint v, uint lo, uint hi) { return min(max(v, lo), hi); }
 inline float mix(float a, float b, float t) { return a * (1.0f - t) + b * t; } // GLSL: x * (1 - a) + y * a
 inline float abs(float v) { return fabsf(v); }
 inline int abs(int v) { return v < 0 ? -v : v; }
@@ -273,7 +274,7 @@ GLSL_INT_OPS(uvec4, 4)
 	inline float dot(const V &a, const V &b) { float s = a.d[0] * b.d[0]; for (int i = 1; i < N; i++) s = s + a.d[i] * b.d[i]; return s; } \
 	inline float length(const V &a) { return sqrtf(dot(a, a)); }                                                                  \
 	inline float distance(const V &a, const V &b) { return length(a - b); }                                                       \
-	inline V normalize(const V &a) { return a * inversesqrt(dot(a, a)); }
+	inline V normalize(const V &a) { return a / length(a); } /* as the oracle states it: every step an IEEE operation */
 GLSL_FLOAT_FUNCS(vec2, 2)
 GLSL_FLOAT_FUNCS(vec3, 3)
 GLSL_FLOAT_FUNCS(vec4, 4)
@@ -327,14 +328,40 @@ struct mat3
 {
 	vec3 c[3];
 	mat3() {}
+	mat3(const vec3 &a, const vec3 &b, const vec3 &cc) { c[0] = a; c[1] = b; c[2] = cc; }
 	explicit mat3(const mat4 &m) { for (int i = 0; i < 3; i++) c[i] = vec3(m.c[i]); }
 	vec3 &operator[](int i) { return c[i]; }
 	const vec3 &operator[](int i) const { return c[i]; }
 };
 inline vec3 operator*(const mat3 &m, const vec3 &v) { return m.c[0] * v.x + m.c[1] * v.y + m.c[2] * v.z; }
 
+// mat3x4: 3 columns of 4 components; vec4 * mat3x4 = the three column dot products.
+struct mat3x4
+{
+	vec4 c[3];
+	mat3x4() {}
+	mat3x4(const vec4 &a, const vec4 &b, const vec4 &cc) { c[0] = a; c[1] = b; c[2] = cc; }
+};
+inline vec3 operator*(const vec4 &v, const mat3x4 &m) { return vec3(dot(v, m.c[0]), dot(v, m.c[1]), dot(v, m.c[2])); }
+inline vec3 operator*(const vec3 &v, const mat3 &m) { return vec3(dot(v, m.c[0]), dot(v, m.c[1]), dot(v, m.c[2])); }
+
+// ---- integer / packing built-ins -------------------------------------------------------------------------------------------
+inline int findLSB(uint v) { return v ? __builtin_ctz(v) : -1; }
+inline int findLSB(int v) { return findLSB(uint(v)); }
+inline int findMSB(uint v) { return v ? 31 - __builtin_clz(v) : -1; }
+inline int bitCount(uint v) { return __builtin_popcount(v); }
+inline vec2 unpackHalf2x16(uint v) { return vec2(orc::half_to_float(uint16_t(v & 0xffffu)), orc::half_to_float(uint16_t(v >> 16))); }
+inline uint bitfieldExtract(uint v, int offset, int bits) { return bits == 0 ? 0u : (v >> offset) & (bits == 32 ? 0xffffffffu : ((1u << bits) - 1u)); }
+
+// ---- subgroup operations of a one-invocation subgroup (each invocation runs alone: the exact per-pixel form) -----------------
+template <typename T> inline T subgroupMin(const T &v) { return v; }
+template <typename T> inline T subgroupMax(const T &v) { return v; }
+template <typename T> inline T subgroupOr(const T &v) { return v; }
+template <typename T> inline T subgroupBroadcastFirst(const T &v) { return v; }
+template <typename T> inline const T &nonuniformEXT(const T &v) { return v; }
+
 // ---- resources ------------------------------------------------------------------------------------------------------------
-enum class Format { RGBA16F, RGBA8_UNORM, RGBA8_SRGB, R32F, RG16F, RG8_UNORM, R8_UNORM };
+enum class Format { RGBA16F, RGBA8_UNORM, RGBA8_SRGB, R32F, RG16F, RG8_UNORM, R8_UNORM, A2B10G10R10_UNORM };
 enum class Filter { Linear, Nearest };
 
 struct Texture
@@ -380,6 +407,11 @@ struct Texture
 		}
 		case Format::R8_UNORM:
 			return vec4(float(static_cast<const uint8_t *>(data)[i]) / 255.0f, 0.0f, 0.0f, 1.0f);
+		case Format::A2B10G10R10_UNORM:
+		{
+			const orc::vec4 v = orc::unpack_a2b10g10r10(static_cast<const uint32_t *>(data)[i]);
+			return vec4(v.x, v.y, v.z, v.w);
+		}
 		}
 		return vec4();
 	}
@@ -399,6 +431,7 @@ struct Texture
 };
 using sampler2D = Texture;
 using texture2D = Texture;
+using subpassInput = Texture; // an input attachment: the texel under the fragment
 
 inline vec4 textureLod(const Texture &t, const vec2 &uv, float) { return t.sample(uv); }
 inline vec4 texture(const Texture &t, const vec2 &uv) { return t.sample(uv); }
@@ -455,6 +488,7 @@ inline void imageStore(Image &img, const ivec2 &p, const vec4 &v)
 inline thread_local uvec3 gl_GlobalInvocationID, gl_LocalInvocationID, gl_WorkGroupID;
 inline thread_local uint gl_LocalInvocationIndex;
 inline thread_local vec4 gl_FragCoord;
+inline vec4 subpassLoad(const Texture &t) { return t.texel(int(gl_FragCoord.x), int(gl_FragCoord.y)); }
 } // namespace glsl
 
 // Qualifiers that mean nothing on the CPU.

@@ -102,3 +102,38 @@ def test_whole_chain_equals_hdr_chain_helper(ref):
     u0 = out["u0"]
     ref.ref_tonemap(ptr(hdr), w, h, ptr(u0), u0.shape[1], u0.shape[0], ptr(out["lum"]), 1.0, ptr(got))
     np.testing.assert_array_equal(got, out["tonemapped"])
+
+
+# ---- deferred lighting: lights/directional.frag + lights/clustering.frag and everything they include -----------------------
+def lighting_scene(w, h, num_lights, seed_offset=0):
+    cam = synth.Camera(w, h)
+    gbuf = synth.make_gbuffer(cam)
+    rp = cam.render_params()
+    n, lights, model, tmask, _ = orc.pack_lights(synth.make_lights(cam, num_lights), rp[99:102])
+    prm = orc.cluster_params(rp, *synth.CLUSTER_RESOLUTION, n)
+    cb = orc.cluster_build(rp, prm, lights, model, tmask, n, synth.CLUSTER_RESOLUTION[2])
+    return gbuf, rp, prm, lights, tmask, cb
+
+
+@pytest.mark.parametrize("w,h,num_lights", [(160, 90, 300), (97, 61, 64), (64, 36, 4096), (48, 27, 0), (33, 19, 1)])
+def test_lighting_shaders_bit_for_bit(ref, w, h, num_lights):
+    """render_light's two quads with the shader variants of this path (renderer.cpp:1020-1056,1125-1147), one fragment per
+    subgroup (the exact per-pixel light set = the oracle's wave_tile 0 form): directional with / without the fallback ambient
+    term, the AMBIENT_OCCLUSION variant with a half-size AO texture, clustered point + spot lights, and both blended."""
+    gbuf, rp, prm, lights, tmask, cb = lighting_scene(w, h, num_lights)
+    ao = np.random.default_rng(w).integers(0, 256, (max(h // 2, 1), max(w // 2, 1)), dtype=np.uint8)
+
+    def both(**kw):
+        args = (gbuf, rp, prm, lights, tmask, cb["bitmask"], cb["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
+        return orc.lighting(*args, **kw), orc.lighting(*args, entry=ref.ref_lighting, **kw)
+
+    for kw in (dict(clustered=False, ambient_fallback=False), dict(clustered=False), dict(directional=False), dict(),
+               dict(ambient_occlusion=ao)):
+        want, got = both(**kw)
+        np.testing.assert_array_equal(got, want, err_msg=str({k: (v if k != "ambient_occlusion" else "ao") for k, v in kw.items()}))
+    # sky pixels (depth 0) are untouched by both quads: depth test NOT_EQUAL
+    sky = gbuf["depth"] == 0.0
+    np.testing.assert_array_equal(got[sky], gbuf["emissive"][sky])
+    if num_lights:
+        plain, _ = both(clustered=False)
+        assert (want != plain).any(), "clustered lights must contribute"
