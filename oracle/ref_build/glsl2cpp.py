@@ -47,7 +47,7 @@ def respell(text: str) -> str:
 
     def block(m):
         name, body, instance = m.group(1), m.group(2), m.group(3)
-        body = re.sub(r"(\w+)\s+(\w+)\s*\[\s*\]\s*;", r"const \1 *\2;", body)  # run-time sized array: a pointer
+        body = re.sub(r"(\w+)\s+(\w+)\s*\[\s*\]\s*;", r"\1 *\2;", body)  # run-time sized array: a pointer
         if instance:
             return "struct %s_block {%s} %s;" % (name, body, instance)
         return body  # no instance name: the members are globals

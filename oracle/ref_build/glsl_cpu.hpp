@@ -133,6 +133,7 @@ struct tvec4
 		swz4<T, 4, 0, 1, 2, 3> xyzw;
 		swz4<T, 4, 0, 1, 2, 3> rgba;
 		swz4<T, 4, 3, 2, 0, 1> wzxy;
+		swz4<T, 4, 0, 2, 1, 3> xzyw;
 		swz4<T, 4, 0, 2, 0, 2> xzxz;
 		swz4<T, 4, 1, 3, 1, 3> ywyw;
 		swz4<T, 4, 0, 0, 1, 1> xxyy;
@@ -147,6 +148,7 @@ struct tvec4
 	tvec4(const tvec2<T> &v, T z_, T w_) : x(v.x), y(v.y), z(z_), w(w_) {}
 	tvec4(const tvec2<T> &a_, const tvec2<T> &b_) : x(a_.x), y(a_.y), z(b_.x), w(b_.y) {}
 	tvec4(T x_, const tvec3<T> &v) : x(x_), y(v.x), z(v.y), w(v.z) {}
+	tvec4(T x_, const tvec2<T> &v, T w_) : x(x_), y(v.x), z(v.y), w(w_) {}
 	template <typename U> explicit tvec4(const tvec4<U> &o) : x(T(o.x)), y(T(o.y)), z(T(o.z)), w(T(o.w)) {}
 	tvec4(const tvec4 &o) : x(o.x), y(o.y), z(o.z), w(o.w) {}
 	tvec4 &operator=(const tvec4 &o) { x = o.x; y = o.y; z = o.z; w = o.w; return *this; }
@@ -306,17 +308,32 @@ inline bool all(const bvec2 &v) { return v.x && v.y; }
 inline bool all(const bvec3 &v) { return v.x && v.y && v.z; }
 inline bool all(const bvec4 &v) { return v.x && v.y && v.z && v.w; }
 inline bvec2 operator!(const bvec2 &v) { bvec2 r; r.x = !v.x; r.y = !v.y; return r; }
+inline bvec4 operator!(const bvec4 &v) { bvec4 r; for (int i = 0; i < 4; i++) r.d[i] = !v.d[i]; return r; } // GLSL not(): `not` is C++'s !
+inline bool isinf(float v) { return std::isinf(v); }
+inline bvec4 isinf(const vec4 &v) { bvec4 r; for (int i = 0; i < 4; i++) r.d[i] = std::isinf(v.d[i]); return r; }
+inline bvec2 isinf(const vec2 &v) { bvec2 r; r.x = std::isinf(v.x); r.y = std::isinf(v.y); return r; }
 
 // ---- matrices (column major) ----------------------------------------------------------------------------------------------
 struct mat2
 {
 	vec2 c[2];
 	mat2() {}
+	explicit mat2(float d) { c[0] = vec2(d, 0.0f); c[1] = vec2(0.0f, d); }
+	mat2(float a, float b, float cc, float d) { c[0] = vec2(a, b); c[1] = vec2(cc, d); } // column major
 	mat2(const vec2 &a, const vec2 &b) { c[0] = a; c[1] = b; }
 	vec2 &operator[](int i) { return c[i]; }
 	const vec2 &operator[](int i) const { return c[i]; }
 };
 inline vec2 operator*(const mat2 &m, const vec2 &v) { return m.c[0] * v.x + m.c[1] * v.y; }
+inline mat2 operator*(const mat2 &m, float s) { return mat2(m.c[0] * s, m.c[1] * s); }
+struct mat3x2 // 3 columns of 2 components
+{
+	vec2 c[3];
+	mat3x2() {}
+	mat3x2(const vec2 &a, const vec2 &b, const vec2 &cc) { c[0] = a; c[1] = b; c[2] = cc; }
+	vec2 &operator[](int i) { return c[i]; }
+	const vec2 &operator[](int i) const { return c[i]; }
+};
 struct mat4
 {
 	vec4 c[4];
@@ -488,6 +505,8 @@ inline void imageStore(Image &img, const ivec2 &p, const vec4 &v)
 inline thread_local uvec3 gl_GlobalInvocationID, gl_LocalInvocationID, gl_WorkGroupID;
 inline thread_local uint gl_LocalInvocationIndex;
 inline thread_local vec4 gl_FragCoord;
+inline thread_local uint gl_SubgroupSize = 1, gl_SubgroupInvocationID = 0, gl_NumSubgroups = 1, gl_SubgroupID = 0;
+inline uint atomicOr(uint &mem, uint v) { return __atomic_fetch_or(&mem, v, __ATOMIC_SEQ_CST); }
 inline vec4 subpassLoad(const Texture &t) { return t.texel(int(gl_FragCoord.x), int(gl_FragCoord.y)); }
 } // namespace glsl
 

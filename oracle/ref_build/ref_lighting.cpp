@@ -206,8 +206,8 @@ extern "C" void ref_lighting(const LightingArgs *a)
 		}
 		for (int i = 0; i < 128; i++)
 			s::cluster_transforms.type_mask[i] = a->type_mask[i];
-		s::cluster_bitmask = a->bitmask;
-		s::cluster_range = reinterpret_cast<const uvec2 *>(a->range);
+		s::cluster_bitmask = const_cast<uint32_t *>(a->bitmask); // read-only in the shader; run-time sized arrays are plain pointers
+		s::cluster_range = reinterpret_cast<uvec2 *>(const_cast<uint32_t *>(a->range));
 		s::registers.inverse_view_projection_col2 = inv_vp.c[2];
 		s::registers.camera_pos = ld3(a->rp->camera_position);
 		s::registers.inv_resolution = inv_resolution;

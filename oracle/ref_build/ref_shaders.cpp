@@ -15,8 +15,8 @@ namespace
 {
 std::barrier<> *workgroup_barrier = nullptr;
 }
-inline void memoryBarrierShared() {}
-inline void barrier()
+static inline void memoryBarrierShared() {}
+static inline void barrier()
 {
 	if (workgroup_barrier)
 		workgroup_barrier->arrive_and_wait();

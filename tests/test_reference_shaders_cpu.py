@@ -137,3 +137,34 @@ def test_lighting_shaders_bit_for_bit(ref, w, h, num_lights):
     if num_lights:
         plain, _ = both(clustered=False)
         assert (want != plain).any(), "clustered lights must contribute"
+
+
+# ---- cluster build: lights/clusterer_bindless_{spot_transform,setup,binning,z_range}.comp -------------------------------------
+@pytest.mark.parametrize("num_lights,res,forms", [(96, (16, 8, 64), (0, 64, 32)), (300, (32, 16, 256), (64, 32)), (33, (8, 8, 64), (0, 64)),
+                                                  (1, (8, 8, 64), (0, 64))])
+def test_cluster_build_shaders_bit_for_bit(ref, num_lights, res, forms):
+    """The four compute shaders of LightClusterer's GPU cluster build with the push constants / buffers of clusterer.cpp:1277-1346,
+    1463-1562.  Binning runs in all three forms the reference can take: plain (32 threads per cell and 32-light chunk, shared
+    mask, barriers) and SUBGROUPS with 64- and 32-lane subgroups (ballot of the coarse 8 x N tile test, then per-cell tests);
+    workgroups are teams of real threads.  Every buffer -- transformed spots, cull set-up (incl. what the shader leaves
+    untouched), cell bitmasks, per-slice light ranges -- must equal the oracle's bit for bit."""
+    for name, argtypes in (("ref_cluster_spot_transform", [P, P, C.c_int, P]), ("ref_cluster_setup", [P, P, P, P, P, C.c_int, P]),
+                           ("ref_cluster_binning", [P, P, P, P, C.c_int]), ("ref_cluster_z_range", [P, C.c_int, C.c_int, P])):
+        getattr(ref, name).argtypes = argtypes
+    cam = synth.Camera(320, 180)
+    rp = cam.render_params()
+    n, lights, model, tmask, _ = orc.pack_lights(synth.make_lights(cam, num_lights), rp[99:102])
+    prm = orc.cluster_params(rp, *res, n)
+    for subgroup in forms:
+        cb = orc.cluster_build(rp, prm, lights, model, tmask, n, res[2], subgroup_tile_h=subgroup // 8)
+        spots, setup = np.zeros_like(cb["spots"]), np.zeros_like(cb["setup"])
+        bitmask, ranges = np.zeros_like(cb["bitmask"]), np.zeros_like(cb["range"])
+        ref.ref_cluster_spot_transform(ptr(rp), ptr(model), n, ptr(spots))
+        ref.ref_cluster_setup(ptr(rp), ptr(prm), ptr(lights), ptr(tmask), ptr(spots), n, ptr(setup))
+        ref.ref_cluster_binning(ptr(prm), ptr(tmask), ptr(setup), ptr(bitmask), subgroup)
+        ref.ref_cluster_z_range(ptr(cb["light_ranges"]), n, res[2], ptr(ranges))
+        np.testing.assert_array_equal(spots.view(np.uint32), cb["spots"].view(np.uint32), err_msg="transformed spots")
+        np.testing.assert_array_equal(setup.view(np.uint32), cb["setup"].view(np.uint32), err_msg="cull set-up")
+        np.testing.assert_array_equal(bitmask, cb["bitmask"], err_msg=f"cell bitmask, subgroup size {subgroup}")
+        np.testing.assert_array_equal(ranges, cb["range"], err_msg="slice ranges")
+        assert bitmask.any()
