@@ -454,6 +454,14 @@ inline vec4 textureLod(const Texture &t, const vec2 &uv, float) { return t.sampl
 inline vec4 texture(const Texture &t, const vec2 &uv) { return t.sample(uv); }
 inline vec4 textureLodOffset(const Texture &t, const vec2 &uv, float, const ivec2 &o) { return t.sample(uv, o.x, o.y); }
 inline vec4 texelFetch(const Texture &t, const ivec2 &p, int) { return t.texel(p.x, p.y); }
+// textureGather: the 2 x 2 footprint a bilinear fetch at uv would read, one component: (x, y, z, w) = texels
+// (i0, j0 + 1), (i0 + 1, j0 + 1), (i0 + 1, j0), (i0, j0) with (i0, j0) = floor(uv * size - 0.5); coordinates clamp per texel.
+inline vec4 textureGatherOffset(const Texture &t, const vec2 &uv, const ivec2 &o, int comp = 0)
+{
+	const int i0 = int(floorf(uv.x * float(t.w) - 0.5f)) + o.x, j0 = int(floorf(uv.y * float(t.h) - 0.5f)) + o.y;
+	return vec4(t.texel(i0, j0 + 1).d[comp], t.texel(i0 + 1, j0 + 1).d[comp], t.texel(i0 + 1, j0).d[comp], t.texel(i0, j0).d[comp]);
+}
+inline vec4 textureGather(const Texture &t, const vec2 &uv, int comp = 0) { return textureGatherOffset(t, uv, ivec2(0, 0), comp); }
 inline ivec2 textureSize(const Texture &t, int) { return ivec2(t.w, t.h); }
 
 struct Image

@@ -168,3 +168,52 @@ def test_cluster_build_shaders_bit_for_bit(ref, num_lights, res, forms):
         np.testing.assert_array_equal(bitmask, cb["bitmask"], err_msg=f"cell bitmask, subgroup size {subgroup}")
         np.testing.assert_array_equal(ranges, cb["range"], err_msg="slice ranges")
         assert bitmask.any()
+
+
+# ---- anti-aliasing: post/fxaa.frag, post/taa_resolve.frag (+ reprojection.h, reprojection_color_space.h) -----------------------
+def blocky(w, h, seed=7):
+    r = np.random.default_rng(seed)
+    coarse = r.integers(0, 256, ((h + 2) // 3, (w + 2) // 3, 4), dtype=np.uint8)
+    img = np.repeat(np.repeat(coarse, 3, axis=0), 3, axis=1)[:h, :w].copy()
+    fine = r.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    mask = r.random((h, w)) < 0.3
+    img[mask] = fine[mask]
+    img[..., 3] = 255
+    return img
+
+
+@pytest.mark.parametrize("w,h", [(120, 67), (64, 64), (9, 7)])
+def test_fxaa_shader_bit_for_bit(ref, w, h):
+    ref.ref_fxaa.argtypes = [P, C.c_int, C.c_int, P, C.c_int]
+    img = blocky(w, h)
+    for srgb in (False, True):
+        want = orc.fxaa(img, srgb)
+        got = np.zeros_like(want)
+        ref.ref_fxaa(ptr(img), w, h, ptr(got), int(srgb))
+        np.testing.assert_array_equal(got, want, err_msg=f"fxaa, FXAA_TARGET_SRGB={int(srgb)}")
+
+
+@pytest.mark.parametrize("quality", [0, 1, 2])
+def test_taa_resolve_shader_bit_for_bit(ref, quality):
+    """TAA_QUALITY 0 / 1 / 2 (clamp vs AABB clip, 5-tap vs rounded-corner vs variance neighbourhood, bilinear vs Catmull-Rom
+    history, 5-tap vs 3x3 nearest depth), the first frame without history and two frames with it (moving camera + explicit
+    motion vectors)."""
+    ref.ref_taa_resolve.argtypes = [P, P, P, P, C.c_int, C.c_int, P, C.c_int, P, P]
+    w, h = 120, 68
+    cam = synth.Camera(w, h)
+    depth = np.ascontiguousarray(synth.make_gbuffer(cam, 3)["depth"], np.float32)
+    mv = np.ascontiguousarray(synth.make_motion_vectors(w, h), np.uint16)
+    view_prev = synth.look_at((0.01, 2.0, 8.0), (0.01, 1.0, 0.0))
+    T = np.eye(4)
+    T[0, 0] = T[1, 1] = 0.5
+    T[0, 3] = T[1, 3] = 0.5
+    reproj = np.ascontiguousarray((T @ (cam.P @ view_prev) @ cam.invVP).T, np.float32).reshape(16)
+    history = None
+    for frame in range(3):
+        cur = synth.make_hdr(w, h, seed=3 + 8 * frame)
+        want_c, want_h = orc.taa_resolve(cur, depth, mv, history, reproj, quality)
+        got_c, got_h = np.zeros_like(want_c), np.zeros_like(want_h)
+        ref.ref_taa_resolve(ptr(cur), ptr(depth), ptr(mv), ptr(history), w, h, ptr(reproj), quality, ptr(got_c), ptr(got_h))
+        np.testing.assert_array_equal(got_c, want_c, err_msg=f"colour, frame {frame}")
+        np.testing.assert_array_equal(got_h, want_h, err_msg=f"history, frame {frame}")
+        history = want_h
