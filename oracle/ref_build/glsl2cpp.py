@@ -14,7 +14,7 @@ import sys
 
 FLOAT_LITERAL = re.compile(r"(?<![\w.])((?:\d+\.\d*|\.\d+)(?:[eE][-+]?\d+)?|\d+[eE][-+]?\d+)(?![\w.]|f\b)")
 BLOCK = re.compile(r"\b(?:uniform|buffer)\s+(\w+)\s*\{([^{}]*)\}\s*(\w*)\s*;", re.S)
-PARAM_OUT = re.compile(r"\b(?:inout|out)\s+((?:(?:mediump|highp|lowp)\s+)?)(\w+)\s+(\w+)(?=\s*[,)])")
+PARAM_OUT = re.compile(r"\b(?:inout|out)\s+((?:(?:mediump|highp|lowp)\s+)?)(\w+)\s+(\w+)(?=\s*([,)\[]))")
 PARAM_IN = re.compile(r"(?<=[(,])\s*in\s+(?=(?:(?:mediump|highp|lowp)\s+)?\w+\s+\w+\s*[,)])")
 
 
@@ -56,7 +56,9 @@ def respell(text: str) -> str:
     # stage inputs / outputs become per-invocation globals
     text = re.sub(r"^[ \t]*(?:in|out)[ \t]+((?:(?:mediump|highp|lowp|flat)[ \t]+)*\w+[ \t]+\w+[ \t]*;)", r"thread_local \1", text, flags=re.M)
     text = text.replace("flat ", "")
-    text = PARAM_OUT.sub(lambda m: "%s%s &%s" % (m.group(1), m.group(2), m.group(3)), text)
+    # out / inout parameters are references; arrays already are
+    text = PARAM_OUT.sub(lambda m: "%s%s %s%s" % (m.group(1), m.group(2), "" if m.group(4) == "[" else "&", m.group(3)), text)
+    text = re.sub(r"\bvec4\s*\[\s*\]\s*\(", "glsl::array_of_vec4(", text)  # array constructor
     text = PARAM_IN.sub(" ", text)
     text = FLOAT_LITERAL.sub(lambda m: m.group(1) + "f", text)
     return text

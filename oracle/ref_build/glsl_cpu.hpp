@@ -29,19 +29,41 @@ template <typename T> struct tvec2;
 template <typename T> struct tvec3;
 template <typename T> struct tvec4;
 
-// Swizzle proxies: plain arrays that sit in a union with the components and convert to the selected vector.
+// Swizzle proxies: plain arrays that sit in a union with the components and convert to the selected vector.  A swizzle that
+// names consecutive components in order (.xy, .zw, .rgb ...) IS such a vector in memory and converts to a reference, so it
+// can be passed to an inout parameter or compound-assigned; the others convert by value and support plain assignment.
+template <typename T, int N, int A, int B, bool Contiguous = (B == A + 1)>
+struct swz2;
 template <typename T, int N, int A, int B>
-struct swz2
+struct swz2<T, N, A, B, false>
 {
 	T d[N];
 	operator tvec2<T>() const;
 	swz2 &operator=(const tvec2<T> &v);
 };
+template <typename T, int N, int A, int B>
+struct swz2<T, N, A, B, true>
+{
+	T d[N];
+	operator tvec2<T> &();
+	operator const tvec2<T> &() const;
+	swz2 &operator=(const tvec2<T> &v);
+};
+template <typename T, int N, int A, int B, int C, bool Contiguous = (B == A + 1 && C == A + 2)>
+struct swz3;
 template <typename T, int N, int A, int B, int C>
-struct swz3
+struct swz3<T, N, A, B, C, false>
 {
 	T d[N];
 	operator tvec3<T>() const;
+	swz3 &operator=(const tvec3<T> &v);
+};
+template <typename T, int N, int A, int B, int C>
+struct swz3<T, N, A, B, C, true>
+{
+	T d[N];
+	operator tvec3<T> &();
+	operator const tvec3<T> &() const;
 	swz3 &operator=(const tvec3<T> &v);
 };
 template <typename T, int N, int A, int B, int C, int D>
@@ -49,6 +71,7 @@ struct swz4
 {
 	T d[N];
 	operator tvec4<T>() const;
+	swz4 &operator=(const tvec4<T> &v);
 };
 
 template <typename T>
@@ -60,17 +83,13 @@ struct tvec2
 		struct { T x, y; };
 		struct { T r, g; };
 		T d[2];
-		swz2<T, 2, 0, 1> xy;
-		swz2<T, 2, 1, 0> yx;
-		swz2<T, 2, 0, 0> xx;
-		swz2<T, 2, 1, 1> yy;
-		swz2<T, 2, 0, 1> rg;
+#include "gen/swizzles_2.inc"
 	};
 	tvec2() : x(0), y(0) {}
 	explicit tvec2(T s) : x(s), y(s) {}
 	tvec2(T x_, T y_) : x(x_), y(y_) {}
 	template <typename U> explicit tvec2(const tvec2<U> &o) : x(T(o.x)), y(T(o.y)) {}
-	template <typename U, int N, int A, int B> explicit tvec2(const swz2<U, N, A, B> &o) : x(T(o.d[A])), y(T(o.d[B])) {}
+	template <typename U, int N, int A, int B, bool K> explicit tvec2(const swz2<U, N, A, B, K> &o) : x(T(o.d[A])), y(T(o.d[B])) {}
 	tvec2(const tvec2 &o) : x(o.x), y(o.y) {}
 	tvec2 &operator=(const tvec2 &o) { x = o.x; y = o.y; return *this; }
 	T &operator[](int i) { return d[i]; }
@@ -86,14 +105,7 @@ struct tvec3
 		struct { T x, y, z; };
 		struct { T r, g, b; };
 		T d[3];
-		swz2<T, 3, 0, 1> xy;
-		swz2<T, 3, 0, 2> xz;
-		swz2<T, 3, 1, 2> yz;
-		swz2<T, 3, 0, 1> rg;
-		swz3<T, 3, 0, 1, 2> xyz;
-		swz3<T, 3, 0, 1, 2> rgb;
-		swz3<T, 3, 2, 1, 0> zyx;
-		swz3<T, 3, 2, 1, 0> bgr;
+#include "gen/swizzles_3.inc"
 	};
 	tvec3() : x(0), y(0), z(0) {}
 	explicit tvec3(T s) : x(s), y(s), z(s) {}
@@ -117,29 +129,7 @@ struct tvec4
 		struct { T x, y, z, w; };
 		struct { T r, g, b, a; };
 		T d[4];
-		swz2<T, 4, 0, 1> xy;
-		swz2<T, 4, 2, 3> zw;
-		swz2<T, 4, 0, 2> xz;
-		swz2<T, 4, 1, 3> yw;
-		swz2<T, 4, 0, 3> xw;
-		swz2<T, 4, 1, 2> yz;
-		swz2<T, 4, 0, 1> rg;
-		swz2<T, 4, 2, 3> ba;
-		swz2<T, 4, 0, 3> ra;
-		swz3<T, 4, 0, 1, 2> xyz;
-		swz3<T, 4, 0, 1, 2> rgb;
-		swz3<T, 4, 0, 1, 3> xyw;
-		swz3<T, 4, 1, 2, 3> yzw;
-		swz4<T, 4, 0, 1, 2, 3> xyzw;
-		swz4<T, 4, 0, 1, 2, 3> rgba;
-		swz4<T, 4, 3, 2, 0, 1> wzxy;
-		swz4<T, 4, 0, 2, 1, 3> xzyw;
-		swz4<T, 4, 0, 2, 0, 2> xzxz;
-		swz4<T, 4, 1, 3, 1, 3> ywyw;
-		swz4<T, 4, 0, 0, 1, 1> xxyy;
-		swz4<T, 4, 2, 2, 3, 3> zzww;
-		swz4<T, 4, 0, 1, 0, 1> xyxy;
-		swz4<T, 4, 2, 3, 2, 3> zwzw;
+#include "gen/swizzles_4.inc"
 	};
 	tvec4() : x(0), y(0), z(0), w(0) {}
 	explicit tvec4(T s) : x(s), y(s), z(s), w(s) {}
@@ -158,11 +148,23 @@ struct tvec4
 
 template <typename T> tvec3<T>::tvec3(const tvec4<T> &o) : x(o.x), y(o.y), z(o.z) {}
 
-template <typename T, int N, int A, int B> swz2<T, N, A, B>::operator tvec2<T>() const { return tvec2<T>(d[A], d[B]); }
-template <typename T, int N, int A, int B> swz2<T, N, A, B> &swz2<T, N, A, B>::operator=(const tvec2<T> &v) { d[A] = v.x; d[B] = v.y; return *this; }
-template <typename T, int N, int A, int B, int C> swz3<T, N, A, B, C>::operator tvec3<T>() const { return tvec3<T>(d[A], d[B], d[C]); }
-template <typename T, int N, int A, int B, int C> swz3<T, N, A, B, C> &swz3<T, N, A, B, C>::operator=(const tvec3<T> &v) { d[A] = v.x; d[B] = v.y; d[C] = v.z; return *this; }
+template <typename T, int N, int A, int B> swz2<T, N, A, B, false>::operator tvec2<T>() const { return tvec2<T>(d[A], d[B]); }
+template <typename T, int N, int A, int B> swz2<T, N, A, B, false> &swz2<T, N, A, B, false>::operator=(const tvec2<T> &v) { d[A] = v.x; d[B] = v.y; return *this; }
+template <typename T, int N, int A, int B> swz2<T, N, A, B, true>::operator tvec2<T> &() { return *reinterpret_cast<tvec2<T> *>(&d[A]); }
+template <typename T, int N, int A, int B> swz2<T, N, A, B, true>::operator const tvec2<T> &() const { return *reinterpret_cast<const tvec2<T> *>(&d[A]); }
+template <typename T, int N, int A, int B> swz2<T, N, A, B, true> &swz2<T, N, A, B, true>::operator=(const tvec2<T> &v) { d[A] = v.x; d[B] = v.y; return *this; }
+template <typename T, int N, int A, int B, int C> swz3<T, N, A, B, C, false>::operator tvec3<T>() const { return tvec3<T>(d[A], d[B], d[C]); }
+template <typename T, int N, int A, int B, int C> swz3<T, N, A, B, C, false> &swz3<T, N, A, B, C, false>::operator=(const tvec3<T> &v) { d[A] = v.x; d[B] = v.y; d[C] = v.z; return *this; }
+template <typename T, int N, int A, int B, int C> swz3<T, N, A, B, C, true>::operator tvec3<T> &() { return *reinterpret_cast<tvec3<T> *>(&d[A]); }
+template <typename T, int N, int A, int B, int C> swz3<T, N, A, B, C, true>::operator const tvec3<T> &() const { return *reinterpret_cast<const tvec3<T> *>(&d[A]); }
+template <typename T, int N, int A, int B, int C> swz3<T, N, A, B, C, true> &swz3<T, N, A, B, C, true>::operator=(const tvec3<T> &v) { d[A] = v.x; d[B] = v.y; d[C] = v.z; return *this; }
 template <typename T, int N, int A, int B, int C, int D> swz4<T, N, A, B, C, D>::operator tvec4<T>() const { return tvec4<T>(d[A], d[B], d[C], d[D]); }
+template <typename T, int N, int A, int B, int C, int D> swz4<T, N, A, B, C, D> &swz4<T, N, A, B, C, D>::operator=(const tvec4<T> &v)
+{
+	const tvec4<T> t = v; // the right-hand side may alias this vector
+	d[A] = t.x; d[B] = t.y; d[C] = t.z; d[D] = t.w;
+	return *this;
+}
 
 using vec2 = tvec2<float>;
 using vec3 = tvec3<float>;
@@ -282,6 +284,31 @@ GLSL_FLOAT_FUNCS(vec3, 3)
 GLSL_FLOAT_FUNCS(vec4, 4)
 
 inline vec3 cross(const vec3 &a, const vec3 &b) { return vec3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+
+// fma on vectors (SMAA's mad under SMAA_GLSL_4): one fused operation per component.
+#define GLSL_FMA(V, N)                                                                                                          \
+	inline V fma(const V &a, const V &b, const V &c) { V r; for (int i = 0; i < N; i++) r.d[i] = fmaf(a.d[i], b.d[i], c.d[i]); return r; } \
+	inline V fma(const V &a, float b, const V &c) { V r; for (int i = 0; i < N; i++) r.d[i] = fmaf(a.d[i], b, c.d[i]); return r; }      \
+	inline V fma(float a, const V &b, const V &c) { V r; for (int i = 0; i < N; i++) r.d[i] = fmaf(a, b.d[i], c.d[i]); return r; }      \
+	inline V fma(const V &a, const V &b, float c) { V r; for (int i = 0; i < N; i++) r.d[i] = fmaf(a.d[i], b.d[i], c); return r; }      \
+	inline V fma(const V &a, float b, float c) { V r; for (int i = 0; i < N; i++) r.d[i] = fmaf(a.d[i], b, c); return r; }
+GLSL_FMA(vec2, 2)
+GLSL_FMA(vec3, 3)
+GLSL_FMA(vec4, 4)
+inline float round(float v) { return roundf(v); }
+GLSL_MAP1(vec2, 2, round)
+GLSL_MAP1(vec4, 4, round)
+
+// vec4[](a, b, c): an array temporary that decays to a pointer for the call it is written in.
+struct vec4_array
+{
+	vec4 v[4];
+	operator vec4 *() { return v; }
+};
+inline vec4_array array_of_vec4(const vec4 &a, const vec4 &b, const vec4 &c) { vec4_array r; r.v[0] = a; r.v[1] = b; r.v[2] = c; return r; }
+
+// discard: leaves the invocation; the runner keeps the attachment's previous contents.
+struct Discard {};
 
 // mix with a boolean selector picks a side (GLSL 4.5 mix(x, y, bvec)).
 inline vec3 mix(const vec3 &a, const vec3 &b, const bvec3 &t) { return vec3(t.x ? b.x : a.x, t.y ? b.y : a.y, t.z ? b.z : a.z); }
@@ -512,7 +539,7 @@ inline void imageStore(Image &img, const ivec2 &p, const vec4 &v)
 // ---- per-invocation built-in variables --------------------------------------------------------------------------------------
 inline thread_local uvec3 gl_GlobalInvocationID, gl_LocalInvocationID, gl_WorkGroupID;
 inline thread_local uint gl_LocalInvocationIndex;
-inline thread_local vec4 gl_FragCoord;
+inline thread_local vec4 gl_FragCoord, gl_Position;
 inline thread_local uint gl_SubgroupSize = 1, gl_SubgroupInvocationID = 0, gl_NumSubgroups = 1, gl_SubgroupID = 0;
 inline uint atomicOr(uint &mem, uint v) { return __atomic_fetch_or(&mem, v, __ATOMIC_SEQ_CST); }
 inline vec4 subpassLoad(const Texture &t) { return t.texel(int(gl_FragCoord.x), int(gl_FragCoord.y)); }
@@ -530,3 +557,4 @@ inline vec4 subpassLoad(const Texture &t) { return t.texel(int(gl_FragCoord.x), 
 #define shared
 #define buffer
 #define precise
+#define discard throw glsl::Discard()

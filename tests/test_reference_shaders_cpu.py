@@ -217,3 +217,34 @@ def test_taa_resolve_shader_bit_for_bit(ref, quality):
         np.testing.assert_array_equal(got_c, want_c, err_msg=f"colour, frame {frame}")
         np.testing.assert_array_equal(got_h, want_h, err_msg=f"history, frame {frame}")
         history = want_h
+
+
+# ---- SMAA 1x: post/smaa_{edge_detection,blend_weight,neighbor_blend}.{vert,frag} + post/SMAA.hlsl (GLSL 4 spelling) -----------
+@pytest.mark.parametrize("quality", [0, 1, 2, 3])
+@pytest.mark.parametrize("w,h,seed", [(160, 90, 7), (61, 47, 2)])
+def test_smaa_passes_bit_for_bit(ref, quality, w, h, seed):
+    """SMAA_PRESET_LOW .. ULTRA (threshold, search steps, diagonal and corner detection on from HIGH): edge detection with its
+    discards, blend-weight calculation masked to edge pixels (area / search lookup tables, every texture LinearClamp) and the
+    neighbourhood blend into UNORM and sRGB targets.  One translation unit per preset, because SMAA.hlsl keeps the preset as
+    macro state."""
+    from granite_amd.data import load_smaa_luts
+    area, search = load_smaa_luts()
+    img = blocky(w, h, seed)
+    edges_fn, weights_fn = getattr(ref, f"ref_smaa_edges_q{quality}"), getattr(ref, f"ref_smaa_weights_q{quality}")
+    edges_fn.argtypes = [P, C.c_int, C.c_int, P]
+    weights_fn.argtypes = [P, C.c_int, C.c_int, P, P, P]
+    ref.ref_smaa_blend.argtypes = [P, P, C.c_int, C.c_int, P, C.c_int]
+    want_e = orc.smaa_edges(img, quality)
+    got_e = np.full_like(want_e, 0xAA)
+    edges_fn(ptr(img), w, h, ptr(got_e))
+    np.testing.assert_array_equal(got_e, want_e, err_msg="edges")
+    assert (want_e != 0).any()
+    want_w = orc.smaa_weights(want_e, area, search, quality)
+    got_w = np.full_like(want_w, 0xAA)
+    weights_fn(ptr(want_e), w, h, ptr(area), ptr(search), ptr(got_w))
+    np.testing.assert_array_equal(got_w, want_w, err_msg="blend weights")
+    for srgb in (False, True):
+        want = orc.smaa_blend(img, want_w, srgb)
+        got = np.zeros_like(want)
+        ref.ref_smaa_blend(ptr(img), ptr(want_w), w, h, ptr(got), int(srgb))
+        np.testing.assert_array_equal(got, want, err_msg=f"neighbourhood blend, SMAA_TARGET_SRGB={int(srgb)}")
