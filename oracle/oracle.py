@@ -2,8 +2,9 @@
 
 ctypes front-end of oracle/liboracle.so, the CPU restatement of Granite's image-space chain (see oracle_common.h).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
-(granite_amd/) never does.  PARITY UNPINNED by the reference's own tests: pinned by analytic
-known-answer tests in tests/test_oracle_kat.py and fixtures in tests/golden/.
+(granite_amd/) never does.  The reference has no tests for this path; the oracle is pinned by executing the
+reference's own shader sources on the CPU (oracle/ref_build -> oracle/_ref, tests/test_reference_shaders_cpu.py, bit for bit)
+plus analytic known-answer tests and fixtures in tests/golden/.
 """
 from __future__ import annotations
 

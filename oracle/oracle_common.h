@@ -5,12 +5,14 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
 // the product (granite_amd/) never links, imports or calls it.
 //
-// PARITY UNPINNED: the reference holds no golden vectors / known-answer tests for this path
-//  and cannot be built here (no Vulkan/GLSL toolchain).  The oracle is pinned
-// instead by analytic known-answer cases derived from the shader math (tests/test_oracle_kat.py)
-// and by fixtures under tests/golden/.  The host-side math that the reference keeps in buildable C++
-// (math/muglm: half packing, matrix inverse / product) is checked against the real reference code
-// built into oracle/_ref/ by oracle/ref_build/Makefile (tests/test_reference_math_cpu.py).
+// PARITY: the reference holds no golden vectors / known-answer tests for this path and its
+// Vulkan / GLSL toolchain cannot be built here.  The oracle is pinned instead by EXECUTING THE REFERENCE'S OWN
+// SHADER SOURCES on the CPU: oracle/ref_build re-spells them at build time into oracle/_ref/gen and compiles
+// them as C++ against a small GLSL environment; tests/test_reference_shaders_cpu.py requires bit-for-bit
+// equality for the whole post chain, deferred lighting, the cluster build, FXAA, TAA and SMAA.  The host-side
+// math the reference keeps in buildable C++ (math/muglm) is checked against the real code the same way
+// (tests/test_reference_math_cpu.py).  Only the depth hierarchy and the FSR filters (outside the benchmarked
+// path) rest on analytic known-answer tests alone.
 //
 // Conventions
 //   * Images are tightly packed row-major linear buffers, origin top-left (Vulkan framebuffer
