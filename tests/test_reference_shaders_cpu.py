@@ -24,7 +24,10 @@ P = C.c_void_p
 @pytest.fixture(scope="module")
 def ref():
     if os.path.isdir("/root/reference/assets/shaders"):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "ref_build")])
+        try:
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "ref_build")])
+        except (subprocess.CalledProcessError, OSError) as e:  # keep going with a prebuilt library if there is one
+            print("oracle/ref_build did not build:", e)
     if not os.path.exists(REF_LIB):
         pytest.skip("oracle/_ref/libref_shaders.so not built (needs /root/reference)")
     lib = C.CDLL(REF_LIB)
