@@ -1,5 +1,6 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_common.h).  PARITY UNPINNED: the reference has no test or golden data
-// for this pass; pinned by analytic known-answer cases in tests/test_oracle_kat.py.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_common.h).  The reference has no test or golden data for this pass; pinned
+// by executing the reference's own hiz.comp on the CPU (oracle/ref_build/ref_hiz.cpp, tests/test_reference_shaders_cpu.py, bit
+// for bit) and by analytic known-answer cases (tests/test_oracle_hiz_cpu.py).
 //
 // Depth hierarchy: assets/shaders/post/hiz.comp + HiZPassState::build_render_pass (renderer/post/spd.cpp:141-194).
 #include "oracle_common.h"

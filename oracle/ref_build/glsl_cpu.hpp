@@ -364,6 +364,8 @@ struct mat3x2 // 3 columns of 2 components
 struct mat4
 {
 	vec4 c[4];
+	mat4() {}
+	mat4(const vec4 &a, const vec4 &b, const vec4 &cc, const vec4 &d) { c[0] = a; c[1] = b; c[2] = cc; c[3] = d; }
 	vec4 &operator[](int i) { return c[i]; }
 	const vec4 &operator[](int i) const { return c[i]; }
 };
@@ -395,6 +397,13 @@ inline int findLSB(int v) { return findLSB(uint(v)); }
 inline int findMSB(uint v) { return v ? 31 - __builtin_clz(v) : -1; }
 inline int bitCount(uint v) { return __builtin_popcount(v); }
 inline vec2 unpackHalf2x16(uint v) { return vec2(orc::half_to_float(uint16_t(v & 0xffffu)), orc::half_to_float(uint16_t(v >> 16))); }
+inline uint bitfieldInsert(uint base, uint insert, int offset, int bits)
+{
+	if (bits == 0)
+		return base;
+	const uint mask = (bits == 32 ? 0xffffffffu : ((1u << bits) - 1u)) << offset;
+	return (base & ~mask) | ((insert << offset) & mask);
+}
 inline uint bitfieldExtract(uint v, int offset, int bits) { return bits == 0 ? 0u : (v >> offset) & (bits == 32 ? 0xffffffffu : ((1u << bits) - 1u)); }
 
 // ---- subgroup operations of a one-invocation subgroup (each invocation runs alone: the exact per-pixel form) -----------------
@@ -535,6 +544,24 @@ inline void imageStore(Image &img, const ivec2 &p, const vec4 &v)
 		break;
 	}
 }
+
+// imageLoad: texels outside the image read as zero (robust access).
+inline vec4 imageLoad(const Image &img, const ivec2 &p)
+{
+	if (p.x < 0 || p.y < 0 || p.x >= img.w || p.y >= img.h)
+		return vec4(0.0f);
+	const size_t i = size_t(p.y) * img.w + p.x;
+	if (img.format == Format::R32F)
+		return vec4(static_cast<const float *>(img.data)[i], 0.0f, 0.0f, 1.0f);
+	Texture t;
+	t.data = img.data;
+	t.w = img.w;
+	t.h = img.h;
+	t.format = img.format;
+	return t.texel(p.x, p.y);
+}
+inline void memoryBarrierImage() {}
+inline uint atomicAdd(uint &mem, uint v) { return __atomic_fetch_add(&mem, v, __ATOMIC_SEQ_CST); }
 
 // ---- per-invocation built-in variables --------------------------------------------------------------------------------------
 inline thread_local uvec3 gl_GlobalInvocationID, gl_LocalInvocationID, gl_WorkGroupID;

@@ -251,3 +251,25 @@ def test_smaa_passes_bit_for_bit(ref, quality, w, h, seed):
         got = np.zeros_like(want)
         ref.ref_smaa_blend(ptr(img), ptr(want_w), w, h, ptr(got), int(srgb))
         np.testing.assert_array_equal(got, want, err_msg=f"neighbourhood blend, SMAA_TARGET_SRGB={int(srgb)}")
+
+
+# ---- depth hierarchy: post/hiz.comp -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(128, 128), (200, 100), (257, 131), (520, 70), (1000, 300)])
+@pytest.mark.parametrize("output_downsample", [False, True])
+def test_depth_hierarchy_shader_bit_for_bit(ref, w, h, output_downsample):
+    """hiz.comp with the bindings of HiZPassState::build_render_pass (spd.cpp:141-194): workgroups of 256 real threads (subgroups
+    of 64, quad swaps, shared memory, barriers), run one after the other so the last one takes the ticket and reduces mips 7 and
+    up with the odd-size folds.  Every level of the chain equals the oracle's."""
+    ref.ref_hiz.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, C.c_int, C.c_int, C.c_int]
+    depth = (np.random.default_rng(w * 31 + h).random((h, w), dtype=np.float32) * 0.9 + 0.05).astype(np.float32)
+    zt = orc.hiz_z_transform(synth.Camera(w, h).render_params()[48:64])
+    lay = orc.hiz_layout(w, h, output_downsample)
+    want = orc.hiz(depth, zt, output_downsample)
+    chain = np.zeros(sum(l.size for l in want), np.float32)
+    ref.ref_hiz(ptr(depth), w, h, lay["res_w"], lay["res_h"], lay["mips"], ptr(zt), int(not output_downsample), ptr(chain),
+                lay["chain_w"], lay["chain_h"], lay["levels"])
+    offset = 0
+    for level, lv in enumerate(want):
+        got = chain[offset:offset + lv.size].reshape(lv.shape)
+        offset += lv.size
+        np.testing.assert_array_equal(got.view(np.uint32), lv.view(np.uint32), err_msg=f"level {level}")
