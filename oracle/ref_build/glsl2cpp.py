@@ -60,6 +60,9 @@ def respell(text: str) -> str:
     text = PARAM_OUT.sub(lambda m: "%s%s %s%s" % (m.group(1), m.group(2), "" if m.group(4) == "[" else "&", m.group(3)), text)
     text = re.sub(r"\bvec4\s*\[\s*\]\s*\(", "glsl::array_of_vec4(", text)  # array constructor
     text = PARAM_IN.sub(" ", text)
+    # qualifier macros (ffx_a.h: "#define outAF2 out AF2"): the same meaning, spelled for C++
+    text = re.sub(r"^([ \t]*#[ \t]*define[ \t]+\w+)[ \t]+(?:out|inout)[ \t]+(\w+)[ \t]*$", r"\1 \2 &", text, flags=re.M)
+    text = re.sub(r"^([ \t]*#[ \t]*define[ \t]+\w+)[ \t]+in[ \t]+(\w+)[ \t]*$", r"\1 \2", text, flags=re.M)
     text = FLOAT_LITERAL.sub(lambda m: m.group(1) + "f", text)
     return text
 

@@ -244,6 +244,12 @@ GLSL_VEC_ARITH(uvec3, 3)
 GLSL_VEC_ARITH(uvec4, 4)
 
 #define GLSL_INT_OPS(V, N)                                                                                                         \
+	inline V operator^(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] ^ b.d[i]; return r; }          \
+	inline V operator>>(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] >> b.d[i]; return r; }        \
+	inline V operator<<(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] << b.d[i]; return r; }        \
+	inline V operator~(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = ~a.d[i]; return r; }                               \
+	inline bool operator==(const V &a, const V &b) { for (int i = 0; i < N; i++) if (a.d[i] != b.d[i]) return false; return true; } \
+	inline bool operator!=(const V &a, const V &b) { return !(a == b); }                                                          \
 	inline V operator>>(const V &a, int s) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] >> s; return r; }                   \
 	inline V operator<<(const V &a, int s) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] << s; return r; }                   \
 	inline V operator&(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] & b.d[i]; return r; }          \
@@ -252,6 +258,9 @@ GLSL_VEC_ARITH(uvec4, 4)
 	inline V max(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = max(a.d[i], b.d[i]); return r; }             \
 	inline V clamp(const V &v, const V &lo, const V &hi) { return min(max(v, lo), hi); }
 GLSL_INT_OPS(ivec2, 2)
+inline ivec2 abs(const ivec2 &a) { return ivec2(abs(a.x), abs(a.y)); }
+inline ivec3 abs(const ivec3 &a) { return ivec3(abs(a.x), abs(a.y), abs(a.z)); }
+inline ivec4 abs(const ivec4 &a) { return ivec4(abs(a.x), abs(a.y), abs(a.z), abs(a.w)); }
 GLSL_INT_OPS(ivec3, 3)
 GLSL_INT_OPS(ivec4, 4)
 GLSL_INT_OPS(uvec2, 2)
@@ -267,7 +276,7 @@ GLSL_INT_OPS(uvec4, 4)
 #define GLSL_FLOAT_FUNCS(V, N)                                                                                                     \
 	GLSL_MAP1(V, N, abs) GLSL_MAP1(V, N, floor) GLSL_MAP1(V, N, ceil) GLSL_MAP1(V, N, fract) GLSL_MAP1(V, N, sqrt)                 \
 	GLSL_MAP1(V, N, inversesqrt) GLSL_MAP1(V, N, exp2) GLSL_MAP1(V, N, log2) GLSL_MAP1(V, N, sign) GLSL_MAP1(V, N, exp)            \
-	GLSL_MAP1(V, N, log)                                                                                                          \
+	GLSL_MAP1(V, N, log) GLSL_MAP1(V, N, sin) GLSL_MAP1(V, N, cos)                                                                \
 	GLSL_MAP2(V, N, min) GLSL_MAP2(V, N, max) GLSL_MAP2(V, N, pow)                                                                \
 	inline V clamp(const V &v, const V &lo, const V &hi) { return min(max(v, lo), hi); }                                          \
 	inline V clamp(const V &v, float lo, float hi) { return min(max(v, lo), hi); }                                                \
@@ -397,6 +406,13 @@ inline int findLSB(int v) { return findLSB(uint(v)); }
 inline int findMSB(uint v) { return v ? 31 - __builtin_clz(v) : -1; }
 inline int bitCount(uint v) { return __builtin_popcount(v); }
 inline vec2 unpackHalf2x16(uint v) { return vec2(orc::half_to_float(uint16_t(v & 0xffffu)), orc::half_to_float(uint16_t(v >> 16))); }
+inline uvec2 floatBitsToUint(const vec2 &v) { return uvec2(floatBitsToUint(v.x), floatBitsToUint(v.y)); }
+inline uvec3 floatBitsToUint(const vec3 &v) { return uvec3(floatBitsToUint(v.x), floatBitsToUint(v.y), floatBitsToUint(v.z)); }
+inline uvec4 floatBitsToUint(const vec4 &v) { return uvec4(floatBitsToUint(v.x), floatBitsToUint(v.y), floatBitsToUint(v.z), floatBitsToUint(v.w)); }
+inline vec2 uintBitsToFloat(const uvec2 &v) { return vec2(uintBitsToFloat(v.x), uintBitsToFloat(v.y)); }
+inline vec3 uintBitsToFloat(const uvec3 &v) { return vec3(uintBitsToFloat(v.x), uintBitsToFloat(v.y), uintBitsToFloat(v.z)); }
+inline vec4 uintBitsToFloat(const uvec4 &v) { return vec4(uintBitsToFloat(v.x), uintBitsToFloat(v.y), uintBitsToFloat(v.z), uintBitsToFloat(v.w)); }
+inline uint packHalf2x16(const vec2 &v) { return uint(orc::float_to_half_rne(v.x)) | (uint(orc::float_to_half_rne(v.y)) << 16); }
 inline uint bitfieldInsert(uint base, uint insert, int offset, int bits)
 {
 	if (bits == 0)

@@ -273,3 +273,43 @@ def test_depth_hierarchy_shader_bit_for_bit(ref, w, h, output_downsample):
         got = chain[offset:offset + lv.size].reshape(lv.shape)
         offset += lv.size
         np.testing.assert_array_equal(got.view(np.uint32), lv.view(np.uint32), err_msg=f"level {level}")
+
+
+# ---- spatial upscaling: post/ffx-fsr/{upscale,sharpen}.frag + the vendored FidelityFX headers ---------------------------------
+def fsr_image(w, h, kind, seed=3):
+    r = np.random.default_rng(seed)
+    if kind == "noise":
+        img = r.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    else:  # flat areas, hard edges, black and white
+        coarse = r.choice(np.array([0, 0, 255, 17, 128, 200], np.uint8), ((h + 4) // 5, (w + 6) // 7, 4))
+        img = np.repeat(np.repeat(coarse, 5, axis=0), 7, axis=1)[:h, :w].copy()
+    img[..., 3] = 255
+    return img
+
+
+@pytest.mark.parametrize("case", [(160, 90, 240, 135, "noise"), (200, 120, 333, 201, "blocks"), (64, 64, 64, 64, "noise"), (7, 5, 30, 22, "noise"),
+                                  (320, 180, 256, 144, "blocks")])
+def test_fsr_easu_shader_bit_for_bit(ref, case):
+    """upscale.frag with FP16 = 0 (FsrEasuF from ffx_fsr1.h, helpers from ffx_a.h, constants from the header's own FsrEasuCon)
+    against the oracle's fp32 path.  The FP16 = 1 variant needs GLSL float16 types and is not executed; the oracle's half path
+    mirrors the fp32 one operation for operation and the two are held together in tests/test_oracle_fsr_cpu.py."""
+    ref.ref_fsr_easu.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int]
+    w, h, ow, oh, kind = case
+    src = fsr_image(w, h, kind)
+    want = orc.fsr_easu(src, ow, oh, fp16=False)
+    got = np.zeros_like(want)
+    ref.ref_fsr_easu(ptr(src), w, h, ptr(got), ow, oh)
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("kind", ["noise", "blocks"])
+@pytest.mark.parametrize("srgb", [False, True])
+def test_fsr_rcas_shader_bit_for_bit(ref, kind, srgb):
+    """sharpen.frag (FsrRcasF, FsrRcasCon(0.5)), reading through the sRGB or the UNORM view as aa.cpp:147-151 selects; black
+    pixels exercise the 0 * inf paths, decided by minNum / maxNum on both sides."""
+    ref.ref_fsr_rcas.argtypes = [P, C.c_int, C.c_int, P, C.c_float, C.c_int]
+    src = fsr_image(253, 127, kind, seed=9)
+    want = orc.fsr_rcas(src, orc.fsr_rcas_sharpness(0.5), srgb)
+    got = np.zeros_like(want)
+    ref.ref_fsr_rcas(ptr(src), 253, 127, ptr(got), 0.5, int(srgb))
+    np.testing.assert_array_equal(got, want)
