@@ -11,8 +11,7 @@
 // them as C++ against a small GLSL environment; tests/test_reference_shaders_cpu.py requires bit-for-bit
 // equality for the whole post chain, deferred lighting, the cluster build, FXAA, TAA and SMAA.  The host-side
 // math the reference keeps in buildable C++ (math/muglm) is checked against the real code the same way
-// (tests/test_reference_math_cpu.py).  The depth hierarchy, EASU (fp32) and RCAS are pinned the same way; only the
-// FP16 variant of EASU rests on analytic known-answer tests and its operation-for-operation mirror of the fp32 path.
+// (tests/test_reference_math_cpu.py).  The depth hierarchy, EASU (fp32 and fp16) and RCAS are pinned the same way.
 //
 // Conventions
 //   * Images are tightly packed row-major linear buffers, origin top-left (Vulkan framebuffer

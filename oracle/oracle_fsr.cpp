@@ -1,7 +1,6 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_common.h).  The reference has no test or golden data for these passes; the
-// fp32 EASU path and RCAS are pinned by executing the reference's own upscale.frag / sharpen.frag with the vendored
-// FidelityFX headers on the CPU (oracle/ref_build/ref_fsr.cpp, tests/test_reference_shaders_cpu.py, bit for bit), the half
-// path by analytic known-answer cases (tests/test_oracle_fsr_cpu.py).
+// EASU paths (fp32 and fp16) and RCAS are pinned by executing the reference's own upscale.frag / sharpen.frag / FsrEasuH with
+// the vendored FidelityFX headers on the CPU (oracle/ref_build/ref_fsr.cpp, tests/test_reference_shaders_cpu.py, bit for bit).
 //
 // Spatial upscaling after the post chain: setup_after_post_chain_upscaling (renderer/post/aa.cpp:75-174) with
 // assets/shaders/post/ffx-fsr/{upscale,sharpen}.{vert,frag}.  The arithmetic is AMD FidelityFX FSR 1.0 (EASU + RCAS), a

@@ -166,7 +166,41 @@ template <typename T, int N, int A, int B, int C, int D> swz4<T, N, A, B, C, D> 
 	return *this;
 }
 
+// GLSL float16_t (GL_EXT_shader_explicit_arithmetic_types_float16): holds the fp32 value of a half; every operation computes
+// in fp32 and rounds to the nearest half -- exact for + - * and, with 24 >= 2 * 11 + 2 significand bits, for division.
+// Conversion back to float is explicit, so an accidental fp32 operation on halves does not compile.
+struct float16_t
+{
+	float v;
+	float16_t() : v(0.0f) {}
+	float16_t(float f) : v(orc::half_to_float(orc::float_to_half_rne(f))) {}
+	explicit operator float() const { return v; }
+};
+inline float16_t operator+(float16_t a, float16_t b) { return float16_t(a.v + b.v); }
+inline float16_t operator-(float16_t a, float16_t b) { return float16_t(a.v - b.v); }
+inline float16_t operator*(float16_t a, float16_t b) { return float16_t(a.v * b.v); }
+inline float16_t operator/(float16_t a, float16_t b) { return float16_t(a.v / b.v); }
+inline float16_t operator-(float16_t a) { float16_t r; r.v = -a.v; return r; }
+inline float16_t &operator+=(float16_t &a, float16_t b) { a = a + b; return a; }
+inline float16_t &operator-=(float16_t &a, float16_t b) { a = a - b; return a; }
+inline float16_t &operator*=(float16_t &a, float16_t b) { a = a * b; return a; }
+inline bool operator<(float16_t a, float16_t b) { return a.v < b.v; }
+inline bool operator>(float16_t a, float16_t b) { return a.v > b.v; }
+inline bool operator<=(float16_t a, float16_t b) { return a.v <= b.v; }
+inline bool operator>=(float16_t a, float16_t b) { return a.v >= b.v; }
+inline bool operator==(float16_t a, float16_t b) { return a.v == b.v; }
+inline bool operator!=(float16_t a, float16_t b) { return a.v != b.v; }
+
 using vec2 = tvec2<float>;
+using f16vec2 = tvec2<float16_t>;
+using f16vec3 = tvec3<float16_t>;
+using f16vec4 = tvec4<float16_t>;
+using u16vec2 = tvec2<uint16_t>;
+using u16vec3 = tvec3<uint16_t>;
+using u16vec4 = tvec4<uint16_t>;
+using i16vec2 = tvec2<int16_t>;
+using i16vec3 = tvec3<int16_t>;
+using i16vec4 = tvec4<int16_t>;
 using vec3 = tvec3<float>;
 using vec4 = tvec4<float>;
 using ivec2 = tvec2<int>;
@@ -186,6 +220,11 @@ inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
 inline uint min(uint a, uint b) { return a < b ? a : b; }
 inline uint max(uint a, uint b) { return a > b ? a : b; }
+inline uint16_t min(uint16_t a, uint16_t b) { return a < b ? a : b; }
+inline uint16_t max(uint16_t a, uint16_t b) { return a > b ? a : b; }
+inline int16_t min(int16_t a, int16_t b) { return a < b ? a : b; }
+inline int16_t max(int16_t a, int16_t b) { return a > b ? a : b; }
+inline int16_t abs(int16_t v) { return int16_t(v < 0 ? -v : v); }
 inline float clamp(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 inline int clamp(int v, int lo, int hi) { return min(max(v, lo), hi); }
 inline uint clamp(uint v, uint lo, uint hi) { return min(max(v, lo), hi); }
@@ -218,6 +257,26 @@ inline float uintBitsToFloat(uint v) { return orc::u2f(v); }
 inline float intBitsToFloat(int v) { return orc::u2f(uint(v)); }
 inline bool isnan(float v) { return v != v; }
 
+inline float16_t min(float16_t a, float16_t b) { float16_t r; r.v = fminf(a.v, b.v); return r; }
+inline float16_t max(float16_t a, float16_t b) { float16_t r; r.v = fmaxf(a.v, b.v); return r; }
+inline float16_t abs(float16_t a) { float16_t r; r.v = fabsf(a.v); return r; }
+inline float16_t clamp(float16_t v, float16_t lo, float16_t hi) { return min(max(v, lo), hi); }
+inline float16_t floor(float16_t a) { return float16_t(floorf(a.v)); }
+inline float16_t fract(float16_t a) { return a - floor(a); }
+inline float16_t sqrt(float16_t a) { return float16_t(sqrtf(a.v)); }
+inline float16_t inversesqrt(float16_t a) { return float16_t(1.0f / sqrtf(a.v)); }
+inline float16_t exp2(float16_t a) { return float16_t(exp2f(a.v)); }
+inline float16_t log2(float16_t a) { return float16_t(log2f(a.v)); }
+inline float16_t pow(float16_t a, float16_t b) { return float16_t(powf(a.v, b.v)); }
+inline float16_t sign(float16_t a) { return float16_t(sign(a.v)); }
+inline float16_t sin(float16_t a) { return float16_t(sinf(a.v)); }
+inline float16_t cos(float16_t a) { return float16_t(cosf(a.v)); }
+inline float16_t mix(float16_t a, float16_t b, float16_t t) { return a * (float16_t(1.0f) - t) + b * t; }
+inline uint16_t halfBitsToUint16(float16_t a) { return orc::float_to_half_rne(a.v); }
+inline float16_t uint16BitsToHalf(uint16_t b) { float16_t r; r.v = orc::half_to_float(b); return r; }
+inline int16_t halfBitsToInt16(float16_t a) { return int16_t(orc::float_to_half_rne(a.v)); }
+inline float16_t int16BitsToHalf(int16_t b) { return uint16BitsToHalf(uint16_t(b)); }
+
 // ---- component-wise operators and functions -------------------------------------------------------------------------------
 #define GLSL_VEC_BINOP(V, N, op)                                                                                                    \
 	inline V operator op(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] op b.d[i]; return r; }       \
@@ -242,6 +301,40 @@ GLSL_VEC_ARITH(ivec4, 4)
 GLSL_VEC_ARITH(uvec2, 2)
 GLSL_VEC_ARITH(uvec3, 3)
 GLSL_VEC_ARITH(uvec4, 4)
+GLSL_VEC_ARITH(f16vec2, 2)
+GLSL_VEC_ARITH(f16vec3, 3)
+GLSL_VEC_ARITH(f16vec4, 4)
+GLSL_VEC_ARITH(u16vec2, 2)
+GLSL_VEC_ARITH(u16vec3, 3)
+GLSL_VEC_ARITH(u16vec4, 4)
+
+#define GLSL_HALF_FUNCS(V, N)                                                                                                       \
+	inline V min(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = min(a.d[i], b.d[i]); return r; }              \
+	inline V max(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = max(a.d[i], b.d[i]); return r; }              \
+	inline V abs(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = abs(a.d[i]); return r; }                                  \
+	inline V clamp(const V &v, const V &lo, const V &hi) { return min(max(v, lo), hi); }                                           \
+	inline V floor(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = floor(a.d[i]); return r; }                              \
+	inline V fract(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = fract(a.d[i]); return r; }                              \
+	inline V sqrt(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = sqrt(a.d[i]); return r; }                                \
+	inline V inversesqrt(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = inversesqrt(a.d[i]); return r; }                  \
+	inline V exp2(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = exp2(a.d[i]); return r; }                                \
+	inline V log2(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = log2(a.d[i]); return r; }                                \
+	inline V sign(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = sign(a.d[i]); return r; }                                \
+	inline V sin(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = sin(a.d[i]); return r; }                                  \
+	inline V cos(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = cos(a.d[i]); return r; }                                  \
+	inline V pow(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = pow(a.d[i], b.d[i]); return r; }              \
+	inline V mix(const V &a, const V &b, const V &t) { V r; for (int i = 0; i < N; i++) r.d[i] = mix(a.d[i], b.d[i], t.d[i]); return r; }
+GLSL_HALF_FUNCS(f16vec2, 2)
+GLSL_HALF_FUNCS(f16vec3, 3)
+GLSL_HALF_FUNCS(f16vec4, 4)
+inline uint packFloat2x16(const f16vec2 &v) { return uint(halfBitsToUint16(v.x)) | (uint(halfBitsToUint16(v.y)) << 16); }
+inline f16vec2 unpackFloat2x16(uint v) { return f16vec2(uint16BitsToHalf(uint16_t(v & 0xffffu)), uint16BitsToHalf(uint16_t(v >> 16))); }
+inline u16vec2 halfBitsToUint16(const f16vec2 &a) { return u16vec2(halfBitsToUint16(a.x), halfBitsToUint16(a.y)); }
+inline u16vec3 halfBitsToUint16(const f16vec3 &a) { return u16vec3(halfBitsToUint16(a.x), halfBitsToUint16(a.y), halfBitsToUint16(a.z)); }
+inline u16vec4 halfBitsToUint16(const f16vec4 &a) { return u16vec4(halfBitsToUint16(a.x), halfBitsToUint16(a.y), halfBitsToUint16(a.z), halfBitsToUint16(a.w)); }
+inline f16vec2 uint16BitsToHalf(const u16vec2 &a) { return f16vec2(uint16BitsToHalf(a.x), uint16BitsToHalf(a.y)); }
+inline f16vec3 uint16BitsToHalf(const u16vec3 &a) { return f16vec3(uint16BitsToHalf(a.x), uint16BitsToHalf(a.y), uint16BitsToHalf(a.z)); }
+inline f16vec4 uint16BitsToHalf(const u16vec4 &a) { return f16vec4(uint16BitsToHalf(a.x), uint16BitsToHalf(a.y), uint16BitsToHalf(a.z), uint16BitsToHalf(a.w)); }
 
 #define GLSL_INT_OPS(V, N)                                                                                                         \
 	inline V operator^(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] ^ b.d[i]; return r; }          \
@@ -266,6 +359,20 @@ GLSL_INT_OPS(ivec4, 4)
 GLSL_INT_OPS(uvec2, 2)
 GLSL_INT_OPS(uvec3, 3)
 GLSL_INT_OPS(uvec4, 4)
+GLSL_VEC_ARITH(i16vec2, 2)
+GLSL_VEC_ARITH(i16vec3, 3)
+GLSL_VEC_ARITH(i16vec4, 4)
+GLSL_INT_OPS(u16vec2, 2)
+GLSL_INT_OPS(u16vec3, 3)
+GLSL_INT_OPS(u16vec4, 4)
+GLSL_INT_OPS(i16vec2, 2)
+GLSL_INT_OPS(i16vec3, 3)
+GLSL_INT_OPS(i16vec4, 4)
+inline i16vec2 abs(const i16vec2 &a) { return i16vec2(abs(a.x), abs(a.y)); }
+inline i16vec3 abs(const i16vec3 &a) { return i16vec3(abs(a.x), abs(a.y), abs(a.z)); }
+inline i16vec4 abs(const i16vec4 &a) { return i16vec4(abs(a.x), abs(a.y), abs(a.z), abs(a.w)); }
+inline uint packUint2x16(const u16vec2 &v) { return uint(v.x) | (uint(v.y) << 16); }
+inline u16vec2 unpackUint2x16(uint v) { return u16vec2(uint16_t(v & 0xffffu), uint16_t(v >> 16)); }
 
 #define GLSL_MAP1(V, N, fn) \
 	inline V fn(const V &a) { V r; for (int i = 0; i < N; i++) r.d[i] = fn(a.d[i]); return r; }

@@ -291,15 +291,18 @@ def fsr_image(w, h, kind, seed=3):
                                   (320, 180, 256, 144, "blocks")])
 def test_fsr_easu_shader_bit_for_bit(ref, case):
     """upscale.frag with FP16 = 0 (FsrEasuF from ffx_fsr1.h, helpers from ffx_a.h, constants from the header's own FsrEasuCon)
-    against the oracle's fp32 path.  The FP16 = 1 variant needs GLSL float16 types and is not executed; the oracle's half path
-    mirrors the fp32 one operation for operation and the two are held together in tests/test_oracle_fsr_cpu.py."""
+    against the oracle's fp32 path, and FsrEasuH from the same headers on emulated GLSL float16 types (every operation rounds
+    to half; gather callbacks as upscale.frag:8-14) against the oracle's half path -- the variant the reference selects on
+    fp16-capable hardware."""
     ref.ref_fsr_easu.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int]
+    ref.ref_fsr_easu_fp16.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int]
     w, h, ow, oh, kind = case
     src = fsr_image(w, h, kind)
-    want = orc.fsr_easu(src, ow, oh, fp16=False)
-    got = np.zeros_like(want)
-    ref.ref_fsr_easu(ptr(src), w, h, ptr(got), ow, oh)
-    np.testing.assert_array_equal(got, want)
+    for fp16, entry in ((False, ref.ref_fsr_easu), (True, ref.ref_fsr_easu_fp16)):
+        want = orc.fsr_easu(src, ow, oh, fp16=fp16)
+        got = np.zeros_like(want)
+        entry(ptr(src), w, h, ptr(got), ow, oh)
+        np.testing.assert_array_equal(got, want, err_msg="FP16" if fp16 else "FP32")
 
 
 @pytest.mark.parametrize("kind", ["noise", "blocks"])
