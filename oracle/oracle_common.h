@@ -7,7 +7,7 @@
 //
 // PARITY: the reference holds no golden vectors / known-answer tests for this path and its
 // Vulkan / GLSL toolchain cannot be built here.  The oracle is pinned instead by EXECUTING THE REFERENCE'S OWN
-// SHADER SOURCES on the CPU: oracle/ref_build re-spells them at build time into oracle/_ref/gen and compiles
+// SHADER SOURCES on the CPU: oracle/ref_build re-spells them at build time (scratch files, removed again) and compiles
 // them as C++ against a small GLSL environment; tests/test_reference_shaders_cpu.py requires bit-for-bit
 // equality for the whole post chain, deferred lighting, the cluster build, FXAA, TAA and SMAA.  The host-side
 // math the reference keeps in buildable C++ (math/muglm) is checked against the real code the same way

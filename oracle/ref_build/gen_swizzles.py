@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ORACLE — TEST INFRASTRUCTURE ONLY.  Writes the swizzle members of the CPU GLSL vectors (every 2-, 3- and 4-letter selection
-from xyzw / rgba) into oracle/_ref/gen/swizzles_{2,3,4}.inc.  usage: gen_swizzles.py <output directory>"""
+from xyzw / rgba) into swizzles_{2,3,4}.inc of the build scratch directory.  usage: gen_swizzles.py <output directory>"""
 import itertools
 import os
 import sys

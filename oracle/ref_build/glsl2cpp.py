@@ -5,7 +5,7 @@ Re-spells a GLSL shader of the reference so that it compiles as C++ against glsl
 expressions, constants and their order are left exactly as written; only what has no meaning outside a GPU pipeline is
 touched (version / precision lines, layout() qualifiers, interface-block syntax, parameter qualifiers) and floating literals
 get an `f` suffix, because a GLSL literal is fp32 while a C++ literal is a double.  #include directives are expanded from the
-reference tree.  The output goes to oracle/_ref/gen/ (git-ignored): reference text never enters this repository.
+reference tree.  The output goes to the build scratch directory (removed after the compile): reference text never enters this repository.
 
 usage: glsl2cpp.py <shader path under the reference> <output .inc>"""
 import os

@@ -1,7 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.
 //
 // A small GLSL execution environment for the CPU: enough of the language's vector types (with swizzles), built-in functions
-// and resource types that the REFERENCE's own shader sources -- lightly re-spelled by glsl2cpp.py into oracle/_ref/gen/ at
+// and resource types that the REFERENCE's own shader sources -- lightly re-spelled by glsl2cpp.py into a scratch directory at
 // build time, never committed -- compile as C++ and run one invocation per call.  Everything here is this repository's own
 // code; it defines what the hardware defines for a shader (texture filtering, format conversion on image stores, fp32
 // arithmetic with no contraction), in exactly the terms the oracle states them, so that what is compared against the oracle

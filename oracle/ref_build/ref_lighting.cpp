@@ -2,7 +2,7 @@
 //
 // Runs the REFERENCE's own deferred-lighting shaders on the CPU: lights/directional.frag and lights/clustering.frag with
 // everything they include (lighting.h, pbr.h, clusterer_bindless.h, point.h, spot.h ...), re-spelled by glsl2cpp.py at build
-// time into gen/ (git-ignored) and compiled against glsl_cpu.hpp.  Defines as DeferredLightRenderer::render_light sets them
+// time into gen/ (scratch, removed after the compile) and compiled against glsl_cpu.hpp.  Defines as DeferredLightRenderer::render_light sets them
 // on this path (renderer.cpp:1020-1056,1125-1147): VOLUMETRIC_DIFFUSE_FALLBACK (+ AMBIENT_OCCLUSION) for the directional
 // quad, nothing for the clustered quad; STAGE_FRAGMENT from the shader compiler (compiler/compiler.cpp:289).
 //

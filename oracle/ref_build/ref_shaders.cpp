@@ -1,7 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.
 //
-// Runs the REFERENCE's own post-chain shaders on the CPU: each `gen/*.inc` below is the shader source from
-// /root/reference/assets/shaders/post re-spelled by glsl2cpp.py at build time (git-ignored), compiled against the GLSL
+// Runs the REFERENCE's own post-chain shaders on the CPU: each `gen/*.inc` below (build scratch) is the shader source from
+// /root/reference/assets/shaders/post re-spelled by glsl2cpp.py at build time, compiled against the GLSL
 // environment in glsl_cpu.hpp, one namespace per shader variant.  The entry points mirror the oracle's (oracle_post.cpp) so
 // the two can be compared buffer for buffer: what is being checked is the oracle's reading of the shader text.
 #include <barrier>

@@ -1,7 +1,7 @@
 """CPU: the oracle against the REFERENCE's OWN SHADER SOURCES, executed.
 
 oracle/ref_build/ re-spells the GLSL of /root/reference/assets/shaders (glsl2cpp.py: strips layout()/precision/interface-block
-syntax, suffixes float literals -- statements, expressions and constants untouched) into oracle/_ref/gen/ and compiles it
+syntax, suffixes float literals -- statements, expressions and constants untouched) into a scratch directory and compiles it
 as C++ against a small GLSL environment (glsl_cpu.hpp: vectors with swizzles, built-ins, texture / image types).  The shader
 text that runs here is the reference's; the environment (bilinear filtering, format conversion of stores, fp32 without
 contraction) is stated once and shared with the oracle.  Equality below is therefore a statement about the oracle's reading
