@@ -28,7 +28,7 @@ class Config(C.Structure):
                 ("strip_index", C.c_uint32), ("strip_count", C.c_uint32),
                 ("disable_image_aliasing", C.c_int32), ("depth_hierarchy", C.c_int32),
                 ("resolution_scale", C.c_float), ("resolution_scale_sharpen", C.c_int32), ("fsr_fp32", C.c_int32),
-                ("ambient_occlusion", C.c_int32)]
+                ("ambient_occlusion", C.c_int32), ("hdr10", C.c_int32)]
 
 
 # void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream)
@@ -50,7 +50,7 @@ EXPORTED_SYMBOLS = [
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
     "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
-    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_set_exchange_callback", "gra_get_strip_plan",
+    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan",
     "gra_comm_create_unique_id", "gra_comm_init",
 ]
 
@@ -92,6 +92,7 @@ def load_library() -> C.CDLL:
         "gra_get_allocated_bytes": (C.c_int, [vp, vp]),
         "gra_get_render_size": (C.c_int, [vp, vp, vp]),
         "gra_upload_ambient_occlusion": (C.c_int, [vp, vp]),
+        "gra_compute_rec709_to_display": (C.c_int, [vp, vp]),
         "gra_gtx_probe": (C.c_int, [C.c_char_p, vp, vp, C.c_size_t]),
         "gra_gtx_read": (C.c_int, [C.c_char_p, vp, C.c_uint64, vp, C.c_size_t]),
         "gra_gtx_write": (C.c_int, [C.c_char_p, vp, vp, vp, C.c_size_t]),
@@ -122,7 +123,7 @@ class Application:
                  frame_time: float = synth.FRAME_TIME, timestamps: bool = False, strip_index: int = 0, strip_count: int = 1,
                  alias_images: bool = True, depth_hierarchy: int = 0,
                  resolution_scale: float = 1.0, resolution_scale_sharpen: bool = True, fsr_fp16: bool = True,
-                 ambient_occlusion: bool = False):
+                 ambient_occlusion: bool = False, hdr10: bool = False):
         self.lib = load_library()
         cfg = Config()
         cfg.device, cfg.width, cfg.height = device, width, height
@@ -140,6 +141,7 @@ class Application:
         cfg.resolution_scale = float(resolution_scale)
         cfg.resolution_scale_sharpen, cfg.fsr_fp32 = int(resolution_scale_sharpen), int(not fsr_fp16)
         cfg.ambient_occlusion = int(ambient_occlusion)
+        cfg.hdr10 = int(hdr10)
         self._exchange_ref = None
         self.config = cfg
         self.width, self.height = width, height

@@ -164,6 +164,11 @@ class HizArgs(C.Structure):
                 ("counter", C.c_void_p)]
 
 
+class PushPq10(C.Structure):
+    _fields_ = [("primary_conversion", C.c_float * 16), ("hdr_pre_exposure", C.c_float), ("ui_pre_exposure", C.c_float),
+                ("max_light_level", C.c_float), ("inv_max_light_level", C.c_float)]
+
+
 class GraniteHipError(RuntimeError):
     pass
 
@@ -224,6 +229,8 @@ def load_library() -> C.CDLL:
         "gr_taa_resolve": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), P(Image), P(Image), P(PushTaa), C.c_int]),
         "gr_hiz": (C.c_int, [vp, vp, P(HizArgs)]),
         "gr_fill_byte": (C.c_int, [vp, vp, vp, C.c_int, C.c_size_t]),
+        "gr_fill_u32": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_size_t]),
+        "gr_pq10_encode": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushPq10)]),
         "gr_fsr_upscale": (C.c_int, [vp, vp, P(Image), P(Image), C.c_int]),
         "gr_fsr_sharpen": (C.c_int, [vp, vp, P(Image), P(Image), C.c_float]),
         "gr_mip_chain_offset": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -244,7 +251,7 @@ EXPORTED_SYMBOLS = [
     "gr_bloom_threshold_rows", "gr_bloom_downsample_rows", "gr_bloom_upsample_rows", "gr_tonemap_rows",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
     "gr_smaa_set_luts", "gr_fxaa", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
-    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen", "gr_fill_byte",
+    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen", "gr_fill_byte", "gr_fill_u32", "gr_pq10_encode",
 ]
 
 
@@ -426,6 +433,18 @@ class Context:
 
     def fsr_sharpen(self, src: DeviceImage, out: DeviceImage, sharpness: float, stream=None):
         self.check(self.lib.gr_fsr_sharpen(self.handle, stream, src.desc, out.desc, C.c_float(sharpness)))
+
+    def pq10_encode(self, hdr: DeviceImage, ui: DeviceImage, out: DeviceImage, conversion9, hdr_pre_exposure=500.0, ui_pre_exposure=400.0,
+                    max_light_level=1000.0, stream=None):
+        push = PushPq10()
+        m = [float(v) for v in conversion9]
+        for col in range(3):
+            for row in range(3):
+                push.primary_conversion[4 * col + row] = m[3 * col + row]
+        push.primary_conversion[15] = 1.0
+        push.hdr_pre_exposure, push.ui_pre_exposure = hdr_pre_exposure, ui_pre_exposure
+        push.max_light_level, push.inv_max_light_level = max_light_level, float(np.float32(1.0) / np.float32(max_light_level))
+        self.check(self.lib.gr_pq10_encode(self.handle, stream, hdr.desc, ui.desc, out.desc, push))
 
     def hiz(self, depth: DeviceImage, z_transform, output_downsample: bool = False, chain: Optional[DeviceBuffer] = None,
             counter: Optional[DeviceBuffer] = None, stream=None):

@@ -230,6 +230,15 @@ int gr_fill_byte(gr_ctx *ctx, gr_stream stream, void *dst, int value, size_t byt
 	return GR_OK;
 }
 
+int gr_fill_u32(gr_ctx *ctx, gr_stream stream, void *dst, uint32_t value, size_t count)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, dst && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0);
+	GR_CHECK_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dst), int(value), count, gr_to_stream(stream)));
+	return GR_OK;
+}
+
 int gr_timing_enable(gr_ctx *ctx, int enable)
 {
 	if (!ctx)

@@ -1,6 +1,7 @@
 // extern "C" surface of the harness (include/granite_app.h).  Exceptions from the C++ layer stop here.
 #include "image_space_app.hpp"
 #include "../gtx.hpp"
+#include "../post/hdr.hpp"
 #include <cstdio>
 #include <cstring>
 
@@ -149,6 +150,19 @@ int gra_upload_gbuffer(gra_app *app, const void *emissive, const void *albedo, c
                        const void *mv)
 {
 	return guarded(app, [&]() { app->app->upload_gbuffer(emissive, albedo, normal, pbr, depth, mv); });
+}
+
+int gra_compute_rec709_to_display(const float *primaries8, float *out9)
+{
+	if (!primaries8 || !out9)
+		return -1;
+	HdrMetadata md;
+	memcpy(md.display_primary_red, primaries8, 8);
+	memcpy(md.display_primary_green, primaries8 + 2, 8);
+	memcpy(md.display_primary_blue, primaries8 + 4, 8);
+	memcpy(md.white_point, primaries8 + 6, 8);
+	compute_rec709_to_st2020(md, out9);
+	return 0;
 }
 
 int gra_gtx_probe(const char *path, gra_gtx_info *info, char *error, size_t error_size)

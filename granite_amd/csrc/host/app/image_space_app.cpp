@@ -18,6 +18,9 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 		device_holder = std::make_unique<HIP::Device>(config.device);
 	if (!config.width || !config.height)
 		throw std::logic_error("Backbuffer dimensions must be non-zero.");
+	if (config.hdr10 && (!config.enable_lighting || config.hdr_bloom || config.post_aa != GRA_POST_AA_NONE || config.pre_aa != GRA_POST_AA_NONE ||
+	                     config.strip_count > 1 || (config.resolution_scale > 0.0f && config.resolution_scale < 1.0f)))
+		throw std::logic_error("hdr10 needs enable_lighting and excludes hdr_bloom, anti-aliasing, resolution scaling and row bands.");
 	if (config.resolution_scale < 0.0f || config.resolution_scale > 1.0f)
 		throw std::logic_error("resolution_scale must be in (0, 1].");
 	render_width = config.width;
@@ -72,7 +75,7 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 
 	// External swapchain: 4 images R8G8B8A8_SRGB, cycled per frame.
 	for (unsigned i = 0; i < 4; i++)
-		swapchain.push_back(device.create_image(config.width, config.height, VK_FORMAT_R8G8B8A8_SRGB, "swapchain-" + std::to_string(i)));
+		swapchain.push_back(device.create_image(config.width, config.height, backbuffer_format(), "swapchain-" + std::to_string(i)));
 
 	src_emissive = device.create_image(render_width, render_height, VK_FORMAT_R16G16B16A16_SFLOAT, "src-emissive");
 	if (config.enable_lighting)
@@ -412,7 +415,7 @@ void ImageSpaceApplication::bake_render_graph()
 	ResourceDimensions dim;
 	dim.width = config.width;
 	dim.height = config.height;
-	dim.format = VK_FORMAT_R8G8B8A8_SRGB;
+	dim.format = backbuffer_format();
 	graph.set_backbuffer_dimensions(dim);
 
 	const std::string tag = "main";
@@ -459,6 +462,24 @@ void ImageSpaceApplication::bake_render_graph()
 			ui_source = "post-aa-output";
 		if (temporal)
 			jitter = saved;
+	}
+
+	if (config.hdr10)
+	{
+		// scene_viewer_application.cpp:1270-1288: a UI layer cleared to (0, 0, 0, 1), then the PQ encoder as the frame's last pass.
+		auto &ui = graph.add_pass("ui", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		AttachmentInfo ui_info;
+		ui_info.format = VK_FORMAT_R8G8B8A8_SRGB;
+		auto &ui_layer = ui.add_color_output("ui-temporary", ui_info);
+		ui.set_build_render_pass([this, &ui_layer](HIP::CommandBuffer &cmd) {
+			auto &target = graph.get_physical_texture_resource(ui_layer);
+			cmd.check(gr_fill_u32(cmd.get_context(), cmd.get_stream(), target.get_device_pointer(), 0xff000000u, target.get_size_bytes() / 4), "ui clear");
+		});
+		HDR10PQEncodingConfig hdr10_config = {};
+		hdr10_config.hdr_pre_exposure = 500.0f;
+		hdr10_config.ui_pre_exposure = 400.0f;
+		setup_hdr10_pq_encoding(graph, "ui-output", ui_source, "ui-temporary", hdr10_config, HdrMetadata());
+		ui_source = "ui-output";
 	}
 
 	if (scaled()) // scene_viewer_application.cpp:1263-1268

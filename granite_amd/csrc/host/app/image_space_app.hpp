@@ -74,6 +74,7 @@ private:
 	gra_config config;
 	unsigned render_width = 0, render_height = 0; // backbuffer size x resolution_scale
 	bool scaled() const { return config.resolution_scale > 0.0f && config.resolution_scale < 1.0f; }
+	VkFormat backbuffer_format() const { return config.hdr10 ? VK_FORMAT_A2B10G10R10_UNORM_PACK32 : VK_FORMAT_R8G8B8A8_SRGB; }
 	std::unique_ptr<HIP::Device> device_holder;
 	RenderGraph graph;
 	RenderContext context;

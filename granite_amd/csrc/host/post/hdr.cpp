@@ -1,6 +1,7 @@
 // renderer/post/hdr.cpp restated on the HIP executor: identical pass / resource names, formats, size classes and push
 // constants; each recorded dispatch or full-screen quad becomes one C-ABI kernel launch.
 #include "hdr.hpp"
+#include <cstring>
 #include <cmath>
 
 namespace Granite
@@ -297,5 +298,128 @@ void setup_hdr_postprocess(RenderGraph &graph, const FrameParameters &frame, con
 			record_tonemap(tonemap, cmd, hdr_res, bloom_res, ubo, iface);
 		});
 	}
+}
+
+// ---- HDR10 output (hdr.cpp:562-658) --------------------------------------------------------------------------------------------
+namespace
+{
+struct Mat3
+{
+	float c[3][3]; // c[column][row]
+};
+
+void primary_to_xyz(const float xy[2], float out[3])
+{
+	out[0] = xy[0] / xy[1];
+	out[1] = 1.0f;
+	out[2] = (1.0f - xy[0] - xy[1]) / xy[1];
+}
+
+Mat3 inverse3(const Mat3 &m)
+{
+	// adjugate / determinant (muglm::inverse(mat3) has the same form)
+	const float a = m.c[0][0], b = m.c[1][0], c = m.c[2][0];
+	const float d = m.c[0][1], e = m.c[1][1], f = m.c[2][1];
+	const float g = m.c[0][2], h = m.c[1][2], i = m.c[2][2];
+	const float det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+	const float inv = 1.0f / det;
+	Mat3 r;
+	r.c[0][0] = (e * i - f * h) * inv;
+	r.c[1][0] = (c * h - b * i) * inv;
+	r.c[2][0] = (b * f - c * e) * inv;
+	r.c[0][1] = (f * g - d * i) * inv;
+	r.c[1][1] = (a * i - c * g) * inv;
+	r.c[2][1] = (c * d - a * f) * inv;
+	r.c[0][2] = (d * h - e * g) * inv;
+	r.c[1][2] = (b * g - a * h) * inv;
+	r.c[2][2] = (a * e - b * d) * inv;
+	return r;
+}
+
+Mat3 mul3(const Mat3 &a, const Mat3 &b)
+{
+	Mat3 r;
+	for (int col = 0; col < 3; col++)
+		for (int row = 0; row < 3; row++)
+			r.c[col][row] = a.c[0][row] * b.c[col][0] + a.c[1][row] * b.c[col][1] + a.c[2][row] * b.c[col][2];
+	return r;
+}
+
+Mat3 xyz_matrix(const float red[2], const float green[2], const float blue[2], const float white_point[2])
+{
+	Mat3 primaries;
+	float white[3];
+	primary_to_xyz(red, primaries.c[0]);
+	primary_to_xyz(green, primaries.c[1]);
+	primary_to_xyz(blue, primaries.c[2]);
+	primary_to_xyz(white_point, white);
+	const Mat3 inv = inverse3(primaries);
+	float scale[3];
+	for (int row = 0; row < 3; row++)
+		scale[row] = inv.c[0][row] * white[0] + inv.c[1][row] * white[1] + inv.c[2][row] * white[2];
+	Mat3 r;
+	for (int col = 0; col < 3; col++)
+		for (int row = 0; row < 3; row++)
+			r.c[col][row] = primaries.c[col][row] * scale[col];
+	return r;
+}
+} // namespace
+
+void compute_xyz_matrix(const float red[2], const float green[2], const float blue[2], const float white_point[2], float out9[9])
+{
+	const Mat3 m = xyz_matrix(red, green, blue, white_point);
+	memcpy(out9, m.c, sizeof(m.c));
+}
+
+void compute_rec709_to_st2020(const HdrMetadata &metadata, float out9[9])
+{
+	// sRGB in Vulkan uses BT.709 primaries with a D65 white point (hdr.cpp:582-589).
+	const float r709[2] = {0.640f, 0.330f}, g709[2] = {0.3f, 0.6f}, b709[2] = {0.150f, 0.060f}, d65[2] = {0.3127f, 0.3290f};
+	const Mat3 srgb_to_xyz = xyz_matrix(r709, g709, b709, d65);
+	const Mat3 xyz_to_display = inverse3(xyz_matrix(metadata.display_primary_red, metadata.display_primary_green, metadata.display_primary_blue,
+	                                                metadata.white_point));
+	const Mat3 m = mul3(xyz_to_display, srgb_to_xyz);
+	memcpy(out9, m.c, sizeof(m.c));
+}
+
+void setup_hdr10_pq_encoding(RenderGraph &graph, const std::string &output, const std::string &hdr_input, const std::string &ui_input,
+                             const HDR10PQEncodingConfig &config, const HdrMetadata &static_metadata)
+{
+	struct PQEncoder : RenderPassInterface
+	{
+		RenderGraph *graph = nullptr;
+		RenderTextureResource *hdr = nullptr, *ui = nullptr, *out = nullptr;
+		gr_push_pq10 push = {};
+
+		bool get_clear_color(unsigned, VkClearColorValue *) const override { return false; }
+
+		void build_render_pass(HIP::CommandBuffer &cmd) override
+		{
+			auto &hdr_view = graph->get_physical_texture_resource(*hdr);
+			auto &ui_view = graph->get_physical_texture_resource(*ui);
+			auto &target = graph->get_physical_texture_resource(*out);
+			cmd.check(gr_pq10_encode(cmd.get_context(), cmd.get_stream(), &hdr_view.get_view(), &ui_view.get_view(), &target.get_view(), &push),
+			          "pq10 encode");
+		}
+	};
+
+	auto &pq10 = graph.add_pass("pq10", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+	AttachmentInfo att; // swapchain size and format
+	auto pass = std::make_shared<PQEncoder>();
+	pass->graph = &graph;
+	float conversion[9];
+	compute_rec709_to_st2020(static_metadata, conversion);
+	for (int col = 0; col < 3; col++) // mat4(mat3)
+		for (int row = 0; row < 3; row++)
+			pass->push.primary_conversion[4 * col + row] = conversion[3 * col + row];
+	pass->push.primary_conversion[15] = 1.0f;
+	pass->push.hdr_pre_exposure = config.hdr_pre_exposure;
+	pass->push.ui_pre_exposure = config.ui_pre_exposure;
+	pass->push.max_light_level = static_metadata.max_content_light_level;
+	pass->push.inv_max_light_level = 1.0f / static_metadata.max_content_light_level; // pre-Reinhard scaling, hdr.cpp:643-644
+	pass->out = &pq10.add_color_output(output, att);
+	pass->hdr = &pq10.add_texture_input(hdr_input);
+	pass->ui = &pq10.add_texture_input(ui_input);
+	pq10.set_render_pass_interface(std::move(pass));
 }
 } // namespace Granite

@@ -71,6 +71,13 @@ typedef struct gra_config
 	 * R8_UNORM texture "ssao-output-main" as LightingParameters::ambient_occlusion.  Its producer in Granite is FFX CACAO,
 	 * shipped as SPIR-V blobs only; the harness fills the texture from gra_upload_ambient_occlusion like the G-buffer. */
 	int32_t ambient_occlusion;
+	/* HDR10 output (setup_hdr10_pq_encoding, renderer/post/hdr.cpp:595-658): the backbuffer is A2B10G10R10_UNORM_PACK32 and the
+	 * frame ends lighting -> "ui" (an R8G8B8A8_SRGB layer cleared to transparent: (0, 0, 0, 1) = scene fully visible) -> "pq10"
+	 * with ST.2020 primaries, maxContentLightLevel 1000, hdr / ui pre-exposure 500 / 400 (scene_viewer_application.cpp:1283-1285).
+	 * Replaces bloom + tonemap (hdr_bloom must be 0); no AA, no resolution scaling, no row bands.  Note: the viewer itself
+	 * declares the UI layer as a colour read-modify-write of the HDR target with another format, which its own validation
+	 * rejects (scene_viewer_application.cpp:1279-1287); the layer is its own attachment here. */
+	int32_t hdr10;
 } gra_config;
 
 /* Scene-level light description (one PositionalLight + its node transform). */
@@ -186,6 +193,8 @@ int gra_get_strip_plan(gra_app *app, uint32_t *out24);
 /* Host-side frame-loop cost since creation: out[0] = frames, out[1] = seconds spent inside the frame loop (light
  * refresh + graph execution = launches), out[2] = seconds of those spent blocked on GPU back-pressure. */
 int gra_get_host_stats(gra_app *app, double *out3);
+/* compute_rec709_to_st2020 (hdr.cpp:580-593) for display primaries r, g, b, white (CIE xy, 8 floats): column-major 3 x 3. */
+int gra_compute_rec709_to_display(const float *primaries8, float *out9);
 /* Bytes of HBM currently held by the executor's images and buffers (graph attachments, hand-over rings, uploads). */
 int gra_get_allocated_bytes(gra_app *app, uint64_t *out);
 /* Per-kernel timing lives in the kernel library: gr_timing_* on this context. */

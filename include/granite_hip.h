@@ -414,6 +414,23 @@ int gr_hiz(gr_ctx *ctx, gr_stream stream, const gr_hiz_args *args);
 int gr_fsr_upscale(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, int fp16);
 int gr_fsr_sharpen(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, float sharpness);
 
+/* ---- HDR10 output ---------------------------------------------------------------------------------------------------------
+ * setup_hdr10_pq_encoding (renderer/post/hdr.cpp:595-658) + pq10_encode.frag: out = PQ(soft-clip(primary_conversion *
+ * (hdr * hdr_pre_exposure * ui.a + ui.rgb * ui_pre_exposure) / max) * max) in the display's primaries.  hdr R16G16B16A16_SFLOAT
+ * (texel fetch), ui R8G8B8A8 read through its sRGB view, out A2B10G10R10_UNORM_PACK32 (alpha 1); all the same size.  The
+ * push block is byte-identical to the shader's UBO (hdr.cpp:626-633). */
+typedef struct gr_push_pq10
+{
+	float primary_conversion[16]; /* mat4(compute_rec709_to_st2020(metadata)), column major; the 3 x 3 part is used */
+	float hdr_pre_exposure;
+	float ui_pre_exposure;
+	float max_light_level;        /* VkHdrMetadataEXT::maxContentLightLevel */
+	float inv_max_light_level;
+} gr_push_pq10;
+int gr_pq10_encode(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *ui, const gr_image *out, const gr_push_pq10 *push);
+/* Fill with a 32-bit pattern (count dwords): attachment clears to a colour. */
+int gr_fill_u32(gr_ctx *ctx, gr_stream stream, void *dst, uint32_t value, size_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -354,3 +354,34 @@ def fsr_rcas(rgba8: np.ndarray, sharpness: float = None, srgb: bool = True) -> n
     s = fsr_rcas_sharpness() if sharpness is None else sharpness
     lib().orc_fsr_rcas(_p(src), w, h, _p(out), C.c_float(s), int(srgb))
     return out
+
+
+# ---- HDR10 output (renderer/post/hdr.cpp:562-658 + assets/shaders/post/pq10_encode.frag) -----------------------------------
+REC709_PRIMARIES = ((0.640, 0.330), (0.3, 0.6), (0.150, 0.060), (0.3127, 0.3290))  # hdr.cpp:585-589
+ST2020_PRIMARIES = ((0.708, 0.292), (0.170, 0.797), (0.131, 0.046), (0.3127, 0.3290))
+
+
+def xyz_matrix(primaries) -> np.ndarray:
+    """compute_xyz_matrix (math/transforms.cpp:353-370) in float64, for known-answer checks (3x3, columns = primaries)."""
+    def conv(xy):
+        return np.array([xy[0] / xy[1], 1.0, (1.0 - xy[0] - xy[1]) / xy[1]])
+    r, g, b, wp = (conv(p) for p in primaries)
+    scale = np.linalg.solve(np.stack([r, g, b], axis=1), wp)
+    return np.stack([r * scale[0], g * scale[1], b * scale[2]], axis=1)
+
+
+def rec709_to_display(primaries=ST2020_PRIMARIES) -> np.ndarray:
+    """compute_rec709_to_st2020 (hdr.cpp:580-593): column-major 9 floats."""
+    m = np.linalg.inv(xyz_matrix(primaries)) @ xyz_matrix(REC709_PRIMARIES)
+    return np.ascontiguousarray(m.T, np.float32).reshape(9)
+
+
+def pq10_encode(hdr: np.ndarray, ui_rgba8: np.ndarray, conversion9, hdr_pre_exposure=500.0, ui_pre_exposure=400.0,
+                max_light_level=1000.0) -> np.ndarray:
+    w, h = _img16(hdr)
+    ui = np.ascontiguousarray(ui_rgba8, np.uint8)
+    m = np.ascontiguousarray(conversion9, np.float32)
+    out = np.zeros((h, w), np.uint32)
+    lib().orc_pq10_encode(_p(hdr), _p(ui), w, h, _p(m), C.c_float(hdr_pre_exposure), C.c_float(ui_pre_exposure),
+                          C.c_float(max_light_level), _p(out))
+    return out

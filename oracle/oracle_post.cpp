@@ -186,3 +186,50 @@ void orc_sample_linear_rgba16f(const uint16_t *img, int w, int h, float u, float
 	out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w;
 }
 }
+
+// ---- HDR10 output: assets/shaders/post/pq10_encode.frag + setup_hdr10_pq_encoding (renderer/post/hdr.cpp:595-658) --------------
+// hdr: RGBA16F (texelFetch), ui: RGBA8 read through its sRGB view (rgb decoded, alpha linear), both w x h.
+// primary_conversion: column-major mat3 (rec.709 -> display primaries, compute_rec709_to_st2020 hdr.cpp:580-593).
+// out: A2B10G10R10_UNORM_PACK32 (the HDR10 swapchain format), alpha = 1.
+extern "C" void orc_pq10_encode(const uint16_t *hdr, const uint8_t *ui_srgb8, int w, int h, const float *primary_conversion9, float hdr_pre_exposure,
+                                float ui_pre_exposure, float max_light_level, uint32_t *out)
+{
+	using namespace orc;
+	const float inv_max_light_level = 1.0f / max_light_level; // hdr.cpp:644
+	auto encode_pq = [](float nits) {
+		const float y = nits / 10000.0f;
+		const float c1 = 0.8359375f, c2 = 18.8515625f, c3 = 18.6875f, m1 = 0.1593017578125f, m2 = 78.84375f;
+		const float num = c1 + c2 * powf(y, m1);
+		const float den = 1.0f + c3 * powf(y, m1);
+		return powf(num / den, m2);
+	};
+	auto unorm10 = [](float v) -> uint32_t {
+		if (!(v > 0.0f))
+			return 0u;
+		if (v >= 1.0f)
+			return 1023u;
+		return uint32_t(int(v * 1023.0f + 0.5f));
+	};
+#pragma omp parallel for schedule(static)
+	for (int y = 0; y < h; y++)
+		for (int x = 0; x < w; x++)
+		{
+			const size_t i = size_t(y) * w + x;
+			const vec3 c_hdr = V3(half_to_float(hdr[4 * i]), half_to_float(hdr[4 * i + 1]), half_to_float(hdr[4 * i + 2]));
+			const uint8_t *u = ui_srgb8 + 4 * i;
+			const vec3 ui_rgb = V3(srgb8_to_float(u[0]), srgb8_to_float(u[1]), srgb8_to_float(u[2]));
+			const float ui_a = float(u[3]) / 255.0f;
+			vec3 col = c_hdr * (hdr_pre_exposure * ui_a) + ui_rgb * ui_pre_exposure;
+			// mat3(config.primary_conversion) * col
+			const float *m = primary_conversion9;
+			col = V3(m[0], m[1], m[2]) * col.x + V3(m[3], m[4], m[5]) * col.y + V3(m[6], m[7], m[8]) * col.z;
+			col = col * inv_max_light_level;
+			const float K = 4.0f;
+			const vec3 col_k = col * K;
+			const vec3 saturated = col_k / (V3(1.0f) + col_k);
+			// mix(col, saturated, greaterThan(col, vec3(0.75)))
+			col = V3(col.x > 0.75f ? saturated.x : col.x, col.y > 0.75f ? saturated.y : col.y, col.z > 0.75f ? saturated.z : col.z);
+			const vec3 scaled = col * max_light_level;
+			out[i] = unorm10(encode_pq(scaled.x)) | (unorm10(encode_pq(scaled.y)) << 10) | (unorm10(encode_pq(scaled.z)) << 20) | (3u << 30);
+		}
+}

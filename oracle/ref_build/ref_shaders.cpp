@@ -59,6 +59,10 @@ namespace bloom_upsample
 {
 #include "gen/bloom_upsample.inc"
 }
+namespace pq10
+{
+#include "gen/pq10_encode.inc"
+}
 namespace luminance
 {
 #include "gen/luminance.inc"
@@ -239,6 +243,34 @@ void ref_tonemap(const uint16_t *hdr, int w, int h, const uint16_t *bloom, int b
 				color = s::FragColor;
 			}
 			imageStore(target, ivec2(x, y), vec4(color, 1.0f));
+		}
+}
+
+// pq10_encode.frag with the UBO of PQEncoder::build_render_pass (hdr.cpp:626-636): hdr RGBA16F, ui through its sRGB view,
+// output A2B10G10R10 (alpha 1).  conversion9: column-major mat3.
+void ref_pq10_encode(const uint16_t *hdr, const uint8_t *ui_srgb8, int w, int h, const float *conversion9, float hdr_pre_exposure, float ui_pre_exposure,
+                     float max_light_level, uint32_t *out)
+{
+	namespace s = pq10;
+	s::uHDR = tex16(hdr, w, h, Filter::Nearest);
+	s::uUI.data = ui_srgb8;
+	s::uUI.w = w;
+	s::uUI.h = h;
+	s::uUI.format = Format::RGBA8_SRGB;
+	s::uUI.filter = Filter::Nearest;
+	for (int col = 0; col < 4; col++)
+		s::config.primary_conversion.c[col] = col < 3 ? vec4(conversion9[3 * col], conversion9[3 * col + 1], conversion9[3 * col + 2], 0.0f) : vec4(0.0f, 0.0f, 0.0f, 1.0f);
+	s::config.hdr_pre_exposure = hdr_pre_exposure;
+	s::config.ui_pre_exposure = ui_pre_exposure;
+	s::config.max_light_level = max_light_level;
+	s::config.inv_max_light_level = 1.0f / max_light_level;
+	for (int y = 0; y < h; y++)
+		for (int x = 0; x < w; x++)
+		{
+			gl_FragCoord = vec4(float(x) + 0.5f, float(y) + 0.5f, 0.0f, 1.0f);
+			s::main();
+			auto q = [](float v) -> uint32_t { return !(v > 0.0f) ? 0u : (v >= 1.0f ? 1023u : uint32_t(int(v * 1023.0f + 0.5f))); };
+			out[size_t(y) * w + x] = q(s::FragColor.x) | (q(s::FragColor.y) << 10) | (q(s::FragColor.z) << 20) | (3u << 30);
 		}
 }
 

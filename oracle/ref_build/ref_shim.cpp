@@ -7,6 +7,7 @@
 // the real reference code; it never ships and is absent on the GPU box unless built here first.
 #include "muglm/muglm_impl.hpp"
 #include "muglm/matrix_helper.hpp"
+#include "transforms.hpp"
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -87,5 +88,20 @@ void ref_fsr_easu_constants(float iw, float ih, float ow, float oh, uint32_t *ou
 	FsrEasuCon(out16, out16 + 4, out16 + 8, out16 + 12, iw, ih, iw, ih, ow, oh);
 }
 void ref_fsr_rcas_constants(float stops, uint32_t *out4) { FsrRcasCon(out4, stops); }
+
+// compute_rec709_to_st2020 (renderer/post/hdr.cpp:580-593) -- a static function there, so its three statements are repeated
+// here over the reference's own compute_xyz_matrix (math/transforms.cpp:353-370), inverse and mat3 product.
+// primaries8 = display red, green, blue, white point (CIE xy); out9 column major.
+void ref_rec709_to_display(const float *primaries8, float *out9)
+{
+	using namespace Granite;
+	const Primaries rec709 = {vec2(0.640f, 0.330f), vec2(0.3f, 0.6f), vec2(0.150f, 0.060f), vec2(0.3127f, 0.3290f)};
+	const Primaries display = {vec2(primaries8[0], primaries8[1]), vec2(primaries8[2], primaries8[3]), vec2(primaries8[4], primaries8[5]),
+	                           vec2(primaries8[6], primaries8[7])};
+	const mat3 srgb_to_xyz = compute_xyz_matrix(rec709);
+	const mat3 xyz_to_display = inverse(compute_xyz_matrix(display));
+	const mat3 m = xyz_to_display * srgb_to_xyz;
+	memcpy(out9, &m, sizeof(float) * 9);
+}
 
 } // extern "C"

@@ -349,3 +349,27 @@ def test_ambient_occlusion_scales_only_the_fallback_ambient_term():
     want = f32(none)[lit] + 0.2 * (f32(plain)[lit] - f32(none)[lit])
     np.testing.assert_allclose(half[lit][:, :3], want[:, :3], rtol=4e-3, atol=2e-4)
     assert np.abs(f32(plain)[lit][:, :3] - f32(none)[lit][:, :3]).max() > 1e-3
+
+
+def test_pq10_known_answers():
+    """SMPTE ST 2084: 100 nits -> 0.508, 1000 nits -> 0.7518, 10000 -> 1, 0 -> ~0 (c1^m2); the encoder soft-clips above 75 % of
+    maxContentLightLevel (x -> 4x / (1 + 4x)) and the UI layer's alpha is the scene's visibility."""
+    ident = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], np.float32)
+    hdr = np.zeros((1, 6, 4), np.float16)
+    hdr[0, :, :3] = np.array([0.0, 0.2, 1.0, 1.4, 2.0, 200.0])[:, None]  # x 500 nits pre-exposure
+    ui = np.zeros((1, 6, 4), np.uint8)
+    ui[..., 3] = 255
+    out = orc.pq10_encode(hdr.view(np.uint16), ui, ident, 500.0, 400.0, 1000.0)[0]
+    r = (out & 1023).astype(int)
+    assert ((out >> 10) & 1023 == out & 1023).all() and ((out >> 30) == 3).all()
+    def pq(nits):
+        y = nits / 10000.0
+        return ((0.8359375 + 18.8515625 * y ** 0.1593017578125) / (1 + 18.6875 * y ** 0.1593017578125)) ** 78.84375
+    clip = lambda x: 4 * x / (1 + 4 * x) if x > 0.75 else x
+    want = [round(1023 * pq(1000.0 * clip(v * 500.0 / 1000.0))) for v in (0.0, 0.2, 1.0, 1.4, 2.0, 200.0)]
+    assert np.abs(r - np.array(want)).max() <= 1, (r, want)
+    assert r[0] == 0 and abs(r[1] - 520) <= 1 and r[5] < 1023 * pq(1000.0) + 1
+    # alpha 0 hides the scene, the UI colour alone remains: white UI = 400 nits
+    ui[...] = (255, 255, 255, 0)
+    out = orc.pq10_encode(hdr.view(np.uint16), ui, ident, 500.0, 400.0, 1000.0)[0]
+    assert np.abs((out & 1023).astype(int) - round(1023 * pq(400.0))).max() <= 1

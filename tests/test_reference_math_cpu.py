@@ -119,3 +119,20 @@ def test_fsr_constants_equal_the_vendored_header_in_cpu_mode(ref):
     con = np.zeros(4, np.uint32)
     ref.ref_fsr_rcas_constants(0.5, con.ctypes.data)
     assert con.view(np.float32)[0] == np.float32(orc.fsr_rcas_sharpness(0.5))
+
+
+def test_rec709_to_display_matrix_equals_the_reference(ref):
+    """compute_rec709_to_st2020 (hdr.cpp:580-593) in the C++ host layer vs the same three statements over the reference's own
+    compute_xyz_matrix (math/transforms.cpp), inverse and mat3 product: ST.2020, DCI-P3 and rec.709 displays."""
+    ref.ref_rec709_to_display.argtypes = [C.c_void_p, C.c_void_p]
+    lib = gapp.load_library()
+    for prim in ((0.708, 0.292, 0.170, 0.797, 0.131, 0.046, 0.3127, 0.3290), (0.680, 0.320, 0.265, 0.690, 0.150, 0.060, 0.3127, 0.3290),
+                 (0.640, 0.330, 0.3, 0.6, 0.150, 0.060, 0.3127, 0.3290)):
+        p8 = np.array(prim, np.float32)
+        want, got = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        ref.ref_rec709_to_display(p8.ctypes.data, want.ctypes.data)
+        assert lib.gra_compute_rec709_to_display(p8.ctypes.data, got.ctypes.data) == 0
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(want.reshape(3, 3), np.eye(3), atol=2e-6)  # rec.709 display: identity
+    np.testing.assert_allclose(orc.rec709_to_display(), np.array([0.6274039, 0.06909728, 0.01639144, 0.3292831, 0.91954035, 0.08801329,
+                                                                  0.04331313, 0.01136229, 0.8955956], np.float32), atol=1e-6)

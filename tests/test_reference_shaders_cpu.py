@@ -316,3 +316,19 @@ def test_fsr_rcas_shader_bit_for_bit(ref, kind, srgb):
     got = np.zeros_like(want)
     ref.ref_fsr_rcas(ptr(src), 253, 127, ptr(got), 0.5, int(srgb))
     np.testing.assert_array_equal(got, want)
+
+
+# ---- HDR10 output: post/pq10_encode.frag ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("max_light_level", [1000.0, 400.0])
+def test_pq10_encode_shader_bit_for_bit(ref, max_light_level):
+    ref.ref_pq10_encode.argtypes = [P, P, C.c_int, C.c_int, P, C.c_float, C.c_float, C.c_float, P]
+    w, h = 96, 54
+    hdr = synth.make_hdr(w, h, 5)
+    ui = np.random.default_rng(1).integers(0, 256, (h, w, 4), dtype=np.uint8)
+    ui[:20] = (0, 0, 0, 255)  # the cleared layer: scene fully visible
+    conversion = orc.rec709_to_display()
+    want = orc.pq10_encode(hdr, ui, conversion, 500.0, 400.0, max_light_level)
+    got = np.zeros_like(want)
+    ref.ref_pq10_encode(ptr(hdr), ptr(ui), w, h, ptr(conversion), 500.0, 400.0, max_light_level, ptr(got))
+    np.testing.assert_array_equal(got, want)
+    assert len(np.unique(want & 1023)) > 50

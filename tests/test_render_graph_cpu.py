@@ -175,3 +175,13 @@ def test_ambient_occlusion_pass_sits_between_gbuffer_and_lighting():
     assert "ssao-output-main" in {r["name"] for r in lighting["reads"]}
     pp = {p["name"]: p["physical_pass"] for p in g["passes"]}
     assert len({pp["gbuffer-main"], pp["ssao-main"], pp["lighting-main"]}) == 3
+
+
+def test_hdr10_graph_ends_in_the_pq_encoder_on_a_10_bit_backbuffer():
+    g = graph_of(1280, 720, hdr10=True, hdr_bloom=False)
+    assert [p["name"] for p in g["passes"]][-2:] == ["lighting-main", "pq10"] and "ui" in {p["name"] for p in g["passes"]}
+    res = {r["name"]: r for r in g["resources"]}
+    assert res["ui-output"]["format"] == 64 and res["ui-temporary"]["format"] == 43
+    assert g["swapchain_phys"] == res["ui-output"]["phys"]
+    with pytest.raises(capi.GraniteHipError):
+        graph_of(1280, 720, hdr10=True)  # bloom + tonemap and the PQ encoder are alternatives
