@@ -98,6 +98,8 @@ def load_library() -> C.CDLL:
         "gra_gtx_write": (C.c_int, [C.c_char_p, vp, vp, vp, C.c_size_t]),
         "gra_upload_gbuffer_gtx": (C.c_int, [vp] + [C.c_char_p] * 6),
         "gra_save_resource_gtx": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
+        "gra_reset_timestamps": (C.c_int, [vp]),
+        "gra_set_directional_light": (C.c_int, [vp, vp, vp]),
         "gra_set_exchange_callback": (C.c_int, [vp, EXCHANGE_FN, vp]),
         "gra_get_strip_plan": (C.c_int, [vp, vp]),
         "gra_comm_create_unique_id": (C.c_int, [vp]),
@@ -301,6 +303,13 @@ class Application:
         arr = (Timestamp * 64)()
         n = self._check(self.lib.gra_collect_timestamps(self.handle, arr, 64))
         return {arr[i].tag.decode(): (int(arr[i].count), float(arr[i].total_ms)) for i in range(n)}
+
+    def reset_timestamps(self):
+        self._check(self.lib.gra_reset_timestamps(self.handle))
+
+    def set_directional(self, direction, color):
+        d, c = np.asarray(direction, np.float32), np.asarray(color, np.float32)
+        self._check(self.lib.gra_set_directional_light(self.handle, d.ctypes.data, c.ctypes.data))
 
     # ---- row-band tiling ---------------------------------------------------------------------------------------------
     def set_exchange_callback(self, fn):

@@ -239,6 +239,24 @@ int gr_fill_u32(gr_ctx *ctx, gr_stream stream, void *dst, uint32_t value, size_t
 	return GR_OK;
 }
 
+int gr_get_device_info(gr_ctx *ctx, char *name, size_t name_capacity, uint32_t *driver_version)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, name && name_capacity > 0);
+	hipDeviceProp_t props;
+	GR_CHECK_HIP(ctx, hipGetDeviceProperties(&props, ctx->device));
+	// Containers without the amdgpu ids table report an empty marketing name; the ISA name is always there.
+	snprintf(name, name_capacity, "%s", props.name[0] ? props.name : props.gcnArchName);
+	if (driver_version)
+	{
+		int version = 0;
+		GR_CHECK_HIP(ctx, hipDriverGetVersion(&version));
+		*driver_version = uint32_t(version);
+	}
+	return GR_OK;
+}
+
 int gr_timing_enable(gr_ctx *ctx, int enable)
 {
 	if (!ctx)

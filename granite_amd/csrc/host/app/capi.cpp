@@ -464,6 +464,35 @@ size_t gra_dump_graph(gra_app *app, char *buffer, size_t size)
 	return json.size() + 1;
 }
 
+int gra_reset_timestamps(gra_app *app)
+{
+	if (!app)
+		return -1;
+	try
+	{
+		app->app->get_graph().reset_timestamps();
+		return 0;
+	}
+	catch (const std::exception &e)
+	{
+		app->error = e.what();
+		return -1;
+	}
+}
+
+int gra_set_directional_light(gra_app *app, const float direction[3], const float color[3])
+{
+	if (!app)
+		return -1;
+	if (!direction || !color)
+	{
+		app->error = "gra_set_directional_light: null argument";
+		return -1;
+	}
+	app->app->set_directional_light(direction, color);
+	return 0;
+}
+
 int gra_collect_timestamps(gra_app *app, gra_timestamp *entries, int max_entries)
 {
 	if (!app)

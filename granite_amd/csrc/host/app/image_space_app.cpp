@@ -543,4 +543,10 @@ void ImageSpaceApplication::render_frame()
 	host_frames++;
 	host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - host_t0).count();
 }
+
+void ImageSpaceApplication::set_directional_light(const float direction[3], const float color[3])
+{
+	lighting.directional.color = vec3(color[0], color[1], color[2]);
+	lighting.directional.direction = normalize(vec3(direction[0], direction[1], direction[2]));
+}
 } // namespace Granite

@@ -41,6 +41,8 @@ public:
 			throw std::logic_error("Application was created without a device (dry mode).");
 		return *device_holder;
 	}
+	// DirectionalLightComponent of the scene (read_lights, scene_viewer_application.cpp:58-77); direction need not be normalised.
+	void set_directional_light(const float direction[3], const float color[3]);
 	RenderGraph &get_graph() { return graph; }
 	RenderContext &get_context() { return context; }
 	TemporalJitter &get_jitter() { return jitter; }

@@ -1553,14 +1553,34 @@ std::vector<RenderGraph::TimestampReport> RenderGraph::collect_timestamps()
 		float ms = 0.0f;
 		if (hipEventSynchronize(stop) == hipSuccess && hipEventElapsedTime(&ms, start, stop) == hipSuccess)
 		{
-			auto &name = passes[ts.pass]->get_name();
+			// Tag = the physical pass, "a + b" when the reference would run several passes as subpasses of one
+			// VkRenderPass (render_graph.cpp:2274-2289); one accumulation per physical pass instance.
+			std::string name;
+			bool first_of_group = true;
+			if (ts.pass < pass_physical_pass.size())
+			{
+				unsigned group = pass_physical_pass[ts.pass];
+				for (unsigned member : pass_stack)
+				{
+					if (pass_physical_pass[member] != group)
+						continue;
+					if (!name.empty())
+						name += " + ";
+					else
+						first_of_group = member == ts.pass;
+					name += passes[member]->get_name();
+				}
+			}
+			else
+				name = passes[ts.pass]->get_name();
 			auto itr = timestamp_accum.find(name);
 			if (itr == timestamp_accum.end())
 			{
 				timestamp_order.push_back(name);
 				itr = timestamp_accum.emplace(name, std::make_pair(uint64_t(0), 0.0)).first;
 			}
-			itr->second.first++;
+			if (first_of_group)
+				itr->second.first++;
 			itr->second.second += ms;
 		}
 		event_pool.push_back(ts.start);
@@ -1575,6 +1595,13 @@ std::vector<RenderGraph::TimestampReport> RenderGraph::collect_timestamps()
 		out.push_back({name, acc.first, acc.second});
 	}
 	return out;
+}
+
+void RenderGraph::reset_timestamps()
+{
+	collect_timestamps();
+	timestamp_accum.clear();
+	timestamp_order.clear();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

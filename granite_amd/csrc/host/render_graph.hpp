@@ -474,6 +474,8 @@ public:
 		double total_ms;
 	};
 	std::vector<TimestampReport> collect_timestamps();
+	// Device::timestamp_log_reset (application_headless.cpp:591): drop what was accumulated so far (the warm-up frame).
+	void reset_timestamps();
 
 private:
 	HIP::Device *device = nullptr;

@@ -170,6 +170,11 @@ typedef struct gra_timestamp
 	double total_ms;
 } gra_timestamp;
 int gra_collect_timestamps(gra_app *app, gra_timestamp *entries, int max_entries);
+/* Device::timestamp_log_reset (application_headless.cpp:591): forget what was accumulated, e.g. the warm-up frame. */
+int gra_reset_timestamps(gra_app *app);
+/* The scene's DirectionalLightComponent (read_lights, scene_viewer_application.cpp:58-77): replaces the values of
+ * gra_config for the frames that follow; direction is normalised here. */
+int gra_set_directional_light(gra_app *app, const float direction[3], const float color[3]);
 /* T(.5,.5,0) S(.5,.5,1) VP_prev inv(VP_cur) as pushed to the last taa-resolve (temporal.cpp:239-243). */
 int gra_get_taa_reprojection(gra_app *app, float *reproj16);
 /* SMAA AreaTex (160x560 RG8) / SearchTex (64x16 R8) payloads, host pointers; needed before a frame with an SMAA pass. */

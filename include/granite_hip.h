@@ -430,6 +430,9 @@ typedef struct gr_push_pq10
 int gr_pq10_encode(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *ui, const gr_image *out, const gr_push_pq10 *push);
 /* Fill with a 32-bit pattern (count dwords): attachment clears to a colour. */
 int gr_fill_u32(gr_ctx *ctx, gr_stream stream, void *dst, uint32_t value, size_t count);
+/* VkPhysicalDeviceProperties::deviceName / driverVersion as the headless runner reports them in its --stat file
+ * (application_headless.cpp:634-635): HIP device name and hipDriverGetVersion. */
+int gr_get_device_info(gr_ctx *ctx, char *name, size_t name_capacity, uint32_t *driver_version);
 
 #ifdef __cplusplus
 }
