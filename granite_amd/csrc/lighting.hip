@@ -28,6 +28,7 @@
 // The BRDF is algebraically the reference's; normalisations are folded (dot products on the unnormalised light vector,
 // H.V = |V+L|/2, one rcp for G*D) to cut the per-light VALU count.
 #include <cstdlib>
+#include <type_traits>
 #include "ctx.hpp"
 #include "device_common.hpp"
 
@@ -47,6 +48,7 @@ struct KernelArgs
 	DevImage albedo, normal, pbr, depth, emissive, ao;
 	DevImageRW hdr;
 	float inv_vp[16];
+	float clip_dx[4]; // inv_vp column 0 * 2 / width: clip-space step between horizontally adjacent pixels
 	float camera_pos[3];
 	float dir_color[3];
 	float dir_direction[3];
@@ -96,33 +98,40 @@ __device__ __forceinline__ float sample_linear_r8(const DevImage &img, float u, 
 // Per-pixel material terms hoisted out of the light loop.
 struct Surface
 {
-	float3_ pos, N, V, F0, omF0, diffuse; // omF0 = 1 - F0; diffuse = base * (1 - metallic) / PI
-	float NdV, m2m1, c0, k, omk, Gv;     // NdV unclamped; m2m1 = m^2 - 1; c0 = m^2 / (4 PI); Gv = NoV (1-k) + k
+	float3_ pos, N, V, F0, D1;       // D1 = (1 - F0) * base * (1 - metallic) / PI: the diffuse term at f = 0
+	float NdV, m2m1, c0, k, omk, Gv; // NdV unclamped; m2m1 = m^2 - 1; c0 = m^2 / (4 PI); Gv = NoV (1-k) + k
 };
 
 // Shared BRDF tail of compute_point_light / compute_spot_light / compute_lighting (point.h:119-142, spot.h:122-145,
 // lighting.h:26-45) for a unit light direction L given through NdL = dot(N, L) and hh = |V + L|^2 (> 0):
 //   H = (V + L) / |V + L|,  dot(H, V) = |V + L| / 2 (unit V, L),  dot(N, H) = (NdV + NdL) / |V + L|.
-// Returns NoL and brdf = F * G * D + (1 - F) * diffuse; the caller multiplies by NoL and the light colour.
-__device__ __forceinline__ float3_ brdf(const Surface &s, float NdL, float hh, float &NoL)
+// Adds colour * scale * NoL * (F G D + (1 - F) diffuse) to acc.  With f = (1 - HoV)^5 and F = mix(F0, 1, f):
+//   F GD + (1 - F) diffuse = (1 - f) (GD F0 + D1) + f GD,
+// so the per-channel work is three fmas on two scalars that already carry scale * NoL.
+//   * HoV = |V + L| / 2 needs no upper clamp (<= 1 up to rounding, absorbed by the clamp modifier on 1 - HoV); its lower
+//     clamp 0.001 only engages when L is within 0.11 degrees of -V, where it changes f by < 0.5 %.
+//   * The reference's max(Gv Gl, 0.001) never engages: roughness = 0.25 + 0.75 r >= 0.25 gives k = (roughness + 1)^2 / 8
+//     >= 0.195, and Gv, Gl = mix(k, 1, NoX) >= k, so Gv Gl >= 0.038.
+__device__ __forceinline__ void brdf_accumulate(const Surface &s, float NdL, float hh, float scale, float3_ colour, float3_ &acc)
 {
-	NoL = med3(NdL, 0.001f, 1.0f);
+	const float NoL = med3(NdL, 0.001f, 1.0f);
 	const float inv_h = rsq(hh);
-	const float HoV = med3(0.5f * hh * inv_h, 0.001f, 1.0f);
+	const float omh = sat(fmaf(-0.5f * hh, inv_h, 1.0f)); // 1 - HoV
 	const float NoH = med3((s.NdV + NdL) * inv_h, 0.0001f, 1.0f);
 
-	const float omh = 1.0f - HoV;
 	const float omh2 = omh * omh;
 	const float f = omh2 * omh2 * omh; // pow(1 - HoV, 5)
 
-	const float d = fmaf(NoH * NoH, s.m2m1, 1.0f);               // (NoH m2 - NoH) NoH + 1
-	const float g = fmaxf(s.Gv * fmaf(NoL, s.omk, s.k), 0.001f); // G = 0.25 / max(Gv Gl, 0.001)
-	const float GD = s.c0 * rcp(d * d * g);                      // G * D, D = m2 / (PI d^2)
+	const float d = fmaf(NoH * NoH, s.m2m1, 1.0f);     // (NoH m2 - NoH) NoH + 1
+	const float g = s.Gv * fmaf(NoL, s.omk, s.k);      // G = 0.25 / (Gv Gl)
+	const float GD = s.c0 * rcp(d * d * g);            // G * D, D = m2 / (PI d^2)
 
-	// mix(F0, 1, f) * GD + (1 - mix(F0, 1, f)) * diffuse = F * (GD - diffuse) + diffuse
-	const float Fx = fmaf(s.omF0.x, f, s.F0.x), Fy = fmaf(s.omF0.y, f, s.F0.y), Fz = fmaf(s.omF0.z, f, s.F0.z);
-	return f3(fmaf(Fx, GD - s.diffuse.x, s.diffuse.x), fmaf(Fy, GD - s.diffuse.y, s.diffuse.y),
-	          fmaf(Fz, GD - s.diffuse.z, s.diffuse.z));
+	const float w = NoL * scale;
+	const float cw = fmaf(-f, w, w); // (1 - f) w
+	const float fw = f * GD * w;
+	acc.x = fmaf(colour.x, fmaf(fmaf(GD, s.F0.x, s.D1.x), cw, fw), acc.x);
+	acc.y = fmaf(colour.y, fmaf(fmaf(GD, s.F0.y, s.D1.y), cw, fw), acc.y);
+	acc.z = fmaf(colour.z, fmaf(fmaf(GD, s.F0.z, s.D1.z), cw, fw), acc.z);
 }
 
 // clusterer_bindless_buffers.h:17-27 for one light index instead of one 32-bit word.
@@ -153,7 +162,7 @@ __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t v)
 // bookkeeping are shared by 64 * PX pixels, and the PX independent BRDF chains give the wave enough instruction-level
 // parallelism to saturate the VALU at half the resident waves -- which is what leaves wave slots to the executor's other
 // streams while this kernel runs (see gr_lighting).
-template <int PX>
+template <int PX, bool CLAMP_DIST>
 __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], f32x4 q0, f32x4 q1, const f32x4 *slot, bool is_spot,
                                                  float3_ (&result)[PX])
 {
@@ -176,8 +185,10 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], f32x4 q
 	for (int p = 0; p < PX; p++)
 	{
 		inv_d[p] = rsq(d2[p]);
-		len[p] = d2[p] * inv_d[p];                // length(light_dir_full)
-		const float dist = fmaxf(0.1f, len[p]); // light_dist
+		len[p] = d2[p] * inv_d[p]; // length(light_dir_full)
+		// light_dist = max(0.1, length): below 0.1 the smoothstep argument 10 dist / r - 9 is <= 0 either way unless
+		// r < 1/9, so the max is only compiled into the walk used for chunks that hold such a light.
+		const float dist = CLAMP_DIST ? fmaxf(0.1f, len[p]) : len[p];
 		inv_d2[p] = inv_d[p] * inv_d[p];
 		// 1 - smoothstep(0.9, 1.0, dist * inv_radius)
 		const float t = sat(fmaf(dist, q1.w, -9.0f));
@@ -209,12 +220,7 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], f32x4 q
 		// |V + L|^2 with L = Lf / len: |len V + Lf|^2 / len^2
 		const float3_ Hs = f3(fmaf(s[p].V.x, len[p], Lf[p].x), fmaf(s[p].V.y, len[p], Lf[p].y), fmaf(s[p].V.z, len[p], Lf[p].z));
 		const float hh = fmaf(Hs.z, Hs.z, fmaf(Hs.y, Hs.y, fmaf(Hs.x, Hs.x, 1e-30f))) * inv_d2[p];
-		float NoL;
-		const float3_ b = brdf(s[p], NdL, hh, NoL);
-		const float w = NoL * a2;
-		result[p].x = fmaf(q1.x * w, b.x, result[p].x);
-		result[p].y = fmaf(q1.y * w, b.y, result[p].y);
-		result[p].z = fmaf(q1.z * w, b.z, result[p].z);
+		brdf_accumulate(s[p], NdL, hh, a2, f3(q1.x, q1.y, q1.z), result[p]);
 	}
 }
 
@@ -224,6 +230,7 @@ template <int PX, bool AO>
 __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 {
 	__shared__ __attribute__((aligned(16))) f32x4 s_lights[LIGHT_WAVES][64 * (LIGHT_SLOT_BYTES / 16)];
+	__shared__ float s_srgb[256];
 	constexpr int TILE_W = LIGHT_TILE * PX;
 
 	// XCD-aware tile order: block b runs on XCD b % 8; give each XCD one contiguous band of the screen so the cluster
@@ -231,6 +238,8 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 	const int logical = int(blockIdx.x & 7u) * a.blocks_per_xcd + int(blockIdx.x >> 3);
 	if (logical >= a.num_blocks)
 		return;
+	// sRGB8 -> linear table into LDS: one entry per thread (64 * LIGHT_WAVES = 256), the only workgroup-wide step.
+	s_srgb[threadIdx.x] = a.srgb_lut[threadIdx.x];
 	const int block_x = logical % a.blocks_x, block_y = a.block_row0 + logical / a.blocks_x;
 	const int wave = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
@@ -240,8 +249,64 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 	const int W = a.hdr.w, H = a.hdr.h;
 	const bool row_inside = y >= a.row_first && y < a.row_end; // row_end <= H
 
+	// ---- attachment loads, all issued before the first use.  Byte offsets are 32-bit (images < 4 GiB, checked by the
+	// launcher), so every load is base SGPR pair + one VGPR offset.  PX == 2 is only launched for even widths and pitches
+	// that keep the pair of texels naturally aligned: the lane's two pixels are inside or outside together and come in
+	// with one load per attachment. ----
 	bool inside[PX], active[PX];
 	f16x4 dst[PX];
+	float depth_v[PX];
+	uint32_t alb_v[PX], nrm_v[PX], mr_v[PX];
+#pragma unroll
+	for (int p = 0; p < PX; p++)
+	{
+		inside[p] = row_inside && x0 + p < W;
+		depth_v[p] = 0.0f;
+		alb_v[p] = nrm_v[p] = mr_v[p] = 0u;
+		dst[p] = f16x4{0, 0, 0, 0};
+	}
+	if (inside[0])
+	{
+		const uint32_t uy = uint32_t(y), ux = uint32_t(x0);
+		if constexpr (PX == 2)
+		{
+			const float2 d = *reinterpret_cast<const float2 *>(a.depth.ptr + (uy * a.depth.pitch + ux * 4u));
+			const uint2 al = *reinterpret_cast<const uint2 *>(a.albedo.ptr + (uy * a.albedo.pitch + ux * 4u));
+			const uint2 nr = *reinterpret_cast<const uint2 *>(a.normal.ptr + (uy * a.normal.pitch + ux * 4u));
+			const uint32_t m2 = *reinterpret_cast<const uint32_t *>(a.pbr.ptr + (uy * a.pbr.pitch + ux * 2u));
+			const uint4 em = *reinterpret_cast<const uint4 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 8u));
+			depth_v[0] = d.x, depth_v[PX - 1] = d.y;
+			alb_v[0] = al.x, alb_v[PX - 1] = al.y;
+			nrm_v[0] = nr.x, nrm_v[PX - 1] = nr.y;
+			mr_v[0] = m2 & 0xffffu, mr_v[PX - 1] = m2 >> 16;
+			dst[0] = __builtin_bit_cast(f16x4, make_uint2(em.x, em.y));
+			dst[PX - 1] = __builtin_bit_cast(f16x4, make_uint2(em.z, em.w));
+		}
+		else
+		{
+			depth_v[0] = *reinterpret_cast<const float *>(a.depth.ptr + (uy * a.depth.pitch + ux * 4u));
+			alb_v[0] = *reinterpret_cast<const uint32_t *>(a.albedo.ptr + (uy * a.albedo.pitch + ux * 4u));
+			nrm_v[0] = *reinterpret_cast<const uint32_t *>(a.normal.ptr + (uy * a.normal.pitch + ux * 4u));
+			mr_v[0] = *reinterpret_cast<const uint16_t *>(a.pbr.ptr + (uy * a.pbr.pitch + ux * 2u));
+			dst[0] = *reinterpret_cast<const f16x4 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 8u));
+		}
+	}
+	__syncthreads(); // s_srgb
+
+	// ---- position reconstruction (clustering.vert:10-13, clustering.frag:37-39): clip = invVP * (ndc.xy, depth, 1),
+	// pos = clip.xyz / clip.w.  Evaluated with fused multiply-adds and a Newton-refined reciprocal; a pixel that lands
+	// in the neighbouring Z slice because of the last-bit difference sees the same lights up to ones at the very edge
+	// of their radius (falloff -> 0), cf. the conservative slice ranges of clusterer.cpp:1265-1275.  The part that does not
+	// depend on depth is affine in the pixel coordinate: evaluated once per lane, stepped by clip_dx for the second pixel. ----
+	float clip_base[4];
+	{
+		const float ndc_x = fmaf(2.0f * (float(x0) + 0.5f), a.inv_resolution[0], -1.0f);
+		const float ndc_y = fmaf(2.0f * (float(y) + 0.5f), a.inv_resolution[1], -1.0f);
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			clip_base[i] = fmaf(a.inv_vp[4 + i], ndc_y, fmaf(a.inv_vp[i], ndc_x, a.inv_vp[12 + i]));
+	}
+
 	Surface s[PX];
 	float3_ base[PX], accum[PX];
 	bool any_active = false;
@@ -249,40 +314,24 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 	for (int p = 0; p < PX; p++)
 	{
 		const int x = x0 + p;
-		inside[p] = row_inside && x < W;
-		float depth = 0.0f;
-		uint32_t alb = 0, nrm = 0, mr = 0;
-		dst[p] = f16x4{0, 0, 0, 0};
-		if (inside[p])
-		{
-			depth = *reinterpret_cast<const float *>(a.depth.ptr + size_t(y) * a.depth.pitch + size_t(x) * 4u);
-			alb = *reinterpret_cast<const uint32_t *>(a.albedo.ptr + size_t(y) * a.albedo.pitch + size_t(x) * 4u);
-			nrm = *reinterpret_cast<const uint32_t *>(a.normal.ptr + size_t(y) * a.normal.pitch + size_t(x) * 4u);
-			mr = *reinterpret_cast<const uint16_t *>(a.pbr.ptr + size_t(y) * a.pbr.pitch + size_t(x) * 2u);
-			dst[p] = *reinterpret_cast<const f16x4 *>(a.emissive.ptr + size_t(y) * a.emissive.pitch + size_t(x) * 8u);
-		}
+		const float depth = depth_v[p];
+		const uint32_t alb = alb_v[p], nrm = nrm_v[p], mr = mr_v[p];
 		// depth test NOT_EQUAL against the quad at z = 0 (renderer.cpp:1056-1057): reverse-Z far-plane pixels keep the
 		// emissive value (both draws are depth-rejected).
 		active[p] = inside[p] && depth != 0.0f;
 		any_active = any_active || active[p];
 
 		// ---- G-buffer decode (clustering.frag:31-35) ----
-		base[p] = f3(a.srgb_lut[alb & 255u], a.srgb_lut[(alb >> 8) & 255u], a.srgb_lut[(alb >> 16) & 255u]);
+		base[p] = f3(s_srgb[alb & 255u], s_srgb[(alb >> 8) & 255u], s_srgb[(alb >> 16) & 255u]);
 		const float3_ N = f3(float(nrm & 1023u) * (2.0f / 1023.0f) - 1.0f, float((nrm >> 10) & 1023u) * (2.0f / 1023.0f) - 1.0f,
 		                     float((nrm >> 20) & 1023u) * (2.0f / 1023.0f) - 1.0f);
 		const float metallic = float(mr & 255u) * (1.0f / 255.0f);
 		const float mat_roughness = float(mr >> 8) * (1.0f / 255.0f);
 
-		// ---- position reconstruction (clustering.vert:10-13, clustering.frag:37-39): clip = invVP * (ndc.xy, depth, 1),
-		// pos = clip.xyz / clip.w.  Evaluated with fused multiply-adds and a Newton-refined reciprocal; a pixel that lands
-		// in the neighbouring Z slice because of the last-bit difference sees the same lights up to ones at the very edge
-		// of their radius (falloff -> 0), cf. the conservative slice ranges of clusterer.cpp:1265-1275. ----
-		const float ndc_x = fmaf(2.0f * (float(x) + 0.5f), a.inv_resolution[0], -1.0f);
-		const float ndc_y = fmaf(2.0f * (float(y) + 0.5f), a.inv_resolution[1], -1.0f);
 		float clip[4];
 #pragma unroll
 		for (int i = 0; i < 4; i++)
-			clip[i] = fmaf(depth, a.inv_vp[8 + i], fmaf(a.inv_vp[4 + i], ndc_y, fmaf(a.inv_vp[i], ndc_x, a.inv_vp[12 + i])));
+			clip[i] = fmaf(depth, a.inv_vp[8 + i], p == 0 ? clip_base[i] : clip_base[i] + float(p) * a.clip_dx[i]);
 		const float clip_w = active[p] ? clip[3] : 1.0f;
 		float inv_w = rcp(clip_w);
 		inv_w = inv_w * fmaf(-clip_w, inv_w, 2.0f);
@@ -298,7 +347,6 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		const float NoV = med3(s[p].NdV, 0.001f, 1.0f);
 		s[p].F0 = f3(fmaf(base[p].x - 0.04f, metallic, 0.04f), fmaf(base[p].y - 0.04f, metallic, 0.04f),
 		             fmaf(base[p].z - 0.04f, metallic, 0.04f));
-		s[p].omF0 = f3(1.0f - s[p].F0.x, 1.0f - s[p].F0.y, 1.0f - s[p].F0.z);
 		const float roughness = fmaf(mat_roughness, 0.75f, 0.25f);
 		const float m = roughness * roughness;
 		const float m2 = m * m;
@@ -308,7 +356,9 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		s[p].k = r1 * r1 * (1.0f / 8.0f);
 		s[p].omk = 1.0f - s[p].k;
 		s[p].Gv = fmaf(NoV, s[p].omk, s[p].k);
-		s[p].diffuse = base[p] * ((1.0f - metallic) * (1.0f / PI_SIC));
+		const float kd = (1.0f - metallic) * (1.0f / PI_SIC);
+		s[p].D1 = f3(fmaf(-s[p].F0.x, base[p].x, base[p].x) * kd, fmaf(-s[p].F0.y, base[p].y, base[p].y) * kd,
+		             fmaf(-s[p].F0.z, base[p].z, base[p].z) * kd);
 
 		accum[p] = f3(float(dst[p].x), float(dst[p].y), float(dst[p].z));
 
@@ -317,9 +367,8 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		{
 			const float3_ L = f3(a.dir_direction[0], a.dir_direction[1], a.dir_direction[2]);
 			const float3_ Hv = V + L;
-			float NoL;
-			const float3_ b = brdf(s[p], dot(N, L), fmaxf(dot(Hv, Hv), 1e-30f), NoL);
-			float3_ lit = f3(a.dir_color[0] * NoL * b.x, a.dir_color[1] * NoL * b.y, a.dir_color[2] * NoL * b.z);
+			float3_ lit = f3(0.0f, 0.0f, 0.0f);
+			brdf_accumulate(s[p], dot(N, L), fmaxf(dot(Hv, Hv), 1e-30f), 1.0f, f3(a.dir_color[0], a.dir_color[1], a.dir_color[2]), lit);
 			if (a.flags & GR_LIGHTING_AMBIENT_FALLBACK_BIT)
 			{
 				if (AO) // base_ambient * base_color * 0.05 (directional.frag:52-64)
@@ -398,7 +447,7 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 				const uint32_t light_index = uint32_t(chunk) * 64u + uint32_t(lane);
 				const int my_word = chunk * 2 + (lane >> 5);
 				bool keep = false;
-				bool is_spot = false;
+				bool is_spot = false, is_tiny = false;
 				f32x4 r0 = {0, 0, 0, 0}, r1q = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
 				if (index_in_range(light_index, win_lo, win_hi))
 				{
@@ -418,6 +467,7 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 						const float reach = radius + tile_radius;
 						keep = dot(to_light, to_light) <= reach * reach;
 						is_spot = ((a.type_mask[light_index >> 5] >> (light_index & 31u)) & 1u) == 0u;
+						is_tiny = d.w > 8.99f; // radius < 1/9 (with margin for the rounding of 0.1f)
 						// unpackHalf2x16(spot_scale_bias).  The lane is copied to a scalar first: clang (ROCm 7.2) evaluates
 						// __builtin_bit_cast on a vector-component lvalue (v.w) at the address of the whole vector, i.e. as
 						// lane .x (observed: spots shaded with colour.x as scale | bias).
@@ -433,6 +483,7 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 				}
 				uint64_t kept = __ballot(keep);
 				const uint64_t spots = __ballot(keep && is_spot);
+				const uint64_t tinies = __ballot(keep && is_tiny);
 				if (keep)
 				{
 					const int slot = __builtin_amdgcn_mbcnt_hi(uint32_t(kept >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(kept), 0u));
@@ -448,15 +499,21 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 				__builtin_amdgcn_wave_barrier(); // LDS is wave-private: in-order DS execution is the only ordering needed
 
 				// ---- shade: PX pixels per lane, lights broadcast from LDS ----
-				const f32x4 *slot = slots;
-				while (kept != 0ull)
-				{
-					const int src_lane = __builtin_ctzll(kept);
-					kept &= kept - 1ull;
-					const bool spot = ((spots >> src_lane) & 1ull) != 0ull;
-					shade_positional<PX>(s, slot[0], slot[1], slot, spot, result);
-					slot += LIGHT_SLOT_BYTES / 16;
-				}
+				auto walk = [&](auto clamp_dist) {
+					const f32x4 *slot = slots;
+					while (kept != 0ull)
+					{
+						const int src_lane = __builtin_ctzll(kept);
+						kept &= kept - 1ull;
+						const bool spot = ((spots >> src_lane) & 1ull) != 0ull;
+						shade_positional<PX, decltype(clamp_dist)::value>(s, slot[0], slot[1], slot, spot, result);
+						slot += LIGHT_SLOT_BYTES / 16;
+					}
+				};
+				if (tinies == 0ull)
+					walk(std::false_type{});
+				else
+					walk(std::true_type{});
 				__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
 			}
 		}
@@ -466,20 +523,31 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 			              float(_Float16(accum[p].z + result[p].z)));
 	}
 
+	if (!inside[0])
+		return;
+	f16x4 o[PX];
 #pragma unroll
 	for (int p = 0; p < PX; p++)
 	{
-		if (!inside[p])
-			continue;
-		f16x4 o = dst[p];
+		o[p] = dst[p];
 		if (active[p])
 		{
-			o.x = _Float16(accum[p].x);
-			o.y = _Float16(accum[p].y);
-			o.z = _Float16(accum[p].z);
+			o[p].x = _Float16(accum[p].x);
+			o[p].y = _Float16(accum[p].y);
+			o[p].z = _Float16(accum[p].z);
 		}
-		if (active[p] || a.emissive.ptr != a.hdr.ptr)
-			*reinterpret_cast<f16x4 *>(a.hdr.ptr + size_t(y) * a.hdr.pitch + size_t(x0 + p) * 8u) = o;
+	}
+	// In place (emissive == hdr) untouched pixels need no store; a pair with one lit pixel rewrites the other's own value.
+	if (any_active || a.emissive.ptr != a.hdr.ptr)
+	{
+		uint8_t *out = a.hdr.ptr + (uint32_t(y) * a.hdr.pitch + uint32_t(x0) * 8u);
+		if constexpr (PX == 2)
+		{
+			const uint2 lo = __builtin_bit_cast(uint2, o[0]), hi = __builtin_bit_cast(uint2, o[PX - 1]);
+			*reinterpret_cast<uint4 *>(out) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+		}
+		else
+			*reinterpret_cast<f16x4 *>(out) = o[0];
 	}
 }
 
@@ -530,6 +598,8 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	k.hdr = DevImageRW{static_cast<uint8_t *>(args->hdr.ptr), int(W), int(H), args->hdr.pitch_bytes};
 	for (int i = 0; i < 16; i++)
 		k.inv_vp[i] = args->inv_view_projection[i];
+	for (int i = 0; i < 4; i++)
+		k.clip_dx[i] = k.inv_vp[i] * (2.0f * args->clustering.inv_resolution[0]);
 	for (int i = 0; i < 3; i++)
 	{
 		k.camera_pos[i] = args->clustering.camera_pos[i];
@@ -572,11 +642,22 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	k.row_first = int(row_first);
 	k.row_end = int(row_end);
 	k.block_row0 = int(row_first / LIGHT_TILE);
-	// Pixels per lane: 2 by default (GR_LIGHTING_PX=1 selects the one-pixel form, kept for A/B measurements).
-	static const int px = []() {
+	// Pixels per lane: 2 (GR_LIGHTING_PX=1 selects the one-pixel form for A/B measurements) whenever the lane's pair of
+	// texels is one naturally aligned access in every attachment: even width, pitches that are multiples of two texels.
+	// Odd-sized targets run the one-pixel kernel.
+	static const int px_pref = []() {
 		const char *env = getenv("GR_LIGHTING_PX");
 		return env && atoi(env) == 1 ? 1 : 2;
 	}();
+	const bool pairs_aligned = (W & 1u) == 0 && (args->depth.pitch_bytes & 7u) == 0 && (args->albedo.pitch_bytes & 7u) == 0 &&
+	                           (args->normal.pitch_bytes & 7u) == 0 && (args->pbr.pitch_bytes & 3u) == 0 &&
+	                           (args->emissive.pitch_bytes & 15u) == 0 && (args->hdr.pitch_bytes & 15u) == 0 &&
+	                           (reinterpret_cast<uintptr_t>(args->emissive.ptr) & 15u) == 0 && (reinterpret_cast<uintptr_t>(args->hdr.ptr) & 15u) == 0 &&
+	                           (reinterpret_cast<uintptr_t>(args->depth.ptr) & 7u) == 0 && (reinterpret_cast<uintptr_t>(args->albedo.ptr) & 7u) == 0 &&
+	                           (reinterpret_cast<uintptr_t>(args->normal.ptr) & 7u) == 0 && (reinterpret_cast<uintptr_t>(args->pbr.ptr) & 3u) == 0;
+	const int px = pairs_aligned ? px_pref : 1;
+	// 32-bit byte offsets inside the kernel.
+	GR_CHECK_ARG(ctx, uint64_t(args->hdr.pitch_bytes) * H <= 0xffffffffull && uint64_t(args->emissive.pitch_bytes) * H <= 0xffffffffull);
 	k.blocks_x = int(gr_div_up(W, LIGHT_TILE * px * LIGHT_WAVES));
 	k.num_blocks = k.blocks_x * (int(gr_div_up(row_end, LIGHT_TILE)) - k.block_row0);
 	k.blocks_per_xcd = (k.num_blocks + 7) / 8;
@@ -586,13 +667,13 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	// a single wave in.  Padding the workgroup's LDS footprint so that only `max_wgs` workgroups fit per CU leaves the
 	// remaining slots to them.  With two pixels per lane the wave has two independent BRDF chains in flight, so four
 	// workgroups (16 waves) per CU already keep the VALU busy.
-	static const int max_wgs = [&]() {
+	static const int max_wgs_env = []() {
 		const char *env = getenv("GR_LIGHTING_WGS_PER_CU");
-		const int fallback = px == 2 ? 4 : 7;
-		const int v = env ? atoi(env) : fallback;
-		return v >= 1 && v <= 8 ? v : fallback;
+		const int v = env ? atoi(env) : 0;
+		return v >= 1 && v <= 8 ? v : 0;
 	}();
-	const size_t static_lds = sizeof(f32x4) * LIGHT_WAVES * 64 * (LIGHT_SLOT_BYTES / 16);
+	const int max_wgs = max_wgs_env ? max_wgs_env : (px == 2 ? 4 : 7);
+	const size_t static_lds = sizeof(f32x4) * LIGHT_WAVES * 64 * (LIGHT_SLOT_BYTES / 16) + 256 * sizeof(float);
 	const size_t per_wg = (160u * 1024u / unsigned(max_wgs)) & ~size_t(1023);
 	const size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "lighting"};
