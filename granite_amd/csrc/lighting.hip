@@ -145,10 +145,11 @@ template <bool IS_MAX>
 __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t v)
 {
 	auto op = [](uint32_t a, uint32_t b) { return IS_MAX ? max(a, b) : min(a, b); };
-	v = op(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0xB1, 0xf, 0xf, false)));  // quad_perm [1,0,3,2]
-	v = op(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x4E, 0xf, 0xf, false)));  // quad_perm [2,3,0,1]
-	v = op(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x141, 0xf, 0xf, false))); // row_half_mirror
-	v = op(v, uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x140, 0xf, 0xf, false))); // row_mirror
+	// mov_dpp (no `old` operand: every lane of these permutations reads a valid lane) folds into the min / max as a DPP source.
+	v = op(v, uint32_t(__builtin_amdgcn_mov_dpp(int(v), 0xB1, 0xf, 0xf, true)));  // quad_perm [1,0,3,2]
+	v = op(v, uint32_t(__builtin_amdgcn_mov_dpp(int(v), 0x4E, 0xf, 0xf, true)));  // quad_perm [2,3,0,1]
+	v = op(v, uint32_t(__builtin_amdgcn_mov_dpp(int(v), 0x141, 0xf, 0xf, true))); // row_half_mirror
+	v = op(v, uint32_t(__builtin_amdgcn_mov_dpp(int(v), 0x140, 0xf, 0xf, true))); // row_mirror
 	const uint32_t r0 = uint32_t(__builtin_amdgcn_readlane(int(v), 0)), r1 = uint32_t(__builtin_amdgcn_readlane(int(v), 16));
 	const uint32_t r2 = uint32_t(__builtin_amdgcn_readlane(int(v), 32)), r3 = uint32_t(__builtin_amdgcn_readlane(int(v), 48));
 	return op(op(r0, r1), op(r2, r3));
@@ -369,19 +370,18 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 			const float3_ Hv = V + L;
 			float3_ lit = f3(0.0f, 0.0f, 0.0f);
 			brdf_accumulate(s[p], dot(N, L), fmaxf(dot(Hv, Hv), 1e-30f), 1.0f, f3(a.dir_color[0], a.dir_color[1], a.dir_color[2]), lit);
-			if (a.flags & GR_LIGHTING_AMBIENT_FALLBACK_BIT)
-			{
-				if (AO) // base_ambient * base_color * 0.05 (directional.frag:52-64)
-					lit = lit + (base[p] * sample_linear_r8(a.ao, (float(x) + 0.5f) * a.inv_resolution[0], (float(y) + 0.5f) * a.inv_resolution[1])) * 0.05f;
-				else
-					lit = lit + base[p] * 0.05f;
-			}
+			// base_ambient * base_color * 0.05 (directional.frag:52-64); a scalar 0 when the fallback term is off
+			float ambient = (a.flags & GR_LIGHTING_AMBIENT_FALLBACK_BIT) ? 0.05f : 0.0f;
+			if (AO)
+				ambient *= sample_linear_r8(a.ao, (float(x) + 0.5f) * a.inv_resolution[0], (float(y) + 0.5f) * a.inv_resolution[1]);
+			lit = f3(fmaf(base[p].x, ambient, lit.x), fmaf(base[p].y, ambient, lit.y), fmaf(base[p].z, ambient, lit.z));
 			// blend ONE/ONE, attachment store rounds to fp16
 			accum[p] = f3(float(_Float16(accum[p].x + lit.x)), float(_Float16(accum[p].y + lit.y)), float(_Float16(accum[p].z + lit.z)));
 		}
 	}
 
 	// ---- clustered quad (clusterer_bindless.h:29-84) ----
+	f16x4 out_h[PX];
 	if ((a.flags & GR_LIGHTING_CLUSTERED_BIT) && a.cl_num_lights > 0)
 	{
 		float3_ result[PX];
@@ -436,8 +436,9 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 				const float3_ off = s[p].pos - centre;
 				off2 = fmaxf(off2, active[p] ? dot(off, off) : 0.0f);
 			}
+			// v_sqrt_f32 (1 ulp) is well inside the 1.0001 + CULL_SLACK margin
 			const float tile_radius =
-			    __builtin_sqrtf(__builtin_bit_cast(float, wave_minmax_u32<true>(__builtin_bit_cast(uint32_t, off2)))) * 1.0001f + CULL_SLACK;
+			    __builtin_amdgcn_sqrtf(__builtin_bit_cast(float, wave_minmax_u32<true>(__builtin_bit_cast(uint32_t, off2)))) * 1.0001f + CULL_SLACK;
 
 			f32x4 *const slots = s_lights[wave];
 			const int chunk_lo = int(win_lo >> 6u), chunk_hi = int(win_hi >> 6u);
@@ -517,10 +518,24 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 				__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
 			}
 		}
+		// second blend: the attachment store rounds once more, straight into the halves that are written out
 #pragma unroll
 		for (int p = 0; p < PX; p++)
-			accum[p] = f3(float(_Float16(accum[p].x + result[p].x)), float(_Float16(accum[p].y + result[p].y)),
-			              float(_Float16(accum[p].z + result[p].z)));
+		{
+			out_h[p].x = _Float16(accum[p].x + result[p].x);
+			out_h[p].y = _Float16(accum[p].y + result[p].y);
+			out_h[p].z = _Float16(accum[p].z + result[p].z);
+		}
+	}
+	else
+	{
+#pragma unroll
+		for (int p = 0; p < PX; p++)
+		{
+			out_h[p].x = _Float16(accum[p].x); // exact: accum holds fp16 values
+			out_h[p].y = _Float16(accum[p].y);
+			out_h[p].z = _Float16(accum[p].z);
+		}
 	}
 
 	if (!inside[0])
@@ -532,9 +547,9 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		o[p] = dst[p];
 		if (active[p])
 		{
-			o[p].x = _Float16(accum[p].x);
-			o[p].y = _Float16(accum[p].y);
-			o[p].z = _Float16(accum[p].z);
+			o[p].x = out_h[p].x;
+			o[p].y = out_h[p].y;
+			o[p].z = out_h[p].z;
 		}
 	}
 	// In place (emissive == hdr) untouched pixels need no store; a pair with one lit pixel rewrites the other's own value.

@@ -162,7 +162,9 @@ int gra_get_cluster_state(gra_app *app, void *lights48, void *models48, uint32_t
 /* JSON dump of the baked graph (pass order, physical resources).  Returns the length needed. */
 size_t gra_dump_graph(gra_app *app, char *buffer, size_t size);
 
-/* Per-pass GPU time accumulated since creation (enable_timestamps): fills up to max entries, returns the count. */
+/* GPU time per physical pass accumulated since creation or the last gra_reset_timestamps (enable_timestamps): tags are the
+ * reference's (render_graph.cpp:2274-2289, "a + b" for passes it runs as subpasses of one render pass), one accumulation per
+ * physical pass and frame.  Fills up to max entries, returns the count. */
 typedef struct gra_timestamp
 {
 	char tag[64];
