@@ -140,3 +140,59 @@ def test_lighting_ambient_occlusion_variant(gr, ao_size):
     bad, _ = sc.lighting_args(gr, dev, ALL | capi.LIGHTING_AMBIENT_OCCLUSION_BIT)
     with pytest.raises(capi.GraniteHipError):
         gr.check(gr.lib.gr_lighting(gr.handle, None, bad))
+
+
+def test_lights_smaller_than_the_distance_clamp(gr):
+    """Lights of radius < 1/9 sitting on surfaces: pixels closer than 0.1 to the light exercise light_dist = max(0.1, dist)
+    (point.h:36-38 / spot.h:38-40) with a non-zero smoothstep argument -- the kernel compiles that clamp only into the walk
+    used for chunks that hold such a light -- and the 1 / max(dist, 0.1)^2 ceiling.  Mixed with ordinary lights so that both
+    walks run in one launch."""
+    w, h = 480, 270
+    sc = Scene(w, h, 200)
+    cam, depth = sc.cam, sc.gbuf["depth"]
+    rng = np.random.default_rng(5)
+    ys, xs = rng.integers(8, h - 8, 120), rng.integers(8, w - 8, 120)
+    keep = depth[ys, xs] != 0.0
+    ys, xs = ys[keep], xs[keep]
+    ndc = np.stack([2.0 * (xs + 0.5) / w - 1.0, 2.0 * (ys + 0.5) / h - 1.0, depth[ys, xs].astype(np.float64), np.ones(len(xs))])
+    clip = cam.invVP @ ndc
+    pos = (clip[:3] / clip[3]).T
+    tiny = np.zeros(len(xs), synth.LIGHT_DESC_DTYPE)
+    tiny["type"] = np.where(np.arange(len(xs)) % 3 == 0, 0, 1)   # every third one a spot
+    tiny["color"] = rng.uniform(20.0, 60.0, (len(xs), 3))
+    tiny["inner_cone"], tiny["outer_cone"] = np.cos(np.radians(20.0)), np.cos(np.radians(40.0))
+    tiny["cutoff_range"] = rng.uniform(0.04, 0.105, len(xs))
+    tr = np.zeros((len(xs), 3, 4))
+    tr[:, :, :3] = np.eye(3)
+    toward_camera = cam.position[None, :] - pos
+    toward_camera /= np.linalg.norm(toward_camera, axis=1, keepdims=True)
+    tr[:, :, 3] = pos + toward_camera * rng.uniform(0.0, 0.05, (len(xs), 1))
+    # spots look along -Z of the node: point them at the surface (away from the camera)
+    z = toward_camera
+    x = np.cross(np.array([0.0, 1.0, 0.0]), z)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    tr[:, :, 0], tr[:, :, 1], tr[:, :, 2] = x, np.cross(z, x), z
+    tiny["transform"] = tr.astype(np.float32)
+    sc.descs = np.concatenate([sc.descs, tiny])
+    sc.n, sc.lights, sc.model, sc.type_mask, sc.order = orc.pack_lights(sc.descs, sc.rp[99:102])
+    sc.prm = orc.cluster_params(sc.rp, sc.res[0], sc.res[1], sc.res[2], sc.n)
+    inv_radius = sc.lights["inv_radius"][:sc.n]
+    assert (inv_radius > 9.0).sum() >= 60, "the scene must hold lights with radius < 1/9"
+
+    ref_c = orc.cluster_build(sc.rp, sc.prm, sc.lights, sc.model, sc.type_mask, sc.n, sc.res[2])
+    dev = sc.build_clusters_gpu(gr)
+    base = orc.lighting(sc.gbuf, sc.rp, sc.prm, sc.lights, sc.type_mask, np.zeros_like(ref_c["bitmask"]), ref_c["range"],
+                        synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
+    ref = orc.lighting(sc.gbuf, sc.rp, sc.prm, sc.lights, sc.type_mask, ref_c["bitmask"], ref_c["range"],
+                       synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
+    args, imgs = sc.lighting_args(gr, dev, ALL)
+    gr.check(gr.lib.gr_lighting(gr.handle, None, args))
+    gr.sync()
+    got = imgs["hdr"].download()
+    assert_rgba16f_close(got, ref, ulps=3.0, abs_tol=1e-4, what="tiny lights")
+    # the tiny lights do reach pixels: around their centres the frame differs from the frame without positional lights
+    lit = (ref != base).any(axis=2)
+    near = np.zeros((h, w), bool)
+    for yy, xx in zip(ys, xs):
+        near[yy - 2:yy + 3, xx - 2:xx + 3] = True
+    assert (lit & near).sum() > 200
