@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
     "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
     "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan",
-    "gra_comm_create_unique_id", "gra_comm_init",
+    "gra_comm_create_unique_id", "gra_comm_init", "gra_reset_timestamps", "gra_set_directional_light", "gra_generate_mipmaps",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -99,6 +99,7 @@ def load_library() -> C.CDLL:
         "gra_upload_gbuffer_gtx": (C.c_int, [vp] + [C.c_char_p] * 6),
         "gra_save_resource_gtx": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
         "gra_reset_timestamps": (C.c_int, [vp]),
+        "gra_generate_mipmaps": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
         "gra_set_directional_light": (C.c_int, [vp, vp, vp]),
         "gra_set_exchange_callback": (C.c_int, [vp, EXCHANGE_FN, vp]),
         "gra_get_strip_plan": (C.c_int, [vp, vp]),
@@ -303,6 +304,18 @@ class Application:
         arr = (Timestamp * 64)()
         n = self._check(self.lib.gra_collect_timestamps(self.handle, arr, 64))
         return {arr[i].tag.decode(): (int(arr[i].count), float(arr[i].total_ms)) for i in range(n)}
+
+    def generate_mipmaps(self, level0_bits: np.ndarray, levels: int, components: int = 4, filter_mods=None) -> np.ndarray:
+        """RGBA16F image with `levels` mip levels: level 0 = level0_bits, levels 1.. from the single-pass downsampler.
+        Returns the tightly packed chain (uint16 bits, all levels)."""
+        src = np.ascontiguousarray(level0_bits, np.uint16)
+        h, w = src.shape[:2]
+        texels = sum(max(w >> l, 1) * max(h >> l, 1) for l in range(levels))
+        chain = np.zeros(texels * 4, np.uint16)
+        fm = None if filter_mods is None else np.ascontiguousarray(filter_mods, np.float32).reshape(levels - 1, 4)
+        self._check(self.lib.gra_generate_mipmaps(self.handle, src.ctypes.data, w, h, levels, components,
+                                                  None if fm is None else fm.ctypes.data, chain.ctypes.data))
+        return chain
 
     def reset_timestamps(self):
         self._check(self.lib.gra_reset_timestamps(self.handle))

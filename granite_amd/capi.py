@@ -164,6 +164,14 @@ class HizArgs(C.Structure):
                 ("counter", C.c_void_p)]
 
 
+class SpdArgs(C.Structure):
+    _fields_ = [("input", Image), ("chain", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("mips", C.c_uint32),
+                ("components", C.c_uint32), ("reduction_mode", C.c_uint32), ("filter_mods", C.c_void_p)]
+
+
+SPD_REDUCTION_COLOR, SPD_REDUCTION_DEPTH = 0, 1
+
+
 class PushPq10(C.Structure):
     _fields_ = [("primary_conversion", C.c_float * 16), ("hdr_pre_exposure", C.c_float), ("ui_pre_exposure", C.c_float),
                 ("max_light_level", C.c_float), ("inv_max_light_level", C.c_float)]
@@ -231,6 +239,7 @@ def load_library() -> C.CDLL:
         "gr_fill_byte": (C.c_int, [vp, vp, vp, C.c_int, C.c_size_t]),
         "gr_fill_u32": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_size_t]),
         "gr_get_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, vp]),
+        "gr_spd_downsample": (C.c_int, [vp, vp, P(SpdArgs)]),
         "gr_pq10_encode": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushPq10)]),
         "gr_fsr_upscale": (C.c_int, [vp, vp, P(Image), P(Image), C.c_int]),
         "gr_fsr_sharpen": (C.c_int, [vp, vp, P(Image), P(Image), C.c_float]),
@@ -252,7 +261,7 @@ EXPORTED_SYMBOLS = [
     "gr_bloom_threshold_rows", "gr_bloom_downsample_rows", "gr_bloom_upsample_rows", "gr_tonemap_rows",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
     "gr_smaa_set_luts", "gr_fxaa", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
-    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen", "gr_fill_byte", "gr_fill_u32", "gr_pq10_encode", "gr_get_device_info",
+    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen", "gr_fill_byte", "gr_fill_u32", "gr_pq10_encode", "gr_get_device_info", "gr_spd_downsample",
 ]
 
 
@@ -466,6 +475,20 @@ class Context:
         args.counter = counter.ptr
         self.check(self.lib.gr_hiz(self.handle, stream, args))
         return chain, counter, {"chain_w": cw, "chain_h": ch, "levels": levels}
+
+    def spd_downsample(self, source: DeviceImage, width: int, height: int, mips: int, components: int = 4, depth_mode: bool = False,
+                       filter_mods=None, chain: Optional[DeviceBuffer] = None, stream=None) -> DeviceBuffer:
+        """emit_single_pass_downsample: fills an RGBA16F chain whose level 0 is width x height from `source`."""
+        if chain is None:
+            chain = DeviceBuffer(self, self.lib.gr_mip_chain_size(width, height, 8, mips))
+        args = SpdArgs()
+        args.input = source.desc
+        args.chain, args.width, args.height, args.mips, args.components = chain.ptr, width, height, mips, components
+        args.reduction_mode = SPD_REDUCTION_DEPTH if depth_mode else SPD_REDUCTION_COLOR
+        fm = None if filter_mods is None else np.ascontiguousarray(filter_mods, np.float32).reshape(mips, 4)
+        args.filter_mods = None if fm is None else fm.ctypes.data
+        self.check(self.lib.gr_spd_downsample(self.handle, stream, args))
+        return chain
 
     def read_mip_chain(self, chain: DeviceBuffer, layout: dict):
         raw = chain.download(np.float32)

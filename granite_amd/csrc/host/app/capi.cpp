@@ -1,5 +1,6 @@
 // extern "C" surface of the harness (include/granite_app.h).  Exceptions from the C++ layer stop here.
 #include "image_space_app.hpp"
+#include "../post/spd.hpp"
 #include "../gtx.hpp"
 #include "../post/hdr.hpp"
 #include <cstdio>
@@ -462,6 +463,47 @@ size_t gra_dump_graph(gra_app *app, char *buffer, size_t size)
 		buffer[n] = '\0';
 	}
 	return json.size() + 1;
+}
+
+int gra_generate_mipmaps(gra_app *app, const void *level0_rgba16f, uint32_t width, uint32_t height, uint32_t levels,
+                         uint32_t components, const float *filter_mods, void *chain_rgba16f)
+{
+	return guarded(app, [&]() {
+		if (!level0_rgba16f || !chain_rgba16f || width == 0 || height == 0 || levels < 2 || levels > Granite::MaxSPDMips + 1)
+			throw std::logic_error("gra_generate_mipmaps: bad argument");
+		auto &device = app->app->get_device();
+		device.wait_idle();
+		auto image = device.create_image(width, height, VK_FORMAT_R16G16B16A16_SFLOAT, "mipmapped", levels);
+		auto *ctx = device.get_context();
+		auto stream = device.get_stream(HIP::CommandBuffer::Type::Generic);
+		if (gr_upload(ctx, stream, image->get_device_pointer(), level0_rgba16f, size_t(width) * height * 8) < 0)
+			throw std::runtime_error(gr_last_error(ctx));
+
+		// The reference's use of the downsampler (renderer/ocean.cpp:579-601): level 0 is the source, levels 1.. the outputs.
+		const gr_image source = image->get_level_view(0);
+		std::vector<gr_image> views;
+		std::vector<const gr_image *> mips;
+		for (unsigned l = 1; l < levels; l++)
+			views.push_back(image->get_level_view(l));
+		for (auto &v : views)
+			mips.push_back(&v);
+		std::vector<Granite::vec4> mods;
+		if (filter_mods)
+			for (unsigned l = 0; l + 1 < levels; l++)
+				mods.emplace_back(filter_mods[4 * l], filter_mods[4 * l + 1], filter_mods[4 * l + 2], filter_mods[4 * l + 3]);
+
+		Granite::SPDInfo info = {};
+		info.input = &source;
+		info.output_mips = mips.data();
+		info.num_mips = unsigned(mips.size());
+		info.num_components = components;
+		info.filter_mod = filter_mods ? mods.data() : nullptr;
+		info.mode = Granite::ReductionMode::Color;
+		HIP::CommandBuffer cmd{device, stream, HIP::CommandBuffer::Type::Generic};
+		Granite::emit_single_pass_downsample(cmd, info);
+		if (gr_download(ctx, stream, chain_rgba16f, image->get_device_pointer(), image->get_size_bytes()) < 0 || gr_sync(ctx, stream) < 0)
+			throw std::runtime_error(gr_last_error(ctx));
+	});
 }
 
 int gra_reset_timestamps(gra_app *app)

@@ -48,6 +48,39 @@ struct DepthHierarchyPass : RenderPassInterface
 };
 } // namespace
 
+bool supports_single_pass_downsample(HIP::Device &, VkFormat format)
+{
+	// spd.cpp:31-54 asks for subgroup quad operations, 256-wide workgroups and format-less storage access; on this device the
+	// only question left is the storage format the kernel is written for.
+	return format == VK_FORMAT_R16G16B16A16_SFLOAT;
+}
+
+void emit_single_pass_downsample(HIP::CommandBuffer &cmd, const SPDInfo &info)
+{
+	if (!info.input || !info.output_mips || info.num_mips == 0 || info.num_mips > MaxSPDMips)
+		throw std::logic_error("emit_single_pass_downsample: bad SPDInfo.");
+	const gr_image &top = *info.output_mips[0];
+	for (unsigned i = 0; i < info.num_mips; i++)
+	{
+		const gr_image &mip = *info.output_mips[i];
+		const auto *expected = static_cast<const uint8_t *>(top.ptr) + gr_mip_chain_offset(top.width, top.height, 8, i);
+		if (mip.format != VK_FORMAT_R16G16B16A16_SFLOAT || mip.ptr != expected || mip.width != std::max(top.width >> i, 1u) ||
+		    mip.height != std::max(top.height >> i, 1u))
+			throw std::logic_error("emit_single_pass_downsample: output_mips must be consecutive RGBA16F levels of one mip chain.");
+	}
+
+	gr_spd_args args = {};
+	args.input = *info.input;
+	args.chain = top.ptr;
+	args.width = top.width;   // push.base_image_resolution, spd.cpp:85-86
+	args.height = top.height;
+	args.mips = info.num_mips;
+	args.components = info.num_components;
+	args.reduction_mode = info.mode == ReductionMode::Depth ? GR_SPD_REDUCTION_DEPTH : GR_SPD_REDUCTION_COLOR;
+	args.filter_mods = info.filter_mod ? &info.filter_mod[0].x : nullptr;
+	cmd.check(gr_spd_downsample(cmd.get_context(), cmd.get_stream(), &args), "single pass downsample");
+}
+
 void setup_depth_hierarchy_pass(RenderGraph &graph, const std::string &input, const std::string &output,
                                 const RenderContext *context, bool output_downsample)
 {

@@ -1,5 +1,5 @@
-// Depth hierarchy pass: renderer/post/spd.hpp:58-60 / spd.cpp:196-232 restated on the HIP executor.
-// (emit_single_pass_downsample, the FFX SPD colour path, is not part of this build: SURVEY.md §8f.)
+// renderer/post/spd.{hpp,cpp} restated on the HIP executor: the single-pass downsampler (emit_single_pass_downsample, FFX SPD)
+// and the depth hierarchy pass built next to it.
 #pragma once
 #include <string>
 #include "../render_context.hpp"
@@ -7,6 +7,32 @@
 
 namespace Granite
 {
+// spd.hpp:35-58.  A Vulkan::ImageView of one mip level is a gr_image here (HIP::Image::get_level_view).
+bool supports_single_pass_downsample(HIP::Device &device, VkFormat format);
+
+enum ReductionMode : int
+{
+	Color = 0,
+	Depth
+};
+
+struct SPDInfo
+{
+	const gr_image *input;
+	const gr_image *const *output_mips; // num_mips consecutive levels of one mip chain
+	unsigned num_mips;
+	const HIP::Buffer *counter_buffer;  // the shader's atomic ticket; accepted for call-site parity, not touched
+	VkDeviceSize counter_buffer_offset;
+	unsigned num_components;
+	const vec4 *filter_mod;
+	ReductionMode mode;
+};
+
+static constexpr unsigned MaxSPDMips = 12; // the shader binds uImages[12] (spd.comp:38); spd.hpp says 13
+// spd.cpp:56-102: one gr_spd_downsample call where the reference binds the source, the counter and the storage views and
+// dispatches spd.comp.  Throws std::logic_error when output_mips are not consecutive levels of one tightly packed chain.
+void emit_single_pass_downsample(HIP::CommandBuffer &cmd, const SPDInfo &info);
+
 // Adds compute pass `output`: reads texture `input` (the depth attachment), writes the R32_SFLOAT storage image `output`
 // -- a mip chain of max-reduced linear depth, sized to the input rounded up to multiples of 64 (halved when
 // output_downsample, which also drops the full-resolution level) with floor_log2(max(w, h)) - output_downsample levels --

@@ -172,6 +172,13 @@ typedef struct gra_timestamp
 	double total_ms;
 } gra_timestamp;
 int gra_collect_timestamps(gra_app *app, gra_timestamp *entries, int max_entries);
+/* emit_single_pass_downsample (renderer/post/spd.cpp:56-102) the way the reference uses it (renderer/ocean.cpp:579-601): an
+ * RGBA16F image of `levels` mip levels whose level 0 is the source and whose levels 1.. are written by the single-pass
+ * downsampler (`components` channels, optional per-level filter_mods = (levels - 1) x vec4).  level0: width x height texels in;
+ * chain: all levels out, tightly packed (gr_mip_chain_offset).  Runs on the application's device. */
+int gra_generate_mipmaps(gra_app *app, const void *level0_rgba16f, uint32_t width, uint32_t height, uint32_t levels,
+                         uint32_t components, const float *filter_mods, void *chain_rgba16f);
+
 /* Device::timestamp_log_reset (application_headless.cpp:591): forget what was accumulated, e.g. the warm-up frame. */
 int gra_reset_timestamps(gra_app *app);
 /* The scene's DirectionalLightComponent (read_lights, scene_viewer_application.cpp:58-77): replaces the values of

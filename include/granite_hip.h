@@ -402,6 +402,31 @@ typedef struct gr_hiz_args
 } gr_hiz_args;
 int gr_hiz(gr_ctx *ctx, gr_stream stream, const gr_hiz_args *args);
 
+/* ---- single-pass downsampler ----------------------------------------------------------------------------------------------
+ * emit_single_pass_downsample (renderer/post/spd.cpp:56-102) + assets/shaders/post/ffx-spd/spd.comp (AMD FidelityFX SPD):
+ * fills an RGBA16F mip chain from an RGBA16F image in one call -- SPDInfo's input, output_mips[0..num_mips), num_components,
+ * filter_mod and mode.  Level 0 of the chain is width x height (the size of output_mips[0]: half the input when the input
+ * is the level above it, as in the reference's use), written from one LinearClamp tap per texel at the centre of its 2 x 2
+ * source footprint (NearestClamp of the co-located texel in depth mode); levels 1.. are 2 x 2 averages (minima of .x in
+ * depth mode) with SPD's rounding points: fp32 inside a 64 x 64 source tile down to level 5, level 6 from level 5 as
+ * stored.  Every store is multiplied by filter_mods[level] (mips x vec4, host memory, NULL = none) and cut to `components`
+ * channels (the rest written as 0).  Texels of a level that lie outside max(size >> level, 1) do not exist; the chain is
+ * laid out as gr_mip_chain_offset(width, height, 8, level) says.  The shader's atomic counter buffer has no counterpart:
+ * the last-workgroup stage is a second launch on the same stream. */
+#define GR_SPD_REDUCTION_COLOR 0u
+#define GR_SPD_REDUCTION_DEPTH 1u
+typedef struct gr_spd_args
+{
+	gr_image input;            /* R16G16B16A16_SFLOAT */
+	void *chain;               /* R16G16B16A16_SFLOAT mip chain, `mips` levels */
+	uint32_t width, height;    /* level 0 of the chain = push.base_image_resolution (spd.cpp:85-86) */
+	uint32_t mips;             /* 1..12 */
+	uint32_t components;       /* 1..4: COMPONENTS */
+	uint32_t reduction_mode;   /* GR_SPD_REDUCTION_* */
+	const float *filter_mods;  /* FILTER_MOD: mips x 4 floats in host memory, or NULL */
+} gr_spd_args;
+int gr_spd_downsample(gr_ctx *ctx, gr_stream stream, const gr_spd_args *args);
+
 /* ---- spatial upscaling after the post chain ---------------------------------------------------------------------------
  * setup_after_post_chain_upscaling (renderer/post/aa.cpp:75-174).  Both images R8G8B8A8_{UNORM,SRGB}.
  * gr_fsr_upscale: the "-scale" pass, upscale.{vert,frag} + FsrEasu{F,H} with the constants of FsrEasuCon (viewport = input

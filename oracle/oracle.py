@@ -333,6 +333,35 @@ def hiz(depth: np.ndarray, z_transform, output_downsample: bool = False):
     return levels
 
 
+# ---- single-pass downsampler (renderer/post/spd.cpp:56-102 + assets/shaders/post/ffx-spd) -------------------------------------
+def spd_split(chain: np.ndarray, w0: int, h0: int, mips: int):
+    """Views of the levels of a tightly packed RGBA16F chain (uint16 bits)."""
+    levels, o = [], 0
+    flat = chain.reshape(-1)
+    for l in range(mips):
+        w, h = max(w0 >> l, 1), max(h0 >> l, 1)
+        levels.append(flat[o:o + w * h * 4].reshape(h, w, 4))
+        o += w * h * 4
+    return levels
+
+
+def spd_chain_texels(w0: int, h0: int, mips: int) -> int:
+    return sum(max(w0 >> l, 1) * max(h0 >> l, 1) for l in range(mips))
+
+
+def spd(rgba16f_bits: np.ndarray, w0: int, h0: int, mips: int, components: int = 4, depth_mode: bool = False,
+        filter_mods=None, entry=None, fill: int = 0):
+    """emit_single_pass_downsample: levels of the output chain (level 0 = w0 x h0) as uint16 RGBA16F bits.  `fill` is what
+    texels no workgroup reaches keep.  entry: alternative implementation with orc_spd's signature (the executed shader)."""
+    src = np.ascontiguousarray(rgba16f_bits, np.uint16)
+    ih, iw = src.shape[:2]
+    chain = np.full(spd_chain_texels(w0, h0, mips) * 4, fill, np.uint16)
+    fm = None if filter_mods is None else np.ascontiguousarray(filter_mods, np.float32).reshape(mips, 4)
+    fn = entry if entry is not None else lib().orc_spd
+    fn(_p(src), iw, ih, w0, h0, mips, components, int(depth_mode), None if fm is None else _p(fm), _p(chain))
+    return spd_split(chain, w0, h0, mips)
+
+
 # ---- spatial upscaling (renderer/post/aa.cpp:75-174 + assets/shaders/post/ffx-fsr) -----------------------------------------
 def fsr_easu(rgba8: np.ndarray, ow: int, oh: int, fp16: bool = True, target_srgb: bool = False) -> np.ndarray:
     ih, iw = rgba8.shape[:2]

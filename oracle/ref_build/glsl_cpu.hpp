@@ -88,7 +88,9 @@ struct tvec2
 	tvec2() : x(0), y(0) {}
 	explicit tvec2(T s) : x(s), y(s) {}
 	tvec2(T x_, T y_) : x(x_), y(y_) {}
-	template <typename U> explicit tvec2(const tvec2<U> &o) : x(T(o.x)), y(T(o.y)) {}
+	// GLSL converts int to uint implicitly (ffx_spd.h passes ivec2 coordinates to uvec2 parameters); everything else is spelled out
+	template <typename U>
+	explicit(!(std::is_same_v<U, int> && std::is_same_v<T, unsigned>)) tvec2(const tvec2<U> &o) : x(T(o.x)), y(T(o.y)) {}
 	template <typename U, int N, int A, int B, bool K> explicit tvec2(const swz2<U, N, A, B, K> &o) : x(T(o.d[A])), y(T(o.d[B])) {}
 	tvec2(const tvec2 &o) : x(o.x), y(o.y) {}
 	tvec2 &operator=(const tvec2 &o) { x = o.x; y = o.y; return *this; }

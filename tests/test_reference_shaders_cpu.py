@@ -332,3 +332,28 @@ def test_pq10_encode_shader_bit_for_bit(ref, max_light_level):
     ref.ref_pq10_encode(ptr(hdr), ptr(ui), w, h, ptr(conversion), 500.0, 400.0, max_light_level, ptr(got))
     np.testing.assert_array_equal(got, want)
     assert len(np.unique(want & 1023)) > 50
+
+
+# ---- single-pass downsampler: post/ffx-spd/spd.comp + ffx_spd.h --------------------------------------------------------------------
+@pytest.mark.parametrize("iw,ih,w0,h0,mips,components,depth,mods", [
+    (128, 128, 64, 64, 7, 4, False, False),
+    (200, 120, 100, 60, 7, 4, False, False),     # edge workgroups, clamped taps, clamped level-5 reads
+    (256, 128, 128, 64, 7, 3, False, True),      # COMPONENTS 3 + FILTER_MOD: the reference's ocean use
+    (128, 128, 128, 128, 8, 1, True, False),     # REDUCTION_MODE depth
+    (512, 512, 256, 256, 9, 4, False, False),    # 64 workgroups, levels 6, 7, 8 in the last one
+    (64, 64, 32, 32, 3, 4, False, False),
+])
+def test_spd_shader_bit_for_bit(ref, iw, ih, w0, h0, mips, components, depth, mods):
+    ref.ref_spd.restype = C.c_int
+    src = synth.make_hdr(iw, ih, 11).copy()
+    src.view(np.float16)[..., 3] = np.random.default_rng(3).uniform(0.0, 4.0, (ih, iw)).astype(np.float16)
+    fm = None
+    if mods:
+        fm = np.ones((mips, 4), np.float32)
+        fm[mips - 1] = (0.0, 1.0, 1.0, 1.0)
+        fm[2] = (0.5, 2.0, 1.0, 1.0)
+    want = orc.spd(src, w0, h0, mips, components, depth, fm, fill=0x3c00)
+    got = orc.spd(src, w0, h0, mips, components, depth, fm, entry=ref.ref_spd, fill=0x3c00)
+    for level, (a, b) in enumerate(zip(want, got)):
+        np.testing.assert_array_equal(b, a, err_msg=f"level {level}")
+    assert len({int(v) for v in want[0][..., 0].reshape(-1)[:4096]}) > 100
