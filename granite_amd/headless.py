@@ -39,6 +39,9 @@ from . import capi, png, synth
 POST_AA = {"none": gapp.POST_AA_NONE, "fxaa": gapp.POST_AA_FXAA, "smaaLow": gapp.POST_AA_SMAA_LOW,
            "smaaMedium": gapp.POST_AA_SMAA_MEDIUM, "smaaHigh": gapp.POST_AA_SMAA_HIGH, "smaaUltra": gapp.POST_AA_SMAA_ULTRA,
            "taaLow": gapp.POST_AA_TAA_LOW, "taaMedium": gapp.POST_AA_TAA_MEDIUM, "taaHigh": gapp.POST_AA_TAA_HIGH}
+# Not parity targets: aa_sharpen_resolve.frag (fxaa2phase) and smaa_t2x_resolve.frag (smaaUltraT2X) call convert_input /
+# convert_to_output / luminance, which no header of the reference defines any more (they do not compile there either);
+# taaFSR2 is the external FidelityFX FSR2 library.
 UNSUPPORTED_AA = ("fxaa2phase", "smaaUltraT2X", "taaFSR2")
 IGNORED_KEYS = ("directionalLightShadows", "directionalLightShadowsCascaded", "directionalLightShadowsVSM", "PCFKernelWide",
                 "clusteredLightsShadows", "clusteredLightsShadowsResolution", "clusteredLightsShadowsVSM", "showUi",
