@@ -81,3 +81,23 @@ for seed in range(1, 13):
             wc, wh = orc.taa_resolve(cur, depth, mv, hist, reproj, q); gc, gh = np.zeros_like(wc), np.zeros_like(wh)
             ref.ref_taa_resolve(p(cur), p(depth), p(mv), p(hist), w, h, p(reproj), q, p(gc), p(gh)); chk("taa", gc, wc); chk("taa", gh, wh); hist = wh
 print(bad, f"{time.time()-t0:.0f}s")
+# ---- single-pass downsampler and HDR10 encode --------------------------------------------------------------------------------------
+ref.ref_spd.restype = C.c_int
+bad = {}
+for seed in range(1, 13):
+    iw, ih = 96 + 23 * seed, 64 + 17 * seed
+    src = synth.make_hdr(iw, ih, seed)
+    w0, h0 = max(iw // 2 - (seed % 3), 1), max(ih // 2 - (seed % 2), 1)
+    mips = min(12, max(w0, h0).bit_length())
+    for comp, depth, fm in ((4, False, None), (3, False, np.random.default_rng(seed).uniform(0.0, 2.0, (mips, 4)).astype(np.float32)), (1, True, None)):
+        a = orc.spd(src, w0, h0, mips, comp, depth, fm, fill=0x3c00)
+        b = orc.spd(src, w0, h0, mips, comp, depth, fm, entry=ref.ref_spd, fill=0x3c00)
+        bad["spd"] = bad.get("spd", 0) + sum(int((x != y).sum()) for x, y in zip(a, b))
+    ref.ref_pq10_encode.argtypes = [P, P, C.c_int, C.c_int, P, C.c_float, C.c_float, C.c_float, P]
+    ui = np.random.default_rng(seed).integers(0, 256, (ih, iw, 4), dtype=np.uint8)
+    conv = orc.rec709_to_display()
+    want = orc.pq10_encode(src, ui, conv, 500.0, 400.0, 250.0 * seed)
+    got = np.zeros_like(want)
+    ref.ref_pq10_encode(p(src), p(ui), iw, ih, p(conv), 500.0, 400.0, 250.0 * seed, p(got))
+    bad["pq10"] = bad.get("pq10", 0) + int((want != got).sum())
+print("spd / pq10 soak:", bad, f"{time.time()-t0:.0f}s")
