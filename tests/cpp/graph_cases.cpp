@@ -3,8 +3,11 @@
 // tests/render_graph_sandbox.cpp (depth -> first -> async compute -> final, backbuffer "back") with this repo's own code.
 #include "../../granite_amd/csrc/host/render_graph.hpp"
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
+#include <random>
 #include <string>
+#include <vector>
 
 using namespace Granite;
 
@@ -35,8 +38,101 @@ static void print_error(const char *name, const std::function<void()> &fn)
 	}
 }
 
-int main()
+// A random but valid frame graph: `count` passes, each writing one or two fresh images (colour outputs on graphics passes,
+// storage images on compute passes; a handful of size classes and formats so that aliasing candidates exist) and reading up
+// to three images written by earlier passes; a final graphics pass composes the backbuffer from a few of them.  Some passes
+// end up unreferenced and must be culled.  Printed with the declaration so that the checker knows every edge.
+static void random_graph(unsigned seed, bool alias)
 {
+	std::mt19937 rng(seed);
+	auto pick = [&](unsigned n) { return unsigned(rng() % n); };
+	RenderGraph graph;
+	graph.set_backbuffer_dimensions(backbuffer(1280, 720));
+	graph.set_alias_disjoint_images(alias);
+	const unsigned count = 4 + pick(12);
+	struct Produced { std::string name; bool color; unsigned size_class; };
+	std::vector<Produced> produced;
+	std::string decl = "[";
+	static const float scales[3] = {1.0f, 0.5f, 0.25f};
+	static const VkFormat formats[2] = {VK_FORMAT_R16G16B16A16_SFLOAT, VK_FORMAT_R8G8B8A8_UNORM};
+	for (unsigned i = 0; i < count; i++)
+	{
+		const unsigned kind = pick(4); // 0, 1: graphics, 2: compute, 3: async compute
+		const RenderGraphQueueFlagBits queue = kind < 2 ? RENDER_GRAPH_QUEUE_GRAPHICS_BIT : kind == 2 ? RENDER_GRAPH_QUEUE_COMPUTE_BIT : RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT;
+		const std::string name = "p" + std::to_string(i);
+		auto &pass = graph.add_pass(name, queue);
+		decl += std::string(i ? "," : "") + "{\"name\":\"" + name + "\",\"queue\":" + std::to_string(unsigned(queue)) + ",\"reads\":[";
+		const unsigned reads = produced.empty() ? 0 : pick(4);
+		std::vector<std::string> seen;
+		for (unsigned r = 0; r < reads; r++)
+		{
+			const auto &src = produced[pick(unsigned(produced.size()))];
+			bool dup = false;
+			for (auto &n : seen)
+				dup = dup || n == src.name;
+			if (dup)
+				continue;
+			pass.add_texture_input(src.name);
+			decl += std::string(seen.empty() ? "" : ",") + "\"" + src.name + "\"";
+			seen.push_back(src.name);
+		}
+		decl += "],\"writes\":[";
+		const unsigned writes = 1 + pick(2);
+		const unsigned size_class = pick(3); // colour outputs of one pass must agree in size
+		for (unsigned w = 0; w < writes; w++)
+		{
+			AttachmentInfo info;
+			info.size_class = SizeClass::SwapchainRelative;
+			info.size_x = info.size_y = scales[size_class];
+			info.format = formats[pick(2)];
+			const std::string out = name + "-o" + std::to_string(w);
+			if (kind < 2)
+				pass.add_color_output(out, info);
+			else
+				pass.add_storage_texture_output(out, info);
+			produced.push_back({out, kind < 2, size_class});
+			decl += std::string(w ? "," : "") + "\"" + out + "\"";
+		}
+		decl += "]}";
+	}
+	auto &final_pass = graph.add_pass("final", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+	AttachmentInfo back;
+	final_pass.add_color_output("back", back);
+	decl += ",{\"name\":\"final\",\"queue\":1,\"reads\":[";
+	const unsigned taps = 1 + pick(3);
+	std::vector<std::string> seen;
+	for (unsigned r = 0; r < taps; r++)
+	{
+		// bias towards late results so that most of the graph stays alive
+		const unsigned lo = unsigned(produced.size()) > 4 ? unsigned(produced.size()) - 4 : 0;
+		const auto &src = produced[lo + pick(unsigned(produced.size()) - lo)];
+		bool dup = false;
+		for (auto &n : seen)
+			dup = dup || n == src.name;
+		if (dup)
+			continue;
+		final_pass.add_texture_input(src.name);
+		decl += std::string(seen.empty() ? "" : ",") + "\"" + src.name + "\"";
+		seen.push_back(src.name);
+	}
+	decl += "],\"writes\":[\"back\"]}]";
+	graph.set_backbuffer_source("back");
+	graph.bake();
+	printf("{\"case\":\"random-%u-%d\",\"declared\":%s,\"graph\":%s}\n", seed, int(alias), decl.c_str(), graph.dump_json().c_str());
+}
+
+int main(int argc, char **argv)
+{
+	if (argc >= 3 && std::string(argv[1]) == "--random")
+	{
+		const unsigned n = unsigned(atoi(argv[2]));
+		for (unsigned seed = 0; seed < n; seed++)
+		{
+			random_graph(seed, true);
+			random_graph(seed, false);
+		}
+		return 0;
+	}
 	{
 		RenderGraph graph;
 		graph.set_backbuffer_dimensions(backbuffer(1920, 1080));
