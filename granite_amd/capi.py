@@ -240,6 +240,7 @@ def load_library() -> C.CDLL:
         "gr_fill_u32": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_size_t]),
         "gr_get_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, vp]),
         "gr_spd_downsample": (C.c_int, [vp, vp, P(SpdArgs)]),
+        "gr_debug_mix": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_uint32]),
         "gr_pq10_encode": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushPq10)]),
         "gr_fsr_upscale": (C.c_int, [vp, vp, P(Image), P(Image), C.c_int]),
         "gr_fsr_sharpen": (C.c_int, [vp, vp, P(Image), P(Image), C.c_float]),
@@ -261,7 +262,7 @@ EXPORTED_SYMBOLS = [
     "gr_bloom_threshold_rows", "gr_bloom_downsample_rows", "gr_bloom_upsample_rows", "gr_tonemap_rows",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
     "gr_smaa_set_luts", "gr_fxaa", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
-    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen", "gr_fill_byte", "gr_fill_u32", "gr_pq10_encode", "gr_get_device_info", "gr_spd_downsample",
+    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen", "gr_fill_byte", "gr_fill_u32", "gr_pq10_encode", "gr_get_device_info", "gr_spd_downsample", "gr_debug_mix",
 ]
 
 

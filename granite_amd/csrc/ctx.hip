@@ -3,6 +3,36 @@
 #include <cmath>
 #include <cstring>
 
+namespace
+{
+struct MixArgs
+{
+	uint32_t *out;
+	uint32_t out_dwords;
+	const uint32_t *in[4];
+	uint32_t in_dwords[4];
+	uint32_t count, salt;
+};
+
+// Executor self-test operation: every output dword is a hash of its index, a salt and one dword of each input, so a pass that
+// ran before its producers, on a recycled allocation that is still in use, or on the wrong copy of a hand-over ring leaves a
+// different image behind (tests/cpp/graph_cases.cpp --execute).
+__global__ __launch_bounds__(256) void k_debug_mix(MixArgs a)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= a.out_dwords)
+		return;
+	uint32_t h = (i * 0x9E3779B1u) ^ a.salt;
+	for (uint32_t k = 0; k < a.count; k++)
+	{
+		const uint32_t v = a.in[k][(i + k * 977u) % a.in_dwords[k]];
+		h = (h ^ v) * 0x85EBCA6Bu;
+		h ^= h >> 13;
+	}
+	a.out[i] = h;
+}
+} // namespace
+
 extern "C" {
 
 int gr_abi_version(void)
@@ -236,6 +266,28 @@ int gr_fill_u32(gr_ctx *ctx, gr_stream stream, void *dst, uint32_t value, size_t
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, dst && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0);
 	GR_CHECK_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dst), int(value), count, gr_to_stream(stream)));
+	return GR_OK;
+}
+
+int gr_debug_mix(gr_ctx *ctx, gr_stream stream, void *out, size_t out_dwords, const void *const *inputs, const size_t *input_dwords,
+                 uint32_t input_count, uint32_t salt)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, out && out_dwords > 0 && out_dwords <= 0xffffffffull && input_count <= 4 && (input_count == 0 || (inputs && input_dwords)));
+	MixArgs a{};
+	a.out = static_cast<uint32_t *>(out);
+	a.out_dwords = uint32_t(out_dwords);
+	a.count = input_count;
+	a.salt = salt;
+	for (uint32_t k = 0; k < input_count; k++)
+	{
+		GR_CHECK_ARG(ctx, inputs[k] && input_dwords[k] > 0 && input_dwords[k] <= 0xffffffffull);
+		a.in[k] = static_cast<const uint32_t *>(inputs[k]);
+		a.in_dwords[k] = uint32_t(input_dwords[k]);
+	}
+	hipLaunchKernelGGL(k_debug_mix, dim3(unsigned((out_dwords + 255) / 256)), dim3(256), 0, gr_to_stream(stream), a);
+	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
 

@@ -455,6 +455,11 @@ typedef struct gr_push_pq10
 int gr_pq10_encode(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *ui, const gr_image *out, const gr_push_pq10 *push);
 /* Fill with a 32-bit pattern (count dwords): attachment clears to a colour. */
 int gr_fill_u32(gr_ctx *ctx, gr_stream stream, void *dst, uint32_t value, size_t count);
+/* Executor self-test operation (no counterpart in the reference): out[i] = hash(i, salt, one dword of each of up to four
+ * inputs).  Used by tests/cpp/graph_cases.cpp --execute to run random frame graphs on the three-stream executor and compare the
+ * swapchain image with a serial run. */
+int gr_debug_mix(gr_ctx *ctx, gr_stream stream, void *out, size_t out_dwords, const void *const *inputs, const size_t *input_dwords,
+                 uint32_t input_count, uint32_t salt);
 /* VkPhysicalDeviceProperties::deviceName / driverVersion as the headless runner reports them in its --stat file
  * (application_headless.cpp:634-635): HIP device name and hipDriverGetVersion. */
 int gr_get_device_info(gr_ctx *ctx, char *name, size_t name_capacity, uint32_t *driver_version);

@@ -42,11 +42,40 @@ static void print_error(const char *name, const std::function<void()> &fn)
 // storage images on compute passes; a handful of size classes and formats so that aliasing candidates exist) and reading up
 // to three images written by earlier passes; a final graphics pass composes the backbuffer from a few of them.  Some passes
 // end up unreferenced and must be culled.  Printed with the declaration so that the checker knows every edge.
-static void random_graph(unsigned seed, bool alias)
+struct Execution
+{
+	RenderGraph *graph = nullptr;
+	const unsigned *frame = nullptr;
+	bool force_graphics = false; // every pass on the graphics queue: the serial reference run
+};
+
+static void mix_pass(RenderGraph &graph, HIP::CommandBuffer &cmd, const std::vector<RenderTextureResource *> &outs,
+                     const std::vector<RenderTextureResource *> &ins, unsigned salt)
+{
+	const void *in_ptr[4] = {};
+	size_t in_dwords[4] = {};
+	unsigned n = 0;
+	for (auto *r : ins)
+	{
+		if (n == 4)
+			break;
+		auto &view = graph.get_physical_texture_resource(*r);
+		in_ptr[n] = view.get_device_pointer();
+		in_dwords[n++] = view.get_size_bytes() / 4;
+	}
+	unsigned k = 0;
+	for (auto *r : outs)
+	{
+		auto &view = graph.get_physical_texture_resource(*r);
+		cmd.check(gr_debug_mix(cmd.get_context(), cmd.get_stream(), view.get_device_pointer(), view.get_size_bytes() / 4, in_ptr, in_dwords, n,
+		                       salt * 31u + k++), "debug mix");
+	}
+}
+
+static std::string declare_random(RenderGraph &graph, unsigned seed, bool alias, const Execution *exec)
 {
 	std::mt19937 rng(seed);
 	auto pick = [&](unsigned n) { return unsigned(rng() % n); };
-	RenderGraph graph;
 	graph.set_backbuffer_dimensions(backbuffer(1280, 720));
 	graph.set_alias_disjoint_images(alias);
 	const unsigned count = 4 + pick(12);
@@ -58,7 +87,9 @@ static void random_graph(unsigned seed, bool alias)
 	for (unsigned i = 0; i < count; i++)
 	{
 		const unsigned kind = pick(4); // 0, 1: graphics, 2: compute, 3: async compute
-		const RenderGraphQueueFlagBits queue = kind < 2 ? RENDER_GRAPH_QUEUE_GRAPHICS_BIT : kind == 2 ? RENDER_GRAPH_QUEUE_COMPUTE_BIT : RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT;
+		const RenderGraphQueueFlagBits declared_queue = kind < 2 ? RENDER_GRAPH_QUEUE_GRAPHICS_BIT : kind == 2 ? RENDER_GRAPH_QUEUE_COMPUTE_BIT : RENDER_GRAPH_QUEUE_ASYNC_COMPUTE_BIT;
+		const RenderGraphQueueFlagBits queue = exec && exec->force_graphics ? RENDER_GRAPH_QUEUE_GRAPHICS_BIT : declared_queue;
+		std::vector<RenderTextureResource *> ins, outs;
 		const std::string name = "p" + std::to_string(i);
 		auto &pass = graph.add_pass(name, queue);
 		decl += std::string(i ? "," : "") + "{\"name\":\"" + name + "\",\"queue\":" + std::to_string(unsigned(queue)) + ",\"reads\":[";
@@ -72,7 +103,7 @@ static void random_graph(unsigned seed, bool alias)
 				dup = dup || n == src.name;
 			if (dup)
 				continue;
-			pass.add_texture_input(src.name);
+			ins.push_back(&pass.add_texture_input(src.name));
 			decl += std::string(seen.empty() ? "" : ",") + "\"" + src.name + "\"";
 			seen.push_back(src.name);
 		}
@@ -87,17 +118,20 @@ static void random_graph(unsigned seed, bool alias)
 			info.format = formats[pick(2)];
 			const std::string out = name + "-o" + std::to_string(w);
 			if (kind < 2)
-				pass.add_color_output(out, info);
+				outs.push_back(&pass.add_color_output(out, info));
 			else
-				pass.add_storage_texture_output(out, info);
+				outs.push_back(&pass.add_storage_texture_output(out, info));
 			produced.push_back({out, kind < 2, size_class});
 			decl += std::string(w ? "," : "") + "\"" + out + "\"";
 		}
 		decl += "]}";
+		if (exec)
+			pass.set_build_render_pass([exec, outs, ins, i](HIP::CommandBuffer &cmd) { mix_pass(*exec->graph, cmd, outs, ins, *exec->frame * 1000u + i); });
 	}
 	auto &final_pass = graph.add_pass("final", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
 	AttachmentInfo back;
-	final_pass.add_color_output("back", back);
+	std::vector<RenderTextureResource *> final_ins, final_outs;
+	final_outs.push_back(&final_pass.add_color_output("back", back));
 	decl += ",{\"name\":\"final\",\"queue\":1,\"reads\":[";
 	const unsigned taps = 1 + pick(3);
 	std::vector<std::string> seen;
@@ -111,14 +145,63 @@ static void random_graph(unsigned seed, bool alias)
 			dup = dup || n == src.name;
 		if (dup)
 			continue;
-		final_pass.add_texture_input(src.name);
+		final_ins.push_back(&final_pass.add_texture_input(src.name));
 		decl += std::string(seen.empty() ? "" : ",") + "\"" + src.name + "\"";
 		seen.push_back(src.name);
 	}
 	decl += "],\"writes\":[\"back\"]}]";
+	if (exec)
+		final_pass.set_build_render_pass([exec, final_outs, final_ins](HIP::CommandBuffer &cmd) { mix_pass(*exec->graph, cmd, final_outs, final_ins, *exec->frame * 1000u + 999u); });
 	graph.set_backbuffer_source("back");
+	return decl;
+}
+
+static void random_graph(unsigned seed, bool alias)
+{
+	RenderGraph graph;
+	const std::string decl = declare_random(graph, seed, alias, nullptr);
 	graph.bake();
 	printf("{\"case\":\"random-%u-%d\",\"declared\":%s,\"graph\":%s}\n", seed, int(alias), decl.c_str(), graph.dump_json().c_str());
+}
+
+// Runs the random graph of `seed` for four frames without any host synchronisation in between and returns one hash per frame
+// of the swapchain image.  serial = every pass on the graphics queue, nothing hoisted, nothing aliased: one in-order stream.
+static std::vector<uint64_t> execute_random(HIP::Device &device, unsigned seed, bool serial)
+{
+	RenderGraph graph;
+	unsigned frame = 0;
+	Execution exec;
+	exec.graph = &graph;
+	exec.frame = &frame;
+	exec.force_graphics = serial;
+	graph.set_device(&device);
+	declare_random(graph, seed, !serial, &exec);
+	if (serial)
+		graph.set_hoist_independent_compute(false);
+	graph.bake();
+	std::vector<HIP::ImageHandle> swapchain;
+	for (unsigned i = 0; i < 4; i++)
+		swapchain.push_back(device.create_image(1280, 720, VK_FORMAT_R8G8B8A8_SRGB, "swapchain-" + std::to_string(i)));
+	TaskComposer composer;
+	for (frame = 0; frame < 4; frame++)
+	{
+		graph.setup_attachments(device, swapchain[frame].get());
+		graph.enqueue_render_passes(device, composer);
+	}
+	device.wait_idle();
+	std::vector<uint64_t> hashes;
+	std::vector<uint32_t> host(1280 * 720);
+	for (unsigned i = 0; i < 4; i++)
+	{
+		if (gr_download(device.get_context(), nullptr, host.data(), swapchain[i]->get_device_pointer(), host.size() * 4) < 0 ||
+		    gr_sync(device.get_context(), nullptr) < 0)
+			throw std::runtime_error(gr_last_error(device.get_context()));
+		uint64_t h = 1469598103934665603ull;
+		for (uint32_t v : host)
+			h = (h ^ v) * 1099511628211ull;
+		hashes.push_back(h);
+	}
+	return hashes;
 }
 
 int main(int argc, char **argv)
@@ -130,6 +213,23 @@ int main(int argc, char **argv)
 		{
 			random_graph(seed, true);
 			random_graph(seed, false);
+		}
+		return 0;
+	}
+	if (argc >= 3 && std::string(argv[1]) == "--execute")
+	{
+		HIP::Device device(0);
+		const unsigned n = unsigned(atoi(argv[2]));
+		for (unsigned seed = 0; seed < n; seed++)
+		{
+			const auto pipelined = execute_random(device, seed, false), serial = execute_random(device, seed, true);
+			printf("{\"case\":\"execute-%u\",\"pipelined\":[", seed);
+			for (size_t i = 0; i < pipelined.size(); i++)
+				printf("%s\"%016llx\"", i ? "," : "", (unsigned long long)pipelined[i]);
+			printf("],\"serial\":[");
+			for (size_t i = 0; i < serial.size(); i++)
+				printf("%s\"%016llx\"", i ? "," : "", (unsigned long long)serial[i]);
+			printf("]}\n");
 		}
 		return 0;
 	}
