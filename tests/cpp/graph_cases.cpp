@@ -50,11 +50,20 @@ struct Execution
 };
 
 static void mix_pass(RenderGraph &graph, HIP::CommandBuffer &cmd, const std::vector<RenderTextureResource *> &outs,
-                     const std::vector<RenderTextureResource *> &ins, unsigned salt)
+                     const std::vector<RenderTextureResource *> &ins, unsigned salt, RenderTextureResource *feedback = nullptr)
 {
 	const void *in_ptr[4] = {};
 	size_t in_dwords[4] = {};
 	unsigned n = 0;
+	if (feedback)
+	{
+		// null on the first frame (render_graph.cpp get_physical_history_texture_resource): the pass then has one input less
+		if (auto *history = graph.get_physical_history_texture_resource(*feedback))
+		{
+			in_ptr[n] = history->get_device_pointer();
+			in_dwords[n++] = history->get_size_bytes() / 4;
+		}
+	}
 	for (auto *r : ins)
 	{
 		if (n == 4)
@@ -124,9 +133,13 @@ static std::string declare_random(RenderGraph &graph, unsigned seed, bool alias,
 			produced.push_back({out, kind < 2, size_class});
 			decl += std::string(w ? "," : "") + "\"" + out + "\"";
 		}
-		decl += "]}";
+		// Feedback like the bloom chain's: every third pass also reads last frame's version of its own first output.
+		RenderTextureResource *feedback = pick(3) == 0 ? &pass.add_history_input(name + "-o0") : nullptr;
+		decl += std::string("],\"feedback\":") + (feedback ? "true" : "false") + "}";
 		if (exec)
-			pass.set_build_render_pass([exec, outs, ins, i](HIP::CommandBuffer &cmd) { mix_pass(*exec->graph, cmd, outs, ins, *exec->frame * 1000u + i); });
+			pass.set_build_render_pass([exec, outs, ins, i, feedback](HIP::CommandBuffer &cmd) {
+				mix_pass(*exec->graph, cmd, outs, ins, *exec->frame * 1000u + i, feedback);
+			});
 	}
 	auto &final_pass = graph.add_pass("final", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
 	AttachmentInfo back;
