@@ -85,3 +85,39 @@ def test_malformed_files_are_rejected_with_a_reason(tmp_path):
     expect(bytes(bad), "format")
     with pytest.raises(gtx.GtxError, match="cannot open"):
         gtx.read(str(tmp_path / "missing.gtx"))
+
+
+def test_gtx_reader_survives_corrupted_files(tmp_path):
+    """Header fields and length mutated at random: the reader either parses a self-consistent file or reports an error; it never
+    reads past the file (the probe / read entry points validate payload_size against the file and the layout)."""
+    r = np.random.default_rng(7)
+    img = r.integers(0, 256, (16, 24, 4), dtype=np.uint8)
+    good = str(tmp_path / "good.gtx")
+    gtx.write(good, 37, [img, img[:8, :12], img[:4, :6]])
+    blob = bytearray(open(good, "rb").read())
+    ok = bad = 0
+    for trial in range(400):
+        b = bytearray(blob)
+        for _ in range(int(r.integers(1, 4))):
+            kind = int(r.integers(0, 3)) if len(b) >= 64 else 2
+            if kind == 0:                                  # flip a byte somewhere in the 64-byte header
+                b[int(r.integers(0, 64))] = int(r.integers(0, 256))
+            elif kind == 1:                                # overwrite one of the eight u32 header fields with an extreme value
+                field = 16 + 4 * int(r.integers(0, 8))
+                b[field:field + 4] = int(r.choice([0, 1, 0xFFFFFFFF, 0x7FFFFFFF, 65536, 3])).to_bytes(4, "little")
+            else:                                          # truncate or pad the file
+                n = int(r.integers(0, len(b) + 64))
+                b = b[:n] if n <= len(b) else b + bytearray(n - len(b))
+        path = str(tmp_path / f"m{trial}.gtx")
+        with open(path, "wb") as f:
+            f.write(b)
+        try:
+            info = gtx.probe(path)
+            data = gtx.read(path)
+            assert data.payload.nbytes == info.payload_size
+            assert info.payload_size <= max(len(b) - gtx.HEADER_SIZE, 0)
+            ok += 1
+        except gtx.GtxError:
+            bad += 1
+        os.remove(path)
+    assert bad > 100 and ok + bad == 400
