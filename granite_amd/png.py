@@ -35,7 +35,15 @@ def _paeth(a, b, c):
 
 
 def read_png(path: str) -> np.ndarray:
-    """Returns (H, W, 4) uint8; RGB files get alpha 255.  All five scanline filters are handled."""
+    """Returns (H, W, 4) uint8; RGB files get alpha 255.  All five scanline filters are handled.  Anything malformed is a
+    ValueError."""
+    try:
+        return _read_png(path)
+    except (zlib.error, struct.error, IndexError) as e:
+        raise ValueError(f"{path}: corrupt PNG ({e})") from e
+
+
+def _read_png(path: str) -> np.ndarray:
     with open(path, "rb") as f:
         raw = f.read()
     if raw[:8] != SIGNATURE:
@@ -57,7 +65,10 @@ def read_png(path: str) -> np.ndarray:
     if depth != 8 or colour not in (2, 6) or interlace:
         raise ValueError(f"{path}: only 8-bit RGB / RGBA non-interlaced PNG is supported")
     c = 4 if colour == 6 else 3
-    data = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(h, 1 + w * c)
+    pixels = zlib.decompress(b"".join(idat))
+    if len(pixels) != h * (1 + w * c):
+        raise ValueError(f"{path}: {len(pixels)} bytes of image data, IHDR announces {h * (1 + w * c)}")
+    data = np.frombuffer(pixels, np.uint8).reshape(h, 1 + w * c)
     out = np.zeros((h, w * c), np.uint8)
     prev = np.zeros(w * c, np.uint8)
     for y in range(h):

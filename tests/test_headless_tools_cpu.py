@@ -201,3 +201,29 @@ def test_headless_cli_refuses_what_the_reference_refuses(tmp_path):
     cfg.write_text(json.dumps({"renderer": "forward"}))
     r = subprocess.run([exe, "synthetic", "--frames", "1", "--config", str(cfg)], capture_output=True, text=True)
     assert r.returncode == 1 and "deferred" in r.stderr
+
+
+def test_corrupt_png_is_a_load_failure_not_a_crash(tmp_path):
+    r = np.random.default_rng(9)
+    img = r.integers(0, 256, (12, 10, 4), dtype=np.uint8)
+    good = str(tmp_path / "good.png")
+    png.write_png(good, img)
+    blob = open(good, "rb").read()
+    failures = 0
+    for trial in range(200):
+        b = bytearray(blob)
+        for _ in range(int(r.integers(1, 4))):
+            if r.random() < 0.7:
+                b[int(r.integers(8, len(b)))] ^= 1 << int(r.integers(0, 8))
+            else:
+                b = b[:int(r.integers(8, len(b)))]
+        path = str(tmp_path / "m.png")
+        with open(path, "wb") as f:
+            f.write(b)
+        try:
+            out = png.read_png(path)
+            assert out.shape[2] == 4 and out.dtype == np.uint8   # CRCs are not verified: a flipped pixel bit still decodes
+        except ValueError:
+            failures += 1
+            assert image_compare.main([good, path]) == 1          # "Failed to load texture", exit code 1
+    assert failures > 50
