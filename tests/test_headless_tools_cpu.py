@@ -227,3 +227,37 @@ def test_corrupt_png_is_a_load_failure_not_a_crash(tmp_path):
             failures += 1
             assert image_compare.main([good, path]) == 1          # "Failed to load texture", exit code 1
     assert failures > 50
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/tools/sweep_scene.py"), reason="needs the Granite checkout")
+def test_the_references_sweep_script_consumes_our_stat_file(tmp_path):
+    """Granite's own tools/sweep_scene.py, executed, with a stand-in viewer binary that takes the command line the script builds
+    (sweep_scene.py:94-117) through the headless runner's argument parser and writes the --stat document with stat_document():
+    the script must get through run_test / map_result_to_json and write its results file."""
+    stub = tmp_path / "viewer-stub"
+    stub.write_text(f"""#!{sys.executable}
+import json, sys
+sys.path.insert(0, {ROOT!r})
+from granite_amd import headless
+args = headless.parse_args(sys.argv[1:])
+assert args.frames == 7 and args.width == 640 and args.height == 360 and args.timestamp and args.config.endswith(".json")
+kw = headless.viewer_config_to_kwargs(json.load(open(args.config)))
+stamps = {{"gbuffer-main + lighting-main": (7, 1.4), "tonemap": (7, 0.21)}}
+json.dump(headless.stat_document(250.0 if kw["post_aa"] == 0 else 300.0, "stub gpu", 42, stamps, args.frames), open(args.stat, "w"))
+""")
+    stub.chmod(0o755)
+    cfgs = []
+    for name, doc in (("plain", {"renderer": "deferred", "hdrBloom": True}), ("fxaa", {"postAA": "fxaa"})):
+        p = tmp_path / f"{name}.json"
+        p.write_text(json.dumps(doc))
+        cfgs.append(str(p))
+    results = tmp_path / "results.json"
+    r = subprocess.run([sys.executable, "/root/reference/tools/sweep_scene.py", "--viewer-binary", str(stub), "--scene", "synthetic",
+                        "--configs", *cfgs, "--width", "640", "--height", "360", "--frames", "7", "--iterations", "2", "--timestamp",
+                        "--results", str(results)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    runs = json.loads(results.read_text())["runs"]
+    assert [x["config"] for x in runs] == ["plain", "fxaa"] and [x["avg"] for x in runs] == [250.0, 300.0]
+    assert runs[0]["gpu"] == "stub gpu" and runs[0]["version"] == 42 and runs[0]["width"] == 640
+    assert runs[0]["performance"]["tonemap"] == {"timePerAccumulationUs": 30.0, "timePerFrameContextUs": 30.0,
+                                                   "accumulationsPerFrameContext": 1.0}
