@@ -689,7 +689,9 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	}();
 	const int max_wgs = max_wgs_env ? max_wgs_env : (px == 2 ? 4 : 7);
 	const size_t static_lds = sizeof(f32x4) * LIGHT_WAVES * 64 * (LIGHT_SLOT_BYTES / 16) + 256 * sizeof(float);
-	const size_t per_wg = (160u * 1024u / unsigned(max_wgs)) & ~size_t(1023);
+	// 8 KiB of the CU's 160 KiB stay free: back-of-frame kernels that use a little LDS (luminance, the fused pyramid tail)
+	// must be able to start beside resident lighting workgroups instead of waiting for one to retire.
+	const size_t per_wg = ((160u - 8u) * 1024u / unsigned(max_wgs)) & ~size_t(1023);
 	const size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "lighting"};
 	const bool ao = (args->flags & GR_LIGHTING_AMBIENT_OCCLUSION_BIT) != 0;

@@ -12,6 +12,18 @@ namespace
 constexpr int POST_BLOCK_X = 32;
 constexpr int POST_BLOCK_Y = 8;
 
+// Wave priority of the back-of-frame kernels.  They run beside the next frame's lighting kernel, which is VALU-issue-bound
+// and whose (older) waves otherwise win the per-SIMD issue arbitration: these kernels are latency chains with little VALU
+// work, so letting their few instructions go first shortens the critical path of the frame at next to no cost to lighting.
+#ifndef GR_POST_WAVE_PRIORITY
+#define GR_POST_WAVE_PRIORITY 0
+#endif
+__device__ __forceinline__ void post_wave_priority()
+{
+	if (GR_POST_WAVE_PRIORITY != 0)
+		__builtin_amdgcn_s_setprio(GR_POST_WAVE_PRIORITY);
+}
+
 static inline DevImage to_dev(const gr_image *img)
 {
 	return {static_cast<const uint8_t *>(img->ptr), int(img->width), int(img->height), img->pitch_bytes};
@@ -28,6 +40,7 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold(
                                                                                 gr_push_bloom_threshold push, uint32_t y_first,
                                                                                 uint32_t y_end)
 {
+	post_wave_priority();
 	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
 	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
 	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
@@ -69,6 +82,7 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_downsample
                                                                                  gr_push_bloom_downsample push, uint32_t y_first,
                                                                                  uint32_t y_end)
 {
+	post_wave_priority();
 	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
 	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
 	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
@@ -94,6 +108,7 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_upsample(D
                                                                                gr_push_bloom_upsample push, uint32_t y_first,
                                                                                uint32_t y_end)
 {
+	post_wave_priority();
 	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
 	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
 	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
@@ -127,6 +142,7 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k
                                                                                       gr_push_bloom_downsample push, uint32_t y_first,
                                                                                       uint32_t y_end)
 {
+	post_wave_priority();
 	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
 	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
 	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
@@ -183,6 +199,7 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k
                                                                                     gr_push_bloom_upsample push, uint32_t y_first,
                                                                                     uint32_t y_end)
 {
+	post_wave_priority();
 	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
 	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
 	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
@@ -218,6 +235,7 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k
 constexpr int LUM_THREADS = 1024;
 __global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_luminance_data *lum, gr_push_luminance push)
 {
+	post_wave_priority();
 	__shared__ float wave_partial[LUM_THREADS / 64];
 	const int sx = int(push.size[0]), sy = int(push.size[1]);
 	const float inv_x = 1.0f / float(sx), inv_y = 1.0f / float(sy);
@@ -270,6 +288,7 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
                                                                               const gr_luminance_data *lum,
                                                                               gr_push_tonemap push, uint32_t y_first, uint32_t y_end)
 {
+	post_wave_priority();
 	const int x0 = (blockIdx.x * TONEMAP_BLOCK_X + threadIdx.x) * TONEMAP_PX;
 	const int y = int(y_first) + blockIdx.y * TONEMAP_BLOCK_Y + threadIdx.y;
 	if (x0 >= hdr.w || uint32_t(y) >= y_end)
