@@ -275,6 +275,7 @@ void ImageSpaceApplication::add_hdr_input_pass(const std::string &tag)
 {
 	AttachmentInfo hdr;
 	hdr.format = VK_FORMAT_R16G16B16A16_SFLOAT;
+	hdr.flags |= ATTACHMENT_INFO_INTERNAL_RETAINED_BIT; // filled once (needs_fill), never aliased
 	if (scaled())
 		hdr.size_x = hdr.size_y = config.resolution_scale;
 	auto &pass = graph.add_pass(tagcat("hdr-input", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
@@ -292,6 +293,7 @@ void ImageSpaceApplication::add_mv_pass(const std::string &tag)
 {
 	AttachmentInfo mv;
 	mv.format = VK_FORMAT_R16G16_SFLOAT;
+	mv.flags |= ATTACHMENT_INFO_INTERNAL_RETAINED_BIT; // filled once (needs_fill), never aliased
 	if (scaled())
 		mv.size_x = mv.size_y = config.resolution_scale;
 	auto &pass = graph.add_pass(tagcat("mv", tag), RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
@@ -318,6 +320,12 @@ void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
 	if (scaled()) // scene_viewer_application.cpp:758-761,888-889
 		for (auto *info : {&emissive, &albedo, &normal, &pbr, &depth})
 			info->size_x = info->size_y = config.resolution_scale;
+	// Filled once per target and kept (needs_fill): the memory must stay theirs whatever streams the passes land on.
+	// Emissive under the RMW declaration is rewritten every frame and stays an ordinary attachment.
+	for (auto *info : {&albedo, &normal, &pbr, &depth})
+		info->flags |= ATTACHMENT_INFO_INTERNAL_RETAINED_BIT;
+	if (!config.rmw_emissive)
+		emissive.flags |= ATTACHMENT_INFO_INTERNAL_RETAINED_BIT;
 
 	// The G-buffer producer: Granite rasterises the scene here; the harness copies the synthetic attachments in.
 	// Attachments persist across frames, so only what a later pass clobbers (emissive under the RMW declaration) is
@@ -350,6 +358,7 @@ void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
 		auto &ssao = graph.add_pass(tagcat("ssao", tag), RENDER_GRAPH_QUEUE_COMPUTE_BIT);
 		AttachmentInfo ao;
 		ao.format = VK_FORMAT_R8_UNORM;
+		ao.flags |= ATTACHMENT_INFO_INTERNAL_RETAINED_BIT; // filled once (needs_fill), never aliased
 		ao.size_class = SizeClass::InputRelative;
 		ao.size_relative_name = tagcat("depth-transient", tag);
 		auto &ao_out = ssao.add_storage_texture_output(tagcat("ssao-output", tag), ao);
@@ -409,6 +418,7 @@ void ImageSpaceApplication::bake_render_graph()
 	// Keep feedback buffers (average luminance) alive across re-bakes (scene_viewer_application.cpp:1169,1315).
 	auto physical_buffers = graph.consume_physical_buffers();
 	graph.reset();
+	filled_targets.clear(); // keyed by device pointer: a re-baked graph may place a new image at a recycled address
 	graph.set_device(device_holder.get());
 	graph.set_alias_disjoint_images(!config.disable_image_aliasing);
 

@@ -75,6 +75,13 @@ GtxImage gtx_parse(const void *data, size_t size)
 		throw std::runtime_error("GTX: format " + std::to_string(unsigned(img.format)) + " is not one the executor handles.");
 	if (!img.width || !img.height || !img.depth || !img.layers || !img.levels || img.levels > 16)
 		throw std::runtime_error("GTX: empty or implausible dimensions.");
+	// Bound every extent before any size arithmetic: width * height * depth * layers * bpp must not wrap size_t (a header
+	// declaring 65536 x 65536 x 32768 x 32768 layers would otherwise "need" 0 bytes and pass the payload check below).
+	if (img.width > 65536u || img.height > 65536u || img.depth > 65536u || img.layers > 65536u ||
+	    uint64_t(img.depth) * img.layers > (1u << 20))
+		throw std::runtime_error("GTX: empty or implausible dimensions.");
+	if (payload_size > size - GtxImage::HeaderSize)
+		throw std::runtime_error("GTX: file is truncated.");
 	// memory_mapped_texture.cpp:318-321: the header must describe exactly the payload, and the file must hold it.
 	if (payload_size != img.required_payload_size())
 		throw std::runtime_error("GTX: payload size does not match the header's layout.");

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -161,8 +162,11 @@ Device::Device(int device_index) : index(device_index)
 	const int middle = (least + greatest) / 2;
 	int priorities[int(CommandBuffer::Type::Count)] = {greatest, middle, least}; // Generic, AsyncCompute, Front
 	if (const char *env = getenv("GRANITE_STREAM_PRIORITIES")) // experiment: three letters from {h, m, l}, e.g. "lmh"
+	{
+		fprintf(stderr, "[granite-hip] note: stream priorities overridden by GRANITE_STREAM_PRIORITIES=%s (results unchanged, timing differs)\n", env);
 		for (int i = 0; i < 3 && env[i]; i++)
 			priorities[i] = env[i] == 'h' ? greatest : env[i] == 'm' ? middle : least;
+	}
 	for (int i = 0; i < int(CommandBuffer::Type::Count); i++)
 	{
 		hipStream_t stream;
@@ -172,9 +176,12 @@ Device::Device(int device_index) : index(device_index)
 	for (auto &frame : staging)
 	{
 		throw_hip(hipHostMalloc(reinterpret_cast<void **>(&frame.base), StagingBytes, hipHostMallocDefault), "hipHostMalloc");
-		hipEvent_t e;
-		throw_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
-		frame.fence = e;
+		for (auto &fence : frame.fence)
+		{
+			hipEvent_t e;
+			throw_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+			fence = e;
+		}
 	}
 }
 
@@ -186,8 +193,9 @@ Device::~Device()
 	{
 		if (frame.base)
 			(void)hipHostFree(frame.base);
-		if (frame.fence)
-			(void)hipEventDestroy(static_cast<hipEvent_t>(frame.fence));
+		for (auto &fence : frame.fence)
+			if (fence)
+				(void)hipEventDestroy(static_cast<hipEvent_t>(fence));
 	}
 	for (auto &s : streams)
 		if (s)
@@ -224,17 +232,21 @@ void *Device::allocate_staging(size_t size)
 void Device::next_frame_context()
 {
 	// Mark the copies of the frame just recorded, then make sure the slot we are about to reuse has drained.
+	// One fence per stream: a graph built through the public API may consume staging memory on a stream nothing on the
+	// generic stream depends on in that frame, so the generic stream's progress alone does not bound the host's lead.
 	auto &done = staging[staging_index];
-	for (auto &s : streams)
-		(void)s;
-	throw_hip(hipEventRecord(static_cast<hipEvent_t>(done.fence), static_cast<hipStream_t>(streams[0])), "hipEventRecord");
+	for (int i = 0; i < int(CommandBuffer::Type::Count); i++)
+		throw_hip(hipEventRecord(static_cast<hipEvent_t>(done.fence[i]), static_cast<hipStream_t>(streams[i])), "hipEventRecord");
 	staging_index = (staging_index + 1) % StagingFrames;
 	auto &next = staging[staging_index];
-	if (hipEventQuery(static_cast<hipEvent_t>(next.fence)) != hipSuccess)
+	for (auto &fence : next.fence)
 	{
-		auto t0 = std::chrono::steady_clock::now();
-		throw_hip(hipEventSynchronize(static_cast<hipEvent_t>(next.fence)), "hipEventSynchronize");
-		blocked_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		if (hipEventQuery(static_cast<hipEvent_t>(fence)) != hipSuccess)
+		{
+			auto t0 = std::chrono::steady_clock::now();
+			throw_hip(hipEventSynchronize(static_cast<hipEvent_t>(fence)), "hipEventSynchronize");
+			blocked_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		}
 	}
 	next.offset = 0;
 }

@@ -149,7 +149,10 @@ private:
 	{
 		uint8_t *base = nullptr;
 		size_t offset = 0;
-		void *fence = nullptr; // hipEvent_t recorded when the frame's copies were enqueued
+		// hipEvent_t per executor stream, recorded when the frame was enqueued: staging memory is read by kernels on any of
+		// the streams (the cluster pass's batched upload runs on the async-compute stream), so a slot is reusable only once
+		// every stream has passed the frame that used it.
+		void *fence[int(CommandBuffer::Type::Count)] = {};
 	};
 	static constexpr size_t StagingBytes = 4u << 20;
 	static constexpr unsigned StagingFrames = 4;

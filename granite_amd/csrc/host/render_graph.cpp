@@ -1325,6 +1325,7 @@ void RenderGraph::build_aliases()
 	auto eligible = [&](unsigned i) {
 		const uint8_t s = ranges[i].streams;
 		return physical_dimensions[i].buffer_info.size == 0 && !physical_image_has_history[i] && i != swapchain_physical_index &&
+		       (physical_dimensions[i].flags & ATTACHMENT_INFO_INTERNAL_RETAINED_BIT) == 0 &&
 		       i != blit_source && !physical_buffer_double[i] && s != 0 && (s & (s - 1)) == 0;
 	};
 
@@ -1462,7 +1463,15 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 			run_slot++; // rows 1 .. (number of runs <= number of passes); row 0 belongs to the final blit
 			waited.clear();
 		}
-		static const bool no_cross_sync = getenv("GRANITE_UNSAFE_NO_CROSS_SYNC") != nullptr; // measurement only: frames are wrong
+		// Measurement hook (tests/test_gpu_graph_random.py shows that the waits matter): frames are WRONG with it, so
+		// honouring it is announced on stderr instead of corrupting output silently through an inherited environment.
+		static const bool no_cross_sync = []() {
+			const bool off = getenv("GRANITE_UNSAFE_NO_CROSS_SYNC") != nullptr;
+			if (off)
+				fprintf(stderr, "[granite-hip] WARNING: GRANITE_UNSAFE_NO_CROSS_SYNC is set: cross-stream RAW/WAW/WAR waits are "
+				                "DISABLED, rendered frames are not valid.\n");
+			return off;
+		}();
 		const bool sync = uses_async_stream && pass_needs_sync[pass_index] && !no_cross_sync;
 		current_pass = int(pass_index);
 		if (sync)

@@ -80,7 +80,10 @@ enum AttachmentInfoFlagBits
 	ATTACHMENT_INFO_SUPPORTS_PREROTATE_BIT = 1 << 2,
 	ATTACHMENT_INFO_MIPGEN_BIT = 1 << 3,
 	ATTACHMENT_INFO_INTERNAL_TRANSIENT_BIT = 1 << 16,
-	ATTACHMENT_INFO_INTERNAL_PROXY_BIT = 1 << 17
+	ATTACHMENT_INFO_INTERNAL_PROXY_BIT = 1 << 17,
+	// HIP executor extension: the producer keeps the attachment's contents from one frame to the next (a cached fill instead
+	// of a per-frame render), so its memory is never shared with another image, whatever the stream assignment.
+	ATTACHMENT_INFO_INTERNAL_RETAINED_BIT = 1 << 18
 };
 using AttachmentInfoFlags = uint32_t;
 

@@ -173,7 +173,7 @@ def test_application_with_aa_matches_oracle_pipeline(luts, post_aa, pre_aa):
         prm = orc.cluster_params(rp, *synth.CLUSTER_RESOLUTION, n)
         cb = orc.cluster_build(rp, prm, lights, model, tmask, n, synth.CLUSTER_RESOLUTION[2])
         hdr = orc.lighting(gbuf, rp, prm, lights, tmask, cb["bitmask"], cb["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
-        assert_rgba16f_close(a.read("HDR-main"), hdr, ulps=3.0, what=f"frame {frame} HDR-main")
+        assert_rgba16f_close(a.read("HDR-main"), hdr, ulps=2.0, what=f"frame {frame} HDR-main")
         if taa_q is not None:
             # feed the device's lit HDR + previous device history to the oracle: this checks the TAA pass, not carried error
             cur = a.read("HDR-main").copy()

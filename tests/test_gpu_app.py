@@ -63,7 +63,7 @@ def test_frames_match_oracle(scene, compute_post):
     ref = oracle_frames(cam, gbuf, descs, frames)
     a = make_app(cam, gbuf, descs, compute_post=compute_post)
     a.render_frames(frames)
-    assert_rgba16f_close(a.read("HDR-main"), ref["hdr"], ulps=3.0, what="HDR-main")
+    assert_rgba16f_close(a.read("HDR-main"), ref["hdr"], ulps=2.0, what="HDR-main")
     names = ({"threshold": "threshold", "downsample-3": "d3", "upsample-0": "u0"} if compute_post else
              {"threshold": "threshold", "bloom-downsample-3": "d3", "bloom-upsample-2": "u0"})
     for res, key in names.items():
@@ -204,5 +204,5 @@ def test_ambient_occlusion_input_of_the_lighting_pass(scene):
     o = oracle_frames(cam, gbuf, descs, 0)
     want = orc.lighting(gbuf, cam.render_params(), o["prm"], o["lights"], o["type_mask"], o["cluster"]["bitmask"], o["cluster"]["range"],
                         synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION, ambient_occlusion=ao)
-    assert_rgba16f_close(a.read("HDR-main"), want, ulps=3.0, abs_tol=1e-4, what="HDR with ambient occlusion")
+    assert_rgba16f_close(a.read("HDR-main"), want, ulps=2.0, abs_tol=1e-4, what="HDR with ambient occlusion")
     a.close()

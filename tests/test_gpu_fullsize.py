@@ -157,12 +157,13 @@ def test_config3_frame_matches_oracle_at_4k():
     stated fp16 tolerances, backbuffer +-1 LSB.  Exercises what only exists at this size: the XCD-banded block order,
     32-bit offsets over 66 MB targets, 8100-block grids, the all-2:1 stencil pyramid and the fused tail."""
     from test_gpu_app import oracle_frames
-    from util import assert_rgba16f_close, assert_rgba8_close, rgba16f_mismatch
+    from oracle import oracle as orc
+    from util import assert_rgba16f_close, assert_rgba8_close
     cam = synth.Camera(W, H)
     gbuf = synth.make_gbuffer(cam)
     descs = synth.make_lights(cam, LIGHTS)
     frames = 2
-    ref = oracle_frames(cam, gbuf, descs, frames)
+    ref = oracle_frames(cam, gbuf, descs, 0)  # packed lights, cluster build, lit HDR
     a = gapp.Application(W, H)
     a.set_render_parameters(cam.render_params())
     a.set_lights(descs)
@@ -171,15 +172,23 @@ def test_config3_frame_matches_oracle_at_4k():
     n32 = (ref["n"] + 31) // 32
     np.testing.assert_array_equal(a.read("cluster-bitmask").view(np.uint32)[:128 * 64 * n32], ref["cluster"]["bitmask"])
     np.testing.assert_array_equal(a.read("cluster-range").view(np.uint32).reshape(-1, 2), ref["cluster"]["range"])
-    hdr = a.read("HDR-main")
-    assert_rgba16f_close(hdr, ref["hdr"], ulps=3.0, what="4K HDR-main")
-    # ... and at the survey's own 2 ulp for all but a vanishing fraction (two blend roundings, see test_gpu_lighting)
-    frac2 = rgba16f_mismatch(hdr, ref["hdr"], 2.0)[..., :3].mean()
-    assert frac2 < 2e-4, f"{frac2:.2e} of the 4K HDR channels are beyond 2 ulp"
-    for res, key in {"threshold": "threshold", "downsample-3": "d3", "upsample-0": "u0"}.items():
-        assert_rgba16f_close(a.read(res), ref["chain"][key], ulps=4.0, abs_tol=2e-4, what=f"4K {res}")
-    np.testing.assert_allclose(a.read("average-luminance").view(np.float32)[0], ref["chain"]["lum"][0], atol=2e-5)
-    assert_rgba8_close(a.read_backbuffer(), ref["chain"]["tonemapped"], 1, what="4K backbuffer")
+    hdr = a.read("HDR-main").copy()
+    # SURVEY 8a's tolerance as written: 2 ulp fp16 + 1e-4 (measured at this size, tools/ulp_hist.py: 99.97 % of the
+    # channels bit-identical, 3e-4 one ulp apart, 2 of 24.9 M further -- both below the absolute term)
+    assert_rgba16f_close(hdr, ref["hdr"], ulps=2.0, what="4K HDR-main")
+    assert (hdr == ref["hdr"]).mean() > 0.999
+    # The post chain is checked stage by stage on the DEVICE's lit HDR target (the log-luminance channel of the threshold
+    # level is log2 of a value near 1 wherever the scene is near exposure: a one-ulp difference of a lit texel moves it by
+    # more than any relative tolerance, so carried lighting differences are kept out of this comparison).
+    state, chain = {}, None
+    for _ in range(frames):
+        chain = orc.hdr_chain(hdr, state)
+    assert_rgba16f_close(a.read("threshold"), chain["threshold"], ulps=2.0, what="4K threshold")
+    for res, key in {"downsample-3": "d3", "upsample-0": "u0"}.items():
+        # rounding differences of the levels above are carried down and up the pyramid: 4 ulp + 2e-4
+        assert_rgba16f_close(a.read(res), chain[key], ulps=4.0, abs_tol=2e-4, what=f"4K {res}")
+    np.testing.assert_allclose(a.read("average-luminance").view(np.float32)[0], chain["lum"][0], atol=2e-5)
+    assert_rgba8_close(a.read_backbuffer(), chain["tonemapped"], 1, what="4K backbuffer")
     a.close()
 
 
@@ -208,7 +217,7 @@ def test_config4_smaa_taa_sequence_matches_oracle_at_4k():
         prm = orc.cluster_params(rp, *synth.CLUSTER_RESOLUTION, n)
         cb = orc.cluster_build(rp, prm, lights, model, tmask, n, synth.CLUSTER_RESOLUTION[2])
         hdr = orc.lighting(gbuf, rp, prm, lights, tmask, cb["bitmask"], cb["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
-        assert_rgba16f_close(a.read("HDR-main"), hdr, ulps=3.0, what=f"4K frame {frame} HDR-main")
+        assert_rgba16f_close(a.read("HDR-main"), hdr, ulps=2.0, what=f"4K frame {frame} HDR-main")
         cur = a.read("HDR-main").copy()
         ref_c, ref_h = orc.taa_resolve(cur, gbuf["depth"], mv, taa_hist, a.taa_reprojection(), 2)
         assert_rgba16f_close(a.read("HDR-resolved"), ref_c, ulps=3.0, abs_tol=2e-4, what=f"4K frame {frame} HDR-resolved")

@@ -32,7 +32,7 @@ def test_executor_matches_committed_fixtures():
     np.testing.assert_array_equal(nz, ref["bitmask_nonzero_index"])
     np.testing.assert_array_equal(bitmask[nz], ref["bitmask_nonzero_value"])
     np.testing.assert_array_equal(a.read("cluster-range").view(np.uint32).reshape(-1, 2), ref["range"])
-    assert_rgba16f_close(a.read("HDR-main"), ref["hdr"], ulps=3.0, what="HDR-main")
+    assert_rgba16f_close(a.read("HDR-main"), ref["hdr"], ulps=2.0, what="HDR-main")
     assert_rgba16f_close(a.read("threshold"), ref["threshold"], ulps=4.0, abs_tol=2e-4, what="threshold")
     assert_rgba16f_close(a.read("downsample-3"), ref["d3"], ulps=4.0, abs_tol=2e-4, what="downsample-3")
     assert_rgba16f_close(a.read("upsample-0"), ref["u0"], ulps=4.0, abs_tol=2e-4, what="upsample-0")

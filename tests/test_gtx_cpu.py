@@ -83,6 +83,11 @@ def test_malformed_files_are_rejected_with_a_reason(tmp_path):
     bad = bytearray(raw)
     struct.pack_into("<I", bad, 20, 147)  # VK_FORMAT_BC7_UNORM_BLOCK: not handled by this executor
     expect(bytes(bad), "format")
+    # extents whose byte count wraps 64 bits (65536 x 65536 x 32768 x 32768 layers x 4 B = 2^66 = 0 mod 2^64) with an empty payload
+    bad = bytearray(raw[:64])
+    struct.pack_into("<IIII", bad, 24, 65536, 65536, 32768, 32768)
+    struct.pack_into("<Q", bad, 48, 0)
+    expect(bytes(bad), "implausible")
     with pytest.raises(gtx.GtxError, match="cannot open"):
         gtx.read(str(tmp_path / "missing.gtx"))
 
