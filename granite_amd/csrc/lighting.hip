@@ -18,17 +18,18 @@
 //      reference's subgroupOr of per-lane trimmed masks.  What the superset adds lies outside its radius for the pixels
 //      concerned and contributes exactly 0 (point.h:38, spot.h:45); the reference's subgroup footprint cannot matter
 //      for the same reason (oracle: orc_lighting_bruteforce_clustered).
-//   2. cull + stage: each lane tests its light's sphere (1.001 r) against the tile's bounding sphere, survivors are
-//      compacted in index order (ballot + mbcnt) into a wave-private LDS list together with per-light constants
-//      (10 / r, (1.001 r)^2, fp32 spot scale / bias) computed once per light instead of once per pixel.
-//   3. shade (one PIXEL per lane): the list is walked with broadcast ds_read_b128; every BRDF operand is a VGPR.
+//   2. cull + stage: each lane tests its light's sphere (1.001 r) against the tile's bounding sphere, and a spot's cone
+//      against the same sphere (most of a spot's sphere lies outside its cone); survivors are compacted in index order
+//      (ballot + mbcnt), point lights first, spot lights after them, into a wave-private LDS list together with per-light
+//      constants (10 / r, (1.001 r)^2, fp32 spot scale / bias) computed once per light instead of once per pixel.
+//   3. shade (one PIXEL per lane): each of the two lists is walked by its own loop with a straight-line body (no
+//      light-type branch) and broadcast ds_read_b128; every BRDF operand is a VGPR.
 //      On gfx950 fp32 fma / mul / add issue at full rate only with VGPR / literal / inline operands (measured: 1.2 ns per
 //      wave-instruction per SIMD vs 1.9 ns with an SGPR operand, 2.0 ns for min / max / med3 / cmp / cvt, 3.6 ns for
 //      rcp / rsq), which is what bounds this kernel on the 4096-light config, not HBM.
 // The BRDF is algebraically the reference's; normalisations are folded (dot products on the unnormalised light vector,
 // H.V = |V+L|/2, one rcp for G*D) to cut the per-light VALU count.
 #include <cstdlib>
-#include <type_traits>
 #include "ctx.hpp"
 #include "device_common.hpp"
 
@@ -42,6 +43,23 @@ constexpr float PI_SIC = 3.1415628f; // assets/shaders/lights/pbr.h:4-6 (sic)
 // Sphere culling margins: the shader's falloff is exactly 0 once dist * inv_radius >= 1.
 constexpr float CULL_RADIUS_SCALE = 1.001f;
 constexpr float CULL_SLACK = 1e-3f;
+
+// A/B switches of the shading loop (tools/r02_light_variants.sh builds each combination on the GPU box).
+#ifndef LV_LOOP
+#define LV_LOOP 1 // 1: point lights and spot lights staged and walked as two lists (straight-line bodies); 0: one list, run-time type
+#endif
+#ifndef LV_NEAR_TEST
+#define LV_NEAR_TEST 1 // wave-uniform "no pixel inside the radius" early-out per light
+#endif
+#ifndef LV_CONE_CULL
+#define LV_CONE_CULL 1 // staging-time cone vs tile-sphere test for spots
+#endif
+#ifndef LV_SAT_NOH
+#define LV_SAT_NOH 1 // NoH clamp as sat modifier instead of med3
+#endif
+#ifndef LV_GFOLD
+#define LV_GFOLD 1 // c0 folded into the per-pixel G constants
+#endif
 
 struct KernelArgs
 {
@@ -98,8 +116,9 @@ __device__ __forceinline__ float sample_linear_r8(const DevImage &img, float u, 
 // Per-pixel material terms hoisted out of the light loop.
 struct Surface
 {
-	float3_ pos, N, V, F0, D1;       // D1 = (1 - F0) * base * (1 - metallic) / PI: the diffuse term at f = 0
-	float NdV, m2m1, c0, k, omk, Gv; // NdV unclamped; m2m1 = m^2 - 1; c0 = m^2 / (4 PI); Gv = NoV (1-k) + k
+	float3_ pos, N, V, F0, D1; // D1 = (1 - F0) * base * (1 - metallic) / PI: the diffuse term at f = 0
+	float c0;                  // only with LV_GFOLD == 0
+	float NdV, m2m1, gA, gB;   // NdV unclamped; m2m1 = m^2 - 1; Gv Gl / c0 = NoL gA + gB with Gv = NoV (1-k) + k, c0 = m^2 / (4 PI)
 };
 
 // Shared BRDF tail of compute_point_light / compute_spot_light / compute_lighting (point.h:119-142, spot.h:122-145,
@@ -108,23 +127,28 @@ struct Surface
 // Adds colour * scale * NoL * (F G D + (1 - F) diffuse) to acc.  With f = (1 - HoV)^5 and F = mix(F0, 1, f):
 //   F GD + (1 - F) diffuse = (1 - f) (GD F0 + D1) + f GD,
 // so the per-channel work is three fmas on two scalars that already carry scale * NoL.
-//   * HoV = |V + L| / 2 needs no upper clamp (<= 1 up to rounding, absorbed by the clamp modifier on 1 - HoV); its lower
-//     clamp 0.001 only engages when L is within 0.11 degrees of -V, where it changes f by < 0.5 %.
-//   * The reference's max(Gv Gl, 0.001) never engages: roughness = 0.25 + 0.75 r >= 0.25 gives k = (roughness + 1)^2 / 8
-//     >= 0.195, and Gv, Gl = mix(k, 1, NoX) >= k, so Gv Gl >= 0.038.
+// Every clamp of the reference is kept where it can change a bit of the result:
+//   * HoV = clamp(|V + L| / 2, 0.001, 1): 1 - HoV = sat(1.001 - HoV) - 0.001 (the upper clamp is the sat modifier; HoV
+//     exceeds 1 by rounding only, which leaves |1 - HoV| < 2e-7 and f < 1e-33).
+//   * NoH = clamp(., 0.0001, 1) enters only as d = NoH^2 (m^2 - 1) + 1: with NoH <= 1e-4 the product is below 1e-8 <
+//     half an fp32 ulp of 1, so d == 1.0f exactly whether the lower bound is 1e-4 or 0 -- the clamp is the free
+//     sat modifier of the multiply.  (N is not renormalised, clustering.frag:35, so the upper bound does engage.)
+//   * NoL = clamp(., 0.001, 1) is a med3: both bounds matter.
+//   * max(Gv Gl, 0.001) never engages: roughness = 0.25 + 0.75 r >= 0.25 gives k = (roughness + 1)^2 / 8 >= 0.195, and
+//     Gv, Gl = mix(k, 1, NoX) >= k, so Gv Gl >= 0.038.
 __device__ __forceinline__ void brdf_accumulate(const Surface &s, float NdL, float hh, float scale, float3_ colour, float3_ &acc)
 {
 	const float NoL = med3(NdL, 0.001f, 1.0f);
 	const float inv_h = rsq(hh);
-	const float omh = sat(fmaf(-0.5f * hh, inv_h, 1.0f)); // 1 - HoV
-	const float NoH = med3((s.NdV + NdL) * inv_h, 0.0001f, 1.0f);
+	const float omh = sat(fmaf(-0.5f * hh, inv_h, 1.001f)) - 0.001f; // 1 - clamp(HoV, 0.001, 1)
+	const float NoH = LV_SAT_NOH ? sat((s.NdV + NdL) * inv_h) : med3((s.NdV + NdL) * inv_h, 0.0001f, 1.0f);
 
 	const float omh2 = omh * omh;
 	const float f = omh2 * omh2 * omh; // pow(1 - HoV, 5)
 
 	const float d = fmaf(NoH * NoH, s.m2m1, 1.0f);     // (NoH m2 - NoH) NoH + 1
-	const float g = s.Gv * fmaf(NoL, s.omk, s.k);      // G = 0.25 / (Gv Gl)
-	const float GD = s.c0 * rcp(d * d * g);            // G * D, D = m2 / (PI d^2)
+	const float g = fmaf(NoL, s.gA, s.gB);             // Gv Gl / c0, c0 = m^2 / (4 PI): G D = 1 / (d^2 g)
+	const float GD = LV_GFOLD ? rcp(d * d * g) : s.c0 * rcp(d * d * g);
 
 	const float w = NoL * scale;
 	const float cw = fmaf(-f, w, w); // (1 - f) w
@@ -163,10 +187,11 @@ __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t v)
 // bookkeeping are shared by 64 * PX pixels, and the PX independent BRDF chains give the wave enough instruction-level
 // parallelism to saturate the VALU at half the resident waves -- which is what leaves wave slots to the executor's other
 // streams while this kernel runs (see gr_lighting).
-template <int PX, bool CLAMP_DIST>
-__device__ __forceinline__ void shade_positional(const Surface (&s)[PX], f32x4 q0, f32x4 q1, const f32x4 *slot, bool is_spot,
-                                                 float3_ (&result)[PX])
+// KIND: 0 = point light, 1 = spot light, 2 = decided at run time by `is_spot` (one list holding both).
+template <int PX, int KIND>
+__device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f32x4 *slot, bool is_spot, float3_ (&result)[PX])
 {
+	const f32x4 q0 = slot[0], q1 = slot[1];
 	float3_ Lf[PX];
 	float d2[PX];
 	bool near_any = false;
@@ -178,7 +203,7 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], f32x4 q
 		near_any = near_any || d2[p] < q0.w;
 	}
 	// Falloff is exactly 0 once dist * inv_radius >= 1: skip the light when no pixel of the tile is inside 1.001 r.
-	if (!__any(near_any))
+	if (LV_NEAR_TEST && !__any(near_any))
 		return;
 
 	float inv_d[PX], len[PX], inv_d2[PX], atten[PX];
@@ -187,15 +212,13 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], f32x4 q
 	{
 		inv_d[p] = rsq(d2[p]);
 		len[p] = d2[p] * inv_d[p]; // length(light_dir_full)
-		// light_dist = max(0.1, length): below 0.1 the smoothstep argument 10 dist / r - 9 is <= 0 either way unless
-		// r < 1/9, so the max is only compiled into the walk used for chunks that hold such a light.
-		const float dist = CLAMP_DIST ? fmaxf(0.1f, len[p]) : len[p];
+		const float dist = fmaxf(0.1f, len[p]); // light_dist = max(MIN_POINT_DIST, length) (point.h:36, spot.h:38)
 		inv_d2[p] = inv_d[p] * inv_d[p];
 		// 1 - smoothstep(0.9, 1.0, dist * inv_radius)
 		const float t = sat(fmaf(dist, q1.w, -9.0f));
 		atten[p] = fmaf(-(t * t), fmaf(-2.0f, t, 3.0f), 1.0f);
 	}
-	if (is_spot)
+	if (KIND == 1 || (KIND == 2 && is_spot))
 	{
 		// spot.h:41-46: cone = dot(normalize(world_pos - light_pos), direction) = -dot(Lf, direction) / |Lf|
 		const f32x4 q2 = slot[2], q3 = slot[3];
@@ -208,17 +231,18 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], f32x4 q
 			atten[p] *= cone * cone;
 			lit_any = lit_any || atten[p] > 0.0f;
 		}
-		// Most of a spot's bounding sphere is outside its cone: spot_color == 0 for the whole tile -> returns 0.
+		// What is left of a spot's bounding sphere after the staging-time cone test can still miss every pixel.
 		if (!__any(lit_any))
 			return;
 	}
 #pragma unroll
 	for (int p = 0; p < PX; p++)
 	{
-		// colour = light colour * atten / dist^2; dist^2 = max(len, 0.1)^2
+		// colour = light colour * atten / light_dist^2, light_dist^2 = max(len, 0.1)^2
 		const float a2 = atten[p] * fminf(inv_d2[p], 1.0f / (0.1f * 0.1f));
 		const float NdL = dot(s[p].N, Lf[p]) * inv_d[p];
-		// |V + L|^2 with L = Lf / len: |len V + Lf|^2 / len^2
+		// |V + L|^2 with L = Lf / len: |len V + Lf|^2 / len^2.  The vector sum keeps the relative error of hh at
+		// fp32 level when L is nearly -V, where 2 + 2 dot(V, L) would cancel.
 		const float3_ Hs = f3(fmaf(s[p].V.x, len[p], Lf[p].x), fmaf(s[p].V.y, len[p], Lf[p].y), fmaf(s[p].V.z, len[p], Lf[p].z));
 		const float hh = fmaf(Hs.z, Hs.z, fmaf(Hs.y, Hs.y, fmaf(Hs.x, Hs.x, 1e-30f))) * inv_d2[p];
 		brdf_accumulate(s[p], NdL, hh, a2, f3(q1.x, q1.y, q1.z), result[p]);
@@ -352,11 +376,13 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		const float m = roughness * roughness;
 		const float m2 = m * m;
 		s[p].m2m1 = m2 - 1.0f;
-		s[p].c0 = m2 * (0.25f / PI_SIC);
 		const float r1 = roughness + 1.0f;
-		s[p].k = r1 * r1 * (1.0f / 8.0f);
-		s[p].omk = 1.0f - s[p].k;
-		s[p].Gv = fmaf(NoV, s[p].omk, s[p].k);
+		const float k = r1 * r1 * (1.0f / 8.0f);
+		const float omk = 1.0f - k;
+		s[p].c0 = m2 * (0.25f / PI_SIC);
+		const float Gv_over_c0 = LV_GFOLD ? fmaf(NoV, omk, k) * rcp(m2 * (0.25f / PI_SIC)) : fmaf(NoV, omk, k); // m2 >= 0.0039
+		s[p].gA = Gv_over_c0 * omk;
+		s[p].gB = Gv_over_c0 * k;
 		const float kd = (1.0f - metallic) * (1.0f / PI_SIC);
 		s[p].D1 = f3(fmaf(-s[p].F0.x, base[p].x, base[p].x) * kd, fmaf(-s[p].F0.y, base[p].y, base[p].y) * kd,
 		             fmaf(-s[p].F0.z, base[p].z, base[p].z) * kd);
@@ -448,7 +474,7 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 				const uint32_t light_index = uint32_t(chunk) * 64u + uint32_t(lane);
 				const int my_word = chunk * 2 + (lane >> 5);
 				bool keep = false;
-				bool is_spot = false, is_tiny = false;
+				bool is_spot = false;
 				f32x4 r0 = {0, 0, 0, 0}, r1q = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
 				if (index_in_range(light_index, win_lo, win_hi))
 				{
@@ -466,9 +492,9 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 						const float radius = CULL_RADIUS_SCALE * rcp(d.w);
 						const float3_ to_light = f3(pq.x, pq.y, pq.z) - centre;
 						const float reach = radius + tile_radius;
-						keep = dot(to_light, to_light) <= reach * reach;
+						const float dist2 = dot(to_light, to_light);
+						keep = dist2 <= reach * reach;
 						is_spot = ((a.type_mask[light_index >> 5] >> (light_index & 31u)) & 1u) == 0u;
-						is_tiny = d.w > 8.99f; // radius < 1/9 (with margin for the rounding of 0.1f)
 						// unpackHalf2x16(spot_scale_bias).  The lane is copied to a scalar first: clang (ROCm 7.2) evaluates
 						// __builtin_bit_cast on a vector-component lvalue (v.w) at the address of the whole vector, i.e. as
 						// lane .x (observed: spots shaded with colour.x as scale | bias).
@@ -476,18 +502,41 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 						const uint32_t sb_bits = __builtin_bit_cast(uint32_t, sb_lane);
 						const float spot_scale = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits & 0xffffu)));
 						const float spot_bias = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits >> 16)));
+						if (LV_CONE_CULL && is_spot && keep && spot_scale > 0.0f)
+						{
+							// Cone vs the tile's bounding sphere.  spot.h:44-45: the cone factor sat(cone_angle * scale + bias) is
+							// exactly 0 for cone_angle <= -bias / scale =: cos(theta).  With v = centre - light, a = dot(v, dir) and
+							// p = distance of the centre from the axis, e = p cos(theta) - a sin(theta) = |v| sin(phi - theta) is the
+							// distance of the centre from the cone's mantle line (never more than its distance from the cone), so
+							// e > tile_radius (+ margin) puts every pixel of the tile outside the cone by an angle far above fp32
+							// rounding: the light adds exactly 0 there.  (theta >= 90 degrees, cos(theta) <= 0, never culls.)
+							const float cos_t = -spot_bias * rcp(spot_scale);
+							if (cos_t > 0.0f && cos_t < 1.0f)
+							{
+								const float sin_t = __builtin_amdgcn_sqrtf(fmaf(-cos_t, cos_t, 1.0f));
+								const float along = -dot(to_light, f3(d.x, d.y, d.z)); // dot(centre - light, direction)
+								const float off_axis = __builtin_amdgcn_sqrtf(fmaxf(fmaf(-along, along, dist2), 0.0f));
+								const float e = fmaf(off_axis, cos_t, -along * sin_t);
+								keep = e <= tile_radius * 1.001f + CULL_SLACK;
+							}
+						}
 						r0 = f32x4{pq.x, pq.y, pq.z, radius * radius};
 						r1q = f32x4{c.x, c.y, c.z, 10.0f * d.w};
 						r2 = f32x4{d.x, d.y, d.z, 0.0f};
 						r3 = f32x4{spot_scale, spot_bias, 0.0f, 0.0f};
 					}
 				}
-				uint64_t kept = __ballot(keep);
+				const uint64_t kept = __ballot(keep);
 				const uint64_t spots = __ballot(keep && is_spot);
-				const uint64_t tinies = __ballot(keep && is_tiny);
+				// Survivors are compacted in index order (ballot + mbcnt); with LV_LOOP the point lights come first and the
+				// spot lights after them, so that each list is walked by a loop whose body has no light-type branch.
+				const uint64_t first_list = LV_LOOP ? kept & ~spots : kept;
+				const int num_first = __builtin_popcountll(first_list);
 				if (keep)
 				{
-					const int slot = __builtin_amdgcn_mbcnt_hi(uint32_t(kept >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(kept), 0u));
+					const uint64_t mine = (LV_LOOP && is_spot) ? spots : first_list;
+					const int slot = __builtin_amdgcn_mbcnt_hi(uint32_t(mine >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mine), 0u)) +
+					                 ((LV_LOOP && is_spot) ? num_first : 0);
 					f32x4 *dst_slot = slots + slot * (LIGHT_SLOT_BYTES / 16);
 					dst_slot[0] = r0;
 					dst_slot[1] = r1q;
@@ -500,21 +549,26 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 				__builtin_amdgcn_wave_barrier(); // LDS is wave-private: in-order DS execution is the only ordering needed
 
 				// ---- shade: PX pixels per lane, lights broadcast from LDS ----
-				auto walk = [&](auto clamp_dist) {
-					const f32x4 *slot = slots;
-					while (kept != 0ull)
+				const f32x4 *slot = slots;
+				if (LV_LOOP)
+				{
+					for (int i = 0; i < num_first; i++, slot += LIGHT_SLOT_BYTES / 16)
+						shade_positional<PX, 0>(s, slot, false, result);
+					const int num_spots = __builtin_popcountll(spots);
+					for (int i = 0; i < num_spots; i++, slot += LIGHT_SLOT_BYTES / 16)
+						shade_positional<PX, 1>(s, slot, true, result);
+				}
+				else
+				{
+					uint64_t todo = kept;
+					while (todo != 0ull)
 					{
-						const int src_lane = __builtin_ctzll(kept);
-						kept &= kept - 1ull;
-						const bool spot = ((spots >> src_lane) & 1ull) != 0ull;
-						shade_positional<PX, decltype(clamp_dist)::value>(s, slot[0], slot[1], slot, spot, result);
+						const int src_lane = __builtin_ctzll(todo);
+						todo &= todo - 1ull;
+						shade_positional<PX, 2>(s, slot, ((spots >> src_lane) & 1ull) != 0ull, result);
 						slot += LIGHT_SLOT_BYTES / 16;
 					}
-				};
-				if (tinies == 0ull)
-					walk(std::false_type{});
-				else
-					walk(std::true_type{});
+				}
 				__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
 			}
 		}
