@@ -395,6 +395,16 @@ class KernelContextView:
     def timing_reset(self):
         self.lib.gr_timing_reset(self.handle)
 
+    def bandwidth_probe(self, nbytes: int = 1 << 30, repeats: int = 5):
+        """Measured HBM copy / triad rates in GB/s (float4 kernels over arrays beyond the Infinity Cache)."""
+        copy, triad = C.c_double(), C.c_double()
+        if self.lib.gr_bandwidth_probe(self.handle, nbytes, repeats, C.byref(copy), C.byref(triad)) < 0:
+            raise capi.GraniteHipError(self.lib.gr_last_error(self.handle).decode())
+        return copy.value, triad.value
+
+    def timing_set_sampling(self, every_nth: int):
+        self.lib.gr_timing_set_sampling(self.handle, int(every_nth))
+
     def timing_set_filter(self, name=None):
         self.lib.gr_timing_set_filter(self.handle, None if name is None else name.encode())
 

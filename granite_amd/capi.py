@@ -210,6 +210,8 @@ def load_library() -> C.CDLL:
         "gr_fill_zero": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "gr_timing_enable": (C.c_int, [vp, C.c_int]),
         "gr_timing_set_filter": (C.c_int, [vp, C.c_char_p]),
+        "gr_timing_set_sampling": (C.c_int, [vp, C.c_uint32]),
+        "gr_bandwidth_probe": (C.c_int, [vp, C.c_size_t, C.c_int, P(C.c_double), P(C.c_double)]),
         "gr_timing_reset": (C.c_int, [vp]),
         "gr_timing_query": (C.c_int, [vp, P(TimingEntry), C.c_int]),
         "gr_bloom_threshold": (C.c_int, [vp, vp, P(Image), P(Image), vp, P(PushBloomThreshold)]),

@@ -309,6 +309,101 @@ int gr_get_device_info(gr_ctx *ctx, char *name, size_t name_capacity, uint32_t *
 	return GR_OK;
 }
 
+namespace
+{
+// Four independent 16-byte accesses per lane and iteration keep enough bytes in flight per CU to reach the HBM rate.
+__global__ __launch_bounds__(256) void k_probe_copy(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n)
+{
+	const size_t stride = size_t(gridDim.x) * blockDim.x;
+	size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	for (; i + 3 * stride < n; i += 4 * stride)
+	{
+		const float4 v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
+		b[i] = v0;
+		b[i + stride] = v1;
+		b[i + 2 * stride] = v2;
+		b[i + 3 * stride] = v3;
+	}
+	for (; i < n; i += stride)
+		b[i] = a[i];
+}
+__device__ __forceinline__ float4 triad4(float4 x, float4 y, float s)
+{
+	return make_float4(fmaf(s, y.x, x.x), fmaf(s, y.y, x.y), fmaf(s, y.z, x.z), fmaf(s, y.w, x.w));
+}
+__global__ __launch_bounds__(256) void k_probe_triad(float4 *__restrict__ a, const float4 *__restrict__ b, const float4 *__restrict__ c,
+                                                     float s, size_t n)
+{
+	const size_t stride = size_t(gridDim.x) * blockDim.x;
+	size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	for (; i + stride < n; i += 2 * stride)
+	{
+		const float4 x0 = b[i], y0 = c[i], x1 = b[i + stride], y1 = c[i + stride];
+		a[i] = triad4(x0, y0, s);
+		a[i + stride] = triad4(x1, y1, s);
+	}
+	for (; i < n; i += stride)
+		a[i] = triad4(b[i], c[i], s);
+}
+} // namespace
+
+int gr_bandwidth_probe(gr_ctx *ctx, size_t bytes, int repeats, double *copy_GBps, double *triad_GBps)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, bytes >= (size_t(1) << 20) && repeats > 0 && copy_GBps && triad_GBps);
+	const size_t n = bytes / sizeof(float4);
+	float4 *buf[3] = {};
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	int status = GR_OK;
+	auto cleanup = [&]() {
+		for (auto *b : buf)
+			if (b)
+				(void)hipFree(b);
+		if (e0)
+			(void)hipEventDestroy(e0);
+		if (e1)
+			(void)hipEventDestroy(e1);
+	};
+	for (auto &b : buf)
+		if (hipMalloc(reinterpret_cast<void **>(&b), n * sizeof(float4)) != hipSuccess || hipMemset(b, 0, n * sizeof(float4)) != hipSuccess)
+		{
+			cleanup();
+			return ctx->fail(GR_ERR_OUT_OF_MEMORY, "gr_bandwidth_probe: 3 x %zu bytes not available", bytes);
+		}
+	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+	{
+		cleanup();
+		return ctx->fail(GR_ERR_HIP, "gr_bandwidth_probe: hipEventCreate failed");
+	}
+	const dim3 grid(256 * 16), block(256); // 16 workgroups per CU, grid-stride
+	double best[2] = {1e30, 1e30};
+	for (int r = 0; r < repeats + 1 && status == GR_OK; r++) // first round warms up
+		for (int which = 0; which < 2; which++)
+		{
+			(void)hipEventRecord(e0, nullptr);
+			if (which == 0)
+				hipLaunchKernelGGL(k_probe_copy, grid, block, 0, nullptr, buf[0], buf[1], n);
+			else
+				hipLaunchKernelGGL(k_probe_triad, grid, block, 0, nullptr, buf[0], buf[1], buf[2], 0.5f, n);
+			(void)hipEventRecord(e1, nullptr);
+			float ms = 0.0f;
+			if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess)
+			{
+				status = ctx->fail(GR_ERR_HIP, "gr_bandwidth_probe: launch failed");
+				break;
+			}
+			if (r > 0 && ms < best[which])
+				best[which] = ms;
+		}
+	cleanup();
+	if (status != GR_OK)
+		return status;
+	*copy_GBps = 2.0 * double(n * sizeof(float4)) / (best[0] * 1e-3) / 1e9;
+	*triad_GBps = 3.0 * double(n * sizeof(float4)) / (best[1] * 1e-3) / 1e9;
+	return GR_OK;
+}
+
 int gr_timing_enable(gr_ctx *ctx, int enable)
 {
 	if (!ctx)
@@ -322,6 +417,15 @@ int gr_timing_set_filter(gr_ctx *ctx, const char *name)
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	ctx->timing_filter = name ? name : "";
+	return GR_OK;
+}
+
+int gr_timing_set_sampling(gr_ctx *ctx, uint32_t every_nth)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	ctx->timing_every = every_nth ? every_nth : 1;
+	ctx->timing_seen = 0;
 	return GR_OK;
 }
 

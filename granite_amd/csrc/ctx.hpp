@@ -31,6 +31,8 @@ struct gr_ctx
 
 	bool timing_enabled = false;
 	std::string timing_filter; // empty = every launcher
+	unsigned timing_every = 1;  // bracket every n-th matching launch (gr_timing_set_sampling)
+	unsigned timing_seen = 0;
 	std::vector<gr_timing_span> spans;
 	std::vector<hipEvent_t> event_pool;
 	struct Accum { uint64_t count = 0; double ms = 0.0; };
@@ -78,6 +80,8 @@ struct gr_scoped_timing
 		if (!ctx->timing_filter.empty() && ctx->timing_filter != name)
 			return;
 		std::lock_guard<std::mutex> holder{ctx->lock};
+		if (ctx->timing_every > 1 && (ctx->timing_seen++ % ctx->timing_every) != 0)
+			return;
 		span.name = name;
 		span.start = ctx->get_event();
 		span.stop = ctx->get_event();

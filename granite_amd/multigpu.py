@@ -1,8 +1,9 @@
 """Row-band tiling of one frame across ranks: the collectives behind gra_set_exchange_callback.
 
-The executor (C++) decides WHAT each rank computes (StripPlan) and WHERE bands must meet; this module supplies HOW they
-meet: one in-place all-gather per meeting point on torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in the CPU tests).  Nothing here touches pixel values.
+The executor (C++) decides WHAT each rank computes (StripPlan) and WHERE bands must meet.  On the GPU box the bands meet
+through the executor's own RCCL all-gather (csrc/host/collective.cpp, gra_comm_init); this module holds the gloo form of
+the same in-place all-gather for the multi-process CPU test and the one-GPU emulation used by the GPU parity test.
+Nothing here touches pixel values.
 """
 from __future__ import annotations
 
@@ -18,45 +19,6 @@ def all_gather_chunks_inplace(full, rank: int, chunk_elems: int, group=None):
     import torch.distributed as dist
     mine = full[rank * chunk_elems:(rank + 1) * chunk_elems]
     dist.all_gather_into_tensor(full, mine, group=group)
-
-
-class _DevicePointer:
-    """Just enough of the CUDA array interface for torch.as_tensor to wrap a raw HBM pointer without copying."""
-
-    def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3, "strides": None}
-
-
-class TorchDistExchange:
-    """gra_exchange_fn on torch.distributed.  One all-gather per call, enqueued on the executor's own HIP stream (wrapped
-    as a torch ExternalStream) so it is ordered after the band kernels and before their consumers without any host sync."""
-
-    def __init__(self, rank: int, world: int, device_index: int, group=None):
-        import torch
-        self.torch = torch
-        self.rank, self.world, self.group = rank, world, group
-        self.device = torch.device("cuda", device_index)
-        self._tensors: Dict[Tuple[int, int], object] = {}
-        self._streams: Dict[int, object] = {}
-        self.calls = 0
-        self.bytes_gathered = 0
-
-    def __call__(self, tag: str, ptr: int, chunk_bytes: int, ranks: int, stream: int):
-        torch = self.torch
-        assert ranks == self.world, f"plan built for {ranks} ranks, process group has {self.world}"
-        key = (ptr, chunk_bytes * ranks)
-        full = self._tensors.get(key)
-        if full is None:
-            full = torch.as_tensor(_DevicePointer(ptr, chunk_bytes * ranks), device=self.device)
-            self._tensors[key] = full
-        ext = self._streams.get(stream)
-        if ext is None:
-            ext = torch.cuda.ExternalStream(stream, device=self.device)
-            self._streams[stream] = ext
-        with torch.cuda.stream(ext):
-            all_gather_chunks_inplace(full, self.rank, chunk_bytes, self.group)
-        self.calls += 1
-        self.bytes_gathered += chunk_bytes * (ranks - 1)
 
 
 class LocalExchange:

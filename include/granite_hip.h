@@ -93,6 +93,11 @@ int gr_copy(gr_ctx *ctx, gr_stream stream, void *dst, const void *src, size_t by
 int gr_fill_zero(gr_ctx *ctx, gr_stream stream, void *dst, size_t bytes);
 int gr_fill_byte(gr_ctx *ctx, gr_stream stream, void *dst, int value, size_t bytes); /* clear to a UNORM8 constant */
 
+/* Measured HBM ceiling for the roofline ("a hipMemcpyDtoD / stream-triad probe on the box, in the same
+ * run"): a float4 copy b = a and a triad a = b + s * c over `bytes`-sized arrays that do not fit the 256 MiB Infinity
+ * Cache, best of `repeats` launches timed with hipEvents.  GB/s counts bytes read + written (copy 2 x, triad 3 x bytes). */
+int gr_bandwidth_probe(gr_ctx *ctx, size_t bytes, int repeats, double *copy_GBps, double *triad_GBps);
+
 /* Per-kernel GPU timing (RenderGraph::enable_timestamps analogue, render_graph.cpp:2196-2310): when enabled, every
  * launcher brackets its kernel with hipEvents on the launch stream; gr_timing_query drains {name, count, total_ms}. */
 typedef struct gr_timing_entry
@@ -104,6 +109,10 @@ typedef struct gr_timing_entry
 int gr_timing_enable(gr_ctx *ctx, int enable);
 /* Restrict bracketing to launchers whose name equals `name` (NULL = all): keeps event overhead out of a timed loop. */
 int gr_timing_set_filter(gr_ctx *ctx, const char *name);
+/* Bracket only every n-th matching launch (1 = all).  An event pair around a kernel keeps the command processor from
+ * overlapping that launch with its neighbours on the stream; sampling keeps a timed loop close to its unbracketed speed
+ * while the launch duration is still measured live inside it. */
+int gr_timing_set_sampling(gr_ctx *ctx, uint32_t every_nth);
 int gr_timing_reset(gr_ctx *ctx);
 int gr_timing_query(gr_ctx *ctx, gr_timing_entry *entries, int max_entries); /* returns number of entries; syncs */
 
