@@ -1,5 +1,6 @@
 // Context, memory and timing entry points of the C ABI (include/granite_hip.h).
 #include "ctx.hpp"
+#include "device_common.hpp"
 #include <cmath>
 #include <cstring>
 
@@ -40,6 +41,75 @@ int gr_abi_version(void)
 	return GR_ABI_VERSION;
 }
 
+// Linear -> sRGB8 as an *_SRGB attachment store does it (assets/shaders/inc/srgb.h:12-18 + UNORM8 rounding), in fp32.
+static uint32_t srgb8_encode_host(float c)
+{
+	if (!(c > 0.0f))
+		return 0;
+	c = fminf(c, 1.0f);
+	float r = (c <= 0.0031308f) ? (c * 12.92f) : (1.055f * powf(c, 1.0f / 2.4f) - 0.055f);
+	r = fminf(fmaxf(r, 0.0f), 1.0f);
+	return r >= 1.0f ? 255u : uint32_t(int(r * 255.0f + 0.5f));
+}
+
+// tonemap.frag:42-53 for one channel, evaluated in fp32 operation by operation (no contraction), into the sRGB8 byte.
+static uint32_t tonemap_srgb8_host(float x)
+{
+#pragma clang fp contract(off)
+	const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f, W = 11.2f;
+	auto uncharted2 = [=](float v) { return ((v * (A * v + C * B) + D * E) / (v * (A * v + B) + D * F)) - E / F; };
+	const float white_scale = 1.0f / uncharted2(W);
+	return srgb8_encode_host(uncharted2(x) * white_scale);
+}
+
+// Staircase tables share one builder: entry i = {bits of the smallest float of bucket i that encodes above the bucket's
+// first float (or +inf), byte of the bucket's first float}.  -1 if a bucket holds more than one step.
+static int build_staircase(uint32_t (*enc)(float), uint32_t min_bits, uint32_t shift, uint32_t entries, uint32_t *entries_xy)
+{
+	auto at = [enc](uint32_t bits) { return enc(__builtin_bit_cast(float, bits)); };
+	for (uint32_t i = 0; i < entries; i++)
+	{
+		const uint32_t lo = min_bits + (i << shift);
+		const uint32_t hi = lo + (1u << shift) - 1u; // last float of the bucket
+		const uint32_t value = at(lo);
+		uint32_t threshold = 0x7f800000u; // +inf
+		if (i + 1 < entries && at(hi) != value)
+		{
+			if (at(hi) != value + 1)
+				return -1;
+			uint32_t a = lo, b = hi; // at(a) == value, at(b) == value + 1
+			while (b - a > 1)
+			{
+				const uint32_t mid = a + (b - a) / 2;
+				if (at(mid) == value)
+					a = mid;
+				else
+					b = mid;
+			}
+			threshold = b;
+		}
+		entries_xy[2 * i] = threshold;
+		entries_xy[2 * i + 1] = value;
+	}
+	return 0;
+}
+
+extern "C" int gr_tonemap_srgb8_table(uint32_t *entries_xy, uint32_t count)
+{
+	if (!entries_xy || count != TONEMAP_TABLE_ENTRIES)
+		return -1;
+	return build_staircase(tonemap_srgb8_host, TONEMAP_TABLE_MIN_BITS, TONEMAP_TABLE_BUCKET_SHIFT, TONEMAP_TABLE_ENTRIES, entries_xy);
+}
+
+// One entry per bucket of SRGB_ENCODE_BUCKET_SHIFT mantissa bits: {bits of the smallest float of the bucket that encodes
+// to value + 1 (or +inf), value at the bucket's lower bound}.  Returns 0, or -1 if a bucket holds more than one step.
+extern "C" int gr_srgb_encode_table(uint32_t *entries_xy, uint32_t count)
+{
+	if (!entries_xy || count != SRGB_ENCODE_ENTRIES)
+		return -1;
+	return build_staircase(srgb8_encode_host, SRGB_ENCODE_MIN_BITS, SRGB_ENCODE_BUCKET_SHIFT, SRGB_ENCODE_ENTRIES, entries_xy);
+}
+
 gr_ctx *gr_create(int device)
 {
 	int count = 0;
@@ -59,8 +129,17 @@ gr_ctx *gr_create(int device)
 		float r = (c <= 0.0404482362771082f) ? (c / 12.92f) : powf((c + 0.055f) / 1.055f, 2.4f);
 		lut[i] = fminf(fmaxf(r, 0.0f), 1.0f);
 	}
-	if (hipMalloc(reinterpret_cast<void **>(&ctx->srgb_decode_lut), sizeof(lut)) != hipSuccess ||
-	    hipMemcpy(ctx->srgb_decode_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess)
+	static uint32_t encode_table[2 * SRGB_ENCODE_ENTRIES];
+	static const int encode_table_status = gr_srgb_encode_table(encode_table, SRGB_ENCODE_ENTRIES);
+	static uint32_t tonemap_table[2 * TONEMAP_TABLE_ENTRIES];
+	static const int tonemap_table_status = gr_tonemap_srgb8_table(tonemap_table, TONEMAP_TABLE_ENTRIES);
+	if (encode_table_status != 0 || tonemap_table_status != 0 ||
+	    hipMalloc(reinterpret_cast<void **>(&ctx->tonemap_srgb8_lut), sizeof(tonemap_table)) != hipSuccess ||
+	    hipMemcpy(ctx->tonemap_srgb8_lut, tonemap_table, sizeof(tonemap_table), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMalloc(reinterpret_cast<void **>(&ctx->srgb_decode_lut), sizeof(lut)) != hipSuccess ||
+	    hipMemcpy(ctx->srgb_decode_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMalloc(reinterpret_cast<void **>(&ctx->srgb_encode_lut), sizeof(encode_table)) != hipSuccess ||
+	    hipMemcpy(ctx->srgb_encode_lut, encode_table, sizeof(encode_table), hipMemcpyHostToDevice) != hipSuccess)
 	{
 		delete ctx;
 		return nullptr;
@@ -83,6 +162,10 @@ void gr_destroy(gr_ctx *ctx)
 		(void)hipEventDestroy(e);
 	if (ctx->srgb_decode_lut)
 		(void)hipFree(ctx->srgb_decode_lut);
+	if (ctx->srgb_encode_lut)
+		(void)hipFree(ctx->srgb_encode_lut);
+	if (ctx->tonemap_srgb8_lut)
+		(void)hipFree(ctx->tonemap_srgb8_lut);
 	if (ctx->smaa_area)
 		(void)hipFree(ctx->smaa_area);
 	if (ctx->smaa_search)

@@ -24,6 +24,10 @@ struct gr_ctx
 	// 256-entry sRGB8 -> linear table (assets/shaders/inc/srgb.h:4-10 semantics, what the sampler hardware does for
 	// an *_SRGB view), built on the host and resident in HBM.
 	float *srgb_decode_lut = nullptr;
+	// Linear -> sRGB8 staircase table ({threshold bits, byte below it} per bucket; device_common.hpp: encode_srgb8_lut).
+	uint2 *srgb_encode_lut = nullptr;
+	// Exposed colour -> tonemapped sRGB8 staircase (device_common.hpp: tonemap_srgb8_lut).
+	uint2 *tonemap_srgb8_lut = nullptr;
 
 	// SMAA lookup tables (assets/textures/smaa/{area,search}.gtx payloads), uploaded through gr_smaa_set_luts.
 	void *smaa_area = nullptr;   // RG8, 160 x 560

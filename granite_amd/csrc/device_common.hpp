@@ -104,6 +104,38 @@ __device__ __forceinline__ uint32_t encode_srgb8(float c)
 	return uint32_t(e * 255.0f + 0.5f);
 }
 
+// Table form of the same store (gr_ctx::srgb_encode_lut, built on the host from the formula above, staged in LDS by the
+// kernels that use it).  The encode is a monotone staircase of 255 steps: the linear value's exponent and top 7 mantissa
+// bits select a bucket [2^e (1 + i/128), 2^e (1 + (i+1)/128)) that holds at most one step (the densest stretch, c = 0.5,
+// has 0.66 steps per bucket; with 64 buckets per octave some would hold two), so one entry {threshold, value below it} decides the byte exactly: no log / exp / pow, and
+// bit-identical to the formula evaluated in fp32 on the host.
+constexpr uint32_t SRGB_ENCODE_MIN_BITS = 0x39000000u;                 // 2^-13: 255 * 12.92 * 2^-13 = 0.40 -> byte 0 below
+constexpr uint32_t SRGB_ENCODE_BUCKET_SHIFT = 16;                      // 23 - 7 mantissa bits
+constexpr uint32_t SRGB_ENCODE_ENTRIES = 13u * 128u + 1u;              // 13 octaves x 128 buckets, + the entry of 1.0
+__device__ __forceinline__ uint32_t encode_srgb8_lut(float c, const uint2 *lut)
+{
+	c = __builtin_amdgcn_fmed3f(c, 0x1p-13f, 1.0f); // NaN -> 2^-13 -> 0, like the formula's !(c > 0) -> 0
+	const uint32_t index = (__builtin_bit_cast(uint32_t, c) - SRGB_ENCODE_MIN_BITS) >> SRGB_ENCODE_BUCKET_SHIFT;
+	const uint2 e = lut[index];
+	return e.y + (c >= __builtin_bit_cast(float, e.x) ? 1u : 0u);
+}
+
+// The whole tonemap of one channel as a staircase: byte = srgb8(uncharted2(x) * white_scale) is a monotone function of the
+// exposed colour x alone (tonemap.frag:42-53 into an *_SRGB store), 0 below 2^-11.3 and 255 from the white point 11.2 on.
+// Bucketed like encode_srgb8_lut on x itself (16 octaves from 2^-12, 64 buckets each: at most 0.81 steps per bucket), it
+// replaces three fmas, a division, a pow and the rounding by one compare.  Valid for finite x >= 0 (callers send anything
+// else through the formula); built on the host from the formula in fp32 (gr_tonemap_srgb8_table).
+constexpr uint32_t TONEMAP_TABLE_MIN_BITS = 0x39800000u; // 2^-12
+constexpr uint32_t TONEMAP_TABLE_BUCKET_SHIFT = 17;      // 23 - 6 mantissa bits
+constexpr uint32_t TONEMAP_TABLE_ENTRIES = 16u * 64u + 1u;
+__device__ __forceinline__ uint32_t tonemap_srgb8_lut(float x, const uint2 *lut)
+{
+	x = __builtin_amdgcn_fmed3f(x, 0x1p-12f, 16.0f);
+	const uint32_t index = (__builtin_bit_cast(uint32_t, x) - TONEMAP_TABLE_MIN_BITS) >> TONEMAP_TABLE_BUCKET_SHIFT;
+	const uint2 e = lut[index];
+	return e.y + (x >= __builtin_bit_cast(float, e.x) ? 1u : 0u);
+}
+
 __device__ __forceinline__ uint32_t encode_unorm8(float c)
 {
 	return uint32_t(saturatef(c) * 255.0f + 0.5f);

@@ -271,123 +271,158 @@ __global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_lumin
 // kept lean so that the kernel stays on the HBM side of its roofline: the filmic division is num * v_rcp_f32(den) (1 ulp),
 // and when the bloom level is exactly 1/4 resolution (the InputRelative 0.25 level of even-sized targets) the four pixels of
 // a lane share one 3x2 bloom footprint that is lerped separably instead of four independent 4-tap fetches.
-__device__ __forceinline__ float uncharted2(float x)
+// uncharted2(x) * white_scale with the scale folded into the numerator's constants (tonemap.frag:42-53).
+__device__ __forceinline__ float uncharted2_scaled(float x)
 {
-	const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
-	const float num = fmaf(x, fmaf(A, x, C * B), D * E);
+	constexpr float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f, W = 11.2f;
+	constexpr float white = ((W * (A * W + C * B) + D * E) / (W * (A * W + B) + D * F)) - E / F;
+	constexpr float ws = 1.0f / white;
+	const float num = fmaf(x, fmaf(A * ws, x, C * B * ws), D * E * ws);
 	const float den = fmaf(x, fmaf(A, x, B), D * F);
-	return fmaf(num, __builtin_amdgcn_rcpf(den), -(E / F));
+	return fmaf(num, __builtin_amdgcn_rcpf(den), -(E / F) * ws);
 }
 
 constexpr int TONEMAP_PX = 4; // pixels per lane: 2 x 16 B loads, one 16 B store
 constexpr int TONEMAP_BLOCK_X = 64;
 constexpr int TONEMAP_BLOCK_Y = 4;
+constexpr int TONEMAP_ROW_GROUPS = 8; // a workgroup walks 8 x TONEMAP_BLOCK_Y rows: the 8 KiB curve table is staged once per 8192 pixels
 
 template <bool DYNAMIC_EXPOSURE, bool SRGB, bool QUARTER_BLOOM>
 __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(DevImage hdr, DevImage bloom, DevImageRW out,
-                                                                              const gr_luminance_data *lum,
+                                                                              const gr_luminance_data *lum, const uint2 *encode_lut,
                                                                               gr_push_tonemap push, uint32_t y_first, uint32_t y_end)
 {
 	post_wave_priority();
+	// *_SRGB output: the curve and the store's encode are one table lookup per channel (tonemap_srgb8_lut), staged in LDS.
+	__shared__ uint2 s_table[SRGB ? TONEMAP_TABLE_ENTRIES : 1];
+	if (SRGB)
+	{
+		for (uint32_t i = threadIdx.y * TONEMAP_BLOCK_X + threadIdx.x; i < TONEMAP_TABLE_ENTRIES; i += TONEMAP_BLOCK_X * TONEMAP_BLOCK_Y)
+			s_table[i] = encode_lut[i];
+		__syncthreads();
+	}
 	const int x0 = (blockIdx.x * TONEMAP_BLOCK_X + threadIdx.x) * TONEMAP_PX;
-	const int y = int(y_first) + blockIdx.y * TONEMAP_BLOCK_Y + threadIdx.y;
-	if (x0 >= hdr.w || uint32_t(y) >= y_end)
+	if (x0 >= hdr.w)
 		return;
-
-	const float inv_w = 1.0f / float(hdr.w), inv_h = 1.0f / float(hdr.h);
-	const float white_scale = 1.0f / (((11.2f * (0.15f * 11.2f + 0.10f * 0.50f) + 0.20f * 0.02f) /
-	                                   (11.2f * (0.15f * 11.2f + 0.50f) + 0.20f * 0.30f)) - 0.02f / 0.30f);
 	float scale = push.dynamic_exposure;
 	if (DYNAMIC_EXPOSURE)
 		scale *= lum->average_inv_linear_luminance;
-	const float v = (float(y) + 0.5f) * inv_h;
+	const float inv_w = 1.0f / float(hdr.w), inv_h = 1.0f / float(hdr.h);
 
-	const uint8_t *row = hdr.ptr + size_t(y) * hdr.pitch;
-	uint32_t packed[TONEMAP_PX];
-	const bool full = (x0 + TONEMAP_PX <= hdr.w) && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
-	f16x4 texels[TONEMAP_PX];
-	if (full)
+#pragma unroll 1
+	for (int group = 0; group < TONEMAP_ROW_GROUPS; group++)
 	{
-		// 32 contiguous bytes per lane, 2 KiB per wave per row.
-		const u32x4 lo = *reinterpret_cast<const u32x4 *>(row + size_t(x0) * 8u);
-		const u32x4 hi = *reinterpret_cast<const u32x4 *>(row + size_t(x0) * 8u + 16u);
-		texels[0] = __builtin_bit_cast(f16x4, u32x2{lo.x, lo.y});
-		texels[1] = __builtin_bit_cast(f16x4, u32x2{lo.z, lo.w});
-		texels[2] = __builtin_bit_cast(f16x4, u32x2{hi.x, hi.y});
-		texels[3] = __builtin_bit_cast(f16x4, u32x2{hi.z, hi.w});
-	}
-	else
-	{
-#pragma unroll
-		for (int i = 0; i < TONEMAP_PX; i++)
-			texels[i] = *reinterpret_cast<const f16x4 *>(row + size_t(min(x0 + i, hdr.w - 1)) * 8u);
-	}
+		const int y = int(y_first) + (blockIdx.y * TONEMAP_ROW_GROUPS + group) * TONEMAP_BLOCK_Y + threadIdx.y;
+		if (uint32_t(y) >= y_end)
+			return;
+		const float v = (float(y) + 0.5f) * inv_h;
 
-	float bloom_rgb[TONEMAP_PX][3];
-	if (QUARTER_BLOOM)
-	{
-		// hdr = 4 x bloom in both axes and x0 = 4k: the unnormalised bloom coordinate of pixel x0 + i is
-		// k + (i + 0.5)/4 - 0.5, i.e. texel pairs (k-1,k),(k-1,k),(k,k+1),(k,k+1) with weights .625,.875,.125,.375;
-		// rows likewise from y.  Same StockSampler::LinearClamp result, evaluated separably (rows first).
-		const int k = x0 >> 2;
-		const int j = (y >> 2) - (((y & 3) < 2) ? 1 : 0);
-		const float wy = 0.125f + 0.25f * float((y + 2) & 3);
-		const int r0 = clampi(j, 0, bloom.h - 1), r1 = clampi(j + 1, 0, bloom.h - 1);
-		float col[3][3];
-#pragma unroll
-		for (int c = 0; c < 3; c++)
+		const uint8_t *row = hdr.ptr + size_t(y) * hdr.pitch;
+		uint32_t packed[TONEMAP_PX];
+		const bool full = (x0 + TONEMAP_PX <= hdr.w) && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+		f16x4 texels[TONEMAP_PX];
+		if (full)
 		{
-			const int cx = clampi(k - 1 + c, 0, bloom.w - 1);
-			const f16x4 t0 = *reinterpret_cast<const f16x4 *>(bloom.ptr + size_t(r0) * bloom.pitch + size_t(cx) * 8u);
-			const f16x4 t1 = *reinterpret_cast<const f16x4 *>(bloom.ptr + size_t(r1) * bloom.pitch + size_t(cx) * 8u);
-			col[c][0] = fmaf(float(t1.x) - float(t0.x), wy, float(t0.x));
-			col[c][1] = fmaf(float(t1.y) - float(t0.y), wy, float(t0.y));
-			col[c][2] = fmaf(float(t1.z) - float(t0.z), wy, float(t0.z));
+			// 32 contiguous bytes per lane, 2 KiB per wave per row.
+			const u32x4 lo = *reinterpret_cast<const u32x4 *>(row + size_t(x0) * 8u);
+			const u32x4 hi = *reinterpret_cast<const u32x4 *>(row + size_t(x0) * 8u + 16u);
+			texels[0] = __builtin_bit_cast(f16x4, u32x2{lo.x, lo.y});
+			texels[1] = __builtin_bit_cast(f16x4, u32x2{lo.z, lo.w});
+			texels[2] = __builtin_bit_cast(f16x4, u32x2{hi.x, hi.y});
+			texels[3] = __builtin_bit_cast(f16x4, u32x2{hi.z, hi.w});
 		}
-#pragma unroll
-		for (int ch = 0; ch < 3; ch++)
-		{
-			bloom_rgb[0][ch] = fmaf(col[1][ch] - col[0][ch], 0.625f, col[0][ch]);
-			bloom_rgb[1][ch] = fmaf(col[1][ch] - col[0][ch], 0.875f, col[0][ch]);
-			bloom_rgb[2][ch] = fmaf(col[2][ch] - col[1][ch], 0.125f, col[1][ch]);
-			bloom_rgb[3][ch] = fmaf(col[2][ch] - col[1][ch], 0.375f, col[1][ch]);
-		}
-	}
-	else
-	{
-#pragma unroll
-		for (int i = 0; i < TONEMAP_PX; i++)
-		{
-			const float u = (float(x0 + i) + 0.5f) * inv_w;
-			const float4 b = sample_linear_rgba16f(bloom, u, v);
-			bloom_rgb[i][0] = b.x;
-			bloom_rgb[i][1] = b.y;
-			bloom_rgb[i][2] = b.z;
-		}
-	}
-
-#pragma unroll
-	for (int i = 0; i < TONEMAP_PX; i++)
-	{
-		const float r = (float(texels[i].x) + bloom_rgb[i][0]) * scale;
-		const float g = (float(texels[i].y) + bloom_rgb[i][1]) * scale;
-		const float bl = (float(texels[i].z) + bloom_rgb[i][2]) * scale;
-		const float tr = uncharted2(r) * white_scale;
-		const float tg = uncharted2(g) * white_scale;
-		const float tb = uncharted2(bl) * white_scale;
-		if (SRGB)
-			packed[i] = encode_srgb8(tr) | (encode_srgb8(tg) << 8) | (encode_srgb8(tb) << 16) | 0xff000000u;
 		else
-			packed[i] = encode_unorm8(tr) | (encode_unorm8(tg) << 8) | (encode_unorm8(tb) << 16) | 0xff000000u;
-	}
+		{
+#pragma unroll
+			for (int i = 0; i < TONEMAP_PX; i++)
+				texels[i] = *reinterpret_cast<const f16x4 *>(row + size_t(min(x0 + i, hdr.w - 1)) * 8u);
+		}
 
-	uint8_t *orow = out.ptr + size_t(y) * out.pitch;
-	if (full && ((reinterpret_cast<uintptr_t>(orow) & 15u) == 0))
-		*reinterpret_cast<u32x4 *>(orow + size_t(x0) * 4u) = u32x4{packed[0], packed[1], packed[2], packed[3]};
-	else
-	{
-		for (int i = 0; i < TONEMAP_PX && x0 + i < hdr.w; i++)
-			*reinterpret_cast<uint32_t *>(orow + size_t(x0 + i) * 4u) = packed[i];
+		// bloom * scale per pixel and channel (the exposure scale distributes over hdr + bloom)
+		float bloom_rgb[TONEMAP_PX][3];
+		if (QUARTER_BLOOM)
+		{
+			// hdr = 4 x bloom in both axes and x0 = 4k: the unnormalised bloom coordinate of pixel x0 + i is
+			// k + (i + 0.5)/4 - 0.5, i.e. texel pairs (k-1,k),(k-1,k),(k,k+1),(k,k+1) with weights .625,.875,.125,.375;
+			// rows likewise from y.  Same StockSampler::LinearClamp result, evaluated separably (rows first).
+			const int k = x0 >> 2;
+			const int j = (y >> 2) - (((y & 3) < 2) ? 1 : 0);
+			const float wy = 0.125f + 0.25f * float((y + 2) & 3);
+			const int r0 = clampi(j, 0, bloom.h - 1), r1 = clampi(j + 1, 0, bloom.h - 1);
+			float col[3][3];
+#pragma unroll
+			for (int c = 0; c < 3; c++)
+			{
+				const int cx = clampi(k - 1 + c, 0, bloom.w - 1);
+				const f16x4 t0 = *reinterpret_cast<const f16x4 *>(bloom.ptr + size_t(r0) * bloom.pitch + size_t(cx) * 8u);
+				const f16x4 t1 = *reinterpret_cast<const f16x4 *>(bloom.ptr + size_t(r1) * bloom.pitch + size_t(cx) * 8u);
+				col[c][0] = fmaf(float(t1.x) - float(t0.x), wy, float(t0.x));
+				col[c][1] = fmaf(float(t1.y) - float(t0.y), wy, float(t0.y));
+				col[c][2] = fmaf(float(t1.z) - float(t0.z), wy, float(t0.z));
+			}
+#pragma unroll
+			for (int ch = 0; ch < 3; ch++)
+			{
+				bloom_rgb[0][ch] = fmaf(col[1][ch] - col[0][ch], 0.625f, col[0][ch]);
+				bloom_rgb[1][ch] = fmaf(col[1][ch] - col[0][ch], 0.875f, col[0][ch]);
+				bloom_rgb[2][ch] = fmaf(col[2][ch] - col[1][ch], 0.125f, col[1][ch]);
+				bloom_rgb[3][ch] = fmaf(col[2][ch] - col[1][ch], 0.375f, col[1][ch]);
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int i = 0; i < TONEMAP_PX; i++)
+			{
+				const float u = (float(x0 + i) + 0.5f) * inv_w;
+				const float4 b = sample_linear_rgba16f(bloom, u, v);
+				bloom_rgb[i][0] = b.x;
+				bloom_rgb[i][1] = b.y;
+				bloom_rgb[i][2] = b.z;
+			}
+		}
+
+		float x[TONEMAP_PX][3];
+		uint32_t top = 0u;
+#pragma unroll
+		for (int i = 0; i < TONEMAP_PX; i++)
+		{
+			x[i][0] = (float(texels[i].x) + bloom_rgb[i][0]) * scale;
+			x[i][1] = (float(texels[i].y) + bloom_rgb[i][1]) * scale;
+			x[i][2] = (float(texels[i].z) + bloom_rgb[i][2]) * scale;
+			if (SRGB)
+				top = max(top, max(__builtin_bit_cast(uint32_t, x[i][0]), max(__builtin_bit_cast(uint32_t, x[i][1]), __builtin_bit_cast(uint32_t, x[i][2]))));
+		}
+		// The table covers finite x >= 0.  A negative, infinite or NaN colour (as an unsigned word: >= 0x7f800000) sends the
+		// wave through the formula, so that even then the bytes are the ones the shader's arithmetic produces.
+		if (SRGB && !__any(top >= 0x7f800000u))
+		{
+#pragma unroll
+			for (int i = 0; i < TONEMAP_PX; i++)
+				packed[i] = tonemap_srgb8_lut(x[i][0], s_table) | (tonemap_srgb8_lut(x[i][1], s_table) << 8) |
+				            (tonemap_srgb8_lut(x[i][2], s_table) << 16) | 0xff000000u;
+		}
+		else
+		{
+#pragma unroll
+			for (int i = 0; i < TONEMAP_PX; i++)
+			{
+				const float tr = uncharted2_scaled(x[i][0]), tg = uncharted2_scaled(x[i][1]), tb = uncharted2_scaled(x[i][2]);
+				if (SRGB)
+					packed[i] = encode_srgb8(tr) | (encode_srgb8(tg) << 8) | (encode_srgb8(tb) << 16) | 0xff000000u;
+				else
+					packed[i] = encode_unorm8(tr) | (encode_unorm8(tg) << 8) | (encode_unorm8(tb) << 16) | 0xff000000u;
+			}
+		}
+
+		uint8_t *orow = out.ptr + size_t(y) * out.pitch;
+		if (full && ((reinterpret_cast<uintptr_t>(orow) & 15u) == 0))
+			*reinterpret_cast<u32x4 *>(orow + size_t(x0) * 4u) = u32x4{packed[0], packed[1], packed[2], packed[3]};
+		else
+		{
+			for (int i = 0; i < TONEMAP_PX && x0 + i < hdr.w; i++)
+				*reinterpret_cast<uint32_t *>(orow + size_t(x0 + i) * 4u) = packed[i];
+		}
 	}
 }
 
@@ -564,12 +599,12 @@ int gr_tonemap_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr
 	if (span.count() == 0)
 		return GR_OK;
 	dim3 block(TONEMAP_BLOCK_X, TONEMAP_BLOCK_Y);
-	dim3 grid(gr_div_up(hdr->width, TONEMAP_BLOCK_X * TONEMAP_PX), gr_div_up(span.count(), TONEMAP_BLOCK_Y));
+	dim3 grid(gr_div_up(hdr->width, TONEMAP_BLOCK_X * TONEMAP_PX), gr_div_up(span.count(), TONEMAP_BLOCK_Y * TONEMAP_ROW_GROUPS));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "tonemap"};
 	hipStream_t s = gr_to_stream(stream);
 	const bool quarter = hdr->width == 4u * bloom->width && hdr->height == 4u * bloom->height;
 	auto launch = [&](auto kernel) {
-		hipLaunchKernelGGL(kernel, grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, *push, span.first, span.end);
+		hipLaunchKernelGGL(kernel, grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, ctx->tonemap_srgb8_lut, *push, span.first, span.end);
 	};
 	if (quarter)
 	{

@@ -93,6 +93,12 @@ int gr_copy(gr_ctx *ctx, gr_stream stream, void *dst, const void *src, size_t by
 int gr_fill_zero(gr_ctx *ctx, gr_stream stream, void *dst, size_t bytes);
 int gr_fill_byte(gr_ctx *ctx, gr_stream stream, void *dst, int value, size_t bytes); /* clear to a UNORM8 constant */
 
+/* Host-only: the linear -> sRGB8 staircase table the *_SRGB stores use (count must be 1665 {threshold bits, byte} pairs;
+ * csrc/device_common.hpp).  Exposed so that the table can be checked against the transfer function without a GPU. */
+int gr_srgb_encode_table(uint32_t *entries_xy, uint32_t count);
+/* Host-only: the exposed colour -> tonemapped sRGB8 staircase of gr_tonemap's *_SRGB path (1025 pairs). */
+int gr_tonemap_srgb8_table(uint32_t *entries_xy, uint32_t count);
+
 /* Measured HBM ceiling for the roofline ("a hipMemcpyDtoD / stream-triad probe on the box, in the same
  * run"): a float4 copy b = a and a triad a = b + s * c over `bytes`-sized arrays that do not fit the 256 MiB Infinity
  * Cache, best of `repeats` launches timed with hipEvents.  GB/s counts bytes read + written (copy 2 x, triad 3 x bytes). */

@@ -134,6 +134,14 @@ def tonemap(hdr: np.ndarray, bloom: np.ndarray, lum3=None, dynamic_exposure: flo
     return out
 
 
+def float_to_srgb8(values: np.ndarray) -> np.ndarray:
+    """Linear fp32 -> sRGB8 bytes as an *_SRGB attachment store (assets/shaders/inc/srgb.h:12-18 + UNORM8 rounding)."""
+    v = np.ascontiguousarray(values, np.float32).reshape(-1)
+    out = np.zeros(v.size, np.uint8)
+    lib().orc_float_to_srgb8_array(_p(v), C.c_size_t(v.size), _p(out))
+    return out.reshape(np.shape(values))
+
+
 def frame_lerps(frame_time: float):
     """(luminance lerp, bloom feedback lerp) as hdr.cpp:93,181 compute them: float(1.0 - pow(0.5|0.001, frame_time))."""
     import math

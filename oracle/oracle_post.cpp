@@ -178,6 +178,13 @@ void orc_float_to_half_muglm_array(const float *in, uint16_t *out, uint64_t coun
 		out[i] = float_to_half_muglm(in[i]);
 }
 uint8_t orc_float_to_srgb8(float f) { return float_to_srgb8(f); }
+// the same over an array (checks the product's encode table value by value)
+void orc_float_to_srgb8_array(const float *in, size_t n, uint8_t *out)
+{
+#pragma omp parallel for
+	for (long i = 0; i < long(n); i++)
+		out[i] = float_to_srgb8(in[i]);
+}
 float orc_srgb8_to_float(uint8_t v) { return srgb8_to_float(v); }
 void orc_sample_linear_rgba16f(const uint16_t *img, int w, int h, float u, float v, float *out4)
 {
