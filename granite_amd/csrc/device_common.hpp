@@ -65,6 +65,27 @@ __device__ __forceinline__ void store_rgba16f(const DevImageRW &img, int x, int 
 	*reinterpret_cast<f16x4 *>(img.ptr + size_t(y) * img.pitch + size_t(x) * 8u) = pack_rgba16f(v);
 }
 
+// acc + float(half) * w in ONE instruction (v_fma_mix_f32: the fp16 -> fp32 conversion is exact and folded into the
+// fused multiply-add, so the result is bit-identical to cvt + fma at 3.6 instead of 5.9 issue cycles).  `packed` holds
+// two halves; _lo / _hi pick one.
+__device__ __forceinline__ float fma_mix_lo(uint32_t packed, float w, float acc)
+{
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(w), "v"(acc));
+	return r;
+}
+__device__ __forceinline__ float fma_mix_hi(uint32_t packed, float w, float acc)
+{
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(w), "v"(acc));
+	return r;
+}
+// acc += texel * w for an RGBA16F texel given as two dwords (r|g, b|a)
+__device__ __forceinline__ float4 fma_mix_texel(uint32_t rg, uint32_t ba, float w, float4 acc)
+{
+	return make_float4(fma_mix_lo(rg, w, acc.x), fma_mix_hi(rg, w, acc.y), fma_mix_lo(ba, w, acc.z), fma_mix_hi(ba, w, acc.w));
+}
+
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 operator*(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 fma4(float4 a, float s, float4 c)

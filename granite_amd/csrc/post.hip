@@ -62,6 +62,56 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold(
 	              make_float4(fmaxf(r * luminance, 0.0f), fmaxf(g * luminance, 0.0f), fmaxf(b * luminance, 0.0f), loglum));
 }
 
+// 2:1 form (the threshold level of an even-sized HDR target): the LinearClamp tap at an output pixel's centre lands on the
+// corner shared by the four HDR texels (2x, 2y) .. (2x + 1, 2y + 1), so the footprint is known without the sampler's index
+// arithmetic.  The weights are NOT taken as 1/4: uv * size - 0.5 carries the rounding of its fp32 evaluation (up to
+// 1e-4 at 4K), which the log-luminance channel -- log2 of a value near 1 over much of a frame -- is sensitive to, so they
+// are computed exactly as the sampler does (uncontracted).  One lane makes two adjacent outputs from 2 x 32 contiguous bytes
+// per row and stores 16 bytes; conversions ride on v_fma_mix_f32.
+template <bool DYNAMIC_EXPOSURE>
+__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold_2to1(DevImage hdr, DevImageRW out,
+                                                                                     const gr_luminance_data *lum, uint32_t pairs_x,
+                                                                                     float inv_out_w, float inv_out_h, uint32_t y_first,
+                                                                                     uint32_t y_end)
+{
+	post_wave_priority();
+	const uint32_t xp = blockIdx.x * POST_BLOCK_X + threadIdx.x; // output pixels 2 xp, 2 xp + 1
+	const uint32_t y = y_first + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
+	if (xp >= pairs_x || y >= y_end)
+		return;
+	const uint8_t *row0 = hdr.ptr + size_t(2u * y) * hdr.pitch + size_t(xp) * 32u;
+	const u32x4 a0 = *reinterpret_cast<const u32x4 *>(row0), a1 = *reinterpret_cast<const u32x4 *>(row0 + 16);
+	const u32x4 b0 = *reinterpret_cast<const u32x4 *>(row0 + hdr.pitch), b1 = *reinterpret_cast<const u32x4 *>(row0 + hdr.pitch + 16);
+	// fractional sampler coordinate: ((p + 0.5) * inv_out) * size - 0.5, minus its floor (= 2 p)
+	auto fraction = [](uint32_t p, float inv_out, int size) {
+		const float f = __fsub_rn(__fmul_rn(__fmul_rn(float(p) + 0.5f, inv_out), float(size)), 0.5f);
+		return f - floorf(f);
+	};
+	const float wb = fraction(y, inv_out_h, hdr.h), wt = 1.0f - wb;
+	const float threshold = DYNAMIC_EXPOSURE ? 8.0f * lum->average_linear_luminance : 8.0f;
+	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	f16x4 result[2];
+#pragma unroll
+	for (int i = 0; i < 2; i++)
+	{
+		const u32x4 top = i ? a1 : a0, bottom = i ? b1 : b0;
+		const float wr = fraction(2u * xp + uint32_t(i), inv_out_w, hdr.w), wl = 1.0f - wr;
+		// sampler order: (t00 (1-a) + t10 a) (1-b) + (t01 (1-a) + t11 a) b
+		const float4 row_t = fma_mix_texel(top.z, top.w, wr, fma_mix_texel(top.x, top.y, wl, zero));
+		const float4 row_b = fma_mix_texel(bottom.z, bottom.w, wr, fma_mix_texel(bottom.x, bottom.y, wl, zero));
+		const float4 c = fma4(row_b, wb, row_t * wt);
+		float luminance = fmaxf(fmaxf(c.x, c.y), c.z) + 0.0001f;
+		const float loglum = __log2f(luminance);
+		float inv = __builtin_amdgcn_rcpf(luminance);
+		inv = inv * fmaf(-luminance, inv, 2.0f); // one Newton step: the quotient to within an fp32 ulp
+		luminance -= threshold;
+		const float gain = inv * luminance;
+		result[i] = pack_rgba16f(make_float4(fmaxf(c.x * gain, 0.0f), fmaxf(c.y * gain, 0.0f), fmaxf(c.z * gain, 0.0f), loglum));
+	}
+	const u32x2 lo = __builtin_bit_cast(u32x2, result[0]), hi = __builtin_bit_cast(u32x2, result[1]);
+	*reinterpret_cast<u32x4 *>(out.ptr + size_t(y) * out.pitch + size_t(xp) * 16u) = u32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
 // ---- 9-tap tent (bloom_downsample.comp:30-38 / bloom_upsample.comp:25-33) --------------------------------------------
 __device__ __forceinline__ float4 tent9(const DevImage &in, float u, float v, float ox, float oy)
 {
@@ -163,12 +213,13 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k
 			const u32x4 v0 = *reinterpret_cast<const u32x4 *>(row + size_t(col0) * 8u);
 			const u32x4 v1 = *reinterpret_cast<const u32x4 *>(row + size_t(col0 + 2) * 8u);
 			const u32x4 v2 = *reinterpret_cast<const u32x4 *>(row + size_t(col0 + 4) * 8u);
-			h = mul4(cvt4(__builtin_bit_cast(f16x4, u32x2{v0.x, v0.y})), wt[0]);
-			h = fma4(cvt4(__builtin_bit_cast(f16x4, u32x2{v0.z, v0.w})), wt[1], h);
-			h = fma4(cvt4(__builtin_bit_cast(f16x4, u32x2{v1.x, v1.y})), wt[2], h);
-			h = fma4(cvt4(__builtin_bit_cast(f16x4, u32x2{v1.z, v1.w})), wt[3], h);
-			h = fma4(cvt4(__builtin_bit_cast(f16x4, u32x2{v2.x, v2.y})), wt[4], h);
-			h = fma4(cvt4(__builtin_bit_cast(f16x4, u32x2{v2.z, v2.w})), wt[5], h);
+			// conversion folded into the multiply-add (fma_mix_texel): same values as cvt + fma
+			h = fma_mix_texel(v0.x, v0.y, wt[0], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+			h = fma_mix_texel(v0.z, v0.w, wt[1], h);
+			h = fma_mix_texel(v1.x, v1.y, wt[2], h);
+			h = fma_mix_texel(v1.z, v1.w, wt[3], h);
+			h = fma_mix_texel(v2.x, v2.y, wt[4], h);
+			h = fma_mix_texel(v2.z, v2.w, wt[5], h);
 		}
 		else
 		{
@@ -218,10 +269,13 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k
 	for (int r = 0; r < 4; r++)
 	{
 		const uint8_t *row = in.ptr + size_t(clampi(sy + r, 0, in.h - 1)) * in.pitch;
-		float4 h = mul4(cvt4(*reinterpret_cast<const f16x4 *>(row + size_t(cx[0]) * 8u)), wx[0]);
+		float4 h = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-		for (int c = 1; c < 4; c++)
-			h = fma4(cvt4(*reinterpret_cast<const f16x4 *>(row + size_t(cx[c]) * 8u)), wx[c], h);
+		for (int c = 0; c < 4; c++)
+		{
+			const u32x2 t = *reinterpret_cast<const u32x2 *>(row + size_t(cx[c]) * 8u);
+			h = fma_mix_texel(t.x, t.y, wx[c], h); // conversion folded into the multiply-add
+		}
 		acc = fma4(h, wy[r], acc);
 	}
 	store_rgba16f(out, x, y, acc);
@@ -472,7 +526,21 @@ int gr_bloom_threshold_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, 
 	dim3 block(POST_BLOCK_X, POST_BLOCK_Y);
 	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_threshold"};
-	if (lum)
+	static const bool allow_stencil = getenv("GR_NO_STENCIL") == nullptr; // A/B switch for measurements
+	const bool exact = allow_stencil && hdr->width == 2u * push->threads[0] && hdr->height == 2u * push->threads[1] && (push->threads[0] & 1u) == 0 &&
+	                   out->width == push->threads[0] && (hdr->pitch_bytes & 15u) == 0 && (out->pitch_bytes & 15u) == 0 &&
+	                   (reinterpret_cast<uintptr_t>(hdr->ptr) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out->ptr) & 15u) == 0 &&
+	                   push->inv_output_size[0] == 1.0f / float(push->threads[0]) && push->inv_output_size[1] == 1.0f / float(push->threads[1]);
+	if (exact)
+	{
+		const uint32_t pairs = push->threads[0] / 2u;
+		dim3 grid2(gr_div_up(pairs, POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
+		if (lum)
+			hipLaunchKernelGGL(k_bloom_threshold_2to1<true>, grid2, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, pairs, push->inv_output_size[0], push->inv_output_size[1], span.first, span.end);
+		else
+			hipLaunchKernelGGL(k_bloom_threshold_2to1<false>, grid2, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, pairs, push->inv_output_size[0], push->inv_output_size[1], span.first, span.end);
+	}
+	else if (lum)
 		hipLaunchKernelGGL(k_bloom_threshold<true>, grid, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, *push,
 		                   span.first, span.end);
 	else

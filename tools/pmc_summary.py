@@ -19,6 +19,9 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
     for (key, counter), value in per_dispatch.items():
         table[names[key]][counter].append(value)
 counters = sorted({c for k in table.values() for c in k})
+import json
+with open(os.path.join(root, "summary.json"), "w") as f:
+    json.dump({k: {c: sum(v) / len(v) for c, v in vals.items()} for k, vals in table.items()}, f, indent=1)
 print("kernel".ljust(42) + "".join(c[-18:].rjust(20) for c in counters))
 for kernel, vals in sorted(table.items()):
     line = kernel.ljust(42)
