@@ -394,21 +394,22 @@ int gr_get_device_info(gr_ctx *ctx, char *name, size_t name_capacity, uint32_t *
 
 namespace
 {
-// Four independent 16-byte accesses per lane and iteration keep enough bytes in flight per CU to reach the HBM rate.
+// One workgroup per 16 KiB: four independent 16-byte accesses per lane, 256 lanes side by side (every access of a wave is
+// one contiguous 1 KiB), a grid of n / 1024 workgroups.
 __global__ __launch_bounds__(256) void k_probe_copy(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n)
 {
-	const size_t stride = size_t(gridDim.x) * blockDim.x;
-	size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-	for (; i + 3 * stride < n; i += 4 * stride)
+	const size_t i = size_t(blockIdx.x) * 1024u + threadIdx.x;
+	if (i + 768u < n)
 	{
-		const float4 v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
+		const float4 v0 = a[i], v1 = a[i + 256u], v2 = a[i + 512u], v3 = a[i + 768u];
 		b[i] = v0;
-		b[i + stride] = v1;
-		b[i + 2 * stride] = v2;
-		b[i + 3 * stride] = v3;
+		b[i + 256u] = v1;
+		b[i + 512u] = v2;
+		b[i + 768u] = v3;
 	}
-	for (; i < n; i += stride)
-		b[i] = a[i];
+	else
+		for (size_t j = i; j < n; j += 256u)
+			b[j] = a[j];
 }
 __device__ __forceinline__ float4 triad4(float4 x, float4 y, float s)
 {
@@ -417,16 +418,16 @@ __device__ __forceinline__ float4 triad4(float4 x, float4 y, float s)
 __global__ __launch_bounds__(256) void k_probe_triad(float4 *__restrict__ a, const float4 *__restrict__ b, const float4 *__restrict__ c,
                                                      float s, size_t n)
 {
-	const size_t stride = size_t(gridDim.x) * blockDim.x;
-	size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-	for (; i + stride < n; i += 2 * stride)
+	const size_t i = size_t(blockIdx.x) * 512u + threadIdx.x;
+	if (i + 256u < n)
 	{
-		const float4 x0 = b[i], y0 = c[i], x1 = b[i + stride], y1 = c[i + stride];
+		const float4 x0 = b[i], y0 = c[i], x1 = b[i + 256u], y1 = c[i + 256u];
 		a[i] = triad4(x0, y0, s);
-		a[i + stride] = triad4(x1, y1, s);
+		a[i + 256u] = triad4(x1, y1, s);
 	}
-	for (; i < n; i += stride)
-		a[i] = triad4(b[i], c[i], s);
+	else
+		for (size_t j = i; j < n; j += 256u)
+			a[j] = triad4(b[j], c[j], s);
 }
 } // namespace
 
@@ -459,16 +460,16 @@ int gr_bandwidth_probe(gr_ctx *ctx, size_t bytes, int repeats, double *copy_GBps
 		cleanup();
 		return ctx->fail(GR_ERR_HIP, "gr_bandwidth_probe: hipEventCreate failed");
 	}
-	const dim3 grid(256 * 16), block(256); // 16 workgroups per CU, grid-stride
+	const dim3 block(256), grid_copy(unsigned((n + 1023u) / 1024u)), grid_triad(unsigned((n + 511u) / 512u));
 	double best[2] = {1e30, 1e30};
 	for (int r = 0; r < repeats + 1 && status == GR_OK; r++) // first round warms up
 		for (int which = 0; which < 2; which++)
 		{
 			(void)hipEventRecord(e0, nullptr);
 			if (which == 0)
-				hipLaunchKernelGGL(k_probe_copy, grid, block, 0, nullptr, buf[0], buf[1], n);
+				hipLaunchKernelGGL(k_probe_copy, grid_copy, block, 0, nullptr, buf[0], buf[1], n);
 			else
-				hipLaunchKernelGGL(k_probe_triad, grid, block, 0, nullptr, buf[0], buf[1], buf[2], 0.5f, n);
+				hipLaunchKernelGGL(k_probe_triad, grid_triad, block, 0, nullptr, buf[0], buf[1], buf[2], 0.5f, n);
 			(void)hipEventRecord(e1, nullptr);
 			float ms = 0.0f;
 			if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess)

@@ -300,6 +300,15 @@ int gra_get_host_stats(gra_app *app, double *out3)
 	});
 }
 
+int gra_get_prefetched_refreshes(gra_app *app, uint64_t *out)
+{
+	return guarded(app, [&]() {
+		if (!out)
+			throw std::logic_error("gra_get_prefetched_refreshes: null output");
+		*out = app->app->get_clusterer().get_prefetch_hits();
+	});
+}
+
 int gra_get_allocated_bytes(gra_app *app, uint64_t *out)
 {
 	return guarded(app, [&]() {

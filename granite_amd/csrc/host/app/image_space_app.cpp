@@ -89,6 +89,7 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 
 ImageSpaceApplication::~ImageSpaceApplication()
 {
+	cluster.invalidate_prefetch(); // no helper-thread job may outlive the light objects it reads
 	wait_idle();
 }
 
@@ -147,6 +148,7 @@ static PostAAType to_post_aa_type(int32_t v)
 
 void ImageSpaceApplication::set_lights(const gra_light_desc *descs, uint32_t count)
 {
+	cluster.invalidate_prefetch(); // the helper thread may be packing the current list for the next frame
 	light_objects.clear();
 	light_transforms.resize(count);
 	light_list.clear();
@@ -546,6 +548,22 @@ void ImageSpaceApplication::render_frame()
 	{
 		cluster.setup_render_pass_resources(graph);
 		cluster.refresh(context, composer);
+	}
+	if (config.enable_lighting)
+	{
+		// Sort + pack of the NEXT frame's lights on the clusterer's helper threads while this frame is enqueued below, with the
+		// parameters that frame is going to use (the next jitter phase when a temporal AA is active).  A camera or light
+		// change in between simply makes the next refresh() pack on this thread as before.
+		if (jitter.get_jitter_type() != TemporalJitter::Type::None && has_base_camera)
+		{
+			TemporalJitter next_jitter = jitter;
+			next_jitter.step(base_projection, base_view);
+			RenderContext next_context = context;
+			next_context.set_camera(next_jitter.get_jittered_projection(), base_view);
+			cluster.prefetch(next_context.get_render_parameters());
+		}
+		else
+			cluster.prefetch(context.get_render_parameters());
 	}
 	graph.enqueue_render_passes(device, composer);
 	gbuffer_dirty = false;

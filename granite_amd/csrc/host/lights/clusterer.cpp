@@ -55,19 +55,153 @@ void LightClusterer::setup_render_pass_resources(RenderGraph &graph)
 }
 
 // ---- per-frame CPU refresh (clusterer.cpp:656-703,781-827,1133-1176; threaded_scene.cpp:141-150) -----------------------
-float LightClusterer::get_z_slice_extent(const RenderContext &ctx) const
+float LightClusterer::get_z_slice_extent(const RenderParameters &rp) const
 {
-	return std::min(0.5f, ctx.get_render_parameters().z_far / float(resolution_z));
+	return std::min(0.5f, rp.z_far / float(resolution_z));
+}
+
+static bool same_parameters(const RenderParameters &a, const RenderParameters &b)
+{
+	auto eq = [](const auto &x, const auto &y) { return memcmp(&x, &y, sizeof(x)) == 0; };
+	return eq(a.projection, b.projection) && eq(a.view, b.view) && eq(a.view_projection, b.view_projection) &&
+	       eq(a.inv_projection, b.inv_projection) && eq(a.camera_position, b.camera_position) && eq(a.camera_front, b.camera_front) &&
+	       a.z_near == b.z_near && a.z_far == b.z_far;
 }
 
 void LightClusterer::refresh(const RenderContext &context_, TaskComposer &)
+{
+	const RenderParameters &rp = context_.get_render_parameters();
+	{
+		std::unique_lock<std::mutex> holder{ahead.lock};
+		wait_for_workers(holder);
+		if (ahead.result_valid && same_parameters(ahead.parameters, rp))
+		{
+			// The helper threads have already sorted and packed this frame's lights.
+			std::swap(packed.parameters, ahead.result.parameters);
+			packed.lights.swap(ahead.result.lights);
+			packed.model.swap(ahead.result.model);
+			packed.volume_index_range.swap(ahead.result.volume_index_range);
+			memcpy(packed.type_mask, ahead.result.type_mask, sizeof(packed.type_mask));
+			ahead.result_valid = false;
+			prefetch_hits++;
+			return;
+		}
+		ahead.result_valid = false;
+	}
+	sort_and_pack(rp, sort_state, packed);
+}
+
+void LightClusterer::sort_and_pack(const RenderParameters &rp, SortState &sort, PackedLights &out) const
+{
+	sort_lights(rp, sort);
+	begin_pack(rp, sort, out);
+	const unsigned chunks = (unsigned(out.parameters.num_lights) + PackChunk - 1) / PackChunk;
+	for (unsigned c = 0; c < chunks; c++)
+		pack_chunk(rp, sort, out, c);
+}
+
+void LightClusterer::prefetch(const RenderParameters &next_parameters)
+{
+	std::unique_lock<std::mutex> holder{ahead.lock};
+	if (ahead.threads.empty())
+	{
+		const unsigned hw = std::thread::hardware_concurrency();
+		const unsigned count = hw >= 8 ? 3u : (hw >= 4 ? 2u : 1u);
+		for (unsigned i = 0; i < count; i++)
+			ahead.threads.emplace_back([this, i]() { worker_main(i); });
+	}
+	wait_for_workers(holder);
+	ahead.parameters = next_parameters;
+	ahead.result_valid = false;
+	ahead.in_flight = true;
+	ahead.sorted.store(0, std::memory_order_relaxed);
+	ahead.next_chunk.store(0, std::memory_order_relaxed);
+	ahead.workers_left.store(int(ahead.threads.size()), std::memory_order_relaxed);
+	ahead.generation++;
+	ahead.wake.notify_all();
+}
+
+void LightClusterer::invalidate_prefetch()
+{
+	std::unique_lock<std::mutex> holder{ahead.lock};
+	wait_for_workers(holder);
+	ahead.result_valid = false;
+}
+
+void LightClusterer::wait_for_workers(std::unique_lock<std::mutex> &holder)
+{
+	if (!ahead.in_flight)
+		return;
+	// Usually the job finished long ago: it had the whole submission of a frame to run beside.
+	ahead.done.wait(holder, [this]() { return ahead.workers_left.load(std::memory_order_acquire) == 0; });
+	ahead.in_flight = false;
+	ahead.result_valid = true;
+}
+
+void LightClusterer::worker_main(unsigned id)
+{
+	uint64_t seen = 0;
+	for (;;)
+	{
+		RenderParameters rp;
+		{
+			std::unique_lock<std::mutex> holder{ahead.lock};
+			ahead.wake.wait(holder, [&]() { return ahead.generation != seen || ahead.quit; });
+			if (ahead.quit)
+				return;
+			seen = ahead.generation;
+			rp = ahead.parameters;
+		}
+		// scene_lights is only modified after invalidate_prefetch() has seen this job finish
+		if (id == 0)
+		{
+			sort_lights(rp, ahead.sort_state);
+			begin_pack(rp, ahead.sort_state, ahead.result);
+			ahead.num_chunks = int((unsigned(ahead.result.parameters.num_lights) + PackChunk - 1) / PackChunk);
+			ahead.sorted.store(1, std::memory_order_release);
+		}
+		else
+			while (ahead.sorted.load(std::memory_order_acquire) == 0) // thread 0's sort: a few microseconds
+				std::this_thread::yield();
+		for (;;)
+		{
+			const int chunk = ahead.next_chunk.fetch_add(1, std::memory_order_relaxed);
+			if (chunk >= ahead.num_chunks)
+				break;
+			pack_chunk(rp, ahead.sort_state, ahead.result, unsigned(chunk));
+		}
+		if (ahead.workers_left.fetch_sub(1, std::memory_order_acq_rel) == 1)
+		{
+			std::unique_lock<std::mutex> holder{ahead.lock};
+			ahead.done.notify_all();
+		}
+	}
+}
+
+LightClusterer::~LightClusterer()
+{
+	{
+		std::unique_lock<std::mutex> holder{ahead.lock};
+		wait_for_workers(holder);
+		ahead.quit = true;
+		ahead.wake.notify_all();
+	}
+	for (auto &t : ahead.threads)
+		if (t.joinable())
+			t.join();
+}
+
+void LightClusterer::sort_lights(const RenderParameters &rp, SortState &sort) const
 {
 	// Visible positional lights, nearest first along the view direction, so that the per-slice [first, last] index
 	// window produced by the z-range kernel is tight.  Same result as a stable sort of the scene list by
 	// dot(translation, front) (the reference sorts the list with that comparator), done as: one key per light, then
 	// either "last frame's order is still sorted" (static lights + camera: O(n) check) or a stable LSD radix sort.
+	auto &sort_keys = sort.sort_keys;
+	auto &sort_order = sort.sort_order;
+	auto &sort_scratch = sort.sort_scratch;
 	const size_t count = scene_lights ? scene_lights->size() : 0;
-	const vec3 front = context_.get_render_parameters().camera_front;
+	const vec3 front = rp.camera_front;
 	sort_keys.resize(count);
 	for (size_t i = 0; i < count; i++)
 	{
@@ -84,75 +218,50 @@ void LightClusterer::refresh(const RenderContext &context_, TaskComposer &)
 		const uint32_t a = sort_order[i - 1], b = sort_order[i];
 		sorted = sort_keys[a] < sort_keys[b] || (sort_keys[a] == sort_keys[b] && a < b);
 	}
-	if (!sorted)
-	{
-		sort_order.resize(count);
-		sort_scratch.resize(count);
-		for (size_t i = 0; i < count; i++)
-			sort_order[i] = uint32_t(i);
-		// 3 passes of 11 bits, least significant first; each pass is stable, ties keep scene order.
-		uint32_t *src = sort_order.data(), *dst = sort_scratch.data();
-		for (unsigned shift = 0; shift < 33; shift += 11)
-		{
-			uint32_t histogram[2048] = {};
-			for (size_t i = 0; i < count; i++)
-				histogram[(sort_keys[src[i]] >> shift) & 2047u]++;
-			uint32_t sum = 0;
-			for (auto &h : histogram)
-			{
-				uint32_t c = h;
-				h = sum;
-				sum += c;
-			}
-			for (size_t i = 0; i < count; i++)
-				dst[histogram[(sort_keys[src[i]] >> shift) & 2047u]++] = src[i];
-			std::swap(src, dst);
-		}
-		if (src != sort_order.data())
-			sort_order.swap(sort_scratch);
-	}
-
-	light_sort_cache.resize(count);
+	if (sorted)
+		return;
+	sort_order.resize(count);
+	sort_scratch.resize(count);
 	for (size_t i = 0; i < count; i++)
-		light_sort_cache[i] = (*scene_lights)[sort_order[i]];
-	refresh_bindless_prepare(context_);
+		sort_order[i] = uint32_t(i);
+	// 3 passes of 11 bits, least significant first; each pass is stable, ties keep scene order.
+	uint32_t *src = sort_order.data(), *dst = sort_scratch.data();
+	for (unsigned shift = 0; shift < 33; shift += 11)
+	{
+		uint32_t histogram[2048] = {};
+		for (size_t i = 0; i < count; i++)
+			histogram[(sort_keys[src[i]] >> shift) & 2047u]++;
+		uint32_t sum = 0;
+		for (auto &h : histogram)
+		{
+			uint32_t c = h;
+			h = sum;
+			sum += c;
+		}
+		for (size_t i = 0; i < count; i++)
+			dst[histogram[(sort_keys[src[i]] >> shift) & 2047u]++] = src[i];
+		std::swap(src, dst);
+	}
+	if (src != sort_order.data())
+		sort_order.swap(sort_scratch);
 }
 
-void LightClusterer::refresh_bindless_prepare(const RenderContext &context_)
+// Sizes the outputs and fills the cluster parameters; the per-light records follow chunk by chunk (pack_chunk).
+void LightClusterer::begin_pack(const RenderParameters &rp, const SortState &sort, PackedLights &out) const
 {
-	memset(bindless.type_mask, 0, sizeof(bindless.type_mask));
-	bindless.lights.clear();
-	bindless.model.clear();
+	// lights beyond the bindless maximum are dropped
+	const size_t count = std::min(sort.sort_order.size(), size_t(MaxLightsBindless));
+	memset(out.type_mask, 0, sizeof(out.type_mask));
+	out.lights.resize(count);
+	out.model.resize(count);
+	// The z-range kernel must still run with no lights so that the range buffer is cleared to "empty".
+	out.volume_index_range.resize(std::max(count, size_t(1)));
+	if (count == 0)
+		out.volume_index_range[0] = uvec2(~0u, 0u);
 
-	for (auto &entry : light_sort_cache)
-	{
-		if (bindless.lights.size() >= MaxLightsBindless)
-			break; // lights beyond the bindless maximum are dropped
-		unsigned index = unsigned(bindless.lights.size());
-		if (entry.light->get_type() == PositionalLight::Type::Spot)
-		{
-			auto &spot = static_cast<SpotLight &>(*entry.light);
-			bindless.lights.push_back(spot.get_shader_info(*entry.transform));
-			bindless.model.push_back(spot.build_model_matrix(*entry.transform));
-		}
-		else
-		{
-			auto &point = static_cast<PointLight &>(*entry.light);
-			auto info = point.get_shader_info(*entry.transform);
-			bindless.lights.push_back(info);
-			mat_affine m;
-			m[0] = vec4(info.position[0], info.position[1], info.position[2], 1.0f / info.inv_radius);
-			m[1] = vec4(0.0f);
-			m[2] = vec4(0.0f);
-			bindless.model.push_back(m);
-			bindless.type_mask[index >> 5] |= 1u << (index & 31u);
-		}
-	}
-
-	auto &rp = context_.get_render_parameters();
-	auto &p = bindless.parameters;
+	auto &p = out.parameters;
 	p = {};
-	p.num_lights = int32_t(bindless.lights.size());
+	p.num_lights = int32_t(count);
 	p.num_lights_32 = (p.num_lights + 31) / 32;
 	p.clip_scale[0] = rp.projection[0][0];
 	p.clip_scale[1] = -rp.projection[1][1];
@@ -179,13 +288,47 @@ void LightClusterer::refresh_bindless_prepare(const RenderContext &context_)
 	p.resolution_xy[1] = int32_t(resolution_y);
 	p.inv_resolution_xy[0] = 1.0f / float(resolution_x);
 	p.inv_resolution_xy[1] = 1.0f / float(resolution_y);
-	p.z_scale = 1.0f / get_z_slice_extent(context_);
+	p.z_scale = 1.0f / get_z_slice_extent(rp);
 	p.z_max_index = int32_t(resolution_z) - 1;
 }
 
-uvec2 LightClusterer::compute_uint_range(vec2 range) const
+// Lights [chunk * PackChunk, (chunk + 1) * PackChunk) of the sorted order: shader records, cull volumes, type bits and
+// the per-light slice intervals of the z-range kernel (clusterer.cpp:656-698,1265-1275).
+void LightClusterer::pack_chunk(const RenderParameters &rp, const SortState &sort, PackedLights &out, unsigned chunk) const
 {
-	float extent = get_z_slice_extent(*context);
+	const unsigned begin = chunk * PackChunk;
+	const unsigned end = std::min(begin + unsigned(PackChunk), unsigned(out.parameters.num_lights));
+	for (unsigned index = begin; index < end; index++)
+	{
+		const PositionalLightInfo &entry = (*scene_lights)[sort.sort_order[index]];
+		vec2 range;
+		if (entry.light->get_type() == PositionalLight::Type::Spot)
+		{
+			auto &spot = static_cast<SpotLight &>(*entry.light);
+			out.lights[index] = spot.get_shader_info(*entry.transform);
+			out.model[index] = spot.build_model_matrix(*entry.transform);
+			range = spot_light_z_range(rp, out.model[index]);
+		}
+		else
+		{
+			auto &point = static_cast<PointLight &>(*entry.light);
+			const auto info = point.get_shader_info(*entry.transform);
+			out.lights[index] = info;
+			mat_affine m;
+			m[0] = vec4(info.position[0], info.position[1], info.position[2], 1.0f / info.inv_radius);
+			m[1] = vec4(0.0f);
+			m[2] = vec4(0.0f);
+			out.model[index] = m;
+			out.type_mask[index >> 5] |= 1u << (index & 31u);
+			range = point_light_z_range(rp, vec3(info.position[0], info.position[1], info.position[2]), 1.0f / info.inv_radius);
+		}
+		out.volume_index_range[index] = compute_uint_range(rp, range);
+	}
+}
+
+uvec2 LightClusterer::compute_uint_range(const RenderParameters &rp, vec2 range) const
+{
+	float extent = get_z_slice_extent(rp);
 	range = vec2(range.x / extent, range.y / extent);
 	if (range.y < 0.0f)
 		return uvec2(0xffffffffu, 0u);
@@ -201,13 +344,12 @@ void LightClusterer::update_bindless_data(HIP::CommandBuffer &cmd)
 	// The reference records three cmd.update_buffer here and a fourth (the per-light slice intervals) before the z-range
 	// dispatch (clusterer.cpp:1178-1207,1302).  All four are staged now and uploaded by ONE kernel: nothing on the GPU
 	// reads any of them before this point, and a copy-engine transfer in the middle of the pass costs more than the pass.
-	compute_volume_index_ranges();
-	uint32_t count = uint32_t(bindless.parameters.num_lights);
-	auto &ranges = bindless.volume_index_range;
+	uint32_t count = uint32_t(packed.parameters.num_lights);
+	auto &ranges = packed.volume_index_range;
 	const HIP::CommandBuffer::BufferUpdate updates[] = {
-		{bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_LIGHTS, count * sizeof(PositionalFragmentInfo), bindless.lights.data()},
-		{bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_MODEL, count * sizeof(mat_affine), bindless.model.data()},
-		{bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_TYPE_MASK, bindless.parameters.num_lights_32 * sizeof(uint32_t), bindless.type_mask},
+		{bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_LIGHTS, count * sizeof(PositionalFragmentInfo), packed.lights.data()},
+		{bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_MODEL, count * sizeof(mat_affine), packed.model.data()},
+		{bindless.transforms_buffer, GR_TRANSFORMS_OFFSET_TYPE_MASK, packed.parameters.num_lights_32 * sizeof(uint32_t), packed.type_mask},
 		{bindless.light_ranges.get(), 0, ranges.size() * sizeof(uvec2), ranges.data()},
 	};
 	cmd.update_buffers(updates, 4);
@@ -215,7 +357,7 @@ void LightClusterer::update_bindless_data(HIP::CommandBuffer &cmd)
 
 void LightClusterer::update_bindless_mask_buffer_gpu(HIP::CommandBuffer &cmd)
 {
-	uint32_t local_count = uint32_t(bindless.parameters.num_lights);
+	uint32_t local_count = uint32_t(packed.parameters.num_lights);
 	if (local_count == 0)
 		return;
 	auto &rp = context->get_render_parameters();
@@ -240,7 +382,7 @@ void LightClusterer::update_bindless_mask_buffer_gpu(HIP::CommandBuffer &cmd)
 	gr_push_cluster_setup setup_push = {};
 	memcpy(setup_push.view, rp.view.data(), sizeof(setup_push.view));
 	setup_push.num_lights = local_count;
-	cmd.check(gr_cluster_setup(cmd.get_context(), cmd.get_stream(), transforms, spots, cull, &bindless.parameters, &setup_push), "cluster_setup");
+	cmd.check(gr_cluster_setup(cmd.get_context(), cmd.get_stream(), transforms, spots, cull, &packed.parameters, &setup_push), "cluster_setup");
 	cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
 	            VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
 
@@ -248,29 +390,8 @@ void LightClusterer::update_bindless_mask_buffer_gpu(HIP::CommandBuffer &cmd)
 		throw std::logic_error("Cluster resolution must be a multiple of 8 in X and Y.");
 	// MI355X executes wave64 only: this is the SUBGROUPS path with an 8x8 cell tile per wave (clusterer.cpp:1546-1552).
 	cmd.check(gr_cluster_binning(cmd.get_context(), cmd.get_stream(), transforms, cull,
-	                             static_cast<uint32_t *>(bindless.bitmask_buffer->get_device_pointer()), &bindless.parameters),
+	                             static_cast<uint32_t *>(bindless.bitmask_buffer->get_device_pointer()), &packed.parameters),
 	          "cluster_binning");
-}
-
-void LightClusterer::compute_volume_index_ranges()
-{
-	uint32_t count = uint32_t(bindless.parameters.num_lights);
-	bindless.volume_index_range.resize(count);
-	for (unsigned i = 0; i < count; i++)
-	{
-		vec2 range;
-		if (bindless_light_is_point(i))
-		{
-			auto &l = bindless.lights[i];
-			range = point_light_z_range(*context, vec3(l.position[0], l.position[1], l.position[2]), 1.0f / l.inv_radius);
-		}
-		else
-			range = spot_light_z_range(*context, bindless.model[i]);
-		bindless.volume_index_range[i] = compute_uint_range(range);
-	}
-	// The kernel must still run with no lights so that the range buffer is cleared to "empty".
-	if (bindless.volume_index_range.empty())
-		bindless.volume_index_range.push_back(uvec2(~0u, 0u));
 }
 
 void LightClusterer::update_bindless_range_buffer_gpu(HIP::CommandBuffer &cmd)
@@ -278,7 +399,7 @@ void LightClusterer::update_bindless_range_buffer_gpu(HIP::CommandBuffer &cmd)
 	if ((resolution_z & 63) != 0)
 		throw std::logic_error("Cluster Z resolution must be a multiple of 64.");
 
-	auto &ranges = bindless.volume_index_range; // uploaded by update_bindless_data
+	auto &ranges = packed.volume_index_range; // uploaded by update_bindless_data
 	gr_push_z_range push = {};
 	push.num_volumes = uint32_t(ranges.size());
 	push.num_volumes_128 = (push.num_volumes + 127) / 128;

@@ -95,14 +95,22 @@ PositionalFragmentInfo PointLight::get_shader_info(const mat_affine &transform) 
 
 vec2 point_light_z_range(const RenderContext &context, const vec3 &center, float radius)
 {
-	auto &params = context.get_render_parameters();
-	float z = dot(center - params.camera_position, params.camera_front);
-	return vec2(z - radius, z + radius);
+	return point_light_z_range(context.get_render_parameters(), center, radius);
 }
 
 vec2 spot_light_z_range(const RenderContext &context, const mat_affine &model)
 {
-	auto &params = context.get_render_parameters();
+	return spot_light_z_range(context.get_render_parameters(), model);
+}
+
+vec2 point_light_z_range(const RenderParameters &params, const vec3 &center, float radius)
+{
+	float z = dot(center - params.camera_position, params.camera_front);
+	return vec2(z - radius, z + radius);
+}
+
+vec2 spot_light_z_range(const RenderParameters &params, const mat_affine &model)
+{
 	vec3 apex = model.get_translation();
 	vec3 x_off = model.get_right(), y_off = model.get_up();
 	vec3 base = apex + model.get_forward();

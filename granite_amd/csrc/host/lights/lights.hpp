@@ -72,4 +72,7 @@ private:
 
 vec2 point_light_z_range(const RenderContext &context, const vec3 &center, float radius); // lights.cpp:330-337
 vec2 spot_light_z_range(const RenderContext &context, const mat_affine &model);           // lights.cpp:339-370
+// the same on bare render parameters (what the clusterer's refresh works from, on whichever thread it runs)
+vec2 point_light_z_range(const RenderParameters &params, const vec3 &center, float radius);
+vec2 spot_light_z_range(const RenderParameters &params, const mat_affine &model);
 } // namespace Granite

@@ -207,6 +207,9 @@ int gra_get_strip_plan(gra_app *app, uint32_t *out24);
 /* Host-side frame-loop cost since creation: out[0] = frames, out[1] = seconds spent inside the frame loop (light
  * refresh + graph execution = launches), out[2] = seconds of those spent blocked on GPU back-pressure. */
 int gra_get_host_stats(gra_app *app, double *out3);
+/* Frames whose light sort + pack (LightClusterer::refresh) had already been done by the clusterer's helper thread while the
+ * previous frame was being enqueued (the reference runs its refreshes as TaskComposer tasks beside command recording). */
+int gra_get_prefetched_refreshes(gra_app *app, uint64_t *out);
 /* compute_rec709_to_st2020 (hdr.cpp:580-593) for display primaries r, g, b, white (CIE xy, 8 floats): column-major 3 x 3. */
 int gra_compute_rec709_to_display(const float *primaries8, float *out9);
 /* Bytes of HBM currently held by the executor's images and buffers (graph attachments, hand-over rings, uploads). */

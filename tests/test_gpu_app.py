@@ -206,3 +206,41 @@ def test_ambient_occlusion_input_of_the_lighting_pass(scene):
                         synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION, ambient_occlusion=ao)
     assert_rgba16f_close(a.read("HDR-main"), want, ulps=2.0, abs_tol=1e-4, what="HDR with ambient occlusion")
     a.close()
+
+
+def test_light_refresh_done_ahead_by_the_helper_thread_is_the_same_refresh(scene):
+    """LightClusterer::refresh of frame N+1 runs on the clusterer's helper thread while frame N is enqueued.  The packed
+    lights, parameters and slice intervals a later frame uploads must be exactly what a synchronous refresh produces (= the
+    oracle's packing), the prefetch must actually be used, and a light or camera change must fall back to packing in place."""
+    cam, gbuf, descs = scene
+    ref = oracle_frames(cam, gbuf, descs, 0)
+    a = make_app(cam, gbuf, descs)
+    a.render_frames(6)
+    assert a.prefetched_refreshes() >= 4
+    st = a.cluster_state()
+    n = ref["n"]
+    np.testing.assert_array_equal(st["lights"][:n * 48], ref["lights"].view(np.uint8)[:n * 48])
+    np.testing.assert_array_equal(st["models"][:n].view(np.uint32), ref["model"][:n].view(np.uint32))
+    np.testing.assert_array_equal(st["type_mask"], ref["type_mask"])
+    np.testing.assert_array_equal(st["params"], ref["prm"].view(np.uint8).reshape(-1))
+    np.testing.assert_array_equal(st["light_ranges"], ref["cluster"]["light_ranges"])
+    first = a.read("HDR-main").copy()
+    # change the lights between frames: the stale prefetch must not be used
+    fewer = descs[:300].copy()
+    a.set_lights(fewer)
+    a.render_frames(3)
+    ref2 = oracle_frames(cam, gbuf, fewer, 0)
+    st2 = a.cluster_state()
+    assert st2["count"] == ref2["n"]
+    np.testing.assert_array_equal(st2["lights"][:ref2["n"] * 48], ref2["lights"].view(np.uint8)[:ref2["n"] * 48])
+    assert_rgba16f_close(a.read("HDR-main"), ref2["hdr"], ulps=2.0, what="HDR-main after a light change")
+    assert (a.read("HDR-main") != first).any()
+    # move the camera between frames
+    cam2 = synth.Camera(cam.width, cam.height, eye=(0.5, 2.2, 8.0))
+    a.set_render_parameters(cam2.render_params())
+    a.render_frames(2)
+    ref3 = oracle_frames(cam2, gbuf, fewer, 0)
+    st3 = a.cluster_state()
+    np.testing.assert_array_equal(st3["params"], ref3["prm"].view(np.uint8).reshape(-1))
+    np.testing.assert_array_equal(st3["lights"][:ref3["n"] * 48], ref3["lights"].view(np.uint8)[:ref3["n"] * 48])
+    a.close()

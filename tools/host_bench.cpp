@@ -34,5 +34,25 @@ int main()
 		auto t1 = std::chrono::steady_clock::now();
 		printf("refresh: %.1f us/frame\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / 100);
 	}
+	// the same with the next frame's refresh running on the helper threads while this thread is busy "submitting" (70 us)
+	for (int rep = 0; rep < 3; rep++)
+	{
+		double waited = 0.0;
+		auto t0 = std::chrono::steady_clock::now();
+		for (int i = 0; i < 200; i++)
+		{
+			auto a = std::chrono::steady_clock::now();
+			cl.refresh(app.get_context(), composer);
+			waited += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count();
+			cl.prefetch(app.get_context().get_render_parameters());
+			auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(70);
+			while (std::chrono::steady_clock::now() < until)
+			{
+			}
+		}
+		auto t1 = std::chrono::steady_clock::now();
+		printf("prefetched: %.1f us/frame in refresh(), %.1f us/frame loop, hits %llu\n", waited / 200,
+		       std::chrono::duration<double, std::micro>(t1 - t0).count() / 200, (unsigned long long)cl.get_prefetch_hits());
+	}
 	return 0;
 }
