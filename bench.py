@@ -177,9 +177,13 @@ def main():
         app.set_lights(descs)
         app.upload_gbuffer(gbuf)
         if bands:
-            ids = [gapp.Application.comm_create_unique_id() if rank == 0 else None]
+            # two RCCL communicators: the 1/8 bloom level meets inside the frame (on the executor's stream), the tonemapped
+            # bands beside it (their own stream; GRANITE_BENCH_GATHER=inframe keeps them in the frame for an A/B)
+            ids = [gapp.Application.comm_create_unique_id() if rank == 0 else None, gapp.Application.comm_create_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             app.comm_init(ids[0], rank, world)
+            if os.environ.get("GRANITE_BENCH_GATHER", "beside") != "inframe":
+                app.comm_init_output(ids[1], rank, world)
         # Set-up, not a step: bake the graph and let the executor allocate what it creates lazily (physical images, the
         # spare copies of hand-over resources, its event rings) so that no hipMalloc lands in a counted frame.  With bands
         # this also runs the first all-gathers.
@@ -335,7 +339,8 @@ def main():
         "config": {"workload": workload_name, "description": desc, "width": width, "height": height, "lights": num_lights,
                    "cluster_grid": list(synth.CLUSTER_RESOLUTION),
                    "parallelism": ("single" if world == 1 else
-                                   f"{world} row bands, RCCL all-gather of the 1/8 bloom level and of the tonemapped bands" if bands else
+                                   f"{world} row bands, RCCL all-gather of the 1/8 bloom level (in frame) and of the tonemapped bands "
+                                   f"({'in frame' if os.environ.get('GRANITE_BENCH_GATHER', 'beside') == 'inframe' else 'beside the frame, own stream + communicator'})" if bands else
                                    f"{world} independent replicas (row-band set-up failed: {fallback_reason})"),
                    "hdr_format": "R16G16B16A16_SFLOAT (fp16 storage, fp32 arithmetic)", "seed": synth.SEED,
                    "timed_region": "cluster build + per-frame light refresh + lighting + bloom pyramid + luminance + tonemap, every frame; "

@@ -272,6 +272,15 @@ int gra_comm_init(gra_app *app, const uint8_t *id128, int32_t rank, int32_t rank
 	});
 }
 
+int gra_comm_init_output(gra_app *app, const uint8_t *id128, int32_t rank, int32_t ranks)
+{
+	return guarded(app, [&]() {
+		if (!id128)
+			throw std::logic_error("gra_comm_init_output: null id");
+		app->app->init_output_collective(id128, rank, ranks);
+	});
+}
+
 int gra_get_strip_plan(gra_app *app, uint32_t *out24)
 {
 	return guarded(app, [&]() {

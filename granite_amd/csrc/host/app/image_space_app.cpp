@@ -1,4 +1,5 @@
 #include "image_space_app.hpp"
+#include <hip/hip_runtime_api.h>
 #include "../gtx.hpp"
 #include "../post/spd.hpp"
 #include <chrono>
@@ -91,6 +92,10 @@ ImageSpaceApplication::~ImageSpaceApplication()
 {
 	cluster.invalidate_prefetch(); // no helper-thread job may outlive the light objects it reads
 	wait_idle();
+	for (auto &e : output_gather_done)
+		(void)hipEventDestroy(static_cast<hipEvent_t>(e.second));
+	if (output_ready_event)
+		(void)hipEventDestroy(static_cast<hipEvent_t>(output_ready_event));
 }
 
 void ImageSpaceApplication::set_exchange_callback(gra_exchange_fn fn, void *user)
@@ -114,6 +119,50 @@ void ImageSpaceApplication::init_collective(const uint8_t *id128, int rank, int 
 	collective.init(id128, rank, ranks);
 	strip_plan.exchange = [this](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *) {
 		collective.all_gather_in_place(image.get_device_pointer(), size_t(chunk_rows) * image.get_view().pitch_bytes, cmd.get_stream());
+	};
+}
+
+void ImageSpaceApplication::init_output_collective(const uint8_t *id128, int rank, int ranks)
+{
+	if (unsigned(ranks) != strip_plan.count || unsigned(rank) != strip_plan.index)
+		throw std::logic_error("Collective rank / size must match the strip plan of this instance.");
+	if (!collective.is_initialized())
+		throw std::logic_error("init_output_collective: initialise the in-frame communicator (gra_comm_init) first.");
+	auto &device = get_device();
+	device.make_current();
+	output_collective.init(id128, rank, ranks);
+	hipEvent_t ready;
+	if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess)
+		throw std::runtime_error("hipEventCreate failed");
+	output_ready_event = ready;
+
+	// The pass that writes an output image first waits for the gather that last touched it (four swapchain images rotate, so
+	// that gather is normally long finished) ...
+	strip_plan.acquire_output = [this](HIP::CommandBuffer &cmd, HIP::Image &image) {
+		auto itr = output_gather_done.find(image.get_device_pointer());
+		if (itr != output_gather_done.end() && hipEventQuery(static_cast<hipEvent_t>(itr->second)) != hipSuccess)
+			if (hipStreamWaitEvent(static_cast<hipStream_t>(cmd.get_stream()), static_cast<hipEvent_t>(itr->second), 0) != hipSuccess)
+				throw std::runtime_error("hipStreamWaitEvent failed");
+	};
+	// ... and the gather itself runs on the collective stream behind the band's tonemap, beside whatever the executor's
+	// streams do next (the following frames' cluster build, lighting and bloom chain).
+	strip_plan.exchange_output = [this](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *) {
+		auto gather_stream = static_cast<hipStream_t>(get_device().get_collective_stream());
+		auto ready_event = static_cast<hipEvent_t>(output_ready_event);
+		if (hipEventRecord(ready_event, static_cast<hipStream_t>(cmd.get_stream())) != hipSuccess ||
+		    hipStreamWaitEvent(gather_stream, ready_event, 0) != hipSuccess)
+			throw std::runtime_error("output gather: event hand-over failed");
+		output_collective.all_gather_in_place(image.get_device_pointer(), size_t(chunk_rows) * image.get_view().pitch_bytes, gather_stream);
+		void *&done = output_gather_done[image.get_device_pointer()];
+		if (!done)
+		{
+			hipEvent_t e;
+			if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+				throw std::runtime_error("hipEventCreate failed");
+			done = e;
+		}
+		if (hipEventRecord(static_cast<hipEvent_t>(done), gather_stream) != hipSuccess)
+			throw std::runtime_error("hipEventRecord failed");
 	};
 }
 

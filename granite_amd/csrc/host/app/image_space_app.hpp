@@ -4,6 +4,7 @@
 // headless platform's external 4-image swapchain (application/platforms/application_headless.cpp:145-148,207-229).
 #pragma once
 #include <memory>
+#include <unordered_map>
 #include <unordered_set>
 #include <string>
 #include <vector>
@@ -58,6 +59,9 @@ public:
 	const StripPlan &get_strip_plan() const { return strip_plan; }
 	void set_exchange_callback(gra_exchange_fn fn, void *user);
 	void init_collective(const uint8_t *id128, int rank, int ranks);
+	// Second communicator: the all-gather of the tonemapped bands moves to the device's collective stream and overlaps the
+	// next frame ("overlap B with the next frame's lighting").
+	void init_output_collective(const uint8_t *id128, int rank, int ranks);
 	// Host-side cost of the frame loop: frames rendered, wall seconds inside render_frame(), of which blocked on the GPU.
 	size_t get_allocated_bytes() const { return device_holder ? device_holder->get_allocated_bytes() : 0; }
 	void get_host_stats(double out[3]) const
@@ -86,7 +90,10 @@ private:
 	TaskComposer composer;
 	HDROptions hdr_options;
 	StripPlan strip_plan;
-	HIP::Collective collective;
+	HIP::Collective collective, output_collective;
+	// per output image: the event its last beside-the-frame gather records on the collective stream
+	std::unordered_map<const void *, void *> output_gather_done;
+	void *output_ready_event = nullptr;
 	TemporalJitter jitter;
 	mat4 base_projection, base_view;
 	bool has_base_camera = false;

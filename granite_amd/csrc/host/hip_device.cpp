@@ -200,6 +200,8 @@ Device::~Device()
 	for (auto &s : streams)
 		if (s)
 			(void)hipStreamDestroy(static_cast<hipStream_t>(s));
+	if (collective_stream)
+		(void)hipStreamDestroy(static_cast<hipStream_t>(collective_stream));
 	if (ctx)
 		gr_destroy(ctx);
 }
@@ -255,5 +257,18 @@ void Device::wait_idle()
 {
 	for (auto &s : streams)
 		throw_hip(hipStreamSynchronize(static_cast<hipStream_t>(s)), "hipStreamSynchronize");
+	if (collective_stream)
+		throw_hip(hipStreamSynchronize(static_cast<hipStream_t>(collective_stream)), "hipStreamSynchronize");
+}
+
+gr_stream Device::get_collective_stream()
+{
+	if (!collective_stream)
+	{
+		hipStream_t stream;
+		throw_hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+		collective_stream = stream;
+	}
+	return collective_stream;
 }
 } // namespace HIP

@@ -122,6 +122,9 @@ public:
 	int get_device_index() const { return index; }
 	void make_current() const; // hipSetDevice for the calling thread
 	gr_stream get_stream(CommandBuffer::Type type) const { return streams[int(type)]; }
+	// A fourth in-order stream for collectives that run beside the frame (the output all-gather of row-band tiling):
+	// created on first use, drained by wait_idle() like the executor's own.
+	gr_stream get_collective_stream();
 
 	ImageHandle create_image(unsigned width, unsigned height, VkFormat format, const std::string &name, unsigned levels = 1);
 	BufferHandle create_buffer(size_t size, VkBufferUsageFlags usage, const std::string &name);
@@ -145,6 +148,7 @@ private:
 	int index;
 	gr_ctx *ctx = nullptr;
 	gr_stream streams[int(CommandBuffer::Type::Count)] = {};
+	gr_stream collective_stream = nullptr;
 	struct StagingFrame
 	{
 		uint8_t *base = nullptr;

@@ -116,12 +116,16 @@ void record_tonemap(RenderPass &pass, HIP::CommandBuffer &cmd, const RenderTextu
 	auto &output = graph.get_physical_texture_resource(*pass.get_color_outputs()[0]);
 	gr_push_tonemap push = {iface ? iface->get_exposure() : 1.0f};
 	gr_rows rows;
+	if (strip && strip->acquire_output)
+		strip->acquire_output(cmd, output);
 	if (to_rows(strip ? &strip->tonemap : nullptr, rows))
 		cmd.check(gr_tonemap_rows(cmd.get_context(), cmd.get_stream(), &hdr.get_view(), &bloom.get_view(), &output.get_view(),
 		                          luminance_ptr(graph, ubo), &push, &rows),
 		          "tonemap");
 	// Row-band tiling: the tonemapped bands of all ranks meet in every rank's output image.
-	if (strip && strip->exchange)
+	if (strip && strip->exchange_output)
+		strip->exchange_output(cmd, output, strip->out_chunk_rows, "tonemapped");
+	else if (strip && strip->exchange)
 		strip->exchange(cmd, output, strip->out_chunk_rows, "tonemapped");
 }
 

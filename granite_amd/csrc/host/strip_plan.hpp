@@ -48,5 +48,11 @@ struct StripPlan
 	// is padded to count * chunk_rows rows).  Installed by the application; runs on the command buffer's stream.
 	using ExchangeHook = std::function<void(HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *tag)>;
 	ExchangeHook exchange;
+	// Optional: the all-gather of the tonemapped bands, issued beside the frame instead of inside it (its own stream and
+	// communicator), so that it overlaps the next frame; `exchange` is then only used for the 1/8 bloom level.  Together
+	// with acquire_output, which the pass that writes the output image calls first: it makes the writing stream wait for the
+	// previous gather that still reads or writes that image.
+	ExchangeHook exchange_output;
+	std::function<void(HIP::CommandBuffer &cmd, HIP::Image &image)> acquire_output;
 };
 } // namespace Granite

@@ -200,6 +200,10 @@ int gra_set_exchange_callback(gra_app *app, gra_exchange_fn fn, void *user);
  * config's strip_count and rank its strip_index. */
 int gra_comm_create_unique_id(uint8_t *id128);
 int gra_comm_init(gra_app *app, const uint8_t *id128, int32_t rank, int32_t ranks);
+/* Optional second communicator (its own id from gra_comm_create_unique_id, after gra_comm_init): the all-gather of the
+ * tonemapped bands then runs on a stream of its own behind each frame's tonemap and overlaps the following frames instead of
+ * sitting on the back-of-frame stream.  gra_sync / readbacks wait for it. */
+int gra_comm_init_output(gra_app *app, const uint8_t *id128, int32_t rank, int32_t ranks);
 /* The band plan of this instance: out[0..3] = index, count, width, height; then {whole, first, count} for lighting,
  * threshold, downsample-0, downsample-1, upsample-0, tonemap; then d1_chunk_rows, out_chunk_rows (24 values). */
 int gra_get_strip_plan(gra_app *app, uint32_t *out24);

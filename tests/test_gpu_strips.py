@@ -99,3 +99,32 @@ def test_single_rank_rccl_exchange_is_identity():
     with pytest.raises(capi.GraniteHipError):
         a.comm_init(uid, 0, 1)  # already initialised
     a.close()
+
+
+def test_output_gather_beside_the_frame_gives_the_same_frames():
+    """The tonemapped bands gathered on the device's collective stream through a second communicator (gra_comm_init_output),
+    overlapping the following frames: un-synchronised runs of more frames than there are swapchain images (so that the
+    write-after-gather wait is exercised) must leave the same backbuffer, exposure and history as the in-frame form."""
+    w, h = 480, 270
+    cam = synth.Camera(w, h)
+    gbuf = synth.make_gbuffer(cam)
+    descs = synth.make_lights(cam, 200)
+    results = []
+    for beside in (False, True):
+        a = make_app(w, h, cam, gbuf, descs)
+        a.comm_init(gapp.Application.comm_create_unique_id(), 0, 1)
+        if beside:
+            with pytest.raises(capi.GraniteHipError):
+                a.comm_init_output(gapp.Application.comm_create_unique_id(), 1, 2)  # does not match this instance's plan
+            a.comm_init_output(gapp.Application.comm_create_unique_id(), 0, 1)
+        a.render_frames(11, sync=False)
+        a.sync()
+        results.append((a.read_backbuffer().copy(), a.read("average-luminance").copy(), a.read("downsample-3").copy()))
+        a.close()
+    for got, want in zip(results[1], results[0]):
+        np.testing.assert_array_equal(got, want)
+    # without the in-frame communicator there is nothing to move beside the frame
+    b = make_app(w, h, cam, gbuf, descs)
+    with pytest.raises(capi.GraniteHipError):
+        b.comm_init_output(gapp.Application.comm_create_unique_id(), 0, 1)
+    b.close()
