@@ -218,6 +218,10 @@ def load_library() -> C.CDLL:
         "gr_bloom_downsample": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushBloomDownsample)]),
         "gr_bloom_upsample": (C.c_int, [vp, vp, P(Image), P(Image), P(PushBloomUpsample)]),
         "gr_luminance": (C.c_int, [vp, vp, P(Image), vp, P(PushLuminance)]),
+        "gr_bloom_tail_supported": (C.c_int, [P(Image), P(Image), P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample),
+                                              P(PushBloomUpsample), P(PushBloomUpsample)]),
+        "gr_bloom_down_tail": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample)]),
+        "gr_bloom_up_tail": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushBloomUpsample), P(PushBloomUpsample), P(PushLuminance)]),
         "gr_tonemap": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushTonemap)]),
         "gr_bloom_threshold_rows": (C.c_int, [vp, vp, P(Image), P(Image), vp, P(PushBloomThreshold), P(Rows)]),
         "gr_bloom_downsample_rows": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushBloomDownsample), P(Rows)]),
@@ -398,6 +402,23 @@ class Context:
         push = PushBloomUpsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height),
                                  (1.0 / src.width, 1.0 / src.height))
         self.check(self.lib.gr_bloom_upsample_rows(self.handle, stream, src.desc, out.desc, push, self._rows(rows)))
+
+    def bloom_tail(self, d1: DeviceImage, d2: DeviceImage, d3: DeviceImage, history: DeviceImage, u2: DeviceImage, u1: DeviceImage,
+                   feedback_lerp: float, lum_ptr=None, lum_lerp: float = 0.0, stream=None) -> bool:
+        """downsample-2, downsample-3 (+ feedback), luminance, upsample-2, upsample-1 as the two fused launches; False (nothing
+        launched) when the pyramid does not qualify."""
+        def down(out, src):
+            return PushBloomDownsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height), (1.0 / src.width, 1.0 / src.height), feedback_lerp)
+
+        def up(out, src):
+            return PushBloomUpsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height), (1.0 / src.width, 1.0 / src.height))
+        p_d2, p_d3, p_u2, p_u1 = down(d2, d1), down(d3, d2), up(u2, d3), up(u1, u2)
+        if not self.lib.gr_bloom_tail_supported(d1.desc, d2.desc, d3.desc, u2.desc, u1.desc, p_d2, p_d3, p_u2, p_u1):
+            return False
+        self.check(self.lib.gr_bloom_down_tail(self.handle, stream, d1.desc, d2.desc, d3.desc, history.desc, p_d2, p_d3))
+        p_lum = PushLuminance((d3.width // 2, d3.height // 2), lum_lerp, -3.0, 2.0) if lum_ptr is not None else None
+        self.check(self.lib.gr_bloom_up_tail(self.handle, stream, d3.desc, u2.desc, u1.desc, lum_ptr, p_u2, p_u1, p_lum))
+        return True
 
     def luminance(self, d3: DeviceImage, lum_ptr, lerp: float, min_loglum: float = -3.0, max_loglum: float = 2.0, stream=None):
         push = PushLuminance((d3.width // 2, d3.height // 2), lerp, min_loglum, max_loglum)

@@ -93,24 +93,34 @@ __device__ __forceinline__ float4 fma4(float4 a, float s, float4 c)
 	return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
 }
 
-// StockSampler::LinearClamp, LOD 0, on an RGBA16F image: unnormalised coordinate uv*size - 0.5, exact fp32 weights.
-__device__ __forceinline__ float4 sample_linear_rgba16f(const DevImage &img, float u, float v)
+// StockSampler::LinearClamp, LOD 0, unnormalised coordinate uv*size - 0.5, exact fp32 weights, over any source of
+// texels: fetch(x, y) takes coordinates already clamped to the image and returns the
+// four channels as fp32 (sample_linear_rgba16f is this with a global-memory fetch; the fused pyramid kernels fetch a staged
+// tile from LDS).  One definition, so that every path weighs and sums in the same order.
+template <typename Fetch>
+__device__ __forceinline__ float4 sample_linear_with(Fetch fetch, int w, int h, float u, float v)
 {
-	const float fx = u * float(img.w) - 0.5f;
-	const float fy = v * float(img.h) - 0.5f;
+	const float fx = u * float(w) - 0.5f;
+	const float fy = v * float(h) - 0.5f;
 	const float flx = floorf(fx), fly = floorf(fy);
 	const float a = fx - flx, b = fy - fly;
 	const int ix = int(flx), iy = int(fly);
-	const int x0 = clampi(ix, 0, img.w - 1), x1 = clampi(ix + 1, 0, img.w - 1);
-	const int y0 = clampi(iy, 0, img.h - 1), y1 = clampi(iy + 1, 0, img.h - 1);
-	const float4 t00 = load_rgba16f(img, x0, y0), t10 = load_rgba16f(img, x1, y0);
-	const float4 t01 = load_rgba16f(img, x0, y1), t11 = load_rgba16f(img, x1, y1);
+	const int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
+	const int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
+	const float4 t00 = fetch(x0, y0), t10 = fetch(x1, y0);
+	const float4 t01 = fetch(x0, y1), t11 = fetch(x1, y1);
 	const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
 	float4 r = t00 * w00;
 	r = fma4(t10, w10, r);
 	r = fma4(t01, w01, r);
 	r = fma4(t11, w11, r);
 	return r;
+}
+
+// StockSampler::LinearClamp, LOD 0, on an RGBA16F image: unnormalised coordinate uv*size - 0.5, exact fp32 weights.
+__device__ __forceinline__ float4 sample_linear_rgba16f(const DevImage &img, float u, float v)
+{
+	return sample_linear_with([&img](int x, int y) { return load_rgba16f(img, x, y); }, img.w, img.h, u, v);
 }
 
 __device__ __forceinline__ float saturatef(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }

@@ -106,6 +106,72 @@ void record_upsample(HIP::CommandBuffer &cmd, RenderGraph &graph, const RenderTe
 	          "bloom_upsample");
 }
 
+gr_push_bloom_downsample downsample_push(const FrameParameters &frame, HIP::ImageView &output, HIP::ImageView &input)
+{
+	gr_push_bloom_downsample push = {};
+	push.threads[0] = output.get_width();
+	push.threads[1] = output.get_height();
+	push.inv_output_size[0] = 1.0f / float(push.threads[0]);
+	push.inv_output_size[1] = 1.0f / float(push.threads[1]);
+	push.inv_input_size[0] = 1.0f / float(input.get_width());
+	push.inv_input_size[1] = 1.0f / float(input.get_height());
+	push.lerp = float(1.0 - std::pow(0.001, frame.frame_time));
+	return push;
+}
+
+gr_push_bloom_upsample upsample_push(HIP::ImageView &output, HIP::ImageView &input)
+{
+	gr_push_bloom_upsample push = {};
+	push.threads[0] = output.get_width();
+	push.threads[1] = output.get_height();
+	push.inv_output_size[0] = 1.0f / float(push.threads[0]);
+	push.inv_output_size[1] = 1.0f / float(push.threads[1]);
+	push.inv_input_size[0] = 1.0f / float(input.get_width());
+	push.inv_input_size[1] = 1.0f / float(input.get_height());
+	return push;
+}
+
+// The dispatches hdr.cpp:364-377 records for downsample-2, downsample-3, the luminance reduction, upsample-2 and upsample-1,
+// as the two fused launches of the C ABI when the pyramid qualifies (gr_bloom_tail_supported); returns false otherwise and
+// records nothing.  Same values in every level either way.
+bool record_pyramid_tail(HIP::CommandBuffer &cmd, const FrameParameters &frame, RenderGraph &graph, const RenderTextureResource &d1_res,
+                         const RenderTextureResource &d2_res, const RenderTextureResource &d3_res, const RenderTextureResource &u2_res,
+                         const RenderTextureResource &u1_res, const RenderBufferResource *lum_res)
+{
+	auto &d1 = graph.get_physical_texture_resource(d1_res);
+	auto &d2 = graph.get_physical_texture_resource(d2_res);
+	auto &d3 = graph.get_physical_texture_resource(d3_res);
+	auto &u2 = graph.get_physical_texture_resource(u2_res);
+	auto &u1 = graph.get_physical_texture_resource(u1_res);
+	HIP::ImageView *history = graph.get_physical_history_texture_resource(d3_res); // null on frame 0
+	if (!history)
+		return false;
+	const gr_push_bloom_downsample push_d2 = downsample_push(frame, d2, d1), push_d3 = downsample_push(frame, d3, d2);
+	const gr_push_bloom_upsample push_u2 = upsample_push(u2, d3), push_u1 = upsample_push(u1, u2);
+	if (!gr_bloom_tail_supported(&d1.get_view(), &d2.get_view(), &d3.get_view(), &u2.get_view(), &u1.get_view(), &push_d2, &push_d3, &push_u2, &push_u1))
+		return false;
+	cmd.check(gr_bloom_down_tail(cmd.get_context(), cmd.get_stream(), &d1.get_view(), &d2.get_view(), &d3.get_view(), &history->get_view(), &push_d2,
+	                             &push_d3),
+	          "bloom_down_tail");
+	cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
+	            VK_ACCESS_2_SHADER_SAMPLED_READ_BIT);
+	gr_push_luminance push_lum = {};
+	gr_luminance_data *lum = nullptr;
+	if (lum_res)
+	{
+		push_lum.size[0] = d3.get_width() / 2;
+		push_lum.size[1] = d3.get_height() / 2;
+		push_lum.lerp = float(1.0 - std::pow(0.5, frame.frame_time));
+		push_lum.min_loglum = -3.0f;
+		push_lum.max_loglum = 2.0f;
+		lum = static_cast<gr_luminance_data *>(graph.get_physical_buffer_resource(*lum_res).get_device_pointer());
+	}
+	cmd.check(gr_bloom_up_tail(cmd.get_context(), cmd.get_stream(), &d3.get_view(), &u2.get_view(), &u1.get_view(), lum, &push_u2, &push_u1,
+	                           lum ? &push_lum : nullptr),
+	          "bloom_up_tail");
+	return true;
+}
+
 // tonemap_build_render_pass (hdr.cpp:283-306)
 void record_tonemap(RenderPass &pass, HIP::CommandBuffer &cmd, const RenderTextureResource &hdr_res, const RenderTextureResource &bloom_res,
                     const RenderBufferResource *ubo, const HDRDynamicExposureInterface *iface, const StripPlan *strip = nullptr)
@@ -186,15 +252,18 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 		if (strip && strip->exchange)
 			strip->exchange(cmd, graph.get_physical_texture_resource(d1), strip->d1_chunk_rows, "downsample-1");
 		compute_to_compute();
-		record_downsample(cmd, frame, graph, d2, d1, nullptr);
-		compute_to_compute();
-		record_downsample(cmd, frame, graph, d3, d2, &d3);
-		compute_to_compute();
-		if (ubo)
-			record_luminance(cmd, frame, graph, *ubo, d3);
-		record_upsample(cmd, graph, u2, d3);
-		compute_to_compute();
-		record_upsample(cmd, graph, u1, u2);
+		if (!record_pyramid_tail(cmd, frame, graph, d1, d2, d3, u2, u1, ubo))
+		{
+			record_downsample(cmd, frame, graph, d2, d1, nullptr);
+			compute_to_compute();
+			record_downsample(cmd, frame, graph, d3, d2, &d3);
+			compute_to_compute();
+			if (ubo)
+				record_luminance(cmd, frame, graph, *ubo, d3);
+			record_upsample(cmd, graph, u2, d3);
+			compute_to_compute();
+			record_upsample(cmd, graph, u1, u2);
+		}
 		compute_to_compute();
 		record_upsample(cmd, graph, u0, u1, strip ? &strip->u0 : nullptr);
 	});

@@ -113,18 +113,34 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold_
 }
 
 // ---- 9-tap tent (bloom_downsample.comp:30-38 / bloom_upsample.comp:25-33) --------------------------------------------
+// `sample(u, v)` is a LinearClamp fetch of the input level; the tap order is the shaders'.
+template <typename Sample>
+__device__ __forceinline__ float4 tent9_with(Sample sample, float u, float v, float ox, float oy)
+{
+	float4 value = sample(u, v) * 0.25f;
+	value = fma4(sample(u - ox, v + oy), 0.0625f, value);
+	value = fma4(sample(u, v + oy), 0.125f, value);
+	value = fma4(sample(u + ox, v + oy), 0.0625f, value);
+	value = fma4(sample(u - ox, v), 0.125f, value);
+	value = fma4(sample(u + ox, v), 0.125f, value);
+	value = fma4(sample(u - ox, v - oy), 0.0625f, value);
+	value = fma4(sample(u, v - oy), 0.125f, value);
+	value = fma4(sample(u + ox, v - oy), 0.0625f, value);
+	return value;
+}
 __device__ __forceinline__ float4 tent9(const DevImage &in, float u, float v, float ox, float oy)
 {
-	float4 value = sample_linear_rgba16f(in, u, v) * 0.25f;
-	value = fma4(sample_linear_rgba16f(in, u - ox, v + oy), 0.0625f, value);
-	value = fma4(sample_linear_rgba16f(in, u, v + oy), 0.125f, value);
-	value = fma4(sample_linear_rgba16f(in, u + ox, v + oy), 0.0625f, value);
-	value = fma4(sample_linear_rgba16f(in, u - ox, v), 0.125f, value);
-	value = fma4(sample_linear_rgba16f(in, u + ox, v), 0.125f, value);
-	value = fma4(sample_linear_rgba16f(in, u - ox, v - oy), 0.0625f, value);
-	value = fma4(sample_linear_rgba16f(in, u, v - oy), 0.125f, value);
-	value = fma4(sample_linear_rgba16f(in, u + ox, v - oy), 0.0625f, value);
-	return value;
+	return tent9_with([&in](float su, float sv) { return sample_linear_rgba16f(in, su, sv); }, u, v, ox, oy);
+}
+
+// Temporal feedback of the last downsample level (hdr.cpp:160-166): NearestClamp fetch of the previous frame's level at the
+// same texel, mix(history, value, vec4(lerp, lerp, lerp, 1)).
+__device__ __forceinline__ float4 apply_feedback(float4 value, const DevImage &history, float u, float v, float l)
+{
+	const int hx = clampi(int(floorf(u * float(history.w))), 0, history.w - 1);
+	const int hy = clampi(int(floorf(v * float(history.h))), 0, history.h - 1);
+	const float4 h = load_rgba16f(history, hx, hy);
+	return make_float4(h.x * (1.0f - l) + value.x * l, h.y * (1.0f - l) + value.y * l, h.z * (1.0f - l) + value.z * l, value.w);
 }
 
 template <bool FEEDBACK>
@@ -141,16 +157,7 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_downsample
 	const float v = (float(y) + 0.5f) * push.inv_output_size[1];
 	float4 value = tent9(in, u, v, 1.75f * push.inv_input_size[0], 1.75f * push.inv_input_size[1]);
 	if (FEEDBACK)
-	{
-		// NearestClamp fetch of the previous frame's level at the same texel (hdr.cpp:160-166).
-		const int hx = clampi(int(floorf(u * float(history.w))), 0, history.w - 1);
-		const int hy = clampi(int(floorf(v * float(history.h))), 0, history.h - 1);
-		const float4 h = load_rgba16f(history, hx, hy);
-		const float l = push.lerp;
-		// mix(history, value, vec4(lerp, lerp, lerp, 1)) = h*(1-a) + value*a
-		value = make_float4(h.x * (1.0f - l) + value.x * l, h.y * (1.0f - l) + value.y * l, h.z * (1.0f - l) + value.z * l,
-		                    value.w);
-	}
+		value = apply_feedback(value, history, u, v, push.lerp);
 	store_rgba16f(out, x, y, value);
 }
 
@@ -187,22 +194,17 @@ __device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a
 // 72 us instead of 8 us).  Under 56 registers one wave per SIMD always fits, under 48 two.
 #define POST_VGPR_BUDGET /* documentation only: clang (ROCm 7.2) ignores amdgpu_num_vgpr below the 64-register occupancy step; the kernels are written to stay under 56 */
 
-template <bool FEEDBACK>
-__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k_bloom_downsample_2to1(DevImage in, DevImageRW out, DevImage history,
-                                                                                      gr_push_bloom_downsample push, uint32_t y_first,
-                                                                                      uint32_t y_end)
+// One output texel of the 2:1 downsample: the 6 x 6 stencil over `in`, row by row.  ROWS_IN_FLIGHT = 1 keeps one row of six
+// texels live at a time (the standalone kernel's register budget); the fused tail, whose few workgroups are latency-bound,
+// unrolls the rows so that all 18 loads are in flight together.  Same arithmetic either way.
+template <int ROWS_IN_FLIGHT = 1>
+__device__ __forceinline__ float4 downsample_2to1_value(const DevImage &in, int x, int y)
 {
-	post_wave_priority();
-	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
-	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
-	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
-		return;
 	const float wt[6] = {0.0625f, 0.1875f, 0.25f, 0.25f, 0.1875f, 0.0625f};
 	const int col0 = 2 * x - 2; // first of 6 input columns; even, so 16-byte aligned when inside the image
 	const bool interior = col0 >= 0 && col0 + 5 < in.w;
 	float4 acc = make_float4(0, 0, 0, 0);
-	// Row by row (not unrolled across rows): one row of six texels is live at a time.
-#pragma unroll 1
+#pragma unroll ROWS_IN_FLIGHT
 	for (int r = 0; r < 6; r++)
 	{
 		const int iy = clampi(2 * y - 2 + r, 0, in.h - 1);
@@ -231,19 +233,54 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k
 		const float wr = r == 0 || r == 5 ? 0.0625f : (r == 1 || r == 4 ? 0.1875f : 0.25f);
 		acc = fma4(h, wr, acc);
 	}
-	float4 value = acc;
+	return acc;
+}
+
+template <bool FEEDBACK>
+__global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k_bloom_downsample_2to1(DevImage in, DevImageRW out, DevImage history,
+                                                                                      gr_push_bloom_downsample push, uint32_t y_first,
+                                                                                      uint32_t y_end)
+{
+	post_wave_priority();
+	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
+	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
+	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
+		return;
+	float4 value = downsample_2to1_value(in, x, y);
 	if (FEEDBACK)
-	{
-		// NearestClamp fetch of the previous frame's level at the same texel (hdr.cpp:160-166).
-		const float u = (float(x) + 0.5f) * push.inv_output_size[0];
-		const float v = (float(y) + 0.5f) * push.inv_output_size[1];
-		const int hx = clampi(int(floorf(u * float(history.w))), 0, history.w - 1);
-		const int hy = clampi(int(floorf(v * float(history.h))), 0, history.h - 1);
-		const float4 hv = load_rgba16f(history, hx, hy);
-		const float l = push.lerp;
-		value = make_float4(hv.x * (1.0f - l) + value.x * l, hv.y * (1.0f - l) + value.y * l, hv.z * (1.0f - l) + value.z * l, value.w);
-	}
+		value = apply_feedback(value, history, (float(x) + 0.5f) * push.inv_output_size[0], (float(y) + 0.5f) * push.inv_output_size[1], push.lerp);
 	store_rgba16f(out, x, y, value);
+}
+
+// One output texel of the 1:2 upsample: the 4 x 4 stencil; `texel(x, y)` returns the two dwords of an input texel at
+// coordinates already clamped to the `w` x `h` input.
+template <typename Texel>
+__device__ __forceinline__ float4 upsample_1to2_value(Texel texel, int w, int h, int x, int y)
+{
+	// even output: texels k-2..k+1, weights (1 11 15 5)/32; odd output: texels k-1..k+2, weights (5 15 11 1)/32
+	const bool odd_x = (x & 1) != 0, odd_y = (y & 1) != 0;
+	const int sx = (x >> 1) - 2 + (odd_x ? 1 : 0), sy = (y >> 1) - 2 + (odd_y ? 1 : 0);
+	const float wx[4] = {odd_x ? 0.15625f : 0.03125f, odd_x ? 0.46875f : 0.34375f, odd_x ? 0.34375f : 0.46875f, odd_x ? 0.03125f : 0.15625f};
+	const float wy[4] = {odd_y ? 0.15625f : 0.03125f, odd_y ? 0.46875f : 0.34375f, odd_y ? 0.34375f : 0.46875f, odd_y ? 0.03125f : 0.15625f};
+	int cx[4];
+#pragma unroll
+	for (int c = 0; c < 4; c++)
+		cx[c] = clampi(sx + c, 0, w - 1);
+	float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+	for (int r = 0; r < 4; r++)
+	{
+		const int cy = clampi(sy + r, 0, h - 1);
+		float4 hsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+		{
+			const u32x2 t = texel(cx[c], cy);
+			hsum = fma_mix_texel(t.x, t.y, wx[c], hsum); // conversion folded into the multiply-add
+		}
+		acc = fma4(hsum, wy[r], acc);
+	}
+	return acc;
 }
 
 __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k_bloom_upsample_1to2(DevImage in, DevImageRW out,
@@ -255,30 +292,8 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k
 	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
 	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
 		return;
-	// even output: texels k-2..k+1, weights (1 11 15 5)/32; odd output: texels k-1..k+2, weights (5 15 11 1)/32
-	const bool odd_x = (x & 1) != 0, odd_y = (y & 1) != 0;
-	const int sx = (x >> 1) - 2 + (odd_x ? 1 : 0), sy = (y >> 1) - 2 + (odd_y ? 1 : 0);
-	const float wx[4] = {odd_x ? 0.15625f : 0.03125f, odd_x ? 0.46875f : 0.34375f, odd_x ? 0.34375f : 0.46875f, odd_x ? 0.03125f : 0.15625f};
-	const float wy[4] = {odd_y ? 0.15625f : 0.03125f, odd_y ? 0.46875f : 0.34375f, odd_y ? 0.34375f : 0.46875f, odd_y ? 0.03125f : 0.15625f};
-	int cx[4];
-#pragma unroll
-	for (int c = 0; c < 4; c++)
-		cx[c] = clampi(sx + c, 0, in.w - 1);
-	float4 acc = make_float4(0, 0, 0, 0);
-#pragma unroll
-	for (int r = 0; r < 4; r++)
-	{
-		const uint8_t *row = in.ptr + size_t(clampi(sy + r, 0, in.h - 1)) * in.pitch;
-		float4 h = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-		for (int c = 0; c < 4; c++)
-		{
-			const u32x2 t = *reinterpret_cast<const u32x2 *>(row + size_t(cx[c]) * 8u);
-			h = fma_mix_texel(t.x, t.y, wx[c], h); // conversion folded into the multiply-add
-		}
-		acc = fma4(h, wy[r], acc);
-	}
-	store_rgba16f(out, x, y, acc);
+	const auto texel = [&in](int tx, int ty) { return *reinterpret_cast<const u32x2 *>(in.ptr + size_t(ty) * in.pitch + size_t(tx) * 8u); };
+	store_rgba16f(out, x, y, upsample_1to2_value(texel, in.w, in.h, x, y));
 }
 
 // ---- average luminance (luminance.comp:25-67) ---------------------------------------------------------------------
@@ -287,24 +302,24 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k
 // Summation order is fixed (deterministic across runs and ranks) but differs from the reference's tree: covered by the
 // stated fp32 tolerance on LuminanceData.
 constexpr int LUM_THREADS = 1024;
-__global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_luminance_data *lum, gr_push_luminance push)
+// Called by all LUM_THREADS threads of a workgroup (thread = 0 .. LUM_THREADS - 1); wave_partial: LUM_THREADS / 64 floats of LDS.
+__device__ __forceinline__ void luminance_block(const DevImage &in, gr_luminance_data *lum, const gr_push_luminance &push, int thread,
+                                                float *wave_partial)
 {
-	post_wave_priority();
-	__shared__ float wave_partial[LUM_THREADS / 64];
 	const int sx = int(push.size[0]), sy = int(push.size[1]);
 	const float inv_x = 1.0f / float(sx), inv_y = 1.0f / float(sy);
 	const int total = sx * sy;
 	float sum = 0.0f;
-	for (int i = threadIdx.x; i < total; i += LUM_THREADS)
+	for (int i = thread; i < total; i += LUM_THREADS)
 	{
 		const int py = i / sx, px = i - py * sx;
 		sum += sample_linear_rgba16f(in, (float(px) + 0.5f) * inv_x, (float(py) + 0.5f) * inv_y).w;
 	}
 	sum = wave_sum(sum);
-	if ((threadIdx.x & 63) == 0)
-		wave_partial[threadIdx.x >> 6] = sum;
+	if ((thread & 63) == 0)
+		wave_partial[thread >> 6] = sum;
 	__syncthreads();
-	if (threadIdx.x == 0)
+	if (thread == 0)
 	{
 		float loglum = 0.0f;
 #pragma unroll
@@ -318,6 +333,155 @@ __global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_lumin
 		lum->average_linear_luminance = exp2f(new_log_luma);
 		lum->average_inv_linear_luminance = exp2f(-new_log_luma);
 	}
+}
+
+__global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_luminance_data *lum, gr_push_luminance push)
+{
+	post_wave_priority();
+	__shared__ float wave_partial[LUM_THREADS / 64];
+	luminance_block(in, lum, push, int(threadIdx.x), wave_partial);
+}
+
+// ---- the coarse end of the pyramid in two launches --------------------------------------------------------------------------
+// downsample-2 -> downsample-3 (+ feedback) -> luminance -> upsample-2 -> upsample-1 touch under 3 MB at 4K, yet as five
+// dependent launches they are a third of the back-of-frame chain's latency (each pays a dispatch, a fill of the machine and
+// a drain for a few microseconds of work).  Fused through LDS, with every texel computed by the very functions the separate
+// kernels use (so the values, their fp16 roundings between levels included, are the same):
+//   k_bloom_down_tail: a workgroup makes an 8 x 8 tile of downsample-3; it first makes the patch of downsample-2 under that
+//     tile's tent taps (2:1 stencil from downsample-1), stores it (LDS as fp16, and to the downsample-2 image: neighbouring
+//     workgroups write identical values into the overlap), then filters the patch.
+//   k_bloom_up_tail: a workgroup of 1024 threads makes a 32 x 32 tile of upsample-1 from the 20 x 20 patch of upsample-2
+//     under it, which it first makes from downsample-3; workgroup 0 also runs the luminance reduction (same 1024-thread
+//     order as k_luminance).
+// D3_EXACT / U2_EXACT mirror what the separate launchers would pick for that level (2:1 / 1:2 stencil or the generic tent).
+constexpr int TAIL_TILE = 8;
+constexpr int TAIL_PATCH = 24; // rows / columns of downsample-2 under an 8 x 8 tile of downsample-3 (<= 2 * 8 + 4 + slack)
+struct TailPatch
+{
+	const f16x4 *texels;
+	int x0, y0, w, h; // patch origin and size inside the level
+	__device__ __forceinline__ float4 fetch(int x, int y) const { return cvt4(texels[(y - y0) * w + (x - x0)]); }
+};
+
+// First and last input row (column) a run of outputs [lo, hi] of `out_n` samples through taps displaced by `reach` input
+// texels in an `in_n`-sized level, with one texel of slack either side for the fp32 evaluation of the coordinates.
+__device__ __forceinline__ void tap_span(int lo, int hi, int out_n, int in_n, float reach, int &first, int &last)
+{
+	const float scale = float(in_n) / float(out_n);
+	first = clampi(int(floorf((float(lo) + 0.5f) * scale - 0.5f - reach)) - 1, 0, in_n - 1);
+	last = clampi(int(floorf((float(hi) + 0.5f) * scale - 0.5f + reach)) + 2, 0, in_n - 1);
+}
+
+template <bool D3_EXACT>
+__global__ __launch_bounds__(256) void k_bloom_down_tail(DevImage d1, DevImageRW d2, DevImageRW d3, DevImage history,
+                                                         gr_push_bloom_downsample push3)
+{
+	post_wave_priority();
+	__shared__ f16x4 s_patch[TAIL_PATCH * TAIL_PATCH];
+	const int tile_x0 = blockIdx.x * TAIL_TILE, tile_y0 = blockIdx.y * TAIL_TILE;
+	const int tile_x1 = min(tile_x0 + TAIL_TILE, d3.w) - 1, tile_y1 = min(tile_y0 + TAIL_TILE, d3.h) - 1;
+	int px0, px1, py0, py1;
+	if (D3_EXACT)
+	{
+		px0 = clampi(2 * tile_x0 - 2, 0, d2.w - 1), px1 = clampi(2 * tile_x1 + 3, 0, d2.w - 1);
+		py0 = clampi(2 * tile_y0 - 2, 0, d2.h - 1), py1 = clampi(2 * tile_y1 + 3, 0, d2.h - 1);
+	}
+	else
+	{
+		tap_span(tile_x0, tile_x1, d3.w, d2.w, 1.75f, px0, px1);
+		tap_span(tile_y0, tile_y1, d3.h, d2.h, 1.75f, py0, py1);
+	}
+	const int pw = px1 - px0 + 1, ph = py1 - py0 + 1; // <= TAIL_PATCH (checked by the launcher)
+	const DevImage d2_read{d2.ptr, d2.w, d2.h, d2.pitch};
+	for (int i = threadIdx.x; i < pw * ph; i += 256)
+	{
+		const int ly = i / pw, lx = i - ly * pw;
+		const f16x4 texel = pack_rgba16f(downsample_2to1_value<6>(d1, px0 + lx, py0 + ly));
+		s_patch[i] = texel;
+		*reinterpret_cast<f16x4 *>(d2.ptr + size_t(py0 + ly) * d2.pitch + size_t(px0 + lx) * 8u) = texel;
+	}
+	__syncthreads();
+	if (threadIdx.x >= TAIL_TILE * TAIL_TILE)
+		return;
+	const int x = tile_x0 + int(threadIdx.x & (TAIL_TILE - 1)), y = tile_y0 + int(threadIdx.x / TAIL_TILE);
+	if (x >= d3.w || y >= d3.h)
+		return;
+	const TailPatch patch{s_patch, px0, py0, pw, ph};
+	const float u = (float(x) + 0.5f) * push3.inv_output_size[0], v = (float(y) + 0.5f) * push3.inv_output_size[1];
+	float4 value;
+	if (D3_EXACT)
+	{
+		// the 2:1 stencil of downsample_2to1_value over the patch (same weights, same order; the patch covers every clamped index)
+		const float wt[6] = {0.0625f, 0.1875f, 0.25f, 0.25f, 0.1875f, 0.0625f};
+		float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll 1
+		for (int r = 0; r < 6; r++)
+		{
+			const int iy = clampi(2 * y - 2 + r, 0, d2.h - 1);
+			float4 h = mul4(patch.fetch(clampi(2 * x - 2, 0, d2.w - 1), iy), wt[0]);
+#pragma unroll
+			for (int c = 1; c < 6; c++)
+				h = fma4(patch.fetch(clampi(2 * x - 2 + c, 0, d2.w - 1), iy), wt[c], h);
+			const float wr = r == 0 || r == 5 ? 0.0625f : (r == 1 || r == 4 ? 0.1875f : 0.25f);
+			acc = fma4(h, wr, acc);
+		}
+		value = acc;
+	}
+	else
+	{
+		const auto sample = [&](float su, float sv) {
+			return sample_linear_with([&patch](int tx, int ty) { return patch.fetch(tx, ty); }, d2_read.w, d2_read.h, su, sv);
+		};
+		value = tent9_with(sample, u, v, 1.75f * push3.inv_input_size[0], 1.75f * push3.inv_input_size[1]);
+	}
+	value = apply_feedback(value, history, u, v, push3.lerp);
+	store_rgba16f(d3, x, y, value);
+}
+
+constexpr int UP_TILE = 32;
+constexpr int UP_PATCH = UP_TILE / 2 + 4; // upsample-2 texels under 32 outputs of upsample-1: k - 2 .. k + 2 for k = x / 2
+template <bool U2_EXACT, bool LUMINANCE>
+__global__ __launch_bounds__(LUM_THREADS) void k_bloom_up_tail(DevImage d3, DevImageRW u2, DevImageRW u1, gr_luminance_data *lum,
+                                                               gr_push_bloom_upsample push2, gr_push_luminance push_lum)
+{
+	post_wave_priority();
+	__shared__ f16x4 s_patch[UP_PATCH * UP_PATCH];
+	__shared__ float wave_partial[LUM_THREADS / 64];
+	const int thread = int(threadIdx.x);
+	const int tile_x0 = blockIdx.x * UP_TILE, tile_y0 = blockIdx.y * UP_TILE;
+	const int tile_x1 = min(tile_x0 + UP_TILE, u1.w) - 1, tile_y1 = min(tile_y0 + UP_TILE, u1.h) - 1;
+	const int px0 = clampi((tile_x0 >> 1) - 2, 0, u2.w - 1), px1 = clampi((tile_x1 >> 1) + 2, 0, u2.w - 1);
+	const int py0 = clampi((tile_y0 >> 1) - 2, 0, u2.h - 1), py1 = clampi((tile_y1 >> 1) + 2, 0, u2.h - 1);
+	const int pw = px1 - px0 + 1, ph = py1 - py0 + 1;
+	if (thread < pw * ph)
+	{
+		const int ly = thread / pw, lx = thread - ly * pw;
+		const int x = px0 + lx, y = py0 + ly;
+		float4 value;
+		if (U2_EXACT)
+		{
+			const auto texel = [&d3](int tx, int ty) { return *reinterpret_cast<const u32x2 *>(d3.ptr + size_t(ty) * d3.pitch + size_t(tx) * 8u); };
+			value = upsample_1to2_value(texel, d3.w, d3.h, x, y);
+		}
+		else
+			value = tent9(d3, (float(x) + 0.5f) * push2.inv_output_size[0], (float(y) + 0.5f) * push2.inv_output_size[1],
+			              0.875f * push2.inv_input_size[0], 0.875f * push2.inv_input_size[1]);
+		const f16x4 texel16 = pack_rgba16f(value);
+		s_patch[thread] = texel16;
+		*reinterpret_cast<f16x4 *>(u2.ptr + size_t(y) * u2.pitch + size_t(x) * 8u) = texel16;
+	}
+	__syncthreads();
+	{
+		const int x = tile_x0 + (thread & (UP_TILE - 1)), y = tile_y0 + thread / UP_TILE;
+		if (x < u1.w && y < u1.h)
+		{
+			const auto texel = [&](int tx, int ty) { return __builtin_bit_cast(u32x2, s_patch[(ty - py0) * pw + (tx - px0)]); };
+			store_rgba16f(u1, x, y, upsample_1to2_value(texel, u2.w, u2.h, x, y));
+		}
+	}
+	// hdr.cpp:368-371 records the luminance pass between downsample-3 and upsample-2; nothing in between reads its result
+	if (LUMINANCE && blockIdx.x == 0 && blockIdx.y == 0)
+		luminance_block(d3, lum, push_lum, thread, wave_partial);
 }
 
 // ---- tonemap (tonemap.frag:30-66) -----------------------------------------------------------------------------------
@@ -500,6 +664,23 @@ static bool is_rgba16f(const gr_image *img)
 	return img && img->ptr && img->format == GR_FORMAT_R16G16B16A16_SFLOAT && img->width && img->height &&
 	       img->pitch_bytes >= img->width * 8u && (img->pitch_bytes & 7u) == 0;
 }
+// What gr_bloom_downsample / gr_bloom_upsample pick for a level: the constant-weight stencil when it is exactly 2:1 / 1:2.
+static bool downsample_is_exact(const gr_image *in, const gr_push_bloom_downsample *push)
+{
+	static const bool allow_stencil = getenv("GR_NO_STENCIL") == nullptr;
+	return allow_stencil && in->width == 2u * push->threads[0] && in->height == 2u * push->threads[1] && (in->pitch_bytes & 15u) == 0 &&
+	       (reinterpret_cast<uintptr_t>(in->ptr) & 15u) == 0 && push->inv_output_size[0] == 1.0f / float(push->threads[0]) &&
+	       push->inv_output_size[1] == 1.0f / float(push->threads[1]) && push->inv_input_size[0] == 1.0f / float(in->width) &&
+	       push->inv_input_size[1] == 1.0f / float(in->height);
+}
+static bool upsample_is_exact(const gr_image *in, const gr_push_bloom_upsample *push)
+{
+	static const bool allow_stencil = getenv("GR_NO_STENCIL") == nullptr;
+	return allow_stencil && push->threads[0] == 2u * in->width && push->threads[1] == 2u * in->height &&
+	       push->inv_output_size[0] == 1.0f / float(push->threads[0]) && push->inv_output_size[1] == 1.0f / float(push->threads[1]) &&
+	       push->inv_input_size[0] == 1.0f / float(in->width) && push->inv_input_size[1] == 1.0f / float(in->height);
+}
+
 } // namespace
 
 extern "C" {
@@ -574,11 +755,7 @@ int gr_bloom_downsample_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, 
 	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_downsample"};
 	// Exact 2:1 level (and push constants that say so): constant-weight stencil, two outputs per thread.
-	static const bool allow_stencil = getenv("GR_NO_STENCIL") == nullptr; // A/B switch for measurements
-	const bool exact = allow_stencil && in->width == 2u * push->threads[0] && in->height == 2u * push->threads[1] && (in->pitch_bytes & 15u) == 0 &&
-	                   (reinterpret_cast<uintptr_t>(in->ptr) & 15u) == 0 && push->inv_output_size[0] == 1.0f / float(push->threads[0]) &&
-	                   push->inv_output_size[1] == 1.0f / float(push->threads[1]) && push->inv_input_size[0] == 1.0f / float(in->width) &&
-	                   push->inv_input_size[1] == 1.0f / float(in->height);
+	const bool exact = downsample_is_exact(in, push);
 	if (exact)
 	{
 		if (history)
@@ -619,15 +796,81 @@ int gr_bloom_upsample_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, co
 	dim3 block(POST_BLOCK_X, POST_BLOCK_Y);
 	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_upsample"};
-	static const bool allow_stencil = getenv("GR_NO_STENCIL") == nullptr;
-	const bool exact = allow_stencil && push->threads[0] == 2u * in->width && push->threads[1] == 2u * in->height &&
-	                   push->inv_output_size[0] == 1.0f / float(push->threads[0]) && push->inv_output_size[1] == 1.0f / float(push->threads[1]) &&
-	                   push->inv_input_size[0] == 1.0f / float(in->width) && push->inv_input_size[1] == 1.0f / float(in->height);
+	const bool exact = upsample_is_exact(in, push);
 	if (exact)
 		hipLaunchKernelGGL(k_bloom_upsample_1to2, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out), *push, span.first,
 		                   span.end);
 	else
 		hipLaunchKernelGGL(k_bloom_upsample, grid, block, 0, gr_to_stream(stream), to_dev(in), to_dev_rw(out), *push, span.first, span.end);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_bloom_tail_supported(const gr_image *d1, const gr_image *d2, const gr_image *d3, const gr_image *u2, const gr_image *u1,
+                            const gr_push_bloom_downsample *push_d2, const gr_push_bloom_downsample *push_d3,
+                            const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1)
+{
+	static const bool allow_fusion = getenv("GR_NO_TAIL_FUSION") == nullptr; // A/B switch for measurements
+	if (!allow_fusion || !is_rgba16f(d1) || !is_rgba16f(d2) || !is_rgba16f(d3) || !is_rgba16f(u2) || !is_rgba16f(u1))
+		return 0;
+	if (!push_d2 || !push_d3 || !push_u2 || !push_u1)
+		return 0;
+	// whole levels only, downsample-2 and upsample-1 in their exact forms, upsample-2 the size of downsample-2
+	if (push_d2->threads[0] != d2->width || push_d2->threads[1] != d2->height || push_d3->threads[0] != d3->width || push_d3->threads[1] != d3->height ||
+	    push_u2->threads[0] != u2->width || push_u2->threads[1] != u2->height || push_u1->threads[0] != u1->width || push_u1->threads[1] != u1->height)
+		return 0;
+	if (!downsample_is_exact(d1, push_d2) || !upsample_is_exact(u2, push_u1) || u2->width != d2->width || u2->height != d2->height)
+		return 0;
+	// the patch of downsample-2 under an 8 x 8 tile of downsample-3 must fit the kernel's LDS patch
+	if (d3->width == 0 || d3->height == 0 || float(d2->width) > 2.3f * float(d3->width) || float(d2->height) > 2.3f * float(d3->height))
+		return 0;
+	return 1;
+}
+
+int gr_bloom_down_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d1, const gr_image *d2, const gr_image *d3, const gr_image *history,
+                       const gr_push_bloom_downsample *push_d2, const gr_push_bloom_downsample *push_d3)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push_d2 != nullptr && push_d3 != nullptr);
+	GR_CHECK_ARG(ctx, is_rgba16f(d1) && is_rgba16f(d2) && is_rgba16f(d3));
+	GR_CHECK_ARG(ctx, !history || (is_rgba16f(history) && history->ptr != d3->ptr));
+	GR_CHECK_ARG(ctx, downsample_is_exact(d1, push_d2) && push_d2->threads[0] == d2->width && push_d2->threads[1] == d2->height);
+	GR_CHECK_ARG(ctx, push_d3->threads[0] == d3->width && push_d3->threads[1] == d3->height);
+	GR_CHECK_ARG(ctx, float(d2->width) <= 2.3f * float(d3->width) && float(d2->height) <= 2.3f * float(d3->height));
+	GR_CHECK_ARG(ctx, history != nullptr); // the last level of the pyramid always carries the temporal feedback (hdr.cpp:366)
+	dim3 grid(gr_div_up(d3->width, TAIL_TILE), gr_div_up(d3->height, TAIL_TILE));
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_down_tail"};
+	if (downsample_is_exact(d2, push_d3))
+		hipLaunchKernelGGL(k_bloom_down_tail<true>, grid, dim3(256), 0, gr_to_stream(stream), to_dev(d1), to_dev_rw(d2), to_dev_rw(d3), to_dev(history), *push_d3);
+	else
+		hipLaunchKernelGGL(k_bloom_down_tail<false>, grid, dim3(256), 0, gr_to_stream(stream), to_dev(d1), to_dev_rw(d2), to_dev_rw(d3), to_dev(history), *push_d3);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_bloom_up_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_image *u2, const gr_image *u1, gr_luminance_data *lum,
+                     const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1, const gr_push_luminance *push_lum)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push_u2 != nullptr && push_u1 != nullptr && (lum == nullptr) == (push_lum == nullptr));
+	GR_CHECK_ARG(ctx, is_rgba16f(d3) && is_rgba16f(u2) && is_rgba16f(u1));
+	GR_CHECK_ARG(ctx, upsample_is_exact(u2, push_u1) && push_u1->threads[0] == u1->width && push_u1->threads[1] == u1->height);
+	GR_CHECK_ARG(ctx, push_u2->threads[0] == u2->width && push_u2->threads[1] == u2->height);
+	GR_CHECK_ARG(ctx, !push_lum || (push_lum->size[0] != 0 && push_lum->size[1] != 0));
+	dim3 grid(gr_div_up(u1->width, UP_TILE), gr_div_up(u1->height, UP_TILE));
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_up_tail"};
+	const gr_push_luminance no_lum = {};
+	const bool exact = upsample_is_exact(d3, push_u2);
+	auto launch = [&](auto kernel) {
+		hipLaunchKernelGGL(kernel, grid, dim3(LUM_THREADS), 0, gr_to_stream(stream), to_dev(d3), to_dev_rw(u2), to_dev_rw(u1), lum, *push_u2,
+		                   push_lum ? *push_lum : no_lum);
+	};
+	if (exact && lum) launch(k_bloom_up_tail<true, true>);
+	else if (exact) launch(k_bloom_up_tail<true, false>);
+	else if (lum) launch(k_bloom_up_tail<false, true>);
+	else launch(k_bloom_up_tail<false, false>);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

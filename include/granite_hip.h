@@ -192,6 +192,22 @@ typedef struct gr_push_luminance
 int gr_luminance(gr_ctx *ctx, gr_stream stream, const gr_image *in, gr_luminance_data *lum,
                  const gr_push_luminance *push);
 
+/* The coarse end of the pyramid as recorded by hdr.cpp:364-377 -- downsample-2, downsample-3 (+ feedback), luminance,
+ * upsample-2, upsample-1 -- in two launches instead of five: every texel is computed by the same code as the separate entry
+ * points above (values and fp16 roundings between levels are identical), the intermediate levels are still written.
+ * gr_bloom_tail_supported() says whether a pyramid qualifies (whole levels, downsample-2 / upsample-1 exactly 2:1 / 1:2 of
+ * their inputs); otherwise the five separate calls are the path. */
+int gr_bloom_tail_supported(const gr_image *d1, const gr_image *d2, const gr_image *d3, const gr_image *u2, const gr_image *u1,
+                            const gr_push_bloom_downsample *push_d2, const gr_push_bloom_downsample *push_d3,
+                            const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1);
+int gr_bloom_down_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d1, const gr_image *d2, const gr_image *d3,
+                       const gr_image *history, const gr_push_bloom_downsample *push_d2,
+                       const gr_push_bloom_downsample *push_d3);
+/* lum / push_lum both NULL: no dynamic exposure, no luminance reduction. */
+int gr_bloom_up_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_image *u2, const gr_image *u1,
+                     gr_luminance_data *lum, const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1,
+                     const gr_push_luminance *push_lum);
+
 /* tonemap_build_render_pass (hdr.cpp:283-306) + tonemap.frag (full-screen quad).  out: R8G8B8A8_SRGB (linear value
  * is sRGB-encoded on store, as the attachment hardware does) or R8G8B8A8_UNORM.  lum NULL => DYNAMIC_EXPOSURE=0. */
 typedef struct gr_push_tonemap

@@ -154,3 +154,47 @@ def test_argument_validation(gr):
         gr.bloom_threshold(bad, hdr)
     with pytest.raises(capi.GraniteHipError):
         gr.tonemap(hdr, hdr, capi.DeviceImage(gr, 8, 8, capi.FORMAT_R8G8B8A8_SRGB))
+
+
+@pytest.mark.parametrize("w,h", [(3840, 2160), (7680, 4320), (2048, 2048), (2560, 1440), (1280, 720), (256, 256)])
+def test_fused_pyramid_tail_equals_the_five_separate_launches(gr, w, h):
+    """gr_bloom_down_tail + gr_bloom_up_tail (downsample-2 -> downsample-3 + feedback -> luminance -> upsample-2 -> upsample-1
+    through LDS, two launches) must leave the very bytes of the five separate launches in every level and in the luminance
+    buffer: 4K and 1440p (downsample-3 and upsample-2 on the generic tent: 135 -> 68, 90 -> 45 exact but 45 -> 23), sizes where
+    both are exact 2:1 / 1:2, small ones with partial tiles."""
+    sz = [orc.level_size(w, h, s) for s in (0.125, 0.0625, 0.03125)]
+    assert sz[0] == (2 * sz[1][0], 2 * sz[1][1]), "test sizes are those whose 1/8 -> 1/16 step is exact"
+    rng = np.random.default_rng(w * 31 + h)
+    d1_bits = np.exp2(rng.uniform(-8, 6, (sz[0][1], sz[0][0], 4))).astype(np.float16).view(np.uint16)
+    hist_bits = np.exp2(rng.uniform(-8, 4, (sz[2][1], sz[2][0], 4))).astype(np.float16).view(np.uint16)
+    d1 = capi.DeviceImage(gr, *sz[0], F16).upload(d1_bits)
+    hist = capi.DeviceImage(gr, *sz[2], F16).upload(hist_bits)
+    lum0 = np.array([0.25, 2.0 ** 0.25, 2.0 ** -0.25], np.float32)
+    lum_lerp, fb_lerp = orc.frame_lerps(0.01)
+    got = {}
+    for fused in (False, True):
+        d2, u2 = capi.DeviceImage(gr, *sz[1], F16), capi.DeviceImage(gr, *sz[1], F16)
+        d3, u1 = capi.DeviceImage(gr, *sz[2], F16), capi.DeviceImage(gr, *sz[0], F16)
+        lum = capi.DeviceBuffer(gr, 12).upload(lum0)
+        if fused:
+            assert gr.bloom_tail(d1, d2, d3, hist, u2, u1, fb_lerp, lum.ptr, lum_lerp), "this pyramid must qualify for the fused tail"
+        else:
+            gr.bloom_downsample(d1, d2)
+            gr.bloom_downsample(d2, d3, hist, fb_lerp)
+            gr.luminance(d3, lum.ptr, lum_lerp)
+            gr.bloom_upsample(d3, u2)
+            gr.bloom_upsample(u2, u1)
+        gr.sync()
+        got[fused] = (d2.download(), d3.download(), u2.download(), u1.download(), lum.download(np.float32))
+    for a, b, name in zip(got[True], got[False], ("downsample-2", "downsample-3", "upsample-2", "upsample-1", "luminance")):
+        np.testing.assert_array_equal(a, b, err_msg=name)
+    assert got[True][4][0] != lum0[0]
+
+
+def test_fused_pyramid_tail_declines_what_it_does_not_cover(gr):
+    """Levels that are not 2:1 / 1:2 where the fused kernels need them to be fall back to the separate launches."""
+    d1 = capi.DeviceImage(gr, 101, 57, F16)
+    d2, u2 = capi.DeviceImage(gr, 51, 29, F16), capi.DeviceImage(gr, 51, 29, F16)   # 101 -> 51 is not exact
+    d3, hist = capi.DeviceImage(gr, 26, 15, F16), capi.DeviceImage(gr, 26, 15, F16)
+    u1 = capi.DeviceImage(gr, 101, 57, F16)
+    assert not gr.bloom_tail(d1, d2, d3, hist, u2, u1, 0.1)
