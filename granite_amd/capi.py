@@ -21,6 +21,7 @@ FORMAT_R8G8_UNORM = 16
 FORMAT_R8G8B8A8_UNORM = 37
 FORMAT_R8G8B8A8_SRGB = 43
 FORMAT_A2B10G10R10_UNORM_PACK32 = 64
+FORMAT_R16_SFLOAT = 76
 FORMAT_R16G16_SFLOAT = 83
 FORMAT_R16G16B16A16_SFLOAT = 97
 FORMAT_R32_SFLOAT = 100
@@ -33,6 +34,7 @@ FORMAT_BPP = {
     FORMAT_R8G8B8A8_UNORM: 4,
     FORMAT_R8G8B8A8_SRGB: 4,
     FORMAT_A2B10G10R10_UNORM_PACK32: 4,
+    FORMAT_R16_SFLOAT: 2,
     FORMAT_R16G16_SFLOAT: 4,
     FORMAT_R16G16B16A16_SFLOAT: 8,
     FORMAT_R32_SFLOAT: 4,
@@ -164,6 +166,19 @@ class HizArgs(C.Structure):
                 ("counter", C.c_void_p)]
 
 
+class SsrArgs(C.Structure):
+    _fields_ = [("depth_chain", C.c_void_p), ("chain_width", C.c_uint32), ("chain_height", C.c_uint32), ("chain_levels", C.c_uint32),
+                ("pbr", Image), ("normal", Image), ("light", Image), ("dither_lut", C.c_void_p), ("frame", C.c_uint32),
+                ("view_projection", C.c_float * 16), ("inv_view_projection", C.c_float * 16), ("camera_position", C.c_float * 3),
+                ("output", Image), ("ray_length", Image), ("ray_confidence", Image), ("ray_list", C.c_void_p), ("ray_counter", C.c_void_p),
+                ("scratch", C.c_void_p)]
+
+
+class SsrApplyArgs(C.Structure):
+    _fields_ = [("hdr", Image), ("reflected", Image), ("albedo", Image), ("normal", Image), ("pbr", Image), ("depth", Image),
+                ("brdf_lut", Image), ("inv_view_projection", C.c_float * 16), ("camera_position", C.c_float * 3)]
+
+
 class SpdArgs(C.Structure):
     _fields_ = [("input", Image), ("chain", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("mips", C.c_uint32),
                 ("components", C.c_uint32), ("reduction_mode", C.c_uint32), ("filter_mods", C.c_void_p)]
@@ -218,6 +233,9 @@ def load_library() -> C.CDLL:
         "gr_bloom_downsample": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushBloomDownsample)]),
         "gr_bloom_upsample": (C.c_int, [vp, vp, P(Image), P(Image), P(PushBloomUpsample)]),
         "gr_luminance": (C.c_int, [vp, vp, P(Image), vp, P(PushLuminance)]),
+        "gr_ssr_scratch_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+        "gr_ssr_trace": (C.c_int, [vp, vp, P(SsrArgs)]),
+        "gr_ssr_apply": (C.c_int, [vp, vp, P(SsrApplyArgs)]),
         "gr_bloom_tail_supported": (C.c_int, [P(Image), P(Image), P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample),
                                               P(PushBloomUpsample), P(PushBloomUpsample)]),
         "gr_bloom_down_tail": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample)]),
@@ -345,6 +363,8 @@ class DeviceImage:
             return out.view(np.uint32).reshape(self.height, self.width)
         if self.format == FORMAT_R16G16_SFLOAT:
             return out.view(np.uint16).reshape(self.height, self.width, 2)
+        if self.format == FORMAT_R16_SFLOAT:
+            return out.view(np.uint16).reshape(self.height, self.width)
         return out.reshape(self.height, self.pitch)
 
 
@@ -499,6 +519,33 @@ class Context:
         args.counter = counter.ptr
         self.check(self.lib.gr_hiz(self.handle, stream, args))
         return chain, counter, {"chain_w": cw, "chain_h": ch, "levels": levels}
+
+    def ssr_trace(self, chain: DeviceBuffer, layout: dict, pbr: DeviceImage, normal: DeviceImage, light: DeviceImage, dither: DeviceBuffer,
+                  frame: int, view_projection, inv_view_projection, camera_position, stream=None) -> dict:
+        """classify + build_indirect + trace_primary.  Returns the output / ray-length / confidence images and the ray buffers."""
+        w, h = light.width, light.height
+        out = {"output": DeviceImage(self, w, h, FORMAT_R16G16B16A16_SFLOAT), "ray_length": DeviceImage(self, w, h, FORMAT_R16_SFLOAT),
+               "confidence": DeviceImage(self, w, h, FORMAT_R8_UNORM), "ray_list": DeviceBuffer(self, w * h * 4),
+               "ray_counter": DeviceBuffer(self, 4096), "scratch": DeviceBuffer(self, self.lib.gr_ssr_scratch_bytes(w, h))}
+        a = SsrArgs()
+        a.depth_chain, a.chain_width, a.chain_height, a.chain_levels = chain.ptr, layout["chain_w"], layout["chain_h"], layout["levels"]
+        a.pbr, a.normal, a.light = pbr.desc, normal.desc, light.desc
+        a.dither_lut, a.frame = dither.ptr, frame
+        a.view_projection[:] = [float(v) for v in view_projection]
+        a.inv_view_projection[:] = [float(v) for v in inv_view_projection]
+        a.camera_position[:] = [float(v) for v in camera_position]
+        a.output, a.ray_length, a.ray_confidence = out["output"].desc, out["ray_length"].desc, out["confidence"].desc
+        a.ray_list, a.ray_counter, a.scratch = out["ray_list"].ptr, out["ray_counter"].ptr, out["scratch"].ptr
+        self.check(self.lib.gr_ssr_trace(self.handle, stream, a))
+        return out
+
+    def ssr_apply(self, hdr: DeviceImage, reflected: DeviceImage, albedo: DeviceImage, normal: DeviceImage, pbr: DeviceImage, depth: DeviceImage,
+                  brdf_lut: DeviceImage, inv_view_projection, camera_position, stream=None):
+        a = SsrApplyArgs()
+        a.hdr, a.reflected, a.albedo, a.normal, a.pbr, a.depth, a.brdf_lut = (i.desc for i in (hdr, reflected, albedo, normal, pbr, depth, brdf_lut))
+        a.inv_view_projection[:] = [float(v) for v in inv_view_projection]
+        a.camera_position[:] = [float(v) for v in camera_position]
+        self.check(self.lib.gr_ssr_apply(self.handle, stream, a))
 
     def spd_downsample(self, source: DeviceImage, width: int, height: int, mips: int, components: int = 4, depth_mode: bool = False,
                        filter_mods=None, chain: Optional[DeviceBuffer] = None, stream=None) -> DeviceBuffer:

@@ -45,6 +45,7 @@ typedef enum gr_format
 	GR_FORMAT_R8G8B8A8_UNORM = 37,
 	GR_FORMAT_R8G8B8A8_SRGB = 43,
 	GR_FORMAT_A2B10G10R10_UNORM_PACK32 = 64,
+	GR_FORMAT_R16_SFLOAT = 76,
 	GR_FORMAT_R16G16_SFLOAT = 83,
 	GR_FORMAT_R16G16B16A16_SFLOAT = 97,
 	GR_FORMAT_R32_SFLOAT = 100,
@@ -432,6 +433,51 @@ typedef struct gr_hiz_args
 	uint32_t *counter;         /* the pass's "-counter" buffer (one uint32); never written, stays zero */
 } gr_hiz_args;
 int gr_hiz(gr_ctx *ctx, gr_stream stream, const gr_hiz_args *args);
+
+/* ---- screen-space reflections ------------------------------------------------------------------------------------------------
+ * SSRState::build_render_pass (renderer/post/ssr.cpp:84-173) with ffx-sssr/{classify,build_indirect,trace_primary}.comp, and
+ * the apply pass (ssr.cpp:286-322, apply.frag).  gr_ssr_trace = classify (clears `output` / `ray_confidence`, lists one ray per
+ * glossy (roughness < 0.2), reflective (hierarchy level 0 < 1) pixel -- one per 2 x 2 quad phase for non-mirror surfaces, with
+ * copy flags), build_indirect (the counter buffer: indirect.xyzw, atomic_count = 0, copied_count) and trace_primary (GGX VNDF
+ * reflection direction from the blue-noise dither layer `frame`, hierarchical traversal of the depth chain from mip 1,
+ * hit validation, radiance from `light`) in one call.  The ray list is in tile order (8 x 8 tiles row-major, Z-order inside a
+ * tile) -- one of the orders the shader's atomic append can produce -- so the wave-level early exit of the traversal is
+ * reproducible.  texelFetch outside a level reads 0.  scratch: gr_ssr_scratch_bytes(width, height) bytes. */
+typedef struct gr_ssr_args
+{
+	const void *depth_chain;      /* R32_SFLOAT mip chain as gr_hiz writes it ("<depth>-hier") */
+	uint32_t chain_width, chain_height, chain_levels;
+	gr_image pbr;                 /* R8G8_UNORM */
+	gr_image normal;              /* A2B10G10R10_UNORM_PACK32 */
+	gr_image light;               /* R16G16B16A16_SFLOAT: the lit target rays fetch radiance from */
+	const void *dither_lut;       /* R8G8_UNORM 128 x 128 x 64 layers (ssr.cpp:178-205) */
+	uint32_t frame;               /* dither layer, 0..63 (ssr.cpp:161) */
+	float view_projection[16];    /* column-major */
+	float inv_view_projection[16];
+	float camera_position[3];
+	gr_image output;              /* R16G16B16A16_SFLOAT "<output>-sssr" */
+	gr_image ray_length;          /* R16_SFLOAT */
+	gr_image ray_confidence;      /* R8_UNORM */
+	uint32_t *ray_list;           /* width * height dwords */
+	uint32_t *ray_counter;        /* >= 6 dwords */
+	void *scratch;
+} gr_ssr_args;
+size_t gr_ssr_scratch_bytes(uint32_t width, uint32_t height);
+int gr_ssr_trace(gr_ctx *ctx, gr_stream stream, const gr_ssr_args *args);
+
+typedef struct gr_ssr_apply_args
+{
+	gr_image hdr;       /* R16G16B16A16_SFLOAT, read-modify-write: blend ONE / ONE, fp16 rounding of the sum */
+	gr_image reflected; /* "<output>-sssr", NearestClamp at the pixel centre */
+	gr_image albedo;    /* R8G8B8A8_SRGB */
+	gr_image normal;
+	gr_image pbr;
+	gr_image depth;     /* D32_SFLOAT: pixels at exactly 1.0 are skipped (depth test NOT_EQUAL against the quad at z = 1) */
+	gr_image brdf_lut;  /* R16G16_SFLOAT split-sum table (builtin://textures/ibl_brdf_lut.gtx), LinearClamp at (NoV, roughness) */
+	float inv_view_projection[16];
+	float camera_position[3];
+} gr_ssr_apply_args;
+int gr_ssr_apply(gr_ctx *ctx, gr_stream stream, const gr_ssr_apply_args *args);
 
 /* ---- single-pass downsampler ----------------------------------------------------------------------------------------------
  * emit_single_pass_downsample (renderer/post/spd.cpp:56-102) + assets/shaders/post/ffx-spd/spd.comp (AMD FidelityFX SPD):

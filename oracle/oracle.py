@@ -422,3 +422,51 @@ def pq10_encode(hdr: np.ndarray, ui_rgba8: np.ndarray, conversion9, hdr_pre_expo
     lib().orc_pq10_encode(_p(hdr), _p(ui), w, h, _p(m), C.c_float(hdr_pre_exposure), C.c_float(ui_pre_exposure),
                           C.c_float(max_light_level), _p(out))
     return out
+
+
+# ---- screen-space reflections (renderer/post/ssr.cpp + assets/shaders/post/ffx-sssr) -------------------------------------------
+class SSRArgs(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("hier", C.c_void_p), ("hier_w", C.c_int32), ("hier_h", C.c_int32),
+                ("hier_levels", C.c_int32), ("pbr", C.c_void_p), ("normal", C.c_void_p), ("light", C.c_void_p), ("noise", C.c_void_p),
+                ("frame", C.c_int32), ("view_projection", C.c_void_p), ("inv_view_projection", C.c_void_p),
+                ("camera_position", C.c_float * 3), ("output", C.c_void_p), ("ray_length", C.c_void_p), ("confidence", C.c_void_p),
+                ("ray_list", C.c_void_p), ("ray_counter", C.c_void_p)]
+
+
+def ssr_trace(hier_levels, pbr, normal, light, noise, frame, view_projection, inv_view_projection, camera_position, entry=None):
+    """classify + build_indirect + trace_primary over a depth hierarchy given as a list of float32 levels (level 0 first).
+    Returns {"output" RGBA16F bits, "ray_length" R16F bits, "confidence" R8, "ray_list" uint32[count], "ray_counter" uint32[6]}.
+    entry: (classify, trace) pair of another implementation over the same struct (oracle/_ref: the reference's own shaders)."""
+    h, w = pbr.shape
+    chain = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(l, np.float32).reshape(-1) for l in hier_levels]))
+    keep = [chain, np.ascontiguousarray(pbr, np.uint16), np.ascontiguousarray(normal, np.uint32), np.ascontiguousarray(light, np.uint16),
+            np.ascontiguousarray(noise, np.uint16), np.ascontiguousarray(view_projection, np.float32), np.ascontiguousarray(inv_view_projection, np.float32)]
+    out = {"output": np.zeros((h, w, 4), np.uint16), "ray_length": np.zeros((h, w), np.uint16), "confidence": np.zeros((h, w), np.uint8),
+           "ray_list": np.zeros(w * h, np.uint32), "ray_counter": np.zeros(6, np.uint32)}
+    a = SSRArgs()
+    a.width, a.height = w, h
+    a.hier, a.hier_w, a.hier_h, a.hier_levels = keep[0].ctypes.data, hier_levels[0].shape[1], hier_levels[0].shape[0], len(hier_levels)
+    a.pbr, a.normal, a.light, a.noise = (k.ctypes.data for k in keep[1:5])
+    a.frame = int(frame)
+    a.view_projection, a.inv_view_projection = keep[5].ctypes.data, keep[6].ctypes.data
+    a.camera_position = (C.c_float * 3)(*[float(v) for v in camera_position])
+    a.output, a.ray_length, a.confidence = out["output"].ctypes.data, out["ray_length"].ctypes.data, out["confidence"].ctypes.data
+    a.ray_list, a.ray_counter = out["ray_list"].ctypes.data, out["ray_counter"].ctypes.data
+    classify, trace = entry if entry is not None else (lib().orc_ssr_classify, lib().orc_ssr_trace)
+    classify(C.byref(a))
+    trace(C.byref(a))
+    out["ray_list"] = out["ray_list"][:int(out["ray_counter"][5])].copy()
+    return out
+
+
+def ssr_apply(hdr, reflected, albedo, normal, pbr, depth, brdf_lut, inv_view_projection, camera_position) -> np.ndarray:
+    """apply.frag blended ONE / ONE into `hdr` (RGBA16F bits); returns the new target."""
+    h, w = depth.shape
+    out = np.array(hdr, np.uint16, copy=True)
+    lut = np.ascontiguousarray(brdf_lut, np.uint16)
+    ivp = np.ascontiguousarray(inv_view_projection, np.float32)
+    cam = np.ascontiguousarray(camera_position, np.float32)
+    lib().orc_ssr_apply(w, h, _p(np.ascontiguousarray(reflected, np.uint16)), _p(np.ascontiguousarray(albedo, np.uint32)),
+                        _p(np.ascontiguousarray(normal, np.uint32)), _p(np.ascontiguousarray(pbr, np.uint16)),
+                        _p(np.ascontiguousarray(depth, np.float32)), _p(lut), lut.shape[1], lut.shape[0], _p(ivp), _p(cam), _p(out))
+    return out

@@ -1,0 +1,108 @@
+"""GPU parity of the screen-space reflection kernels (gr_ssr_trace = classify + build_indirect + trace_primary, gr_ssr_apply)
+against the oracle, through the C ABI.
+
+The ray list, the counter buffer, the cleared / copied pixels and every hit validation are deterministic and compared exactly.
+Traced colours are compared statistically: the reflection direction goes through sin / cos / sqrt of the device's math
+library, one ulp away from the host's, and a traversal that takes a different branch at one of its ~100 cell decisions lands on
+another texel -- as two GPUs would.  The tests require that this is rare and that everything else agrees to the storage
+tolerances."""
+import numpy as np
+import pytest
+
+from granite_amd import capi, synth
+from granite_amd.data import expand_sssr_dither, load_brdf_lut, load_sssr_noise_base
+from oracle import oracle as orc
+from util import half_bits_to_f32, rgba16f_mismatch
+
+pytestmark = pytest.mark.gpu
+
+F16 = capi.FORMAT_R16G16B16A16_SFLOAT
+
+
+def close_up_scene(w, h, seed=0):
+    """A trough within one unit of the camera (the pass only reflects where the hierarchy's level 0 is below 1: sssr_util.h
+    IsReflective on the view-space depth chain the reference feeds it): floor in the middle, walls rising towards the camera at
+    both sides and at the top, normals derived from that geometry so that reflected rays do find it again.  Left half glossy
+    (denoised: one ray per quad phase + copies), a mirror strip (one ray per pixel), the rest too rough to reflect."""
+    cam = synth.Camera(w, h)
+    g = synth.make_gbuffer(cam, synth.SEED + seed)
+    u, v = (np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h
+    view_z = 0.95 - 0.6 * np.abs(2 * u - 1)[None, :] ** 2 * np.ones((h, 1)) - 0.25 * (1 - v)[:, None] ** 2
+    view_z = np.clip(view_z, 0.25, 0.97)
+    depth = cam.depth_from_view_distance(view_z).astype(np.float32)
+    ys, xs = np.mgrid[0:h, 0:w]
+    ndc = np.stack([2 * (xs + 0.5) / w - 1, 2 * (ys + 0.5) / h - 1, depth.astype(np.float64), np.ones((h, w))], 0).reshape(4, -1)
+    clip = cam.invVP @ ndc
+    pos = (clip[:3] / clip[3]).T.reshape(h, w, 3)
+    n = np.cross(np.gradient(pos, axis=1), np.gradient(pos, axis=0))
+    n /= np.linalg.norm(n, axis=2, keepdims=True)
+    n[(n * (cam.position[None, None, :] - pos)).sum(2) < 0] *= -1
+    q = np.clip(np.rint((0.5 * n + 0.5) * 1023.0), 0, 1023).astype(np.uint32)
+    normal = (q[..., 0] | (q[..., 1] << 10) | (q[..., 2] << 20) | np.uint32(3 << 30)).astype(np.uint32)
+    pbr = g["pbr"].copy()
+    pbr[:, :w // 2] = (pbr[:, :w // 2] & 0xff) | (np.uint16(25) << 8)   # roughness 0.098: glossy, denoised
+    pbr[:, :w // 8] &= 0xff                                              # roughness 0: mirror
+    light = synth.make_hdr(w, h, synth.SEED + seed)
+    return cam, depth, normal, pbr, g["albedo"], light
+
+
+def run_both(gr, w, h, frame, seed=0):
+    cam, depth, normal, pbr, albedo, light = close_up_scene(w, h, seed)
+    rp = cam.render_params()
+    zt = orc.hiz_z_transform(rp[48:64])
+    levels = orc.hiz(depth, zt)
+    noise = expand_sssr_dither(load_sssr_noise_base())
+    ref = orc.ssr_trace(levels, pbr, normal, light, noise, frame, rp[32:48], rp[80:96], rp[96:99])
+    ddepth = capi.DeviceImage(gr, w, h, capi.FORMAT_D32_SFLOAT).upload(depth)
+    chain, _, layout = gr.hiz(ddepth, zt)
+    dev = gr.ssr_trace(chain, layout, capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8_UNORM).upload(pbr),
+                       capi.DeviceImage(gr, w, h, capi.FORMAT_A2B10G10R10_UNORM_PACK32).upload(normal),
+                       capi.DeviceImage(gr, w, h, F16).upload(light), capi.DeviceBuffer(gr, noise.nbytes).upload(noise), frame,
+                       rp[32:48], rp[80:96], rp[96:99])
+    gr.sync()
+    return ref, dev, (cam, depth, normal, pbr, albedo, light, rp)
+
+
+@pytest.mark.parametrize("w,h,frame", [(256, 144, 0), (333, 77, 7), (960, 540, 63)])
+def test_ray_list_and_traced_images_match_the_oracle(gr, w, h, frame):
+    ref, dev, _ = run_both(gr, w, h, frame)
+    counter = dev["ray_counter"].download(np.uint32)[:6]
+    np.testing.assert_array_equal(counter, ref["ray_counter"])
+    count = int(counter[5])
+    assert count > 0.2 * w * h * 0.3, "the scene must produce rays"
+    np.testing.assert_array_equal(dev["ray_list"].download(np.uint32)[:count], ref["ray_list"])
+    got_conf, got_out, got_len = dev["confidence"].download()[:, :w], dev["output"].download(), dev["ray_length"].download()
+    # pixels no ray wrote keep the cleared value on both sides
+    untouched = (ref["output"] == 0).all(axis=2) & (ref["confidence"] == 0)
+    assert (got_out[untouched] == 0).all()
+    # confidence: identical up to the rare traversal that took another branch
+    conf_diff = np.abs(got_conf.astype(np.int16) - ref["confidence"].astype(np.int16))
+    assert (conf_diff > 1).mean() < 2e-3, (conf_diff > 1).mean()
+    agree = conf_diff <= 1
+    bad = rgba16f_mismatch(got_out, ref["output"], 2.0, 1e-4).any(axis=2) & agree
+    assert bad.mean() < 2e-3, bad.mean()
+    len_bad = np.abs(half_bits_to_f32(got_len) - half_bits_to_f32(ref["ray_length"])) > 1e-2 * (1.0 + np.abs(half_bits_to_f32(ref["ray_length"])))
+    assert (len_bad & agree).mean() < 2e-3
+    assert (ref["confidence"] > 0).sum() > 30, "some rays must hit with confidence"
+
+
+def test_apply_pass_matches_the_oracle(gr):
+    w, h, frame = 320, 180, 5
+    ref, dev, (cam, depth, normal, pbr, albedo, light, rp) = run_both(gr, w, h, frame, seed=1)
+    lut = load_brdf_lut()
+    # feed the apply pass with the DEVICE's traced image, so that it is checked on its own
+    reflected = dev["output"].download()
+    real_depth = depth.copy()
+    real_depth[::17, ::13] = 1.0  # pixels the NOT_EQUAL depth test rejects
+    want = orc.ssr_apply(light, reflected, albedo, normal, pbr, real_depth, lut, rp[80:96], rp[96:99])
+    hdr = capi.DeviceImage(gr, w, h, F16).upload(light)
+    gr.ssr_apply(hdr, dev["output"], capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8B8A8_SRGB).upload(albedo),
+                 capi.DeviceImage(gr, w, h, capi.FORMAT_A2B10G10R10_UNORM_PACK32).upload(normal),
+                 capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8_UNORM).upload(pbr), capi.DeviceImage(gr, w, h, capi.FORMAT_D32_SFLOAT).upload(real_depth),
+                 capi.DeviceImage(gr, 256, 256, capi.FORMAT_R16G16_SFLOAT).upload(lut), rp[80:96], rp[96:99])
+    gr.sync()
+    got = hdr.download()
+    assert not rgba16f_mismatch(got, want, 2.0, 1e-4).any()
+    np.testing.assert_array_equal(got[::17, ::13], light[::17, ::13])  # rejected pixels untouched
+    assert (got != light).any(axis=2).mean() > 0.3                     # the pass does add reflections
+    np.testing.assert_array_equal(got[..., 3], light[..., 3])          # alpha untouched
