@@ -28,11 +28,19 @@ class Config(C.Structure):
                 ("strip_index", C.c_uint32), ("strip_count", C.c_uint32),
                 ("disable_image_aliasing", C.c_int32), ("depth_hierarchy", C.c_int32),
                 ("resolution_scale", C.c_float), ("resolution_scale_sharpen", C.c_int32), ("fsr_fp32", C.c_int32),
-                ("ambient_occlusion", C.c_int32), ("hdr10", C.c_int32)]
+                ("ambient_occlusion", C.c_int32), ("hdr10", C.c_int32), ("ssr", C.c_int32)]
 
 
 # void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream)
 EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p)
+
+
+def install_ssr_tables():
+    """Hands the SSR pass its two constant tables (granite_amd/data: blue-noise values, split-sum BRDF table)."""
+    from .data import load_brdf_lut, load_sssr_noise_base
+    noise, lut = np.ascontiguousarray(load_sssr_noise_base()), np.ascontiguousarray(load_brdf_lut())
+    if load_library().gra_install_ssr_tables(noise.ctypes.data, lut.ctypes.data, lut.shape[1], lut.shape[0]) != 0:
+        raise capi.GraniteHipError("gra_install_ssr_tables failed")
 
 
 class ResourceInfo(C.Structure):
@@ -51,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
     "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_prefetched_refreshes", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
     "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan",
-    "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_init_output", "gra_reset_timestamps", "gra_set_directional_light", "gra_generate_mipmaps",
+    "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_init_output", "gra_install_ssr_tables", "gra_reset_timestamps", "gra_set_directional_light", "gra_generate_mipmaps",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -89,6 +97,7 @@ def load_library() -> C.CDLL:
         "gra_get_taa_reprojection": (C.c_int, [vp, vp]),
         "gra_set_smaa_luts": (C.c_int, [vp, vp, vp]),
         "gra_get_host_stats": (C.c_int, [vp, vp]),
+        "gra_install_ssr_tables": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32]),
         "gra_get_prefetched_refreshes": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "gra_get_allocated_bytes": (C.c_int, [vp, vp]),
         "gra_get_render_size": (C.c_int, [vp, vp, vp]),
@@ -128,7 +137,7 @@ class Application:
                  frame_time: float = synth.FRAME_TIME, timestamps: bool = False, strip_index: int = 0, strip_count: int = 1,
                  alias_images: bool = True, depth_hierarchy: int = 0,
                  resolution_scale: float = 1.0, resolution_scale_sharpen: bool = True, fsr_fp16: bool = True,
-                 ambient_occlusion: bool = False, hdr10: bool = False):
+                 ambient_occlusion: bool = False, hdr10: bool = False, ssr: bool = False):
         self.lib = load_library()
         cfg = Config()
         cfg.device, cfg.width, cfg.height = device, width, height
@@ -147,6 +156,9 @@ class Application:
         cfg.resolution_scale_sharpen, cfg.fsr_fp32 = int(resolution_scale_sharpen), int(not fsr_fp16)
         cfg.ambient_occlusion = int(ambient_occlusion)
         cfg.hdr10 = int(hdr10)
+        cfg.ssr = int(ssr)
+        if ssr:
+            install_ssr_tables()
         self._exchange_ref = None
         self.config = cfg
         self.width, self.height = width, height

@@ -1,5 +1,6 @@
 // extern "C" surface of the harness (include/granite_app.h).  Exceptions from the C++ layer stop here.
 #include "image_space_app.hpp"
+#include "../post/ssr.hpp"
 #include "../post/spd.hpp"
 #include "../gtx.hpp"
 #include "../post/hdr.hpp"
@@ -307,6 +308,20 @@ int gra_get_host_stats(gra_app *app, double *out3)
 			throw std::logic_error("gra_get_host_stats: null output");
 		app->app->get_host_stats(out3);
 	});
+}
+
+int gra_install_ssr_tables(const uint8_t *blue_noise_128x128_rg8, const uint16_t *brdf_lut_rg16f, uint32_t brdf_width, uint32_t brdf_height)
+{
+	try
+	{
+		Granite::ssr_install_tables(blue_noise_128x128_rg8, brdf_lut_rg16f, brdf_width, brdf_height);
+		return 0;
+	}
+	catch (const std::exception &e)
+	{
+		fprintf(stderr, "gra_install_ssr_tables: %s\n", e.what());
+		return -1;
+	}
 }
 
 int gra_get_prefetched_refreshes(gra_app *app, uint64_t *out)

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime_api.h>
 #include "../gtx.hpp"
 #include "../post/spd.hpp"
+#include "../post/ssr.hpp"
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -433,7 +434,9 @@ void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
 		hdr_out = &lighting_pass.add_color_output(tagcat("HDR", tag), emissive, tagcat("emissive", tag)); // reference form
 	else
 	{
-		hdr_out = &lighting_pass.add_color_output(tagcat("HDR", tag), emissive);
+		AttachmentInfo hdr_info = emissive;
+		hdr_info.flags &= ~ATTACHMENT_INFO_INTERNAL_RETAINED_BIT; // the lit target is rewritten every frame: an ordinary attachment
+		hdr_out = &lighting_pass.add_color_output(tagcat("HDR", tag), hdr_info);
 		emissive_in = &lighting_pass.add_attachment_input(tagcat("emissive", tag));
 	}
 	auto &in_albedo = lighting_pass.add_attachment_input(tagcat("albedo", tag));
@@ -489,6 +492,16 @@ void ImageSpaceApplication::bake_render_graph()
 		add_hdr_input_pass(tag);
 
 	std::string light_output = tagcat("HDR", tag);
+	if (config.ssr)
+	{
+		// scene_viewer_application.cpp:1206-1212
+		if (!config.enable_lighting)
+			throw std::logic_error("SSR needs the G-buffer of the deferred graph.");
+		if (!ssr_tables_installed())
+			throw std::logic_error("SSR: install the blue-noise and BRDF tables first (gra_install_ssr_tables).");
+		setup_ssr_pass(graph, context, tagcat("depth-transient", tag), tagcat("albedo", tag), tagcat("normal", tag), tagcat("pbr", tag), light_output, "SSR");
+		light_output = "SSR";
+	}
 	std::string ui_source = light_output;
 	const PostAAType pre_aa = to_post_aa_type(config.pre_aa);
 	const PostAAType post_aa = to_post_aa_type(config.post_aa);

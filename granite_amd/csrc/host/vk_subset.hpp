@@ -20,6 +20,7 @@ enum VkFormat : uint32_t
 	VK_FORMAT_R8G8B8A8_UNORM = 37,
 	VK_FORMAT_R8G8B8A8_SRGB = 43,
 	VK_FORMAT_A2B10G10R10_UNORM_PACK32 = 64,
+	VK_FORMAT_R16_SFLOAT = 76,
 	VK_FORMAT_R16G16_SFLOAT = 83,
 	VK_FORMAT_R16G16B16A16_SFLOAT = 97,
 	VK_FORMAT_R32_SFLOAT = 100,
@@ -80,6 +81,7 @@ static inline unsigned vk_format_block_size(VkFormat format)
 	case VK_FORMAT_R8_UNORM: return 1;
 	case VK_FORMAT_R8G8_UNORM: return 2;
 	case VK_FORMAT_D16_UNORM: return 2;
+	case VK_FORMAT_R16_SFLOAT: return 2;
 	case VK_FORMAT_R8G8B8A8_UNORM:
 	case VK_FORMAT_R8G8B8A8_SRGB:
 	case VK_FORMAT_A2B10G10R10_UNORM_PACK32:

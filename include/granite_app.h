@@ -78,6 +78,10 @@ typedef struct gra_config
 	 * declares the UI layer as a colour read-modify-write of the HDR target with another format, which its own validation
 	 * rejects (scene_viewer_application.cpp:1279-1287); the layer is its own attachment here. */
 	int32_t hdr10;
+	/* viewer_config "ssr" on the deferred path (scene_viewer_application.cpp:1206-1212): setup_ssr_pass between lighting and
+	 * the post chain -- depth hierarchy "depth-transient-main-hier", "SSR-trace" (classify + trace), "SSR" (apply, blended into
+	 * the lit target).  Needs enable_lighting and gra_install_ssr_tables before the first frame. */
+	int32_t ssr;
 } gra_config;
 
 /* Scene-level light description (one PositionalLight + its node transform). */
@@ -210,6 +214,9 @@ int gra_get_strip_plan(gra_app *app, uint32_t *out24);
 
 /* Host-side frame-loop cost since creation: out[0] = frames, out[1] = seconds spent inside the frame loop (light
  * refresh + graph execution = launches), out[2] = seconds of those spent blocked on GPU back-pressure. */
+/* The constant tables of the SSR pass (process-wide): the blue-noise sampler's 128 x 128 x 2 integer values and the
+ * R16G16_SFLOAT split-sum BRDF table (width x height texels); see csrc/host/post/ssr.hpp. */
+int gra_install_ssr_tables(const uint8_t *blue_noise_128x128_rg8, const uint16_t *brdf_lut_rg16f, uint32_t brdf_width, uint32_t brdf_height);
 int gra_get_host_stats(gra_app *app, double *out3);
 /* Frames whose light sort + pack (LightClusterer::refresh) had already been done by the clusterer's helper thread while the
  * previous frame was being enqueued (the reference runs its refreshes as TaskComposer tasks beside command recording). */

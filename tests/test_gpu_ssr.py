@@ -106,3 +106,44 @@ def test_apply_pass_matches_the_oracle(gr):
     np.testing.assert_array_equal(got[::17, ::13], light[::17, ::13])  # rejected pixels untouched
     assert (got != light).any(axis=2).mean() > 0.3                     # the pass does add reflections
     np.testing.assert_array_equal(got[..., 3], light[..., 3])          # alpha untouched
+
+
+def test_ssr_in_the_graph_matches_the_oracle_pipeline():
+    """viewer_config "ssr": depth hierarchy -> SSR-trace -> SSR (apply) between lighting and the post chain, through the
+    executor, against the oracle driven in graph order (lighting -> hiz -> classify / trace with the pass's dither layer ->
+    apply).  Two frames: the dither layer advances per frame (ssr.cpp:161)."""
+    from granite_amd import app as gapp
+    w, h = 384, 216
+    cam, depth, normal, pbr, albedo, light = close_up_scene(w, h, seed=2)
+    gbuf = {"emissive": light, "albedo": albedo, "normal": normal, "pbr": pbr, "depth": depth}
+    descs = synth.make_lights(cam, 64, z_lo=0.3, z_hi=3.0, max_range=1.5)
+    a = gapp.Application(w, h, ssr=True)
+    a.set_render_parameters(cam.render_params())
+    a.set_lights(descs)
+    a.upload_gbuffer(gbuf)
+    names = [p["name"] for p in a.graph()["passes"]]
+    assert names.index("lighting-main") < names.index("depth-transient-main-hier") < names.index("SSR-trace") < names.index("SSR") < names.index("bloom-compute")
+    rp = cam.render_params()
+    n, lights, model, tmask, _ = orc.pack_lights(descs, rp[99:102])
+    prm = orc.cluster_params(rp, *synth.CLUSTER_RESOLUTION, n)
+    cb = orc.cluster_build(rp, prm, lights, model, tmask, n, synth.CLUSTER_RESOLUTION[2])
+    lit = orc.lighting(gbuf, rp, prm, lights, tmask, cb["bitmask"], cb["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
+    levels = orc.hiz(depth, orc.hiz_z_transform(rp[48:64]))
+    noise, lut = expand_sssr_dither(load_sssr_noise_base()), load_brdf_lut()
+    for frame in (1, 2):
+        a.render_frames(1)
+        ref = orc.ssr_trace(levels, pbr, normal, lit, noise, frame, rp[32:48], rp[80:96], rp[96:99])
+        counter = a.read("ssr-ray-counter").view(np.uint32)[:6]
+        np.testing.assert_array_equal(counter, ref["ray_counter"])
+        np.testing.assert_array_equal(a.read("ssr-ray-list").view(np.uint32)[:int(counter[5])], ref["ray_list"])
+        conf = a.read("SSR-confidence").reshape(h, -1)[:, :w]
+        assert (np.abs(conf.astype(np.int16) - ref["confidence"].astype(np.int16)) > 1).mean() < 2e-3
+        sssr = a.read("SSR-sssr")
+        # the lit target differs from the oracle's by an ulp in a few texels; a reflected texel carries that along
+        assert rgba16f_mismatch(sssr, ref["output"], 3.0, 1e-4).any(axis=2).mean() < 3e-3
+        want = orc.ssr_apply(lit, sssr, albedo, normal, pbr, depth, lut, rp[80:96], rp[96:99])
+        assert rgba16f_mismatch(a.read("SSR"), want, 3.0, 1e-4).any(axis=2).mean() < 1e-3
+        assert (ref["confidence"] > 0).sum() > 100
+    # the post chain consumes the reflected target
+    assert (a.read_backbuffer()[..., :3] > 0).any()
+    a.close()
