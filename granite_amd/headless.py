@@ -19,7 +19,7 @@ frames, wait idle; `averageFrameTimeUs` = wall time / frames.  --stat keys: aver
 with --timestamp, performance{pass: timePerAccumulationUs, timePerFrameContextUs, accumulationsPerFrameContext}.
 --config understands the viewer_config keys that select image-space work (read_config, scene_viewer_application.cpp:
 163-260): renderer, hdrBloom, hdrBloomDynamicExposure, clusteredLights, postAA, resolutionScale, resolutionScaleSharpen,
-hdr10, ssao (as the lighting pass's ambient-occlusion input); keys that concern geometry or shadow passes are accepted and
+hdr10, ssao (as the lighting pass's ambient-occlusion input), ssr; keys that concern geometry or shadow passes are accepted and
 ignored, a forward renderer or MSAA is refused (no G-buffer for this executor to consume)."""
 from __future__ import annotations
 
@@ -46,7 +46,7 @@ UNSUPPORTED_AA = ("fxaa2phase", "smaaUltraT2X", "taaFSR2")
 IGNORED_KEYS = ("directionalLightShadows", "directionalLightShadowsCascaded", "directionalLightShadowsVSM", "PCFKernelWide",
                 "clusteredLightsShadows", "clusteredLightsShadowsResolution", "clusteredLightsShadowsVSM", "showUi",
                 "forwardDepthPrepass", "shadowMapResolution", "renderTargetFp16", "rescaleScene", "lodBias", "debugProbes",
-                "cameraIndex", "clusteredLightsBindless", "maxSpotLights", "maxPointLights", "ssr", "volumetricFog",
+                "cameraIndex", "clusteredLightsBindless", "maxSpotLights", "maxPointLights", "volumetricFog",
                 "volumetricDiffuse", "deferredClusteredStencilCulling")
 
 
@@ -58,7 +58,7 @@ def viewer_config_to_kwargs(doc: dict) -> dict:
     """viewer_config JSON -> Application keyword arguments.  Defaults are the viewer's (scene_viewer_application.hpp
     Config: deferred, hdr_bloom on, dynamic exposure on, clustered lights off, post AA none, resolution scale 1)."""
     kw = dict(lighting=True, hdr_bloom=True, dynamic_exposure=True, post_aa=gapp.POST_AA_NONE, resolution_scale=1.0,
-              resolution_scale_sharpen=True, hdr10=False, ambient_occlusion=False)
+              resolution_scale_sharpen=True, hdr10=False, ambient_occlusion=False, ssr=False)
     for key, value in doc.items():
         if key == "renderer":
             if value != "deferred":
@@ -86,6 +86,8 @@ def viewer_config_to_kwargs(doc: dict) -> dict:
             kw["hdr10"] = bool(value)
         elif key == "ssao":
             kw["ambient_occlusion"] = bool(value)
+        elif key == "ssr":
+            kw["ssr"] = bool(value)  # setup_ssr_pass on the deferred path (scene_viewer_application.cpp:1206-1212)
         elif key in IGNORED_KEYS:
             continue
         else:

@@ -141,7 +141,7 @@ def test_image_compare_directories(tmp_path):
 def test_viewer_config_mapping():
     kw = headless.viewer_config_to_kwargs({})
     assert kw == dict(lighting=True, hdr_bloom=True, dynamic_exposure=True, post_aa=gapp.POST_AA_NONE, resolution_scale=1.0,
-                      resolution_scale_sharpen=True, hdr10=False, ambient_occlusion=False)
+                      resolution_scale_sharpen=True, hdr10=False, ambient_occlusion=False, ssr=False)
     kw = headless.viewer_config_to_kwargs({"renderer": "deferred", "msaa": 1, "hdrBloom": True, "hdrBloomDynamicExposure": False,
                                            "postAA": "smaaHigh", "resolutionScale": 0.75, "resolutionScaleSharpen": False,
                                            "clusteredLights": True, "directionalLightShadows": True, "ssao": True,
@@ -149,6 +149,7 @@ def test_viewer_config_mapping():
     assert kw["post_aa"] == gapp.POST_AA_SMAA_HIGH and kw["resolution_scale"] == 0.75 and not kw["resolution_scale_sharpen"]
     assert not kw["dynamic_exposure"] and kw["ambient_occlusion"]
     assert headless.viewer_config_to_kwargs({"hdr10": True})["hdr_bloom"] is False
+    assert headless.viewer_config_to_kwargs({"ssr": True})["ssr"] is True
     for bad in ({"renderer": "forward"}, {"msaa": 4}, {"postAA": "taaFSR2"}, {"postAA": "bogus"}):
         with pytest.raises(headless.ConfigError):
             headless.viewer_config_to_kwargs(bad)
@@ -157,7 +158,7 @@ def test_viewer_config_mapping():
                                                                      "smaaUltra", "smaaUltraT2X", "taaLow", "taaMedium", "taaHigh",
                                                                      "taaFSR2"}
     # the mapped configs bake (no GPU needed)
-    for doc in ({"postAA": "fxaa"}, {"postAA": "taaMedium"}, {"resolutionScale": 0.5}, {"hdr10": True}, {"hdrBloom": False}):
+    for doc in ({"postAA": "fxaa"}, {"postAA": "taaMedium"}, {"resolutionScale": 0.5}, {"hdr10": True}, {"hdrBloom": False}, {"ssr": True}):
         a = gapp.Application(640, 360, device=-1, **headless.viewer_config_to_kwargs(doc))
         assert a.graph()["passes"]
         a.close()
