@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 // ImageSpaceApplication — headless composition + frame loop of the image-space chain on the HIP executor.
 // Graph composition follows SceneViewerApplication::bake_render_graph / add_main_pass_deferred
 // (application/scene_viewer_application.cpp:876-991,1167-1318); the frame loop follows render_frame (:1540-1611) and the

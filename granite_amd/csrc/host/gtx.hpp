@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 // GTX ("GRANITE TEXFMT1"): the container Granite stores textures and image dumps in
 // (vulkan/texture/memory_mapped_texture.cpp:29-44 header, vulkan/texture/texture_format.cpp:349-387 payload layout).
 // The wire format on either side of the image-space chain: G-buffer attachments dumped by a Granite build come in as

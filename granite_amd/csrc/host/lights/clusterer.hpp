@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 // LightClusterer — the bindless clustered-light path of renderer/lights/clusterer.{hpp,cpp} on the HIP executor.
 // Shadows, decals, volumetric diffuse / fog and the legacy (non-bindless) clusterer need scene geometry and are out of
 // scope; the class keeps the RenderPassCreator / PerFrameRefreshable surface used by the hot path.

@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 // Minimal column-major vector/matrix types with muglm's conventions (math/muglm/muglm.hpp): mat4 m[col][row],
 // mat_affine = 3 row vec4.  Only what the image-space host code needs.
 #pragma once

@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 // Anti-aliasing pass setup: renderer/post/{aa,fxaa,smaa,temporal}.hpp restated on the HIP executor.
 // Live variants only: FXAA, SMAA 1x Low..Ultra, TAA Low/Medium/High.  FXAA-2phase and SMAA-T2X do not
 // compile in the reference (missing GLSL functions), FSR2 needs an absent third_party module.

@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 // renderer/post/hdr.cpp restated on the HIP executor: identical pass / resource names, formats, size classes and push
 // constants; each recorded dispatch or full-screen quad becomes one C-ABI kernel launch.
 #include "hdr.hpp"

@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 // renderer/post/spd.{hpp,cpp} restated on the HIP executor: the single-pass downsampler (emit_single_pass_downsample, FFX SPD)
 // and the depth hierarchy pass built next to it.
 #pragma once

@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 // renderer/post/ssr.{hpp,cpp} restated on the HIP executor: the screen-space reflection passes (FidelityFX SSSR as Granite
 // vendors it).  Same pass / resource names, formats and sizes; the classify, build_indirect and trace_primary dispatches are one
 // gr_ssr_trace call, the blended apply quad one gr_ssr_apply call.

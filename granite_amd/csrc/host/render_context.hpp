@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 // FrameParameters / RenderParameters / RenderContext / LightingParameters — the slices of
 // renderer/render_context.{hpp,cpp} and math/render_parameters.hpp:37-59,155-162 the image-space passes read.
 #pragma once

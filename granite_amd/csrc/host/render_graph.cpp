@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 // Granite::RenderGraph on HIP streams — see render_graph.hpp for what is kept from / dropped against
 // renderer/render_graph.cpp.  Reference line numbers are cited per function.
 #include "render_graph.hpp"

@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 // Granite::RenderGraph — Vulkan-free restatement of the pass/attachment declaration API in
 // renderer/render_graph.hpp:48-73,124-251,434-893 so that code written against Granite's graph (setup_hdr_postprocess,
 // LightClusterer::add_render_passes, tests/render_graph_sandbox.cpp ...) declares its passes unchanged while the

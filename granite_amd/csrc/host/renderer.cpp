@@ -1,3 +1,5 @@
+// Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
+// THIRD_PARTY_NOTICES.md at the repository root.
 #include "renderer.hpp"
 #include "lights/clusterer.hpp"
 #include <cstring>
