@@ -21,6 +21,10 @@
 //   * `confidence` of a ray whose depth is exactly 1.0 is an uninitialised `out` in the shader; 0 here (unreachable:
 //     classify.comp only lists pixels with depth < 1).
 // trace_fallback.comp only runs with a volumetric-diffuse probe set bound (ssr.cpp:141), which is outside this path.
+//
+// PINNED: oracle/ref_build/ref_ssr.cpp executes the reference's own four shaders (re-spelled at build time, 64 real threads
+// per workgroup) under the same four statements; tests/test_reference_shaders_cpu.py::test_sssr_shaders_bit_for_bit requires
+// ray list, counters, traced colour, ray length, confidence and the blended target to be identical, bit for bit.
 #include "oracle_common.h"
 #include <vector>
 

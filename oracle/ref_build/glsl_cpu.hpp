@@ -141,6 +141,7 @@ struct tvec4
 	tvec4(const tvec2<T> &a_, const tvec2<T> &b_) : x(a_.x), y(a_.y), z(b_.x), w(b_.y) {}
 	tvec4(T x_, const tvec3<T> &v) : x(x_), y(v.x), z(v.y), w(v.z) {}
 	tvec4(T x_, const tvec2<T> &v, T w_) : x(x_), y(v.x), z(v.y), w(w_) {}
+	tvec4(T x_, T y_, const tvec2<T> &v) : x(x_), y(y_), z(v.x), w(v.y) {}
 	template <typename U> explicit tvec4(const tvec4<U> &o) : x(T(o.x)), y(T(o.y)), z(T(o.z)), w(T(o.w)) {}
 	tvec4(const tvec4 &o) : x(o.x), y(o.y), z(o.z), w(o.w) {}
 	tvec4 &operator=(const tvec4 &o) { x = o.x; y = o.y; z = o.z; w = o.w; return *this; }
@@ -251,6 +252,10 @@ inline float smoothstep(float e0, float e1, float v)
 {
 	const float t = clamp((v - e0) / (e1 - e0), 0.0f, 1.0f);
 	return t * t * (3.0f - 2.0f * t);
+}
+inline tvec2<float> smoothstep(const tvec2<float> &e0, const tvec2<float> &e1, const tvec2<float> &v)
+{
+	return tvec2<float>(smoothstep(e0.x, e1.x, v.x), smoothstep(e0.y, e1.y, v.y));
 }
 inline float fma(float a, float b, float c) { return fmaf(a, b, c); }
 inline uint floatBitsToUint(float v) { return orc::f2u(v); }
@@ -539,7 +544,7 @@ template <typename T> inline T subgroupBroadcastFirst(const T &v) { return v; }
 template <typename T> inline const T &nonuniformEXT(const T &v) { return v; }
 
 // ---- resources ------------------------------------------------------------------------------------------------------------
-enum class Format { RGBA16F, RGBA8_UNORM, RGBA8_SRGB, R32F, RG16F, RG8_UNORM, R8_UNORM, A2B10G10R10_UNORM };
+enum class Format { RGBA16F, RGBA8_UNORM, RGBA8_SRGB, R32F, RG16F, RG8_UNORM, R8_UNORM, A2B10G10R10_UNORM, R16F };
 enum class Filter { Linear, Nearest };
 
 struct Texture
@@ -590,6 +595,8 @@ struct Texture
 			const orc::vec4 v = orc::unpack_a2b10g10r10(static_cast<const uint32_t *>(data)[i]);
 			return vec4(v.x, v.y, v.z, v.w);
 		}
+		case Format::R16F:
+			return vec4(orc::half_to_float(static_cast<const uint16_t *>(data)[i]), 0.0f, 0.0f, 1.0f);
 		}
 		return vec4();
 	}
@@ -664,6 +671,12 @@ inline void imageStore(Image &img, const ivec2 &p, const vec4 &v)
 	}
 	case Format::R32F:
 		static_cast<float *>(img.data)[i] = v.x;
+		break;
+	case Format::R16F:
+		static_cast<uint16_t *>(img.data)[i] = orc::float_to_half_rne(v.x);
+		break;
+	case Format::R8_UNORM:
+		static_cast<uint8_t *>(img.data)[i] = orc::float_to_unorm8(v.x);
 		break;
 	default:
 		break;

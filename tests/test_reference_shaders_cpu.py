@@ -357,3 +357,44 @@ def test_spd_shader_bit_for_bit(ref, iw, ih, w0, h0, mips, components, depth, mo
     for level, (a, b) in enumerate(zip(want, got)):
         np.testing.assert_array_equal(b, a, err_msg=f"level {level}")
     assert len({int(v) for v in want[0][..., 0].reshape(-1)[:4096]}) > 100
+
+
+@pytest.mark.parametrize("w,h,frame", [(96, 64, 0), (75, 41, 5), (192, 108, 63)])
+def test_sssr_shaders_bit_for_bit(ref, w, h, frame):
+    """post/ffx-sssr: classify.comp + build_indirect.comp + trace_primary.comp (64 real threads per workgroup: quad swaps,
+    the ordered append, subgroupBallot as a rendezvous of the lanes still traversing) and apply.frag, on the close-up trough
+    scene of the GPU tests: ray list, counters, traced colour, ray length, confidence and the blended target, bit for bit with
+    oracle_ssr.cpp.  What the shader leaves to the hardware (append order, copy conflicts) is fixed as ref_ssr.cpp's header
+    says -- the same statement oracle_ssr.cpp makes."""
+    from granite_amd.data import expand_sssr_dither, load_brdf_lut, load_sssr_noise_base
+    from util import close_up_scene
+    cam, depth, normal, pbr, albedo, light = close_up_scene(w, h, seed=2)
+    rp = cam.render_params()
+    levels = orc.hiz(depth, orc.hiz_z_transform(rp[48:64]))
+    noise = expand_sssr_dither(load_sssr_noise_base())
+    want = orc.ssr_trace(levels, pbr, normal, light, noise, frame, rp[32:48], rp[80:96], rp[96:99])
+    ref.ref_ssr_classify.argtypes = ref.ref_ssr_trace.argtypes = [P]
+    got = orc.ssr_trace(levels, pbr, normal, light, noise, frame, rp[32:48], rp[80:96], rp[96:99],
+                        entry=(ref.ref_ssr_classify, ref.ref_ssr_trace))
+    np.testing.assert_array_equal(got["ray_counter"], want["ray_counter"])
+    assert len(want["ray_list"]) > 0.1 * w * h
+    np.testing.assert_array_equal(got["ray_list"], want["ray_list"])
+    assert (want["confidence"] > 0).sum() > 10, "some rays must hit with confidence"
+    copies = (want["ray_list"] >> 28) & 7
+    assert (copies & 1).any() and (copies & 2).any(), "the scene must exercise horizontal and vertical copies"
+    np.testing.assert_array_equal(got["confidence"], want["confidence"])
+    np.testing.assert_array_equal(got["ray_length"], want["ray_length"])
+    np.testing.assert_array_equal(got["output"], want["output"])
+
+    lut = load_brdf_lut()
+    real_depth = depth.copy()
+    real_depth[::7, ::5] = 1.0
+    want_hdr = orc.ssr_apply(light, want["output"], albedo, normal, pbr, real_depth, lut, rp[80:96], rp[96:99])
+    got_hdr = np.array(light, np.uint16, copy=True)
+    ivp, cam_pos = np.ascontiguousarray(rp[80:96], np.float32), np.ascontiguousarray(rp[96:99], np.float32)
+    ref.ref_ssr_apply.argtypes = [C.c_int, C.c_int, P, P, P, P, P, P, C.c_int, C.c_int, P, P, P]
+    keep = [np.ascontiguousarray(want["output"]), np.ascontiguousarray(albedo, np.uint32), np.ascontiguousarray(normal, np.uint32),
+            np.ascontiguousarray(pbr, np.uint16), np.ascontiguousarray(real_depth, np.float32), np.ascontiguousarray(lut, np.uint16)]
+    ref.ref_ssr_apply(w, h, *[ptr(k) for k in keep], lut.shape[1], lut.shape[0], ptr(ivp), ptr(cam_pos), ptr(got_hdr))
+    np.testing.assert_array_equal(got_hdr, want_hdr)
+    assert (got_hdr != light).any(axis=2).mean() > 0.2

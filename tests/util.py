@@ -1,6 +1,8 @@
 """Comparators that carry the stated tolerances (SURVEY.md §8a tolerance note)."""
 import numpy as np
 
+from granite_amd import synth
+
 
 def half_bits_to_f32(bits):
     return np.asarray(bits, np.uint16).view(np.float16).astype(np.float32)
@@ -41,3 +43,30 @@ def assert_rgba8_close(a, b, lsb=1, what=""):
         idx = np.argwhere(d > lsb)[0]
         raise AssertionError(f"{what}: {(d > lsb).sum()} of {d.size} bytes differ by more than {lsb} LSB; "
                              f"first at {tuple(idx)}: {np.asarray(a)[tuple(idx)]} vs {np.asarray(b)[tuple(idx)]} (max {d.max()})")
+
+
+def close_up_scene(w, h, seed=0):
+    """A trough within one unit of the camera (the pass only reflects where the hierarchy's level 0 is below 1: sssr_util.h
+    IsReflective on the view-space depth chain the reference feeds it): floor in the middle, walls rising towards the camera at
+    both sides and at the top, normals derived from that geometry so that reflected rays do find it again.  Left half glossy
+    (denoised: one ray per quad phase + copies), a mirror strip (one ray per pixel), the rest too rough to reflect."""
+    cam = synth.Camera(w, h)
+    g = synth.make_gbuffer(cam, synth.SEED + seed)
+    u, v = (np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h
+    view_z = 0.95 - 0.6 * np.abs(2 * u - 1)[None, :] ** 2 * np.ones((h, 1)) - 0.25 * (1 - v)[:, None] ** 2
+    view_z = np.clip(view_z, 0.25, 0.97)
+    depth = cam.depth_from_view_distance(view_z).astype(np.float32)
+    ys, xs = np.mgrid[0:h, 0:w]
+    ndc = np.stack([2 * (xs + 0.5) / w - 1, 2 * (ys + 0.5) / h - 1, depth.astype(np.float64), np.ones((h, w))], 0).reshape(4, -1)
+    clip = cam.invVP @ ndc
+    pos = (clip[:3] / clip[3]).T.reshape(h, w, 3)
+    n = np.cross(np.gradient(pos, axis=1), np.gradient(pos, axis=0))
+    n /= np.linalg.norm(n, axis=2, keepdims=True)
+    n[(n * (cam.position[None, None, :] - pos)).sum(2) < 0] *= -1
+    q = np.clip(np.rint((0.5 * n + 0.5) * 1023.0), 0, 1023).astype(np.uint32)
+    normal = (q[..., 0] | (q[..., 1] << 10) | (q[..., 2] << 20) | np.uint32(3 << 30)).astype(np.uint32)
+    pbr = g["pbr"].copy()
+    pbr[:, :w // 2] = (pbr[:, :w // 2] & 0xff) | (np.uint16(25) << 8)   # roughness 0.098: glossy, denoised
+    pbr[:, :w // 8] &= 0xff                                              # roughness 0: mirror
+    light = synth.make_hdr(w, h, synth.SEED + seed)
+    return cam, depth, normal, pbr, g["albedo"], light
