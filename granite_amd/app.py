@@ -58,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
     "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_prefetched_refreshes", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
-    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan",
+    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan", "gra_get_strip_plan_aa",
     "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_init_output", "gra_install_ssr_tables", "gra_reset_timestamps", "gra_set_directional_light", "gra_generate_mipmaps",
 ]
 
@@ -113,6 +113,7 @@ def load_library() -> C.CDLL:
         "gra_set_directional_light": (C.c_int, [vp, vp, vp]),
         "gra_set_exchange_callback": (C.c_int, [vp, EXCHANGE_FN, vp]),
         "gra_get_strip_plan": (C.c_int, [vp, vp]),
+        "gra_get_strip_plan_aa": (C.c_int, [vp, vp]),
         "gra_comm_create_unique_id": (C.c_int, [vp]),
         "gra_comm_init": (C.c_int, [vp, vp, C.c_int32, C.c_int32]),
         "gra_comm_init_output": (C.c_int, [vp, vp, C.c_int32, C.c_int32]),
@@ -380,6 +381,11 @@ class Application:
             whole, first, count = (int(v) for v in out[4 + 3 * i:7 + 3 * i])
             plan[name] = None if whole else (first, count)
         plan["d1_chunk_rows"], plan["out_chunk_rows"] = int(out[22]), int(out[23])
+        aa = np.zeros(12, np.uint32)
+        self._check(self.lib.gra_get_strip_plan_aa(self.handle, aa.ctypes.data))
+        for i, name in enumerate(("taa", "smaa_edges", "smaa_weights", "aa_out")):
+            whole, first, count = (int(v) for v in aa[3 * i:3 * i + 3])
+            plan[name] = None if whole else (first, count)
         return plan
 
     def host_stats(self) -> dict:

@@ -86,11 +86,11 @@ __device__ __forceinline__ void store_rgba8(uint8_t *ptr, uint32_t pitch, int x,
 }
 
 // ---- FXAA (fxaa.frag:20-67) --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_fxaa(Tex8<4> tex, uint8_t *out, uint32_t out_pitch, gr_push_fxaa push)
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_fxaa(Tex8<4> tex, uint8_t *out, uint32_t out_pitch, gr_push_fxaa push, RowSpan rows)
 {
 	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
-	const int y = blockIdx.y * AA_BLOCK_Y + threadIdx.y;
-	if (x >= tex.w || y >= tex.h)
+	const int y = int(rows.first) + blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	if (x >= tex.w || y >= int(rows.end))
 		return;
 	const float FXAA_REDUCE_MIN = 1.0f / 128.0f, FXAA_REDUCE_MUL = 1.0f / 8.0f, FXAA_SPAN_MAX = 8.0f;
 	const v2 inv_resolution = mk2(push.inv_resolution[0], push.inv_resolution[1]);
@@ -141,11 +141,11 @@ static SmaaPreset smaa_preset(int quality)
 // SMAALumaEdgeDetectionPS (SMAA.hlsl:689-740).  Every pixel is written (0 = what the reference leaves as the clear value
 // when the fragment is discarded), so no separate clear pass is needed.
 __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_edges(Tex8<4> tex, uint8_t *edges, uint32_t edges_pitch, gr_push_smaa push,
-                                                                       SmaaPreset P)
+                                                                       SmaaPreset P, RowSpan rows)
 {
 	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
-	const int y = blockIdx.y * AA_BLOCK_Y + threadIdx.y;
-	if (x >= tex.w || y >= tex.h)
+	const int y = int(rows.first) + blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	if (x >= tex.w || y >= int(rows.end))
 		return;
 	const v2 rt = mk2(push.rt_metrics[0], push.rt_metrics[1]);
 	const v2 tc = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
@@ -462,11 +462,11 @@ struct SmaaWeights
 
 // SMAABlendingWeightCalculationPS.  The reference runs this quad under a depth mask EQUAL to the edge pass's
 // non-discarded pixels (smaa.cpp:101-112,170-177); the mask is the edge texel itself here: zero edge => zero weights.
-__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_weights(SmaaWeights S, uint8_t *out, uint32_t out_pitch)
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_weights(SmaaWeights S, uint8_t *out, uint32_t out_pitch, RowSpan rows)
 {
 	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
-	const int y = blockIdx.y * AA_BLOCK_Y + threadIdx.y;
-	if (x >= S.edges.w || y >= S.edges.h)
+	const int y = int(rows.first) + blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	if (x >= S.edges.w || y >= int(rows.end))
 		return;
 	const uint16_t e = *reinterpret_cast<const uint16_t *>(S.edges.ptr + size_t(y) * S.edges.pitch + size_t(x) * 2u);
 	uint32_t packed = 0u;
@@ -479,11 +479,12 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_weights(SmaaWei
 }
 
 // SMAANeighborhoodBlendingPS (SMAA.hlsl:1252-1308)
-__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_blend(Tex8<4> ctex, Tex8<4> btex, uint8_t *out, uint32_t out_pitch, gr_push_smaa push)
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_blend(Tex8<4> ctex, Tex8<4> btex, uint8_t *out, uint32_t out_pitch, gr_push_smaa push,
+                                                                       RowSpan rows)
 {
 	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
-	const int y = blockIdx.y * AA_BLOCK_Y + threadIdx.y;
-	if (x >= ctex.w || y >= ctex.h)
+	const int y = int(rows.first) + blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	if (x >= ctex.w || y >= int(rows.end))
 		return;
 	const v2 rt = mk2(push.rt_metrics[0], push.rt_metrics[1]);
 	const v2 texcoord = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
@@ -562,6 +563,7 @@ struct TaaArgs
 	float rt[4];
 	int quality;
 	int has_history;
+	RowSpan rows;
 };
 
 __device__ __forceinline__ v3 sample_linear3(const DevImage &img, float u, float v)
@@ -581,9 +583,9 @@ __device__ __forceinline__ v3 sample_linear3(const DevImage &img, float u, float
 __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs a)
 {
 	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
-	const int y = blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	const int y = int(a.rows.first) + blockIdx.y * AA_BLOCK_Y + threadIdx.y;
 	const int w = a.current.w, h = a.current.h;
-	if (x >= w || y >= h)
+	if (x >= w || y >= int(a.rows.end))
 		return;
 	const v4 rt = mk4(a.rt[0], a.rt[1], a.rt[2], a.rt[3]);
 	const v2 uv = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
@@ -758,19 +760,33 @@ int gr_smaa_set_luts(gr_ctx *ctx, const void *area_rg8, const void *search_r8)
 
 int gr_fxaa(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_push_fxaa *push)
 {
+	return gr_fxaa_rows(ctx, stream, in, out, push, nullptr);
+}
+
+int gr_fxaa_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_push_fxaa *push, const gr_rows *rows)
+{
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, push && in && out && in->width && in->height);
 	GR_CHECK_ARG(ctx, check_image(in, 4, in->width, in->height) && check_image(out, 4, in->width, in->height));
 	GR_CHECK_ARG(ctx, is_rgba8(in->format) && is_rgba8(out->format) && in->ptr != out->ptr);
+	const RowSpan span = resolve_rows(rows, in->height);
+	if (span.count() == 0)
+		return GR_OK;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "fxaa"};
-	hipLaunchKernelGGL(k_fxaa, aa_grid(in->width, in->height), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), make_tex8<4>(in),
-	                   static_cast<uint8_t *>(out->ptr), out->pitch_bytes, *push);
+	hipLaunchKernelGGL(k_fxaa, aa_grid(in->width, span.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), make_tex8<4>(in),
+	                   static_cast<uint8_t *>(out->ptr), out->pitch_bytes, *push, span);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
 
 int gr_smaa_edge_detection(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *edges, const gr_push_smaa *push, int quality)
+{
+	return gr_smaa_edge_detection_rows(ctx, stream, color, edges, push, quality, nullptr);
+}
+
+int gr_smaa_edge_detection_rows(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *edges, const gr_push_smaa *push, int quality,
+                                const gr_rows *rows)
 {
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
@@ -778,14 +794,23 @@ int gr_smaa_edge_detection(gr_ctx *ctx, gr_stream stream, const gr_image *color,
 	GR_CHECK_ARG(ctx, quality >= 0 && quality <= 3);
 	GR_CHECK_ARG(ctx, check_image(color, 4, color->width, color->height) && is_rgba8(color->format));
 	GR_CHECK_ARG(ctx, check_image(edges, 2, color->width, color->height) && edges->format == GR_FORMAT_R8G8_UNORM);
+	const RowSpan span = resolve_rows(rows, color->height);
+	if (span.count() == 0)
+		return GR_OK;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_edge_detection"};
-	hipLaunchKernelGGL(k_smaa_edges, aa_grid(color->width, color->height), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), make_tex8<4>(color),
-	                   static_cast<uint8_t *>(edges->ptr), edges->pitch_bytes, *push, smaa_preset(quality));
+	hipLaunchKernelGGL(k_smaa_edges, aa_grid(color->width, span.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), make_tex8<4>(color),
+	                   static_cast<uint8_t *>(edges->ptr), edges->pitch_bytes, *push, smaa_preset(quality), span);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
 
 int gr_smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality)
+{
+	return gr_smaa_blend_weight_rows(ctx, stream, edges, weights, push, quality, nullptr);
+}
+
+int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality,
+                              const gr_rows *rows)
 {
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
@@ -801,9 +826,12 @@ int gr_smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, c
 	S.search = {static_cast<const uint8_t *>(ctx->smaa_search), 64, 16, 64u};
 	S.rt = v4{push->rt_metrics[0], push->rt_metrics[1], push->rt_metrics[2], push->rt_metrics[3]};
 	S.P = smaa_preset(quality);
+	const RowSpan span = resolve_rows(rows, edges->height);
+	if (span.count() == 0)
+		return GR_OK;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_blend_weight"};
-	hipLaunchKernelGGL(k_smaa_weights, aa_grid(edges->width, edges->height), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), S,
-	                   static_cast<uint8_t *>(weights->ptr), weights->pitch_bytes);
+	hipLaunchKernelGGL(k_smaa_weights, aa_grid(edges->width, span.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), S,
+	                   static_cast<uint8_t *>(weights->ptr), weights->pitch_bytes, span);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
@@ -811,21 +839,36 @@ int gr_smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, c
 int gr_smaa_neighbor_blend(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *weights, const gr_image *out,
                            const gr_push_smaa *push)
 {
+	return gr_smaa_neighbor_blend_rows(ctx, stream, color, weights, out, push, nullptr);
+}
+
+int gr_smaa_neighbor_blend_rows(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *weights, const gr_image *out,
+                                const gr_push_smaa *push, const gr_rows *rows)
+{
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, push && color && weights && out && color->width && color->height);
 	GR_CHECK_ARG(ctx, check_image(color, 4, color->width, color->height) && is_rgba8(color->format));
 	GR_CHECK_ARG(ctx, check_image(weights, 4, color->width, color->height) && weights->format == GR_FORMAT_R8G8B8A8_UNORM);
 	GR_CHECK_ARG(ctx, check_image(out, 4, color->width, color->height) && is_rgba8(out->format) && out->ptr != color->ptr);
+	const RowSpan span = resolve_rows(rows, color->height);
+	if (span.count() == 0)
+		return GR_OK;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_neighbor_blend"};
-	hipLaunchKernelGGL(k_smaa_blend, aa_grid(color->width, color->height), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream),
-	                   make_tex8<4>(color), make_tex8<4>(weights), static_cast<uint8_t *>(out->ptr), out->pitch_bytes, *push);
+	hipLaunchKernelGGL(k_smaa_blend, aa_grid(color->width, span.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream),
+	                   make_tex8<4>(color), make_tex8<4>(weights), static_cast<uint8_t *>(out->ptr), out->pitch_bytes, *push, span);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
 
 int gr_taa_resolve(gr_ctx *ctx, gr_stream stream, const gr_image *current, const gr_image *depth, const gr_image *mv, const gr_image *history,
                    const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality)
+{
+	return gr_taa_resolve_rows(ctx, stream, current, depth, mv, history, out_color, out_history, push, quality, nullptr);
+}
+
+int gr_taa_resolve_rows(gr_ctx *ctx, gr_stream stream, const gr_image *current, const gr_image *depth, const gr_image *mv, const gr_image *history,
+                        const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality, const gr_rows *rows)
 {
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
@@ -855,8 +898,11 @@ int gr_taa_resolve(gr_ctx *ctx, gr_stream stream, const gr_image *current, const
 		a.rt[i] = push->rt_metrics[i];
 	a.quality = quality;
 	a.has_history = history != nullptr;
+	a.rows = resolve_rows(rows, h);
+	if (a.rows.count() == 0)
+		return GR_OK;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "taa_resolve"};
-	hipLaunchKernelGGL(k_taa_resolve, aa_grid(w, h), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), a);
+	hipLaunchKernelGGL(k_taa_resolve, aa_grid(w, a.rows.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), a);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

@@ -129,3 +129,18 @@ struct gr_scoped_timing
 
 static inline hipStream_t gr_to_stream(gr_stream s) { return static_cast<hipStream_t>(s); }
 static inline unsigned gr_div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+// Resolves a render area (gr_rows) against `height` output rows: [first, end), empty when the band lies outside the image.
+struct RowSpan
+{
+	uint32_t first, end;
+	uint32_t count() const { return end - first; }
+};
+static inline RowSpan resolve_rows(const gr_rows *rows, uint32_t height)
+{
+	if (!rows || rows->count == 0)
+		return {0, height};
+	const uint32_t first = rows->first < height ? rows->first : height;
+	const uint64_t end = uint64_t(rows->first) + rows->count;
+	return {first, end < height ? uint32_t(end) : height};
+}

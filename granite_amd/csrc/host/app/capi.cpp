@@ -301,6 +301,22 @@ int gra_get_strip_plan(gra_app *app, uint32_t *out24)
 	});
 }
 
+int gra_get_strip_plan_aa(gra_app *app, uint32_t *out12)
+{
+	return guarded(app, [&]() {
+		if (!out12)
+			throw std::logic_error("gra_get_strip_plan_aa: null output");
+		auto &p = app->app->get_strip_plan();
+		uint32_t *o = out12;
+		for (const Granite::RowRange *r : {&p.taa, &p.smaa_edges, &p.smaa_weights, &p.aa_out})
+		{
+			*o++ = r->whole ? 1u : 0u;
+			*o++ = r->first;
+			*o++ = r->count;
+		}
+	});
+}
+
 int gra_get_host_stats(gra_app *app, double *out3)
 {
 	return guarded(app, [&]() {

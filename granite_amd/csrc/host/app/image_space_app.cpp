@@ -16,6 +16,22 @@ static std::string tagcat(const std::string &a, const std::string &b)
 	return a + "-" + b;
 }
 
+static PostAAType to_post_aa_type(int32_t v)
+{
+	switch (v)
+	{
+	case GRA_POST_AA_FXAA: return PostAAType::FXAA;
+	case GRA_POST_AA_SMAA_LOW: return PostAAType::SMAA_Low;
+	case GRA_POST_AA_SMAA_MEDIUM: return PostAAType::SMAA_Medium;
+	case GRA_POST_AA_SMAA_HIGH: return PostAAType::SMAA_High;
+	case GRA_POST_AA_SMAA_ULTRA: return PostAAType::SMAA_Ultra;
+	case GRA_POST_AA_TAA_LOW: return PostAAType::TAA_Low;
+	case GRA_POST_AA_TAA_MEDIUM: return PostAAType::TAA_Medium;
+	case GRA_POST_AA_TAA_HIGH: return PostAAType::TAA_High;
+	default: return PostAAType::None;
+	}
+}
+
 ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config(config_)
 {
 	if (config.device >= 0)
@@ -60,11 +76,21 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 	{
 		if (config.strip_index >= config.strip_count)
 			throw std::logic_error("strip_index must be below strip_count.");
-		if (!config.enable_lighting || !config.hdr_bloom || !config.compute_post || config.post_aa != GRA_POST_AA_NONE ||
-		    config.pre_aa != GRA_POST_AA_NONE || config.rmw_emissive)
-			throw std::logic_error("Row-band tiling needs the deferred compute-post graph without AA and without the RMW emissive declaration.");
+		if (!config.enable_lighting || !config.hdr_bloom || !config.compute_post || config.rmw_emissive || config.ssr)
+			throw std::logic_error("Row-band tiling needs the deferred compute-post graph without SSR and without the RMW emissive declaration.");
 	}
-	strip_plan = StripPlan::build(config.strip_index, config.strip_count, config.width, config.height);
+	// What the anti-aliasing passes reach for around a band: FXAA / SMAA after the tonemap, TAA before it.
+	StripAA strip_aa;
+	const PostAAType post_type = to_post_aa_type(config.post_aa), pre_type = to_post_aa_type(config.pre_aa);
+	if (post_type == PostAAType::FXAA)
+		strip_aa.post = StripAA::Post::FXAA;
+	else if (smaa_search_steps(post_type))
+	{
+		strip_aa.post = StripAA::Post::SMAA;
+		strip_aa.smaa_search_steps = smaa_search_steps(post_type);
+	}
+	strip_aa.temporal = pre_type == PostAAType::TAA_Low || pre_type == PostAAType::TAA_Medium || pre_type == PostAAType::TAA_High;
+	strip_plan = StripPlan::build(config.strip_index, config.strip_count, config.width, config.height, strip_aa);
 	hdr_options.strip = &strip_plan;
 
 	// Default camera of the survey's synthetic scene; gra_set_camera / gra_set_render_parameters override it.
@@ -182,21 +208,6 @@ mat4 ImageSpaceApplication::get_taa_reprojection() const
 	return translate(vec3(0.5f, 0.5f, 0.0f)) * scale(vec3(0.5f, 0.5f, 1.0f)) * jitter.get_history_view_proj(1) * jitter.get_history_inv_view_proj(0);
 }
 
-static PostAAType to_post_aa_type(int32_t v)
-{
-	switch (v)
-	{
-	case GRA_POST_AA_FXAA: return PostAAType::FXAA;
-	case GRA_POST_AA_SMAA_LOW: return PostAAType::SMAA_Low;
-	case GRA_POST_AA_SMAA_MEDIUM: return PostAAType::SMAA_Medium;
-	case GRA_POST_AA_SMAA_HIGH: return PostAAType::SMAA_High;
-	case GRA_POST_AA_SMAA_ULTRA: return PostAAType::SMAA_Ultra;
-	case GRA_POST_AA_TAA_LOW: return PostAAType::TAA_Low;
-	case GRA_POST_AA_TAA_MEDIUM: return PostAAType::TAA_Medium;
-	case GRA_POST_AA_TAA_HIGH: return PostAAType::TAA_High;
-	default: return PostAAType::None;
-	}
-}
 
 void ImageSpaceApplication::set_lights(const gra_light_desc *descs, uint32_t count)
 {
@@ -520,7 +531,7 @@ void ImageSpaceApplication::bake_render_graph()
 	if (config.hdr_bloom)
 	{
 		bool resolved = setup_before_post_chain_antialiasing(pre_aa, graph, jitter, context, 1.0f, light_output, tagcat("depth", tag),
-		                                                     tagcat("mv", tag), "HDR-resolved");
+		                                                     tagcat("mv", tag), "HDR-resolved", &strip_plan);
 		const std::string hdr_source = resolved ? "HDR-resolved" : light_output;
 		if (config.compute_post)
 			setup_hdr_postprocess_compute(graph, frame, hdr_source, "tonemapped", hdr_options);
@@ -534,7 +545,7 @@ void ImageSpaceApplication::bake_render_graph()
 		// PostAAType is a single enum in the viewer; the API composes TAA before and FXAA/SMAA after the chain, but the
 		// later jitter.init() wins (smaa.cpp:60-67), so the temporal table is restored afterwards.
 		TemporalJitter saved = jitter;
-		if (setup_after_post_chain_antialiasing(post_aa, graph, jitter, 1.0f, ui_source, tagcat("depth", tag), "post-aa-output"))
+		if (setup_after_post_chain_antialiasing(post_aa, graph, jitter, 1.0f, ui_source, tagcat("depth", tag), "post-aa-output", &strip_plan))
 			ui_source = "post-aa-output";
 		if (temporal)
 			jitter = saved;

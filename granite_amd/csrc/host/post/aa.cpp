@@ -68,8 +68,33 @@ unsigned TemporalJitter::get_offset_phase(int frames) const
 	return phase >= unsigned(frames) ? phase - unsigned(frames) : jitter_count - unsigned(frames);
 }
 
+namespace
+{
+// The plan when there is anything to restrict (or a transport to exercise), else nullptr.
+const StripPlan *live(const StripPlan *plan)
+{
+	return plan && (plan->active() || plan->exchange) ? plan : nullptr;
+}
+
+// The pass that writes the frame's output image under row bands: waits for the gather that last used the image before
+// writing its band (acquire), and sends the bands to meet in every rank's image afterwards.
+void acquire_output(const StripPlan *strip, HIP::CommandBuffer &cmd, HIP::Image &output)
+{
+	if (strip && strip->acquire_output)
+		strip->acquire_output(cmd, output);
+}
+
+void gather_output(const StripPlan *strip, HIP::CommandBuffer &cmd, HIP::Image &output, const char *tag)
+{
+	if (strip && strip->exchange_output)
+		strip->exchange_output(cmd, output, strip->out_chunk_rows, tag);
+	else if (strip && strip->exchange)
+		strip->exchange(cmd, output, strip->out_chunk_rows, tag);
+}
+} // namespace
+
 // ---- FXAA (fxaa.cpp:28-55) ------------------------------------------------------------------------------------------------
-void setup_fxaa_postprocess(RenderGraph &graph, const std::string &input, const std::string &output, VkFormat output_format)
+void setup_fxaa_postprocess(RenderGraph &graph, const std::string &input, const std::string &output, VkFormat output_format, const StripPlan *plan)
 {
 	graph.get_texture_resource(input).get_attachment_info().flags |= ATTACHMENT_INFO_UNORM_SRGB_ALIAS_BIT;
 
@@ -82,17 +107,22 @@ void setup_fxaa_postprocess(RenderGraph &graph, const std::string &input, const 
 	fxaa.add_color_output(output, fxaa_output);
 	auto &fxaa_input = fxaa.add_texture_input(input);
 
-	fxaa.set_build_render_pass([&graph, &fxaa, &fxaa_input](HIP::CommandBuffer &cmd) {
+	fxaa.set_build_render_pass([&graph, &fxaa, &fxaa_input, plan](HIP::CommandBuffer &cmd) {
+		const StripPlan *strip = live(plan);
 		auto &input_image = graph.get_physical_texture_resource(fxaa_input);
 		auto &output_image = graph.get_physical_texture_resource(*fxaa.get_color_outputs()[0]);
 		gr_push_fxaa push = {{1.0f / float(input_image.get_width()), 1.0f / float(input_image.get_height())}};
-		cmd.check(gr_fxaa(cmd.get_context(), cmd.get_stream(), &input_image.get_view(), &output_image.get_view(), &push), "fxaa");
+		gr_rows rows;
+		acquire_output(strip, cmd, output_image);
+		if (to_rows(strip ? &strip->aa_out : nullptr, rows))
+			cmd.check(gr_fxaa_rows(cmd.get_context(), cmd.get_stream(), &input_image.get_view(), &output_image.get_view(), &push, &rows), "fxaa");
+		gather_output(strip, cmd, output_image, "fxaa");
 	});
 }
 
 // ---- SMAA (smaa.cpp:32-208) ------------------------------------------------------------------------------------------------
 void setup_smaa_postprocess(RenderGraph &graph, TemporalJitter &jitter, float, const std::string &input, const std::string &,
-                            const std::string &output, SMAAPreset preset)
+                            const std::string &output, SMAAPreset preset, const StripPlan *plan)
 {
 	if (preset == SMAAPreset::Ultra_T2X)
 		throw std::logic_error("SMAA T2X is not live in the reference (smaa_t2x_resolve.frag does not compile) and is not provided.");
@@ -142,34 +172,48 @@ void setup_smaa_postprocess(RenderGraph &graph, TemporalJitter &jitter, float, c
 
 	// Both kernels write every pixel (0 where the shader would discard / be masked), which subsumes the reference's
 	// LOAD_OP_CLEAR to 0 (smaa.cpp:139-143,180-184): no get_clear_color callbacks are installed.
-	smaa_edge.set_build_render_pass([&graph, &edge_input_res, &edge_output_res, metrics, q = smaa_quality](HIP::CommandBuffer &cmd) {
+	// Row bands (plan): each pass covers the rows the next one reads around this rank's output chunk (StripPlan::build).
+	smaa_edge.set_build_render_pass([&graph, &edge_input_res, &edge_output_res, metrics, q = smaa_quality, plan](HIP::CommandBuffer &cmd) {
+		const StripPlan *strip = live(plan);
 		auto &input_image = graph.get_physical_texture_resource(edge_input_res);
 		auto &edges = graph.get_physical_texture_resource(edge_output_res);
 		auto push = metrics(input_image);
-		cmd.check(gr_smaa_edge_detection(cmd.get_context(), cmd.get_stream(), &input_image.get_view(), &edges.get_view(), &push, q), "smaa-edge");
+		gr_rows rows;
+		if (to_rows(strip ? &strip->smaa_edges : nullptr, rows))
+			cmd.check(gr_smaa_edge_detection_rows(cmd.get_context(), cmd.get_stream(), &input_image.get_view(), &edges.get_view(), &push, q, &rows),
+			          "smaa-edge");
 	});
 
-	smaa_weight.set_build_render_pass([&graph, &weight_input_res, &weight_output_res, metrics, q = smaa_quality](HIP::CommandBuffer &cmd) {
+	smaa_weight.set_build_render_pass([&graph, &weight_input_res, &weight_output_res, metrics, q = smaa_quality, plan](HIP::CommandBuffer &cmd) {
+		const StripPlan *strip = live(plan);
 		auto &edges = graph.get_physical_texture_resource(weight_input_res);
 		auto &weights = graph.get_physical_texture_resource(weight_output_res);
 		auto push = metrics(edges);
-		cmd.check(gr_smaa_blend_weight(cmd.get_context(), cmd.get_stream(), &edges.get_view(), &weights.get_view(), &push, q), "smaa-weights");
+		gr_rows rows;
+		if (to_rows(strip ? &strip->smaa_weights : nullptr, rows))
+			cmd.check(gr_smaa_blend_weight_rows(cmd.get_context(), cmd.get_stream(), &edges.get_view(), &weights.get_view(), &push, q, &rows),
+			          "smaa-weights");
 	});
 
-	smaa_blend.set_build_render_pass([&graph, &smaa_blend, &blend_input_res, &blend_weight_res, metrics](HIP::CommandBuffer &cmd) {
+	smaa_blend.set_build_render_pass([&graph, &smaa_blend, &blend_input_res, &blend_weight_res, metrics, plan](HIP::CommandBuffer &cmd) {
+		const StripPlan *strip = live(plan);
 		auto &input_image = graph.get_physical_texture_resource(blend_input_res);
 		auto &blend_image = graph.get_physical_texture_resource(blend_weight_res);
 		auto &output_image = graph.get_physical_texture_resource(*smaa_blend.get_color_outputs()[0]);
 		auto push = metrics(input_image);
-		cmd.check(gr_smaa_neighbor_blend(cmd.get_context(), cmd.get_stream(), &input_image.get_view(), &blend_image.get_view(),
-		                                 &output_image.get_view(), &push),
-		          "smaa-blend");
+		gr_rows rows;
+		acquire_output(strip, cmd, output_image);
+		if (to_rows(strip ? &strip->aa_out : nullptr, rows))
+			cmd.check(gr_smaa_neighbor_blend_rows(cmd.get_context(), cmd.get_stream(), &input_image.get_view(), &blend_image.get_view(),
+			                                      &output_image.get_view(), &push, &rows),
+			          "smaa-blend");
+		gather_output(strip, cmd, output_image, "smaa-blend");
 	});
 }
 
 // ---- TAA (temporal.cpp:199-266) ---------------------------------------------------------------------------------------------
 void setup_taa_resolve(RenderGraph &graph, TemporalJitter &jitter, float scaling_factor, const std::string &input, const std::string &input_depth,
-                       const std::string &input_mv, const std::string &output, TAAQuality quality)
+                       const std::string &input_mv, const std::string &output, TAAQuality quality, const StripPlan *plan)
 {
 	jitter.init(TemporalJitter::Type::TAA_16Phase,
 	            vec2(float(graph.get_backbuffer_dimensions().width) * scaling_factor, float(graph.get_backbuffer_dimensions().height) * scaling_factor));
@@ -189,7 +233,8 @@ void setup_taa_resolve(RenderGraph &graph, TemporalJitter &jitter, float scaling
 	auto &history = resolve.add_history_input(output + "-history");
 
 	resolve.set_build_render_pass(
-	    [&graph, &jitter, &out_color, &out_history, &input_res, &input_res_mv, &input_depth_res, &history, q = int(quality)](HIP::CommandBuffer &cmd) {
+	    [&graph, &jitter, &out_color, &out_history, &input_res, &input_res_mv, &input_depth_res, &history, q = int(quality), plan](HIP::CommandBuffer &cmd) {
+		    const StripPlan *strip = live(plan);
 		    auto &image = graph.get_physical_texture_resource(input_res);
 		    auto &image_mv = graph.get_physical_texture_resource(input_res_mv);
 		    auto &depth = graph.get_physical_texture_resource(input_depth_res);
@@ -205,16 +250,23 @@ void setup_taa_resolve(RenderGraph &graph, TemporalJitter &jitter, float scaling
 		    push.rt_metrics[1] = 1.0f / float(image.get_height());
 		    push.rt_metrics[2] = float(image.get_width());
 		    push.rt_metrics[3] = float(image.get_height());
-		    cmd.check(gr_taa_resolve(cmd.get_context(), cmd.get_stream(), &image.get_view(), &depth.get_view(), &image_mv.get_view(),
-		                             prev ? &prev->get_view() : nullptr, &color.get_view(), &hist.get_view(), &push, q),
-		              "taa-resolve");
+		    gr_rows rows;
+		    if (to_rows(strip ? &strip->taa : nullptr, rows))
+			    cmd.check(gr_taa_resolve_rows(cmd.get_context(), cmd.get_stream(), &image.get_view(), &depth.get_view(), &image_mv.get_view(),
+			                                  prev ? &prev->get_view() : nullptr, &color.get_view(), &hist.get_view(), &push, q, &rows),
+			              "taa-resolve");
+		    // Row bands: next frame's reprojection may read the history anywhere, so the bands meet in every rank's history
+		    // image (same chunking as the output image; rows a rank resolved beyond its chunk are overwritten with the
+		    // owner's identical values).
+		    if (strip && strip->exchange)
+			    strip->exchange(cmd, hist, strip->out_chunk_rows, "taa-history");
 	    });
 }
 
 // ---- dispatcher (aa.cpp:176-290) ----------------------------------------------------------------------------------------------
 bool setup_before_post_chain_antialiasing(PostAAType type, RenderGraph &graph, TemporalJitter &jitter, const RenderContext &, float scaling_factor,
                                           const std::string &input, const std::string &input_depth, const std::string &input_mv,
-                                          const std::string &output)
+                                          const std::string &output, const StripPlan *strip)
 {
 	TAAQuality taa_quality;
 	switch (type)
@@ -225,7 +277,7 @@ bool setup_before_post_chain_antialiasing(PostAAType type, RenderGraph &graph, T
 	case PostAAType::TAA_FSR2: throw std::logic_error("FSR2 needs third_party/fsr2, which the reference checkout does not contain.");
 	default: return false;
 	}
-	setup_taa_resolve(graph, jitter, scaling_factor, input, input_depth, input_mv, output, taa_quality);
+	setup_taa_resolve(graph, jitter, scaling_factor, input, input_depth, input_mv, output, taa_quality, strip);
 	return true;
 }
 
@@ -266,8 +318,20 @@ bool setup_after_post_chain_upscaling(RenderGraph &graph, const std::string &inp
 	return true;
 }
 
+unsigned smaa_search_steps(PostAAType type)
+{
+	switch (type)
+	{
+	case PostAAType::SMAA_Low: return 4;
+	case PostAAType::SMAA_Medium: return 8;
+	case PostAAType::SMAA_High: return 16;
+	case PostAAType::SMAA_Ultra: return 32;
+	default: return 0;
+	}
+}
+
 bool setup_after_post_chain_antialiasing(PostAAType type, RenderGraph &graph, TemporalJitter &jitter, float scaling_factor, const std::string &input,
-                                         const std::string &input_depth, const std::string &output)
+                                         const std::string &input_depth, const std::string &output, const StripPlan *strip)
 {
 	switch (type)
 	{
@@ -275,19 +339,19 @@ bool setup_after_post_chain_antialiasing(PostAAType type, RenderGraph &graph, Te
 		jitter.init(TemporalJitter::Type::None, vec2(0.0f));
 		return false;
 	case PostAAType::FXAA:
-		setup_fxaa_postprocess(graph, input, output);
+		setup_fxaa_postprocess(graph, input, output, VK_FORMAT_UNDEFINED, strip);
 		return true;
 	case PostAAType::SMAA_Low:
-		setup_smaa_postprocess(graph, jitter, scaling_factor, input, input_depth, output, SMAAPreset::Low);
+		setup_smaa_postprocess(graph, jitter, scaling_factor, input, input_depth, output, SMAAPreset::Low, strip);
 		return true;
 	case PostAAType::SMAA_Medium:
-		setup_smaa_postprocess(graph, jitter, scaling_factor, input, input_depth, output, SMAAPreset::Medium);
+		setup_smaa_postprocess(graph, jitter, scaling_factor, input, input_depth, output, SMAAPreset::Medium, strip);
 		return true;
 	case PostAAType::SMAA_High:
-		setup_smaa_postprocess(graph, jitter, scaling_factor, input, input_depth, output, SMAAPreset::High);
+		setup_smaa_postprocess(graph, jitter, scaling_factor, input, input_depth, output, SMAAPreset::High, strip);
 		return true;
 	case PostAAType::SMAA_Ultra:
-		setup_smaa_postprocess(graph, jitter, scaling_factor, input, input_depth, output, SMAAPreset::Ultra);
+		setup_smaa_postprocess(graph, jitter, scaling_factor, input, input_depth, output, SMAAPreset::Ultra, strip);
 		return true;
 	case PostAAType::FXAA_2Phase:
 	case PostAAType::SMAA_Ultra_T2X:

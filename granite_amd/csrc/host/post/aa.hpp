@@ -8,6 +8,7 @@
 #include <vector>
 #include "../render_context.hpp"
 #include "../render_graph.hpp"
+#include "../strip_plan.hpp"
 
 namespace Granite
 {
@@ -62,23 +63,29 @@ private:
 };
 
 // fxaa.cpp:28-55
-void setup_fxaa_postprocess(RenderGraph &graph, const std::string &input, const std::string &output, VkFormat output_format = VK_FORMAT_UNDEFINED);
+// HIP executor extension on every set-up function below: `strip` = the row-band plan of this instance (strip_plan.hpp),
+// nullptr or an inactive plan = the whole frame, as the reference.
+void setup_fxaa_postprocess(RenderGraph &graph, const std::string &input, const std::string &output, VkFormat output_format = VK_FORMAT_UNDEFINED,
+                            const StripPlan *strip = nullptr);
 // smaa.cpp:32-208
 void setup_smaa_postprocess(RenderGraph &graph, TemporalJitter &jitter, float scaling_factor, const std::string &input,
-                            const std::string &input_depth, const std::string &output, SMAAPreset preset);
+                            const std::string &input_depth, const std::string &output, SMAAPreset preset, const StripPlan *strip = nullptr);
 // temporal.cpp:199-266
 void setup_taa_resolve(RenderGraph &graph, TemporalJitter &jitter, float scaling_factor, const std::string &input, const std::string &input_depth,
-                       const std::string &input_mv, const std::string &output, TAAQuality quality);
+                       const std::string &input_mv, const std::string &output, TAAQuality quality, const StripPlan *strip = nullptr);
 
 // aa.cpp:176-253
 bool setup_before_post_chain_antialiasing(PostAAType type, RenderGraph &graph, TemporalJitter &jitter, const RenderContext &context,
                                           float scaling_factor, const std::string &input, const std::string &input_depth,
-                                          const std::string &input_mv, const std::string &output);
+                                          const std::string &input_mv, const std::string &output, const StripPlan *strip = nullptr);
 // aa.cpp:75-174: `output + "-scale"` (FSR 1.0 EASU from `input` to the swapchain size) and, with use_sharpen,
 // `output + "-sharpen"` (RCAS, 0.5 stops).  fp16 = the FP16 shader variant (the reference picks it from the device's
 // shaderFloat16 / FIDELITYFX_FSR_FP16, aa.cpp:118-119; on MI355X that is true).
 bool setup_after_post_chain_upscaling(RenderGraph &graph, const std::string &input, const std::string &output, bool use_sharpen, bool fp16 = true);
 bool setup_after_post_chain_antialiasing(PostAAType type, RenderGraph &graph, TemporalJitter &jitter, float scaling_factor,
-                                         const std::string &input, const std::string &input_depth, const std::string &output);
+                                         const std::string &input, const std::string &input_depth, const std::string &output,
+                                         const StripPlan *strip = nullptr);
+// SMAA_MAX_SEARCH_STEPS of a preset (SMAA.hlsl:304-324), 0 for anything that is not SMAA: what StripAA wants to know.
+unsigned smaa_search_steps(PostAAType type);
 PostAAType string_to_post_antialiasing_type(const char *type);
 } // namespace Granite

@@ -10,19 +10,6 @@ namespace Granite
 {
 namespace
 {
-// RowRange -> the C ABI's render area.  Returns false when the band is empty (nothing to launch on this rank).
-bool to_rows(const RowRange *range, gr_rows &rows)
-{
-	rows = {0, 0};
-	if (!range || range->whole)
-		return true;
-	if (range->count == 0)
-		return false;
-	rows.first = range->first;
-	rows.count = range->count;
-	return true;
-}
-
 const gr_luminance_data *luminance_ptr(RenderGraph &graph, const RenderBufferResource *res)
 {
 	return res ? static_cast<const gr_luminance_data *>(graph.get_physical_buffer_resource(*res).get_device_pointer()) : nullptr;
@@ -184,13 +171,16 @@ void record_tonemap(RenderPass &pass, HIP::CommandBuffer &cmd, const RenderTextu
 	auto &output = graph.get_physical_texture_resource(*pass.get_color_outputs()[0]);
 	gr_push_tonemap push = {iface ? iface->get_exposure() : 1.0f};
 	gr_rows rows;
-	if (strip && strip->acquire_output)
+	const bool final_pass = !strip || !strip->post_aa(); // a post-tonemap AA pass owns the output image and its gather
+	if (strip && strip->acquire_output && final_pass)
 		strip->acquire_output(cmd, output);
 	if (to_rows(strip ? &strip->tonemap : nullptr, rows))
 		cmd.check(gr_tonemap_rows(cmd.get_context(), cmd.get_stream(), &hdr.get_view(), &bloom.get_view(), &output.get_view(),
 		                          luminance_ptr(graph, ubo), &push, &rows),
 		          "tonemap");
 	// Row-band tiling: the tonemapped bands of all ranks meet in every rank's output image.
+	if (!final_pass)
+		return;
 	if (strip && strip->exchange_output)
 		strip->exchange_output(cmd, output, strip->out_chunk_rows, "tonemapped");
 	else if (strip && strip->exchange)

@@ -48,6 +48,14 @@ RowRange to_range(Span s)
 	return r;
 }
 
+// `rows` grown by `reach` rows either side, inside the image.
+Span grown(Span rows, int64_t reach, uint32_t height)
+{
+	if (rows.hi < rows.lo)
+		return rows;
+	return {std::max<int64_t>(rows.lo - reach, 0), std::min<int64_t>(rows.hi + reach, int64_t(height) - 1)};
+}
+
 Span chunk_of(unsigned index, uint32_t chunk, uint32_t height)
 {
 	const int64_t lo = int64_t(index) * chunk;
@@ -56,7 +64,7 @@ Span chunk_of(unsigned index, uint32_t chunk, uint32_t height)
 }
 } // namespace
 
-StripPlan StripPlan::build(unsigned index, unsigned count, uint32_t width, uint32_t height)
+StripPlan StripPlan::build(unsigned index, unsigned count, uint32_t width, uint32_t height, const StripAA &aa)
 {
 	if (count == 0 || index >= count)
 		throw std::logic_error("StripPlan: rank index out of range.");
@@ -71,13 +79,39 @@ StripPlan StripPlan::build(unsigned index, unsigned count, uint32_t width, uint3
 	plan.h_u0 = plan.h_d0;
 	plan.out_chunk_rows = (height + count - 1) / count;
 	plan.d1_chunk_rows = (plan.h_d1 + count - 1) / count;
+	plan.aa = aa;
 	if (count == 1)
 		return plan; // every range stays "whole"; one chunk = the whole level
 
-	const Span out = chunk_of(index, plan.out_chunk_rows, height);
+	const Span chunk = chunk_of(index, plan.out_chunk_rows, height);
 	const Span d1 = chunk_of(index, plan.d1_chunk_rows, plan.h_d1);
-	plan.tonemap = to_range(out);
 	plan.d1 = to_range(d1);
+
+	// Tonemapped rows this rank needs: its chunk, or what the post-tonemap AA reads to produce its chunk.
+	Span out = chunk;
+	if (aa.post == StripAA::Post::FXAA)
+	{
+		// fxaa.frag: the four corner taps (1 row) and two pairs of bilinear taps along the edge direction, which is clamped
+		// to FXAA_SPAN_MAX = 8 texels and scaled by at most 0.5: 4 rows + 1 for the bilinear footprint, + 1 of safety.
+		plan.aa_out = to_range(chunk);
+		out = grown(chunk, 6, height);
+	}
+	else if (aa.post == StripAA::Post::SMAA)
+	{
+		// SMAA.hlsl, back to front.  Neighbourhood blending reads the weights of its own pixel, of the one to the right and
+		// of the one below, and the colour up to one texel away.  The weight pass walks the edge texture up and down by
+		// at most 2 * SMAA_MAX_SEARCH_STEPS texels, + 3.25 for the search-texture correction of the last step, + 1.5 for the
+		// crossing-edge and corner fetches at the ends (the diagonal search, 16 + 4 texels at most, stays inside that):
+		// 2 * steps + 8 rows are kept.  Edge detection compares with the pixels above (2 rows up for the local contrast
+		// adaptation) and below (1 row); one row of safety.
+		plan.aa_out = to_range(chunk);
+		const Span weights = grown(chunk, 1 + 1, height);
+		const Span edges = grown(weights, int64_t(2 * aa.smaa_search_steps) + 8, height);
+		plan.smaa_weights = to_range(weights);
+		plan.smaa_edges = to_range(edges);
+		out = grown(edges, 2 + 1, height);
+	}
+	plan.tonemap = to_range(out);
 
 	Span hdr_rows = out;
 	if (d1.hi >= d1.lo)
@@ -96,6 +130,12 @@ StripPlan StripPlan::build(unsigned index, unsigned count, uint32_t width, uint3
 	{
 		plan.d0 = to_range({0, -1});
 		plan.threshold = to_range({0, -1});
+	}
+	if (aa.temporal)
+	{
+		// taa_resolve.frag reads the lit image, depth and motion vectors in the 3 x 3 neighbourhood of its pixel.
+		plan.taa = to_range(hdr_rows);
+		hdr_rows = grown(hdr_rows, 1 + 1, height);
 	}
 	plan.lighting = to_range(hdr_rows);
 	plan.u0 = out.hi >= out.lo ? to_range(footprint(out, height, plan.h_u0, 0.0)) : to_range({0, -1});

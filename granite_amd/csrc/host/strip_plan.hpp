@@ -7,6 +7,7 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include "../../../include/granite_hip.h"
 
 namespace HIP
 {
@@ -25,6 +26,28 @@ struct RowRange
 	bool empty() const { return !whole && count == 0; }
 };
 
+// RowRange -> the C ABI's render area.  Returns false when the band is empty (nothing to launch on this rank).
+inline bool to_rows(const RowRange *range, gr_rows &rows)
+{
+	rows = {0, 0};
+	if (!range || range->whole)
+		return true;
+	if (range->count == 0)
+		return false;
+	rows.first = range->first;
+	rows.count = range->count;
+	return true;
+}
+
+// The anti-aliasing passes around the post chain, as far as the band arithmetic cares.
+struct StripAA
+{
+	enum class Post { None, FXAA, SMAA };
+	Post post = Post::None;          // after the tonemap: reads the tonemapped image above and below its band
+	unsigned smaa_search_steps = 0;  // SMAA_MAX_SEARCH_STEPS of the preset (4 / 8 / 16 / 32)
+	bool temporal = false;           // TAA resolve between lighting and the post chain
+};
+
 struct StripPlan
 {
 	unsigned index = 0, count = 1;
@@ -37,12 +60,22 @@ struct StripPlan
 	RowRange d0;        // 1/4 level
 	RowRange d1;        // 1/8 level: exactly this rank's all-gather chunk
 	RowRange u0;        // 1/4 level rows the tonemap band samples
-	RowRange tonemap;   // full-res rows: exactly this rank's all-gather chunk
+	RowRange tonemap;   // full-res rows: this rank's all-gather chunk, plus the rows a post-tonemap AA pass reads around it
 	uint32_t d1_chunk_rows = 0;  // rows per rank in the 1/8-level all-gather (last ranks may own fewer real rows)
-	uint32_t out_chunk_rows = 0; // rows per rank in the final all-gather
+	uint32_t out_chunk_rows = 0; // rows per rank in the final all-gather (and in the TAA history all-gather)
+
+	// Anti-aliasing under row bands.  The halo rows are RECOMPUTED (lighting / resolve / tonemap run on a taller band), not
+	// exchanged: values are those of the whole-frame launch, no further meeting point is needed for FXAA / SMAA.  The TAA
+	// history is the exception -- reprojection may reach any row, so the history bands are all-gathered every frame.
+	StripAA aa;
+	RowRange taa;          // rows the temporal resolve writes (= the HDR rows the post chain reads on this rank)
+	RowRange smaa_edges;   // rows of "smaa-edge" the weight pass searches through
+	RowRange smaa_weights; // rows of "smaa-weights" the blend pass reads
+	RowRange aa_out;       // rows of the post-AA output: exactly this rank's all-gather chunk
+	bool post_aa() const { return aa.post != StripAA::Post::None; }
 
 	bool active() const { return count > 1; }
-	static StripPlan build(unsigned index, unsigned count, uint32_t width, uint32_t height);
+	static StripPlan build(unsigned index, unsigned count, uint32_t width, uint32_t height, const StripAA &aa = {});
 
 	// All-gather of `chunk_rows` rows per rank inside `image` (rank r's rows start at r * chunk_rows; the image's memory
 	// is padded to count * chunk_rows rows).  Installed by the application; runs on the command buffer's stream.

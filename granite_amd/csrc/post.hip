@@ -644,20 +644,6 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 	}
 }
 
-// Resolves a render area against `height` output rows: [first, end), empty when the band lies outside the image.
-struct RowSpan
-{
-	uint32_t first, end;
-	uint32_t count() const { return end - first; }
-};
-static RowSpan resolve_rows(const gr_rows *rows, uint32_t height)
-{
-	if (!rows || rows->count == 0)
-		return {0, height};
-	const uint32_t first = rows->first < height ? rows->first : height;
-	const uint64_t end = uint64_t(rows->first) + rows->count;
-	return {first, end < height ? uint32_t(end) : height};
-}
 
 static bool is_rgba16f(const gr_image *img)
 {

@@ -67,10 +67,10 @@ def weak_scaled_frame(world: int, base=(3840, 2160)) -> Tuple[int, int]:
     return w, h
 
 
-def plan_numpy(index: int, count: int, width: int, height: int) -> dict:
-    """StripPlan::build through the C ABI without a GPU (dry application)."""
+def plan_numpy(index: int, count: int, width: int, height: int, post_aa: int = 0, pre_aa: int = 0) -> dict:
+    """StripPlan::build through the C ABI without a GPU (dry application); post_aa / pre_aa = app.POST_AA_* values."""
     from . import app as gapp
-    a = gapp.Application(width, height, device=-1, strip_index=index, strip_count=count)
+    a = gapp.Application(width, height, device=-1, strip_index=index, strip_count=count, post_aa=post_aa, pre_aa=pre_aa)
     try:
         return a.strip_plan()
     finally:

@@ -211,6 +211,10 @@ int gra_comm_init_output(gra_app *app, const uint8_t *id128, int32_t rank, int32
 /* The band plan of this instance: out[0..3] = index, count, width, height; then {whole, first, count} for lighting,
  * threshold, downsample-0, downsample-1, upsample-0, tonemap; then d1_chunk_rows, out_chunk_rows (24 values). */
 int gra_get_strip_plan(gra_app *app, uint32_t *out24);
+/* The anti-aliasing part of the plan (config.pre_aa / post_aa under row bands): {whole, first, count} for the TAA resolve,
+ * smaa-edge, smaa-weights and the post-AA output band (12 values).  The tonemap and lighting ranges of gra_get_strip_plan
+ * already include the rows these passes read around the band. */
+int gra_get_strip_plan_aa(gra_app *app, uint32_t *out12);
 
 /* Host-side frame-loop cost since creation: out[0] = frames, out[1] = seconds spent inside the frame loop (light
  * refresh + graph execution = launches), out[2] = seconds of those spent blocked on GPU back-pressure. */

@@ -379,6 +379,9 @@ typedef struct gr_push_fxaa
 	float inv_resolution[2];
 } gr_push_fxaa;
 int gr_fxaa(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_push_fxaa *push);
+/* The anti-aliasing passes over a render area (row bands): *_rows = the same pass restricted to output
+ * rows [first, first + count); what a pass reads above and below its band is the executor's business (StripPlan). */
+int gr_fxaa_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, const gr_push_fxaa *push, const gr_rows *rows);
 
 /* SMAA 1x (smaa.cpp:32-208 + SMAA.hlsl).  quality 0..3 = SMAA_PRESET_LOW..ULTRA (smaa_common.h).
  * rt_metrics = (1/w, 1/h, w, h) (smaa.cpp:129-133). */
@@ -396,6 +399,12 @@ int gr_smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, c
 /* smaa-blend pass: SMAANeighborhoodBlendingPS. */
 int gr_smaa_neighbor_blend(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *weights, const gr_image *out,
                            const gr_push_smaa *push);
+int gr_smaa_edge_detection_rows(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *edges, const gr_push_smaa *push,
+                                int quality, const gr_rows *rows);
+int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push,
+                              int quality, const gr_rows *rows);
+int gr_smaa_neighbor_blend_rows(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *weights, const gr_image *out,
+                                const gr_push_smaa *push, const gr_rows *rows);
 
 /* setup_taa_resolve (temporal.cpp:199-266) + taa_resolve.frag.  quality 0..2 = TAAQuality Low/Medium/High.
  * history NULL => REPROJECTION_HISTORY = 0 (first frame).  current/out_color/history: R16G16B16A16_SFLOAT,
@@ -407,6 +416,9 @@ typedef struct gr_push_taa
 } gr_push_taa;
 int gr_taa_resolve(gr_ctx *ctx, gr_stream stream, const gr_image *current, const gr_image *depth, const gr_image *mv,
                    const gr_image *history, const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality);
+int gr_taa_resolve_rows(gr_ctx *ctx, gr_stream stream, const gr_image *current, const gr_image *depth, const gr_image *mv,
+                        const gr_image *history, const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality,
+                        const gr_rows *rows);
 
 /* ---- depth hierarchy ---------------------------------------------------------------------------------------------------
  * HiZPassState::build_render_pass (renderer/post/spd.cpp:141-194) + assets/shaders/post/hiz.comp: turns the depth

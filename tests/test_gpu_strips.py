@@ -12,12 +12,89 @@ from granite_amd import app as gapp, capi, multigpu, synth
 pytestmark = pytest.mark.gpu
 
 
-def make_app(w, h, cam, gbuf, descs, **kw):
+def make_app(w, h, cam, gbuf, descs, mv=None, **kw):
     a = gapp.Application(w, h, **kw)
-    a.set_render_parameters(cam.render_params())
+    if mv is None:
+        a.set_render_parameters(cam.render_params())
+    else:  # temporal AA jitters the projection itself: it needs the camera, not verbatim render parameters
+        a.set_camera(np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16))
     a.set_lights(descs)
-    a.upload_gbuffer(gbuf)
+    a.upload_gbuffer(gbuf, mv)
     return a
+
+
+def run_emulated_ranks(world, frames, make, reads):
+    """`world` instances on the one device, one thread each, bands meeting through LocalExchange; returns got[rank][frame] =
+    tuple of the `reads` resources (backbuffer first) and the plans."""
+    lib = capi.load_library()
+    lib.gr_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.gr_sync.argtypes = [C.c_void_p, C.c_void_p]
+    apps = [make(strip_index=r, strip_count=world) for r in range(world)]
+    ctx = apps[0].lib.gra_get_kernel_context(apps[0].handle)
+
+    def copy(dst, src, nbytes, stream):
+        assert lib.gr_copy(ctx, stream, dst, src, nbytes) == 0
+
+    def sync(stream):
+        assert lib.gr_sync(ctx, stream) == 0
+
+    local = multigpu.LocalExchange(world, copy, sync)
+    got = [[] for _ in range(world)]
+    errors = []
+
+    def run(rank):
+        try:
+            a = apps[rank]
+            a.set_exchange_callback(local.for_rank(rank))
+            for _ in range(frames):
+                a.render_frames(1)
+                got[rank].append(tuple([a.read_backbuffer().copy()] + [a.read(name).copy() for name in reads]))
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            local.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    assert not errors, errors
+    plans = [a.strip_plan() for a in apps]
+    for a in apps:
+        a.close()
+    return got, plans
+
+
+@pytest.mark.parametrize("world,w,h,post,pre", [(2, 480, 272, "POST_AA_FXAA", 0), (3, 333, 250, "POST_AA_SMAA_ULTRA", "POST_AA_TAA_HIGH"),
+                                                (4, 512, 512, "POST_AA_SMAA_LOW", "POST_AA_TAA_LOW"), (2, 960, 540, "POST_AA_SMAA_HIGH", 0)])
+def test_emulated_ranks_with_anti_aliasing_reproduce_the_single_device_frame(world, w, h, post, pre):
+    """FXAA / SMAA behind the tonemap and the TAA resolve in front of the post chain under row bands (config
+    4's chain tiles).  The halo rows are recomputed, the TAA history bands meet in an all-gather of their own; backbuffer,
+    the resolved HDR history and the exposure must be those of the single-instance frames, bit for bit, over 4 frames (the
+    history and the jitter sequence carry state from frame to frame)."""
+    frames = 4
+    kw = dict(post_aa=getattr(gapp, post) if post else 0, pre_aa=getattr(gapp, pre) if pre else 0)
+    cam = synth.Camera(w, h)
+    gbuf = synth.make_gbuffer(cam)
+    descs = synth.make_lights(cam, 200)
+    mv = synth.make_motion_vectors(w, h) if pre else None
+    reads = ["average-luminance"] + (["HDR-resolved-history"] if pre else [])
+
+    ref = make_app(w, h, cam, gbuf, descs, mv, **kw)
+    want = []
+    for _ in range(frames):
+        ref.render_frames(1)
+        want.append(tuple([ref.read_backbuffer().copy()] + [ref.read(name).copy() for name in reads]))
+    ref.close()
+    assert any((want[f][0] != want[0][0]).any() for f in range(1, frames)), "frames must differ (exposure, jitter, history)"
+
+    got, plans = run_emulated_ranks(world, frames, lambda **strip: make_app(w, h, cam, gbuf, descs, mv, **kw, **strip), reads)
+    for rank in range(world):
+        assert plans[rank]["aa_out"] is not None and plans[rank]["tonemap"][1] > plans[rank]["aa_out"][1]
+        assert (plans[rank]["taa"] is not None) == bool(pre)
+        for f in range(frames):
+            for i, name in enumerate(["backbuffer"] + reads):
+                np.testing.assert_array_equal(got[rank][f][i], want[f][i], err_msg=f"rank {rank} frame {f}: {name}")
 
 
 @pytest.mark.parametrize("world,w,h,lights", [(2, 480, 272, 300), (3, 333, 250, 200), (4, 512, 512, 64)])

