@@ -61,6 +61,66 @@ struct Tex8
 	}
 };
 
+// The neighbourhood of a 32 x 8 block of an RGBA8 image, decoded to fp32 ONCE into LDS (clamp-to-edge applied while staging):
+// the passes below take 5 to 9 bilinear taps per pixel within a few texels of it, i.e. 20 to 36 texel decodes per pixel from
+// global memory otherwise.  sample() is Tex8::sample statement for statement -- same coordinates, same weights, same order of
+// the lerps -- with the four texels read from the tile; a tap outside the tile (the passes' reach is below HALO, so this is a
+// safety net, not a path) falls back to the image.
+template <int HALO>
+struct Tile8
+{
+	static constexpr int W = AA_BLOCK_X + 2 * HALO, H = AA_BLOCK_Y + 2 * HALO;
+	const float4 *texels; // [H][W]
+	int ox, oy;           // image coordinates of texels[0]
+	Tex8<4> tex;
+
+	__device__ __forceinline__ v4 sample(v2 uv, int offx = 0, int offy = 0) const
+	{
+		const float fx = uv.x * float(tex.w) - 0.5f;
+		const float fy = uv.y * float(tex.h) - 0.5f;
+		const float flx = floorf(fx), fly = floorf(fy);
+		const float a = fx - flx, b = fy - fly;
+		const int x0 = int(flx) + offx, y0 = int(fly) + offy;
+		const int tx = x0 - ox, ty = y0 - oy;
+		v4 t00, t10, t01, t11;
+		// one decision per wave: the tile, or (never expected) the image for all four texels of every lane
+		if (__all(unsigned(tx) < unsigned(W - 1) && unsigned(ty) < unsigned(H - 1)))
+		{
+			const float4 *p = texels + ty * W + tx;
+			const float4 q00 = p[0], q10 = p[1], q01 = p[W], q11 = p[W + 1];
+			t00 = mk4(q00.x, q00.y, q00.z, q00.w);
+			t10 = mk4(q10.x, q10.y, q10.z, q10.w);
+			t01 = mk4(q01.x, q01.y, q01.z, q01.w);
+			t11 = mk4(q11.x, q11.y, q11.z, q11.w);
+		}
+		else
+		{
+			t00 = tex.fetch(x0, y0);
+			t10 = tex.fetch(x0 + 1, y0);
+			t01 = tex.fetch(x0, y0 + 1);
+			t11 = tex.fetch(x0 + 1, y0 + 1);
+		}
+		const v4 top = t00 * (1.0f - a) + t10 * a;
+		const v4 bot = t01 * (1.0f - a) + t11 * a;
+		return top * (1.0f - b) + bot * b;
+	}
+};
+
+// Fills `lds` (Tile8<HALO>::W * H texels) for the block whose first pixel is (bx, by); every thread of the block must call it.
+template <int HALO>
+__device__ __forceinline__ Tile8<HALO> stage_tile(float4 *lds, const Tex8<4> &tex, int bx, int by)
+{
+	constexpr int W = Tile8<HALO>::W, H = Tile8<HALO>::H;
+	for (int i = threadIdx.y * AA_BLOCK_X + threadIdx.x; i < W * H; i += AA_BLOCK_X * AA_BLOCK_Y)
+	{
+		const int ty = i / W, tx = i - ty * W;
+		const v4 t = tex.fetch(bx - HALO + tx, by - HALO + ty);
+		lds[i] = make_float4(t.x, t.y, t.z, t.w);
+	}
+	__syncthreads();
+	return {lds, bx - HALO, by - HALO, tex};
+}
+
 template <int CH>
 static Tex8<CH> make_tex8(const gr_image *img)
 {
@@ -86,11 +146,16 @@ __device__ __forceinline__ void store_rgba8(uint8_t *ptr, uint32_t pitch, int x,
 }
 
 // ---- FXAA (fxaa.frag:20-67) --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_fxaa(Tex8<4> tex, uint8_t *out, uint32_t out_pitch, gr_push_fxaa push, RowSpan rows)
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_fxaa(Tex8<4> tex_, uint8_t *out, uint32_t out_pitch, gr_push_fxaa push, RowSpan rows)
 {
-	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
-	const int y = int(rows.first) + blockIdx.y * AA_BLOCK_Y + threadIdx.y;
-	if (x >= tex.w || y >= int(rows.end))
+	// reach: the corner taps 1 texel, the edge taps at most FXAA_SPAN_MAX * 0.5 = 4 texels, + 1 for the bilinear footprint
+	constexpr int HALO = 6;
+	__shared__ float4 s_tile[Tile8<HALO>::W * Tile8<HALO>::H];
+	const Tex8<4> image = tex_;
+	const int bx = blockIdx.x * AA_BLOCK_X, by = int(rows.first) + blockIdx.y * AA_BLOCK_Y;
+	const Tile8<HALO> tex = stage_tile<HALO>(s_tile, image, bx, by);
+	const int x = bx + threadIdx.x, y = by + threadIdx.y;
+	if (x >= image.w || y >= int(rows.end))
 		return;
 	const float FXAA_REDUCE_MIN = 1.0f / 128.0f, FXAA_REDUCE_MUL = 1.0f / 8.0f, FXAA_SPAN_MAX = 8.0f;
 	const v2 inv_resolution = mk2(push.inv_resolution[0], push.inv_resolution[1]);
@@ -140,12 +205,15 @@ static SmaaPreset smaa_preset(int quality)
 
 // SMAALumaEdgeDetectionPS (SMAA.hlsl:689-740).  Every pixel is written (0 = what the reference leaves as the clear value
 // when the fragment is discarded), so no separate clear pass is needed.
-__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_edges(Tex8<4> tex, uint8_t *edges, uint32_t edges_pitch, gr_push_smaa push,
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_edges(Tex8<4> image, uint8_t *edges, uint32_t edges_pitch, gr_push_smaa push,
                                                                        SmaaPreset P, RowSpan rows)
 {
-	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
-	const int y = int(rows.first) + blockIdx.y * AA_BLOCK_Y + threadIdx.y;
-	if (x >= tex.w || y >= int(rows.end))
+	constexpr int HALO = 3; // taps two texels to the left / above, one to the right / below, + 1 for the bilinear footprint
+	__shared__ float4 s_tile[Tile8<HALO>::W * Tile8<HALO>::H];
+	const int bx = blockIdx.x * AA_BLOCK_X, by = int(rows.first) + blockIdx.y * AA_BLOCK_Y;
+	const Tile8<HALO> tex = stage_tile<HALO>(s_tile, image, bx, by);
+	const int x = bx + threadIdx.x, y = by + threadIdx.y;
+	if (x >= image.w || y >= int(rows.end))
 		return;
 	const v2 rt = mk2(push.rt_metrics[0], push.rt_metrics[1]);
 	const v2 tc = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
@@ -172,9 +240,64 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_edges(Tex8<4> t
 	*reinterpret_cast<uint16_t *>(edges + size_t(y) * edges_pitch + size_t(x) * 2u) = uint16_t(result);
 }
 
-struct SmaaWeights
+// The edge texture around a block, decoded once into LDS (as Tile8, two channels): the weight pass samples it bilinearly
+// 20 to 100 times per edge pixel, mostly within a few texels of the pixel.  HALO = 16 holds the whole diagonal search and the
+// first eight steps of the orthogonal ones; a longer search leaves the tile and continues on the image, decided per wave
+// and per tap.
+template <int HALO>
+struct EdgeTile
+{
+	static constexpr int W = AA_BLOCK_X + 2 * HALO, H = AA_BLOCK_Y + 2 * HALO;
+	const float2 *texels; // [H][W]
+	int ox, oy;
+	Tex8<2> tex;
+
+	__device__ __forceinline__ v4 sample(v2 uv, int offx = 0, int offy = 0) const
+	{
+		const float fx = uv.x * float(tex.w) - 0.5f;
+		const float fy = uv.y * float(tex.h) - 0.5f;
+		const float flx = floorf(fx), fly = floorf(fy);
+		const float a = fx - flx, b = fy - fly;
+		const int x0 = int(flx) + offx, y0 = int(fly) + offy;
+		const int tx = x0 - ox, ty = y0 - oy;
+		v4 t00, t10, t01, t11;
+		if (__all(unsigned(tx) < unsigned(W - 1) && unsigned(ty) < unsigned(H - 1)))
+		{
+			const float2 *p = texels + ty * W + tx;
+			const float2 q00 = p[0], q10 = p[1], q01 = p[W], q11 = p[W + 1];
+			t00 = mk4(q00.x, q00.y, 0.0f, 1.0f);
+			t10 = mk4(q10.x, q10.y, 0.0f, 1.0f);
+			t01 = mk4(q01.x, q01.y, 0.0f, 1.0f);
+			t11 = mk4(q11.x, q11.y, 0.0f, 1.0f);
+		}
+		else
+		{
+			t00 = tex.fetch(x0, y0);
+			t10 = tex.fetch(x0 + 1, y0);
+			t01 = tex.fetch(x0, y0 + 1);
+			t11 = tex.fetch(x0 + 1, y0 + 1);
+		}
+		const v4 top = t00 * (1.0f - a) + t10 * a;
+		const v4 bot = t01 * (1.0f - a) + t11 * a;
+		return top * (1.0f - b) + bot * b;
+	}
+};
+constexpr int SMAA_EDGE_HALO = 16;
+
+struct SmaaWeightsArgs
 {
 	Tex8<2> edges;
+	Tex8<2> area;
+	Tex8<1> search;
+	v4 rt;
+	SmaaPreset P;
+};
+
+// Edges = Tex8<2> (the image) or EdgeTile (its LDS copy around the block): the same sample() either way.
+template <typename Edges>
+struct SmaaWeights
+{
+	Edges edges;
 	Tex8<2> area;
 	Tex8<1> search;
 	v4 rt;
@@ -462,29 +585,57 @@ struct SmaaWeights
 
 // SMAABlendingWeightCalculationPS.  The reference runs this quad under a depth mask EQUAL to the edge pass's
 // non-discarded pixels (smaa.cpp:101-112,170-177); the mask is the edge texel itself here: zero edge => zero weights.
-__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_weights(SmaaWeights S, uint8_t *out, uint32_t out_pitch, RowSpan rows)
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_weights(SmaaWeightsArgs A, uint8_t *out, uint32_t out_pitch, RowSpan rows)
 {
-	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
-	const int y = int(rows.first) + blockIdx.y * AA_BLOCK_Y + threadIdx.y;
-	if (x >= S.edges.w || y >= int(rows.end))
-		return;
-	const uint16_t e = *reinterpret_cast<const uint16_t *>(S.edges.ptr + size_t(y) * S.edges.pitch + size_t(x) * 2u);
+	using Tile = EdgeTile<SMAA_EDGE_HALO>;
+	__shared__ float2 s_edges[Tile::W * Tile::H];
+	const int bx = blockIdx.x * AA_BLOCK_X, by = int(rows.first) + blockIdx.y * AA_BLOCK_Y;
+	const int x = bx + threadIdx.x, y = by + threadIdx.y;
+	const bool inside = x < A.edges.w && y < int(rows.end);
+	uint16_t e = 0;
+	if (inside)
+		e = *reinterpret_cast<const uint16_t *>(A.edges.ptr + size_t(y) * A.edges.pitch + size_t(x) * 2u);
+	// Staging the tile costs about as much as twenty taps per pixel of the block: it pays where edges are dense (a quarter of
+	// the block or more), not on the few-per-cent edge density of a rendered frame.
+	const int edge_pixels = __syncthreads_count(e != 0);
 	uint32_t packed = 0u;
-	if (e != 0)
+	if (edge_pixels >= AA_BLOCK_X * AA_BLOCK_Y / 4)
 	{
+		for (int i = threadIdx.y * AA_BLOCK_X + threadIdx.x; i < Tile::W * Tile::H; i += AA_BLOCK_X * AA_BLOCK_Y)
+		{
+			const int ty = i / Tile::W, tx = i - ty * Tile::W;
+			const v4 t = A.edges.fetch(bx - SMAA_EDGE_HALO + tx, by - SMAA_EDGE_HALO + ty);
+			s_edges[i] = make_float2(t.x, t.y);
+		}
+		__syncthreads();
+		if (e != 0)
+		{
+			const SmaaWeights<Tile> S = {{s_edges, bx - SMAA_EDGE_HALO, by - SMAA_EDGE_HALO, A.edges}, A.area, A.search, A.rt, A.P};
+			const v4 w = S.weights_at(x, y);
+			packed = unorm8(w.x) | (unorm8(w.y) << 8) | (unorm8(w.z) << 16) | (unorm8(w.w) << 24);
+		}
+	}
+	else if (e != 0)
+	{
+		const SmaaWeights<Tex8<2>> S = {A.edges, A.area, A.search, A.rt, A.P};
 		const v4 w = S.weights_at(x, y);
 		packed = unorm8(w.x) | (unorm8(w.y) << 8) | (unorm8(w.z) << 16) | (unorm8(w.w) << 24);
 	}
-	*reinterpret_cast<uint32_t *>(out + size_t(y) * out_pitch + size_t(x) * 4u) = packed;
+	if (inside)
+		*reinterpret_cast<uint32_t *>(out + size_t(y) * out_pitch + size_t(x) * 4u) = packed;
 }
 
 // SMAANeighborhoodBlendingPS (SMAA.hlsl:1252-1308)
-__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_blend(Tex8<4> ctex, Tex8<4> btex, uint8_t *out, uint32_t out_pitch, gr_push_smaa push,
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_blend(Tex8<4> cimage, Tex8<4> bimage, uint8_t *out, uint32_t out_pitch, gr_push_smaa push,
                                                                        RowSpan rows)
 {
-	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
-	const int y = int(rows.first) + blockIdx.y * AA_BLOCK_Y + threadIdx.y;
-	if (x >= ctex.w || y >= int(rows.end))
+	constexpr int HALO = 2; // weights of the right / bottom neighbour, colour up to one texel away, + 1 for the bilinear footprint
+	__shared__ float4 s_color[Tile8<HALO>::W * Tile8<HALO>::H], s_weights[Tile8<HALO>::W * Tile8<HALO>::H];
+	const int bx = blockIdx.x * AA_BLOCK_X, by = int(rows.first) + blockIdx.y * AA_BLOCK_Y;
+	const Tile8<HALO> ctex = stage_tile<HALO>(s_color, cimage, bx, by);
+	const Tile8<HALO> btex = stage_tile<HALO>(s_weights, bimage, bx, by);
+	const int x = bx + threadIdx.x, y = by + threadIdx.y;
+	if (x >= cimage.w || y >= int(rows.end))
 		return;
 	const v2 rt = mk2(push.rt_metrics[0], push.rt_metrics[1]);
 	const v2 texcoord = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
@@ -566,6 +717,14 @@ struct TaaArgs
 	RowSpan rows;
 };
 
+// One history texel (clamp-to-edge), addressed with a 32-bit offset from the uniform base (images stay below 4 GiB).
+__device__ __forceinline__ v3 history_texel(const DevImage &img, int x, int y)
+{
+	const uint32_t offset = uint32_t(clampi(y, 0, img.h - 1)) * img.pitch + uint32_t(clampi(x, 0, img.w - 1)) * 8u;
+	const f16x4 t = *reinterpret_cast<const f16x4 *>(img.ptr + offset);
+	return mk3(float(t.x), float(t.y), float(t.z));
+}
+
 __device__ __forceinline__ v3 sample_linear3(const DevImage &img, float u, float v)
 {
 	const float fx = u * float(img.w) - 0.5f;
@@ -573,57 +732,77 @@ __device__ __forceinline__ v3 sample_linear3(const DevImage &img, float u, float
 	const float flx = floorf(fx), fly = floorf(fy);
 	const float a = fx - flx, b = fy - fly;
 	const int ix = int(flx), iy = int(fly);
-	const float4 t00 = load_rgba16f_clamped(img, ix, iy), t10 = load_rgba16f_clamped(img, ix + 1, iy);
-	const float4 t01 = load_rgba16f_clamped(img, ix, iy + 1), t11 = load_rgba16f_clamped(img, ix + 1, iy + 1);
-	const v3 top = mk3(t00.x, t00.y, t00.z) * (1.0f - a) + mk3(t10.x, t10.y, t10.z) * a;
-	const v3 bot = mk3(t01.x, t01.y, t01.z) * (1.0f - a) + mk3(t11.x, t11.y, t11.z) * a;
+	const v3 t00 = history_texel(img, ix, iy), t10 = history_texel(img, ix + 1, iy);
+	const v3 t01 = history_texel(img, ix, iy + 1), t11 = history_texel(img, ix + 1, iy + 1);
+	const v3 top = t00 * (1.0f - a) + t10 * a;
+	const v3 bot = t01 * (1.0f - a) + t11 * a;
 	return top * (1.0f - b) + bot * b;
 }
 
+// The 3 x 3 neighbourhood of every pixel of a 32 x 8 block comes out of LDS: the 34 x 10 texels around the block are
+// fetched, clamped to the image and converted to the resolve's colour space ONCE (instead of up to nine times each), depth
+// beside them.  QUALITY / HISTORY are compile-time: the three qualities differ in how much of the neighbourhood they use.
+constexpr int TAA_TILE_W = AA_BLOCK_X + 2, TAA_TILE_H = AA_BLOCK_Y + 2;
+
+template <int QUALITY, bool HISTORY>
 __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs a)
 {
-	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x;
-	const int y = int(a.rows.first) + blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	__shared__ float s_cur[3][TAA_TILE_H][TAA_TILE_W];
+	__shared__ float s_depth[TAA_TILE_H][TAA_TILE_W];
 	const int w = a.current.w, h = a.current.h;
+	const int x0 = blockIdx.x * AA_BLOCK_X, y0 = int(a.rows.first) + blockIdx.y * AA_BLOCK_Y;
+	const int lx = threadIdx.x, ly = threadIdx.y;
+	if (HISTORY)
+	{
+		for (int i = ly * AA_BLOCK_X + lx; i < TAA_TILE_W * TAA_TILE_H; i += AA_BLOCK_X * AA_BLOCK_Y)
+		{
+			const int ty = i / TAA_TILE_W, tx = i - ty * TAA_TILE_W;
+			const int px = clampi(x0 + tx - 1, 0, w - 1), py = clampi(y0 + ty - 1, 0, h - 1);
+			const float4 t = load_rgba16f(a.current, px, py);
+			const v3 c = hdr_to_taa(mk3(t.x, t.y, t.z));
+			s_cur[0][ty][tx] = c.x;
+			s_cur[1][ty][tx] = c.y;
+			s_cur[2][ty][tx] = c.z;
+			s_depth[ty][tx] = *reinterpret_cast<const float *>(a.depth.ptr + uint32_t(py) * a.depth.pitch + uint32_t(px) * 4u);
+		}
+		__syncthreads();
+	}
+	const int x = x0 + lx, y = y0 + ly;
 	if (x >= w || y >= int(a.rows.end))
 		return;
 	const v4 rt = mk4(a.rt[0], a.rt[1], a.rt[2], a.rt[3]);
 	const v2 uv = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
-	auto cur_at = [&](int px, int py) {
-		const float4 t = load_rgba16f_clamped(a.current, px, py);
-		return hdr_to_taa(mk3(t.x, t.y, t.z));
-	};
-	auto depth_at = [&](int px, int py) {
-		return *reinterpret_cast<const float *>(a.depth.ptr + size_t(clampi(py, 0, h - 1)) * a.depth.pitch + size_t(clampi(px, 0, w - 1)) * 4u);
-	};
-	auto mv_at = [&](int px, int py) {
-		const f16x2 m = *reinterpret_cast<const f16x2 *>(a.mv.ptr + size_t(clampi(py, 0, h - 1)) * a.mv.pitch + size_t(clampi(px, 0, w - 1)) * 4u);
-		return mk2(float(m.x), float(m.y));
-	};
+	auto cur_at = [&](int ox, int oy) { return mk3(s_cur[0][ly + 1 + oy][lx + 1 + ox], s_cur[1][ly + 1 + oy][lx + 1 + ox], s_cur[2][ly + 1 + oy][lx + 1 + ox]); };
+	auto depth_at = [&](int ox, int oy) { return s_depth[ly + 1 + oy][lx + 1 + ox]; };
 
-	const v3 current_c = cur_at(x, y);
 	v3 out_c, hist_c;
-	if (!a.has_history)
+	if (!HISTORY)
 	{
+		const float4 t = load_rgba16f(a.current, x, y);
+		const v3 current_c = hdr_to_taa(mk3(t.x, t.y, t.z));
 		out_c = taa_to_hdr(current_c);
 		hist_c = current_c;
 	}
 	else
 	{
-		v2 mv;
+		const v3 current_c = cur_at(0, 0);
+		// Motion vector of the nearest-depth pixel of the neighbourhood (first wins on ties, in the shader's order).
+		int mx, my;
 		float d;
 		auto consider = [&](int ox, int oy) {
-			const float dd = depth_at(x + ox, y + oy);
+			const float dd = depth_at(ox, oy);
 			if (dd > d)
 			{
-				mv = mv_at(x + ox, y + oy);
+				mx = ox;
+				my = oy;
 				d = dd;
 			}
 		};
-		if (a.quality <= 1)
+		if (QUALITY <= 1)
 		{
-			mv = mv_at(x - 1, y);
-			d = depth_at(x - 1, y);
+			mx = -1;
+			my = 0;
+			d = depth_at(-1, 0);
 			consider(0, 0);
 			consider(0, -1);
 			consider(0, 1);
@@ -631,8 +810,9 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs 
 		}
 		else
 		{
-			mv = mv_at(x + 1, y + 1);
-			d = depth_at(x + 1, y + 1);
+			mx = 1;
+			my = 1;
+			d = depth_at(1, 1);
 			consider(-1, 0);
 			consider(0, 0);
 			consider(0, -1);
@@ -642,6 +822,8 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs 
 			consider(-1, 1);
 			consider(0, 1);
 		}
+		const f16x2 m = *reinterpret_cast<const f16x2 *>(a.mv.ptr + uint32_t(clampi(y + my, 0, h - 1)) * a.mv.pitch + uint32_t(clampi(x + mx, 0, w - 1)) * 4u);
+		v2 mv = mk2(float(m.x), float(m.y));
 
 		v2 old_uv;
 		if (mv.x == 0.0f && mv.y == 0.0f)
@@ -658,7 +840,7 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs 
 			old_uv = uv - mv;
 
 		v3 history_color;
-		if (a.quality == 2)
+		if (QUALITY == 2)
 		{
 			const v2 samplePos = mk2(old_uv.x * rt.z, old_uv.y * rt.w);
 			const v2 texPos1 = mk2(floorf(samplePos.x - 0.5f) + 0.5f, floorf(samplePos.y - 0.5f) + 0.5f);
@@ -673,16 +855,42 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs 
 			const v2 texPos0 = (texPos1 - mk2(1.0f, 1.0f)) * mk2(rt.x, rt.y);
 			const v2 texPos3 = (texPos1 + mk2(2.0f, 2.0f)) * mk2(rt.x, rt.y);
 			const v2 texPos12 = (texPos1 + offset12) * mk2(rt.x, rt.y);
+			// Nine bilinear taps on a 3 x 3 grid of positions: the column / row indices, clamps, weights and byte offsets are
+			// worked out once per axis (three positions x two texels) instead of once per tap.  Each tap is sample_linear3()
+			// statement for statement.
+			const float px[3] = {texPos0.x, texPos12.x, texPos3.x}, py[3] = {texPos0.y, texPos12.y, texPos3.y};
+			const float wx[3] = {w0.x, w12.x, w3.x}, wy[3] = {w0.y, w12.y, w3.y};
+			uint32_t col[3][2], row[3][2];
+			float fa[3], fb[3];
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+			{
+				const float fx = px[i] * float(a.history.w) - 0.5f, fy = py[i] * float(a.history.h) - 0.5f;
+				const float flx = floorf(fx), fly = floorf(fy);
+				fa[i] = fx - flx;
+				fb[i] = fy - fly;
+				const int ix = int(flx), iy = int(fly);
+				col[i][0] = uint32_t(clampi(ix, 0, w - 1)) * 8u;
+				col[i][1] = uint32_t(clampi(ix + 1, 0, w - 1)) * 8u;
+				row[i][0] = uint32_t(clampi(iy, 0, h - 1)) * a.history.pitch;
+				row[i][1] = uint32_t(clampi(iy + 1, 0, h - 1)) * a.history.pitch;
+			}
+			auto texel = [&](uint32_t offset) {
+				const f16x4 t = *reinterpret_cast<const f16x4 *>(a.history.ptr + offset);
+				return mk3(float(t.x), float(t.y), float(t.z));
+			};
 			v3 r = mk3(0.0f, 0.0f, 0.0f);
-			r = r + sample_linear3(a.history, texPos0.x, texPos0.y) * w0.x * w0.y;
-			r = r + sample_linear3(a.history, texPos12.x, texPos0.y) * w12.x * w0.y;
-			r = r + sample_linear3(a.history, texPos3.x, texPos0.y) * w3.x * w0.y;
-			r = r + sample_linear3(a.history, texPos0.x, texPos12.y) * w0.x * w12.y;
-			r = r + sample_linear3(a.history, texPos12.x, texPos12.y) * w12.x * w12.y;
-			r = r + sample_linear3(a.history, texPos3.x, texPos12.y) * w3.x * w12.y;
-			r = r + sample_linear3(a.history, texPos0.x, texPos3.y) * w0.x * w3.y;
-			r = r + sample_linear3(a.history, texPos12.x, texPos3.y) * w12.x * w3.y;
-			r = r + sample_linear3(a.history, texPos3.x, texPos3.y) * w3.x * w3.y;
+#pragma unroll
+			for (int j = 0; j < 3; j++)
+#pragma unroll
+				for (int i = 0; i < 3; i++)
+				{
+					const v3 t00 = texel(row[j][0] + col[i][0]), t10 = texel(row[j][0] + col[i][1]);
+					const v3 t01 = texel(row[j][1] + col[i][0]), t11 = texel(row[j][1] + col[i][1]);
+					const v3 top = t00 * (1.0f - fa[i]) + t10 * fa[i];
+					const v3 bot = t01 * (1.0f - fa[i]) + t11 * fa[i];
+					r = r + (top * (1.0f - fb[j]) + bot * fb[j]) * wx[i] * wy[j];
+				}
 			history_color = r;
 		}
 		else
@@ -695,17 +903,17 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs 
 		const float lerp_factor = (1.0f + 2.0f * mv_fast) / 16.0f;
 
 		const v3 c11 = current_c;
-		const v3 c01 = cur_at(x - 1, y), c21 = cur_at(x + 1, y), c10 = cur_at(x, y - 1), c12 = cur_at(x, y + 1);
+		const v3 c01 = cur_at(-1, 0), c21 = cur_at(1, 0), c10 = cur_at(0, -1), c12 = cur_at(0, 1);
 		v3 lo, hi;
-		if (a.quality == 0)
+		if (QUALITY == 0)
 		{
 			lo = min3v(min3v(min3v(min3v(c11, c01), c21), c10), c12);
 			hi = max3v(max3v(max3v(max3v(c11, c01), c21), c10), c12);
 		}
 		else
 		{
-			const v3 c00 = cur_at(x - 1, y - 1), c22 = cur_at(x + 1, y + 1), c02 = cur_at(x - 1, y + 1), c20 = cur_at(x + 1, y - 1);
-			if (a.quality == 1)
+			const v3 c00 = cur_at(-1, -1), c22 = cur_at(1, 1), c02 = cur_at(-1, 1), c20 = cur_at(1, -1);
+			if (QUALITY == 1)
 			{
 				const v3 clo = min3v(min3v(min3v(min3v(c11, c01), c21), c10), c12);
 				const v3 chi = max3v(max3v(max3v(max3v(c11, c01), c21), c10), c12);
@@ -725,7 +933,7 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs 
 				hi = m1 + gamma * sigma;
 			}
 		}
-		history_color = clamp_box(history_color, lo, hi, a.quality >= 1);
+		history_color = clamp_box(history_color, lo, hi, QUALITY >= 1);
 		const v3 mixed = mix3(history_color, current_c, lerp_factor);
 		hist_c = mixed;
 		out_c = taa_to_hdr(mixed);
@@ -820,7 +1028,7 @@ int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edg
 	GR_CHECK_ARG(ctx, check_image(weights, 4, edges->width, edges->height) && weights->format == GR_FORMAT_R8G8B8A8_UNORM);
 	if (!ctx->smaa_area || !ctx->smaa_search)
 		return ctx->fail(GR_ERR_INVALID_ARGUMENT, "gr_smaa_blend_weight: SMAA lookup tables not set (gr_smaa_set_luts)");
-	SmaaWeights S;
+	SmaaWeightsArgs S;
 	S.edges = make_tex8<2>(edges);
 	S.area = {static_cast<const uint8_t *>(ctx->smaa_area), 160, 560, 320u};
 	S.search = {static_cast<const uint8_t *>(ctx->smaa_search), 64, 16, 64u};
@@ -902,7 +1110,16 @@ int gr_taa_resolve_rows(gr_ctx *ctx, gr_stream stream, const gr_image *current, 
 	if (a.rows.count() == 0)
 		return GR_OK;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "taa_resolve"};
-	hipLaunchKernelGGL(k_taa_resolve, aa_grid(w, a.rows.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), a);
+	const dim3 grid = aa_grid(w, a.rows.count()), block(AA_BLOCK_X, AA_BLOCK_Y);
+	hipStream_t s = gr_to_stream(stream);
+	if (!history)
+		hipLaunchKernelGGL((k_taa_resolve<0, false>), grid, block, 0, s, a);
+	else if (quality == 0)
+		hipLaunchKernelGGL((k_taa_resolve<0, true>), grid, block, 0, s, a);
+	else if (quality == 1)
+		hipLaunchKernelGGL((k_taa_resolve<1, true>), grid, block, 0, s, a);
+	else
+		hipLaunchKernelGGL((k_taa_resolve<2, true>), grid, block, 0, s, a);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

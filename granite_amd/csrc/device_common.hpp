@@ -27,13 +27,13 @@ struct DevImageRW
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 // UNORM8 -> float: v / 255 for an integer v in [0, 255], bit-identical to the IEEE quotient for all 256 inputs
-// (tests/test_oracle_kat.py) at three VALU operations instead of a full division: one Newton step on v * (1 / 255).
+// (tests/test_oracle_kat.py) at two VALU operations instead of a full division: 1 / 255 split into its fp32 rounding and
+// the remainder, v * hi + fl(v * lo) with one rounding at the end.
 __device__ __forceinline__ float unorm8_to_float(uint32_t v)
 {
 	const float f = float(v);
-	const float r = 1.0f / 255.0f;
-	const float q = f * r;
-	return fmaf(fmaf(-q, 255.0f, f), r, q);
+	const float hi = 0x1.010102p-8f, lo = -0x1.fdfdfep-33f;
+	return fmaf(f, hi, f * lo);
 }
 
 // RGBA16F texel fetch: one 8-byte load, hardware cvt to fp32.

@@ -60,6 +60,7 @@ struct SSRParams
 	DevImageRW output, ray_length, confidence;
 	uint32_t *ray_list, *ray_counter;
 	uint32_t *tile_count, *tile_offset; // scratch: one dword per 8 x 8 tile each
+	uint32_t *block_base;               // scratch: one dword per 1024 tiles
 	int tiles_x, tiles_y;
 };
 
@@ -180,36 +181,74 @@ __global__ __launch_bounds__(256) void k_ssr_classify_count(SSRParams p)
 	}
 }
 
-// exclusive scan of the tile counts (one workgroup) + build_indirect.comp
-constexpr int SCAN_THREADS = 1024;
-__global__ __launch_bounds__(SCAN_THREADS) void k_ssr_scan(SSRParams p)
+// Exclusive scan of the tile counts in two levels, every access coalesced: k_ssr_scan_blocks scans 1024 consecutive counts per
+// workgroup (local offsets + one block sum), k_ssr_scan_top scans the block sums in one workgroup and is build_indirect.comp.
+constexpr uint32_t SCAN_BLOCK = 1024; // counts per workgroup: 256 threads x 4
+constexpr uint32_t SCAN_MAX_BLOCKS = 1024;
+
+// Exclusive scan of one value per thread over a 256-thread workgroup; returns the exclusive prefix, `total` = the sum.
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t value, uint32_t *wave_sums, uint32_t &total)
 {
-	__shared__ uint32_t partial[SCAN_THREADS];
-	const uint32_t tiles = uint32_t(p.tiles_x * p.tiles_y);
-	const uint32_t per_thread = (tiles + SCAN_THREADS - 1) / SCAN_THREADS;
-	const uint32_t begin = threadIdx.x * per_thread, end = min(begin + per_thread, tiles);
-	uint32_t sum = 0;
-	for (uint32_t i = begin; i < end; i++)
-		sum += p.tile_count[i];
-	partial[threadIdx.x] = sum;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t inclusive = value;
+#pragma unroll
+	for (int step = 1; step < 64; step <<= 1)
+	{
+		const uint32_t up = __shfl_up(inclusive, step, 64);
+		if (lane >= uint32_t(step))
+			inclusive += up;
+	}
+	if (lane == 63u)
+		wave_sums[wave] = inclusive;
 	__syncthreads();
-	// Hillis-Steele over 1024 partials
-	for (uint32_t step = 1; step < SCAN_THREADS; step <<= 1)
+	uint32_t base = 0;
+	for (uint32_t w = 0; w < wave; w++)
+		base += wave_sums[w];
+	total = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+	return base + inclusive - value;
+}
+
+__global__ __launch_bounds__(256) void k_ssr_scan_blocks(SSRParams p)
+{
+	__shared__ uint32_t wave_sums[4];
+	const uint32_t tiles = uint32_t(p.tiles_x * p.tiles_y);
+	const uint32_t first = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4u;
+	uint32_t c[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+		c[k] = first + k < tiles ? p.tile_count[first + k] : 0u;
+	uint32_t total;
+	uint32_t running = block_exclusive_scan_256(c[0] + c[1] + c[2] + c[3], wave_sums, total);
+#pragma unroll
+	for (int k = 0; k < 4; k++)
 	{
-		const uint32_t add = threadIdx.x >= step ? partial[threadIdx.x - step] : 0u;
-		__syncthreads();
-		partial[threadIdx.x] += add;
-		__syncthreads();
+		if (first + k < tiles)
+			p.tile_offset[first + k] = running; // local to the block; the emit pass adds block_base
+		running += c[k];
 	}
-	uint32_t running = threadIdx.x ? partial[threadIdx.x - 1] : 0u;
-	for (uint32_t i = begin; i < end; i++)
+	if (threadIdx.x == 0)
+		p.block_base[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_ssr_scan_top(SSRParams p, uint32_t blocks)
+{
+	__shared__ uint32_t wave_sums[4];
+	const uint32_t first = threadIdx.x * 4u;
+	uint32_t c[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+		c[k] = first + k < blocks ? p.block_base[first + k] : 0u;
+	uint32_t count;
+	uint32_t running = block_exclusive_scan_256(c[0] + c[1] + c[2] + c[3], wave_sums, count);
+#pragma unroll
+	for (int k = 0; k < 4; k++)
 	{
-		p.tile_offset[i] = running;
-		running += p.tile_count[i];
+		if (first + k < blocks)
+			p.block_base[first + k] = running;
+		running += c[k];
 	}
-	if (threadIdx.x == SCAN_THREADS - 1)
+	if (threadIdx.x == 0)
 	{
-		const uint32_t count = partial[SCAN_THREADS - 1];
 		p.ray_counter[0] = (count + 63u) / 64u; // indirect
 		p.ray_counter[1] = 1u;
 		p.ray_counter[2] = 1u;
@@ -233,7 +272,7 @@ __global__ __launch_bounds__(256) void k_ssr_classify_emit(SSRParams p)
 	{
 		const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(rays >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(rays), 0u));
 		// PackRay
-		p.ray_list[p.tile_offset[tile] + rank] = c.gx | (c.gy << 14u) | (uint32_t(c.base_ray && horiz) << 28u) | (uint32_t(c.base_ray && vert) << 29u) |
+		p.ray_list[p.block_base[tile / SCAN_BLOCK] + p.tile_offset[tile] + rank] = c.gx | (c.gy << 14u) | (uint32_t(c.base_ray && horiz) << 28u) | (uint32_t(c.base_ray && vert) << 29u) |
 		                                         (uint32_t(c.base_ray && diag) << 30u);
 	}
 }
@@ -550,7 +589,8 @@ extern "C" {
 
 size_t gr_ssr_scratch_bytes(uint32_t width, uint32_t height)
 {
-	return size_t((width + 7u) / 8u) * size_t((height + 7u) / 8u) * 2u * sizeof(uint32_t);
+	const size_t tiles = size_t((width + 7u) / 8u) * size_t((height + 7u) / 8u);
+	return (tiles * 2u + (tiles + SCAN_BLOCK - 1) / SCAN_BLOCK) * sizeof(uint32_t);
 }
 
 int gr_ssr_trace(gr_ctx *ctx, gr_stream stream, const gr_ssr_args *args)
@@ -601,12 +641,16 @@ int gr_ssr_trace(gr_ctx *ctx, gr_stream stream, const gr_ssr_args *args)
 	const uint32_t tiles = uint32_t(p.tiles_x) * uint32_t(p.tiles_y);
 	p.tile_count = static_cast<uint32_t *>(args->scratch);
 	p.tile_offset = p.tile_count + tiles;
+	p.block_base = p.tile_offset + tiles;
+	const uint32_t scan_blocks = gr_div_up(tiles, SCAN_BLOCK);
+	GR_CHECK_ARG(ctx, scan_blocks <= SCAN_MAX_BLOCKS); // 1 Mi tiles = 67 M pixels
 
 	hipStream_t s = gr_to_stream(stream);
 	{
 		gr_scoped_timing timing{ctx, s, "ssr_classify"};
 		hipLaunchKernelGGL(k_ssr_classify_count, dim3(gr_div_up(tiles, 4u)), dim3(256), 0, s, p);
-		hipLaunchKernelGGL(k_ssr_scan, dim3(1), dim3(SCAN_THREADS), 0, s, p);
+		hipLaunchKernelGGL(k_ssr_scan_blocks, dim3(scan_blocks), dim3(256), 0, s, p);
+		hipLaunchKernelGGL(k_ssr_scan_top, dim3(1), dim3(256), 0, s, p, scan_blocks);
 		hipLaunchKernelGGL(k_ssr_classify_emit, dim3(gr_div_up(tiles, 4u)), dim3(256), 0, s, p);
 	}
 	{

@@ -314,16 +314,23 @@ def test_oracle_reproduces_committed_fixtures():
 
 
 def test_unorm8_decode_without_a_division_is_exact():
-    """device_common.hpp unorm8_to_float: v * (1/255) followed by one Newton step equals the IEEE quotient v / 255 for every
-    byte, so kernels may use it where the oracle divides."""
+    """device_common.hpp unorm8_to_float: fma(v, hi, fl(v * lo)) with hi = fl(1/255), lo = fl(1/255 - hi) equals the IEEE
+    quotient v / 255 for every byte (exact rational arithmetic, one rounding per operation, ties to even), so kernels may
+    use it where the oracle divides."""
+    from fractions import Fraction
     f32 = np.float32
-    r = f32(1.0) / f32(255.0)
+
+    def rounded(q: Fraction):
+        near = f32(float(q))  # within one ulp: pick the best of it and its neighbours exactly
+        cands = [np.nextafter(near, f32(-np.inf)), near, np.nextafter(near, f32(np.inf))]
+        return min(cands, key=lambda c: (abs(Fraction(float(c)) - q), int(f32(c).view(np.uint32)) & 1))
+
+    hi, lo = f32(float.fromhex("0x1.010102p-8")), f32(float.fromhex("-0x1.fdfdfep-33"))
+    assert hi == f32(1.0) / f32(255.0)
     for v in range(256):
-        f = f32(v)
-        q = f32(f * r)
-        e = f32(np.float64(-q) * 255.0 + np.float64(f))      # fma: one rounding
-        got = f32(np.float64(e) * np.float64(r) + np.float64(q))
-        assert got == f32(f / f32(255.0)), v
+        p = rounded(Fraction(v) * Fraction(float(lo)))
+        got = rounded(Fraction(v) * Fraction(float(hi)) + Fraction(float(p)))
+        assert got == f32(v) / f32(255.0), v
 
 
 def test_ambient_occlusion_scales_only_the_fallback_ambient_term():
