@@ -28,7 +28,7 @@ class Config(C.Structure):
                 ("strip_index", C.c_uint32), ("strip_count", C.c_uint32),
                 ("disable_image_aliasing", C.c_int32), ("depth_hierarchy", C.c_int32),
                 ("resolution_scale", C.c_float), ("resolution_scale_sharpen", C.c_int32), ("fsr_fp32", C.c_int32),
-                ("ambient_occlusion", C.c_int32), ("hdr10", C.c_int32), ("ssr", C.c_int32)]
+                ("ambient_occlusion", C.c_int32), ("hdr10", C.c_int32), ("ssr", C.c_int32), ("aa_bench", C.c_int32)]
 
 
 # void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream)
@@ -58,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
     "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_prefetched_refreshes", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
-    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan", "gra_get_strip_plan_aa",
+    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_upload_aa_bench_images", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan", "gra_get_strip_plan_aa",
     "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_init_output", "gra_install_ssr_tables", "gra_reset_timestamps", "gra_set_directional_light", "gra_generate_mipmaps",
 ]
 
@@ -102,6 +102,7 @@ def load_library() -> C.CDLL:
         "gra_get_allocated_bytes": (C.c_int, [vp, vp]),
         "gra_get_render_size": (C.c_int, [vp, vp, vp]),
         "gra_upload_ambient_occlusion": (C.c_int, [vp, vp]),
+        "gra_upload_aa_bench_images": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32]),
         "gra_compute_rec709_to_display": (C.c_int, [vp, vp]),
         "gra_gtx_probe": (C.c_int, [C.c_char_p, vp, vp, C.c_size_t]),
         "gra_gtx_read": (C.c_int, [C.c_char_p, vp, C.c_uint64, vp, C.c_size_t]),
@@ -138,7 +139,7 @@ class Application:
                  frame_time: float = synth.FRAME_TIME, timestamps: bool = False, strip_index: int = 0, strip_count: int = 1,
                  alias_images: bool = True, depth_hierarchy: int = 0,
                  resolution_scale: float = 1.0, resolution_scale_sharpen: bool = True, fsr_fp16: bool = True,
-                 ambient_occlusion: bool = False, hdr10: bool = False, ssr: bool = False):
+                 ambient_occlusion: bool = False, hdr10: bool = False, ssr: bool = False, aa_bench: bool = False):
         self.lib = load_library()
         cfg = Config()
         cfg.device, cfg.width, cfg.height = device, width, height
@@ -158,6 +159,7 @@ class Application:
         cfg.ambient_occlusion = int(ambient_occlusion)
         cfg.hdr10 = int(hdr10)
         cfg.ssr = int(ssr)
+        cfg.aa_bench = int(aa_bench)
         if ssr:
             install_ssr_tables()
         self._exchange_ref = None
@@ -212,6 +214,12 @@ class Application:
                 for k in ("emissive", "albedo", "normal", "pbr", "depth")]
         mv = None if motion_vectors is None else np.ascontiguousarray(motion_vectors)
         self._check(self.lib.gra_upload_gbuffer(self.handle, *[_ptr(k) for k in keep], _ptr(mv)))
+
+    def upload_aa_bench_images(self, first: np.ndarray, second: np.ndarray):
+        """The two RGBA8 (sRGB) input images of the aa_bench graph, both H x W x 4 uint8 of one size."""
+        a, b = np.ascontiguousarray(first, np.uint8), np.ascontiguousarray(second, np.uint8)
+        assert a.shape == b.shape and a.ndim == 3 and a.shape[2] == 4
+        self._check(self.lib.gra_upload_aa_bench_images(self.handle, a.ctypes.data, b.ctypes.data, a.shape[1], a.shape[0]))
 
     def upload_ambient_occlusion(self, ao: np.ndarray):
         """Render-sized uint8 image for "ssao-output-main" (needs ambient_occlusion=True)."""

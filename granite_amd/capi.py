@@ -255,6 +255,7 @@ def load_library() -> C.CDLL:
         "gr_lighting": (C.c_int, [vp, vp, P(LightingArgs)]),
         "gr_smaa_set_luts": (C.c_int, [vp, vp, vp]),
         "gr_fxaa": (C.c_int, [vp, vp, P(Image), P(Image), P(PushFxaa)]),
+        "gr_blit": (C.c_int, [vp, vp, P(Image), P(Image), C.c_int]),
         "gr_smaa_edge_detection": (C.c_int, [vp, vp, P(Image), P(Image), P(PushSmaa), C.c_int]),
         "gr_smaa_blend_weight": (C.c_int, [vp, vp, P(Image), P(Image), P(PushSmaa), C.c_int]),
         "gr_smaa_neighbor_blend": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushSmaa)]),
@@ -285,7 +286,7 @@ EXPORTED_SYMBOLS = [
     "gr_bloom_threshold", "gr_bloom_downsample", "gr_bloom_upsample", "gr_luminance", "gr_tonemap",
     "gr_bloom_threshold_rows", "gr_bloom_downsample_rows", "gr_bloom_upsample_rows", "gr_tonemap_rows",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
-    "gr_smaa_set_luts", "gr_fxaa", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
+    "gr_smaa_set_luts", "gr_fxaa", "gr_blit", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
     "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen", "gr_fill_byte", "gr_fill_u32", "gr_pq10_encode", "gr_get_device_info", "gr_spd_downsample", "gr_debug_mix",
 ]
 
@@ -481,6 +482,9 @@ class Context:
         self.check(self.lib.gr_taa_resolve(self.handle, stream, current.desc, depth.desc, mv.desc,
                                            history.desc if history is not None else None, out_color.desc, out_history.desc, push,
                                            quality))
+
+    def blit(self, src: DeviceImage, out: DeviceImage, linear: bool, stream=None):
+        self.check(self.lib.gr_blit(self.handle, stream, src.desc, out.desc, int(linear)))
 
     def fsr_upscale(self, src: DeviceImage, out: DeviceImage, fp16: bool = True, stream=None):
         self.check(self.lib.gr_fsr_upscale(self.handle, stream, src.desc, out.desc, int(fp16)))

@@ -942,6 +942,68 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs 
 	store_rgba16f(a.out_history, x, y, make_float4(hist_c.x, hist_c.y, hist_c.z, 1.0f));
 }
 
+// ---- blit (shaders/blit.frag: FragColor = textureLod(uTex, vUV, 0)) -----------------------------------------------------------
+// The full-screen copy Granite's tools use between targets of different size / format (tools/aa_bench.cpp:97-105,138-147).
+// Texel decode by input format, LinearClamp or NearestClamp at the output pixel's centre, store by output format.
+struct BlitArgs
+{
+	DevImage in;
+	DevImageRW out;
+	uint32_t in_format, out_format;
+	int linear;
+	const float *srgb_decode;
+	const uint2 *srgb_encode;
+};
+
+__device__ __forceinline__ v4 blit_texel(const BlitArgs &a, int x, int y)
+{
+	x = clampi(x, 0, a.in.w - 1);
+	y = clampi(y, 0, a.in.h - 1);
+	if (a.in_format == GR_FORMAT_R16G16B16A16_SFLOAT)
+	{
+		const float4 t = load_rgba16f(a.in, x, y);
+		return mk4(t.x, t.y, t.z, t.w);
+	}
+	const uint32_t t = *reinterpret_cast<const uint32_t *>(a.in.ptr + uint32_t(y) * a.in.pitch + uint32_t(x) * 4u);
+	if (a.in_format == GR_FORMAT_R8G8B8A8_SRGB)
+		return mk4(a.srgb_decode[t & 255u], a.srgb_decode[(t >> 8) & 255u], a.srgb_decode[(t >> 16) & 255u], unorm8_to_float(t >> 24));
+	return mk4(unorm8_to_float(t & 255u), unorm8_to_float((t >> 8) & 255u), unorm8_to_float((t >> 16) & 255u), unorm8_to_float(t >> 24));
+}
+
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_blit(BlitArgs a)
+{
+	const int x = blockIdx.x * AA_BLOCK_X + threadIdx.x, y = blockIdx.y * AA_BLOCK_Y + threadIdx.y;
+	if (x >= a.out.w || y >= a.out.h)
+		return;
+	const v2 uv = mk2((float(x) + 0.5f) * (1.0f / float(a.out.w)), (float(y) + 0.5f) * (1.0f / float(a.out.h)));
+	v4 c;
+	if (a.linear)
+	{
+		const float fx = uv.x * float(a.in.w) - 0.5f, fy = uv.y * float(a.in.h) - 0.5f;
+		const float flx = floorf(fx), fly = floorf(fy);
+		const float wa = fx - flx, wb = fy - fly;
+		const int x0 = int(flx), y0 = int(fly);
+		const v4 t00 = blit_texel(a, x0, y0), t10 = blit_texel(a, x0 + 1, y0), t01 = blit_texel(a, x0, y0 + 1), t11 = blit_texel(a, x0 + 1, y0 + 1);
+		const v4 top = t00 * (1.0f - wa) + t10 * wa;
+		const v4 bot = t01 * (1.0f - wa) + t11 * wa;
+		c = top * (1.0f - wb) + bot * wb;
+	}
+	else
+		c = blit_texel(a, int(floorf(uv.x * float(a.in.w))), int(floorf(uv.y * float(a.in.h))));
+	if (a.out_format == GR_FORMAT_R16G16B16A16_SFLOAT)
+		store_rgba16f(a.out, x, y, make_float4(c.x, c.y, c.z, c.w));
+	else
+	{
+		uint32_t packed;
+		if (a.out_format == GR_FORMAT_R8G8B8A8_SRGB)
+			packed = encode_srgb8_lut(c.x, a.srgb_encode) | (encode_srgb8_lut(c.y, a.srgb_encode) << 8) | (encode_srgb8_lut(c.z, a.srgb_encode) << 16) |
+			         (unorm8(c.w) << 24);
+		else
+			packed = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24);
+		*reinterpret_cast<uint32_t *>(a.out.ptr + uint32_t(y) * a.out.pitch + uint32_t(x) * 4u) = packed;
+	}
+}
+
 static bool check_image(const gr_image *img, uint32_t bpp, uint32_t w, uint32_t h)
 {
 	return img && img->ptr && img->width == w && img->height == h && img->pitch_bytes >= w * bpp;
@@ -1120,6 +1182,29 @@ int gr_taa_resolve_rows(gr_ctx *ctx, gr_stream stream, const gr_image *current, 
 		hipLaunchKernelGGL((k_taa_resolve<1, true>), grid, block, 0, s, a);
 	else
 		hipLaunchKernelGGL((k_taa_resolve<2, true>), grid, block, 0, s, a);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_blit(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, int linear)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, in && out && in->ptr && out->ptr && in->ptr != out->ptr && in->width && in->height && out->width && out->height);
+	auto supported = [](uint32_t f) { return f == GR_FORMAT_R16G16B16A16_SFLOAT || f == GR_FORMAT_R8G8B8A8_SRGB || f == GR_FORMAT_R8G8B8A8_UNORM; };
+	GR_CHECK_ARG(ctx, supported(in->format) && supported(out->format));
+	GR_CHECK_ARG(ctx, in->pitch_bytes >= in->width * (in->format == GR_FORMAT_R16G16B16A16_SFLOAT ? 8u : 4u));
+	GR_CHECK_ARG(ctx, out->pitch_bytes >= out->width * (out->format == GR_FORMAT_R16G16B16A16_SFLOAT ? 8u : 4u));
+	BlitArgs a = {};
+	a.in = DevImage{static_cast<const uint8_t *>(in->ptr), int(in->width), int(in->height), in->pitch_bytes};
+	a.out = DevImageRW{static_cast<uint8_t *>(out->ptr), int(out->width), int(out->height), out->pitch_bytes};
+	a.in_format = in->format;
+	a.out_format = out->format;
+	a.linear = linear ? 1 : 0;
+	a.srgb_decode = ctx->srgb_decode_lut;
+	a.srgb_encode = ctx->srgb_encode_lut;
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "blit"};
+	hipLaunchKernelGGL(k_blit, aa_grid(out->width, out->height), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), a);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

@@ -209,6 +209,11 @@ int gra_gtx_write(const char *path, const gra_gtx_info *info, const void *payloa
 	});
 }
 
+int gra_upload_aa_bench_images(gra_app *app, const void *rgba8_first, const void *rgba8_second, uint32_t width, uint32_t height)
+{
+	return guarded(app, [&]() { app->app->upload_aa_bench_images(rgba8_first, rgba8_second, width, height); });
+}
+
 int gra_upload_ambient_occlusion(gra_app *app, const void *ao_r8)
 {
 	return guarded(app, [&]() { app->app->upload_ambient_occlusion(ao_r8); });

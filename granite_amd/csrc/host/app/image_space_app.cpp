@@ -41,6 +41,8 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 	if (config.hdr10 && (!config.enable_lighting || config.hdr_bloom || config.post_aa != GRA_POST_AA_NONE || config.pre_aa != GRA_POST_AA_NONE ||
 	                     config.strip_count > 1 || (config.resolution_scale > 0.0f && config.resolution_scale < 1.0f)))
 		throw std::logic_error("hdr10 needs enable_lighting and excludes hdr_bloom, anti-aliasing, resolution scaling and row bands.");
+	if (config.aa_bench && (config.enable_lighting || config.hdr_bloom || config.hdr10 || config.ssr || config.strip_count > 1 || config.depth_hierarchy))
+		throw std::logic_error("aa_bench is a graph of its own: no lighting, bloom, hdr10, SSR, depth hierarchy or row bands.");
 	if (config.resolution_scale < 0.0f || config.resolution_scale > 1.0f)
 		throw std::logic_error("resolution_scale must be in (0, 1].");
 	render_width = config.width;
@@ -97,7 +99,10 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 	set_base_camera(perspective(1.0471975512f, float(config.width) / float(config.height), 0.1f, 100.0f),
 	                look_at(vec3(0.0f, 2.0f, 8.0f), vec3(0.0f, 1.0f, 0.0f), vec3(0.0f, 1.0f, 0.0f)));
 
-	graph.enable_timestamps(config.enable_timestamps != 0);
+	if (config.aa_bench)
+		set_base_camera(mat4(1.0f), mat4(1.0f)); // AABenchApplication::render_frame: jitter.step(mat4(1.0f), mat4(1.0f))
+
+	graph.enable_timestamps(config.enable_timestamps != 0 || config.aa_bench != 0); // aa_bench.cpp:155
 	if (!device_holder)
 		return;
 	auto &device = *device_holder;
@@ -279,6 +284,24 @@ void ImageSpaceApplication::upload_ambient_occlusion(const void *ao_r8)
 	filled_targets.clear();
 }
 
+void ImageSpaceApplication::upload_aa_bench_images(const void *first, const void *second, uint32_t width, uint32_t height)
+{
+	if (!config.aa_bench)
+		throw std::logic_error("This graph takes no benchmark images (config.aa_bench).");
+	if (!first || !second || !width || !height)
+		throw std::logic_error("upload_aa_bench_images: two images and their size are needed.");
+	auto &device = get_device();
+	device.wait_idle();
+	const void *src[2] = {first, second};
+	for (int i = 0; i < 2; i++)
+	{
+		bench_images[i] = device.create_image(width, height, VK_FORMAT_R8G8B8A8_SRGB, "aa-bench-input-" + std::to_string(i));
+		if (gr_upload(device.get_context(), nullptr, bench_images[i]->get_device_pointer(), src[i], size_t(width) * height * 4u) < 0 ||
+		    gr_sync(device.get_context(), nullptr) < 0)
+			throw std::runtime_error(gr_last_error(device.get_context()));
+	}
+}
+
 void ImageSpaceApplication::upload_gbuffer_gtx(const char *const paths[6])
 {
 	struct Slot
@@ -349,6 +372,32 @@ void ImageSpaceApplication::add_hdr_input_pass(const std::string &tag)
 		auto &target = graph.get_physical_texture_resource(out);
 		if (needs_fill(target))
 			cmd.copy_image(target, *src_emissive);
+	});
+}
+
+// tools/aa_bench.cpp:76-117: the "main" pass of the AA benchmark -- HDR-main (B10G11R11 there, RGBA16F here, as the TAA output)
+// and depth-main at `scale`, colour = one of the two input images through blit.frag with LinearClamp, depth cleared to 0.
+void ImageSpaceApplication::add_aa_bench_main_pass(const std::string &tag)
+{
+	AttachmentInfo main_output, main_depth;
+	main_output.format = VK_FORMAT_R16G16B16A16_SFLOAT;
+	main_depth.format = VK_FORMAT_D32_SFLOAT;
+	if (scaled())
+	{
+		main_output.size_x = main_output.size_y = config.resolution_scale;
+		main_depth.size_x = main_depth.size_y = config.resolution_scale;
+	}
+	auto &pass = graph.add_pass(tag, RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+	auto &color = pass.add_color_output(tagcat("HDR", tag), main_output);
+	auto &depth = pass.set_depth_stencil_output(tagcat("depth", tag), main_depth);
+	pass.set_build_render_pass([this, &color, &depth](HIP::CommandBuffer &cmd) {
+		auto &target = graph.get_physical_texture_resource(color);
+		cmd.clear_image(graph.get_physical_texture_resource(depth)); // set_get_clear_depth_stencil: depth = 0.0
+		HIP::Image *img = bench_images[(bench_input_index++) & 1].get();
+		if (img)
+			cmd.check(gr_blit(cmd.get_context(), cmd.get_stream(), &img->get_view(), &target.get_view(), 1), "blit");
+		else
+			cmd.clear_image(target); // set_get_clear_color: zero
 	});
 }
 
@@ -496,7 +545,9 @@ void ImageSpaceApplication::bake_render_graph()
 	graph.set_backbuffer_dimensions(dim);
 
 	const std::string tag = "main";
-	if (config.enable_lighting)
+	if (config.aa_bench)
+		add_aa_bench_main_pass(tag);
+	else if (config.enable_lighting)
 	{
 		cluster.add_render_passes(graph);
 		add_main_pass_deferred(tag);
@@ -523,9 +574,9 @@ void ImageSpaceApplication::bake_render_graph()
 	bool temporal = pre_aa == PostAAType::TAA_Low || pre_aa == PostAAType::TAA_Medium || pre_aa == PostAAType::TAA_High;
 	if (temporal)
 	{
-		if (!config.enable_lighting)
+		if (!config.enable_lighting && !config.aa_bench)
 			throw std::logic_error("TAA needs the depth attachment of the deferred graph.");
-		add_mv_pass(tag);
+		add_mv_pass(tag); // aa_bench.cpp hands the resolve an unnamed motion-vector input; here: the zero image
 	}
 
 	if (config.hdr_bloom)
@@ -538,6 +589,24 @@ void ImageSpaceApplication::bake_render_graph()
 		else
 			setup_hdr_postprocess(graph, frame, hdr_source, "tonemapped", hdr_options);
 		ui_source = "tonemapped";
+	}
+
+	if (config.aa_bench)
+	{
+		// aa_bench.cpp:127-147: TAA in front, then "tonemap" = blit.frag with NearestClamp into a swapchain-sized target.
+		const float scale = scaled() ? config.resolution_scale : 1.0f;
+		bool resolved = setup_before_post_chain_antialiasing(pre_aa, graph, jitter, context, scale, light_output, tagcat("depth", tag),
+		                                                     tagcat("mv", tag), "HDR-resolved");
+		auto &tonemap = graph.add_pass("tonemap", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
+		AttachmentInfo swapchain_output;
+		auto &tonemap_out = tonemap.add_color_output("tonemap", swapchain_output);
+		auto &tonemap_res = tonemap.add_texture_input(resolved ? "HDR-resolved" : light_output);
+		tonemap.set_build_render_pass([this, &tonemap_out, &tonemap_res](HIP::CommandBuffer &cmd) {
+			auto &input = graph.get_physical_texture_resource(tonemap_res);
+			auto &output = graph.get_physical_texture_resource(tonemap_out);
+			cmd.check(gr_blit(cmd.get_context(), cmd.get_stream(), &input.get_view(), &output.get_view(), 0), "blit");
+		});
+		ui_source = "tonemap";
 	}
 
 	if (post_aa != PostAAType::None)

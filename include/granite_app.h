@@ -82,6 +82,12 @@ typedef struct gra_config
 	 * the post chain -- depth hierarchy "depth-transient-main-hier", "SSR-trace" (classify + trace), "SSR" (apply, blended into
 	 * the lit target).  Needs enable_lighting and gra_install_ssr_tables before the first frame. */
 	int32_t ssr;
+	/* The frame graph of Granite's AA benchmark (tools/aa_bench.cpp:65-161) instead of the viewer's: "main" blits one of two
+	 * input images (alternating per frame, gra_upload_aa_bench_images) into "HDR-main" with LinearClamp and clears "depth-main",
+	 * pre_aa (TAA) resolves it, "tonemap" blits the result into a swapchain-sized target with NearestClamp, post_aa (FXAA /
+	 * SMAA) follows, and with 0 < resolution_scale < 1 FSR 1.0 (+ sharpen) ends the frame.  Identity camera matrices feed the
+	 * temporal jitter (aa_bench.cpp:52), timestamps are on.  enable_lighting and hdr_bloom must be 0. */
+	int32_t aa_bench;
 } gra_config;
 
 /* Scene-level light description (one PositionalLight + its node transform). */
@@ -119,6 +125,8 @@ int gra_upload_gbuffer(gra_app *app, const void *emissive_rgba16f, const void *a
                        const void *pbr_rg8, const void *depth_d32f, const void *motion_vectors_rg16f);
 
 /* Render-sized R8_UNORM ambient-occlusion image (host pointer, tightly packed); needs config.ambient_occlusion. */
+/* The two input images of the aa_bench graph: R8G8B8A8_SRGB, tightly packed, any size (both the same). */
+int gra_upload_aa_bench_images(gra_app *app, const void *rgba8_first, const void *rgba8_second, uint32_t width, uint32_t height);
 int gra_upload_ambient_occlusion(gra_app *app, const void *ao_r8);
 
 /* ---- GTX ("GRANITE TEXFMT1", vulkan/texture/memory_mapped_texture.cpp:29-44): the container Granite keeps textures and

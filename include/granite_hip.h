@@ -369,6 +369,12 @@ typedef struct gr_lighting_args
 } gr_lighting_args;
 int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args);
 
+/* builtin://shaders/blit.frag over a full-screen quad (FragColor = textureLod(uTex, vUV, 0)): the copy between targets of
+ * different size / format that Granite's tools record (tools/aa_bench.cpp:97-105 into the HDR target with LinearClamp,
+ * :138-147 into the swapchain with NearestClamp).  in / out: R16G16B16A16_SFLOAT, R8G8B8A8_UNORM or R8G8B8A8_SRGB (decoded on
+ * the fetch / encoded by the store, as the image views would); linear != 0 = StockSampler::LinearClamp, else NearestClamp. */
+int gr_blit(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_image *out, int linear);
+
 /* ---- anti-aliasing (renderer/post/{fxaa,smaa,temporal}.cpp) ------------------------------------------------------------ */
 
 /* setup_fxaa_postprocess (fxaa.cpp:28-55) + fxaa.frag.  `in` is read through its UNORM alias (cmd.set_unorm_texture):

@@ -142,6 +142,18 @@ def float_to_srgb8(values: np.ndarray) -> np.ndarray:
     return out.reshape(np.shape(values))
 
 
+BLIT_FORMATS = {"rgba16f": 0, "rgba8_unorm": 1, "rgba8_srgb": 2}
+
+
+def blit(src: np.ndarray, in_format: str, ow: int, oh: int, out_format: str, linear: bool) -> np.ndarray:
+    """blit.frag over a full-screen quad: `src` (H x W x 4, uint16 half bits or uint8) -> oh x ow x 4 in `out_format`."""
+    src = np.ascontiguousarray(src)
+    assert src.dtype == (np.uint16 if in_format == "rgba16f" else np.uint8) and src.shape[2] == 4
+    out = np.zeros((oh, ow, 4), np.uint16 if out_format == "rgba16f" else np.uint8)
+    lib().orc_blit(_p(src), src.shape[1], src.shape[0], BLIT_FORMATS[in_format], _p(out), ow, oh, BLIT_FORMATS[out_format], int(linear))
+    return out
+
+
 def frame_lerps(frame_time: float):
     """(luminance lerp, bloom feedback lerp) as hdr.cpp:93,181 compute them: float(1.0 - pow(0.5|0.001, frame_time))."""
     import math

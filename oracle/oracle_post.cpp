@@ -186,6 +186,54 @@ void orc_float_to_srgb8_array(const float *in, size_t n, uint8_t *out)
 		out[i] = float_to_srgb8(in[i]);
 }
 float orc_srgb8_to_float(uint8_t v) { return srgb8_to_float(v); }
+
+// builtin://shaders/blit.frag over a full-screen quad: FragColor = textureLod(uTex, vUV, 0.0), vUV = the pixel centre; the
+// copy Granite's tools record between targets of different size / format (tools/aa_bench.cpp:97-105 LinearClamp into the HDR
+// target, :138-147 NearestClamp into the swapchain).  Formats: 0 = R16G16B16A16_SFLOAT, 1 = R8G8B8A8_UNORM, 2 = R8G8B8A8_SRGB.
+void orc_blit(const void *in, int iw, int ih, int in_format, void *out, int ow, int oh, int out_format, int linear)
+{
+	auto texel = [&](int x, int y) {
+		x = clampi(x, 0, iw - 1);
+		y = clampi(y, 0, ih - 1);
+		if (in_format == 0)
+			return load_rgba16f(static_cast<const uint16_t *>(in), iw, x, y);
+		const uint8_t *p = static_cast<const uint8_t *>(in) + (size_t(y) * iw + x) * 4;
+		if (in_format == 2)
+			return V4(srgb8_to_float(p[0]), srgb8_to_float(p[1]), srgb8_to_float(p[2]), unorm8_to_float(p[3]));
+		return V4(unorm8_to_float(p[0]), unorm8_to_float(p[1]), unorm8_to_float(p[2]), unorm8_to_float(p[3]));
+	};
+#pragma omp parallel for
+	for (int y = 0; y < oh; y++)
+		for (int x = 0; x < ow; x++)
+		{
+			const vec2 uv = V2((float(x) + 0.5f) * (1.0f / float(ow)), (float(y) + 0.5f) * (1.0f / float(oh)));
+			vec4 c;
+			if (linear)
+			{
+				const float u = uv.x * float(iw) - 0.5f, v = uv.y * float(ih) - 0.5f;
+				const float fu = floorf(u), fv = floorf(v);
+				const float a = u - fu, b = v - fv;
+				const int x0 = int(fu), y0 = int(fv);
+				const vec4 t00 = texel(x0, y0), t10 = texel(x0 + 1, y0), t01 = texel(x0, y0 + 1), t11 = texel(x0 + 1, y0 + 1);
+				const vec4 top = t00 * (1.0f - a) + t10 * a;
+				const vec4 bot = t01 * (1.0f - a) + t11 * a;
+				c = top * (1.0f - b) + bot * b;
+			}
+			else
+				c = texel(int(floorf(uv.x * float(iw))), int(floorf(uv.y * float(ih))));
+			if (out_format == 0)
+				store_rgba16f(static_cast<uint16_t *>(out), ow, x, y, c);
+			else
+			{
+				uint8_t *p = static_cast<uint8_t *>(out) + (size_t(y) * ow + x) * 4;
+				const bool srgb = out_format == 2;
+				p[0] = srgb ? float_to_srgb8(c.x) : float_to_unorm8(c.x);
+				p[1] = srgb ? float_to_srgb8(c.y) : float_to_unorm8(c.y);
+				p[2] = srgb ? float_to_srgb8(c.z) : float_to_unorm8(c.z);
+				p[3] = float_to_unorm8(c.w);
+			}
+		}
+}
 void orc_sample_linear_rgba16f(const uint16_t *img, int w, int h, float u, float v, float *out4)
 {
 	Tex16F t{img, w, h};

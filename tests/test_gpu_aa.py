@@ -201,3 +201,19 @@ def test_application_with_aa_matches_oracle_pipeline(luts, post_aa, pre_aa):
         expect = T @ cam.VP @ cam.invVP
         np.testing.assert_allclose(a.taa_reprojection().reshape(4, 4).T, expect, atol=2e-5)
     a.close()
+
+
+@pytest.mark.parametrize("src_fmt,dst_fmt,linear,sw,sh,dw,dh", [
+    ("rgba8_srgb", "rgba16f", True, 200, 120, 333, 77), ("rgba16f", "rgba8_srgb", False, 333, 77, 333, 77),
+    ("rgba16f", "rgba8_srgb", False, 167, 39, 333, 77), ("rgba8_unorm", "rgba8_unorm", True, 64, 64, 200, 120),
+    ("rgba16f", "rgba16f", True, 960, 540, 1920, 1080)])
+def test_blit_matches_the_oracle(gr, src_fmt, dst_fmt, linear, sw, sh, dw, dh):
+    """blit.frag (the copy between targets of different size / format in tools/aa_bench.cpp): decode by input format,
+    LinearClamp / NearestClamp at the pixel centre, store by output format.  Same arithmetic as the oracle: exact."""
+    fmt = {"rgba16f": capi.FORMAT_R16G16B16A16_SFLOAT, "rgba8_unorm": capi.FORMAT_R8G8B8A8_UNORM, "rgba8_srgb": capi.FORMAT_R8G8B8A8_SRGB}
+    src = synth.make_hdr(sw, sh) if src_fmt == "rgba16f" else synth.make_ldr_pattern(sw, sh)
+    want = orc.blit(src, src_fmt, dw, dh, dst_fmt, linear)
+    out = capi.DeviceImage(gr, dw, dh, fmt[dst_fmt])
+    gr.blit(capi.DeviceImage(gr, sw, sh, fmt[src_fmt]).upload(src), out, linear)
+    gr.sync()
+    np.testing.assert_array_equal(out.download(), want)

@@ -95,3 +95,60 @@ def test_graphics_variant_tags_merged_passes_and_gtx_scene(tmp_path):
     np.testing.assert_array_equal(png.read_png(out_png), b.read_backbuffer())
     assert len(np.unique(b.read_backbuffer()[..., 1])) > 20
     b.close()
+
+
+AA_EXE = os.path.join(ROOT, "tools", "aa-bench-headless")
+
+
+def aa_bench(tmp_path, images, method, frames, width, height, scale=None):
+    stat, out_png = tmp_path / f"{method}.stat", tmp_path / f"{method}.png"
+    cmd = [AA_EXE, "--frames", str(frames), "--width", str(width), "--height", str(height), "--input-images", *images, "--stat", str(stat),
+           "--aa-method", method, "--png-reference-path", str(out_png)]
+    if scale is not None:
+        cmd += ["--scale", str(scale)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(stat.read_text()), png.read_png(str(out_png)), r
+
+
+def test_aa_bench_stand_in_runs_the_references_graph(tmp_path):
+    """tools/aa-bench-headless with the command line tools/bench_aa.py builds (bench_aa.py:144-148): the graph of
+    tools/aa_bench.cpp -- blit of the alternating input images into the HDR target, AA, blit into the swapchain -- checked
+    against the oracle's blit / FXAA / SMAA for the frame the run ends on, and the --stat document bench_aa.py reads."""
+    from oracle import oracle as orc
+    from granite_amd.data import load_smaa_luts
+    w, h, frames = 320, 180, 5
+    imgs = [synth.make_ldr_pattern(200, 120, seed) for seed in (1, 2)]   # another size than the frame: the blit filters
+    paths = []
+    for i, img in enumerate(imgs):
+        paths.append(str(tmp_path / f"in{i}.png"))
+        png.write_png(paths[-1], img)
+    last = imgs[frames & 1]   # warm-up frame = image 0, then `frames` more: the input index has advanced `frames` times
+    hdr = orc.blit(last, "rgba8_srgb", w, h, "rgba16f", True)
+    plain = orc.blit(hdr, "rgba16f", w, h, "rgba8_srgb", False)
+
+    stat, got, _ = aa_bench(tmp_path, paths, "none", frames, w, h)
+    np.testing.assert_array_equal(got, plain)
+    assert stat["averageFrameTimeUs"] > 0 and stat["driverVersion"] > 0 and {"main", "tonemap"} <= set(stat["performance"])
+    assert stat["performance"]["tonemap"]["accumulationsPerFrameContext"] == 1.0
+
+    stat, got, _ = aa_bench(tmp_path, paths, "fxaa", frames, w, h)
+    assert np.abs(got.astype(np.int16) - orc.fxaa(plain).astype(np.int16)).max() <= 1
+    assert "fxaa" in stat["performance"]
+
+    stat, got, _ = aa_bench(tmp_path, paths, "smaaUltra", frames, w, h)
+    assert np.abs(got.astype(np.int16) - orc.smaa(plain, *load_smaa_luts(), 3)["out"].astype(np.int16)).max() <= 1
+    assert {"smaa-edge", "smaa-weights", "smaa-blend"} <= set(stat["performance"])
+
+    # temporal methods resolve in front of the blit; the frame differs from the unresolved one and carries the pass's timestamp
+    stat, got, _ = aa_bench(tmp_path, paths, "taaHigh", frames, w, h)
+    assert "taa-resolve" in stat["performance"] and (got != plain).any() and np.abs(got.astype(np.int16) - plain.astype(np.int16)).mean() < 40
+
+    # methods bench_aa.py sweeps that are not live in the reference either run as "none"
+    stat, got, r = aa_bench(tmp_path, paths, "taaNightmare", frames, w, h)
+    np.testing.assert_array_equal(got, plain)
+    assert "no live implementation" in r.stderr
+
+    # --scale: HDR target at half size, FSR 1.0 + sharpen behind the blit
+    stat, got, _ = aa_bench(tmp_path, paths, "none", frames, w, h, scale=0.5)
+    assert got.shape == (h, w, 4) and {"post-scale-output-scale", "post-scale-output-sharpen"} <= set(stat["performance"])

@@ -262,3 +262,35 @@ json.dump(headless.stat_document(250.0 if kw["post_aa"] == 0 else 300.0, "stub g
     assert runs[0]["gpu"] == "stub gpu" and runs[0]["version"] == 42 and runs[0]["width"] == 640
     assert runs[0]["performance"]["tonemap"] == {"timePerAccumulationUs": 30.0, "timePerFrameContextUs": 30.0,
                                                    "accumulationsPerFrameContext": 1.0}
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/tools/bench_aa.py"), reason="needs the Granite checkout")
+def test_the_references_aa_bench_script_drives_our_stand_in(tmp_path):
+    """Granite's own tools/bench_aa.py, executed: the command line it builds for aa-bench-headless (bench_aa.py:144-148 +
+    '--aa-method' per method, :161-166) must parse with the stand-in's argument parser and its run_test / map_result_to_json must
+    consume the --stat document.  The stub stands for the GPU run; tests/test_gpu_headless.py runs the real one."""
+    stub = tmp_path / "aa-bench-stub"
+    stub.write_text(f"""#!{sys.executable}
+import json, sys
+sys.path.insert(0, {ROOT!r})
+from granite_amd import aa_bench, headless
+args = aa_bench.parse_args(sys.argv[1:])
+assert args.frames == 9 and args.width == 320 and args.height == 200 and args.input_images == ["a.png", "b.png"]
+kw = aa_bench.method_to_kwargs(args.aa_method)
+cost = 100.0 + 10.0 * kw["post_aa"] + 20.0 * kw["pre_aa"]
+json.dump(headless.stat_document(cost, "stub gpu", 7, {{"tonemap": (9, 0.9)}}, args.frames), open(args.stat, "w"))
+""")
+    stub.chmod(0o755)
+    results = tmp_path / "aa.json"
+    r = subprocess.run([sys.executable, "/root/reference/tools/bench_aa.py", "--binary", str(stub), "--images", "a.png", "b.png", "--width", "320",
+                        "--height", "200", "--frames", "9", "--iterations", "2", "--results", str(results)], capture_output=True, text=True,
+                       timeout=180)
+    assert r.returncode == 0, r.stderr[-1500:]
+    runs = {x["method"]: x for x in json.loads(results.read_text())["runs"]}
+    # bench_aa.py:158-159: every method it knows, live in the reference or not
+    assert set(runs) == {"none", "fxaa", "fxaa2phase", "smaaLow", "smaaMedium", "smaaHigh", "smaaUltra", "smaaUltraT2X", "taaLow", "taaMedium",
+                         "taaHigh", "taaUltra", "taaExtreme", "taaNightmare"}
+    from granite_amd import app as gapp
+    assert runs["none"]["avg"] == 100.0 and runs["fxaa"]["avg"] == 100.0 + 10.0 * gapp.POST_AA_FXAA
+    assert runs["taaHigh"]["avg"] == 100.0 + 20.0 * gapp.POST_AA_TAA_HIGH and runs["taaNightmare"]["avg"] == 100.0
+    assert runs["smaaUltra"]["gpu"] == "stub gpu" and runs["smaaUltra"]["version"] == 7 and runs["smaaUltra"]["width"] == 320
