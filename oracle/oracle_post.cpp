@@ -187,7 +187,8 @@ void orc_float_to_srgb8_array(const float *in, size_t n, uint8_t *out)
 }
 float orc_srgb8_to_float(uint8_t v) { return srgb8_to_float(v); }
 
-// builtin://shaders/blit.frag over a full-screen quad: FragColor = textureLod(uTex, vUV, 0.0), vUV = the pixel centre; the
+// builtin://shaders/blit.frag over a full-screen quad: FragColor = Scale * textureLod(uImage, vUV, 0.0) with Scale = 1, vUV = the
+// pixel centre (pinned: ref_build/ref_shaders.cpp ref_blit executes the shader, test_blit_shader_bit_for_bit); the
 // copy Granite's tools record between targets of different size / format (tools/aa_bench.cpp:97-105 LinearClamp into the HDR
 // target, :138-147 NearestClamp into the swapchain).  Formats: 0 = R16G16B16A16_SFLOAT, 1 = R8G8B8A8_UNORM, 2 = R8G8B8A8_SRGB.
 void orc_blit(const void *in, int iw, int ih, int in_format, void *out, int ow, int oh, int out_format, int linear)

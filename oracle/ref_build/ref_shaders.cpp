@@ -41,6 +41,10 @@ namespace tonemap_static
 {
 #include "gen/tonemap.inc"
 }
+namespace blit
+{
+#include "gen/blit.inc"
+}
 #undef DYNAMIC_EXPOSURE
 
 #define FEEDBACK 1
@@ -271,6 +275,31 @@ void ref_pq10_encode(const uint16_t *hdr, const uint8_t *ui_srgb8, int w, int h,
 			s::main();
 			auto q = [](float v) -> uint32_t { return !(v > 0.0f) ? 0u : (v >= 1.0f ? 1023u : uint32_t(int(v * 1023.0f + 0.5f))); };
 			out[size_t(y) * w + x] = q(s::FragColor.x) | (q(s::FragColor.y) << 10) | (q(s::FragColor.z) << 20) | (3u << 30);
+		}
+}
+
+// blit.frag on a full-screen quad (tools/aa_bench.cpp:97-105,138-147): formats 0 = RGBA16F, 1 = RGBA8_UNORM, 2 = RGBA8_SRGB on
+// either side (the sampled view decodes, the attachment store encodes), LinearClamp or NearestClamp.
+void ref_blit(const void *in, int iw, int ih, int in_format, void *out, int ow, int oh, int out_format, int linear)
+{
+	namespace s = blit;
+	static const Format formats[3] = {Format::RGBA16F, Format::RGBA8_UNORM, Format::RGBA8_SRGB};
+	s::uImage.data = in;
+	s::uImage.w = iw;
+	s::uImage.h = ih;
+	s::uImage.format = formats[in_format];
+	s::uImage.filter = linear ? Filter::Linear : Filter::Nearest;
+	Image target;
+	target.data = out;
+	target.w = ow;
+	target.h = oh;
+	target.format = formats[out_format];
+	for (int y = 0; y < oh; y++)
+		for (int x = 0; x < ow; x++)
+		{
+			s::vUV = (vec2(float(x), float(y)) + vec2(0.5f, 0.5f)) * vec2(1.0f / float(ow), 1.0f / float(oh));
+			s::main();
+			imageStore(target, ivec2(x, y), s::FragColor);
 		}
 }
 

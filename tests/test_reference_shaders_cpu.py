@@ -398,3 +398,19 @@ def test_sssr_shaders_bit_for_bit(ref, w, h, frame):
     ref.ref_ssr_apply(w, h, *[ptr(k) for k in keep], lut.shape[1], lut.shape[0], ptr(ivp), ptr(cam_pos), ptr(got_hdr))
     np.testing.assert_array_equal(got_hdr, want_hdr)
     assert (got_hdr != light).any(axis=2).mean() > 0.2
+
+
+@pytest.mark.parametrize("src_fmt,dst_fmt,linear,sw,sh,dw,dh", [
+    ("rgba8_srgb", "rgba16f", True, 100, 60, 167, 39), ("rgba16f", "rgba8_srgb", False, 167, 39, 167, 39),
+    ("rgba16f", "rgba8_srgb", False, 83, 19, 167, 39), ("rgba8_unorm", "rgba8_unorm", True, 64, 64, 100, 60),
+    ("rgba16f", "rgba16f", True, 96, 54, 192, 108)])
+def test_blit_shader_bit_for_bit(ref, src_fmt, dst_fmt, linear, sw, sh, dw, dh):
+    """assets/shaders/blit.frag (the full-screen copy of tools/aa_bench.cpp) executed == orc.blit, for every format pair and both
+    samplers the AA benchmark graph uses."""
+    src = synth.make_hdr(sw, sh) if src_fmt == "rgba16f" else synth.make_ldr_pattern(sw, sh)
+    want = orc.blit(src, src_fmt, dw, dh, dst_fmt, linear)
+    got = np.zeros_like(want)
+    src = np.ascontiguousarray(src)
+    ref.ref_blit.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int]
+    ref.ref_blit(ptr(src), sw, sh, orc.BLIT_FORMATS[src_fmt], ptr(got), dw, dh, orc.BLIT_FORMATS[dst_fmt], int(linear))
+    np.testing.assert_array_equal(got, want)
