@@ -144,3 +144,13 @@ static inline RowSpan resolve_rows(const gr_rows *rows, uint32_t height)
 	const uint64_t end = uint64_t(rows->first) + rows->count;
 	return {first, end < height ? uint32_t(end) : height};
 }
+
+// A/B switches read from the environment select between implementations that are all parity-tested (results do not change, launch
+// times do).  An inherited environment must not change timing silently: the first read of a set switch says so on stderr.
+static inline const char *gr_measurement_switch(const char *name)
+{
+	const char *value = getenv(name);
+	if (value)
+		fprintf(stderr, "[granite-hip] note: measurement switch %s=%s is set (results unchanged, timing differs)\n", name, value);
+	return value;
+}

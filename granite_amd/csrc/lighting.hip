@@ -715,7 +715,7 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	// texels is one naturally aligned access in every attachment: even width, pitches that are multiples of two texels.
 	// Odd-sized targets run the one-pixel kernel.
 	static const int px_pref = []() {
-		const char *env = getenv("GR_LIGHTING_PX");
+		const char *env = gr_measurement_switch("GR_LIGHTING_PX");
 		return env && atoi(env) == 1 ? 1 : 2;
 	}();
 	const bool pairs_aligned = (W & 1u) == 0 && (args->depth.pitch_bytes & 7u) == 0 && (args->albedo.pitch_bytes & 7u) == 0 &&
@@ -737,7 +737,7 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	// remaining slots to them.  With two pixels per lane the wave has two independent BRDF chains in flight, so four
 	// workgroups (16 waves) per CU already keep the VALU busy.
 	static const int max_wgs_env = []() {
-		const char *env = getenv("GR_LIGHTING_WGS_PER_CU");
+		const char *env = gr_measurement_switch("GR_LIGHTING_WGS_PER_CU");
 		const int v = env ? atoi(env) : 0;
 		return v >= 1 && v <= 8 ? v : 0;
 	}();

@@ -653,7 +653,7 @@ static bool is_rgba16f(const gr_image *img)
 // What gr_bloom_downsample / gr_bloom_upsample pick for a level: the constant-weight stencil when it is exactly 2:1 / 1:2.
 static bool downsample_is_exact(const gr_image *in, const gr_push_bloom_downsample *push)
 {
-	static const bool allow_stencil = getenv("GR_NO_STENCIL") == nullptr;
+	static const bool allow_stencil = gr_measurement_switch("GR_NO_STENCIL") == nullptr;
 	return allow_stencil && in->width == 2u * push->threads[0] && in->height == 2u * push->threads[1] && (in->pitch_bytes & 15u) == 0 &&
 	       (reinterpret_cast<uintptr_t>(in->ptr) & 15u) == 0 && push->inv_output_size[0] == 1.0f / float(push->threads[0]) &&
 	       push->inv_output_size[1] == 1.0f / float(push->threads[1]) && push->inv_input_size[0] == 1.0f / float(in->width) &&
@@ -661,7 +661,7 @@ static bool downsample_is_exact(const gr_image *in, const gr_push_bloom_downsamp
 }
 static bool upsample_is_exact(const gr_image *in, const gr_push_bloom_upsample *push)
 {
-	static const bool allow_stencil = getenv("GR_NO_STENCIL") == nullptr;
+	static const bool allow_stencil = gr_measurement_switch("GR_NO_STENCIL") == nullptr;
 	return allow_stencil && push->threads[0] == 2u * in->width && push->threads[1] == 2u * in->height &&
 	       push->inv_output_size[0] == 1.0f / float(push->threads[0]) && push->inv_output_size[1] == 1.0f / float(push->threads[1]) &&
 	       push->inv_input_size[0] == 1.0f / float(in->width) && push->inv_input_size[1] == 1.0f / float(in->height);
@@ -693,7 +693,7 @@ int gr_bloom_threshold_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, 
 	dim3 block(POST_BLOCK_X, POST_BLOCK_Y);
 	dim3 grid(gr_div_up(push->threads[0], POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_threshold"};
-	static const bool allow_stencil = getenv("GR_NO_STENCIL") == nullptr; // A/B switch for measurements
+	static const bool allow_stencil = gr_measurement_switch("GR_NO_STENCIL") == nullptr; // A/B switch for measurements
 	const bool exact = allow_stencil && hdr->width == 2u * push->threads[0] && hdr->height == 2u * push->threads[1] && (push->threads[0] & 1u) == 0 &&
 	                   out->width == push->threads[0] && (hdr->pitch_bytes & 15u) == 0 && (out->pitch_bytes & 15u) == 0 &&
 	                   (reinterpret_cast<uintptr_t>(hdr->ptr) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out->ptr) & 15u) == 0 &&
@@ -796,7 +796,7 @@ int gr_bloom_tail_supported(const gr_image *d1, const gr_image *d2, const gr_ima
                             const gr_push_bloom_downsample *push_d2, const gr_push_bloom_downsample *push_d3,
                             const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1)
 {
-	static const bool allow_fusion = getenv("GR_NO_TAIL_FUSION") == nullptr; // A/B switch for measurements
+	static const bool allow_fusion = gr_measurement_switch("GR_NO_TAIL_FUSION") == nullptr; // A/B switch for measurements
 	if (!allow_fusion || !is_rgba16f(d1) || !is_rgba16f(d2) || !is_rgba16f(d3) || !is_rgba16f(u2) || !is_rgba16f(u1))
 		return 0;
 	if (!push_d2 || !push_d3 || !push_u2 || !push_u1)
