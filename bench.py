@@ -172,7 +172,8 @@ def main():
         gbuf = synth.make_gbuffer(cam)
         descs = synth.make_lights(cam, num_lights, spot_fraction=0.25 if num_lights > 256 else 0.0)
         app = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True,
-                               compute_post=True, strip_index=rank if bands else 0, strip_count=world if bands else 1)
+                               compute_post=True, strip_index=rank if bands else 0, strip_count=world if bands else 1,
+                               output_gather_rgba=os.environ.get("GRANITE_BENCH_GATHER_RGBA", "0") == "1")
         app.set_render_parameters(cam.render_params())
         app.set_lights(descs)
         app.upload_gbuffer(gbuf)
@@ -339,7 +340,7 @@ def main():
         "config": {"workload": workload_name, "description": desc, "width": width, "height": height, "lights": num_lights,
                    "cluster_grid": list(synth.CLUSTER_RESOLUTION),
                    "parallelism": ("single" if world == 1 else
-                                   f"{world} row bands, RCCL all-gather of the 1/8 bloom level (in frame) and of the tonemapped bands "
+                                   f"{world} row bands, RCCL all-gather of the 1/8 bloom level (in frame) and of the tonemapped bands as RGB888 (alpha is constant: 3/4 of the bytes per xGMI link; GRANITE_BENCH_GATHER_RGBA=1 sends RGBA8) "
                                    f"({'in frame' if os.environ.get('GRANITE_BENCH_GATHER', 'beside') == 'inframe' else 'beside the frame, own stream + communicator'})" if bands else
                                    f"{world} independent replicas (row-band set-up failed: {fallback_reason})"),
                    "hdr_format": "R16G16B16A16_SFLOAT (fp16 storage, fp32 arithmetic)", "seed": synth.SEED,

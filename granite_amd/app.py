@@ -28,7 +28,7 @@ class Config(C.Structure):
                 ("strip_index", C.c_uint32), ("strip_count", C.c_uint32),
                 ("disable_image_aliasing", C.c_int32), ("depth_hierarchy", C.c_int32),
                 ("resolution_scale", C.c_float), ("resolution_scale_sharpen", C.c_int32), ("fsr_fp32", C.c_int32),
-                ("ambient_occlusion", C.c_int32), ("hdr10", C.c_int32), ("ssr", C.c_int32), ("aa_bench", C.c_int32)]
+                ("ambient_occlusion", C.c_int32), ("hdr10", C.c_int32), ("ssr", C.c_int32), ("aa_bench", C.c_int32), ("output_gather_rgba", C.c_int32)]
 
 
 # void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream)
@@ -139,7 +139,8 @@ class Application:
                  frame_time: float = synth.FRAME_TIME, timestamps: bool = False, strip_index: int = 0, strip_count: int = 1,
                  alias_images: bool = True, depth_hierarchy: int = 0,
                  resolution_scale: float = 1.0, resolution_scale_sharpen: bool = True, fsr_fp16: bool = True,
-                 ambient_occlusion: bool = False, hdr10: bool = False, ssr: bool = False, aa_bench: bool = False):
+                 ambient_occlusion: bool = False, hdr10: bool = False, ssr: bool = False, aa_bench: bool = False,
+                 output_gather_rgba: bool = False):
         self.lib = load_library()
         cfg = Config()
         cfg.device, cfg.width, cfg.height = device, width, height
@@ -160,6 +161,7 @@ class Application:
         cfg.hdr10 = int(hdr10)
         cfg.ssr = int(ssr)
         cfg.aa_bench = int(aa_bench)
+        cfg.output_gather_rgba = int(output_gather_rgba)
         if ssr:
             install_ssr_tables()
         self._exchange_ref = None

@@ -34,6 +34,63 @@ __global__ __launch_bounds__(256) void k_debug_mix(MixArgs a)
 }
 } // namespace
 
+// ---- 24-bit transport form of an RGBA8 target whose alpha is 255 everywhere ----------------------------------------------------
+// Row-band tiling sends every band of the finished frame to every other device (collective B); over point-to-point
+// xGMI that all-gather, not the kernels, bounds the multi-GPU frame rate, and the alpha byte of a tonemapped frame is a
+// constant.  Four pixels per lane: 16 B in / 12 B out (pack) and back (unpack, alpha = 255).
+__global__ __launch_bounds__(256) void k_pack_rgb8(const uint8_t *image, uint32_t pitch, uint32_t width, uint32_t row_first, uint32_t rows, uint8_t *packed)
+{
+	const uint32_t groups = (width + 3u) / 4u;
+	const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t y = row_first + blockIdx.y;
+	if (g >= groups || blockIdx.y >= rows)
+		return;
+	const uint8_t *src = image + size_t(y) * pitch + size_t(g) * 16u;
+	uint8_t *dst = packed + (size_t(y) * width + size_t(g) * 4u) * 3u;
+	if (g * 4u + 4u <= width && ((size_t(y) * width * 3u) & 3u) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0)
+	{
+		const uint4 p = *reinterpret_cast<const uint4 *>(src);
+		const uint32_t a = p.x & 0xffffffu, b = p.y & 0xffffffu, c = p.z & 0xffffffu, d = p.w & 0xffffffu;
+		uint32_t *out = reinterpret_cast<uint32_t *>(dst);
+		out[0] = a | (b << 24);
+		out[1] = (b >> 8) | (c << 16);
+		out[2] = (c >> 16) | (d << 8);
+	}
+	else
+		for (uint32_t i = 0; i < 4u && g * 4u + i < width; i++)
+			for (uint32_t ch = 0; ch < 3u; ch++)
+				dst[i * 3u + ch] = src[i * 4u + ch];
+}
+
+__global__ __launch_bounds__(256) void k_unpack_rgb8(const uint8_t *packed, uint8_t *image, uint32_t pitch, uint32_t width, uint32_t row_first, uint32_t rows)
+{
+	const uint32_t groups = (width + 3u) / 4u;
+	const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t y = row_first + blockIdx.y;
+	if (g >= groups || blockIdx.y >= rows)
+		return;
+	const uint8_t *src = packed + (size_t(y) * width + size_t(g) * 4u) * 3u;
+	uint8_t *dst = image + size_t(y) * pitch + size_t(g) * 16u;
+	if (g * 4u + 4u <= width && ((size_t(y) * width * 3u) & 3u) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0)
+	{
+		const uint32_t *in = reinterpret_cast<const uint32_t *>(src);
+		const uint32_t w0 = in[0], w1 = in[1], w2 = in[2];
+		uint4 p;
+		p.x = (w0 & 0xffffffu) | 0xff000000u;
+		p.y = (w0 >> 24) | ((w1 & 0xffffu) << 8) | 0xff000000u;
+		p.z = (w1 >> 16) | ((w2 & 0xffu) << 16) | 0xff000000u;
+		p.w = (w2 >> 8) | 0xff000000u;
+		*reinterpret_cast<uint4 *>(dst) = p;
+	}
+	else
+		for (uint32_t i = 0; i < 4u && g * 4u + i < width; i++)
+		{
+			for (uint32_t ch = 0; ch < 3u; ch++)
+				dst[i * 4u + ch] = src[i * 3u + ch];
+			dst[i * 4u + 3u] = 255;
+		}
+}
+
 extern "C" {
 
 int gr_abi_version(void)
@@ -340,6 +397,42 @@ int gr_fill_byte(gr_ctx *ctx, gr_stream stream, void *dst, int value, size_t byt
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, dst);
 	GR_CHECK_HIP(ctx, hipMemsetAsync(dst, value & 0xff, bytes, gr_to_stream(stream)));
+	return GR_OK;
+}
+
+static bool rgba8_target(const gr_image *image)
+{
+	return image && image->ptr && image->width && image->height && image->pitch_bytes >= image->width * 4u &&
+	       (image->format == GR_FORMAT_R8G8B8A8_SRGB || image->format == GR_FORMAT_R8G8B8A8_UNORM);
+}
+
+int gr_pack_rgb8_rows(gr_ctx *ctx, gr_stream stream, const gr_image *image, const gr_rows *rows, void *packed)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, rgba8_target(image) && packed && (reinterpret_cast<uintptr_t>(packed) & 3u) == 0);
+	const RowSpan span = resolve_rows(rows, image->height);
+	if (span.count() == 0)
+		return GR_OK;
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "pack_rgb8"};
+	hipLaunchKernelGGL(k_pack_rgb8, dim3(gr_div_up(gr_div_up(image->width, 4u), 256u), span.count()), dim3(256), 0, gr_to_stream(stream),
+	                   static_cast<const uint8_t *>(image->ptr), image->pitch_bytes, image->width, span.first, span.count(), static_cast<uint8_t *>(packed));
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_unpack_rgb8_rows(gr_ctx *ctx, gr_stream stream, const void *packed, const gr_image *image, const gr_rows *rows)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, rgba8_target(image) && packed && (reinterpret_cast<uintptr_t>(packed) & 3u) == 0);
+	const RowSpan span = resolve_rows(rows, image->height);
+	if (span.count() == 0)
+		return GR_OK;
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "unpack_rgb8"};
+	hipLaunchKernelGGL(k_unpack_rgb8, dim3(gr_div_up(gr_div_up(image->width, 4u), 256u), span.count()), dim3(256), 0, gr_to_stream(stream),
+	                   static_cast<const uint8_t *>(packed), static_cast<uint8_t *>(image->ptr), image->pitch_bytes, image->width, span.first, span.count());
+	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
 

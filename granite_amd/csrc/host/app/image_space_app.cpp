@@ -132,6 +132,45 @@ ImageSpaceApplication::~ImageSpaceApplication()
 		(void)hipEventDestroy(static_cast<hipEvent_t>(output_ready_event));
 }
 
+// ---- the frame's output bands on the wire --------------------------------------------------------------------------------------
+// Every rank ends up with every band of the finished frame (collective B).  Over point-to-point xGMI each rank's band
+// crosses one link per peer, and that -- 33 MB per 4K band and frame -- bounds the multi-GPU frame rate, not the kernels.  The
+// alpha byte of a tonemapped (or FXAA'd) frame is 255 everywhere, so the bands travel as RGB888: pack the own band, all-gather
+// the 24-bit buffer, unpack the other ranks' rows into the output image.  Three quarters of the bytes per link.
+bool ImageSpaceApplication::output_packs(const HIP::Image &image, const char *tag) const
+{
+	if (config.output_gather_rgba || !tag)
+		return false;
+	const bool output_tag = strcmp(tag, "tonemapped") == 0 || strcmp(tag, "fxaa") == 0; // alpha is written as 1.0 by both passes
+	const VkFormat format = image.get_format();
+	return output_tag && (format == VK_FORMAT_R8G8B8A8_SRGB || format == VK_FORMAT_R8G8B8A8_UNORM) && (image.get_view().pitch_bytes & 15u) == 0;
+}
+
+void ImageSpaceApplication::pack_output_band(HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows)
+{
+	auto &buffer = packed_output[image.get_device_pointer()];
+	const size_t bytes = size_t(strip_plan.count) * chunk_rows * image.get_width() * 3u;
+	if (!buffer || buffer->get_size() < bytes)
+		buffer = get_device().create_buffer(bytes, VK_BUFFER_USAGE_STORAGE_BUFFER_BIT, "packed-output");
+	gr_rows own = {strip_plan.index * chunk_rows, chunk_rows};
+	if (own.first < image.get_height())
+		cmd.check(gr_pack_rgb8_rows(cmd.get_context(), cmd.get_stream(), &image.get_view(), &own, buffer->get_device_pointer()), "pack_rgb8");
+}
+
+void ImageSpaceApplication::gather_packed_output(HIP::Image &image, uint32_t chunk_rows, void *stream, const BandTransport &transport)
+{
+	auto &buffer = packed_output[image.get_device_pointer()];
+	transport(buffer->get_device_pointer(), size_t(chunk_rows) * image.get_width() * 3u, stream);
+	auto *ctx = get_device().get_context();
+	const uint32_t first = std::min(strip_plan.index * chunk_rows, image.get_height());
+	const uint32_t end = std::min(first + chunk_rows, image.get_height());
+	const gr_rows above = {0, first}, below = {end, image.get_height() - end};
+	if (above.count && gr_unpack_rgb8_rows(ctx, stream, buffer->get_device_pointer(), &image.get_view(), &above) < 0)
+		throw std::runtime_error(gr_last_error(ctx));
+	if (below.count && gr_unpack_rgb8_rows(ctx, stream, buffer->get_device_pointer(), &image.get_view(), &below) < 0)
+		throw std::runtime_error(gr_last_error(ctx));
+}
+
 void ImageSpaceApplication::set_exchange_callback(gra_exchange_fn fn, void *user)
 {
 	if (!fn)
@@ -140,8 +179,16 @@ void ImageSpaceApplication::set_exchange_callback(gra_exchange_fn fn, void *user
 		return;
 	}
 	const uint32_t ranks = strip_plan.count;
-	strip_plan.exchange = [fn, user, ranks](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *tag) {
-		fn(user, tag, image.get_device_pointer(), uint64_t(chunk_rows) * image.get_view().pitch_bytes, ranks, cmd.get_stream());
+	strip_plan.exchange = [this, fn, user, ranks](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *tag) {
+		if (output_packs(image, tag))
+		{
+			pack_output_band(cmd, image, chunk_rows);
+			gather_packed_output(image, chunk_rows, cmd.get_stream(), [&](void *base, size_t chunk_bytes, void *stream) {
+				fn(user, tag, base, chunk_bytes, ranks, stream);
+			});
+		}
+		else
+			fn(user, tag, image.get_device_pointer(), uint64_t(chunk_rows) * image.get_view().pitch_bytes, ranks, cmd.get_stream());
 	};
 }
 
@@ -151,8 +198,15 @@ void ImageSpaceApplication::init_collective(const uint8_t *id128, int rank, int 
 		throw std::logic_error("Collective rank / size must match the strip plan of this instance.");
 	get_device().make_current(); // the communicator binds to the calling thread's current device
 	collective.init(id128, rank, ranks);
-	strip_plan.exchange = [this](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *) {
-		collective.all_gather_in_place(image.get_device_pointer(), size_t(chunk_rows) * image.get_view().pitch_bytes, cmd.get_stream());
+	strip_plan.exchange = [this](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *tag) {
+		if (output_packs(image, tag))
+		{
+			pack_output_band(cmd, image, chunk_rows);
+			gather_packed_output(image, chunk_rows, cmd.get_stream(),
+			                     [this](void *base, size_t chunk_bytes, void *stream) { collective.all_gather_in_place(base, chunk_bytes, stream); });
+		}
+		else
+			collective.all_gather_in_place(image.get_device_pointer(), size_t(chunk_rows) * image.get_view().pitch_bytes, cmd.get_stream());
 	};
 }
 
@@ -178,15 +232,22 @@ void ImageSpaceApplication::init_output_collective(const uint8_t *id128, int ran
 			if (hipStreamWaitEvent(static_cast<hipStream_t>(cmd.get_stream()), static_cast<hipEvent_t>(itr->second), 0) != hipSuccess)
 				throw std::runtime_error("hipStreamWaitEvent failed");
 	};
-	// ... and the gather itself runs on the collective stream behind the band's tonemap, beside whatever the executor's
+	// ... and the gather itself runs on the collective stream behind the band's last pass, beside whatever the executor's
 	// streams do next (the following frames' cluster build, lighting and bloom chain).
-	strip_plan.exchange_output = [this](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *) {
+	strip_plan.exchange_output = [this](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *tag) {
 		auto gather_stream = static_cast<hipStream_t>(get_device().get_collective_stream());
 		auto ready_event = static_cast<hipEvent_t>(output_ready_event);
+		const bool packs = output_packs(image, tag);
+		if (packs)
+			pack_output_band(cmd, image, chunk_rows); // behind the band's last pass, on its stream
 		if (hipEventRecord(ready_event, static_cast<hipStream_t>(cmd.get_stream())) != hipSuccess ||
 		    hipStreamWaitEvent(gather_stream, ready_event, 0) != hipSuccess)
 			throw std::runtime_error("output gather: event hand-over failed");
-		output_collective.all_gather_in_place(image.get_device_pointer(), size_t(chunk_rows) * image.get_view().pitch_bytes, gather_stream);
+		const BandTransport rccl = [this](void *base, size_t chunk_bytes, void *stream) { output_collective.all_gather_in_place(base, chunk_bytes, stream); };
+		if (packs)
+			gather_packed_output(image, chunk_rows, gather_stream, rccl);
+		else
+			rccl(image.get_device_pointer(), size_t(chunk_rows) * image.get_view().pitch_bytes, gather_stream);
 		void *&done = output_gather_done[image.get_device_pointer()];
 		if (!done)
 		{

@@ -5,6 +5,7 @@
 // (application/scene_viewer_application.cpp:876-991,1167-1318); the frame loop follows render_frame (:1540-1611) and the
 // headless platform's external 4-image swapchain (application/platforms/application_headless.cpp:145-148,207-229).
 #pragma once
+#include <functional>
 #include <memory>
 #include <unordered_map>
 #include <unordered_set>
@@ -96,6 +97,12 @@ private:
 	HIP::Collective collective, output_collective;
 	// per output image: the event its last beside-the-frame gather records on the collective stream
 	std::unordered_map<const void *, void *> output_gather_done;
+	// 24-bit transport form of the output bands (one buffer per output image, rank_count * chunk_rows rows of width * 3 bytes)
+	std::unordered_map<const void *, HIP::BufferHandle> packed_output;
+	using BandTransport = std::function<void(void *base, size_t chunk_bytes, void *stream)>;
+	bool output_packs(const HIP::Image &image, const char *tag) const;
+	void pack_output_band(HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows);
+	void gather_packed_output(HIP::Image &image, uint32_t chunk_rows, void *stream, const BandTransport &transport);
 	void *output_ready_event = nullptr;
 	TemporalJitter jitter;
 	mat4 base_projection, base_view;

@@ -88,6 +88,10 @@ typedef struct gra_config
 	 * SMAA) follows, and with 0 < resolution_scale < 1 FSR 1.0 (+ sharpen) ends the frame.  Identity camera matrices feed the
 	 * temporal jitter (aa_bench.cpp:52), timestamps are on.  enable_lighting and hdr_bloom must be 0. */
 	int32_t aa_bench;
+	/* Row bands: the finished frame's bands meet in every rank's output image as RGB888 (packed before, unpacked after the
+	 * all-gather; the alpha byte of a tonemapped / FXAA'd frame is 255) -- 3/4 of the bytes per xGMI link.  1 = send the RGBA8 rows
+	 * as they are (A/B).  An SMAA output always travels as RGBA8. */
+	int32_t output_gather_rgba;
 } gra_config;
 
 /* Scene-level light description (one PositionalLight + its node transform). */

@@ -369,6 +369,13 @@ typedef struct gr_lighting_args
 } gr_lighting_args;
 int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args);
 
+/* 24-bit transport form of an RGBA8 target whose alpha byte is 255 everywhere (a tonemapped frame): the row-band executor
+ * all-gathers its finished bands in this form (3/4 of the bytes over xGMI) and restores the RGBA8 rows on arrival.  `packed` is a
+ * width x height x 3 byte image (row y at y * width * 3); *_rows restrict the rows as everywhere else (16-byte accesses where pitch, base and
+ * width allow, bytes otherwise).  No reference counterpart (Granite renders a frame on one device). */
+int gr_pack_rgb8_rows(gr_ctx *ctx, gr_stream stream, const gr_image *image, const gr_rows *rows, void *packed);
+int gr_unpack_rgb8_rows(gr_ctx *ctx, gr_stream stream, const void *packed, const gr_image *image, const gr_rows *rows);
+
 /* builtin://shaders/blit.frag over a full-screen quad (FragColor = textureLod(uTex, vUV, 0)): the copy between targets of
  * different size / format that Granite's tools record (tools/aa_bench.cpp:97-105 into the HDR target with LinearClamp,
  * :138-147 into the swapchain with NearestClamp).  in / out: R16G16B16A16_SFLOAT, R8G8B8A8_UNORM or R8G8B8A8_SRGB (decoded on

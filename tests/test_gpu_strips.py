@@ -205,3 +205,48 @@ def test_output_gather_beside_the_frame_gives_the_same_frames():
     with pytest.raises(capi.GraniteHipError):
         b.comm_init_output(gapp.Application.comm_create_unique_id(), 0, 1)
     b.close()
+
+
+@pytest.mark.parametrize("w,h", [(64, 16), (333, 21), (3840, 9), (6, 5)])
+def test_rgb888_transport_form_round_trips(w, h):
+    """gr_pack_rgb8_rows / gr_unpack_rgb8_rows: the 24-bit form the output bands travel in.  Packing rows [a, b) and unpacking them
+    into another image restores exactly those rows with alpha 255 and touches nothing else."""
+    gr = capi.Context(0)
+    lib = gr.lib
+    lib.gr_pack_rgb8_rows.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(capi.Image), C.POINTER(capi.Rows), C.c_void_p]
+    lib.gr_unpack_rgb8_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(capi.Image), C.POINTER(capi.Rows)]
+    rng = np.random.default_rng(w * 131 + h)
+    src = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    src[..., 3] = 255
+    image = capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8B8A8_SRGB).upload(src)
+    other = capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8B8A8_SRGB).upload(np.full((h, w, 4), 7, np.uint8))
+    packed = capi.DeviceBuffer(gr, w * h * 3)
+    first, count = h // 3, max(h // 2, 1)
+    rows = capi.Rows(first, count)
+    gr.check(lib.gr_pack_rgb8_rows(gr.handle, None, image.desc, rows, packed.ptr))
+    gr.check(lib.gr_unpack_rgb8_rows(gr.handle, None, packed.ptr, other.desc, rows))
+    gr.sync()
+    got = other.download()
+    np.testing.assert_array_equal(got[first:first + count], src[first:first + count])
+    assert (got[:first] == 7).all() and (got[first + count:] == 7).all()
+    raw = packed.download(np.uint8).reshape(h, w, 3)
+    np.testing.assert_array_equal(raw[first:first + count], src[first:first + count, :, :3])
+
+
+def test_packed_and_rgba_output_gathers_give_the_same_frames():
+    """The finished bands travel as RGB888 by default (gra_config.output_gather_rgba = 0); sending the RGBA8 rows instead must not
+    change a byte of any rank's frame."""
+    world, w, h, frames = 3, 332, 250, 3
+    cam = synth.Camera(w, h)
+    gbuf = synth.make_gbuffer(cam)
+    descs = synth.make_lights(cam, 128)
+    results = []
+    for rgba in (False, True):
+        got, plans = run_emulated_ranks(world, frames, lambda **strip: make_app(w, h, cam, gbuf, descs, output_gather_rgba=rgba, **strip), [])
+        results.append(got)
+    for rank in range(world):
+        for f in range(frames):
+            np.testing.assert_array_equal(results[0][rank][f][0], results[1][rank][f][0])
+            assert (results[0][rank][f][0][..., 3] == 255).all()
+    for rank in range(1, world):
+        np.testing.assert_array_equal(results[0][rank][-1][0], results[0][0][-1][0])
