@@ -214,6 +214,26 @@ def main():
     plan = application.strip_plan()
     kctx = application.kernel_context()
 
+    # ---- outside the timed region: the frame the bands assembled (4 set-up frames so far) against the same frames of ONE executor
+    # rendering the whole target on rank 0's GPU -- every byte of the backbuffer must agree (GRANITE_BENCH_CHECK_BANDS=0 skips it).
+    bands_checked = None
+    if bands and os.environ.get("GRANITE_BENCH_CHECK_BANDS", "1") == "1":
+        verdict = torch.tensor([1], dtype=torch.int32)
+        if rank == 0:
+            try:
+                whole = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True, compute_post=True)
+                whole.set_render_parameters(cam.render_params())
+                whole.set_lights(descs)
+                whole.upload_gbuffer(gbuf)
+                whole.render_frames(4, sync=True)
+                verdict[0] = int(np.array_equal(whole.read_backbuffer(), application.read_backbuffer()))
+                whole.close()
+            except Exception as e:  # noqa: BLE001 - e.g. not enough HBM for the whole frame beside the band
+                print(f"[bench] band check not possible: {type(e).__name__}: {e}", file=sys.stderr)
+                verdict[0] = -1
+        dist.broadcast(verdict, src=0)
+        bands_checked = None if int(verdict.item()) < 0 else bool(int(verdict.item()))
+
     def barrier():
         torch.cuda.synchronize()
         application.sync()
@@ -354,6 +374,9 @@ def main():
         "kernels_warmup": warm_breakdown,
         "host_busy_ms_per_step": 1000.0 * host_busy / args.steps,
     }
+    if bands:
+        # the assembled frame == the same frames of one executor rendering the whole target (null = check skipped / not possible)
+        result["bands_checked"] = bands_checked
     if sustained:
         sustained["value"] = pixels_per_step * sustained["steps"] / sustained["seconds"] / 1e6
         sustained["unit"] = "Mpixels/s"

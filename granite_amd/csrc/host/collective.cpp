@@ -1,4 +1,6 @@
 #include "collective.hpp"
+#include <cstdio>
+#include <cstdlib>
 #include <dlfcn.h>
 #include <mutex>
 #include <stdexcept>
@@ -30,7 +32,17 @@ const Api &api()
 	static Api table;
 	static std::once_flag once;
 	std::call_once(once, []() {
-		void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+		void *lib = nullptr;
+		if (const char *other = getenv("GRANITE_RCCL_LIBRARY"))
+		{
+			// Another implementation of the same five entry points (tests/rccl_shim: several ranks on ONE GPU, which RCCL refuses).
+			fprintf(stderr, "[granite-hip] note: collectives go through %s (GRANITE_RCCL_LIBRARY), not librccl.so.1\n", other);
+			lib = dlopen(other, RTLD_NOW | RTLD_LOCAL);
+			if (!lib)
+				throw std::runtime_error(std::string("cannot load GRANITE_RCCL_LIBRARY: ") + dlerror());
+		}
+		if (!lib)
+			lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
 		if (!lib)
 			lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
 		if (!lib)
