@@ -24,6 +24,11 @@ WORKLOADS = {
     # name: (width, height, lights, description)
     "config3_4k_4096lights": (3840, 2160, 4096, "3840x2160, 4096 clustered point+spot lights, bloom pyramid + luminance + tonemap"),
     "config2_1080p_256lights": (1920, 1080, 256, "1920x1080, 256 point lights, full light+post chain"),
+    # BASELINE config 1 (the reference's own CPU-runnable case): no lighting pass, HDR input -> bloom-compute -> tonemap
+    "config1_256_post_only": (256, 256, 0, "256x256 HDR input, bloom pyramid + luminance + tonemap (no lighting pass)"),
+    # BASELINE config 4: config 3 + TAA High in front of the post chain (previous-frame history) + SMAA Ultra behind the tonemap
+    "config4_4k_smaa_taa": (3840, 2160, 4096, "3840x2160, 4096 clustered point+spot lights, TAA High (history feedback edge) + bloom pyramid + "
+                                              "luminance + tonemap + SMAA Ultra; static camera under the 16-phase TAA jitter, motion vectors 0 with a constant-motion region"),
     # BASELINE config 5 as stated: ONE 7680x4320 frame tiled into --gpus row bands (strong scaling; 1 GPU renders it whole)
     "config5_8k": (7680, 4320, 4096, "7680x4320 screen-tiled across the GPUs, 4096 clustered point+spot lights, bloom pyramid + luminance + tonemap"),
 }
@@ -37,6 +42,9 @@ ALGO_BYTES_PER_PX = {
     "tonemap": 8.5 + 4.0,
     "chain": 56.66,
 }
+# SURVEY 8d table rows for the other configurations: post only 26.7 B/px; + SMAA (3 passes) 14 + 12; + TAA (RGBA16F everywhere) 24 + 16
+CHAIN_BYTES_PER_PX = {"config1_256_post_only": 26.7, "config4_4k_smaa_taa": 56.66 + 26.0 + 40.0}
+SINGLE_GPU_WORKLOADS = {"config1_256_post_only", "config4_4k_smaa_taa"}  # not tiled by bench.py: N ranks run N replicas
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy); the run measures its own too
 VALU_SIMDS, VALU_CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 2.0  # 256 CUs x 4 SIMD-32, max clock, wave64 fp32 op
 BRACKET_EVERY = 8  # the dominant kernel keeps its hipEvent bracket on every 8th launch of the timed region (fewer steps: >= 5 brackets)
@@ -171,12 +179,23 @@ def main():
         cam = synth.Camera(width, height)
         gbuf = synth.make_gbuffer(cam)
         descs = synth.make_lights(cam, num_lights, spot_fraction=0.25 if num_lights > 256 else 0.0)
-        app = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True,
-                               compute_post=True, strip_index=rank if bands else 0, strip_count=world if bands else 1,
-                               output_gather_rgba=os.environ.get("GRANITE_BENCH_GATHER_RGBA", "0") == "1")
-        app.set_render_parameters(cam.render_params())
-        app.set_lights(descs)
-        app.upload_gbuffer(gbuf)
+        strips = dict(strip_index=rank if bands else 0, strip_count=world if bands else 1,
+                      output_gather_rgba=os.environ.get("GRANITE_BENCH_GATHER_RGBA", "0") == "1")
+        if args.workload == "config1_256_post_only":
+            app = gapp.Application(width, height, device=local_rank, lighting=False, hdr_bloom=True, dynamic_exposure=True, compute_post=True)
+            app.upload_hdr(gbuf["emissive"])
+        elif args.workload == "config4_4k_smaa_taa":
+            app = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True, compute_post=True,
+                                   pre_aa=gapp.POST_AA_TAA_HIGH, post_aa=gapp.POST_AA_SMAA_ULTRA)
+            app.set_camera(np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16))
+            app.set_lights(descs)
+            app.upload_gbuffer(gbuf, synth.make_motion_vectors(width, height))
+        else:
+            app = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True,
+                                   compute_post=True, **strips)
+            app.set_render_parameters(cam.render_params())
+            app.set_lights(descs)
+            app.upload_gbuffer(gbuf)
         if bands:
             # two RCCL communicators: the 1/8 bloom level meets inside the frame (on the executor's stream), the tonemapped
             # bands beside it (their own stream; GRANITE_BENCH_GATHER=inframe keeps them in the frame for an A/B)
@@ -191,7 +210,7 @@ def main():
         app.render_frames(4, sync=True)
         return app, cam, gbuf, descs, width, height, desc, name
 
-    bands = world > 1 and os.environ.get("GRANITE_BENCH_MULTI", "bands") != "replicas"
+    bands = world > 1 and os.environ.get("GRANITE_BENCH_MULTI", "bands") != "replicas" and args.workload not in SINGLE_GPU_WORKLOADS
     fallback_reason = None
     if bands:
         # Every rank must end up in the same mode: agree on success through the control plane.
@@ -343,7 +362,7 @@ def main():
                                               "class_histogram": entry.get("valu_class_histogram")}
         except (OSError, KeyError, ValueError):
             pass
-    chain_bytes = ALGO_BYTES_PER_PX["chain"] * width * height
+    chain_bytes = CHAIN_BYTES_PER_PX.get(args.workload, ALGO_BYTES_PER_PX["chain"]) * width * height
     chain_gbs = chain_bytes * args.steps / elapsed / 1e9
 
     result = {
@@ -364,10 +383,13 @@ def main():
                    "parallelism": ("single" if world == 1 else
                                    f"{world} row bands, RCCL all-gather of the 1/8 bloom level (in frame) and of the tonemapped bands as RGB888 (alpha is constant: 3/4 of the bytes per xGMI link; GRANITE_BENCH_GATHER_RGBA=1 sends RGBA8) "
                                    f"({'in frame' if os.environ.get('GRANITE_BENCH_GATHER', 'beside') == 'inframe' else 'beside the frame, own stream + communicator'})" if bands else
-                                   f"{world} independent replicas (row-band set-up failed: {fallback_reason})"),
+                                   f"{world} independent replicas ({'this workload is not tiled by bench.py' if args.workload in SINGLE_GPU_WORKLOADS else f'row-band set-up failed: {fallback_reason}'})"),
                    "hdr_format": "R16G16B16A16_SFLOAT (fp16 storage, fp32 arithmetic)", "seed": synth.SEED,
-                   "timed_region": "cluster build + per-frame light refresh + lighting + bloom pyramid + luminance + tonemap, every frame; "
-                                   "the synthetic G-buffer is resident in HBM (its production is outside the path, as in the reference)"},
+                   "timed_region": {"config1_256_post_only": "bloom pyramid + luminance + tonemap, every frame; the HDR input is resident in HBM",
+                                    "config4_4k_smaa_taa": "cluster build + per-frame light refresh + lighting + TAA resolve + bloom pyramid + luminance + "
+                                                           "tonemap + SMAA (edges, weights, blend), every frame; the synthetic G-buffer is resident in HBM"}.get(
+                       args.workload, "cluster build + per-frame light refresh + lighting + bloom pyramid + luminance + tonemap, every frame; "
+                                      "the synthetic G-buffer is resident in HBM (its production is outside the path, as in the reference)")},
         "roofline": roofline,
         "chain": {"algorithmic_GBps": chain_gbs, "frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS,
                   "algorithmic_bytes_per_frame": chain_bytes},
@@ -382,7 +404,7 @@ def main():
         sustained["unit"] = "Mpixels/s"
         result["sustained"] = sustained
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload not in SINGLE_GPU_WORKLOADS:
         rows = args.cpu_sample_rows or height  # whole frame: ~4 s on a 256-thread host, ~20 s on 8 cores
         reference, result["cpu_baseline"] = cpu_baseline(cam, gbuf, descs, width, height, rows)
         # the frame the baseline just rendered is what the GPU frame is compared with (outside the timed region)
@@ -396,7 +418,8 @@ def main():
     else:
         result["cpu_baseline"] = None
         result["parity_checked"] = False
-        result["parity_detail"] = {"reason": "no CPU baseline in this run (multi-GPU rank or --no-cpu-baseline)"}
+        result["parity_detail"] = {"reason": "no CPU baseline in this run (multi-GPU rank, --no-cpu-baseline, or a workload whose oracle comparison "
+                                             "lives in tests/test_gpu_fullsize.py: config 1 / config 4)"}
 
     application.close()
     if dist is not None:
