@@ -152,6 +152,16 @@ def test_upload_batch_writes_every_range(gr):
 # GPU box's host cores, so configs 3 and 4 of BASELINE.json are compared with it directly, at full size.
 
 def test_config3_frame_matches_oracle_at_4k():
+    check_frame_against_oracle(W, H, "4K")
+
+
+def test_config5_frame_whole_on_one_gpu_matches_oracle_at_8k():
+    """BASELINE config 5's 7680x4320 frame rendered whole by one executor (what every rank's bands must assemble to,
+    tests/test_gpu_strips.py, and bench.py's bands_checked reference), against the oracle: 33 M pixels, 265 MB HDR target."""
+    check_frame_against_oracle(7680, 4320, "8K")
+
+
+def check_frame_against_oracle(W, H, tag):
     """BASELINE config 3 through the executor (3840x2160, 4096 clustered point + spot lights, bloom pyramid + luminance +
     tonemap) against the oracle: cluster bitmask / ranges bit-exact, HDR-main, threshold, downsample-3, upsample-0 at the
     stated fp16 tolerances, backbuffer +-1 LSB.  Exercises what only exists at this size: the XCD-banded block order,
@@ -175,7 +185,7 @@ def test_config3_frame_matches_oracle_at_4k():
     hdr = a.read("HDR-main").copy()
     # SURVEY 8a's tolerance as written: 2 ulp fp16 + 1e-4 (measured at this size, tools/ulp_hist.py: 99.97 % of the
     # channels bit-identical, 3e-4 one ulp apart, 2 of 24.9 M further -- both below the absolute term)
-    assert_rgba16f_close(hdr, ref["hdr"], ulps=2.0, what="4K HDR-main")
+    assert_rgba16f_close(hdr, ref["hdr"], ulps=2.0, what=f"{tag} HDR-main")
     assert (hdr == ref["hdr"]).mean() > 0.999
     # The post chain is checked stage by stage on the DEVICE's lit HDR target (the log-luminance channel of the threshold
     # level is log2 of a value near 1 wherever the scene is near exposure: a one-ulp difference of a lit texel moves it by
@@ -183,12 +193,22 @@ def test_config3_frame_matches_oracle_at_4k():
     state, chain = {}, None
     for _ in range(frames):
         chain = orc.hdr_chain(hdr, state)
-    assert_rgba16f_close(a.read("threshold"), chain["threshold"], ulps=2.0, what="4K threshold")
+    assert_rgba16f_close(a.read("threshold"), chain["threshold"], ulps=2.0, what=f"{tag} threshold")
     for res, key in {"downsample-3": "d3", "upsample-0": "u0"}.items():
         # rounding differences of the levels above are carried down and up the pyramid: 4 ulp + 2e-4
-        assert_rgba16f_close(a.read(res), chain[key], ulps=4.0, abs_tol=2e-4, what=f"4K {res}")
+        assert_rgba16f_close(a.read(res), chain[key], ulps=4.0, abs_tol=2e-4, what=f"{tag} {res}")
     np.testing.assert_allclose(a.read("average-luminance").view(np.float32)[0], chain["lum"][0], atol=2e-5)
-    assert_rgba8_close(a.read_backbuffer(), chain["tonemapped"], 1, what="4K backbuffer")
+    got, want = a.read_backbuffer(), chain["tonemapped"]
+    if W <= 4096:
+        assert_rgba8_close(got, want, 1, what=f"{tag} backbuffer")
+    else:
+        # tonemap.frag takes its HDR colour through LinearClamp at the pixel centre.  The oracle's sampler has exact fp32
+        # weights, and past column 4096 the centre (x + 0.5) / w * w - 0.5 is no longer representable: up to 1e-3 of the
+        # neighbouring texel leaks into the sample (hardware samplers, with their 8-bit weights, and the kernel fetch the texel
+        # itself).  Beside one of the scene's 2^8 "hot" pixels that leak is a quarter of a unit, i.e. a second LSB near white:
+        # 2 of 132.7 M bytes at this size (measured).  Everything else stays within +-1 LSB.
+        diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert diff.max() <= 2 and (diff > 1).sum() <= 16, ((diff > 1).sum(), diff.max())
     a.close()
 
 
