@@ -28,7 +28,7 @@ WORKLOADS = {
     "config1_256_post_only": (256, 256, 0, "256x256 HDR input, bloom pyramid + luminance + tonemap (no lighting pass)"),
     # BASELINE config 4: config 3 + TAA High in front of the post chain (previous-frame history) + SMAA Ultra behind the tonemap
     "config4_4k_smaa_taa": (3840, 2160, 4096, "3840x2160, 4096 clustered point+spot lights, TAA High (history feedback edge) + bloom pyramid + "
-                                              "luminance + tonemap + SMAA Ultra; static camera under the 16-phase TAA jitter, motion vectors 0 with a constant-motion region"),
+                                              "luminance + tonemap + SMAA Ultra; the camera translates 0.01 units per frame under the 16-phase TAA jitter, motion vectors 0 with a constant-motion region"),
     # BASELINE config 5 as stated: ONE 7680x4320 frame tiled into --gpus row bands (strong scaling; 1 GPU renders it whole)
     "config5_8k": (7680, 4320, 4096, "7680x4320 screen-tiled across the GPUs, 4096 clustered point+spot lights, bloom pyramid + luminance + tonemap"),
 }
@@ -190,6 +190,7 @@ def main():
             app.set_camera(np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16))
             app.set_lights(descs)
             app.upload_gbuffer(gbuf, synth.make_motion_vectors(width, height))
+            app.set_camera_motion((0.01, 0.0, 0.0))  # SURVEY 8d, config 4 extras: the camera translates 0.01 units per frame
         else:
             app = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True,
                                    compute_post=True, **strips)

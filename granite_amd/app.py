@@ -53,7 +53,7 @@ class Timestamp(C.Structure):
 
 
 EXPORTED_SYMBOLS = [
-    "gra_create", "gra_destroy", "gra_last_error", "gra_set_camera", "gra_set_render_parameters",
+    "gra_create", "gra_destroy", "gra_last_error", "gra_set_camera", "gra_set_camera_motion", "gra_set_render_parameters",
     "gra_get_render_parameters", "gra_set_lights", "gra_upload_gbuffer", "gra_render_frames", "gra_sync",
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
@@ -79,6 +79,7 @@ def load_library() -> C.CDLL:
         "gra_destroy": (None, [vp]),
         "gra_last_error": (C.c_char_p, [vp]),
         "gra_set_camera": (C.c_int, [vp, vp, vp]),
+        "gra_set_camera_motion": (C.c_int, [vp, vp]),
         "gra_set_render_parameters": (C.c_int, [vp, vp]),
         "gra_get_render_parameters": (C.c_int, [vp, vp]),
         "gra_set_lights": (C.c_int, [vp, vp, C.c_uint32]),
@@ -201,6 +202,12 @@ class Application:
     def set_camera(self, projection16, view16):
         p, v = np.ascontiguousarray(projection16, np.float32), np.ascontiguousarray(view16, np.float32)
         self._check(self.lib.gra_set_camera(self.handle, p.ctypes.data, v.ctypes.data))
+
+    def set_camera_motion(self, translation):
+        """The eye moves by `translation` (world units) every frame from now on; (0, 0, 0) stops it."""
+        t = np.ascontiguousarray(translation, np.float32)
+        assert t.size == 3
+        self._check(self.lib.gra_set_camera_motion(self.handle, t.ctypes.data))
 
     def get_render_parameters(self) -> np.ndarray:
         out = np.zeros(104, np.float32)

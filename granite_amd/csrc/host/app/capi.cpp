@@ -106,6 +106,15 @@ int gra_set_camera(gra_app *app, const float *projection16, const float *view16)
 	});
 }
 
+int gra_set_camera_motion(gra_app *app, const float translation[3])
+{
+	return guarded(app, [&]() {
+		if (!translation)
+			throw std::logic_error("gra_set_camera_motion: null translation");
+		app->app->set_camera_motion(vec3(translation[0], translation[1], translation[2]));
+	});
+}
+
 int gra_set_render_parameters(gra_app *app, const float *f)
 {
 	return guarded(app, [&]() {

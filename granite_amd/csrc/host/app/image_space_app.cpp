@@ -269,6 +269,15 @@ void ImageSpaceApplication::set_base_camera(const mat4 &projection, const mat4 &
 	context.set_camera(projection, view);
 }
 
+void ImageSpaceApplication::set_camera_motion(const vec3 &translation_per_frame)
+{
+	if (!has_base_camera)
+		throw std::logic_error("Camera motion needs gra_set_camera (projection + view), not verbatim render parameters.");
+	camera_motion = translation_per_frame;
+	camera_moves = translation_per_frame.x != 0.0f || translation_per_frame.y != 0.0f || translation_per_frame.z != 0.0f;
+	cluster.invalidate_prefetch();
+}
+
 mat4 ImageSpaceApplication::get_taa_reprojection() const
 {
 	return translate(vec3(0.5f, 0.5f, 0.0f)) * scale(vec3(0.5f, 0.5f, 1.0f)) * jitter.get_history_view_proj(1) * jitter.get_history_inv_view_proj(0);
@@ -740,6 +749,8 @@ void ImageSpaceApplication::render_frame()
 	HIP::Image *backbuffer = swapchain[swapchain_index].get();
 	swapchain_index = (swapchain_index + 1) % unsigned(swapchain.size());
 
+	if (camera_moves)
+		base_view = base_view * translate(-camera_motion); // the eye moves by +motion: view' = view * T(-motion)
 	if (jitter.get_jitter_type() != TemporalJitter::Type::None)
 	{
 		if (!has_base_camera)
@@ -747,6 +758,8 @@ void ImageSpaceApplication::render_frame()
 		jitter.step(base_projection, base_view);
 		context.set_camera(jitter.get_jittered_projection(), base_view);
 	}
+	else if (camera_moves)
+		context.set_camera(base_projection, base_view);
 
 	graph.setup_attachments(device, backbuffer);
 	if (config.enable_lighting)
@@ -759,12 +772,19 @@ void ImageSpaceApplication::render_frame()
 		// Sort + pack of the NEXT frame's lights on the clusterer's helper threads while this frame is enqueued below, with the
 		// parameters that frame is going to use (the next jitter phase when a temporal AA is active).  A camera or light
 		// change in between simply makes the next refresh() pack on this thread as before.
+		const mat4 next_view = camera_moves ? base_view * translate(-camera_motion) : base_view;
 		if (jitter.get_jitter_type() != TemporalJitter::Type::None && has_base_camera)
 		{
 			TemporalJitter next_jitter = jitter;
-			next_jitter.step(base_projection, base_view);
+			next_jitter.step(base_projection, next_view);
 			RenderContext next_context = context;
-			next_context.set_camera(next_jitter.get_jittered_projection(), base_view);
+			next_context.set_camera(next_jitter.get_jittered_projection(), next_view);
+			cluster.prefetch(next_context.get_render_parameters());
+		}
+		else if (camera_moves)
+		{
+			RenderContext next_context = context;
+			next_context.set_camera(base_projection, next_view);
 			cluster.prefetch(next_context.get_render_parameters());
 		}
 		else

@@ -75,6 +75,7 @@ public:
 	}
 	// G-buffer attachments from .gtx files (any may be null); the frame written back as .gtx.
 	void upload_gbuffer_gtx(const char *const paths[6]);
+	void set_camera_motion(const vec3 &translation_per_frame);
 	void upload_ambient_occlusion(const void *ao_r8);
 	void upload_aa_bench_images(const void *first, const void *second, uint32_t width, uint32_t height);
 	void save_image_gtx(HIP::Image &image, const std::string &path);
@@ -113,6 +114,8 @@ private:
 	std::vector<mat_affine> light_transforms;
 	PositionalLightList light_list;
 	HIP::ImageHandle src_emissive, src_albedo, src_normal, src_pbr, src_depth, src_mv, src_ao;
+	vec3 camera_motion = vec3(0.0f); // eye translation per frame (world units)
+	bool camera_moves = false;
 	HIP::ImageHandle bench_images[2]; // aa_bench: the two input images, alternating per frame
 	unsigned bench_input_index = 0;
 	void add_aa_bench_main_pass(const std::string &tag);

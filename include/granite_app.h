@@ -115,6 +115,10 @@ const char *gra_last_error(gra_app *app);
 
 /* RenderContext::set_camera(projection, view): derives inverses etc. on the host like the reference. */
 int gra_set_camera(gra_app *app, const float *projection16, const float *view16);
+/* The eye moves by `translation` (world units) every frame, applied to the view matrix of gra_set_camera before each frame
+ * (BASELINE config 4: "camera translates 0.01 units/frame" -- the TAA reprojection and the cluster build then really change from
+ * frame to frame).  (0, 0, 0) = a static camera.  Needs gra_set_camera. */
+int gra_set_camera_motion(gra_app *app, const float translation[3]);
 /* Installs precomputed parameters verbatim (so that the CPU oracle and the device see bit-identical inputs). */
 int gra_set_render_parameters(gra_app *app, const float *params104);
 int gra_get_render_parameters(gra_app *app, float *params104);

@@ -244,3 +244,46 @@ def test_light_refresh_done_ahead_by_the_helper_thread_is_the_same_refresh(scene
     np.testing.assert_array_equal(st3["params"], ref3["prm"].view(np.uint8).reshape(-1))
     np.testing.assert_array_equal(st3["lights"][:ref3["n"] * 48], ref3["lights"].view(np.uint8)[:ref3["n"] * 48])
     a.close()
+
+
+def test_camera_motion_equals_explicit_parameters_and_keeps_the_light_prefetch():
+    """gra_set_camera_motion (BASELINE config 4: the camera translates every frame): each frame's render parameters, read back and
+    installed verbatim in a second executor, give the same frame bit for bit; the parameters really move; and the clusterer's
+    one-frame-ahead light refresh keeps predicting the right camera (no frame falls back to packing on the submitting thread)."""
+    w, h, frames = 480, 270, 6
+    cam = synth.Camera(w, h)
+    gbuf = synth.make_gbuffer(cam)
+    descs = synth.make_lights(cam, 600)
+    P, V = np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16)
+    a = gapp.Application(w, h)
+    a.set_camera(P, V)
+    a.set_lights(descs)
+    a.upload_gbuffer(gbuf)
+    a.set_camera_motion((0.01, 0.0, 0.004))
+    b = gapp.Application(w, h)
+    b.set_lights(descs)
+    b.upload_gbuffer(gbuf)
+    params = []
+    for f in range(frames):
+        a.render_frames(1)
+        rp = a.get_render_parameters()
+        params.append(rp.copy())
+        b.set_render_parameters(rp)
+        b.render_frames(1)
+        np.testing.assert_array_equal(a.read("HDR-main"), b.read("HDR-main"), err_msg=f"frame {f}: lit target")
+        np.testing.assert_array_equal(a.read_backbuffer(), b.read_backbuffer(), err_msg=f"frame {f}: backbuffer")
+    eye = np.array([p[96:99] for p in params])   # camera_position
+    np.testing.assert_allclose(np.diff(eye, axis=0), np.tile([0.01, 0.0, 0.004], (frames - 1, 1)), atol=2e-6)
+    assert a.prefetched_refreshes() >= frames - 1
+    a.close()
+    b.close()
+
+    # with a temporal resolve: the jittered, moving camera still runs with every refresh prefetched
+    c = gapp.Application(w, h, pre_aa=gapp.POST_AA_TAA_HIGH)
+    c.set_camera(P, V)
+    c.set_lights(descs)
+    c.upload_gbuffer(gbuf, synth.make_motion_vectors(w, h))
+    c.set_camera_motion((0.01, 0.0, 0.0))
+    c.render_frames(8)
+    assert c.prefetched_refreshes() >= 7
+    c.close()
