@@ -37,6 +37,19 @@ def assert_rgba16f_close(a_bits, b_bits, ulps=2.0, abs_tol=1e-4, what=""):
                              f"({ulps} ulp fp16 + {abs_tol}); first at {tuple(idx)}: {a} vs {b}")
 
 
+def assert_rgba16f_close_but_for_ill_conditioned_pixels(a_bits, b_bits, ulps=2.0, abs_tol=1e-4, max_pixels=4, outer_ulps=16.0, what=""):
+    """The stated tolerance everywhere except at up to `max_pixels` pixels, which must still be within `outer_ulps`.  For lit
+    frames of millions of pixels under a moving camera: a surface seen edge-on (N.V at its 0.001 clamp) with a light almost
+    exactly behind it along the view ray (|V + L| -> 0) has a condition number of ~1e4 in its specular term -- one rounding of
+    fp32 in the half vector is a per-mille of the pixel; two correct fp32 evaluations differ there."""
+    bad = rgba16f_mismatch(a_bits, b_bits, ulps, abs_tol)
+    pixels = bad.any(axis=-1).sum()
+    if pixels > max_pixels:
+        raise AssertionError(f"{what}: {pixels} pixels out of tolerance ({ulps} ulp fp16 + {abs_tol}); at most {max_pixels} ill-conditioned ones are expected")
+    if pixels:
+        assert_rgba16f_close(a_bits, b_bits, outer_ulps, abs_tol, what=what + " (ill-conditioned pixels)")
+
+
 def assert_rgba8_close(a, b, lsb=1, what=""):
     d = np.abs(np.asarray(a, np.int16) - np.asarray(b, np.int16))
     if (d > lsb).any():
