@@ -597,6 +597,13 @@ int gr_timing_set_filter(gr_ctx *ctx, const char *name)
 	return GR_OK;
 }
 
+int gr_timing_brackets(gr_ctx *ctx, const char *name)
+{
+	if (!ctx || !name)
+		return 0;
+	return ctx->timing_enabled && (ctx->timing_filter.empty() || ctx->timing_filter == name) ? 1 : 0;
+}
+
 int gr_timing_set_sampling(gr_ctx *ctx, uint32_t every_nth)
 {
 	if (!ctx)

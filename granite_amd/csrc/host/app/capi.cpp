@@ -363,6 +363,15 @@ int gra_get_prefetched_refreshes(gra_app *app, uint64_t *out)
 	});
 }
 
+int gra_get_launch_graph_replays(gra_app *app, uint64_t *out)
+{
+	return guarded(app, [&]() {
+		if (!out)
+			throw std::logic_error("gra_get_launch_graph_replays: null output");
+		*out = app->app->get_device().get_launch_graph_replays();
+	});
+}
+
 int gra_get_allocated_bytes(gra_app *app, uint64_t *out)
 {
 	return guarded(app, [&]() {

@@ -606,6 +606,8 @@ void ImageSpaceApplication::bake_render_graph()
 	graph.reset();
 	filled_targets.clear(); // keyed by device pointer: a re-baked graph may place a new image at a recycled address
 	graph.set_device(device_holder.get());
+	if (device_holder)
+		device_holder->reset_launch_cache(); // pre-recorded launch sequences hold the old graph's pointers
 	graph.set_alias_disjoint_images(!config.disable_image_aliasing);
 
 	ResourceDimensions dim;

@@ -132,6 +132,83 @@ void CommandBuffer::update_buffers(const BufferUpdate *updates, unsigned count)
 		check(gr_upload_batch(get_context(), stream, ranges, n), "update_buffers");
 }
 
+void CommandBuffer::replayable(const char *site, const LaunchKey &key, std::initializer_list<const char *> kernel_names,
+                               const std::function<void()> &record)
+{
+	bool direct = !device.launch_graphs;
+	for (const char *name : kernel_names)
+		direct = direct || gr_timing_brackets(get_context(), name) != 0; // a bracketed launch records events: not replayable
+	if (direct)
+	{
+		record();
+		return;
+	}
+	auto &entries = device.replay_sites[site];
+	auto hip_stream = static_cast<hipStream_t>(stream);
+	for (auto &e : entries.captured)
+	{
+		if (e.key == key.get())
+		{
+			throw_hip(hipGraphLaunch(static_cast<hipGraphExec_t>(e.exec), hip_stream), "hipGraphLaunch");
+			device.launch_graph_replays++;
+			return;
+		}
+	}
+	bool seen_before = false;
+	for (auto &k : entries.seen)
+		seen_before = seen_before || k == key.get();
+	if (!seen_before)
+	{
+		// first sight: launch directly and remember the key (a bounded memory: keys that never come back are forgotten)
+		if (entries.seen.size() >= 8)
+			entries.seen.erase(entries.seen.begin());
+		entries.seen.push_back(key.get());
+		record();
+		return;
+	}
+	// second sight: capture the sequence, keep the instantiated graph, run it
+	hipGraph_t graph = nullptr;
+	throw_hip(hipStreamBeginCapture(hip_stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+	try
+	{
+		record();
+	}
+	catch (...)
+	{
+		(void)hipStreamEndCapture(hip_stream, &graph);
+		if (graph)
+			(void)hipGraphDestroy(graph);
+		throw;
+	}
+	throw_hip(hipStreamEndCapture(hip_stream, &graph), "hipStreamEndCapture");
+	hipGraphExec_t exec = nullptr;
+	const hipError_t instantiated = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+	(void)hipGraphDestroy(graph);
+	throw_hip(instantiated, "hipGraphInstantiate");
+	if (entries.captured.size() >= 16)
+	{
+		(void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(entries.captured.front().exec));
+		entries.captured.erase(entries.captured.begin());
+	}
+	entries.captured.push_back({key.get(), exec});
+	for (auto itr = entries.seen.begin(); itr != entries.seen.end(); ++itr)
+		if (*itr == key.get())
+		{
+			entries.seen.erase(itr);
+			break;
+		}
+	throw_hip(hipGraphLaunch(exec, hip_stream), "hipGraphLaunch");
+	device.launch_graph_replays++;
+}
+
+void Device::reset_launch_cache()
+{
+	for (auto &site : replay_sites)
+		for (auto &e : site.second.captured)
+			(void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(e.exec));
+	replay_sites.clear();
+}
+
 void CommandBuffer::fill_buffer(const Buffer &dst, size_t offset, size_t size)
 {
 	check(gr_fill_zero(get_context(), stream, static_cast<uint8_t *>(dst.get_device_pointer()) + offset, size), "fill_buffer");
@@ -167,6 +244,11 @@ Device::Device(int device_index) : index(device_index)
 		for (int i = 0; i < 3 && env[i]; i++)
 			priorities[i] = env[i] == 'h' ? greatest : env[i] == 'm' ? middle : least;
 	}
+	if (getenv("GRANITE_LAUNCH_GRAPHS"))
+	{
+		fprintf(stderr, "[granite-hip] note: GRANITE_LAUNCH_GRAPHS is set: repeating launch sequences are replayed as hipGraphs (results unchanged, timing differs)\n");
+		launch_graphs = true;
+	}
 	for (int i = 0; i < int(CommandBuffer::Type::Count); i++)
 	{
 		hipStream_t stream;
@@ -189,6 +271,7 @@ Device::~Device()
 {
 	(void)hipSetDevice(index);
 	(void)hipDeviceSynchronize();
+	reset_launch_cache();
 	for (auto &frame : staging)
 	{
 		if (frame.base)

@@ -413,9 +413,20 @@ void LightClusterer::update_bindless_range_buffer_gpu(HIP::CommandBuffer &cmd)
 
 void LightClusterer::build_cluster_bindless_gpu(HIP::CommandBuffer &cmd)
 {
-	update_bindless_data(cmd);
+	update_bindless_data(cmd); // reads this frame's slot of the pinned staging ring: launched directly
 	cmd.barrier(VK_PIPELINE_STAGE_2_COPY_BIT, VK_ACCESS_TRANSFER_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
-	update_bindless_mask_buffer_gpu(cmd);
-	update_bindless_range_buffer_gpu(cmd);
+	// The four build kernels depend on the buffers, the light count and the camera only: under a camera that stands still (or
+	// a jitter sequence that repeats) they are replayed as one pre-recorded sequence; a moving camera launches them directly.
+	auto &rp = context->get_render_parameters();
+	HIP::CommandBuffer::LaunchKey key;
+	key.add(bindless.transforms_buffer->get_device_pointer()).add(bindless.transformed_spots->get_device_pointer());
+	key.add(bindless.cull_data->get_device_pointer()).add(bindless.bitmask_buffer->get_device_pointer());
+	key.add(bindless.light_ranges->get_device_pointer()).add(bindless.range_buffer->get_device_pointer());
+	key.add(packed.parameters).add(uint32_t(packed.volume_index_range.size())).add(resolution_x).add(resolution_y).add(resolution_z);
+	key.add(rp.view_projection).add(rp.view).add(rp.camera_position).add(rp.camera_front).add(rp.z_near).add(rp.z_far);
+	cmd.replayable("clustering-bindless", key, {"cluster_spot_transform", "cluster_setup", "cluster_binning", "cluster_z_range"}, [&]() {
+		update_bindless_mask_buffer_gpu(cmd);
+		update_bindless_range_buffer_gpu(cmd);
+	});
 }
 } // namespace Granite

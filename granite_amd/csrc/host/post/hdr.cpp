@@ -232,32 +232,51 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 	const StripPlan *plan = options.strip;
 	bloom_pass.set_build_render_pass([&graph, &frame, &t, &d0, &d1, &d2, &d3, &u0, &u1, &u2, &hdr, ubo = lum, plan](HIP::CommandBuffer &cmd) {
 		const StripPlan *strip = plan && (plan->active() || plan->exchange) ? plan : nullptr;
-		const auto compute_to_compute = [&cmd]() {
-			cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
-			            VK_ACCESS_2_SHADER_SAMPLED_READ_BIT);
+		const auto record = [&]() {
+			const auto compute_to_compute = [&cmd]() {
+				cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
+				            VK_ACCESS_2_SHADER_SAMPLED_READ_BIT);
+			};
+			record_threshold(cmd, graph, t, hdr, ubo, strip ? &strip->threshold : nullptr);
+			compute_to_compute();
+			record_downsample(cmd, frame, graph, d0, t, nullptr, strip ? &strip->d0 : nullptr);
+			compute_to_compute();
+			record_downsample(cmd, frame, graph, d1, d0, nullptr, strip ? &strip->d1 : nullptr);
+			if (strip && strip->exchange)
+				strip->exchange(cmd, graph.get_physical_texture_resource(d1), strip->d1_chunk_rows, "downsample-1");
+			compute_to_compute();
+			if (!record_pyramid_tail(cmd, frame, graph, d1, d2, d3, u2, u1, ubo))
+			{
+				record_downsample(cmd, frame, graph, d2, d1, nullptr);
+				compute_to_compute();
+				record_downsample(cmd, frame, graph, d3, d2, &d3);
+				compute_to_compute();
+				if (ubo)
+					record_luminance(cmd, frame, graph, *ubo, d3);
+				record_upsample(cmd, graph, u2, d3);
+				compute_to_compute();
+				record_upsample(cmd, graph, u1, u2);
+			}
+			compute_to_compute();
+			record_upsample(cmd, graph, u0, u1, strip ? &strip->u0 : nullptr);
 		};
-		record_threshold(cmd, graph, t, hdr, ubo, strip ? &strip->threshold : nullptr);
-		compute_to_compute();
-		record_downsample(cmd, frame, graph, d0, t, nullptr, strip ? &strip->d0 : nullptr);
-		compute_to_compute();
-		record_downsample(cmd, frame, graph, d1, d0, nullptr, strip ? &strip->d1 : nullptr);
-		if (strip && strip->exchange)
-			strip->exchange(cmd, graph.get_physical_texture_resource(d1), strip->d1_chunk_rows, "downsample-1");
-		compute_to_compute();
-		if (!record_pyramid_tail(cmd, frame, graph, d1, d2, d3, u2, u1, ubo))
+		if (strip)
 		{
-			record_downsample(cmd, frame, graph, d2, d1, nullptr);
-			compute_to_compute();
-			record_downsample(cmd, frame, graph, d3, d2, &d3);
-			compute_to_compute();
-			if (ubo)
-				record_luminance(cmd, frame, graph, *ubo, d3);
-			record_upsample(cmd, graph, u2, d3);
-			compute_to_compute();
-			record_upsample(cmd, graph, u1, u2);
+			record(); // the band exchange in the middle of the sequence is not a launch
+			return;
 		}
-		compute_to_compute();
-		record_upsample(cmd, graph, u0, u1, strip ? &strip->u0 : nullptr);
+		// Six launches with nothing between them and every argument a function of the attachments: replayed as one
+		// pre-recorded sequence once a key comes back (two keys in steady state: the feedback history ping-pongs).
+		HIP::CommandBuffer::LaunchKey key;
+		for (const RenderTextureResource *res : {&t, &d0, &d1, &d2, &d3, &u0, &u1, &u2})
+			key.add(graph.get_physical_texture_resource(*res).get_view());
+		key.add(graph.get_physical_texture_resource(hdr).get_view());
+		const HIP::ImageView *history = graph.get_physical_history_texture_resource(d3);
+		key.add(history ? history->get_device_pointer() : nullptr);
+		key.add(ubo ? graph.get_physical_buffer_resource(*ubo).get_device_pointer() : nullptr);
+		key.add(frame.frame_time);
+		cmd.replayable("bloom-compute", key,
+		               {"bloom_threshold", "bloom_downsample", "bloom_down_tail", "bloom_up_tail", "luminance", "bloom_upsample"}, record);
 	});
 
 	{

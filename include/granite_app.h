@@ -241,6 +241,10 @@ int gra_get_host_stats(gra_app *app, double *out3);
 /* Frames whose light sort + pack (LightClusterer::refresh) had already been done by the clusterer's helper thread while the
  * previous frame was being enqueued (the reference runs its refreshes as TaskComposer tasks beside command recording). */
 int gra_get_prefetched_refreshes(gra_app *app, uint64_t *out);
+/* Pre-recorded launch sequences replayed so far (HIP::CommandBuffer::replayable, opt-in with GRANITE_LAUNCH_GRAPHS=1: the bloom
+ * pass's six launches and the cluster build's four go out as one hipGraph launch each once their arguments repeat; less host
+ * time, but a slower frame on this runtime -- see hip_device.hpp -- so the default launches every kernel directly). */
+int gra_get_launch_graph_replays(gra_app *app, uint64_t *out);
 /* compute_rec709_to_st2020 (hdr.cpp:580-593) for display primaries r, g, b, white (CIE xy, 8 floats): column-major 3 x 3. */
 int gra_compute_rec709_to_display(const float *primaries8, float *out9);
 /* Bytes of HBM currently held by the executor's images and buffers (graph attachments, hand-over rings, uploads). */

@@ -116,6 +116,9 @@ typedef struct gr_timing_entry
 int gr_timing_enable(gr_ctx *ctx, int enable);
 /* Restrict bracketing to launchers whose name equals `name` (NULL = all): keeps event overhead out of a timed loop. */
 int gr_timing_set_filter(gr_ctx *ctx, const char *name);
+/* 1 when a launch of the kernel timed under `name` would currently get a hipEvent bracket (timing enabled and the filter, if any,
+ * names it): a pre-recorded launch sequence containing it must be launched directly instead. */
+int gr_timing_brackets(gr_ctx *ctx, const char *name);
 /* Bracket only every n-th matching launch (1 = all).  An event pair around a kernel keeps the command processor from
  * overlapping that launch with its neighbours on the stream; sampling keeps a timed loop close to its unbracketed speed
  * while the launch duration is still measured live inside it. */

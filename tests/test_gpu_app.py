@@ -287,3 +287,61 @@ def test_camera_motion_equals_explicit_parameters_and_keeps_the_light_prefetch()
     c.render_frames(8)
     assert c.prefetched_refreshes() >= 7
     c.close()
+
+
+def test_prerecorded_launch_sequences_do_not_change_a_byte():
+    """HIP::CommandBuffer::replayable (opt-in, GRANITE_LAUNCH_GRAPHS=1): once their arguments repeat, the bloom pass's six launches
+    and the cluster build's four go out as one pre-instantiated hipGraph each.  Twenty-four pipelined frames with them (a separate
+    process with the variable set) equal the same frames with every kernel launched directly, byte for byte; the sequences really
+    are replayed; per-kernel timing brackets switch the affected sequence back to direct launches; a moving camera never captures
+    the cluster build."""
+    import subprocess, sys, os, tempfile
+    w, h, frames = 640, 360, 24
+    cam = synth.Camera(w, h)
+    a = gapp.Application(w, h)
+    a.set_render_parameters(cam.render_params())
+    a.set_lights(synth.make_lights(cam, 700))
+    a.upload_gbuffer(synth.make_gbuffer(cam))
+    a.render_frames(frames, sync=False)
+    a.sync()
+    assert a.launch_graph_replays() == 0  # the default launches every kernel directly
+    direct = dict(bb=a.read_backbuffer().copy(), hdr=a.read("HDR-main").copy(), d3=a.read("downsample-3").copy(), lum=a.read("average-luminance").copy())
+    a.close()
+
+    out = os.path.join(tempfile.mkdtemp(), "graphs.npz")
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from granite_amd import app as gapp, synth
+w, h, frames = {w}, {h}, {frames}
+cam = synth.Camera(w, h)
+gbuf, descs = synth.make_gbuffer(cam), synth.make_lights(cam, 700)
+a = gapp.Application(w, h)
+a.set_render_parameters(cam.render_params()); a.set_lights(descs); a.upload_gbuffer(gbuf)
+a.render_frames(frames, sync=False); a.sync()
+# per frame one cluster replay from the second frame on, and one bloom replay from the second occurrence of its key on: the bloom
+# pass's attachments rotate (feedback history, the executor's spare copies of hand-over resources) with a period of a few frames
+assert a.launch_graph_replays() >= (frames - 1) + (frames - 12), a.launch_graph_replays()
+np.savez({out!r}, bb=a.read_backbuffer(), hdr=a.read("HDR-main"), d3=a.read("downsample-3"), lum=a.read("average-luminance"))
+# brackets on a kernel of the bloom sequence: that sequence is launched directly again, the cluster one keeps replaying
+k = a.kernel_context()
+before = a.launch_graph_replays()
+k.timing_set_filter("bloom_threshold"); k.timing_enable(True); k.timing_reset()
+a.render_frames(4)
+assert k.timing_query()["bloom_threshold"][0] == 4
+k.timing_enable(False); k.timing_set_filter(None)
+assert a.launch_graph_replays() - before == 4, a.launch_graph_replays() - before
+a.close()
+# a camera that moves every frame: the cluster build's arguments never repeat, the bloom sequence still replays
+m = gapp.Application(w, h)
+m.set_camera(np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16))
+m.set_lights(descs); m.upload_gbuffer(gbuf); m.set_camera_motion((0.01, 0.0, 0.0))
+m.render_frames(frames)
+assert frames - 12 <= m.launch_graph_replays() <= frames, m.launch_graph_replays()
+m.close()
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GRANITE_LAUNCH_GRAPHS="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2500:]
+    graphs = np.load(out)
+    for key, want in direct.items():
+        np.testing.assert_array_equal(graphs[key], want, err_msg=key)
