@@ -16,13 +16,17 @@ def main():
     from granite_amd import app as gapp, synth
     w, h, lights, frames, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     post_aa = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    pre_aa = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
     cam = synth.Camera(w, h)
-    a = gapp.Application(w, h, device=0, strip_index=rank, strip_count=world, post_aa=post_aa)
-    a.set_render_parameters(cam.render_params())
+    a = gapp.Application(w, h, device=0, strip_index=rank, strip_count=world, post_aa=post_aa, pre_aa=pre_aa)
+    if pre_aa:  # the temporal resolve jitters the projection: it needs the camera, and motion vectors
+        a.set_camera(np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16))
+    else:
+        a.set_render_parameters(cam.render_params())
     a.set_lights(synth.make_lights(cam, lights))
-    a.upload_gbuffer(synth.make_gbuffer(cam))
+    a.upload_gbuffer(synth.make_gbuffer(cam), synth.make_motion_vectors(w, h) if pre_aa else None)
     ids = [gapp.Application.comm_create_unique_id() if rank == 0 else None, gapp.Application.comm_create_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
     a.comm_init(ids[0], rank, world)

@@ -28,18 +28,22 @@ def launch(world, script_args, port, extra_env=None, timeout=420):
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
 
 
-@pytest.mark.parametrize("world,w,h,post_aa", [(2, 480, 272, 0), (3, 512, 250, 0), (2, 480, 272, gapp.POST_AA_FXAA)])
-def test_ranks_in_separate_processes_assemble_the_single_process_frame(tmp_path, world, w, h, post_aa):
+@pytest.mark.parametrize("world,w,h,post_aa,pre_aa", [(2, 480, 272, 0, 0), (3, 512, 250, 0, 0), (2, 480, 272, gapp.POST_AA_FXAA, 0),
+                                                       (2, 480, 272, gapp.POST_AA_SMAA_ULTRA, gapp.POST_AA_TAA_HIGH)])
+def test_ranks_in_separate_processes_assemble_the_single_process_frame(tmp_path, world, w, h, post_aa, pre_aa):
     frames, lights = 6, 200
     out = str(tmp_path / "rank{rank}.npz")
-    r = launch(world, [os.path.join(ROOT, "tests", "band_worker_gpu.py"), str(w), str(h), str(lights), str(frames), out, str(post_aa)],
+    r = launch(world, [os.path.join(ROOT, "tests", "band_worker_gpu.py"), str(w), str(h), str(lights), str(frames), out, str(post_aa), str(pre_aa)],
                29600 + (os.getpid() % 300))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     cam = synth.Camera(w, h)
-    a = gapp.Application(w, h, post_aa=post_aa)
-    a.set_render_parameters(cam.render_params())
+    a = gapp.Application(w, h, post_aa=post_aa, pre_aa=pre_aa)
+    if pre_aa:
+        a.set_camera(np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16))
+    else:
+        a.set_render_parameters(cam.render_params())
     a.set_lights(synth.make_lights(cam, lights))
-    a.upload_gbuffer(synth.make_gbuffer(cam))
+    a.upload_gbuffer(synth.make_gbuffer(cam), synth.make_motion_vectors(w, h) if pre_aa else None)
     a.render_frames(frames)
     want = (a.read_backbuffer().copy(), a.read("downsample-1").copy(), a.read("average-luminance").copy())
     a.close()
