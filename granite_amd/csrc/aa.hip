@@ -875,21 +875,27 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs 
 				row[i][0] = uint32_t(clampi(iy, 0, h - 1)) * a.history.pitch;
 				row[i][1] = uint32_t(clampi(iy + 1, 0, h - 1)) * a.history.pitch;
 			}
-			auto texel = [&](uint32_t offset) {
-				const f16x4 t = *reinterpret_cast<const f16x4 *>(a.history.ptr + offset);
-				return mk3(float(t.x), float(t.y), float(t.z));
-			};
+			// Each tap: sample_linear3()'s lerps with the fp16 -> fp32 conversion folded into the multiply-add (v_fma_mix_f32) and
+			// the two weights of the tap multiplied first -- 22 instructions per tap instead of 48.  Against the statement-for-statement
+			// form this re-associates two products and drops three intermediate roundings per channel: a few fp32 ulps on a value
+			// that is stored as fp16 (the resolve's tolerance is 3 ulp fp16).
+			auto texel = [&](uint32_t offset) { return *reinterpret_cast<const uint2 *>(a.history.ptr + offset); };
 			v3 r = mk3(0.0f, 0.0f, 0.0f);
 #pragma unroll
 			for (int j = 0; j < 3; j++)
 #pragma unroll
 				for (int i = 0; i < 3; i++)
 				{
-					const v3 t00 = texel(row[j][0] + col[i][0]), t10 = texel(row[j][0] + col[i][1]);
-					const v3 t01 = texel(row[j][1] + col[i][0]), t11 = texel(row[j][1] + col[i][1]);
-					const v3 top = t00 * (1.0f - fa[i]) + t10 * fa[i];
-					const v3 bot = t01 * (1.0f - fa[i]) + t11 * fa[i];
-					r = r + (top * (1.0f - fb[j]) + bot * fb[j]) * wx[i] * wy[j];
+					const uint2 t00 = texel(row[j][0] + col[i][0]), t10 = texel(row[j][0] + col[i][1]);
+					const uint2 t01 = texel(row[j][1] + col[i][0]), t11 = texel(row[j][1] + col[i][1]);
+					const float wa = fa[i], oma = 1.0f - fa[i], wb = fb[j], omb = 1.0f - fb[j];
+					const float wxy = wx[i] * wy[j];
+					const float top_r = fma_mix_lo(t10.x, wa, fma_mix_lo(t00.x, oma, 0.0f)), bot_r = fma_mix_lo(t11.x, wa, fma_mix_lo(t01.x, oma, 0.0f));
+					const float top_g = fma_mix_hi(t10.x, wa, fma_mix_hi(t00.x, oma, 0.0f)), bot_g = fma_mix_hi(t11.x, wa, fma_mix_hi(t01.x, oma, 0.0f));
+					const float top_b = fma_mix_lo(t10.y, wa, fma_mix_lo(t00.y, oma, 0.0f)), bot_b = fma_mix_lo(t11.y, wa, fma_mix_lo(t01.y, oma, 0.0f));
+					r.x = fmaf(fmaf(bot_r, wb, top_r * omb), wxy, r.x);
+					r.y = fmaf(fmaf(bot_g, wb, top_g * omb), wxy, r.y);
+					r.z = fmaf(fmaf(bot_b, wb, top_b * omb), wxy, r.z);
 				}
 			history_color = r;
 		}
