@@ -8,6 +8,7 @@
 // is compiled with -ffp-contract=off and every expression keeps a fixed association order; `mad` is a real fma in the
 // reference (SMAA_GLSL_4) and is written fmaf here.  Images in *_SRGB formats are read through their UNORM alias: the
 // stored bytes.
+#include <vector>
 #include "ctx.hpp"
 #include "device_common.hpp"
 #include "device_vec.hpp"
@@ -29,7 +30,7 @@ struct Tex8
 	{
 		x = clampi(x, 0, w - 1);
 		y = clampi(y, 0, h - 1);
-		const uint8_t *p = ptr + size_t(y) * pitch + size_t(x) * CH;
+		const uint8_t *p = ptr + (uint32_t(y) * pitch + uint32_t(x) * uint32_t(CH)); // images stay below 4 GiB
 		v4 r = mk4(0.0f, 0.0f, 0.0f, 1.0f);
 		if (CH == 4)
 		{
@@ -44,6 +45,40 @@ struct Tex8
 		}
 		else
 			r.x = unorm8_to_float(p[0]);
+		return r;
+	}
+
+	__device__ __forceinline__ v4 sample(v2 uv, int ox = 0, int oy = 0) const
+	{
+		const float fx = uv.x * float(w) - 0.5f;
+		const float fy = uv.y * float(h) - 0.5f;
+		const float flx = floorf(fx), fly = floorf(fy);
+		const float a = fx - flx, b = fy - fly;
+		const int x0 = int(flx) + ox, y0 = int(fly) + oy;
+		const v4 t00 = fetch(x0, y0), t10 = fetch(x0 + 1, y0), t01 = fetch(x0, y0 + 1), t11 = fetch(x0 + 1, y0 + 1);
+		const v4 top = t00 * (1.0f - a) + t10 * a;
+		const v4 bot = t01 * (1.0f - a) + t11 * a;
+		return top * (1.0f - b) + bot * b;
+	}
+};
+
+// The same sampler over a texture that was decoded to fp32 when it was uploaded (SMAA's area and search tables: constant data,
+// v / 255 evaluated once on the host instead of at every fetch -- the same float either way).
+template <int CH>
+struct TexF
+{
+	const float *data;
+	int w, h;
+
+	__device__ __forceinline__ v4 fetch(int x, int y) const
+	{
+		x = clampi(x, 0, w - 1);
+		y = clampi(y, 0, h - 1);
+		const float *p = data + (uint32_t(y) * uint32_t(w) + uint32_t(x)) * uint32_t(CH);
+		v4 r = mk4(0.0f, 0.0f, 0.0f, 1.0f);
+		r.x = p[0];
+		if (CH >= 2)
+			r.y = p[1];
 		return r;
 	}
 
@@ -287,8 +322,8 @@ constexpr int SMAA_EDGE_HALO = 16;
 struct SmaaWeightsArgs
 {
 	Tex8<2> edges;
-	Tex8<2> area;
-	Tex8<1> search;
+	TexF<2> area;
+	TexF<1> search;
 	v4 rt;
 	SmaaPreset P;
 };
@@ -298,8 +333,8 @@ template <typename Edges>
 struct SmaaWeights
 {
 	Edges edges;
-	Tex8<2> area;
-	Tex8<1> search;
+	TexF<2> area;
+	TexF<1> search;
 	v4 rt;
 	SmaaPreset P;
 
@@ -1025,12 +1060,18 @@ int gr_smaa_set_luts(gr_ctx *ctx, const void *area_rg8, const void *search_r8)
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, area_rg8 && search_r8);
+	// Both tables are kept decoded (float(v) / 255.0f, the UNORM8 conversion of the fetch, evaluated once here).
+	std::vector<float> area(160 * 560 * 2), search(64 * 16);
+	for (size_t i = 0; i < area.size(); i++)
+		area[i] = float(static_cast<const uint8_t *>(area_rg8)[i]) / 255.0f;
+	for (size_t i = 0; i < search.size(); i++)
+		search[i] = float(static_cast<const uint8_t *>(search_r8)[i]) / 255.0f;
 	if (!ctx->smaa_area)
-		GR_CHECK_HIP(ctx, hipMalloc(&ctx->smaa_area, 160 * 560 * 2));
+		GR_CHECK_HIP(ctx, hipMalloc(&ctx->smaa_area, area.size() * sizeof(float)));
 	if (!ctx->smaa_search)
-		GR_CHECK_HIP(ctx, hipMalloc(&ctx->smaa_search, 64 * 16));
-	GR_CHECK_HIP(ctx, hipMemcpy(ctx->smaa_area, area_rg8, 160 * 560 * 2, hipMemcpyHostToDevice));
-	GR_CHECK_HIP(ctx, hipMemcpy(ctx->smaa_search, search_r8, 64 * 16, hipMemcpyHostToDevice));
+		GR_CHECK_HIP(ctx, hipMalloc(&ctx->smaa_search, search.size() * sizeof(float)));
+	GR_CHECK_HIP(ctx, hipMemcpy(ctx->smaa_area, area.data(), area.size() * sizeof(float), hipMemcpyHostToDevice));
+	GR_CHECK_HIP(ctx, hipMemcpy(ctx->smaa_search, search.data(), search.size() * sizeof(float), hipMemcpyHostToDevice));
 	return GR_OK;
 }
 
@@ -1098,8 +1139,8 @@ int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edg
 		return ctx->fail(GR_ERR_INVALID_ARGUMENT, "gr_smaa_blend_weight: SMAA lookup tables not set (gr_smaa_set_luts)");
 	SmaaWeightsArgs S;
 	S.edges = make_tex8<2>(edges);
-	S.area = {static_cast<const uint8_t *>(ctx->smaa_area), 160, 560, 320u};
-	S.search = {static_cast<const uint8_t *>(ctx->smaa_search), 64, 16, 64u};
+	S.area = {static_cast<const float *>(ctx->smaa_area), 160, 560};
+	S.search = {static_cast<const float *>(ctx->smaa_search), 64, 16};
 	S.rt = v4{push->rt_metrics[0], push->rt_metrics[1], push->rt_metrics[2], push->rt_metrics[3]};
 	S.P = smaa_preset(quality);
 	const RowSpan span = resolve_rows(rows, edges->height);

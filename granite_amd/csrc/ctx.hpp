@@ -30,8 +30,8 @@ struct gr_ctx
 	uint2 *tonemap_srgb8_lut = nullptr;
 
 	// SMAA lookup tables (assets/textures/smaa/{area,search}.gtx payloads), uploaded through gr_smaa_set_luts.
-	void *smaa_area = nullptr;   // RG8, 160 x 560
-	void *smaa_search = nullptr; // R8, 64 x 16
+	void *smaa_area = nullptr;   // 160 x 560 x 2 floats (the RG8 area texture, decoded)
+	void *smaa_search = nullptr; // 64 x 16 floats (the R8 search texture, decoded)
 
 	bool timing_enabled = false;
 	std::string timing_filter; // empty = every launcher
