@@ -12,13 +12,17 @@
 #include "ctx.hpp"
 #include "device_common.hpp"
 #include "device_vec.hpp"
+#include "aa_core.hpp"
+#include "aa_fast_kernels.hpp"
 
 namespace
 {
 constexpr int AA_BLOCK_X = 32;
 constexpr int AA_BLOCK_Y = 8;
 
-// StockSampler::LinearClamp on a UNORM8 image with CH channels; texel offsets are applied after the floor.
+// StockSampler::LinearClamp on a UNORM8 image with CH channels; texel offsets are applied after the floor.  The sampler
+// model is the oracle's (aa_core.hpp: exact fp32 weights, coordinates within 2^-8 of a texel centre read that texel): for UNORM
+// texels t * 1 + t' * 0 == t, so the snapped case goes through the same lerps.
 template <int CH>
 struct Tex8
 {
@@ -50,11 +54,12 @@ struct Tex8
 
 	__device__ __forceinline__ v4 sample(v2 uv, int ox = 0, int oy = 0) const
 	{
-		const float fx = uv.x * float(w) - 0.5f;
-		const float fy = uv.y * float(h) - 0.5f;
-		const float flx = floorf(fx), fly = floorf(fy);
-		const float a = fx - flx, b = fy - fly;
-		const int x0 = int(flx) + ox, y0 = int(fly) + oy;
+		int x0, y0;
+		float a, b;
+		aa::linear_axis(uv.x * float(w) - 0.5f, x0, a);
+		aa::linear_axis(uv.y * float(h) - 0.5f, y0, b);
+		x0 += ox;
+		y0 += oy;
 		const v4 t00 = fetch(x0, y0), t10 = fetch(x0 + 1, y0), t01 = fetch(x0, y0 + 1), t11 = fetch(x0 + 1, y0 + 1);
 		const v4 top = t00 * (1.0f - a) + t10 * a;
 		const v4 bot = t01 * (1.0f - a) + t11 * a;
@@ -84,11 +89,12 @@ struct TexF
 
 	__device__ __forceinline__ v4 sample(v2 uv, int ox = 0, int oy = 0) const
 	{
-		const float fx = uv.x * float(w) - 0.5f;
-		const float fy = uv.y * float(h) - 0.5f;
-		const float flx = floorf(fx), fly = floorf(fy);
-		const float a = fx - flx, b = fy - fly;
-		const int x0 = int(flx) + ox, y0 = int(fly) + oy;
+		int x0, y0;
+		float a, b;
+		aa::linear_axis(uv.x * float(w) - 0.5f, x0, a);
+		aa::linear_axis(uv.y * float(h) - 0.5f, y0, b);
+		x0 += ox;
+		y0 += oy;
 		const v4 t00 = fetch(x0, y0), t10 = fetch(x0 + 1, y0), t01 = fetch(x0, y0 + 1), t11 = fetch(x0 + 1, y0 + 1);
 		const v4 top = t00 * (1.0f - a) + t10 * a;
 		const v4 bot = t01 * (1.0f - a) + t11 * a;
@@ -111,11 +117,12 @@ struct Tile8
 
 	__device__ __forceinline__ v4 sample(v2 uv, int offx = 0, int offy = 0) const
 	{
-		const float fx = uv.x * float(tex.w) - 0.5f;
-		const float fy = uv.y * float(tex.h) - 0.5f;
-		const float flx = floorf(fx), fly = floorf(fy);
-		const float a = fx - flx, b = fy - fly;
-		const int x0 = int(flx) + offx, y0 = int(fly) + offy;
+		int x0, y0;
+		float a, b;
+		aa::linear_axis(uv.x * float(tex.w) - 0.5f, x0, a);
+		aa::linear_axis(uv.y * float(tex.h) - 0.5f, y0, b);
+		x0 += offx;
+		y0 += offy;
 		const int tx = x0 - ox, ty = y0 - oy;
 		v4 t00, t10, t01, t11;
 		// one decision per wave: the tile, or (never expected) the image for all four texels of every lane
@@ -181,7 +188,7 @@ __device__ __forceinline__ void store_rgba8(uint8_t *ptr, uint32_t pitch, int x,
 }
 
 // ---- FXAA (fxaa.frag:20-67) --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_fxaa(Tex8<4> tex_, uint8_t *out, uint32_t out_pitch, gr_push_fxaa push, RowSpan rows)
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_fxaa_generic(Tex8<4> tex_, uint8_t *out, uint32_t out_pitch, gr_push_fxaa push, RowSpan rows)
 {
 	// reach: the corner taps 1 texel, the edge taps at most FXAA_SPAN_MAX * 0.5 = 4 texels, + 1 for the bilinear footprint
 	constexpr int HALO = 6;
@@ -240,7 +247,7 @@ static SmaaPreset smaa_preset(int quality)
 
 // SMAALumaEdgeDetectionPS (SMAA.hlsl:689-740).  Every pixel is written (0 = what the reference leaves as the clear value
 // when the fragment is discarded), so no separate clear pass is needed.
-__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_edges(Tex8<4> image, uint8_t *edges, uint32_t edges_pitch, gr_push_smaa push,
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_edges_generic(Tex8<4> image, uint8_t *edges, uint32_t edges_pitch, gr_push_smaa push,
                                                                        SmaaPreset P, RowSpan rows)
 {
 	constexpr int HALO = 3; // taps two texels to the left / above, one to the right / below, + 1 for the bilinear footprint
@@ -289,11 +296,12 @@ struct EdgeTile
 
 	__device__ __forceinline__ v4 sample(v2 uv, int offx = 0, int offy = 0) const
 	{
-		const float fx = uv.x * float(tex.w) - 0.5f;
-		const float fy = uv.y * float(tex.h) - 0.5f;
-		const float flx = floorf(fx), fly = floorf(fy);
-		const float a = fx - flx, b = fy - fly;
-		const int x0 = int(flx) + offx, y0 = int(fly) + offy;
+		int x0, y0;
+		float a, b;
+		aa::linear_axis(uv.x * float(tex.w) - 0.5f, x0, a);
+		aa::linear_axis(uv.y * float(tex.h) - 0.5f, y0, b);
+		x0 += offx;
+		y0 += offy;
 		const int tx = x0 - ox, ty = y0 - oy;
 		v4 t00, t10, t01, t11;
 		if (__all(unsigned(tx) < unsigned(W - 1) && unsigned(ty) < unsigned(H - 1)))
@@ -661,7 +669,7 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_weights(SmaaWei
 }
 
 // SMAANeighborhoodBlendingPS (SMAA.hlsl:1252-1308)
-__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_blend(Tex8<4> cimage, Tex8<4> bimage, uint8_t *out, uint32_t out_pitch, gr_push_smaa push,
+__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_blend_generic(Tex8<4> cimage, Tex8<4> bimage, uint8_t *out, uint32_t out_pitch, gr_push_smaa push,
                                                                        RowSpan rows)
 {
 	constexpr int HALO = 2; // weights of the right / bottom neighbour, colour up to one texel away, + 1 for the bilinear footprint
@@ -702,6 +710,28 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_blend(Tex8<4> c
 		result = result + blendingWeight.y * ctex.sample(mk2(bc.z, bc.w));
 	}
 	store_rgba8(out, out_pitch, x, y, result);
+}
+
+// Cached per context: do pixel-centre taps at offsets -2 .. 2 resolve to texel fetches along an axis of n texels?
+static bool centre_taps_exact(gr_ctx *ctx, uint32_t n, float inv)
+{
+	const uint64_t key = (uint64_t(n) << 32) | __builtin_bit_cast(uint32_t, inv);
+	{
+		std::lock_guard<std::mutex> holder{ctx->lock};
+		auto it = ctx->centre_taps_exact.find(key);
+		if (it != ctx->centre_taps_exact.end())
+			return it->second;
+	}
+	static const int ks[] = {-2, -1, 0, 1, 2};
+	const bool ok = aa::axis_taps_exact(int(n), inv, ks, 5);
+	std::lock_guard<std::mutex> holder{ctx->lock};
+	ctx->centre_taps_exact[key] = ok;
+	return ok;
+}
+static bool use_fast_aa(gr_ctx *ctx, uint32_t w, uint32_t h, float inv_w, float inv_h)
+{
+	static const bool forced_generic = gr_measurement_switch("GRANITE_AA_GENERIC") != nullptr;
+	return !forced_generic && centre_taps_exact(ctx, w, inv_w) && centre_taps_exact(ctx, h, inv_h);
 }
 
 // ---- TAA resolve (taa_resolve.frag + reprojection.h) -------------------------------------------------------------------------
@@ -762,11 +792,10 @@ __device__ __forceinline__ v3 history_texel(const DevImage &img, int x, int y)
 
 __device__ __forceinline__ v3 sample_linear3(const DevImage &img, float u, float v)
 {
-	const float fx = u * float(img.w) - 0.5f;
-	const float fy = v * float(img.h) - 0.5f;
-	const float flx = floorf(fx), fly = floorf(fy);
-	const float a = fx - flx, b = fy - fly;
-	const int ix = int(flx), iy = int(fly);
+	int ix, iy;
+	float a, b;
+	aa::linear_axis(u * float(img.w) - 0.5f, ix, a);
+	aa::linear_axis(v * float(img.h) - 0.5f, iy, b);
 	const v3 t00 = history_texel(img, ix, iy), t10 = history_texel(img, ix + 1, iy);
 	const v3 t01 = history_texel(img, ix, iy + 1), t11 = history_texel(img, ix + 1, iy + 1);
 	const v3 top = t00 * (1.0f - a) + t10 * a;
@@ -900,11 +929,9 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs 
 #pragma unroll
 			for (int i = 0; i < 3; i++)
 			{
-				const float fx = px[i] * float(a.history.w) - 0.5f, fy = py[i] * float(a.history.h) - 0.5f;
-				const float flx = floorf(fx), fly = floorf(fy);
-				fa[i] = fx - flx;
-				fb[i] = fy - fly;
-				const int ix = int(flx), iy = int(fly);
+				int ix, iy;
+				aa::linear_axis(px[i] * float(a.history.w) - 0.5f, ix, fa[i]);
+				aa::linear_axis(py[i] * float(a.history.h) - 0.5f, iy, fb[i]);
 				col[i][0] = uint32_t(clampi(ix, 0, w - 1)) * 8u;
 				col[i][1] = uint32_t(clampi(ix + 1, 0, w - 1)) * 8u;
 				row[i][0] = uint32_t(clampi(iy, 0, h - 1)) * a.history.pitch;
@@ -1020,10 +1047,10 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_blit(BlitArgs a)
 	v4 c;
 	if (a.linear)
 	{
-		const float fx = uv.x * float(a.in.w) - 0.5f, fy = uv.y * float(a.in.h) - 0.5f;
-		const float flx = floorf(fx), fly = floorf(fy);
-		const float wa = fx - flx, wb = fy - fly;
-		const int x0 = int(flx), y0 = int(fly);
+		int x0, y0;
+		float wa, wb;
+		aa::linear_axis(uv.x * float(a.in.w) - 0.5f, x0, wa);
+		aa::linear_axis(uv.y * float(a.in.h) - 0.5f, y0, wb);
 		const v4 t00 = blit_texel(a, x0, y0), t10 = blit_texel(a, x0 + 1, y0), t01 = blit_texel(a, x0, y0 + 1), t11 = blit_texel(a, x0 + 1, y0 + 1);
 		const v4 top = t00 * (1.0f - wa) + t10 * wa;
 		const v4 bot = t01 * (1.0f - wa) + t11 * wa;
@@ -1051,6 +1078,7 @@ static bool check_image(const gr_image *img, uint32_t bpp, uint32_t w, uint32_t 
 }
 static bool is_rgba8(uint32_t f) { return f == GR_FORMAT_R8G8B8A8_SRGB || f == GR_FORMAT_R8G8B8A8_UNORM; }
 static dim3 aa_grid(uint32_t w, uint32_t h) { return dim3(gr_div_up(w, AA_BLOCK_X), gr_div_up(h, AA_BLOCK_Y)); }
+static dim3 fast_grid(uint32_t w, uint32_t h) { return dim3(gr_div_up(w, FAST_BW), gr_div_up(h, FAST_BH)); }
 } // namespace
 
 extern "C" {
@@ -1090,9 +1118,15 @@ int gr_fxaa_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, const gr_ima
 	const RowSpan span = resolve_rows(rows, in->height);
 	if (span.count() == 0)
 		return GR_OK;
+	const bool fast = use_fast_aa(ctx, in->width, in->height, push->inv_resolution[0], push->inv_resolution[1]);
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "fxaa"};
-	hipLaunchKernelGGL(k_fxaa, aa_grid(in->width, span.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), make_tex8<4>(in),
-	                   static_cast<uint8_t *>(out->ptr), out->pitch_bytes, *push, span);
+	if (fast)
+		hipLaunchKernelGGL(k_fxaa_fast, fast_grid(in->width, span.count()), dim3(FAST_BW, FAST_BH), 0, gr_to_stream(stream),
+		                   static_cast<const uint8_t *>(in->ptr), in->pitch_bytes, int(in->width), int(in->height), static_cast<uint8_t *>(out->ptr),
+		                   out->pitch_bytes, push->inv_resolution[0], push->inv_resolution[1], span);
+	else
+		hipLaunchKernelGGL(k_fxaa_generic, aa_grid(in->width, span.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), make_tex8<4>(in),
+		                   static_cast<uint8_t *>(out->ptr), out->pitch_bytes, *push, span);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
@@ -1114,9 +1148,15 @@ int gr_smaa_edge_detection_rows(gr_ctx *ctx, gr_stream stream, const gr_image *c
 	const RowSpan span = resolve_rows(rows, color->height);
 	if (span.count() == 0)
 		return GR_OK;
+	const bool fast = use_fast_aa(ctx, color->width, color->height, push->rt_metrics[0], push->rt_metrics[1]);
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_edge_detection"};
-	hipLaunchKernelGGL(k_smaa_edges, aa_grid(color->width, span.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), make_tex8<4>(color),
-	                   static_cast<uint8_t *>(edges->ptr), edges->pitch_bytes, *push, smaa_preset(quality), span);
+	if (fast)
+		hipLaunchKernelGGL(k_smaa_edges_fast, fast_grid(color->width, span.count()), dim3(FAST_BW, FAST_BH), 0, gr_to_stream(stream),
+		                   static_cast<const uint8_t *>(color->ptr), color->pitch_bytes, int(color->width), int(color->height),
+		                   static_cast<uint8_t *>(edges->ptr), edges->pitch_bytes, smaa_preset(quality).threshold, span);
+	else
+		hipLaunchKernelGGL(k_smaa_edges_generic, aa_grid(color->width, span.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream),
+		                   make_tex8<4>(color), static_cast<uint8_t *>(edges->ptr), edges->pitch_bytes, *push, smaa_preset(quality), span);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
@@ -1171,9 +1211,25 @@ int gr_smaa_neighbor_blend_rows(gr_ctx *ctx, gr_stream stream, const gr_image *c
 	const RowSpan span = resolve_rows(rows, color->height);
 	if (span.count() == 0)
 		return GR_OK;
+	const bool fast = use_fast_aa(ctx, color->width, color->height, push->rt_metrics[0], push->rt_metrics[1]);
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_neighbor_blend"};
-	hipLaunchKernelGGL(k_smaa_blend, aa_grid(color->width, span.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream),
-	                   make_tex8<4>(color), make_tex8<4>(weights), static_cast<uint8_t *>(out->ptr), out->pitch_bytes, *push, span);
+	if (fast)
+	{
+		const ColorImage c = {static_cast<const uint8_t *>(color->ptr), color->pitch_bytes, int(color->width), int(color->height)};
+		const ColorImage b = {static_cast<const uint8_t *>(weights->ptr), weights->pitch_bytes, int(weights->width), int(weights->height)};
+		const bool wide = color->width % 4 == 0 && ((color->pitch_bytes | weights->pitch_bytes | out->pitch_bytes) & 15u) == 0 &&
+		                  ((uintptr_t(color->ptr) | uintptr_t(weights->ptr) | uintptr_t(out->ptr)) & 15u) == 0;
+		const dim3 block(64, 4);
+		if (wide)
+			hipLaunchKernelGGL(k_smaa_blend_fast<4>, dim3(gr_div_up(color->width, 256), gr_div_up(span.count(), 4)), block, 0, gr_to_stream(stream), c, b,
+			                   static_cast<uint8_t *>(out->ptr), out->pitch_bytes, push->rt_metrics[0], push->rt_metrics[1], span);
+		else
+			hipLaunchKernelGGL(k_smaa_blend_fast<1>, dim3(gr_div_up(color->width, 64), gr_div_up(span.count(), 4)), block, 0, gr_to_stream(stream), c, b,
+			                   static_cast<uint8_t *>(out->ptr), out->pitch_bytes, push->rt_metrics[0], push->rt_metrics[1], span);
+	}
+	else
+		hipLaunchKernelGGL(k_smaa_blend_generic, aa_grid(color->width, span.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream),
+		                   make_tex8<4>(color), make_tex8<4>(weights), static_cast<uint8_t *>(out->ptr), out->pitch_bytes, *push, span);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

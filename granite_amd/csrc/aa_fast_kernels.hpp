@@ -1,0 +1,162 @@
+// The fast anti-aliasing kernels for gfx950: tiling, LDS staging and launch geometry around the per-pixel arithmetic of
+// aa_core.hpp.  Included by aa.hip (after the HIP runtime and device_common.hpp) and, unchanged, by the host emulation the CPU
+// tests run (tests/cpp/hip_emu.hpp: one std::thread per lane, barriers and wave votes as rendezvous) -- so indexing, halos,
+// clamping and band handling are checked against the oracle before a GPU sees them.  Uses only what both environments
+// provide: threadIdx / blockIdx, __shared__, __syncthreads*, float4 / uint4, min / max.
+#pragma once
+#include "aa_core.hpp"
+#include "row_span.hpp"
+
+// ---- fast forms: pixel-centre taps as texel fetches (aa_core.hpp) ----------------------------------------------------------------
+// Under the sampler model a tap on a pixel centre IS the texel, so FXAA's corner lumas, every tap of the SMAA edge pass and
+// the weight fetches of the SMAA blend are exact reads of values that are decoded once.  The launchers use these kernels when
+// aa::axis_taps_exact() holds for both axes of the image (any size below ~16K), the *_generic ones above otherwise.
+constexpr int FAST_BW = 32, FAST_BH = 16; // 512 threads: 8 waves of two 32-pixel rows
+
+__device__ __forceinline__ uint32_t load_rgba8_clamped(const uint8_t *ptr, uint32_t pitch, int w, int h, int x, int y)
+{
+	x = aa::clampi(x, 0, w - 1);
+	y = aa::clampi(y, 0, h - 1);
+	return *reinterpret_cast<const uint32_t *>(ptr + (uint32_t(y) * pitch + uint32_t(x) * 4u));
+}
+
+struct FxaaTile
+{
+	static constexpr int HALO = 6; // edge taps reach FXAA_SPAN_MAX / 2 = 4 texels, + 1 for the bilinear footprint, + 1 of slack
+	static constexpr int W = FAST_BW + 2 * HALO, H = FAST_BH + 2 * HALO;
+	const float4 *texels; // [H][W]: r, g, b, luma
+	int ox, oy;
+	__device__ __forceinline__ aa::f4 texel(int x, int y) const
+	{
+		const float4 t = texels[(y - oy) * W + (x - ox)];
+		return {t.x, t.y, t.z, t.w};
+	}
+};
+
+__global__ __launch_bounds__(FAST_BW *FAST_BH) void k_fxaa_fast(const uint8_t *in, uint32_t in_pitch, int w, int h, uint8_t *out, uint32_t out_pitch,
+                                                                 float inv_w, float inv_h, RowSpan rows)
+{
+	constexpr int HALO = FxaaTile::HALO, TW = FxaaTile::W, TH = FxaaTile::H;
+	__shared__ uint32_t s_raw[TW * TH];
+	__shared__ float4 s_dec[TW * TH];
+	const int bx = blockIdx.x * FAST_BW, by = int(rows.first) + blockIdx.y * FAST_BH;
+	const int tid = threadIdx.y * FAST_BW + threadIdx.x;
+	for (int i = tid; i < TW * TH; i += FAST_BW * FAST_BH)
+	{
+		const int ty = i / TW, tx = i - ty * TW;
+		s_raw[i] = load_rgba8_clamped(in, in_pitch, w, h, bx - HALO + tx, by - HALO + ty);
+	}
+	__syncthreads();
+	const int x = bx + threadIdx.x, y = by + threadIdx.y;
+	const bool inside = x < w && y < int(rows.end);
+	const uint32_t *centre = s_raw + (threadIdx.y + HALO) * TW + (threadIdx.x + HALO);
+	// dir == 0 where the four corners carry the same colour: the pass copies the pixel (most of a rendered frame)
+	const bool flat = aa::fxaa_corners_equal(centre[-TW - 1], centre[-TW + 1], centre[TW - 1], centre[TW + 1]);
+	uint32_t *dst = reinterpret_cast<uint32_t *>(out + (uint32_t(y) * out_pitch + uint32_t(x) * 4u));
+	if (!__syncthreads_or(inside && !flat))
+	{
+		if (inside)
+			*dst = centre[0] | 0xff000000u;
+		return;
+	}
+	for (int i = tid; i < TW * TH; i += FAST_BW * FAST_BH)
+	{
+		const uint32_t t = s_raw[i];
+		const float r = aa::unorm8_decode(t & 255u), g = aa::unorm8_decode((t >> 8) & 255u), b = aa::unorm8_decode((t >> 16) & 255u);
+		s_dec[i] = make_float4(r, g, b, aa::luma_of(r, g, b, aa::FXAA_LUMA_R, aa::FXAA_LUMA_G, aa::FXAA_LUMA_B));
+	}
+	__syncthreads();
+	if (!inside)
+		return;
+	if (flat)
+		*dst = centre[0] | 0xff000000u;
+	else
+	{
+		const FxaaTile tile = {s_dec, bx - HALO, by - HALO};
+		*dst = aa::fxaa_pixel(tile, x, y, inv_w, inv_h, float(w), float(h));
+	}
+}
+
+struct EdgeLumaTile
+{
+	static constexpr int W = FAST_BW + 3, H = FAST_BH + 3; // two texels to the left / above, one to the right / below
+	const float *values;
+	int ox, oy;
+	__device__ __forceinline__ float luma(int x, int y) const { return values[(y - oy) * W + (x - ox)]; }
+};
+
+__global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_edges_fast(const uint8_t *in, uint32_t in_pitch, int w, int h, uint8_t *edges, uint32_t edges_pitch,
+                                                                       float threshold, RowSpan rows)
+{
+	constexpr int TW = EdgeLumaTile::W, TH = EdgeLumaTile::H;
+	__shared__ float s_luma[TW * TH];
+	const int bx = blockIdx.x * FAST_BW, by = int(rows.first) + blockIdx.y * FAST_BH;
+	for (int i = threadIdx.y * FAST_BW + threadIdx.x; i < TW * TH; i += FAST_BW * FAST_BH)
+	{
+		const int ty = i / TW, tx = i - ty * TW;
+		const uint32_t t = load_rgba8_clamped(in, in_pitch, w, h, bx - 2 + tx, by - 2 + ty);
+		s_luma[i] = aa::luma_of(aa::unorm8_decode(t & 255u), aa::unorm8_decode((t >> 8) & 255u), aa::unorm8_decode((t >> 16) & 255u), aa::SMAA_LUMA_R,
+		                        aa::SMAA_LUMA_G, aa::SMAA_LUMA_B);
+	}
+	__syncthreads();
+	const int x = bx + threadIdx.x, y = by + threadIdx.y;
+	if (x >= w || y >= int(rows.end))
+		return;
+	const EdgeLumaTile tile = {s_luma, bx - 2, by - 2};
+	*reinterpret_cast<uint16_t *>(edges + (uint32_t(y) * edges_pitch + uint32_t(x) * 2u)) = uint16_t(aa::smaa_edges_pixel(tile, x, y, threshold));
+}
+
+struct ColorImage
+{
+	const uint8_t *ptr;
+	uint32_t pitch;
+	int w, h;
+	__device__ __forceinline__ uint32_t raw(int x, int y) const { return load_rgba8_clamped(ptr, pitch, w, h, x, y); }
+};
+
+// PX pixels per lane along x (PX = 4: 16-byte accesses; needs width % 4 == 0 and 16-byte aligned rows).  No LDS: a pixel
+// without weights -- nearly all of them -- is three weight texels and a copy; the few with weights take two one-axis lerps
+// of colour texels straight from the image.
+template <int PX>
+__global__ __launch_bounds__(256) void k_smaa_blend_fast(ColorImage color, ColorImage weights, uint8_t *out, uint32_t out_pitch, float rt_x, float rt_y,
+                                                          RowSpan rows)
+{
+	const int x0 = (blockIdx.x * 64 + threadIdx.x) * PX, y = int(rows.first) + blockIdx.y * 4 + threadIdx.y;
+	if (x0 >= color.w || y >= int(rows.end))
+		return;
+	const int yb = min(y + 1, color.h - 1);
+	uint32_t wc[PX + 1], wb[PX], col[PX];
+	if (PX == 4)
+	{
+		const uint4 a = *reinterpret_cast<const uint4 *>(weights.ptr + (uint32_t(y) * weights.pitch + uint32_t(x0) * 4u));
+		const uint4 b = *reinterpret_cast<const uint4 *>(weights.ptr + (uint32_t(yb) * weights.pitch + uint32_t(x0) * 4u));
+		const uint4 c = *reinterpret_cast<const uint4 *>(color.ptr + (uint32_t(y) * color.pitch + uint32_t(x0) * 4u));
+		wc[0] = a.x, wc[1] = a.y, wc[2] = a.z, wc[3] = a.w;
+		wb[0] = b.x, wb[1] = b.y, wb[2] = b.z, wb[3] = b.w;
+		col[0] = c.x, col[1] = c.y, col[2] = c.z, col[3] = c.w;
+		wc[PX] = weights.raw(x0 + PX, y);
+	}
+	else
+	{
+		wc[0] = weights.raw(x0, y);
+		wc[1] = weights.raw(x0 + 1, y);
+		wb[0] = weights.raw(x0, yb);
+		col[0] = color.raw(x0, y);
+	}
+	uint32_t result[PX];
+#pragma unroll
+	for (int i = 0; i < PX; i++)
+	{
+		// a = (right.a, bottom.g, this.b, this.r): all zero -> the colour texel itself
+		if (((wc[i + 1] >> 24) | ((wb[i] >> 8) & 255u) | ((wc[i] >> 16) & 255u) | (wc[i] & 255u)) == 0u)
+			result[i] = col[i];
+		else
+			result[i] = aa::smaa_blend_pixel(color, wc[i], wc[i + 1], wb[i], x0 + i, y, rt_x, rt_y, float(color.w), float(color.h));
+	}
+	uint8_t *dst = out + (uint32_t(y) * out_pitch + uint32_t(x0) * 4u);
+	if (PX == 4)
+		*reinterpret_cast<uint4 *>(dst) = make_uint4(result[0], result[1], result[2], result[3]);
+	else
+		*reinterpret_cast<uint32_t *>(dst) = result[0];
+}
+

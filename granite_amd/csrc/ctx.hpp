@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include "../../include/granite_hip.h"
+#include "row_span.hpp"
 
 struct gr_timing_span
 {
@@ -32,6 +33,9 @@ struct gr_ctx
 	// SMAA lookup tables (assets/textures/smaa/{area,search}.gtx payloads), uploaded through gr_smaa_set_luts.
 	void *smaa_area = nullptr;   // 160 x 560 x 2 floats (the RG8 area texture, decoded)
 	void *smaa_search = nullptr; // 64 x 16 floats (the R8 search texture, decoded)
+
+	// aa.hip: (axis length, 1 / length bits) -> "pixel-centre taps along this axis are texel fetches" (aa_core.hpp: axis_taps_exact)
+	std::map<uint64_t, bool> centre_taps_exact;
 
 	bool timing_enabled = false;
 	std::string timing_filter; // empty = every launcher
@@ -131,11 +135,6 @@ static inline hipStream_t gr_to_stream(gr_stream s) { return static_cast<hipStre
 static inline unsigned gr_div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 // Resolves a render area (gr_rows) against `height` output rows: [first, end), empty when the band lies outside the image.
-struct RowSpan
-{
-	uint32_t first, end;
-	uint32_t count() const { return end - first; }
-};
 static inline RowSpan resolve_rows(const gr_rows *rows, uint32_t height)
 {
 	if (!rows || rows->count == 0)

@@ -34,15 +34,13 @@ struct Tex8
 	}
 	vec4 sample(vec2 uv, int ox = 0, int oy = 0) const
 	{
-		float fx = uv.x * float(w) - 0.5f;
-		float fy = uv.y * float(h) - 0.5f;
-		float flx = floorf(fx), fly = floorf(fy);
-		float a = fx - flx, b = fy - fly;
-		int x0 = int(flx) + ox, y0 = int(fly) + oy;
-		vec4 t00 = fetch(x0, y0), t10 = fetch(x0 + 1, y0), t01 = fetch(x0, y0 + 1), t11 = fetch(x0 + 1, y0 + 1);
-		vec4 top = t00 * (1.0f - a) + t10 * a;
-		vec4 bot = t01 * (1.0f - a) + t11 * a;
-		return top * (1.0f - b) + bot * b;
+		float a, b;
+		int x0, y0;
+		linear_axis(uv.x * float(w) - 0.5f, x0, a);
+		linear_axis(uv.y * float(h) - 0.5f, y0, b);
+		x0 += ox;
+		y0 += oy;
+		return linear_combine(fetch(x0, y0), fetch(x0 + 1, y0), fetch(x0, y0 + 1), fetch(x0 + 1, y0 + 1), a, b);
 	}
 };
 

@@ -259,8 +259,37 @@ static inline vec4 unpack_a2b10g10r10(uint32_t p)
 // ---------------------------------------------------------------------------------------------
 // Software sampler over an RGBA16F linear image: StockSampler::LinearClamp / NearestClamp
 // (vulkan/device.cpp:1142-1149), explicit LOD 0, unnormalised coord = uv*size-0.5, exact fp32
-// weights (Vulkan leaves weight precision implementation-defined; tolerance is stated in tests).
+// weights outside the sub-texel snap below (Vulkan leaves weight precision implementation-defined;
+// tolerance is stated in tests).
 // ---------------------------------------------------------------------------------------------
+// Sub-texel resolution of the sampler.  Vulkan leaves the precision of bilinear weights to the implementation
+// (subTexelPrecisionBits; every desktop implementation, lavapipe included, reports 8).  The model here: weights are exact
+// fp32, EXCEPT that a coordinate within 2^-8 of a texel centre selects that texel alone -- no implementation with <= 8
+// fractional coordinate bits can resolve it from the centre, and the fp32 round trip (x + 0.5) / w * w - 0.5 of a pixel-centre
+// tap (error <= 3 x 2^-24 ~ 1.5e-3 texels at x = 8192) then reads the texel itself at any image width, as a hardware sampler
+// does.  A weight of exactly zero means the neighbouring texel is not part of the result (no 0 * inf).
+// linear_axis: f = unnormalised coordinate - 0.5; returns the index of the first texel and the weight of the second.
+constexpr float SAMPLER_SNAP = 1.0f / 256.0f;
+static inline void linear_axis(float f, int &i0, float &weight)
+{
+	const float fl = floorf(f + SAMPLER_SNAP);
+	float a = f - fl;
+	if (a < SAMPLER_SNAP)
+		a = 0.0f;
+	i0 = int(fl);
+	weight = a;
+}
+// The two lerps of a bilinear fetch in the order every sampler of the oracle uses; T has +, * float.
+template <typename T>
+static inline T linear_combine(const T &t00, const T &t10, const T &t01, const T &t11, float a, float b)
+{
+	const T top = (a == 0.0f) ? t00 : t00 * (1.0f - a) + t10 * a;
+	if (b == 0.0f)
+		return top;
+	const T bot = (a == 0.0f) ? t01 : t01 * (1.0f - a) + t11 * a;
+	return top * (1.0f - b) + bot * b;
+}
+
 struct Tex16F
 {
 	const uint16_t *data;
@@ -273,15 +302,11 @@ struct Tex16F
 	}
 	vec4 sample_linear(vec2 uv) const
 	{
-		float u = uv.x * float(w) - 0.5f;
-		float v = uv.y * float(h) - 0.5f;
-		float fu = floorf(u), fv = floorf(v);
-		float a = u - fu, b = v - fv;
-		int x0 = int(fu), y0 = int(fv);
-		vec4 t00 = fetch(x0, y0), t10 = fetch(x0 + 1, y0), t01 = fetch(x0, y0 + 1), t11 = fetch(x0 + 1, y0 + 1);
-		vec4 top = t00 * (1.0f - a) + t10 * a;
-		vec4 bot = t01 * (1.0f - a) + t11 * a;
-		return top * (1.0f - b) + bot * b;
+		float a, b;
+		int x0, y0;
+		linear_axis(uv.x * float(w) - 0.5f, x0, a);
+		linear_axis(uv.y * float(h) - 0.5f, y0, b);
+		return linear_combine(fetch(x0, y0), fetch(x0 + 1, y0), fetch(x0, y0 + 1), fetch(x0 + 1, y0 + 1), a, b);
 	}
 	vec4 sample_nearest(vec2 uv) const
 	{

@@ -805,14 +805,12 @@ struct OrcLightingArgs
 static float sample_ambient_occlusion(const OrcLightingArgs *a, float u, float v)
 {
 	const int w = a->ao_width, h = a->ao_height;
-	const float fx = u * float(w) - 0.5f, fy = v * float(h) - 0.5f;
-	const float flx = floorf(fx), fly = floorf(fy);
-	const float wx = fx - flx, wy = fy - fly;
+	float wx, wy;
+	int x0, y0;
+	linear_axis(u * float(w) - 0.5f, x0, wx);
+	linear_axis(v * float(h) - 0.5f, y0, wy);
 	auto texel = [&](int x, int y) { return float(a->ambient_occlusion[size_t(clampi(y, 0, h - 1)) * w + clampi(x, 0, w - 1)]) / 255.0f; };
-	const int x0 = int(flx), y0 = int(fly);
-	const float top = texel(x0, y0) * (1.0f - wx) + texel(x0 + 1, y0) * wx;
-	const float bottom = texel(x0, y0 + 1) * (1.0f - wx) + texel(x0 + 1, y0 + 1) * wx;
-	return top * (1.0f - wy) + bottom * wy;
+	return linear_combine(texel(x0, y0), texel(x0 + 1, y0), texel(x0, y0 + 1), texel(x0 + 1, y0 + 1), wx, wy);
 }
 
 // DeferredLightRenderer::render_light (renderer.cpp:1004-1156): directional quad then clustered quad, each blended

@@ -211,14 +211,11 @@ void orc_blit(const void *in, int iw, int ih, int in_format, void *out, int ow, 
 			vec4 c;
 			if (linear)
 			{
-				const float u = uv.x * float(iw) - 0.5f, v = uv.y * float(ih) - 0.5f;
-				const float fu = floorf(u), fv = floorf(v);
-				const float a = u - fu, b = v - fv;
-				const int x0 = int(fu), y0 = int(fv);
-				const vec4 t00 = texel(x0, y0), t10 = texel(x0 + 1, y0), t01 = texel(x0, y0 + 1), t11 = texel(x0 + 1, y0 + 1);
-				const vec4 top = t00 * (1.0f - a) + t10 * a;
-				const vec4 bot = t01 * (1.0f - a) + t11 * a;
-				c = top * (1.0f - b) + bot * b;
+				float a, b;
+				int x0, y0;
+				linear_axis(uv.x * float(iw) - 0.5f, x0, a);
+				linear_axis(uv.y * float(ih) - 0.5f, y0, b);
+				c = linear_combine(texel(x0, y0), texel(x0 + 1, y0), texel(x0, y0 + 1), texel(x0 + 1, y0 + 1), a, b);
 			}
 			else
 				c = texel(int(floorf(uv.x * float(iw))), int(floorf(uv.y * float(ih))));

@@ -503,18 +503,17 @@ void orc_ssr_apply(int width, int height, const uint16_t *reflected, const uint3
 			// fresnel_ibl (pbr.h): F0 + (max(vec3(1 - roughness), F0) - F0) * pow(1 - cos_theta, 5)
 			const vec3 F = F0 + (max3(V3(1.0f - roughness), F0) - F0) * powf(1.0f - NoV, 5.0f);
 			// textureLod(uBRDFLut, vec2(NoV, roughness), 0): LinearClamp on RG16F
-			const float fx = NoV * float(lut_w) - 0.5f, fy = roughness * float(lut_h) - 0.5f;
-			const float flx = floorf(fx), fly = floorf(fy);
-			const float wa = fx - flx, wb = fy - fly;
-			const int x0 = clampi(int(flx), 0, lut_w - 1), x1 = clampi(int(flx) + 1, 0, lut_w - 1);
-			const int y0 = clampi(int(fly), 0, lut_h - 1), y1 = clampi(int(fly) + 1, 0, lut_h - 1);
+			float wa, wb;
+			int ix, iy;
+			linear_axis(NoV * float(lut_w) - 0.5f, ix, wa);
+			linear_axis(roughness * float(lut_h) - 0.5f, iy, wb);
+			const int x0 = clampi(ix, 0, lut_w - 1), x1 = clampi(ix + 1, 0, lut_w - 1);
+			const int y0 = clampi(iy, 0, lut_h - 1), y1 = clampi(iy + 1, 0, lut_h - 1);
 			auto lut = [&](int lx, int ly) {
 				const uint16_t *p = brdf_lut_rg16f + (size_t(ly) * lut_w + lx) * 2;
 				return V2(half_to_float(p[0]), half_to_float(p[1]));
 			};
-			const vec2 top = lut(x0, y0) * (1.0f - wa) + lut(x1, y0) * wa;
-			const vec2 bot = lut(x0, y1) * (1.0f - wa) + lut(x1, y1) * wa;
-			const vec2 brdf = top * (1.0f - wb) + bot * wb;
+			const vec2 brdf = linear_combine(lut(x0, y0), lut(x1, y0), lut(x0, y1), lut(x1, y1), wa, wb);
 			const vec4 r = load_rgba16f(reflected, width, x, y); // NearestClamp at the pixel centre
 			const vec3 color = V3(r.x, r.y, r.z) * (F * brdf.x + V3(brdf.y));
 			// blend ONE / ONE into the RGBA16F target; alpha untouched (the shader writes a vec3)

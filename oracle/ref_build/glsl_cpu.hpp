@@ -603,15 +603,16 @@ struct Texture
 
 	vec4 sample(const vec2 &uv, int ox = 0, int oy = 0) const
 	{
-		const float fx = uv.x * float(w) - 0.5f, fy = uv.y * float(h) - 0.5f;
-		const float flx = floorf(fx), fly = floorf(fy);
 		if (filter == Filter::Nearest)
 			return texel(int(floorf(uv.x * float(w))) + ox, int(floorf(uv.y * float(h))) + oy);
-		const float a = fx - flx, b = fy - fly;
-		const int x0 = int(flx) + ox, y0 = int(fly) + oy;
-		const vec4 top = texel(x0, y0) * (1.0f - a) + texel(x0 + 1, y0) * a;
-		const vec4 bottom = texel(x0, y0 + 1) * (1.0f - a) + texel(x0 + 1, y0 + 1) * a;
-		return top * (1.0f - b) + bottom * b;
+		// the sampler model stated once in oracle_common.h: exact fp32 weights + the sub-texel snap onto texel centres
+		float a, b;
+		int x0, y0;
+		orc::linear_axis(uv.x * float(w) - 0.5f, x0, a);
+		orc::linear_axis(uv.y * float(h) - 0.5f, y0, b);
+		x0 += ox;
+		y0 += oy;
+		return orc::linear_combine(texel(x0, y0), texel(x0 + 1, y0), texel(x0, y0 + 1), texel(x0 + 1, y0 + 1), a, b);
 	}
 };
 using sampler2D = Texture;

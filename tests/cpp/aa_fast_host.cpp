@@ -1,0 +1,48 @@
+// TEST INFRASTRUCTURE.  Runs the fast anti-aliasing kernels of granite_amd/csrc/aa_fast_kernels.hpp -- the text the GPU build
+// compiles -- on the CPU through tests/cpp/hip_emu.hpp, with the launch geometry of the launchers in aa.hip.  Built by
+// tests/test_aa_fast_kernels_cpu.py with g++ -ffp-contract=off and compared with the oracle bit for bit.
+#include "hip_emu.hpp"
+#include "../../granite_amd/csrc/aa_fast_kernels.hpp"
+
+static unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+static RowSpan span_of(int h, int first, int count)
+{
+	if (count <= 0)
+		return {0u, uint32_t(h)};
+	const uint32_t f = uint32_t(std::min(first, h)), e = uint32_t(std::min(first + count, h));
+	return {f, e};
+}
+
+extern "C" {
+int aah_centre_taps_exact(int n, float inv)
+{
+	static const int ks[] = {-2, -1, 0, 1, 2};
+	return aa::axis_taps_exact(n, inv, ks, 5) ? 1 : 0;
+}
+
+void aah_fxaa(const uint8_t *in, int w, int h, uint8_t *out, int row_first, int row_count)
+{
+	const RowSpan rows = span_of(h, row_first, row_count);
+	emu::launch(k_fxaa_fast, dim3(div_up(w, FAST_BW), div_up(rows.count(), FAST_BH)), dim3(FAST_BW, FAST_BH), in, uint32_t(w * 4), w, h, out, uint32_t(w * 4),
+	            1.0f / float(w), 1.0f / float(h), rows);
+}
+
+void aah_smaa_edges(const uint8_t *in, int w, int h, uint8_t *edges, float threshold, int row_first, int row_count)
+{
+	const RowSpan rows = span_of(h, row_first, row_count);
+	emu::launch(k_smaa_edges_fast, dim3(div_up(w, FAST_BW), div_up(rows.count(), FAST_BH)), dim3(FAST_BW, FAST_BH), in, uint32_t(w * 4), w, h, edges,
+	            uint32_t(w * 2), threshold, rows);
+}
+
+void aah_smaa_blend(const uint8_t *color, const uint8_t *weights, int w, int h, uint8_t *out, int wide, int row_first, int row_count)
+{
+	const RowSpan rows = span_of(h, row_first, row_count);
+	const ColorImage c = {color, uint32_t(w * 4), w, h}, b = {weights, uint32_t(w * 4), w, h};
+	if (wide)
+		emu::launch(k_smaa_blend_fast<4>, dim3(div_up(w, 256), div_up(rows.count(), 4)), dim3(64, 4), c, b, out, uint32_t(w * 4), 1.0f / float(w),
+		            1.0f / float(h), rows);
+	else
+		emu::launch(k_smaa_blend_fast<1>, dim3(div_up(w, 64), div_up(rows.count(), 4)), dim3(64, 4), c, b, out, uint32_t(w * 4), 1.0f / float(w),
+		            1.0f / float(h), rows);
+}
+}

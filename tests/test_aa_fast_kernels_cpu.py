@@ -1,0 +1,107 @@
+"""CPU: the fast anti-aliasing kernels (granite_amd/csrc/aa_fast_kernels.hpp, the text the GPU build compiles) run through the
+host emulation of tests/cpp/hip_emu.hpp -- a thread per lane, barriers and votes as rendezvous -- and must equal the oracle bit
+for bit: what is checked here is the kernels' tiling, halo staging, clamping at the image border, row bands and the per-pixel
+arithmetic of aa_core.hpp; what a GPU run adds is the compiler and the hardware."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from granite_amd import synth
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRESET_THRESHOLD = (0.15, 0.1, 0.1, 0.05)  # SMAA.hlsl:304-324
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("aa_fast_host") / "libaa_fast_host.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                           os.path.join(ROOT, "tests", "cpp", "aa_fast_host.cpp"), "-o", so])
+    lib = C.CDLL(so)
+    lib.aah_centre_taps_exact.argtypes = [C.c_int, C.c_float]
+    lib.aah_centre_taps_exact.restype = C.c_int
+    return lib
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def noisy(w, h, seed=7):
+    """Blocky random gamma-space bytes with single-pixel speckle: every pixel is an edge candidate (tests/test_gpu_aa.py)."""
+    r = np.random.default_rng(seed)
+    coarse = r.integers(0, 256, ((h + 2) // 3, (w + 2) // 3, 4), dtype=np.uint8)
+    img = np.repeat(np.repeat(coarse, 3, axis=0), 3, axis=1)[:h, :w].copy()
+    fine = r.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    mask = r.random((h, w)) < 0.3
+    img[mask] = fine[mask]
+    img[..., 3] = 255
+    return img
+
+
+SIZES = [(70, 40, "pattern"), (67, 35, "noise"), (33, 17, "pattern"), (8, 8, "noise"), (96, 20, "noise")]
+
+
+def source(w, h, kind):
+    return synth.make_ldr_pattern(w, h) if kind == "pattern" else noisy(w, h)
+
+
+def test_pixel_centre_taps_are_texel_fetches_at_every_size_in_use(host):
+    """The launchers' guard (aa_core.hpp: axis_taps_exact) holds for every axis length up to 8K and for the sizes of the
+    multi-GPU weak-scaling frames; it fails where the fp32 round trip of a pixel centre leaves the snap radius."""
+    for n in list(range(1, 600)) + [1080, 1920, 2160, 3840, 4320, 7680, 8640]:
+        assert host.aah_centre_taps_exact(n, np.float32(1.0) / np.float32(n)), n
+    assert not host.aah_centre_taps_exact(100000, np.float32(1.0) / np.float32(100000))
+
+
+@pytest.mark.parametrize("w,h,kind", SIZES)
+def test_fxaa_kernel_equals_oracle(host, w, h, kind):
+    src = source(w, h, kind)
+    out = np.zeros_like(src)
+    host.aah_fxaa(p(src), w, h, p(out), 0, 0)
+    np.testing.assert_array_equal(out, orc.fxaa(src, False))
+
+
+def test_fxaa_kernel_row_band(host):
+    w, h = 70, 61
+    src = noisy(w, h, 3)
+    ref = orc.fxaa(src, False)
+    out = np.full_like(src, 0xAB)
+    host.aah_fxaa(p(src), w, h, p(out), 19, 23)
+    np.testing.assert_array_equal(out[19:42], ref[19:42])
+    assert (out[:19] == 0xAB).all() and (out[42:] == 0xAB).all()
+
+
+@pytest.mark.parametrize("quality", [0, 3])
+@pytest.mark.parametrize("w,h,kind", SIZES)
+def test_smaa_edge_kernel_equals_oracle(host, w, h, kind, quality):
+    src = source(w, h, kind)
+    edges = np.full((h, w, 2), 0xCD, np.uint8)
+    host.aah_smaa_edges(p(src), w, h, p(edges), C.c_float(PRESET_THRESHOLD[quality]), 0, 0)
+    ref = orc.smaa_edges(src, quality)
+    np.testing.assert_array_equal(edges, ref)
+    assert ref.any()
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("w,h,kind", [(72, 40, "pattern"), (68, 36, "noise"), (8, 8, "noise"), (67, 35, "noise")])
+def test_smaa_blend_kernel_equals_oracle(host, w, h, kind, wide):
+    if wide and w % 4:
+        pytest.skip("the 4-pixel form needs width % 4 == 0")
+    from granite_amd.data import load_smaa_luts
+    area, search = load_smaa_luts()
+    src = source(w, h, kind)
+    ref = orc.smaa(src, area, search, 3, False)
+    out = np.zeros_like(src)
+    host.aah_smaa_blend(p(src), p(ref["weights"]), w, h, p(out), wide, 0, 0)
+    np.testing.assert_array_equal(out, ref["out"])
+    assert (out != src).any()
+    # a band
+    out2 = np.full_like(src, 0x11)
+    host.aah_smaa_blend(p(src), p(ref["weights"]), w, h, p(out2), wide, 5, 13)
+    np.testing.assert_array_equal(out2[5:18], ref["out"][5:18])
+    assert (out2[:5] == 0x11).all() and (out2[18:] == 0x11).all()
