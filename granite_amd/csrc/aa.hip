@@ -734,281 +734,7 @@ static bool use_fast_aa(gr_ctx *ctx, uint32_t w, uint32_t h, float inv_w, float 
 	return !forced_generic && centre_taps_exact(ctx, w, inv_w) && centre_taps_exact(ctx, h, inv_h);
 }
 
-// ---- TAA resolve (taa_resolve.frag + reprojection.h) -------------------------------------------------------------------------
-__device__ __forceinline__ v3 taa_tonemap(v3 c)
-{
-	c = c * 8.0f;
-	return c * (1.0f / (fmaxf(c.x, fmaxf(c.y, c.z)) + 1.0f));
-}
-__device__ __forceinline__ v3 taa_tonemap_invert(v3 c)
-{
-	return (1.0f / 8.0f) * c * (1.0f / (1.0f - fmaxf(c.x, fmaxf(c.y, c.z))));
-}
-__device__ __forceinline__ v3 rgb_to_ycgco(v3 c)
-{
-	return mk3(0.25f * c.x + 0.5f * c.y + 0.25f * c.z, 0.5f * c.y - 0.25f * c.x - 0.25f * c.z, 0.5f * c.x - 0.5f * c.z);
-}
-__device__ __forceinline__ v3 ycgco_to_rgb(v3 c)
-{
-	const float tmp = c.x - c.y;
-	return mk3(tmp + c.z, c.x + c.y, tmp - c.z);
-}
-__device__ __forceinline__ v3 hdr_to_taa(v3 c) { return rgb_to_ycgco(taa_tonemap(c)); }
-__device__ __forceinline__ v3 taa_to_hdr(v3 c)
-{
-	const v3 r = ycgco_to_rgb(c);
-	return taa_tonemap_invert(mk3(clampfv(r.x, 0.0f, 0.999f), clampfv(r.y, 0.0f, 0.999f), clampfv(r.z, 0.0f, 0.999f)));
-}
-__device__ __forceinline__ v3 clamp_box(v3 color, v3 lo, v3 hi, bool aabb)
-{
-	if (!aabb)
-		return mk3(clampfv(color.x, lo.x, hi.x), clampfv(color.y, lo.y, hi.y), clampfv(color.z, lo.z, hi.z));
-	const v3 center = 0.5f * (lo + hi);
-	const v3 radius = max3v(0.5f * (hi - lo), mk3(0.0001f, 0.0001f, 0.0001f));
-	const v3 v = color - center;
-	const v3 units = v / radius;
-	const float max_unit = fmaxf(fmaxf(fabsf(units.x), fabsf(units.y)), fabsf(units.z));
-	return max_unit > 1.0f ? center + v / max_unit : color;
-}
-
-struct TaaArgs
-{
-	DevImage current, depth, mv, history;
-	DevImageRW out_color, out_history;
-	float reproj[16];
-	float rt[4];
-	int quality;
-	int has_history;
-	RowSpan rows;
-};
-
-// One history texel (clamp-to-edge), addressed with a 32-bit offset from the uniform base (images stay below 4 GiB).
-__device__ __forceinline__ v3 history_texel(const DevImage &img, int x, int y)
-{
-	const uint32_t offset = uint32_t(clampi(y, 0, img.h - 1)) * img.pitch + uint32_t(clampi(x, 0, img.w - 1)) * 8u;
-	const f16x4 t = *reinterpret_cast<const f16x4 *>(img.ptr + offset);
-	return mk3(float(t.x), float(t.y), float(t.z));
-}
-
-__device__ __forceinline__ v3 sample_linear3(const DevImage &img, float u, float v)
-{
-	int ix, iy;
-	float a, b;
-	aa::linear_axis(u * float(img.w) - 0.5f, ix, a);
-	aa::linear_axis(v * float(img.h) - 0.5f, iy, b);
-	const v3 t00 = history_texel(img, ix, iy), t10 = history_texel(img, ix + 1, iy);
-	const v3 t01 = history_texel(img, ix, iy + 1), t11 = history_texel(img, ix + 1, iy + 1);
-	const v3 top = t00 * (1.0f - a) + t10 * a;
-	const v3 bot = t01 * (1.0f - a) + t11 * a;
-	return top * (1.0f - b) + bot * b;
-}
-
-// The 3 x 3 neighbourhood of every pixel of a 32 x 8 block comes out of LDS: the 34 x 10 texels around the block are
-// fetched, clamped to the image and converted to the resolve's colour space ONCE (instead of up to nine times each), depth
-// beside them.  QUALITY / HISTORY are compile-time: the three qualities differ in how much of the neighbourhood they use.
-constexpr int TAA_TILE_W = AA_BLOCK_X + 2, TAA_TILE_H = AA_BLOCK_Y + 2;
-
-template <int QUALITY, bool HISTORY>
-__global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_taa_resolve(TaaArgs a)
-{
-	__shared__ float s_cur[3][TAA_TILE_H][TAA_TILE_W];
-	__shared__ float s_depth[TAA_TILE_H][TAA_TILE_W];
-	const int w = a.current.w, h = a.current.h;
-	const int x0 = blockIdx.x * AA_BLOCK_X, y0 = int(a.rows.first) + blockIdx.y * AA_BLOCK_Y;
-	const int lx = threadIdx.x, ly = threadIdx.y;
-	if (HISTORY)
-	{
-		for (int i = ly * AA_BLOCK_X + lx; i < TAA_TILE_W * TAA_TILE_H; i += AA_BLOCK_X * AA_BLOCK_Y)
-		{
-			const int ty = i / TAA_TILE_W, tx = i - ty * TAA_TILE_W;
-			const int px = clampi(x0 + tx - 1, 0, w - 1), py = clampi(y0 + ty - 1, 0, h - 1);
-			const float4 t = load_rgba16f(a.current, px, py);
-			const v3 c = hdr_to_taa(mk3(t.x, t.y, t.z));
-			s_cur[0][ty][tx] = c.x;
-			s_cur[1][ty][tx] = c.y;
-			s_cur[2][ty][tx] = c.z;
-			s_depth[ty][tx] = *reinterpret_cast<const float *>(a.depth.ptr + uint32_t(py) * a.depth.pitch + uint32_t(px) * 4u);
-		}
-		__syncthreads();
-	}
-	const int x = x0 + lx, y = y0 + ly;
-	if (x >= w || y >= int(a.rows.end))
-		return;
-	const v4 rt = mk4(a.rt[0], a.rt[1], a.rt[2], a.rt[3]);
-	const v2 uv = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
-	auto cur_at = [&](int ox, int oy) { return mk3(s_cur[0][ly + 1 + oy][lx + 1 + ox], s_cur[1][ly + 1 + oy][lx + 1 + ox], s_cur[2][ly + 1 + oy][lx + 1 + ox]); };
-	auto depth_at = [&](int ox, int oy) { return s_depth[ly + 1 + oy][lx + 1 + ox]; };
-
-	v3 out_c, hist_c;
-	if (!HISTORY)
-	{
-		const float4 t = load_rgba16f(a.current, x, y);
-		const v3 current_c = hdr_to_taa(mk3(t.x, t.y, t.z));
-		out_c = taa_to_hdr(current_c);
-		hist_c = current_c;
-	}
-	else
-	{
-		const v3 current_c = cur_at(0, 0);
-		// Motion vector of the nearest-depth pixel of the neighbourhood (first wins on ties, in the shader's order).
-		int mx, my;
-		float d;
-		auto consider = [&](int ox, int oy) {
-			const float dd = depth_at(ox, oy);
-			if (dd > d)
-			{
-				mx = ox;
-				my = oy;
-				d = dd;
-			}
-		};
-		if (QUALITY <= 1)
-		{
-			mx = -1;
-			my = 0;
-			d = depth_at(-1, 0);
-			consider(0, 0);
-			consider(0, -1);
-			consider(0, 1);
-			consider(1, 0);
-		}
-		else
-		{
-			mx = 1;
-			my = 1;
-			d = depth_at(1, 1);
-			consider(-1, 0);
-			consider(0, 0);
-			consider(0, -1);
-			consider(-1, -1);
-			consider(1, 0);
-			consider(1, -1);
-			consider(-1, 1);
-			consider(0, 1);
-		}
-		const f16x2 m = *reinterpret_cast<const f16x2 *>(a.mv.ptr + uint32_t(clampi(y + my, 0, h - 1)) * a.mv.pitch + uint32_t(clampi(x + mx, 0, w - 1)) * 4u);
-		v2 mv = mk2(float(m.x), float(m.y));
-
-		v2 old_uv;
-		if (mv.x == 0.0f && mv.y == 0.0f)
-		{
-			const float cx = 2.0f * uv.x - 1.0f, cy = 2.0f * uv.y - 1.0f;
-			v4 rp = mk4(a.reproj[0], a.reproj[1], a.reproj[2], a.reproj[3]) * cx;
-			rp = rp + mk4(a.reproj[4], a.reproj[5], a.reproj[6], a.reproj[7]) * cy;
-			rp = rp + mk4(a.reproj[8], a.reproj[9], a.reproj[10], a.reproj[11]) * d;
-			rp = rp + mk4(a.reproj[12], a.reproj[13], a.reproj[14], a.reproj[15]) * 1.0f;
-			old_uv = mk2(rp.x / rp.w, rp.y / rp.w);
-			mv = uv - old_uv;
-		}
-		else
-			old_uv = uv - mv;
-
-		v3 history_color;
-		if (QUALITY == 2)
-		{
-			const v2 samplePos = mk2(old_uv.x * rt.z, old_uv.y * rt.w);
-			const v2 texPos1 = mk2(floorf(samplePos.x - 0.5f) + 0.5f, floorf(samplePos.y - 0.5f) + 0.5f);
-			const v2 f = samplePos - texPos1;
-			auto W0 = [](float t) { return t * (-0.5f + t * (1.0f - 0.5f * t)); };
-			auto W1 = [](float t) { return 1.0f + t * t * (-2.5f + 1.5f * t); };
-			auto W2 = [](float t) { return t * (0.5f + t * (2.0f - 1.5f * t)); };
-			auto W3 = [](float t) { return t * t * (-0.5f + 0.5f * t); };
-			const v2 w0 = mk2(W0(f.x), W0(f.y)), w1 = mk2(W1(f.x), W1(f.y)), w2 = mk2(W2(f.x), W2(f.y)), w3 = mk2(W3(f.x), W3(f.y));
-			const v2 w12 = w1 + w2;
-			const v2 offset12 = w2 / (w1 + w2);
-			const v2 texPos0 = (texPos1 - mk2(1.0f, 1.0f)) * mk2(rt.x, rt.y);
-			const v2 texPos3 = (texPos1 + mk2(2.0f, 2.0f)) * mk2(rt.x, rt.y);
-			const v2 texPos12 = (texPos1 + offset12) * mk2(rt.x, rt.y);
-			// Nine bilinear taps on a 3 x 3 grid of positions: the column / row indices, clamps, weights and byte offsets are
-			// worked out once per axis (three positions x two texels) instead of once per tap.  Each tap is sample_linear3()
-			// statement for statement.
-			const float px[3] = {texPos0.x, texPos12.x, texPos3.x}, py[3] = {texPos0.y, texPos12.y, texPos3.y};
-			const float wx[3] = {w0.x, w12.x, w3.x}, wy[3] = {w0.y, w12.y, w3.y};
-			uint32_t col[3][2], row[3][2];
-			float fa[3], fb[3];
-#pragma unroll
-			for (int i = 0; i < 3; i++)
-			{
-				int ix, iy;
-				aa::linear_axis(px[i] * float(a.history.w) - 0.5f, ix, fa[i]);
-				aa::linear_axis(py[i] * float(a.history.h) - 0.5f, iy, fb[i]);
-				col[i][0] = uint32_t(clampi(ix, 0, w - 1)) * 8u;
-				col[i][1] = uint32_t(clampi(ix + 1, 0, w - 1)) * 8u;
-				row[i][0] = uint32_t(clampi(iy, 0, h - 1)) * a.history.pitch;
-				row[i][1] = uint32_t(clampi(iy + 1, 0, h - 1)) * a.history.pitch;
-			}
-			// Each tap: sample_linear3()'s lerps with the fp16 -> fp32 conversion folded into the multiply-add (v_fma_mix_f32) and
-			// the two weights of the tap multiplied first -- 22 instructions per tap instead of 48.  Against the statement-for-statement
-			// form this re-associates two products and drops three intermediate roundings per channel: a few fp32 ulps on a value
-			// that is stored as fp16 (the resolve's tolerance is 3 ulp fp16).
-			auto texel = [&](uint32_t offset) { return *reinterpret_cast<const uint2 *>(a.history.ptr + offset); };
-			v3 r = mk3(0.0f, 0.0f, 0.0f);
-#pragma unroll
-			for (int j = 0; j < 3; j++)
-#pragma unroll
-				for (int i = 0; i < 3; i++)
-				{
-					const uint2 t00 = texel(row[j][0] + col[i][0]), t10 = texel(row[j][0] + col[i][1]);
-					const uint2 t01 = texel(row[j][1] + col[i][0]), t11 = texel(row[j][1] + col[i][1]);
-					const float wa = fa[i], oma = 1.0f - fa[i], wb = fb[j], omb = 1.0f - fb[j];
-					const float wxy = wx[i] * wy[j];
-					const float top_r = fma_mix_lo(t10.x, wa, fma_mix_lo(t00.x, oma, 0.0f)), bot_r = fma_mix_lo(t11.x, wa, fma_mix_lo(t01.x, oma, 0.0f));
-					const float top_g = fma_mix_hi(t10.x, wa, fma_mix_hi(t00.x, oma, 0.0f)), bot_g = fma_mix_hi(t11.x, wa, fma_mix_hi(t01.x, oma, 0.0f));
-					const float top_b = fma_mix_lo(t10.y, wa, fma_mix_lo(t00.y, oma, 0.0f)), bot_b = fma_mix_lo(t11.y, wa, fma_mix_lo(t01.y, oma, 0.0f));
-					r.x = fmaf(fmaf(bot_r, wb, top_r * omb), wxy, r.x);
-					r.y = fmaf(fmaf(bot_g, wb, top_g * omb), wxy, r.y);
-					r.z = fmaf(fmaf(bot_b, wb, top_b * omb), wxy, r.z);
-				}
-			history_color = r;
-		}
-		else
-			history_color = sample_linear3(a.history, old_uv.x, old_uv.y);
-
-		const float mv_length = len2(mv);
-		const float mv_fast = fminf(mv_length * 50.0f, 1.0f);
-		const float gamma = mixf(1.5f, 0.5f, mv_fast);
-		history_color = mk3(clampfv(history_color.x, 0.0f, 1.0f), clampfv(history_color.y, -1.0f, 1.0f), clampfv(history_color.z, -1.0f, 1.0f));
-		const float lerp_factor = (1.0f + 2.0f * mv_fast) / 16.0f;
-
-		const v3 c11 = current_c;
-		const v3 c01 = cur_at(-1, 0), c21 = cur_at(1, 0), c10 = cur_at(0, -1), c12 = cur_at(0, 1);
-		v3 lo, hi;
-		if (QUALITY == 0)
-		{
-			lo = min3v(min3v(min3v(min3v(c11, c01), c21), c10), c12);
-			hi = max3v(max3v(max3v(max3v(c11, c01), c21), c10), c12);
-		}
-		else
-		{
-			const v3 c00 = cur_at(-1, -1), c22 = cur_at(1, 1), c02 = cur_at(-1, 1), c20 = cur_at(1, -1);
-			if (QUALITY == 1)
-			{
-				const v3 clo = min3v(min3v(min3v(min3v(c11, c01), c21), c10), c12);
-				const v3 chi = max3v(max3v(max3v(max3v(c11, c01), c21), c10), c12);
-				lo = min3v(min3v(min3v(min3v(clo, c00), c22), c02), c20);
-				hi = max3v(max3v(max3v(max3v(chi, c00), c22), c02), c20);
-				lo = 0.5f * (clo + lo);
-				hi = 0.5f * (chi + hi);
-			}
-			else
-			{
-				const v3 m1 = (c00 + 2.0f * c01 + c02 + 2.0f * c10 + 4.0f * c11 + 2.0f * c12 + c20 + 2.0f * c21 + c22) / 16.0f;
-				const v3 m2 = c00 * c00 + 2.0f * c01 * c01 + c02 * c02 + 2.0f * c10 * c10 + 4.0f * c11 * c11 + 2.0f * c12 * c12 + c20 * c20 +
-				              2.0f * c21 * c21 + c22 * c22;
-				const v3 variance = max3v(m2 / 16.0f - m1 * m1, mk3(0.0f, 0.0f, 0.0f));
-				const v3 sigma = mk3(sqrtf(variance.x), sqrtf(variance.y), sqrtf(variance.z));
-				lo = m1 - gamma * sigma;
-				hi = m1 + gamma * sigma;
-			}
-		}
-		history_color = clamp_box(history_color, lo, hi, QUALITY >= 1);
-		const v3 mixed = mix3(history_color, current_c, lerp_factor);
-		hist_c = mixed;
-		out_c = taa_to_hdr(mixed);
-	}
-	store_rgba16f(a.out_color, x, y, make_float4(out_c.x, out_c.y, out_c.z, 1.0f));
-	store_rgba16f(a.out_history, x, y, make_float4(hist_c.x, hist_c.y, hist_c.z, 1.0f));
-}
+// TAA resolve (taa_resolve.frag + reprojection.h): aa_core.hpp (taa_pixel) + aa_fast_kernels.hpp (k_taa_fast).
 
 // ---- blit (shaders/blit.frag: FragColor = textureLod(uTex, vUV, 0)) -----------------------------------------------------------
 // The full-screen copy Granite's tools use between targets of different size / format (tools/aa_bench.cpp:97-105,138-147).
@@ -1255,36 +981,40 @@ int gr_taa_resolve_rows(gr_ctx *ctx, gr_stream stream, const gr_image *current, 
 	GR_CHECK_ARG(ctx, check_image(out_color, 8, w, h) && out_color->format == GR_FORMAT_R16G16B16A16_SFLOAT);
 	GR_CHECK_ARG(ctx, check_image(out_history, 8, w, h) && out_history->format == GR_FORMAT_R16G16B16A16_SFLOAT);
 	GR_CHECK_ARG(ctx, !history || (check_image(history, 8, w, h) && history->format == GR_FORMAT_R16G16B16A16_SFLOAT && history->ptr != out_history->ptr));
-	auto dev = [](const gr_image *i) { return DevImage{static_cast<const uint8_t *>(i->ptr), int(i->width), int(i->height), i->pitch_bytes}; };
-	auto devrw = [](const gr_image *i) { return DevImageRW{static_cast<uint8_t *>(i->ptr), int(i->width), int(i->height), i->pitch_bytes}; };
-	TaaArgs a = {};
-	a.current = dev(current);
-	a.depth = dev(depth);
-	a.mv = dev(mv);
-	if (history)
-		a.history = dev(history);
-	a.out_color = devrw(out_color);
-	a.out_history = devrw(out_history);
-	for (int i = 0; i < 16; i++)
-		a.reproj[i] = push->reproj[i];
-	for (int i = 0; i < 4; i++)
-		a.rt[i] = push->rt_metrics[i];
-	a.quality = quality;
-	a.has_history = history != nullptr;
-	a.rows = resolve_rows(rows, h);
-	if (a.rows.count() == 0)
+	const RowSpan span = resolve_rows(rows, h);
+	if (span.count() == 0)
 		return GR_OK;
+	TaaImages im = {};
+	im.current = static_cast<const uint8_t *>(current->ptr);
+	im.depth = static_cast<const uint8_t *>(depth->ptr);
+	im.mv = static_cast<const uint8_t *>(mv->ptr);
+	im.history = history ? static_cast<const uint8_t *>(history->ptr) : nullptr;
+	im.out_color = static_cast<uint8_t *>(out_color->ptr);
+	im.out_history = static_cast<uint8_t *>(out_history->ptr);
+	im.current_pitch = current->pitch_bytes;
+	im.depth_pitch = depth->pitch_bytes;
+	im.mv_pitch = mv->pitch_bytes;
+	im.history_pitch = history ? history->pitch_bytes : 0u;
+	im.out_color_pitch = out_color->pitch_bytes;
+	im.out_history_pitch = out_history->pitch_bytes;
+	im.w = int(w);
+	im.h = int(h);
+	aa::TaaPush tp;
+	for (int i = 0; i < 16; i++)
+		tp.reproj[i] = push->reproj[i];
+	for (int i = 0; i < 4; i++)
+		tp.rt[i] = push->rt_metrics[i];
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "taa_resolve"};
-	const dim3 grid = aa_grid(w, a.rows.count()), block(AA_BLOCK_X, AA_BLOCK_Y);
+	const dim3 grid = fast_grid(w, span.count()), block(FAST_BW, FAST_BH);
 	hipStream_t s = gr_to_stream(stream);
 	if (!history)
-		hipLaunchKernelGGL((k_taa_resolve<0, false>), grid, block, 0, s, a);
+		hipLaunchKernelGGL((k_taa_fast<0, false>), grid, block, 0, s, im, tp, span);
 	else if (quality == 0)
-		hipLaunchKernelGGL((k_taa_resolve<0, true>), grid, block, 0, s, a);
+		hipLaunchKernelGGL((k_taa_fast<0, true>), grid, block, 0, s, im, tp, span);
 	else if (quality == 1)
-		hipLaunchKernelGGL((k_taa_resolve<1, true>), grid, block, 0, s, a);
+		hipLaunchKernelGGL((k_taa_fast<1, true>), grid, block, 0, s, im, tp, span);
 	else
-		hipLaunchKernelGGL((k_taa_resolve<2, true>), grid, block, 0, s, a);
+		hipLaunchKernelGGL((k_taa_fast<2, true>), grid, block, 0, s, im, tp, span);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

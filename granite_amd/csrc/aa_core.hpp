@@ -12,6 +12,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #define AA_HD __host__ __device__ __forceinline__
@@ -235,5 +236,319 @@ AA_HD uint32_t smaa_blend_pixel(const Color &c, uint32_t w_c, uint32_t w_r, uint
 	f4 r = {bwx * s0.x, bwx * s0.y, bwx * s0.z, bwx * s0.w};
 	r = {r.x + bwy * s1.x, r.y + bwy * s1.y, r.z + bwy * s1.z, r.w + bwy * s1.w};
 	return unorm8_encode(r.x) | (unorm8_encode(r.y) << 8) | (unorm8_encode(r.z) << 16) | (unorm8_encode(r.w) << 24);
+}
+
+// ---- fp16 storage helpers ------------------------------------------------------------------------------------------------------
+// Two halves in a dword, as RGBA16F / RG16F texels hold them.  On the device the conversion rides in v_fma_mix_f32 (exact
+// conversion + one fused multiply-add); the host form states the same arithmetic.
+#if defined(__HIP_DEVICE_COMPILE__)
+AA_HD float half_lo(uint32_t p) { return float(__builtin_bit_cast(_Float16, uint16_t(p & 0xffffu))); }
+AA_HD float half_hi(uint32_t p) { return float(__builtin_bit_cast(_Float16, uint16_t(p >> 16))); }
+AA_HD float mad_half_lo(uint32_t p, float w, float acc)
+{
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(w), "v"(acc));
+	return r;
+}
+AA_HD float mad_half_hi(uint32_t p, float w, float acc)
+{
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(w), "v"(acc));
+	return r;
+}
+AA_HD uint32_t pack_half2_rne(float lo, float hi)
+{
+	return uint32_t(__builtin_bit_cast(uint16_t, _Float16(lo))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(hi))) << 16);
+}
+AA_HD float approx_rcp(float v) { return __builtin_amdgcn_rcpf(v); }   // 1 ulp; used where the result is stored as fp16
+AA_HD float approx_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); } // 1 ulp
+#else
+inline float half_bits_to_float(uint32_t h)
+{
+	const uint32_t s = (h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+	uint32_t u;
+	if (e == 0)
+	{
+		const float v = float(m) * 5.9604644775390625e-08f;
+		return s ? -v : v;
+	}
+	u = e == 31 ? (s | 0x7f800000u | (m << 13)) : (s | ((e + 112u) << 23) | (m << 13));
+	float f;
+	memcpy(&f, &u, 4);
+	return f;
+}
+inline uint32_t float_to_half_bits_rne(float f)
+{
+	uint32_t u;
+	memcpy(&u, &f, 4);
+	const uint32_t s = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+	if (a >= 0x7f800000u)
+		return s | 0x7c00u | ((a > 0x7f800000u) ? (0x200u | ((a >> 13) & 0x3ffu)) : 0u);
+	if (a >= 0x477ff000u)
+		return s | 0x7c00u;
+	if (a < 0x38800000u)
+	{
+		if (a < 0x33000000u)
+			return s;
+		const uint32_t e = a >> 23, m = (a & 0x7fffffu) | 0x800000u, shift = 126u - e;
+		uint32_t q = m >> shift;
+		const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+		if (rem > half || (rem == half && (q & 1u)))
+			q++;
+		return s | q;
+	}
+	uint32_t q = (((a >> 23) - 112u) << 10) | ((a & 0x7fffffu) >> 13);
+	const uint32_t rem = a & 0x1fffu;
+	if (rem > 0x1000u || (rem == 0x1000u && (q & 1u)))
+		q++;
+	return s | q;
+}
+inline float half_lo(uint32_t p) { return half_bits_to_float(p & 0xffffu); }
+inline float half_hi(uint32_t p) { return half_bits_to_float(p >> 16); }
+inline float mad_half_lo(uint32_t p, float w, float acc) { return fmaf(half_lo(p), w, acc); }
+inline float mad_half_hi(uint32_t p, float w, float acc) { return fmaf(half_hi(p), w, acc); }
+inline uint32_t pack_half2_rne(float lo, float hi) { return float_to_half_bits_rne(lo) | (float_to_half_bits_rne(hi) << 16); }
+inline float approx_rcp(float v) { return 1.0f / v; }
+inline float approx_sqrt(float v) { return sqrtf(v); }
+#endif
+
+struct u2
+{
+	uint32_t x, y;
+};
+
+// ---- TAA resolve (taa_resolve.frag, reprojection.h, reprojection_color_space.h) ---------------------------------------------------
+// The resolve's result is stored as fp16 and compared at 3 ulp fp16: divisions and square roots on continuous paths use the
+// hardware reciprocal / root (1 ulp fp32), products of tap weights are formed first (w_x * w_y) and folded into one fma per
+// channel -- a few fp32 ulps.  What takes decisions (texel selection, the neighbourhood's nearest depth) is exact.
+AA_HD f3 taa_from_hdr(float r, float g, float b)
+{
+	r *= 8.0f;
+	g *= 8.0f;
+	b *= 8.0f;
+	const float s = approx_rcp(fmaxf(r, fmaxf(g, b)) + 1.0f);
+	r *= s;
+	g *= s;
+	b *= s;
+	return {0.25f * r + 0.5f * g + 0.25f * b, 0.5f * g - 0.25f * r - 0.25f * b, 0.5f * r - 0.5f * b};
+}
+AA_HD f3 taa_to_hdr(f3 c)
+{
+	const float tmp = c.x - c.y;
+	const float r = fminf(fmaxf(tmp + c.z, 0.0f), 0.999f), g = fminf(fmaxf(c.x + c.y, 0.0f), 0.999f), b = fminf(fmaxf(tmp - c.z, 0.0f), 0.999f);
+	const float s = approx_rcp(1.0f - fmaxf(r, fmaxf(g, b)));
+	return {(0.125f * r) * s, (0.125f * g) * s, (0.125f * b) * s};
+}
+
+struct TaaPush
+{
+	float reproj[16];
+	float rt[4]; // 1/w, 1/h, w, h
+};
+
+// Tile: f4 cur(int ox, int oy) = (Y, Cg, Co, depth) of the clamped neighbour (x + ox, y + oy), |o| <= 1.
+// Mv:   uint32_t mv(int x, int y), the RG16F texel of the clamped pixel.
+// Hist: u2 texel(int x, int y), the RGBA16F history texel; coordinates arrive clamped to the image.
+// QUALITY 0 / 1 / 2 = TAAQuality Low / Medium / High.  Writes the resolved colour and the new history as RGBA16F texels.
+template <int QUALITY, typename Tile, typename Mv, typename Hist>
+AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int y, int w, int h, const TaaPush &P, u2 &out_color, u2 &out_history)
+{
+	const float u = (float(x) + 0.5f) * P.rt[0], v = (float(y) + 0.5f) * P.rt[1];
+	const f4 c11 = t.cur(0, 0);
+	// sample_nearest_velocity (reprojection.h:213-283): the neighbour nearest to the camera, first wins on ties
+	int mx, my;
+	float d;
+#define TAA_CONSIDER(OX, OY)                  \
+	{                                         \
+		const float dd = t.cur(OX, OY).w;     \
+		if (dd > d)                           \
+		{                                     \
+			mx = OX;                          \
+			my = OY;                          \
+			d = dd;                           \
+		}                                     \
+	}
+	if (QUALITY <= 1)
+	{
+		mx = -1, my = 0, d = t.cur(-1, 0).w;
+		if (c11.w > d)
+			mx = 0, my = 0, d = c11.w;
+		TAA_CONSIDER(0, -1)
+		TAA_CONSIDER(0, 1)
+		TAA_CONSIDER(1, 0)
+	}
+	else
+	{
+		mx = 1, my = 1, d = t.cur(1, 1).w;
+		TAA_CONSIDER(-1, 0)
+		if (c11.w > d)
+			mx = 0, my = 0, d = c11.w;
+		TAA_CONSIDER(0, -1)
+		TAA_CONSIDER(-1, -1)
+		TAA_CONSIDER(1, 0)
+		TAA_CONSIDER(1, -1)
+		TAA_CONSIDER(-1, 1)
+		TAA_CONSIDER(0, 1)
+	}
+#undef TAA_CONSIDER
+	const uint32_t m = mvs.mv(x + mx, y + my);
+	float mvx = half_lo(m), mvy = half_hi(m);
+	float ou, ov;
+	if (mvx == 0.0f && mvy == 0.0f)
+	{
+		const float cx = 2.0f * u - 1.0f, cy = 2.0f * v - 1.0f;
+		// rows x, y, w of reproj * (cx, cy, d, 1), summed column by column like the shader's mat4 * vec4
+		float rx = P.reproj[0] * cx, ry = P.reproj[1] * cx, rw = P.reproj[3] * cx;
+		rx = rx + P.reproj[4] * cy, ry = ry + P.reproj[5] * cy, rw = rw + P.reproj[7] * cy;
+		rx = rx + P.reproj[8] * d, ry = ry + P.reproj[9] * d, rw = rw + P.reproj[11] * d;
+		rx = rx + P.reproj[12] * 1.0f, ry = ry + P.reproj[13] * 1.0f, rw = rw + P.reproj[15] * 1.0f;
+		ou = rx / rw; // exact: the history position selects texels
+		ov = ry / rw;
+		mvx = u - ou;
+		mvy = v - ov;
+	}
+	else
+	{
+		ou = u - mvx;
+		ov = v - mvy;
+	}
+
+	f3 hc;
+	if (QUALITY == 2)
+	{
+		// sample_catmull_rom (reprojection.h:286-334): nine LinearClamp taps on a 3 x 3 grid of positions.  The outer positions
+		// sit on texel centres (texels k - 1, k + 2), the middle one between k and k + 1: sixteen texels.
+		const float spx = ou * P.rt[2], spy = ov * P.rt[3];
+		const float kx = floorf(spx - 0.5f), ky = floorf(spy - 0.5f);
+		const float fx = spx - (kx + 0.5f), fy = spy - (ky + 0.5f);
+		float wx[3], wy[3], ax, ay;
+		int ix, iy;
+		{
+			const float f = fx;
+			const float w0 = f * (-0.5f + f * (1.0f - 0.5f * f)), w1 = 1.0f + f * f * (-2.5f + 1.5f * f);
+			const float w2 = f * (0.5f + f * (2.0f - 1.5f * f)), w3 = f * f * (-0.5f + 0.5f * f);
+			wx[0] = w0, wx[1] = w1 + w2, wx[2] = w3;
+			const float off = w2 * approx_rcp(w1 + w2);
+			linear_axis((((kx + 0.5f) + off) * P.rt[0]) * float(w) - 0.5f, ix, ax);
+		}
+		{
+			const float f = fy;
+			const float w0 = f * (-0.5f + f * (1.0f - 0.5f * f)), w1 = 1.0f + f * f * (-2.5f + 1.5f * f);
+			const float w2 = f * (0.5f + f * (2.0f - 1.5f * f)), w3 = f * f * (-0.5f + 0.5f * f);
+			wy[0] = w0, wy[1] = w1 + w2, wy[2] = w3;
+			const float off = w2 * approx_rcp(w1 + w2);
+			linear_axis((((ky + 0.5f) + off) * P.rt[1]) * float(h) - 0.5f, iy, ay);
+		}
+		const int k = int(kx), j = int(ky);
+		// the middle tap's pair is (k, k + 1); a coordinate that resolved onto k + 1 reads it with weight 1
+		if (ix != k)
+			ax = 1.0f;
+		if (iy != j)
+			ay = 1.0f;
+		int col[4], row[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+		{
+			col[i] = clampi(k - 1 + i, 0, w - 1);
+			row[i] = clampi(j - 1 + i, 0, h - 1);
+		}
+		// weight of texel column i / row i inside its tap, and the tap it belongs to
+		const float cwx[4] = {1.0f, 1.0f - ax, ax, 1.0f}, cwy[4] = {1.0f, 1.0f - ay, ay, 1.0f};
+		const int tapx[4] = {0, 1, 1, 2}, tapy[4] = {0, 1, 1, 2};
+		float r = 0.0f, g = 0.0f, b = 0.0f;
+#pragma unroll
+		for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+			for (int ii = 0; ii < 4; ii++)
+			{
+				const u2 tx = hist.texel(col[ii], row[jj]);
+				const float wgt = (cwx[ii] * cwy[jj]) * (wx[tapx[ii]] * wy[tapy[jj]]);
+				r = mad_half_lo(tx.x, wgt, r);
+				g = mad_half_hi(tx.x, wgt, g);
+				b = mad_half_lo(tx.y, wgt, b);
+			}
+		hc = {r, g, b};
+	}
+	else
+	{
+		int ix, iy;
+		float a, b;
+		linear_axis(ou * float(w) - 0.5f, ix, a);
+		linear_axis(ov * float(h) - 0.5f, iy, b);
+		const int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1), y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
+		const u2 t00 = hist.texel(x0, y0), t10 = hist.texel(x1, y0), t01 = hist.texel(x0, y1), t11 = hist.texel(x1, y1);
+		const float oma = 1.0f - a, omb = 1.0f - b;
+		const float top_r = mad_half_lo(t10.x, a, mad_half_lo(t00.x, oma, 0.0f)), bot_r = mad_half_lo(t11.x, a, mad_half_lo(t01.x, oma, 0.0f));
+		const float top_g = mad_half_hi(t10.x, a, mad_half_hi(t00.x, oma, 0.0f)), bot_g = mad_half_hi(t11.x, a, mad_half_hi(t01.x, oma, 0.0f));
+		const float top_b = mad_half_lo(t10.y, a, mad_half_lo(t00.y, oma, 0.0f)), bot_b = mad_half_lo(t11.y, a, mad_half_lo(t01.y, oma, 0.0f));
+		hc = {fmaf(bot_r, b, top_r * omb), fmaf(bot_g, b, top_g * omb), fmaf(bot_b, b, top_b * omb)};
+	}
+
+	const float mv_length = approx_sqrt(mvx * mvx + mvy * mvy);
+	const float mv_fast = fminf(mv_length * 50.0f, 1.0f);
+	const float gamma = 1.5f * (1.0f - mv_fast) + 0.5f * mv_fast;
+	hc = {fminf(fmaxf(hc.x, 0.0f), 1.0f), fminf(fmaxf(hc.y, -1.0f), 1.0f), fminf(fmaxf(hc.z, -1.0f), 1.0f)};
+	const float lerp_factor = (1.0f + 2.0f * mv_fast) * (1.0f / 16.0f);
+
+	// clamp_history_box (reprojection.h:107-183)
+	const f4 c01 = t.cur(-1, 0), c21 = t.cur(1, 0), c10 = t.cur(0, -1), c12 = t.cur(0, 1);
+	f3 lo, hi;
+#define TAA_MIN5(C) fminf(fminf(fminf(fminf(c11.C, c01.C), c21.C), c10.C), c12.C)
+#define TAA_MAX5(C) fmaxf(fmaxf(fmaxf(fmaxf(c11.C, c01.C), c21.C), c10.C), c12.C)
+	if (QUALITY == 0)
+	{
+		lo = {TAA_MIN5(x), TAA_MIN5(y), TAA_MIN5(z)};
+		hi = {TAA_MAX5(x), TAA_MAX5(y), TAA_MAX5(z)};
+	}
+	else
+	{
+		const f4 c00 = t.cur(-1, -1), c22 = t.cur(1, 1), c02 = t.cur(-1, 1), c20 = t.cur(1, -1);
+		if (QUALITY == 1)
+		{
+			const f3 clo = {TAA_MIN5(x), TAA_MIN5(y), TAA_MIN5(z)}, chi = {TAA_MAX5(x), TAA_MAX5(y), TAA_MAX5(z)};
+#define TAA_MIN4(C) fminf(fminf(fminf(fminf(clo.C, c00.C), c22.C), c02.C), c20.C)
+#define TAA_MAX4(C) fmaxf(fmaxf(fmaxf(fmaxf(chi.C, c00.C), c22.C), c02.C), c20.C)
+			lo = {0.5f * (clo.x + TAA_MIN4(x)), 0.5f * (clo.y + TAA_MIN4(y)), 0.5f * (clo.z + TAA_MIN4(z))};
+			hi = {0.5f * (chi.x + TAA_MAX4(x)), 0.5f * (chi.y + TAA_MAX4(y)), 0.5f * (chi.z + TAA_MAX4(z))};
+#undef TAA_MIN4
+#undef TAA_MAX4
+		}
+		else
+		{
+#define TAA_M1(C) ((c00.C + 2.0f * c01.C + c02.C + 2.0f * c10.C + 4.0f * c11.C + 2.0f * c12.C + c20.C + 2.0f * c21.C + c22.C) * (1.0f / 16.0f))
+#define TAA_M2(C)                                                                                                                           \
+	(c00.C * c00.C + 2.0f * c01.C * c01.C + c02.C * c02.C + 2.0f * c10.C * c10.C + 4.0f * c11.C * c11.C + 2.0f * c12.C * c12.C + c20.C * c20.C + \
+	 2.0f * c21.C * c21.C + c22.C * c22.C)
+			const f3 m1 = {TAA_M1(x), TAA_M1(y), TAA_M1(z)};
+			const f3 m2 = {TAA_M2(x), TAA_M2(y), TAA_M2(z)};
+#undef TAA_M1
+#undef TAA_M2
+			const f3 sigma = {approx_sqrt(fmaxf(m2.x * (1.0f / 16.0f) - m1.x * m1.x, 0.0f)), approx_sqrt(fmaxf(m2.y * (1.0f / 16.0f) - m1.y * m1.y, 0.0f)),
+			                  approx_sqrt(fmaxf(m2.z * (1.0f / 16.0f) - m1.z * m1.z, 0.0f))};
+			lo = {m1.x - gamma * sigma.x, m1.y - gamma * sigma.y, m1.z - gamma * sigma.z};
+			hi = {m1.x + gamma * sigma.x, m1.y + gamma * sigma.y, m1.z + gamma * sigma.z};
+		}
+	}
+#undef TAA_MIN5
+#undef TAA_MAX5
+	if (QUALITY == 0)
+		hc = {fminf(fmaxf(hc.x, lo.x), hi.x), fminf(fmaxf(hc.y, lo.y), hi.y), fminf(fmaxf(hc.z, lo.z), hi.z)};
+	else
+	{
+		const f3 center = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+		const f3 radius = {fmaxf(0.5f * (hi.x - lo.x), 0.0001f), fmaxf(0.5f * (hi.y - lo.y), 0.0001f), fmaxf(0.5f * (hi.z - lo.z), 0.0001f)};
+		const f3 dv = {hc.x - center.x, hc.y - center.y, hc.z - center.z};
+		const float max_unit = fmaxf(fmaxf(fabsf(dv.x * approx_rcp(radius.x)), fabsf(dv.y * approx_rcp(radius.y))), fabsf(dv.z * approx_rcp(radius.z)));
+		if (max_unit > 1.0f)
+		{
+			const float s = approx_rcp(max_unit);
+			hc = {center.x + dv.x * s, center.y + dv.y * s, center.z + dv.z * s};
+		}
+	}
+	const float oml = 1.0f - lerp_factor;
+	const f3 mixed = {hc.x * oml + c11.x * lerp_factor, hc.y * oml + c11.y * lerp_factor, hc.z * oml + c11.z * lerp_factor};
+	const f3 o = taa_to_hdr(mixed);
+	out_color = {pack_half2_rne(o.x, o.y), pack_half2_rne(o.z, 1.0f)};
+	out_history = {pack_half2_rne(mixed.x, mixed.y), pack_half2_rne(mixed.z, 1.0f)};
 }
 } // namespace aa

@@ -160,3 +160,88 @@ __global__ __launch_bounds__(256) void k_smaa_blend_fast(ColorImage color, Color
 		*reinterpret_cast<uint32_t *>(dst) = result[0];
 }
 
+
+// ---- TAA resolve ---------------------------------------------------------------------------------------------------------------
+// The 3 x 3 neighbourhood of every pixel of a 32 x 16 block comes out of LDS: the 34 x 18 texels around the block are fetched,
+// clamped to the image and converted to the resolve's colour space ONCE, depth in the fourth component (one ds_read_b128 per
+// neighbour).  The history taps go to the image: sixteen texels per pixel at TAAQuality High (aa_core.hpp: taa_pixel).
+struct TaaImages
+{
+	const uint8_t *current, *depth, *mv, *history;
+	uint8_t *out_color, *out_history;
+	uint32_t current_pitch, depth_pitch, mv_pitch, history_pitch, out_color_pitch, out_history_pitch;
+	int w, h;
+};
+
+struct TaaTile
+{
+	static constexpr int W = FAST_BW + 2, H = FAST_BH + 2;
+	const float4 *texels;
+	int lx, ly; // position of the pixel inside the tile
+	__device__ __forceinline__ aa::f4 cur(int ox, int oy) const
+	{
+		const float4 t = texels[(ly + oy) * W + (lx + ox)];
+		return {t.x, t.y, t.z, t.w};
+	}
+};
+struct TaaMotion
+{
+	const uint8_t *ptr;
+	uint32_t pitch;
+	int w, h;
+	__device__ __forceinline__ uint32_t mv(int x, int y) const
+	{
+		return *reinterpret_cast<const uint32_t *>(ptr + (uint32_t(aa::clampi(y, 0, h - 1)) * pitch + uint32_t(aa::clampi(x, 0, w - 1)) * 4u));
+	}
+};
+struct TaaHistory
+{
+	const uint8_t *ptr;
+	uint32_t pitch;
+	__device__ __forceinline__ aa::u2 texel(int x, int y) const
+	{
+		const uint2 t = *reinterpret_cast<const uint2 *>(ptr + (uint32_t(y) * pitch + uint32_t(x) * 8u));
+		return {t.x, t.y};
+	}
+};
+
+template <int QUALITY, bool HISTORY>
+__global__ __launch_bounds__(FAST_BW *FAST_BH) void k_taa_fast(TaaImages im, aa::TaaPush push, RowSpan rows)
+{
+	constexpr int TW = TaaTile::W, TH = TaaTile::H;
+	__shared__ float4 s_cur[TW * TH];
+	const int bx = blockIdx.x * FAST_BW, by = int(rows.first) + blockIdx.y * FAST_BH;
+	const int x = bx + threadIdx.x, y = by + threadIdx.y;
+	if (!HISTORY)
+	{
+		// first frame (REPROJECTION_HISTORY = 0): the colour goes through the resolve's colour space and back
+		if (x >= im.w || y >= int(rows.end))
+			return;
+		const uint2 t = *reinterpret_cast<const uint2 *>(im.current + (uint32_t(y) * im.current_pitch + uint32_t(x) * 8u));
+		const aa::f3 c = aa::taa_from_hdr(aa::half_lo(t.x), aa::half_hi(t.x), aa::half_lo(t.y));
+		const aa::f3 o = aa::taa_to_hdr(c);
+		*reinterpret_cast<uint2 *>(im.out_color + (uint32_t(y) * im.out_color_pitch + uint32_t(x) * 8u)) =
+		    make_uint2(aa::pack_half2_rne(o.x, o.y), aa::pack_half2_rne(o.z, 1.0f));
+		*reinterpret_cast<uint2 *>(im.out_history + (uint32_t(y) * im.out_history_pitch + uint32_t(x) * 8u)) =
+		    make_uint2(aa::pack_half2_rne(c.x, c.y), aa::pack_half2_rne(c.z, 1.0f));
+		return;
+	}
+	for (int i = threadIdx.y * FAST_BW + threadIdx.x; i < TW * TH; i += FAST_BW * FAST_BH)
+	{
+		const int ty = i / TW, tx = i - ty * TW;
+		const int px = aa::clampi(bx + tx - 1, 0, im.w - 1), py = aa::clampi(by + ty - 1, 0, im.h - 1);
+		const uint2 t = *reinterpret_cast<const uint2 *>(im.current + (uint32_t(py) * im.current_pitch + uint32_t(px) * 8u));
+		const aa::f3 c = aa::taa_from_hdr(aa::half_lo(t.x), aa::half_hi(t.x), aa::half_lo(t.y));
+		s_cur[i] = make_float4(c.x, c.y, c.z, *reinterpret_cast<const float *>(im.depth + (uint32_t(py) * im.depth_pitch + uint32_t(px) * 4u)));
+	}
+	__syncthreads();
+	if (x >= im.w || y >= int(rows.end))
+		return;
+	const TaaTile tile = {s_cur, int(threadIdx.x) + 1, int(threadIdx.y) + 1};
+	const TaaMotion motion = {im.mv, im.mv_pitch, im.w, im.h};
+	const TaaHistory history = {im.history, im.history_pitch};
+	aa::u2 color, hist;
+	aa::taa_pixel<QUALITY>(tile, motion, history, x, y, im.w, im.h, push, color, hist);
+	*reinterpret_cast<uint2 *>(im.out_color + (uint32_t(y) * im.out_color_pitch + uint32_t(x) * 8u)) = make_uint2(color.x, color.y);
+	*reinterpret_cast<uint2 *>(im.out_history + (uint32_t(y) * im.out_history_pitch + uint32_t(x) * 8u)) = make_uint2(hist.x, hist.y);
+}

@@ -93,18 +93,30 @@ __device__ __forceinline__ float4 fma4(float4 a, float s, float4 c)
 	return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
 }
 
-// StockSampler::LinearClamp, LOD 0, unnormalised coordinate uv*size - 0.5, exact fp32 weights, over any source of
-// texels: fetch(x, y) takes coordinates already clamped to the image and returns the
+// StockSampler::LinearClamp, LOD 0, unnormalised coordinate uv*size - 0.5, exact fp32 weights (+ the snap above), over any
+// source of texels: fetch(x, y) takes coordinates already clamped to the image and returns the
 // four channels as fp32 (sample_linear_rgba16f is this with a global-memory fetch; the fused pyramid kernels fetch a staged
 // tile from LDS).  One definition, so that every path weighs and sums in the same order.
+// Sub-texel resolution of the sampler (the oracle's model, oracle_common.h / aa_core.hpp): f = unnormalised coordinate - 0.5;
+// a coordinate within 2^-8 of a texel centre reads that texel alone (weight 0 for its neighbour).
+constexpr float SAMPLER_SNAP = 1.0f / 256.0f;
+__device__ __forceinline__ void linear_axis(float f, int &i0, float &weight)
+{
+	const float fl = floorf(f + SAMPLER_SNAP);
+	float a = f - fl;
+	if (a < SAMPLER_SNAP)
+		a = 0.0f;
+	i0 = int(fl);
+	weight = a;
+}
+
 template <typename Fetch>
 __device__ __forceinline__ float4 sample_linear_with(Fetch fetch, int w, int h, float u, float v)
 {
-	const float fx = u * float(w) - 0.5f;
-	const float fy = v * float(h) - 0.5f;
-	const float flx = floorf(fx), fly = floorf(fy);
-	const float a = fx - flx, b = fy - fly;
-	const int ix = int(flx), iy = int(fly);
+	int ix, iy;
+	float a, b;
+	linear_axis(u * float(w) - 0.5f, ix, a);
+	linear_axis(v * float(h) - 0.5f, iy, b);
 	const int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
 	const int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
 	const float4 t00 = fetch(x0, y0), t10 = fetch(x1, y0);

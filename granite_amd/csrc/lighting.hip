@@ -102,11 +102,12 @@ __device__ __forceinline__ float sat(float v) { return __builtin_amdgcn_fmed3f(v
 // StockSampler::LinearClamp on an R8_UNORM image (the ambient-occlusion input).
 __device__ __forceinline__ float sample_linear_r8(const DevImage &img, float u, float v)
 {
-	const float fx = u * float(img.w) - 0.5f, fy = v * float(img.h) - 0.5f;
-	const float flx = floorf(fx), fly = floorf(fy);
-	const float wx = fx - flx, wy = fy - fly;
-	const int x0 = clampi(int(flx), 0, img.w - 1), x1 = clampi(int(flx) + 1, 0, img.w - 1);
-	const int y0 = clampi(int(fly), 0, img.h - 1), y1 = clampi(int(fly) + 1, 0, img.h - 1);
+	int ix, iy;
+	float wx, wy;
+	linear_axis(u * float(img.w) - 0.5f, ix, wx);
+	linear_axis(v * float(img.h) - 0.5f, iy, wy);
+	const int x0 = clampi(ix, 0, img.w - 1), x1 = clampi(ix + 1, 0, img.w - 1);
+	const int y0 = clampi(iy, 0, img.h - 1), y1 = clampi(iy + 1, 0, img.h - 1);
 	const uint8_t *r0 = img.ptr + size_t(y0) * img.pitch, *r1 = img.ptr + size_t(y1) * img.pitch;
 	const float t00 = unorm8_to_float(r0[x0]), t10 = unorm8_to_float(r0[x1]), t01 = unorm8_to_float(r1[x0]), t11 = unorm8_to_float(r1[x1]);
 	const float top = t00 * (1.0f - wx) + t10 * wx, bottom = t01 * (1.0f - wx) + t11 * wx;

@@ -553,11 +553,12 @@ __global__ __launch_bounds__(256) void k_ssr_apply(ApplyParams p)
 	const float fp = powf(1.0f - NoV, 5.0f);
 	const float3_ F = F0 + (f3(fmaxf(omr, F0.x), fmaxf(omr, F0.y), fmaxf(omr, F0.z)) - F0) * fp;
 	// textureLod(uBRDFLut, vec2(NoV, roughness), 0): LinearClamp
-	const float fx = NoV * float(p.lut_w) - 0.5f, fy = roughness * float(p.lut_h) - 0.5f;
-	const float flx = floorf(fx), fly = floorf(fy);
-	const float wa = fx - flx, wb = fy - fly;
-	const int x0 = clampi(int(flx), 0, p.lut_w - 1), x1 = clampi(int(flx) + 1, 0, p.lut_w - 1);
-	const int y0 = clampi(int(fly), 0, p.lut_h - 1), y1 = clampi(int(fly) + 1, 0, p.lut_h - 1);
+	int ix, iy;
+	float wa, wb;
+	linear_axis(NoV * float(p.lut_w) - 0.5f, ix, wa);
+	linear_axis(roughness * float(p.lut_h) - 0.5f, iy, wb);
+	const int x0 = clampi(ix, 0, p.lut_w - 1), x1 = clampi(ix + 1, 0, p.lut_w - 1);
+	const int y0 = clampi(iy, 0, p.lut_h - 1), y1 = clampi(iy + 1, 0, p.lut_h - 1);
 	auto lut = [&](int lx, int ly, int c) { return float(__builtin_bit_cast(_Float16, p.brdf_lut[(size_t(ly) * p.lut_w + lx) * 2 + c])); };
 	float brdf[2];
 #pragma unroll

@@ -45,4 +45,29 @@ void aah_smaa_blend(const uint8_t *color, const uint8_t *weights, int w, int h, 
 		emu::launch(k_smaa_blend_fast<1>, dim3(div_up(w, 64), div_up(rows.count(), 4)), dim3(64, 4), c, b, out, uint32_t(w * 4), 1.0f / float(w),
 		            1.0f / float(h), rows);
 }
+
+void aah_taa(const uint8_t *current, const uint8_t *depth, const uint8_t *mv, const uint8_t *history, int w, int h, const float *reproj16, int quality,
+             uint8_t *out_color, uint8_t *out_history, int row_first, int row_count)
+{
+	const RowSpan rows = span_of(h, row_first, row_count);
+	TaaImages im = {};
+	im.current = current, im.depth = depth, im.mv = mv, im.history = history;
+	im.out_color = out_color, im.out_history = out_history;
+	im.current_pitch = im.history_pitch = im.out_color_pitch = im.out_history_pitch = uint32_t(w * 8);
+	im.depth_pitch = im.mv_pitch = uint32_t(w * 4);
+	im.w = w, im.h = h;
+	aa::TaaPush push;
+	for (int i = 0; i < 16; i++)
+		push.reproj[i] = reproj16[i];
+	push.rt[0] = 1.0f / float(w), push.rt[1] = 1.0f / float(h), push.rt[2] = float(w), push.rt[3] = float(h);
+	const dim3 grid(div_up(w, FAST_BW), div_up(rows.count(), FAST_BH)), block(FAST_BW, FAST_BH);
+	if (!history)
+		emu::launch(k_taa_fast<0, false>, grid, block, im, push, rows);
+	else if (quality == 0)
+		emu::launch(k_taa_fast<0, true>, grid, block, im, push, rows);
+	else if (quality == 1)
+		emu::launch(k_taa_fast<1, true>, grid, block, im, push, rows);
+	else
+		emu::launch(k_taa_fast<2, true>, grid, block, im, push, rows);
+}
 }

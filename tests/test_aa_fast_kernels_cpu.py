@@ -105,3 +105,46 @@ def test_smaa_blend_kernel_equals_oracle(host, w, h, kind, wide):
     host.aah_smaa_blend(p(src), p(ref["weights"]), w, h, p(out2), wide, 5, 13)
     np.testing.assert_array_equal(out2[5:18], ref["out"][5:18])
     assert (out2[:5] == 0x11).all() and (out2[18:] == 0x11).all()
+
+
+def taa_inputs(w, h, seed=3):
+    cam = synth.Camera(w, h)
+    gbuf = synth.make_gbuffer(cam, seed)
+    cur = synth.make_hdr(w, h, seed)
+    mv = synth.make_motion_vectors(w, h)
+    V2 = synth.look_at((0.01, 2.0, 8.0), (0.01, 1.0, 0.0))  # VP_prev = the camera translated by 0.01 along x
+    T = np.eye(4); T[0, 0] = T[1, 1] = 0.5; T[0, 3] = T[1, 3] = 0.5
+    reproj = T @ (cam.P @ V2) @ cam.invVP
+    return cur, gbuf["depth"], mv, np.ascontiguousarray(reproj.T, np.float32).reshape(16)
+
+
+@pytest.mark.parametrize("quality", [0, 1, 2])
+@pytest.mark.parametrize("w,h", [(80, 45), (67, 35)])
+def test_taa_kernel_within_the_resolve_tolerance(host, w, h, quality):
+    """k_taa_fast against the oracle at the tolerance of tests/test_gpu_aa.py (the oracle's history is fed to both, so errors are
+    not carried): first frame without history, then two frames with it; a row band writes only its rows."""
+    from util import assert_rgba16f_close
+    cur, depth, mv, reproj = taa_inputs(w, h)
+    col, hist = np.zeros((h, w, 4), np.uint16), np.zeros((h, w, 4), np.uint16)
+    host.aah_taa(p(cur), p(depth), p(mv), None, w, h, p(reproj), quality, p(col), p(hist), 0, 0)
+    ref_c, ref_h = orc.taa_resolve(cur, depth, mv, None, reproj, quality)
+    assert_rgba16f_close(col, ref_c, what="f0 colour")
+    assert_rgba16f_close(hist, ref_h, what="f0 history")
+    cur2 = synth.make_hdr(w, h, seed=11)
+    prev = ref_h
+    for f in range(2):
+        host.aah_taa(p(cur2), p(depth), p(mv), p(prev), w, h, p(reproj), quality, p(col), p(hist), 0, 0)
+        ref_c, ref_h2 = orc.taa_resolve(cur2, depth, mv, prev, reproj, quality)
+        assert_rgba16f_close(col, ref_c, ulps=3.0, abs_tol=2e-4, what=f"q{quality} f{f + 1} colour")
+        assert_rgba16f_close(hist, ref_h2, ulps=3.0, abs_tol=2e-4, what=f"q{quality} f{f + 1} history")
+        same = (hist == ref_h2).mean()
+        assert same > 0.9, same
+        prev = ref_h2
+    band = np.full((h, w, 4), 0x1234, np.uint16)
+    band_h = band.copy()
+    host.aah_taa(p(cur2), p(depth), p(mv), p(prev), w, h, p(reproj), quality, p(band), p(band_h), 7, 20)
+    full_c, full_h = np.zeros_like(band), np.zeros_like(band)
+    host.aah_taa(p(cur2), p(depth), p(mv), p(prev), w, h, p(reproj), quality, p(full_c), p(full_h), 0, 0)
+    np.testing.assert_array_equal(band[7:27], full_c[7:27])
+    np.testing.assert_array_equal(band_h[7:27], full_h[7:27])
+    assert (band[:7] == 0x1234).all() and (band[27:] == 0x1234).all()
