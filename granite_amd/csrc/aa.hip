@@ -14,6 +14,7 @@
 #include "device_vec.hpp"
 #include "aa_core.hpp"
 #include "aa_fast_kernels.hpp"
+#include "smaa_weights.hpp"
 
 namespace
 {
@@ -26,6 +27,7 @@ constexpr int AA_BLOCK_Y = 8;
 template <int CH>
 struct Tex8
 {
+	static constexpr bool HAS_RUNS = false; // smaa_weights.hpp: no bit planes behind this accessor, the searches sample
 	const uint8_t *ptr;
 	int w, h;
 	uint32_t pitch;
@@ -52,41 +54,7 @@ struct Tex8
 		return r;
 	}
 
-	__device__ __forceinline__ v4 sample(v2 uv, int ox = 0, int oy = 0) const
-	{
-		int x0, y0;
-		float a, b;
-		aa::linear_axis(uv.x * float(w) - 0.5f, x0, a);
-		aa::linear_axis(uv.y * float(h) - 0.5f, y0, b);
-		x0 += ox;
-		y0 += oy;
-		const v4 t00 = fetch(x0, y0), t10 = fetch(x0 + 1, y0), t01 = fetch(x0, y0 + 1), t11 = fetch(x0 + 1, y0 + 1);
-		const v4 top = t00 * (1.0f - a) + t10 * a;
-		const v4 bot = t01 * (1.0f - a) + t11 * a;
-		return top * (1.0f - b) + bot * b;
-	}
-};
-
-// The same sampler over a texture that was decoded to fp32 when it was uploaded (SMAA's area and search tables: constant data,
-// v / 255 evaluated once on the host instead of at every fetch -- the same float either way).
-template <int CH>
-struct TexF
-{
-	const float *data;
-	int w, h;
-
-	__device__ __forceinline__ v4 fetch(int x, int y) const
-	{
-		x = clampi(x, 0, w - 1);
-		y = clampi(y, 0, h - 1);
-		const float *p = data + (uint32_t(y) * uint32_t(w) + uint32_t(x)) * uint32_t(CH);
-		v4 r = mk4(0.0f, 0.0f, 0.0f, 1.0f);
-		r.x = p[0];
-		if (CH >= 2)
-			r.y = p[1];
-		return r;
-	}
-
+	template <bool COLUMNS = false> // smaa_weights.hpp: which staged words a bit-plane accessor reads; one image here
 	__device__ __forceinline__ v4 sample(v2 uv, int ox = 0, int oy = 0) const
 	{
 		int x0, y0;
@@ -115,6 +83,7 @@ struct Tile8
 	int ox, oy;           // image coordinates of texels[0]
 	Tex8<4> tex;
 
+	template <bool COLUMNS = false>
 	__device__ __forceinline__ v4 sample(v2 uv, int offx = 0, int offy = 0) const
 	{
 		int x0, y0;
@@ -224,16 +193,6 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_fxaa_generic(Tex8<4>
 }
 
 // ---- SMAA ---------------------------------------------------------------------------------------------------------------
-struct SmaaPreset
-{
-	float threshold;
-	int max_search_steps;
-	int max_search_steps_diag;
-	float corner_rounding_norm;
-	int diag;
-	int corner;
-};
-
 static SmaaPreset smaa_preset(int quality)
 {
 	switch (quality) // SMAA.hlsl:304-324
@@ -289,11 +248,13 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_edges_generic(T
 template <int HALO>
 struct EdgeTile
 {
+	static constexpr bool HAS_RUNS = false;
 	static constexpr int W = AA_BLOCK_X + 2 * HALO, H = AA_BLOCK_Y + 2 * HALO;
 	const float2 *texels; // [H][W]
 	int ox, oy;
 	Tex8<2> tex;
 
+	template <bool COLUMNS = false>
 	__device__ __forceinline__ v4 sample(v2 uv, int offx = 0, int offy = 0) const
 	{
 		int x0, y0;
@@ -336,296 +297,6 @@ struct SmaaWeightsArgs
 	SmaaPreset P;
 };
 
-// Edges = Tex8<2> (the image) or EdgeTile (its LDS copy around the block): the same sample() either way.
-template <typename Edges>
-struct SmaaWeights
-{
-	Edges edges;
-	TexF<2> area;
-	TexF<1> search;
-	v4 rt;
-	SmaaPreset P;
-
-	__device__ __forceinline__ static v2 rg(v4 v) { return mk2(v.x, v.y); }
-	__device__ __forceinline__ v2 rtxy() const { return mk2(rt.x, rt.y); }
-
-	__device__ static v2 decode_diag2(v2 e)
-	{
-		e.x = e.x * fabsf(5.0f * e.x - 5.0f * 0.75f);
-		return mk2(roundf(e.x), roundf(e.y));
-	}
-	__device__ static v4 decode_diag4(v4 e)
-	{
-		e.x = e.x * fabsf(5.0f * e.x - 5.0f * 0.75f);
-		e.z = e.z * fabsf(5.0f * e.z - 5.0f * 0.75f);
-		return mk4(roundf(e.x), roundf(e.y), roundf(e.z), roundf(e.w));
-	}
-	__device__ v2 search_diag1(v2 texcoord, v2 dir, v2 &e) const
-	{
-		v4 coord = mk4(texcoord.x, texcoord.y, -1.0f, 1.0f);
-		while (coord.z < float(P.max_search_steps_diag - 1) && coord.w > 0.9f)
-		{
-			coord.x = fmaf(rt.x, dir.x, coord.x);
-			coord.y = fmaf(rt.y, dir.y, coord.y);
-			coord.z = fmaf(1.0f, 1.0f, coord.z);
-			e = rg(edges.sample(mk2(coord.x, coord.y)));
-			coord.w = dot2(e, mk2(0.5f, 0.5f));
-		}
-		return mk2(coord.z, coord.w);
-	}
-	__device__ v2 search_diag2(v2 texcoord, v2 dir, v2 &e) const
-	{
-		v4 coord = mk4(texcoord.x, texcoord.y, -1.0f, 1.0f);
-		coord.x += 0.25f * rt.x;
-		while (coord.z < float(P.max_search_steps_diag - 1) && coord.w > 0.9f)
-		{
-			coord.x = fmaf(rt.x, dir.x, coord.x);
-			coord.y = fmaf(rt.y, dir.y, coord.y);
-			coord.z = fmaf(1.0f, 1.0f, coord.z);
-			e = decode_diag2(rg(edges.sample(mk2(coord.x, coord.y))));
-			coord.w = dot2(e, mk2(0.5f, 0.5f));
-		}
-		return mk2(coord.z, coord.w);
-	}
-	__device__ v2 area_diag(v2 dist, v2 e, float offset) const
-	{
-		v2 texcoord = fma2(mk2(20.0f, 20.0f), e, dist);
-		const v2 px = mk2(1.0f / 160.0f, 1.0f / 560.0f);
-		texcoord = fma2(px, texcoord, 0.5f * px);
-		texcoord.x += 0.5f;
-		texcoord.y += (1.0f / 7.0f) * offset;
-		return rg(area.sample(texcoord));
-	}
-	__device__ v2 diag_weights(v2 texcoord, v2 e) const
-	{
-		v2 weights = mk2(0.0f, 0.0f);
-		v4 d;
-		v2 end = mk2(0.0f, 0.0f);
-		if (e.x > 0.0f)
-		{
-			const v2 r = search_diag1(texcoord, mk2(-1.0f, 1.0f), end);
-			d.x = r.x;
-			d.z = r.y;
-			d.x += float(end.y > 0.9f);
-		}
-		else
-		{
-			d.x = 0.0f;
-			d.z = 0.0f;
-		}
-		{
-			const v2 r = search_diag1(texcoord, mk2(1.0f, -1.0f), end);
-			d.y = r.x;
-			d.w = r.y;
-		}
-		if (d.x + d.y > 2.0f)
-		{
-			const v4 coords = mk4(fmaf(-d.x + 0.25f, rt.x, texcoord.x), fmaf(d.x, rt.y, texcoord.y), fmaf(d.y, rt.x, texcoord.x),
-			                      fmaf(-d.y - 0.25f, rt.y, texcoord.y));
-			const v2 a = rg(edges.sample(mk2(coords.x, coords.y), -1, 0));
-			const v2 b = rg(edges.sample(mk2(coords.z, coords.w), 1, 0));
-			const v4 dec = decode_diag4(mk4(a.x, a.y, b.x, b.y));
-			const v4 c = mk4(dec.y, dec.x, dec.w, dec.z);
-			v2 cc = fma2(mk2(2.0f, 2.0f), mk2(c.x, c.z), mk2(c.y, c.w));
-			if (d.z >= 0.9f)
-				cc.x = 0.0f;
-			if (d.w >= 0.9f)
-				cc.y = 0.0f;
-			weights = weights + area_diag(mk2(d.x, d.y), cc, 0.0f);
-		}
-
-		{
-			const v2 r = search_diag2(texcoord, mk2(-1.0f, -1.0f), end);
-			d.x = r.x;
-			d.z = r.y;
-		}
-		if (edges.sample(texcoord, 1, 0).x > 0.0f)
-		{
-			const v2 r = search_diag2(texcoord, mk2(1.0f, 1.0f), end);
-			d.y = r.x;
-			d.w = r.y;
-			d.y += float(end.y > 0.9f);
-		}
-		else
-		{
-			d.y = 0.0f;
-			d.w = 0.0f;
-		}
-		if (d.x + d.y > 2.0f)
-		{
-			const v4 coords = mk4(fmaf(-d.x, rt.x, texcoord.x), fmaf(-d.x, rt.y, texcoord.y), fmaf(d.y, rt.x, texcoord.x), fmaf(d.y, rt.y, texcoord.y));
-			v4 c;
-			c.x = edges.sample(mk2(coords.x, coords.y), -1, 0).y;
-			c.y = edges.sample(mk2(coords.x, coords.y), 0, -1).x;
-			const v4 zw = edges.sample(mk2(coords.z, coords.w), 1, 0);
-			c.z = zw.y;
-			c.w = zw.x;
-			v2 cc = fma2(mk2(2.0f, 2.0f), mk2(c.x, c.z), mk2(c.y, c.w));
-			if (d.z >= 0.9f)
-				cc.x = 0.0f;
-			if (d.w >= 0.9f)
-				cc.y = 0.0f;
-			const v2 ar = area_diag(mk2(d.x, d.y), cc, 0.0f);
-			weights = weights + mk2(ar.y, ar.x);
-		}
-		return weights;
-	}
-
-	__device__ float search_length(v2 e, float offset) const
-	{
-		v2 scale = mk2(66.0f * 0.5f, 33.0f * -1.0f);
-		v2 bias = mk2(66.0f * offset, 33.0f * 1.0f);
-		scale = scale + mk2(-1.0f, 1.0f);
-		bias = bias + mk2(0.5f, -0.5f);
-		scale = scale * mk2(1.0f / 64.0f, 1.0f / 16.0f);
-		bias = bias * mk2(1.0f / 64.0f, 1.0f / 16.0f);
-		return search.sample(fma2(scale, e, bias)).x;
-	}
-	__device__ float search_x_left(v2 texcoord, float end) const
-	{
-		v2 e = mk2(0.0f, 1.0f);
-		while (texcoord.x > end && e.y > 0.8281f && e.x == 0.0f)
-		{
-			e = rg(edges.sample(texcoord));
-			texcoord = fma2(mk2(-2.0f, -0.0f), rtxy(), texcoord);
-		}
-		const float offset = fmaf(-(255.0f / 127.0f), search_length(e, 0.0f), 3.25f);
-		return fmaf(rt.x, offset, texcoord.x);
-	}
-	__device__ float search_x_right(v2 texcoord, float end) const
-	{
-		v2 e = mk2(0.0f, 1.0f);
-		while (texcoord.x < end && e.y > 0.8281f && e.x == 0.0f)
-		{
-			e = rg(edges.sample(texcoord));
-			texcoord = fma2(mk2(2.0f, 0.0f), rtxy(), texcoord);
-		}
-		const float offset = fmaf(-(255.0f / 127.0f), search_length(e, 0.5f), 3.25f);
-		return fmaf(-rt.x, offset, texcoord.x);
-	}
-	__device__ float search_y_up(v2 texcoord, float end) const
-	{
-		v2 e = mk2(1.0f, 0.0f);
-		while (texcoord.y > end && e.x > 0.8281f && e.y == 0.0f)
-		{
-			e = rg(edges.sample(texcoord));
-			texcoord = fma2(mk2(-0.0f, -2.0f), rtxy(), texcoord);
-		}
-		const float offset = fmaf(-(255.0f / 127.0f), search_length(mk2(e.y, e.x), 0.0f), 3.25f);
-		return fmaf(rt.y, offset, texcoord.y);
-	}
-	__device__ float search_y_down(v2 texcoord, float end) const
-	{
-		v2 e = mk2(1.0f, 0.0f);
-		while (texcoord.y < end && e.x > 0.8281f && e.y == 0.0f)
-		{
-			e = rg(edges.sample(texcoord));
-			texcoord = fma2(mk2(0.0f, 2.0f), rtxy(), texcoord);
-		}
-		const float offset = fmaf(-(255.0f / 127.0f), search_length(mk2(e.y, e.x), 0.5f), 3.25f);
-		return fmaf(-rt.y, offset, texcoord.y);
-	}
-	__device__ v2 area_lookup(v2 dist, float e1, float e2) const
-	{
-		v2 texcoord = fma2(mk2(16.0f, 16.0f), mk2(roundf(4.0f * e1), roundf(4.0f * e2)), dist);
-		const v2 px = mk2(1.0f / 160.0f, 1.0f / 560.0f);
-		texcoord = fma2(px, texcoord, 0.5f * px);
-		texcoord.y = fmaf(1.0f / 7.0f, 0.0f, texcoord.y);
-		return rg(area.sample(texcoord));
-	}
-	__device__ void corner(v2 &weights, v4 texcoord, v2 d, bool horizontal) const
-	{
-		if (!P.corner)
-			return;
-		const v2 leftRight = mk2(stepf(d.x, d.y), stepf(d.y, d.x));
-		v2 rounding = leftRight * (1.0f - P.corner_rounding_norm);
-		const float sum = leftRight.x + leftRight.y;
-		rounding = mk2(rounding.x / sum, rounding.y / sum);
-		v2 factor = mk2(1.0f, 1.0f);
-		if (horizontal)
-		{
-			factor.x -= rounding.x * edges.sample(mk2(texcoord.x, texcoord.y), 0, 1).x;
-			factor.x -= rounding.y * edges.sample(mk2(texcoord.z, texcoord.w), 1, 1).x;
-			factor.y -= rounding.x * edges.sample(mk2(texcoord.x, texcoord.y), 0, -2).x;
-			factor.y -= rounding.y * edges.sample(mk2(texcoord.z, texcoord.w), 1, -2).x;
-		}
-		else
-		{
-			factor.x -= rounding.x * edges.sample(mk2(texcoord.x, texcoord.y), 1, 0).y;
-			factor.x -= rounding.y * edges.sample(mk2(texcoord.z, texcoord.w), 1, 1).y;
-			factor.y -= rounding.x * edges.sample(mk2(texcoord.x, texcoord.y), -2, 0).y;
-			factor.y -= rounding.y * edges.sample(mk2(texcoord.z, texcoord.w), -2, 1).y;
-		}
-		weights = weights * mk2(clampfv(factor.x, 0.0f, 1.0f), clampfv(factor.y, 0.0f, 1.0f));
-	}
-
-	__device__ v4 weights_at(int x, int y) const
-	{
-		const v2 texcoord = mk2((float(x) + 0.5f) * rt.x, (float(y) + 0.5f) * rt.y);
-		const v2 pixcoord = mk2(texcoord.x * rt.z, texcoord.y * rt.w);
-		const v4 off0 = mk4(fmaf(rt.x, -0.25f, texcoord.x), fmaf(rt.y, -0.125f, texcoord.y), fmaf(rt.x, 1.25f, texcoord.x), fmaf(rt.y, -0.125f, texcoord.y));
-		const v4 off1 = mk4(fmaf(rt.x, -0.125f, texcoord.x), fmaf(rt.y, -0.25f, texcoord.y), fmaf(rt.x, -0.125f, texcoord.x), fmaf(rt.y, 1.25f, texcoord.y));
-		const float steps = float(P.max_search_steps);
-		const v4 off2 = mk4(fmaf(rt.x, -2.0f * steps, off0.x), fmaf(rt.x, 2.0f * steps, off0.z), fmaf(rt.y, -2.0f * steps, off1.y),
-		                    fmaf(rt.y, 2.0f * steps, off1.w));
-
-		v4 weights = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-		v2 e = rg(edges.sample(texcoord));
-		if (e.y > 0.0f)
-		{
-			bool orthogonal = true;
-			if (P.diag)
-			{
-				const v2 dw = diag_weights(texcoord, e);
-				weights.x = dw.x;
-				weights.y = dw.y;
-				orthogonal = (weights.x == -weights.y);
-			}
-			if (orthogonal)
-			{
-				v2 d;
-				v3 coords;
-				coords.x = search_x_left(mk2(off0.x, off0.y), off2.x);
-				coords.y = off1.y;
-				d.x = coords.x;
-				const float e1 = edges.sample(mk2(coords.x, coords.y)).x;
-				coords.z = search_x_right(mk2(off0.z, off0.w), off2.y);
-				d.y = coords.z;
-				d = mk2(fabsf(roundf(fmaf(rt.z, d.x, -pixcoord.x))), fabsf(roundf(fmaf(rt.z, d.y, -pixcoord.x))));
-				const v2 sqrt_d = mk2(sqrtf(d.x), sqrtf(d.y));
-				const float e2 = edges.sample(mk2(coords.z, coords.y), 1, 0).x;
-				v2 wrg = area_lookup(sqrt_d, e1, e2);
-				coords.y = texcoord.y;
-				corner(wrg, mk4(coords.x, coords.y, coords.z, coords.y), d, true);
-				weights.x = wrg.x;
-				weights.y = wrg.y;
-			}
-			else
-				e.x = 0.0f;
-		}
-		if (e.x > 0.0f)
-		{
-			v2 d;
-			v3 coords;
-			coords.y = search_y_up(mk2(off1.x, off1.y), off2.z);
-			coords.x = off0.x;
-			d.x = coords.y;
-			const float e1 = edges.sample(mk2(coords.x, coords.y)).y;
-			coords.z = search_y_down(mk2(off1.z, off1.w), off2.w);
-			d.y = coords.z;
-			d = mk2(fabsf(roundf(fmaf(rt.w, d.x, -pixcoord.y))), fabsf(roundf(fmaf(rt.w, d.y, -pixcoord.y))));
-			const v2 sqrt_d = mk2(sqrtf(d.x), sqrtf(d.y));
-			const float e2 = edges.sample(mk2(coords.x, coords.z), 0, 1).y;
-			v2 wba = area_lookup(sqrt_d, e1, e2);
-			coords.x = texcoord.x;
-			corner(wba, mk4(coords.x, coords.y, coords.x, coords.z), d, false);
-			weights.z = wba.x;
-			weights.w = wba.y;
-		}
-		return weights;
-	}
-};
-
 // SMAABlendingWeightCalculationPS.  The reference runs this quad under a depth mask EQUAL to the edge pass's
 // non-discarded pixels (smaa.cpp:101-112,170-177); the mask is the edge texel itself here: zero edge => zero weights.
 __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_weights(SmaaWeightsArgs A, uint8_t *out, uint32_t out_pitch, RowSpan rows)
@@ -653,14 +324,14 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_smaa_weights(SmaaWei
 		__syncthreads();
 		if (e != 0)
 		{
-			const SmaaWeights<Tile> S = {{s_edges, bx - SMAA_EDGE_HALO, by - SMAA_EDGE_HALO, A.edges}, A.area, A.search, A.rt, A.P};
+			SmaaWeights<Tile> S = {{s_edges, bx - SMAA_EDGE_HALO, by - SMAA_EDGE_HALO, A.edges}, A.area, A.search, A.rt, A.P};
 			const v4 w = S.weights_at(x, y);
 			packed = unorm8(w.x) | (unorm8(w.y) << 8) | (unorm8(w.z) << 16) | (unorm8(w.w) << 24);
 		}
 	}
 	else if (e != 0)
 	{
-		const SmaaWeights<Tex8<2>> S = {A.edges, A.area, A.search, A.rt, A.P};
+		SmaaWeights<Tex8<2>> S = {A.edges, A.area, A.search, A.rt, A.P};
 		const v4 w = S.weights_at(x, y);
 		packed = unorm8(w.x) | (unorm8(w.y) << 8) | (unorm8(w.z) << 16) | (unorm8(w.w) << 24);
 	}
@@ -912,6 +583,55 @@ int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edg
 	const RowSpan span = resolve_rows(rows, edges->height);
 	if (span.count() == 0)
 		return GR_OK;
+	// Bit-plane form (smaa_weights.hpp): the searches' pass conditions are read off the flags, which stands on the search
+	// coordinates staying within a few hundredths of a texel of their nominal positions -- true far beyond 16K texels per axis.
+	static const bool forced_generic = gr_measurement_switch("GRANITE_AA_GENERIC") != nullptr;
+	if (!forced_generic && edges->width <= 16384 && edges->height <= 16384)
+	{
+		SmaaBitPlanes planes = {};
+		planes.row_words = smaa_bit_words(int(edges->width));
+		planes.col_words = smaa_bit_words(int(edges->height));
+		const size_t row_plane = size_t(planes.rows()) * planes.row_words * 8u, col_plane = size_t(planes.cols()) * planes.col_words * 8u;
+		const size_t need = 2 * row_plane + 2 * col_plane;
+		uint8_t *memory = nullptr;
+		{
+			std::lock_guard<std::mutex> holder{ctx->lock};
+			gr_ctx::SmaaBits &bits = ctx->smaa_bits[stream];
+			if (bits.bytes < need)
+			{
+				// a replaced allocation may still be read by a launch in flight on this stream: drain it first
+				if (bits.memory)
+				{
+					(void)hipStreamSynchronize(gr_to_stream(stream));
+					(void)hipFree(bits.memory);
+					bits = {};
+				}
+				if (hipMalloc(&bits.memory, need) != hipSuccess)
+				{
+					bits = {};
+					return ctx->fail(GR_ERR_OUT_OF_MEMORY, "gr_smaa_blend_weight: %zu bytes of edge bit planes", need);
+				}
+				bits.bytes = need;
+			}
+			memory = static_cast<uint8_t *>(bits.memory);
+		}
+		planes.row_r = reinterpret_cast<uint64_t *>(memory);
+		planes.row_g = reinterpret_cast<uint64_t *>(memory + row_plane);
+		planes.col_r = reinterpret_cast<uint64_t *>(memory + 2 * row_plane);
+		planes.col_g = reinterpret_cast<uint64_t *>(memory + 2 * row_plane + col_plane);
+		// tiles of 64 padded rows the band's workgroups stage from: rows first - 128 .. end + 191 (+ the block rounding)
+		const int tile_first = max(0, (int(span.first) - 128 + SMAA_BITS_PAD) >> 6);
+		const int tile_last = min(planes.col_words - 1, (int(span.end) + FAST_BH + 192 + SMAA_BITS_PAD) >> 6);
+		const int tiles = planes.row_words * (tile_last - tile_first + 1);
+		SmaaWeightsBitsArgs B = {static_cast<const uint8_t *>(edges->ptr), edges->pitch_bytes, int(edges->width), int(edges->height), planes, S.area, S.search, S.rt, S.P};
+		gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_blend_weight"};
+		hipLaunchKernelGGL(k_smaa_pack_edges, dim3(gr_div_up(tiles, 4)), dim3(256), 0, gr_to_stream(stream), B.edges, B.edges_pitch, B.w, B.h, planes,
+		                   tile_first, tile_last - tile_first + 1);
+		hipLaunchKernelGGL(k_smaa_weights_bits, fast_grid(edges->width, span.count()), dim3(FAST_BW, FAST_BH), 0, gr_to_stream(stream), B,
+		                   static_cast<uint8_t *>(weights->ptr), weights->pitch_bytes, span);
+		GR_CHECK_LAUNCH(ctx);
+		return GR_OK;
+	}
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_blend_weight"};
 	hipLaunchKernelGGL(k_smaa_weights, aa_grid(edges->width, span.count()), dim3(AA_BLOCK_X, AA_BLOCK_Y), 0, gr_to_stream(stream), S,
 	                   static_cast<uint8_t *>(weights->ptr), weights->pitch_bytes, span);

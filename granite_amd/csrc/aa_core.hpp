@@ -428,7 +428,7 @@ AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int 
 			const float w0 = f * (-0.5f + f * (1.0f - 0.5f * f)), w1 = 1.0f + f * f * (-2.5f + 1.5f * f);
 			const float w2 = f * (0.5f + f * (2.0f - 1.5f * f)), w3 = f * f * (-0.5f + 0.5f * f);
 			wx[0] = w0, wx[1] = w1 + w2, wx[2] = w3;
-			const float off = w2 * approx_rcp(w1 + w2);
+			const float off = w2 / (w1 + w2); // exact: the tap position takes the sampler's snap decision
 			linear_axis((((kx + 0.5f) + off) * P.rt[0]) * float(w) - 0.5f, ix, ax);
 		}
 		{
@@ -436,7 +436,7 @@ AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int 
 			const float w0 = f * (-0.5f + f * (1.0f - 0.5f * f)), w1 = 1.0f + f * f * (-2.5f + 1.5f * f);
 			const float w2 = f * (0.5f + f * (2.0f - 1.5f * f)), w3 = f * f * (-0.5f + 0.5f * f);
 			wy[0] = w0, wy[1] = w1 + w2, wy[2] = w3;
-			const float off = w2 * approx_rcp(w1 + w2);
+			const float off = w2 / (w1 + w2); // exact: the tap position takes the sampler's snap decision
 			linear_axis((((ky + 0.5f) + off) * P.rt[1]) * float(h) - 0.5f, iy, ay);
 		}
 		const int k = int(kx), j = int(ky);
@@ -452,9 +452,8 @@ AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int 
 			col[i] = clampi(k - 1 + i, 0, w - 1);
 			row[i] = clampi(j - 1 + i, 0, h - 1);
 		}
-		// weight of texel column i / row i inside its tap, and the tap it belongs to
-		const float cwx[4] = {1.0f, 1.0f - ax, ax, 1.0f}, cwy[4] = {1.0f, 1.0f - ay, ay, 1.0f};
-		const int tapx[4] = {0, 1, 1, 2}, tapy[4] = {0, 1, 1, 2};
+		// weight of texel column i / row i: its tap's Catmull-Rom weight times its share of the tap's lerp
+		const float cwx[4] = {wx[0], wx[1] * (1.0f - ax), wx[1] * ax, wx[2]}, cwy[4] = {wy[0], wy[1] * (1.0f - ay), wy[1] * ay, wy[2]};
 		float r = 0.0f, g = 0.0f, b = 0.0f;
 #pragma unroll
 		for (int jj = 0; jj < 4; jj++)
@@ -462,7 +461,7 @@ AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int 
 			for (int ii = 0; ii < 4; ii++)
 			{
 				const u2 tx = hist.texel(col[ii], row[jj]);
-				const float wgt = (cwx[ii] * cwy[jj]) * (wx[tapx[ii]] * wy[tapy[jj]]);
+				const float wgt = cwx[ii] * cwy[jj];
 				r = mad_half_lo(tx.x, wgt, r);
 				g = mad_half_hi(tx.x, wgt, g);
 				b = mad_half_lo(tx.y, wgt, b);

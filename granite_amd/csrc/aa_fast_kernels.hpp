@@ -37,31 +37,26 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_fxaa_fast(const uint8_t *i
                                                                  float inv_w, float inv_h, RowSpan rows)
 {
 	constexpr int HALO = FxaaTile::HALO, TW = FxaaTile::W, TH = FxaaTile::H;
-	__shared__ uint32_t s_raw[TW * TH];
 	__shared__ float4 s_dec[TW * TH];
 	const int bx = blockIdx.x * FAST_BW, by = int(rows.first) + blockIdx.y * FAST_BH;
-	const int tid = threadIdx.y * FAST_BW + threadIdx.x;
-	for (int i = tid; i < TW * TH; i += FAST_BW * FAST_BH)
-	{
-		const int ty = i / TW, tx = i - ty * TW;
-		s_raw[i] = load_rgba8_clamped(in, in_pitch, w, h, bx - HALO + tx, by - HALO + ty);
-	}
-	__syncthreads();
 	const int x = bx + threadIdx.x, y = by + threadIdx.y;
 	const bool inside = x < w && y < int(rows.end);
-	const uint32_t *centre = s_raw + (threadIdx.y + HALO) * TW + (threadIdx.x + HALO);
-	// dir == 0 where the four corners carry the same colour: the pass copies the pixel (most of a rendered frame)
-	const bool flat = aa::fxaa_corners_equal(centre[-TW - 1], centre[-TW + 1], centre[TW - 1], centre[TW + 1]);
+	// dir == 0 where the four corners carry the same colour: the pass copies the pixel (most of a rendered frame).  Decided on
+	// the bytes, straight from the image: a workgroup of such pixels never stages or decodes anything.
+	const uint32_t centre = load_rgba8_clamped(in, in_pitch, w, h, x, y);
+	const bool flat = aa::fxaa_corners_equal(load_rgba8_clamped(in, in_pitch, w, h, x - 1, y - 1), load_rgba8_clamped(in, in_pitch, w, h, x + 1, y - 1),
+	                                         load_rgba8_clamped(in, in_pitch, w, h, x - 1, y + 1), load_rgba8_clamped(in, in_pitch, w, h, x + 1, y + 1));
 	uint32_t *dst = reinterpret_cast<uint32_t *>(out + (uint32_t(y) * out_pitch + uint32_t(x) * 4u));
 	if (!__syncthreads_or(inside && !flat))
 	{
 		if (inside)
-			*dst = centre[0] | 0xff000000u;
+			*dst = centre | 0xff000000u;
 		return;
 	}
-	for (int i = tid; i < TW * TH; i += FAST_BW * FAST_BH)
+	for (int i = threadIdx.y * FAST_BW + threadIdx.x; i < TW * TH; i += FAST_BW * FAST_BH)
 	{
-		const uint32_t t = s_raw[i];
+		const int ty = i / TW, tx = i - ty * TW;
+		const uint32_t t = load_rgba8_clamped(in, in_pitch, w, h, bx - HALO + tx, by - HALO + ty);
 		const float r = aa::unorm8_decode(t & 255u), g = aa::unorm8_decode((t >> 8) & 255u), b = aa::unorm8_decode((t >> 16) & 255u);
 		s_dec[i] = make_float4(r, g, b, aa::luma_of(r, g, b, aa::FXAA_LUMA_R, aa::FXAA_LUMA_G, aa::FXAA_LUMA_B));
 	}
@@ -69,7 +64,7 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_fxaa_fast(const uint8_t *i
 	if (!inside)
 		return;
 	if (flat)
-		*dst = centre[0] | 0xff000000u;
+		*dst = centre | 0xff000000u;
 	else
 	{
 		const FxaaTile tile = {s_dec, bx - HALO, by - HALO};

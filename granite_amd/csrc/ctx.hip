@@ -227,6 +227,9 @@ void gr_destroy(gr_ctx *ctx)
 		(void)hipFree(ctx->smaa_area);
 	if (ctx->smaa_search)
 		(void)hipFree(ctx->smaa_search);
+	for (auto &bits : ctx->smaa_bits)
+		if (bits.second.memory)
+			(void)hipFree(bits.second.memory);
 	delete ctx;
 }
 

@@ -33,6 +33,13 @@ struct gr_ctx
 	// SMAA lookup tables (assets/textures/smaa/{area,search}.gtx payloads), uploaded through gr_smaa_set_luts.
 	void *smaa_area = nullptr;   // 160 x 560 x 2 floats (the RG8 area texture, decoded)
 	void *smaa_search = nullptr; // 64 x 16 floats (the R8 search texture, decoded)
+	// Bit planes of the SMAA edge texture (smaa_weights.hpp), one set per launch stream, grown on demand.
+	struct SmaaBits
+	{
+		void *memory = nullptr;
+		size_t bytes = 0;
+	};
+	std::map<void *, SmaaBits> smaa_bits;
 
 	// aa.hip: (axis length, 1 / length bits) -> "pixel-centre taps along this axis are texel fetches" (aa_core.hpp: axis_taps_exact)
 	std::map<uint64_t, bool> centre_taps_exact;

@@ -3,6 +3,7 @@
 // tests/test_aa_fast_kernels_cpu.py with g++ -ffp-contract=off and compared with the oracle bit for bit.
 #include "hip_emu.hpp"
 #include "../../granite_amd/csrc/aa_fast_kernels.hpp"
+#include "../../granite_amd/csrc/smaa_weights.hpp"
 
 static unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
 static RowSpan span_of(int h, int first, int count)
@@ -69,5 +70,41 @@ void aah_taa(const uint8_t *current, const uint8_t *depth, const uint8_t *mv, co
 		emu::launch(k_taa_fast<1, true>, grid, block, im, push, rows);
 	else
 		emu::launch(k_taa_fast<2, true>, grid, block, im, push, rows);
+}
+
+// SMAA.hlsl:304-324
+static SmaaPreset preset_of(int quality)
+{
+	switch (quality)
+	{
+	case 0: return {0.15f, 4, 8, 0.25f, 0, 0};
+	case 1: return {0.1f, 8, 8, 0.25f, 0, 0};
+	case 2: return {0.1f, 16, 8, 0.25f, 1, 1};
+	default: return {0.05f, 32, 16, 0.25f, 1, 1};
+	}
+}
+
+void aah_smaa_weights(const uint8_t *edges, int w, int h, const uint8_t *area_rg8, const uint8_t *search_r8, int quality, uint8_t *out, int row_first,
+                      int row_count)
+{
+	const RowSpan rows = span_of(h, row_first, row_count);
+	std::vector<float> area(160 * 560 * 2), search(64 * 16);
+	for (size_t i = 0; i < area.size(); i++)
+		area[i] = float(area_rg8[i]) / 255.0f;
+	for (size_t i = 0; i < search.size(); i++)
+		search[i] = float(search_r8[i]) / 255.0f;
+	SmaaBitPlanes planes = {};
+	planes.row_words = smaa_bit_words(w);
+	planes.col_words = smaa_bit_words(h);
+	// poisoned: a word the pack kernel did not write for this band must not matter
+	std::vector<uint64_t> row_r(size_t(planes.rows()) * planes.row_words, 0xA5A5A5A5A5A5A5A5ull), row_g(row_r), col_r(size_t(planes.cols()) * planes.col_words, 0x5A5A5A5A5A5A5A5Aull), col_g(col_r);
+	planes.row_r = row_r.data(), planes.row_g = row_g.data(), planes.col_r = col_r.data(), planes.col_g = col_g.data();
+	const int tile_first = std::max(0, (int(rows.first) - 128 + SMAA_BITS_PAD) >> 6);
+	const int tile_last = std::min(planes.col_words - 1, (int(rows.end) + FAST_BH + 192 + SMAA_BITS_PAD) >> 6);
+	const int tiles = planes.row_words * (tile_last - tile_first + 1);
+	emu::launch(k_smaa_pack_edges, dim3(div_up(tiles, 4)), dim3(256), edges, uint32_t(w * 2), w, h, planes, tile_first, tile_last - tile_first + 1);
+	SmaaWeightsBitsArgs B = {edges, uint32_t(w * 2), w, h, planes, {area.data(), 160, 560}, {search.data(), 64, 16},
+	                         v4{1.0f / float(w), 1.0f / float(h), float(w), float(h)}, preset_of(quality)};
+	emu::launch(k_smaa_weights_bits, dim3(div_up(w, FAST_BW), div_up(rows.count(), FAST_BH)), dim3(FAST_BW, FAST_BH), B, out, uint32_t(w * 4), rows);
 }
 }

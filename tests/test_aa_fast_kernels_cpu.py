@@ -20,6 +20,7 @@ PRESET_THRESHOLD = (0.15, 0.1, 0.1, 0.05)  # SMAA.hlsl:304-324
 def host(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("aa_fast_host") / "libaa_fast_host.so")
     subprocess.check_call(["g++", "-O1", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                           "-I" + os.path.join(ROOT, "tests", "cpp", "emu_include"),
                            os.path.join(ROOT, "tests", "cpp", "aa_fast_host.cpp"), "-o", so])
     lib = C.CDLL(so)
     lib.aah_centre_taps_exact.argtypes = [C.c_int, C.c_float]
@@ -148,3 +149,42 @@ def test_taa_kernel_within_the_resolve_tolerance(host, w, h, quality):
     np.testing.assert_array_equal(band[7:27], full_c[7:27])
     np.testing.assert_array_equal(band_h[7:27], full_h[7:27])
     assert (band[:7] == 0x1234).all() and (band[27:] == 0x1234).all()
+
+
+def stair_card(w, h):
+    """Long straight and stair-stepped edges, so that the orthogonal searches run to their limit (32 steps at Ultra) and the
+    diagonal ones find real diagonals; plus the test card's features."""
+    img = synth.make_ldr_pattern(w, h).copy()
+    y, x = np.mgrid[0:h, 0:w]
+    img[(y > h // 3) & (y < h // 3 + 3)] = (250, 250, 250, 255)                      # a bar across the whole image
+    img[(x > w // 2) & (x < w // 2 + 2)] = (5, 5, 5, 255)                            # a column down the whole image
+    img[(y - x // 7) % 23 == 0] = (255, 40, 40, 255)                                  # shallow stairs: Z patterns with far ends
+    img[(x - y // 5) % 31 == 0] = (40, 255, 40, 255)                                  # steep stairs
+    return img
+
+
+@pytest.mark.parametrize("quality", [0, 1, 2, 3])
+@pytest.mark.parametrize("w,h,kind", [(200, 120, "stairs"), (70, 40, "pattern"), (67, 35, "noise"), (8, 8, "noise"), (150, 33, "stairs")])
+def test_smaa_weight_kernel_over_bit_planes_equals_oracle(host, w, h, kind, quality):
+    from granite_amd.data import load_smaa_luts
+    area, search = load_smaa_luts()
+    src = stair_card(w, h) if kind == "stairs" else source(w, h, kind)
+    edges = orc.smaa_edges(src, quality)
+    ref = orc.smaa_weights(edges, area, search, quality)
+    out = np.full((h, w, 4), 0x77, np.uint8)
+    host.aah_smaa_weights(p(edges), w, h, p(area), p(search), quality, p(out), 0, 0)
+    np.testing.assert_array_equal(out, ref)
+    assert ref.any()
+
+
+def test_smaa_weight_kernel_row_band(host):
+    from granite_amd.data import load_smaa_luts
+    area, search = load_smaa_luts()
+    w, h = 160, 300
+    src = stair_card(w, h)
+    edges = orc.smaa_edges(src, 3)
+    ref = orc.smaa_weights(edges, area, search, 3)
+    out = np.full((h, w, 4), 0x77, np.uint8)
+    host.aah_smaa_weights(p(edges), w, h, p(area), p(search), 3, p(out), 130, 41)
+    np.testing.assert_array_equal(out[130:171], ref[130:171])
+    assert (out[:130] == 0x77).all() and (out[171:] == 0x77).all()
