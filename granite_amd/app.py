@@ -12,7 +12,8 @@ import numpy as np
 from . import capi, synth
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgranite_host.so")
+# GRANITE_LIB_DIR: an A/B build of the same sources (make OUT=../lib_xyz EXTRA_<unit>=...), for measurements only
+LIB_PATH = os.path.join(_HERE, os.environ.get("GRANITE_LIB_DIR", "lib"), "libgranite_host.so")
 
 POST_AA_NONE, POST_AA_FXAA = 0, 1
 POST_AA_SMAA_LOW, POST_AA_SMAA_MEDIUM, POST_AA_SMAA_HIGH, POST_AA_SMAA_ULTRA = 2, 3, 4, 5

@@ -13,7 +13,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgranite_hip.so")
+# GRANITE_LIB_DIR: an A/B build of the same sources (make OUT=../lib_xyz EXTRA_<unit>=...), for measurements only
+LIB_PATH = os.path.join(_HERE, os.environ.get("GRANITE_LIB_DIR", "lib"), "libgranite_hip.so")
 
 # gr_format (VkFormat numeric values)
 FORMAT_R8_UNORM = 9

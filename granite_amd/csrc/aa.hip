@@ -619,13 +619,13 @@ int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edg
 		planes.row_g = reinterpret_cast<uint64_t *>(memory + row_plane);
 		planes.col_r = reinterpret_cast<uint64_t *>(memory + 2 * row_plane);
 		planes.col_g = reinterpret_cast<uint64_t *>(memory + 2 * row_plane + col_plane);
-		// tiles of 64 padded rows the band's workgroups stage from: rows first - 128 .. end + 191 (+ the block rounding)
-		const int tile_first = max(0, (int(span.first) - 128 + SMAA_BITS_PAD) >> 6);
-		const int tile_last = min(planes.col_words - 1, (int(span.end) + FAST_BH + 192 + SMAA_BITS_PAD) >> 6);
+		// tiles of 64 padded rows the band's workgroups stage from: rows first - 96 .. end + 127 (+ the block rounding)
+		const int tile_first = max(0, (int(span.first) - 96 + SMAA_BITS_PAD) >> 6);
+		const int tile_last = min(planes.col_words - 1, (int(span.end) + FAST_BH + 128 + SMAA_BITS_PAD) >> 6);
 		const int tiles = planes.row_words * (tile_last - tile_first + 1);
 		SmaaWeightsBitsArgs B = {static_cast<const uint8_t *>(edges->ptr), edges->pitch_bytes, int(edges->width), int(edges->height), planes, S.area, S.search, S.rt, S.P};
 		gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_blend_weight"};
-		hipLaunchKernelGGL(k_smaa_pack_edges, dim3(gr_div_up(tiles, 4)), dim3(256), 0, gr_to_stream(stream), B.edges, B.edges_pitch, B.w, B.h, planes,
+		hipLaunchKernelGGL(k_smaa_pack_edges, dim3(tiles), dim3(256), 0, gr_to_stream(stream), B.edges, B.edges_pitch, B.w, B.h, planes,
 		                   tile_first, tile_last - tile_first + 1);
 		hipLaunchKernelGGL(k_smaa_weights_bits, fast_grid(edges->width, span.count()), dim3(FAST_BW, FAST_BH), 0, gr_to_stream(stream), B,
 		                   static_cast<uint8_t *>(weights->ptr), weights->pitch_bytes, span);

@@ -423,12 +423,13 @@ struct SmaaWeights
 
 // ---- the edge texture as bit planes ------------------------------------------------------------------------------------------------
 // An edge texel is two flags (R: edge at the left, G: edge at the top; the bytes are 0 or 255).  k_smaa_pack_edges writes them as
-// four planes of 64-bit words -- R and G along rows, R and G along columns -- padded by SMAA_BITS_PAD texels of clamp-to-edge
-// replicas on every side, so that nothing downstream clamps.  A workgroup of the weight pass stages the words around its
-// 32 x 16 pixels into LDS: rows y0 - 18 .. y0 + 33 over x0 - 128 .. x0 + 191 (the horizontal searches, the diagonal searches, every
-// near fetch of a horizontal edge) and columns x0 - 2 .. x0 + 33 over y0 - 128 .. y0 + 191 (the vertical searches and what follows
-// them).  A search step of the shader -- "edge continues on both texels of this pair, no crossing edge on the four" -- is then a
-// bit pair of  C = G(y) & ~R(y) & ~R(y - 1)  (columns:  R(x) & ~G(x) & ~G(x - 1)),  and the run length a count of trailing ones.
+// four planes of bits -- R and G along rows, R and G along columns -- padded by SMAA_BITS_PAD texels of clamp-to-edge replicas on
+// every side, so that nothing downstream clamps.  A workgroup of the weight pass stages the 32-bit words around its 32 x 16 pixels
+// into LDS: rows y0 - 18 .. y0 + 33 over x0 - 64 .. x0 + 95 (the horizontal searches, the diagonal searches, every near fetch of
+// a horizontal edge) and columns x0 - 2 .. x0 + 33 over 192 rows from the 32-aligned row at or below y0 - 64 (the vertical
+// searches and what follows them): 3.7 KB.  A search step of the shader -- "edge continues on both texels of this pair, no
+// crossing edge on the four" -- is then a bit pair of  C = G(y) & ~R(y) & ~R(y - 1)  (columns:  R(x) & ~G(x) & ~G(x - 1)),  and
+// the run length a count of trailing ones in a 64-bit window: 32 steps, the longest search of any preset.
 constexpr int SMAA_BITS_PAD = 192;
 
 struct SmaaBitPlanes
@@ -441,56 +442,73 @@ struct SmaaBitPlanes
 };
 inline int smaa_bit_words(int n) { return (2 * SMAA_BITS_PAD + ((n + 63) & ~63)) / 64; }
 
-// One wave per 64 x 64 tile of the padded domain: 64 coalesced row reads, the row words by ballot, the column words collected
-// per lane.  tile_y0 .. : only the tiles a row band needs are written.
+// One workgroup of four waves per 64 x 64 tile of the padded domain; wave v takes rows 16 v .. 16 v + 15: sixteen coalesced row
+// reads issued together, the row words by ballot, the column words collected per lane and joined through LDS.
+// tile_y_first / tile_y_count: only the tiles a row band needs are written.
 __global__ __launch_bounds__(256) void k_smaa_pack_edges(const uint8_t *edges, uint32_t pitch, int w, int h, SmaaBitPlanes planes, int tile_y_first,
                                                           int tile_y_count)
 {
+	__shared__ uint32_t s_col[2][4][64]; // [plane][wave][column]: 16 bits each
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int tile = blockIdx.x * 4 + wave;
-	if (tile >= planes.row_words * tile_y_count)
-		return;
-	const int ty = tile_y_first + tile / planes.row_words, tx = tile % planes.row_words;
+	const int ty = tile_y_first + int(blockIdx.x) / planes.row_words, tx = int(blockIdx.x) % planes.row_words;
 	const int x = aa::clampi(tx * 64 - SMAA_BITS_PAD + lane, 0, w - 1);
-	uint64_t col_r = 0, col_g = 0, my_r = 0, my_g = 0;
-	for (int r = 0; r < 64; r++)
+	uint32_t t[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++)
 	{
-		const int y = aa::clampi(ty * 64 - SMAA_BITS_PAD + r, 0, h - 1);
-		const uint32_t t = *reinterpret_cast<const uint16_t *>(edges + (uint32_t(y) * pitch + uint32_t(x) * 2u));
-		const bool er = (t & 255u) != 0u, eg = (t >> 8) != 0u;
+		const int y = aa::clampi(ty * 64 - SMAA_BITS_PAD + wave * 16 + r, 0, h - 1);
+		t[r] = *reinterpret_cast<const uint16_t *>(edges + (uint32_t(y) * pitch + uint32_t(x) * 2u));
+	}
+	uint32_t col_r = 0, col_g = 0;
+	uint64_t my_r = 0, my_g = 0;
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+	{
+		const bool er = (t[r] & 255u) != 0u, eg = (t[r] >> 8) != 0u;
 		const uint64_t word_r = __ballot(er), word_g = __ballot(eg);
 		if (lane == r)
 		{
 			my_r = word_r;
 			my_g = word_g;
 		}
-		col_r |= uint64_t(er) << r;
-		col_g |= uint64_t(eg) << r;
+		col_r |= uint32_t(er) << r;
+		col_g |= uint32_t(eg) << r;
 	}
-	planes.row_r[size_t(ty * 64 + lane) * planes.row_words + tx] = my_r;
-	planes.row_g[size_t(ty * 64 + lane) * planes.row_words + tx] = my_g;
-	planes.col_r[size_t(tx * 64 + lane) * planes.col_words + ty] = col_r;
-	planes.col_g[size_t(tx * 64 + lane) * planes.col_words + ty] = col_g;
+	if (lane < 16)
+	{
+		planes.row_r[size_t(ty * 64 + wave * 16 + lane) * planes.row_words + tx] = my_r;
+		planes.row_g[size_t(ty * 64 + wave * 16 + lane) * planes.row_words + tx] = my_g;
+	}
+	s_col[0][wave][lane] = col_r;
+	s_col[1][wave][lane] = col_g;
+	__syncthreads();
+	if (wave < 2)
+	{
+		const uint64_t word = uint64_t(s_col[wave][0][lane]) | (uint64_t(s_col[wave][1][lane]) << 16) | (uint64_t(s_col[wave][2][lane]) << 32) |
+		                      (uint64_t(s_col[wave][3][lane]) << 48);
+		(wave == 0 ? planes.col_r : planes.col_g)[size_t(tx * 64 + lane) * planes.col_words + ty] = word;
+	}
 }
 
 struct EdgeBitTiles
 {
 	static constexpr bool HAS_RUNS = true;
-	static constexpr int ROWS = FAST_BH + 36, COLS = FAST_BW + 4, WORDS = 5; // 320 bits per staged row / column
-	const uint64_t *row_r, *row_g; // [ROWS][WORDS]: bit b of row i is texel (x0 - 128 + b, y0 - 18 + i)
-	const uint64_t *col_r, *col_g; // [COLS][WORDS]: bit b of column i is texel (x0 - 2 + i, y0 - 128 + b)
-	int x0, y0;
+	static constexpr int ROWS = FAST_BH + 36, ROW_DWORDS = 5;  // 160 bits per staged row: x0 - 64 .. x0 + 95
+	static constexpr int COLS = FAST_BW + 4, COL_DWORDS = 6;   // 192 bits per staged column, from col_y0
+	const uint32_t *row_r, *row_g; // [ROWS][ROW_DWORDS]: bit b of row i is texel (x0 - 64 + b, y0 - 18 + i)
+	const uint32_t *col_r, *col_g; // [COLS][COL_DWORDS]: bit b of column i is texel (x0 - 2 + i, col_y0 + b)
+	int x0, y0, col_y0;
 	int w, h;
-	const uint8_t *image; // the RG8 edge texture itself, for a fetch outside the staged words (not expected)
+	const uint8_t *image; // the RG8 edge texture itself, for what lies outside the staged words
 	uint32_t pitch;
 
-	// 128 bits starting at bit p of a staged row / column (p + 128 <= 320)
-	__device__ __forceinline__ static void window(const uint64_t *words, int p, uint64_t &lo, uint64_t &hi)
+	// 64 bits starting at bit p of a staged row / column (p + 64 within the staged bits)
+	__device__ __forceinline__ static uint64_t window(const uint32_t *words, int p)
 	{
-		const int wi = p >> 6, sh = p & 63;
-		const uint64_t a = words[wi], b = words[wi + 1], c = (wi + 2 < WORDS) ? words[wi + 2] : 0ull;
-		lo = sh ? ((a >> sh) | (b << (64 - sh))) : a;
-		hi = sh ? ((b >> sh) | (c << (64 - sh))) : b;
+		const int k = p >> 5, sh = p & 31;
+		const uint32_t a = words[k], b = words[k + 1], c = words[k + 2];
+		const uint32_t lo = sh ? ((a >> sh) | (b << (32 - sh))) : a, hi = sh ? ((b >> sh) | (c << (32 - sh))) : b;
+		return uint64_t(lo) | (uint64_t(hi) << 32);
 	}
 	__device__ __forceinline__ static uint64_t reverse64(uint64_t v)
 	{
@@ -503,74 +521,76 @@ struct EdgeBitTiles
 		return r;
 #endif
 	}
-	// number of leading steps j = 0, 1, .. whose texel pair (bits 2j, 2j + 1 of the 128-bit window) is set on both
-	__device__ __forceinline__ static int leading_pairs(uint64_t lo, uint64_t hi)
+	// number of leading steps j = 0, 1, .. whose texel pair (bits 2j, 2j + 1) is set on both: 0 .. 32
+	__device__ __forceinline__ static int leading_pairs(uint64_t c)
 	{
-		const uint64_t even = 0x5555555555555555ull;
-		const uint64_t miss_lo = ~(lo & (lo >> 1)) & even, miss_hi = ~(hi & (hi >> 1)) & even;
-		if (miss_lo)
-			return __builtin_ctzll(miss_lo) >> 1;
-		return 32 + (miss_hi ? (__builtin_ctzll(miss_hi) >> 1) : 32);
+		const uint64_t miss = ~(c & (c >> 1)) & 0x5555555555555555ull;
+		return miss ? (__builtin_ctzll(miss) >> 1) : 32;
 	}
-	__device__ __forceinline__ void row_condition(int x_first, int y, uint64_t &lo, uint64_t &hi) const
+	// the search's condition on one texel, for a step beyond the staged window (the 33rd: only the rounding of the shader's own
+	// end-of-search comparison lets it happen)
+	template <bool COLUMNS>
+	__device__ __attribute__((noinline)) bool pair_continues(int xa, int ya, int xb, int yb) const
 	{
-		const int i = y - (y0 - 18), p = x_first - (x0 - 128);
-		uint64_t g_lo, g_hi, r_lo, r_hi, q_lo, q_hi;
-		window(row_g + i * WORDS, p, g_lo, g_hi);
-		window(row_r + i * WORDS, p, r_lo, r_hi);
-		window(row_r + (i - 1) * WORDS, p, q_lo, q_hi);
-		lo = g_lo & ~r_lo & ~q_lo;
-		hi = g_hi & ~r_hi & ~q_hi;
+		// horizontal: G on both texels of row y, R clear on both of rows y, y - 1; vertical: the transposed statement
+		const v2 a = texel<COLUMNS>(xa, ya), b = texel<COLUMNS>(xb, yb);
+		const v2 a1 = COLUMNS ? texel<COLUMNS>(xa - 1, ya) : texel<COLUMNS>(xa, ya - 1), b1 = COLUMNS ? texel<COLUMNS>(xb - 1, yb) : texel<COLUMNS>(xb, yb - 1);
+		if (COLUMNS)
+			return a.x != 0.0f && b.x != 0.0f && a.y == 0.0f && b.y == 0.0f && a1.y == 0.0f && b1.y == 0.0f;
+		return a.y != 0.0f && b.y != 0.0f && a.x == 0.0f && b.x == 0.0f && a1.x == 0.0f && b1.x == 0.0f;
 	}
-	__device__ __forceinline__ void column_condition(int x, int y_first, uint64_t &lo, uint64_t &hi) const
+	__device__ __forceinline__ uint64_t row_condition(int x_first, int y) const
 	{
-		const int i = x - (x0 - 2), p = y_first - (y0 - 128);
-		uint64_t r_lo, r_hi, g_lo, g_hi, q_lo, q_hi;
-		window(col_r + i * WORDS, p, r_lo, r_hi);
-		window(col_g + i * WORDS, p, g_lo, g_hi);
-		window(col_g + (i - 1) * WORDS, p, q_lo, q_hi);
-		lo = r_lo & ~g_lo & ~q_lo;
-		hi = r_hi & ~g_hi & ~q_hi;
+		const int i = y - (y0 - 18), p = x_first - (x0 - 64);
+		return window(row_g + i * ROW_DWORDS, p) & ~window(row_r + i * ROW_DWORDS, p) & ~window(row_r + (i - 1) * ROW_DWORDS, p);
 	}
-	// step j of the left search samples texels (x - 1 - 2j, x - 2j) of rows y - 1, y: the window [x - 127, x], mirrored
+	__device__ __forceinline__ uint64_t column_condition(int x, int y_first) const
+	{
+		const int i = x - (x0 - 2), p = y_first - col_y0;
+		return window(col_r + i * COL_DWORDS, p) & ~window(col_g + i * COL_DWORDS, p) & ~window(col_g + (i - 1) * COL_DWORDS, p);
+	}
+	// step j of the left search samples texels (x - 1 - 2j, x - 2j) of rows y - 1, y: the window [x - 63, x], mirrored
 	__device__ __forceinline__ int run_left(int x, int y) const
 	{
-		uint64_t lo, hi;
-		row_condition(x - 127, y, lo, hi);
-		return leading_pairs(reverse64(hi), reverse64(lo));
+		int run = leading_pairs(reverse64(row_condition(x - 63, y)));
+		if (run == 32 && pair_continues<false>(x - 64, y, x - 65, y))
+			run++;
+		return run;
 	}
 	// step j of the right search samples texels (x + 1 + 2j, x + 2 + 2j)
 	__device__ __forceinline__ int run_right(int x, int y) const
 	{
-		uint64_t lo, hi;
-		row_condition(x + 1, y, lo, hi);
-		return leading_pairs(lo, hi);
+		int run = leading_pairs(row_condition(x + 1, y));
+		if (run == 32 && pair_continues<false>(x + 65, y, x + 66, y))
+			run++;
+		return run;
 	}
 	__device__ __forceinline__ int run_up(int x, int y) const
 	{
-		uint64_t lo, hi;
-		column_condition(x, y - 127, lo, hi);
-		return leading_pairs(reverse64(hi), reverse64(lo));
+		int run = leading_pairs(reverse64(column_condition(x, y - 63)));
+		if (run == 32 && pair_continues<true>(x, y - 64, x, y - 65))
+			run++;
+		return run;
 	}
 	__device__ __forceinline__ int run_down(int x, int y) const
 	{
-		uint64_t lo, hi;
-		column_condition(x, y + 1, lo, hi);
-		return leading_pairs(lo, hi);
+		int run = leading_pairs(column_condition(x, y + 1));
+		if (run == 32 && pair_continues<true>(x, y + 65, x, y + 66))
+			run++;
+		return run;
 	}
 
 	// (R, G) of one texel as 0.0 / 1.0.  COLUMNS = false: from the staged rows (everything a horizontal edge and the diagonal
-	// searches touch); true: from the staged columns (a vertical edge's searches and what follows them).  Every reach of the pass
-	// is bounded by its search limits and lies inside the staged words; a texel outside them (not expected) is read from the image.
+	// searches touch); true: from the staged columns (a vertical edge's searches and what follows them).  What lies outside the
+	// staged words (the far end of a 32-step search) is read from the image.
 	template <bool COLUMNS>
 	__device__ __forceinline__ v2 texel(int x, int y) const
 	{
-		const int line = COLUMNS ? x - (x0 - 2) : y - (y0 - 18), bit = COLUMNS ? y - (y0 - 128) : x - (x0 - 128);
-		if (unsigned(line) >= unsigned(COLUMNS ? COLS : ROWS) || unsigned(bit) >= unsigned(WORDS * 64))
+		const int line = COLUMNS ? x - (x0 - 2) : y - (y0 - 18), bit = COLUMNS ? y - col_y0 : x - (x0 - 64);
+		if (unsigned(line) >= unsigned(COLUMNS ? COLS : ROWS) || unsigned(bit) >= unsigned((COLUMNS ? COL_DWORDS : ROW_DWORDS) * 32))
 			return texel_from_image(x, y);
-		const uint32_t *r32 = reinterpret_cast<const uint32_t *>(COLUMNS ? col_r : row_r), *g32 = reinterpret_cast<const uint32_t *>(COLUMNS ? col_g : row_g);
-		const int k = line * (WORDS * 2) + (bit >> 5), s = bit & 31;
-		return mk2(float((r32[k] >> s) & 1u), float((g32[k] >> s) & 1u));
+		const int k = line * (COLUMNS ? COL_DWORDS : ROW_DWORDS) + (bit >> 5), s = bit & 31;
+		return mk2(float(((COLUMNS ? col_r : row_r)[k] >> s) & 1u), float(((COLUMNS ? col_g : row_g)[k] >> s) & 1u));
 	}
 	__device__ __attribute__((noinline)) v2 texel_from_image(int x, int y) const
 	{
@@ -628,7 +648,8 @@ struct SmaaWeightsBitsArgs
 __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_weights_bits(SmaaWeightsBitsArgs A, uint8_t *out, uint32_t out_pitch, RowSpan rows)
 {
 	using T = EdgeBitTiles;
-	__shared__ uint64_t s_row_r[T::ROWS * T::WORDS], s_row_g[T::ROWS * T::WORDS], s_col_r[T::COLS * T::WORDS], s_col_g[T::COLS * T::WORDS];
+	__shared__ uint32_t s_row_r[T::ROWS * T::ROW_DWORDS + 1], s_row_g[T::ROWS * T::ROW_DWORDS + 1]; // + 1: window() reads one word ahead
+	__shared__ uint32_t s_col_r[T::COLS * T::COL_DWORDS + 1], s_col_g[T::COLS * T::COL_DWORDS + 1];
 	const int bx = blockIdx.x * FAST_BW, by = int(rows.first) + blockIdx.y * FAST_BH;
 	const int x = bx + threadIdx.x, y = by + threadIdx.y;
 	const bool inside = x < A.w && y < int(rows.end);
@@ -643,38 +664,27 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_weights_bits(SmaaWeig
 		return;
 	}
 	const int tid = threadIdx.y * FAST_BW + threadIdx.x;
-	// words of the padded planes: bit 0 of the staged rows is texel x0 - 128 = plane bit x0 + 64, i.e. word bx / 64 + 1 when
-	// bx is a multiple of 64, and a word-aligned start otherwise needs the shift below
-	const int row_bit0 = bx - 128 + SMAA_BITS_PAD, col_bit0 = by - 128 + SMAA_BITS_PAD;
-	for (int i = tid; i < T::ROWS * T::WORDS; i += FAST_BW * FAST_BH)
+	// the planes as 32-bit words: bx is a multiple of 32 and so is the pad, the staged rows start on a word; the staged columns
+	// start on the word holding row by - 64
+	const uint32_t *row_r32 = reinterpret_cast<const uint32_t *>(A.planes.row_r), *row_g32 = reinterpret_cast<const uint32_t *>(A.planes.row_g);
+	const uint32_t *col_r32 = reinterpret_cast<const uint32_t *>(A.planes.col_r), *col_g32 = reinterpret_cast<const uint32_t *>(A.planes.col_g);
+	const int row_word0 = (bx - 64 + SMAA_BITS_PAD) >> 5;
+	const int col_word0 = (by - 64 + SMAA_BITS_PAD) >> 5, col_y0 = (col_word0 << 5) - SMAA_BITS_PAD;
+	// without the diagonal searches nothing reaches beyond two rows above / one below the block's pixels
+	const int row_first = A.P.diag ? 0 : 16, row_count = A.P.diag ? T::ROWS : FAST_BH + 4;
+	for (int i = tid; i < row_count * T::ROW_DWORDS; i += FAST_BW * FAST_BH)
 	{
-		const int r = i / T::WORDS, k = i - r * T::WORDS;
-		const size_t base = size_t(by - 18 + r + SMAA_BITS_PAD) * A.planes.row_words;
-		const int bit = row_bit0 + 64 * k, wi = bit >> 6, sh = bit & 63;
-		const uint64_t r0 = A.planes.row_r[base + wi], g0 = A.planes.row_g[base + wi];
-		uint64_t vr = r0, vg = g0;
-		if (sh)
-		{
-			vr = (r0 >> sh) | (A.planes.row_r[base + wi + 1] << (64 - sh));
-			vg = (g0 >> sh) | (A.planes.row_g[base + wi + 1] << (64 - sh));
-		}
-		s_row_r[i] = vr;
-		s_row_g[i] = vg;
+		const int r = row_first + i / T::ROW_DWORDS, k = i % T::ROW_DWORDS;
+		const size_t word = size_t(by - 18 + r + SMAA_BITS_PAD) * (A.planes.row_words * 2) + row_word0 + k;
+		s_row_r[r * T::ROW_DWORDS + k] = row_r32[word];
+		s_row_g[r * T::ROW_DWORDS + k] = row_g32[word];
 	}
-	for (int i = tid; i < T::COLS * T::WORDS; i += FAST_BW * FAST_BH)
+	for (int i = tid; i < T::COLS * T::COL_DWORDS; i += FAST_BW * FAST_BH)
 	{
-		const int c = i / T::WORDS, k = i - c * T::WORDS;
-		const size_t base = size_t(bx - 2 + c + SMAA_BITS_PAD) * A.planes.col_words;
-		const int bit = col_bit0 + 64 * k, wi = bit >> 6, sh = bit & 63;
-		const uint64_t r0 = A.planes.col_r[base + wi], g0 = A.planes.col_g[base + wi];
-		uint64_t vr = r0, vg = g0;
-		if (sh)
-		{
-			vr = (r0 >> sh) | (A.planes.col_r[base + wi + 1] << (64 - sh));
-			vg = (g0 >> sh) | (A.planes.col_g[base + wi + 1] << (64 - sh));
-		}
-		s_col_r[i] = vr;
-		s_col_g[i] = vg;
+		const int c = i / T::COL_DWORDS, k = i % T::COL_DWORDS;
+		const size_t word = size_t(bx - 2 + c + SMAA_BITS_PAD) * (A.planes.col_words * 2) + col_word0 + k;
+		s_col_r[i] = col_r32[word];
+		s_col_g[i] = col_g32[word];
 	}
 	__syncthreads();
 	if (!inside)
@@ -682,7 +692,7 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_weights_bits(SmaaWeig
 	uint32_t packed = 0u;
 	if (e != 0u)
 	{
-		SmaaWeights<EdgeBitTiles> S = {{s_row_r, s_row_g, s_col_r, s_col_g, bx, by, A.w, A.h, A.edges, A.edges_pitch}, A.area, A.search, A.rt, A.P};
+		SmaaWeights<EdgeBitTiles> S = {{s_row_r, s_row_g, s_col_r, s_col_g, bx, by, col_y0, A.w, A.h, A.edges, A.edges_pitch}, A.area, A.search, A.rt, A.P};
 		const v4 wgt = S.weights_at(x, y);
 		packed = aa::unorm8_encode(wgt.x) | (aa::unorm8_encode(wgt.y) << 8) | (aa::unorm8_encode(wgt.z) << 16) | (aa::unorm8_encode(wgt.w) << 24);
 	}

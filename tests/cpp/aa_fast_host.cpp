@@ -99,10 +99,10 @@ void aah_smaa_weights(const uint8_t *edges, int w, int h, const uint8_t *area_rg
 	// poisoned: a word the pack kernel did not write for this band must not matter
 	std::vector<uint64_t> row_r(size_t(planes.rows()) * planes.row_words, 0xA5A5A5A5A5A5A5A5ull), row_g(row_r), col_r(size_t(planes.cols()) * planes.col_words, 0x5A5A5A5A5A5A5A5Aull), col_g(col_r);
 	planes.row_r = row_r.data(), planes.row_g = row_g.data(), planes.col_r = col_r.data(), planes.col_g = col_g.data();
-	const int tile_first = std::max(0, (int(rows.first) - 128 + SMAA_BITS_PAD) >> 6);
-	const int tile_last = std::min(planes.col_words - 1, (int(rows.end) + FAST_BH + 192 + SMAA_BITS_PAD) >> 6);
+	const int tile_first = std::max(0, (int(rows.first) - 96 + SMAA_BITS_PAD) >> 6);
+	const int tile_last = std::min(planes.col_words - 1, (int(rows.end) + FAST_BH + 128 + SMAA_BITS_PAD) >> 6);
 	const int tiles = planes.row_words * (tile_last - tile_first + 1);
-	emu::launch(k_smaa_pack_edges, dim3(div_up(tiles, 4)), dim3(256), edges, uint32_t(w * 2), w, h, planes, tile_first, tile_last - tile_first + 1);
+	emu::launch(k_smaa_pack_edges, dim3(tiles), dim3(256), edges, uint32_t(w * 2), w, h, planes, tile_first, tile_last - tile_first + 1);
 	SmaaWeightsBitsArgs B = {edges, uint32_t(w * 2), w, h, planes, {area.data(), 160, 560}, {search.data(), 64, 16},
 	                         v4{1.0f / float(w), 1.0f / float(h), float(w), float(h)}, preset_of(quality)};
 	emu::launch(k_smaa_weights_bits, dim3(div_up(w, FAST_BW), div_up(rows.count(), FAST_BH)), dim3(FAST_BW, FAST_BH), B, out, uint32_t(w * 4), rows);
