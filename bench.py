@@ -47,7 +47,8 @@ CHAIN_BYTES_PER_PX = {"config1_256_post_only": 26.7, "config4_4k_smaa_taa": 56.6
 SINGLE_GPU_WORKLOADS = {"config1_256_post_only", "config4_4k_smaa_taa"}  # not tiled by bench.py: N ranks run N replicas
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy); the run measures its own too
 VALU_SIMDS, VALU_CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 2.0  # 256 CUs x 4 SIMD-32, max clock, wave64 fp32 op
-BRACKET_EVERY = 8  # the dominant kernel keeps its hipEvent bracket on every 8th launch of the timed region (fewer steps: >= 5 brackets)
+BRACKET_EVERY = 8  # the dominant kernel keeps its hipEvent bracket on every 8th launch of the timed region (short runs: >= 16 brackets, or all)
+MIN_BRACKETS = 16
 
 
 def parse_args():
@@ -60,6 +61,16 @@ def parse_args():
     ap.add_argument("--sustain-seconds", type=float, default=1.0, help="length of the unbracketed run after the timed region (0 = off)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     return ap.parse_args()
+
+
+def vulkan_probe():
+    """The reference's own path as a CPU baseline needs a Vulkan loader + a software ICD (lavapipe) on this host: say whether one
+    is there, so that the day it is, the record shows it (none in this image)."""
+    import ctypes.util
+    import glob
+    icds = os.environ.get("VK_ICD_FILENAMES") or os.environ.get("VK_DRIVER_FILES")
+    found = glob.glob("/usr/share/vulkan/icd.d/*.json") + glob.glob("/etc/vulkan/icd.d/*.json")
+    return {"libvulkan": ctypes.util.find_library("vulkan"), "VK_ICD_FILENAMES": icds, "icd_manifests": found[:4]}
 
 
 def cpu_baseline(cam, gbuf, descs, width, height, sample_rows):
@@ -109,7 +120,9 @@ def cpu_baseline(cam, gbuf, descs, width, height, sample_rows):
         "value": width * height / frame_s / 1e6,
         "unit": "Mpixels/s",
         "cores": cores,
-        "kind": "cpu-oracle",  # the CPU restatement (oracle/), not the reference's Vulkan path on lavapipe
+        "kind": "port",  # the CPU restatement (oracle/): BASELINE.md 3 calls it "cpu-oracle", as opposed to the reference's Vulkan path on lavapipe
+        "name": "cpu-oracle",
+        "vulkan_icd": vulkan_probe(),
         "sample": f"{frames} frame(s) averaged, {width}x{sample_rows} band of the same G-buffer (all {n} lights, full cluster build): "
                   f"cluster {t_cluster:.2f}s + lighting {t_light:.2f}s + bloom/tonemap {t_post:.2f}s on {cores} OpenMP threads; "
                   f"value = full-frame rate extrapolated as cluster + per-pixel passes x {height}/{sample_rows}",
@@ -283,7 +296,7 @@ def main():
     # pair around a kernel stops the command processor from overlapping it with its neighbours on the stream: bracketing
     # every launch costs the frame ~8 %; the launch duration is still measured live, inside the timed frames.) ----
     kctx.timing_set_filter(dominant)
-    kctx.timing_set_sampling(max(1, min(BRACKET_EVERY, args.steps // 5)))
+    kctx.timing_set_sampling(max(1, min(BRACKET_EVERY, args.steps // MIN_BRACKETS)))
     kctx.timing_reset()
     barrier()
     t0 = time.perf_counter()
@@ -350,6 +363,15 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
             entry = pmc["kernels"].get(dominant)
+            if entry and args.workload == "config3_4k_4096lights" and world == 1:
+                # counters of another build of the kernel say nothing about this one
+                import hashlib
+                src = entry.get("source_file")
+                current = hashlib.sha256(open(os.path.join(ROOT, src), "rb").read()).hexdigest() if src else None
+                if current is None or current != entry.get("source_sha256"):
+                    roofline["traffic_source"] = (f"profiles/pmc_traffic.json is stale: {src or 'the kernel source'} changed since the counters were "
+                                                  "collected (tools/pmc_passes.sh regenerates it); traffic not quoted")
+                    entry = None
             if entry and args.workload == "config3_4k_4096lights" and world == 1:
                 roofline["traffic"] = entry["hbm_bytes_per_launch"]
                 roofline["traffic_source"] = "profiles/pmc_traffic.json (" + pmc["source"] + "; " + entry["correction"] + ")"

@@ -619,9 +619,9 @@ int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edg
 		planes.row_g = reinterpret_cast<uint64_t *>(memory + row_plane);
 		planes.col_r = reinterpret_cast<uint64_t *>(memory + 2 * row_plane);
 		planes.col_g = reinterpret_cast<uint64_t *>(memory + 2 * row_plane + col_plane);
-		// tiles of 64 padded rows the band's workgroups stage from: rows first - 96 .. end + 127 (+ the block rounding)
-		const int tile_first = max(0, (int(span.first) - 96 + SMAA_BITS_PAD) >> 6);
-		const int tile_last = min(planes.col_words - 1, (int(span.end) + FAST_BH + 128 + SMAA_BITS_PAD) >> 6);
+		// tiles of 64 padded rows the band's workgroups stage from: rows first - 127 .. end + 175 (+ the block rounding)
+		const int tile_first = max(0, (int(span.first) - 128 + SMAA_BITS_PAD) >> 6);
+		const int tile_last = min(planes.col_words - 1, (int(span.end) + FAST_BH + 192 + SMAA_BITS_PAD) >> 6);
 		const int tiles = planes.row_words * (tile_last - tile_first + 1);
 		SmaaWeightsBitsArgs B = {static_cast<const uint8_t *>(edges->ptr), edges->pitch_bytes, int(edges->width), int(edges->height), planes, S.area, S.search, S.rt, S.P};
 		gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_blend_weight"};

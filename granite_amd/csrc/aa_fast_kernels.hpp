@@ -33,27 +33,44 @@ struct FxaaTile
 	}
 };
 
+// Pixels whose four corners carry the same colour are copied (dir == 0: most of a rendered frame), decided on the bytes straight
+// from the image: a workgroup of such pixels never stages or decodes anything.  The others are a small share of a workgroup that
+// has any: they go into a list that the workgroup walks with all of its lanes (full waves on the 300-instruction path instead of
+// a few live lanes per wave).
 __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_fxaa_fast(const uint8_t *in, uint32_t in_pitch, int w, int h, uint8_t *out, uint32_t out_pitch,
                                                                  float inv_w, float inv_h, RowSpan rows)
 {
-	constexpr int HALO = FxaaTile::HALO, TW = FxaaTile::W, TH = FxaaTile::H;
+	constexpr int HALO = FxaaTile::HALO, TW = FxaaTile::W, TH = FxaaTile::H, THREADS = FAST_BW * FAST_BH, WAVES = THREADS / 64;
 	__shared__ float4 s_dec[TW * TH];
+	__shared__ uint16_t s_list[THREADS];
+	__shared__ uint32_t s_wave_count[WAVES];
 	const int bx = blockIdx.x * FAST_BW, by = int(rows.first) + blockIdx.y * FAST_BH;
-	const int x = bx + threadIdx.x, y = by + threadIdx.y;
-	const bool inside = x < w && y < int(rows.end);
-	// dir == 0 where the four corners carry the same colour: the pass copies the pixel (most of a rendered frame).  Decided on
-	// the bytes, straight from the image: a workgroup of such pixels never stages or decodes anything.
-	const uint32_t centre = load_rgba8_clamped(in, in_pitch, w, h, x, y);
-	const bool flat = aa::fxaa_corners_equal(load_rgba8_clamped(in, in_pitch, w, h, x - 1, y - 1), load_rgba8_clamped(in, in_pitch, w, h, x + 1, y - 1),
-	                                         load_rgba8_clamped(in, in_pitch, w, h, x - 1, y + 1), load_rgba8_clamped(in, in_pitch, w, h, x + 1, y + 1));
-	uint32_t *dst = reinterpret_cast<uint32_t *>(out + (uint32_t(y) * out_pitch + uint32_t(x) * 4u));
-	if (!__syncthreads_or(inside && !flat))
+	const int tid = threadIdx.y * FAST_BW + threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	{
-		if (inside)
-			*dst = centre | 0xff000000u;
-		return;
+		const int x = bx + threadIdx.x, y = by + threadIdx.y;
+		const bool inside = x < w && y < int(rows.end);
+		const uint32_t centre = load_rgba8_clamped(in, in_pitch, w, h, x, y);
+		const bool flat = aa::fxaa_corners_equal(load_rgba8_clamped(in, in_pitch, w, h, x - 1, y - 1), load_rgba8_clamped(in, in_pitch, w, h, x + 1, y - 1),
+		                                         load_rgba8_clamped(in, in_pitch, w, h, x - 1, y + 1), load_rgba8_clamped(in, in_pitch, w, h, x + 1, y + 1));
+		const bool work = inside && !flat;
+		const uint64_t mine = __ballot(work);
+		if (lane == 0)
+			s_wave_count[wave] = uint32_t(__popcll(mine));
+		if (inside && flat)
+			*reinterpret_cast<uint32_t *>(out + (uint32_t(y) * out_pitch + uint32_t(x) * 4u)) = centre | 0xff000000u;
+		__syncthreads();
+		uint32_t total = 0, before = 0;
+		for (int i = 0; i < WAVES; i++)
+		{
+			before += i < wave ? s_wave_count[i] : 0u;
+			total += s_wave_count[i];
+		}
+		if (total == 0u)
+			return;
+		if (work)
+			s_list[before + uint32_t(__popcll(mine & ((1ull << lane) - 1ull)))] = uint16_t(tid);
 	}
-	for (int i = threadIdx.y * FAST_BW + threadIdx.x; i < TW * TH; i += FAST_BW * FAST_BH)
+	for (int i = tid; i < TW * TH; i += THREADS)
 	{
 		const int ty = i / TW, tx = i - ty * TW;
 		const uint32_t t = load_rgba8_clamped(in, in_pitch, w, h, bx - HALO + tx, by - HALO + ty);
@@ -61,14 +78,14 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_fxaa_fast(const uint8_t *i
 		s_dec[i] = make_float4(r, g, b, aa::luma_of(r, g, b, aa::FXAA_LUMA_R, aa::FXAA_LUMA_G, aa::FXAA_LUMA_B));
 	}
 	__syncthreads();
-	if (!inside)
-		return;
-	if (flat)
-		*dst = centre | 0xff000000u;
-	else
+	uint32_t total = 0;
+	for (int i = 0; i < WAVES; i++)
+		total += s_wave_count[i];
+	const FxaaTile tile = {s_dec, bx - HALO, by - HALO};
+	for (uint32_t i = uint32_t(tid); i < total; i += uint32_t(THREADS))
 	{
-		const FxaaTile tile = {s_dec, bx - HALO, by - HALO};
-		*dst = aa::fxaa_pixel(tile, x, y, inv_w, inv_h, float(w), float(h));
+		const int t = s_list[i], x = bx + (t & (FAST_BW - 1)), y = by + (t / FAST_BW);
+		*reinterpret_cast<uint32_t *>(out + (uint32_t(y) * out_pitch + uint32_t(x) * 4u)) = aa::fxaa_pixel(tile, x, y, inv_w, inv_h, float(w), float(h));
 	}
 }
 

@@ -493,22 +493,22 @@ __global__ __launch_bounds__(256) void k_smaa_pack_edges(const uint8_t *edges, u
 struct EdgeBitTiles
 {
 	static constexpr bool HAS_RUNS = true;
-	static constexpr int ROWS = FAST_BH + 36, ROW_DWORDS = 5;  // 160 bits per staged row: x0 - 64 .. x0 + 95
-	static constexpr int COLS = FAST_BW + 4, COL_DWORDS = 6;   // 192 bits per staged column, from col_y0
-	const uint32_t *row_r, *row_g; // [ROWS][ROW_DWORDS]: bit b of row i is texel (x0 - 64 + b, y0 - 18 + i)
+	// Everything the pass reads for a pixel lies within 2 x (32 + 1) + 2 = 68 texels of it along a search axis and within 18
+	// across (the 16-step diagonal searches); the staged words cover 96 / 18 on every side of the block, so no fetch leaves them.
+	static constexpr int HALO = 96;
+	static constexpr int ROWS = FAST_BH + 36, ROW_DWORDS = (FAST_BW + 2 * HALO) / 32;       // x0 - 96 .. x0 + 127: 7 words
+	static constexpr int COLS = FAST_BW + 4, COL_DWORDS = (FAST_BH + 2 * HALO + 31) / 32 + 1; // from col_y0 <= y0 - 96: 8 words
+	const uint32_t *row_r, *row_g; // [ROWS][ROW_DWORDS]: bit b of row i is texel (x0 - 96 + b, y0 - 18 + i)
 	const uint32_t *col_r, *col_g; // [COLS][COL_DWORDS]: bit b of column i is texel (x0 - 2 + i, col_y0 + b)
 	int x0, y0, col_y0;
 	int w, h;
-	const uint8_t *image; // the RG8 edge texture itself, for what lies outside the staged words
-	uint32_t pitch;
 
-	// 64 bits starting at bit p of a staged row / column (p + 64 within the staged bits)
+	// 64 bits starting at bit p of a staged row / column
 	__device__ __forceinline__ static uint64_t window(const uint32_t *words, int p)
 	{
 		const int k = p >> 5, sh = p & 31;
-		const uint32_t a = words[k], b = words[k + 1], c = words[k + 2];
-		const uint32_t lo = sh ? ((a >> sh) | (b << (32 - sh))) : a, hi = sh ? ((b >> sh) | (c << (32 - sh))) : b;
-		return uint64_t(lo) | (uint64_t(hi) << 32);
+		const uint64_t ab = uint64_t(words[k]) | (uint64_t(words[k + 1]) << 32), bc = uint64_t(words[k + 1]) | (uint64_t(words[k + 2]) << 32);
+		return uint64_t(uint32_t(ab >> sh)) | (uint64_t(uint32_t(bc >> sh)) << 32);
 	}
 	__device__ __forceinline__ static uint64_t reverse64(uint64_t v)
 	{
@@ -527,21 +527,9 @@ struct EdgeBitTiles
 		const uint64_t miss = ~(c & (c >> 1)) & 0x5555555555555555ull;
 		return miss ? (__builtin_ctzll(miss) >> 1) : 32;
 	}
-	// the search's condition on one texel, for a step beyond the staged window (the 33rd: only the rounding of the shader's own
-	// end-of-search comparison lets it happen)
-	template <bool COLUMNS>
-	__device__ __attribute__((noinline)) bool pair_continues(int xa, int ya, int xb, int yb) const
-	{
-		// horizontal: G on both texels of row y, R clear on both of rows y, y - 1; vertical: the transposed statement
-		const v2 a = texel<COLUMNS>(xa, ya), b = texel<COLUMNS>(xb, yb);
-		const v2 a1 = COLUMNS ? texel<COLUMNS>(xa - 1, ya) : texel<COLUMNS>(xa, ya - 1), b1 = COLUMNS ? texel<COLUMNS>(xb - 1, yb) : texel<COLUMNS>(xb, yb - 1);
-		if (COLUMNS)
-			return a.x != 0.0f && b.x != 0.0f && a.y == 0.0f && b.y == 0.0f && a1.y == 0.0f && b1.y == 0.0f;
-		return a.y != 0.0f && b.y != 0.0f && a.x == 0.0f && b.x == 0.0f && a1.x == 0.0f && b1.x == 0.0f;
-	}
 	__device__ __forceinline__ uint64_t row_condition(int x_first, int y) const
 	{
-		const int i = y - (y0 - 18), p = x_first - (x0 - 64);
+		const int i = y - (y0 - 18), p = x_first - (x0 - HALO);
 		return window(row_g + i * ROW_DWORDS, p) & ~window(row_r + i * ROW_DWORDS, p) & ~window(row_r + (i - 1) * ROW_DWORDS, p);
 	}
 	__device__ __forceinline__ uint64_t column_condition(int x, int y_first) const
@@ -549,57 +537,69 @@ struct EdgeBitTiles
 		const int i = x - (x0 - 2), p = y_first - col_y0;
 		return window(col_r + i * COL_DWORDS, p) & ~window(col_g + i * COL_DWORDS, p) & ~window(col_g + (i - 1) * COL_DWORDS, p);
 	}
+	// The search's condition on a pair beyond the 64-bit window (the 33rd step: only the rounding of the shader's own
+	// end-of-search comparison lets it happen).  Horizontal: G on both texels of row y, R clear on both of rows y, y - 1;
+	// vertical: the transposed statement.
+	template <bool COLUMNS>
+	__device__ __forceinline__ bool pair_continues(int xa, int ya, int xb, int yb) const
+	{
+		const v2 a = texel<COLUMNS>(xa, ya), b = texel<COLUMNS>(xb, yb);
+		const v2 a1 = COLUMNS ? texel<COLUMNS>(xa - 1, ya) : texel<COLUMNS>(xa, ya - 1), b1 = COLUMNS ? texel<COLUMNS>(xb - 1, yb) : texel<COLUMNS>(xb, yb - 1);
+		if (COLUMNS)
+			return a.x * b.x != 0.0f && a.y + b.y + a1.y + b1.y == 0.0f;
+		return a.y * b.y != 0.0f && a.x + b.x + a1.x + b1.x == 0.0f;
+	}
 	// step j of the left search samples texels (x - 1 - 2j, x - 2j) of rows y - 1, y: the window [x - 63, x], mirrored
 	__device__ __forceinline__ int run_left(int x, int y) const
 	{
 		int run = leading_pairs(reverse64(row_condition(x - 63, y)));
-		if (run == 32 && pair_continues<false>(x - 64, y, x - 65, y))
-			run++;
+		if (run == 32)
+			run += pair_continues<false>(x - 64, y, x - 65, y) ? 1 : 0;
 		return run;
 	}
 	// step j of the right search samples texels (x + 1 + 2j, x + 2 + 2j)
 	__device__ __forceinline__ int run_right(int x, int y) const
 	{
 		int run = leading_pairs(row_condition(x + 1, y));
-		if (run == 32 && pair_continues<false>(x + 65, y, x + 66, y))
-			run++;
+		if (run == 32)
+			run += pair_continues<false>(x + 65, y, x + 66, y) ? 1 : 0;
 		return run;
 	}
 	__device__ __forceinline__ int run_up(int x, int y) const
 	{
 		int run = leading_pairs(reverse64(column_condition(x, y - 63)));
-		if (run == 32 && pair_continues<true>(x, y - 64, x, y - 65))
-			run++;
+		if (run == 32)
+			run += pair_continues<true>(x, y - 64, x, y - 65) ? 1 : 0;
 		return run;
 	}
 	__device__ __forceinline__ int run_down(int x, int y) const
 	{
 		int run = leading_pairs(column_condition(x, y + 1));
-		if (run == 32 && pair_continues<true>(x, y + 65, x, y + 66))
-			run++;
+		if (run == 32)
+			run += pair_continues<true>(x, y + 65, x, y + 66) ? 1 : 0;
 		return run;
 	}
 
 	// (R, G) of one texel as 0.0 / 1.0.  COLUMNS = false: from the staged rows (everything a horizontal edge and the diagonal
-	// searches touch); true: from the staged columns (a vertical edge's searches and what follows them).  What lies outside the
-	// staged words (the far end of a 32-step search) is read from the image.
+	// searches touch); true: from the staged columns (a vertical edge's searches and what follows them).  No branch: the reach of
+	// the pass stays inside the staged words (above); the index is clamped into them all the same.
 	template <bool COLUMNS>
 	__device__ __forceinline__ v2 texel(int x, int y) const
 	{
-		const int line = COLUMNS ? x - (x0 - 2) : y - (y0 - 18), bit = COLUMNS ? y - col_y0 : x - (x0 - 64);
+		int line = COLUMNS ? x - (x0 - 2) : y - (y0 - 18), bit = COLUMNS ? y - col_y0 : x - (x0 - HALO);
+#if defined(AA_EMU_CHECK_REACH)
 		if (unsigned(line) >= unsigned(COLUMNS ? COLS : ROWS) || unsigned(bit) >= unsigned((COLUMNS ? COL_DWORDS : ROW_DWORDS) * 32))
-			return texel_from_image(x, y);
+			aa_emu_reach_violation(COLUMNS, x, y, x0, y0);
+#endif
+		line = aa::clampi(line, 0, (COLUMNS ? COLS : ROWS) - 1);
+		bit = aa::clampi(bit, 0, (COLUMNS ? COL_DWORDS : ROW_DWORDS) * 32 - 1);
 		const int k = line * (COLUMNS ? COL_DWORDS : ROW_DWORDS) + (bit >> 5), s = bit & 31;
 		return mk2(float(((COLUMNS ? col_r : row_r)[k] >> s) & 1u), float(((COLUMNS ? col_g : row_g)[k] >> s) & 1u));
 	}
-	__device__ __attribute__((noinline)) v2 texel_from_image(int x, int y) const
-	{
-		const uint32_t t = *reinterpret_cast<const uint16_t *>(image + (uint32_t(aa::clampi(y, 0, h - 1)) * pitch + uint32_t(aa::clampi(x, 0, w - 1)) * 2u));
-		return mk2((t & 255u) ? 1.0f : 0.0f, (t >> 8) ? 1.0f : 0.0f);
-	}
 
 	// LinearClamp over the edge texture: the sampler of the byte image (aa.hip: Tex8::sample) with the texels taken from the bits.
-	// 0.0 / 1.0 texels make t * (1 - a) + t' * a exact for a = 0, so the snapped cases need fewer texels, not another formula.
+	// Straight-line code -- four texels, three lerps -- whatever the weights: with 0.0 / 1.0 texels t * (1 - a) + t' * a is exact for
+	// a snapped weight (a = 0), and the lanes of a wave take their taps in lockstep.
 	template <bool COLUMNS = false>
 	__device__ __forceinline__ v4 sample(v2 uv, int ox = 0, int oy = 0) const
 	{
@@ -609,25 +609,11 @@ struct EdgeBitTiles
 		aa::linear_axis(uv.y * float(h) - 0.5f, iy, b);
 		ix += ox;
 		iy += oy;
-		const v2 t00 = texel<COLUMNS>(ix, iy);
-		v2 top = t00;
-		if (a != 0.0f)
-		{
-			const v2 t10 = texel<COLUMNS>(ix + 1, iy);
-			top = t00 * (1.0f - a) + t10 * a;
-		}
-		if (b != 0.0f)
-		{
-			const v2 t01 = texel<COLUMNS>(ix, iy + 1);
-			v2 bot = t01;
-			if (a != 0.0f)
-			{
-				const v2 t11 = texel<COLUMNS>(ix + 1, iy + 1);
-				bot = t01 * (1.0f - a) + t11 * a;
-			}
-			top = top * (1.0f - b) + bot * b;
-		}
-		return mk4(top.x, top.y, 0.0f, 1.0f);
+		const v2 t00 = texel<COLUMNS>(ix, iy), t10 = texel<COLUMNS>(ix + 1, iy), t01 = texel<COLUMNS>(ix, iy + 1), t11 = texel<COLUMNS>(ix + 1, iy + 1);
+		const v2 top = t00 * (1.0f - a) + t10 * a;
+		const v2 bot = t01 * (1.0f - a) + t11 * a;
+		const v2 r = top * (1.0f - b) + bot * b;
+		return mk4(r.x, r.y, 0.0f, 1.0f);
 	}
 };
 
@@ -644,42 +630,59 @@ struct SmaaWeightsBitsArgs
 };
 
 // SMAABlendingWeightCalculationPS over the bit planes.  The reference runs the quad under a depth mask EQUAL to the edge pass's
-// non-discarded pixels (smaa.cpp:101-112,170-177); the mask is the edge texel itself: zero edge => zero weights.
+// non-discarded pixels (smaa.cpp:101-112,170-177); the mask is the edge texel itself: zero edge => zero weights.  Edge pixels are
+// a few per cent of a frame and take different paths through the pass (horizontal / vertical / diagonal patterns), so the
+// workgroup first writes its edge pixels into a list and then walks the list with all of its lanes: full waves of edge pixels
+// instead of a few live lanes per wave.
 __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_weights_bits(SmaaWeightsBitsArgs A, uint8_t *out, uint32_t out_pitch, RowSpan rows)
 {
 	using T = EdgeBitTiles;
-	__shared__ uint32_t s_row_r[T::ROWS * T::ROW_DWORDS + 1], s_row_g[T::ROWS * T::ROW_DWORDS + 1]; // + 1: window() reads one word ahead
-	__shared__ uint32_t s_col_r[T::COLS * T::COL_DWORDS + 1], s_col_g[T::COLS * T::COL_DWORDS + 1];
+	constexpr int THREADS = FAST_BW * FAST_BH, WAVES = THREADS / 64;
+	__shared__ uint32_t s_row_r[T::ROWS * T::ROW_DWORDS + 2], s_row_g[T::ROWS * T::ROW_DWORDS + 2]; // + 2: window() reads two words ahead
+	__shared__ uint32_t s_col_r[T::COLS * T::COL_DWORDS + 2], s_col_g[T::COLS * T::COL_DWORDS + 2];
+	__shared__ uint16_t s_list[THREADS];
+	__shared__ uint32_t s_wave_count[WAVES];
 	const int bx = blockIdx.x * FAST_BW, by = int(rows.first) + blockIdx.y * FAST_BH;
-	const int x = bx + threadIdx.x, y = by + threadIdx.y;
-	const bool inside = x < A.w && y < int(rows.end);
-	uint32_t e = 0;
-	if (inside)
-		e = *reinterpret_cast<const uint16_t *>(A.edges + (uint32_t(y) * A.edges_pitch + uint32_t(x) * 2u));
-	uint32_t *dst = reinterpret_cast<uint32_t *>(out + (uint32_t(y) * out_pitch + uint32_t(x) * 4u));
-	if (!__syncthreads_or(e != 0u))
+	const int tid = threadIdx.y * FAST_BW + threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	{
+		const int x = bx + threadIdx.x, y = by + threadIdx.y;
+		const bool inside = x < A.w && y < int(rows.end);
+		uint32_t e = 0;
 		if (inside)
-			*dst = 0u;
-		return;
+			e = *reinterpret_cast<const uint16_t *>(A.edges + (uint32_t(y) * A.edges_pitch + uint32_t(x) * 2u));
+		const uint64_t mine = __ballot(e != 0u);
+		if (lane == 0)
+			s_wave_count[wave] = uint32_t(__popcll(mine));
+		if (inside && e == 0u)
+			*reinterpret_cast<uint32_t *>(out + (uint32_t(y) * out_pitch + uint32_t(x) * 4u)) = 0u;
+		__syncthreads();
+		uint32_t total = 0, before = 0;
+		for (int i = 0; i < WAVES; i++)
+		{
+			before += i < wave ? s_wave_count[i] : 0u;
+			total += s_wave_count[i];
+		}
+		if (total == 0u)
+			return;
+		if (e != 0u)
+			s_list[before + uint32_t(__popcll(mine & ((1ull << lane) - 1ull)))] = uint16_t(tid);
 	}
-	const int tid = threadIdx.y * FAST_BW + threadIdx.x;
 	// the planes as 32-bit words: bx is a multiple of 32 and so is the pad, the staged rows start on a word; the staged columns
-	// start on the word holding row by - 64
+	// start on the word holding row by - HALO
 	const uint32_t *row_r32 = reinterpret_cast<const uint32_t *>(A.planes.row_r), *row_g32 = reinterpret_cast<const uint32_t *>(A.planes.row_g);
 	const uint32_t *col_r32 = reinterpret_cast<const uint32_t *>(A.planes.col_r), *col_g32 = reinterpret_cast<const uint32_t *>(A.planes.col_g);
-	const int row_word0 = (bx - 64 + SMAA_BITS_PAD) >> 5;
-	const int col_word0 = (by - 64 + SMAA_BITS_PAD) >> 5, col_y0 = (col_word0 << 5) - SMAA_BITS_PAD;
+	const int row_word0 = (bx - T::HALO + SMAA_BITS_PAD) >> 5;
+	const int col_word0 = (by - T::HALO + SMAA_BITS_PAD) >> 5, col_y0 = (col_word0 << 5) - SMAA_BITS_PAD;
 	// without the diagonal searches nothing reaches beyond two rows above / one below the block's pixels
 	const int row_first = A.P.diag ? 0 : 16, row_count = A.P.diag ? T::ROWS : FAST_BH + 4;
-	for (int i = tid; i < row_count * T::ROW_DWORDS; i += FAST_BW * FAST_BH)
+	for (int i = tid; i < row_count * T::ROW_DWORDS; i += THREADS)
 	{
 		const int r = row_first + i / T::ROW_DWORDS, k = i % T::ROW_DWORDS;
 		const size_t word = size_t(by - 18 + r + SMAA_BITS_PAD) * (A.planes.row_words * 2) + row_word0 + k;
 		s_row_r[r * T::ROW_DWORDS + k] = row_r32[word];
 		s_row_g[r * T::ROW_DWORDS + k] = row_g32[word];
 	}
-	for (int i = tid; i < T::COLS * T::COL_DWORDS; i += FAST_BW * FAST_BH)
+	for (int i = tid; i < T::COLS * T::COL_DWORDS; i += THREADS)
 	{
 		const int c = i / T::COL_DWORDS, k = i % T::COL_DWORDS;
 		const size_t word = size_t(bx - 2 + c + SMAA_BITS_PAD) * (A.planes.col_words * 2) + col_word0 + k;
@@ -687,14 +690,15 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_weights_bits(SmaaWeig
 		s_col_g[i] = col_g32[word];
 	}
 	__syncthreads();
-	if (!inside)
-		return;
-	uint32_t packed = 0u;
-	if (e != 0u)
+	uint32_t total = 0;
+	for (int i = 0; i < WAVES; i++)
+		total += s_wave_count[i];
+	SmaaWeights<EdgeBitTiles> S = {{s_row_r, s_row_g, s_col_r, s_col_g, bx, by, col_y0, A.w, A.h}, A.area, A.search, A.rt, A.P};
+	for (uint32_t i = uint32_t(tid); i < total; i += uint32_t(THREADS))
 	{
-		SmaaWeights<EdgeBitTiles> S = {{s_row_r, s_row_g, s_col_r, s_col_g, bx, by, col_y0, A.w, A.h, A.edges, A.edges_pitch}, A.area, A.search, A.rt, A.P};
+		const int t = s_list[i], x = bx + (t & (FAST_BW - 1)), y = by + (t / FAST_BW);
 		const v4 wgt = S.weights_at(x, y);
-		packed = aa::unorm8_encode(wgt.x) | (aa::unorm8_encode(wgt.y) << 8) | (aa::unorm8_encode(wgt.z) << 16) | (aa::unorm8_encode(wgt.w) << 24);
+		*reinterpret_cast<uint32_t *>(out + (uint32_t(y) * out_pitch + uint32_t(x) * 4u)) =
+		    aa::unorm8_encode(wgt.x) | (aa::unorm8_encode(wgt.y) << 8) | (aa::unorm8_encode(wgt.z) << 16) | (aa::unorm8_encode(wgt.w) << 24);
 	}
-	*dst = packed;
 }

@@ -2,6 +2,15 @@
 // compiles -- on the CPU through tests/cpp/hip_emu.hpp, with the launch geometry of the launchers in aa.hip.  Built by
 // tests/test_aa_fast_kernels_cpu.py with g++ -ffp-contract=off and compared with the oracle bit for bit.
 #include "hip_emu.hpp"
+#include <cstdio>
+#include <cstdlib>
+// smaa_weights.hpp under AA_EMU_CHECK_REACH: a texel fetch outside the staged bit words is a defect of the reach analysis
+#define AA_EMU_CHECK_REACH 1
+static void aa_emu_reach_violation(bool columns, int x, int y, int x0, int y0)
+{
+	fprintf(stderr, "EdgeBitTiles: %s fetch of texel (%d, %d) outside the words staged for the block at (%d, %d)\n", columns ? "column" : "row", x, y, x0, y0);
+	abort();
+}
 #include "../../granite_amd/csrc/aa_fast_kernels.hpp"
 #include "../../granite_amd/csrc/smaa_weights.hpp"
 
@@ -99,8 +108,8 @@ void aah_smaa_weights(const uint8_t *edges, int w, int h, const uint8_t *area_rg
 	// poisoned: a word the pack kernel did not write for this band must not matter
 	std::vector<uint64_t> row_r(size_t(planes.rows()) * planes.row_words, 0xA5A5A5A5A5A5A5A5ull), row_g(row_r), col_r(size_t(planes.cols()) * planes.col_words, 0x5A5A5A5A5A5A5A5Aull), col_g(col_r);
 	planes.row_r = row_r.data(), planes.row_g = row_g.data(), planes.col_r = col_r.data(), planes.col_g = col_g.data();
-	const int tile_first = std::max(0, (int(rows.first) - 96 + SMAA_BITS_PAD) >> 6);
-	const int tile_last = std::min(planes.col_words - 1, (int(rows.end) + FAST_BH + 128 + SMAA_BITS_PAD) >> 6);
+	const int tile_first = std::max(0, (int(rows.first) - 128 + SMAA_BITS_PAD) >> 6);
+	const int tile_last = std::min(planes.col_words - 1, (int(rows.end) + FAST_BH + 192 + SMAA_BITS_PAD) >> 6);
 	const int tiles = planes.row_words * (tile_last - tile_first + 1);
 	emu::launch(k_smaa_pack_edges, dim3(tiles), dim3(256), edges, uint32_t(w * 2), w, h, planes, tile_first, tile_last - tile_first + 1);
 	SmaaWeightsBitsArgs B = {edges, uint32_t(w * 2), w, h, planes, {area.data(), 160, 560}, {search.data(), 64, 16},

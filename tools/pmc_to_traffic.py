@@ -3,7 +3,7 @@
 figures bench.py quotes in `roofline.traffic` / `roofline.valu_issue`.  HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE (KB):
 rocprofv3 on gfx950 tallies 128-byte read requests at 64 bytes (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as
 reported.  usage: pmc_to_traffic.py <summary.json> <out.json> <round>"""
-import json, sys
+import hashlib, json, os, sys
 
 summary, out, rnd = sys.argv[1], sys.argv[2], int(sys.argv[3])
 table = json.load(open(summary))
@@ -12,12 +12,17 @@ correction = ("FETCH_SIZE doubled (gfx950 rocprofv3 tallies 128-B read requests 
               "WRITE_SIZE as reported")
 classes = {"fma_f32": "SQ_INSTS_VALU_FMA_F32", "mul_f32": "SQ_INSTS_VALU_MUL_F32", "add_f32": "SQ_INSTS_VALU_ADD_F32",
            "transcendental_f32": "SQ_INSTS_VALU_TRANS_F32", "cvt": "SQ_INSTS_VALU_CVT", "int32": "SQ_INSTS_VALU_INT32"}
+# the translation unit each kernel comes from: bench.py refuses these figures once the source has changed since they were taken
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sources = {"lighting": "granite_amd/csrc/lighting.hip", "tonemap": "granite_amd/csrc/post.hip", "bloom_threshold": "granite_amd/csrc/post.hip"}
+def sha256(path):
+    return hashlib.sha256(open(os.path.join(ROOT, path), "rb").read()).hexdigest()
 kernels = {}
 for key, name in want.items():
     vals = table.get(name)
     if not vals:
         continue
-    entry = {"kernel": name, "FETCH_SIZE_KB": vals.get("FETCH_SIZE"), "WRITE_SIZE_KB": vals.get("WRITE_SIZE"), "correction": correction}
+    entry = {"kernel": name, "source_file": sources[key], "source_sha256": sha256(sources[key]), "FETCH_SIZE_KB": vals.get("FETCH_SIZE"), "WRITE_SIZE_KB": vals.get("WRITE_SIZE"), "correction": correction}
     if vals.get("FETCH_SIZE") is not None and vals.get("WRITE_SIZE") is not None:
         entry["hbm_bytes_per_launch"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"):
