@@ -623,7 +623,8 @@ int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edg
 		const int tile_first = max(0, (int(span.first) - 128 + SMAA_BITS_PAD) >> 6);
 		const int tile_last = min(planes.col_words - 1, (int(span.end) + FAST_BH + 192 + SMAA_BITS_PAD) >> 6);
 		const int tiles = planes.row_words * (tile_last - tile_first + 1);
-		SmaaWeightsBitsArgs B = {static_cast<const uint8_t *>(edges->ptr), edges->pitch_bytes, int(edges->width), int(edges->height), planes, S.area, S.search, S.rt, S.P};
+		SmaaWeightsBitsArgs B = {static_cast<const uint8_t *>(edges->ptr), edges->pitch_bytes, int(edges->width), int(edges->height), planes, S.area, S.search, S.rt, S.P,
+		                         centre_taps_exact(ctx, edges->width, push->rt_metrics[0]) && centre_taps_exact(ctx, edges->height, push->rt_metrics[1])};
 		gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_blend_weight"};
 		hipLaunchKernelGGL(k_smaa_pack_edges, dim3(tiles), dim3(256), 0, gr_to_stream(stream), B.edges, B.edges_pitch, B.w, B.h, planes,
 		                   tile_first, tile_last - tile_first + 1);

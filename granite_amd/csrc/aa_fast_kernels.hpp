@@ -84,7 +84,7 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_fxaa_fast(const uint8_t *i
 	const FxaaTile tile = {s_dec, bx - HALO, by - HALO};
 	for (uint32_t i = uint32_t(tid); i < total; i += uint32_t(THREADS))
 	{
-		const int t = s_list[i], x = bx + (t & (FAST_BW - 1)), y = by + (t / FAST_BW);
+		const int t = total == uint32_t(THREADS) ? int(i) : int(s_list[i]), x = bx + (t & (FAST_BW - 1)), y = by + (t / FAST_BW);
 		*reinterpret_cast<uint32_t *>(out + (uint32_t(y) * out_pitch + uint32_t(x) * 4u)) = aa::fxaa_pixel(tile, x, y, inv_w, inv_h, float(w), float(h));
 	}
 }

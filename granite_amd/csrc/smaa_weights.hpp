@@ -334,6 +334,30 @@ struct SmaaWeights
 		const float sum = leftRight.x + leftRight.y;
 		rounding = mk2(rounding.x / sum, rounding.y / sum);
 		v2 factor = mk2(1.0f, 1.0f);
+		if constexpr (Edges::HAS_RUNS)
+		{
+			// The crossing-edge taps of a horizontal (vertical) edge sit on the pixel's own row (column): where pixel-centre taps are
+			// texel fetches (edges.centres_snap, aa_core.hpp: axis_taps_exact) they read one line of texels, lerped along the edge only.
+			if (edges.centres_snap)
+			{
+				if (horizontal)
+				{
+					factor.x -= rounding.x * edges.template sample_along<false>(texcoord.x, px, py, 0, 1).x;
+					factor.x -= rounding.y * edges.template sample_along<false>(texcoord.z, px, py, 1, 1).x;
+					factor.y -= rounding.x * edges.template sample_along<false>(texcoord.x, px, py, 0, -2).x;
+					factor.y -= rounding.y * edges.template sample_along<false>(texcoord.z, px, py, 1, -2).x;
+				}
+				else
+				{
+					factor.x -= rounding.x * edges.template sample_along<true>(texcoord.y, px, py, 1, 0).y;
+					factor.x -= rounding.y * edges.template sample_along<true>(texcoord.w, px, py, 1, 1).y;
+					factor.y -= rounding.x * edges.template sample_along<true>(texcoord.y, px, py, -2, 0).y;
+					factor.y -= rounding.y * edges.template sample_along<true>(texcoord.w, px, py, -2, 1).y;
+				}
+				weights = weights * mk2(clampfv(factor.x, 0.0f, 1.0f), clampfv(factor.y, 0.0f, 1.0f));
+				return;
+			}
+		}
 		if (horizontal)
 		{
 			factor.x -= rounding.x * edges.sample(mk2(texcoord.x, texcoord.y), 0, 1).x;
@@ -502,6 +526,7 @@ struct EdgeBitTiles
 	const uint32_t *col_r, *col_g; // [COLS][COL_DWORDS]: bit b of column i is texel (x0 - 2 + i, col_y0 + b)
 	int x0, y0, col_y0;
 	int w, h;
+	bool centres_snap; // pixel-centre coordinates of this image resolve to texel fetches (aa_core.hpp: axis_taps_exact)
 
 	// 64 bits starting at bit p of a staged row / column
 	__device__ __forceinline__ static uint64_t window(const uint32_t *words, int p)
@@ -597,6 +622,19 @@ struct EdgeBitTiles
 		return mk2(float(((COLUMNS ? col_r : row_r)[k] >> s) & 1u), float(((COLUMNS ? col_g : row_g)[k] >> s) & 1u));
 	}
 
+	// A tap whose coordinate across the edge is the centre of pixel (px, py) -- a texel fetch on that axis -- and whose coordinate
+	// along the edge is `t` (u for a horizontal edge, COLUMNS = false; v for a vertical one): two texels, one lerp.
+	template <bool COLUMNS>
+	__device__ __forceinline__ v2 sample_along(float t, int px, int py, int ox, int oy) const
+	{
+		int i;
+		float a;
+		aa::linear_axis(t * float(COLUMNS ? h : w) - 0.5f, i, a);
+		const int ix = (COLUMNS ? px : i) + ox, iy = (COLUMNS ? i : py) + oy;
+		const v2 t0 = texel<COLUMNS>(ix, iy), t1 = COLUMNS ? texel<COLUMNS>(ix, iy + 1) : texel<COLUMNS>(ix + 1, iy);
+		return t0 * (1.0f - a) + t1 * a;
+	}
+
 	// LinearClamp over the edge texture: the sampler of the byte image (aa.hip: Tex8::sample) with the texels taken from the bits.
 	// Straight-line code -- four texels, three lerps -- whatever the weights: with 0.0 / 1.0 texels t * (1 - a) + t' * a is exact for
 	// a snapped weight (a = 0), and the lanes of a wave take their taps in lockstep.
@@ -627,6 +665,7 @@ struct SmaaWeightsBitsArgs
 	TexF<1> search;
 	v4 rt;
 	SmaaPreset P;
+	int centres_snap;
 };
 
 // SMAABlendingWeightCalculationPS over the bit planes.  The reference runs the quad under a depth mask EQUAL to the edge pass's
@@ -693,7 +732,7 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_weights_bits(SmaaWeig
 	uint32_t total = 0;
 	for (int i = 0; i < WAVES; i++)
 		total += s_wave_count[i];
-	SmaaWeights<EdgeBitTiles> S = {{s_row_r, s_row_g, s_col_r, s_col_g, bx, by, col_y0, A.w, A.h}, A.area, A.search, A.rt, A.P};
+	SmaaWeights<EdgeBitTiles> S = {{s_row_r, s_row_g, s_col_r, s_col_g, bx, by, col_y0, A.w, A.h, A.centres_snap != 0}, A.area, A.search, A.rt, A.P};
 	for (uint32_t i = uint32_t(tid); i < total; i += uint32_t(THREADS))
 	{
 		const int t = s_list[i], x = bx + (t & (FAST_BW - 1)), y = by + (t / FAST_BW);

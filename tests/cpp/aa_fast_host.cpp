@@ -113,7 +113,8 @@ void aah_smaa_weights(const uint8_t *edges, int w, int h, const uint8_t *area_rg
 	const int tiles = planes.row_words * (tile_last - tile_first + 1);
 	emu::launch(k_smaa_pack_edges, dim3(tiles), dim3(256), edges, uint32_t(w * 2), w, h, planes, tile_first, tile_last - tile_first + 1);
 	SmaaWeightsBitsArgs B = {edges, uint32_t(w * 2), w, h, planes, {area.data(), 160, 560}, {search.data(), 64, 16},
-	                         v4{1.0f / float(w), 1.0f / float(h), float(w), float(h)}, preset_of(quality)};
+	                         v4{1.0f / float(w), 1.0f / float(h), float(w), float(h)}, preset_of(quality),
+	                         aah_centre_taps_exact(w, 1.0f / float(w)) && aah_centre_taps_exact(h, 1.0f / float(h)) && !getenv("AAH_NO_CENTRE_SNAP")};
 	emu::launch(k_smaa_weights_bits, dim3(div_up(w, FAST_BW), div_up(rows.count(), FAST_BH)), dim3(FAST_BW, FAST_BH), B, out, uint32_t(w * 4), rows);
 }
 }
