@@ -47,7 +47,8 @@ class LightingArgs(C.Structure):
                 ("cluster", C.c_void_p), ("lights", C.c_void_p), ("type_mask", C.c_void_p), ("bitmask", C.c_void_p),
                 ("range", C.c_void_p), ("dir_color", C.c_float * 3), ("dir_direction", C.c_float * 3),
                 ("enable_directional", C.c_int32), ("enable_clustered", C.c_int32), ("ambient_fallback", C.c_int32),
-                ("wave_tile", C.c_int32), ("ambient_occlusion", C.c_void_p), ("ao_width", C.c_int32), ("ao_height", C.c_int32)]
+                ("wave_tile", C.c_int32), ("ambient_occlusion", C.c_void_p), ("ao_width", C.c_int32), ("ao_height", C.c_int32),
+                ("hdr_b10g11r11", C.c_int32)]
 
 
 def build(force: bool = False) -> str:
@@ -231,10 +232,35 @@ def cluster_build(rp, prm, lights, model, type_mask, num_lights: int, res_z: int
     return {"spots": spots, "setup": setup, "bitmask": bitmask, "light_ranges": zr, "range": ranges}
 
 
+def pack_b10g11r11(rgba16f: np.ndarray) -> np.ndarray:
+    """RGBA16F bits (h, w, 4) -> B10G11R11_UFLOAT_PACK32 words (h, w): the attachment store conversion (round to the closest finite
+    value, ties to even; negatives -> 0)."""
+    src = np.ascontiguousarray(rgba16f, np.uint16)
+    out = np.zeros(src.shape[:-1], np.uint32)
+    lib().orc_pack_b10g11r11_from_rgba16f(_p(src), _p(out), C.c_uint64(out.size))
+    return out
+
+
+def unpack_b10g11r11(words: np.ndarray) -> np.ndarray:
+    """B10G11R11 words (h, w) -> the same texels as RGBA16F bits (h, w, 4): exact, alpha 1."""
+    src = np.ascontiguousarray(words, np.uint32)
+    out = np.zeros(src.shape + (4,), np.uint16)
+    lib().orc_unpack_b10g11r11_to_rgba16f(_p(src), _p(out), C.c_uint64(src.size))
+    return out
+
+
+def quantize_b10g11r11(rgba16f: np.ndarray) -> np.ndarray:
+    """What an RGBA16F image becomes when it is stored into a B10G11R11 attachment, as RGBA16F bits again."""
+    return unpack_b10g11r11(pack_b10g11r11(rgba16f))
+
+
 def lighting(gbuf: dict, rp, prm, lights, type_mask, bitmask, ranges, dir_color, dir_direction, directional=True,
-             clustered=True, ambient_fallback=True, wave_tile=0, bruteforce=False, ambient_occlusion=None, entry=None) -> np.ndarray:
+             clustered=True, ambient_fallback=True, wave_tile=0, bruteforce=False, ambient_occlusion=None, entry=None,
+             b10g11r11=False) -> np.ndarray:
     """Returns the HDR target (RGBA16F bits) after DeferredLightRenderer::render_light on gbuf['emissive'].
-    entry: another implementation taking the same OrcLightingArgs (oracle/_ref's ref_lighting: the reference's own shaders)."""
+    entry: another implementation taking the same OrcLightingArgs (oracle/_ref's ref_lighting: the reference's own shaders).
+    b10g11r11: the target is a B10G11R11_UFLOAT_PACK32 attachment (renderTargetFp16 = false): gbuf['emissive'] must hold packed-
+    representable values (quantize_b10g11r11), both blends round to the packed format, the result is returned as RGBA16F bits."""
     h, w = gbuf["depth"].shape
     hdr = np.array(gbuf["emissive"], np.uint16, copy=True)
     a = LightingArgs()
@@ -250,6 +276,7 @@ def lighting(gbuf: dict, rp, prm, lights, type_mask, bitmask, ranges, dir_color,
     a.dir_direction = (C.c_float * 3)(*[float(v) for v in dir_direction])
     a.enable_directional, a.enable_clustered = int(directional), int(clustered)
     a.ambient_fallback, a.wave_tile = int(ambient_fallback), int(wave_tile)
+    a.hdr_b10g11r11 = int(b10g11r11)
     if ambient_occlusion is not None:  # AMBIENT_OCCLUSION variant: R8_UNORM image of any size
         ao = np.ascontiguousarray(ambient_occlusion, np.uint8)
         keep.append(ao)
@@ -308,14 +335,15 @@ def smaa(rgba8: np.ndarray, area, search, quality: int, target_srgb: bool = True
     return {"edges": e, "weights": wt, "out": smaa_blend(rgba8, wt, target_srgb)}
 
 
-def taa_resolve(current: np.ndarray, depth: np.ndarray, mv: np.ndarray, history, reproj16, quality: int):
+def taa_resolve(current: np.ndarray, depth: np.ndarray, mv: np.ndarray, history, reproj16, quality: int, color_b10g11r11: bool = False):
+    """color_b10g11r11: the resolved colour is stored to a B10G11R11 attachment (returned as its exact RGBA16F texels)."""
     w, h = _img16(current)
     d = np.ascontiguousarray(depth, np.float32)
     m = np.ascontiguousarray(mv, np.uint16)
     r = np.ascontiguousarray(reproj16, np.float32)
     out_c = np.zeros((h, w, 4), np.uint16)
     out_h = np.zeros((h, w, 4), np.uint16)
-    lib().orc_taa_resolve(_p(current), _p(d), _p(m), _p(history), w, h, _p(r), quality, _p(out_c), _p(out_h))
+    lib().orc_taa_resolve_fmt(_p(current), _p(d), _p(m), _p(history), w, h, _p(r), quality, _p(out_c), _p(out_h), int(color_b10g11r11))
     return out_c, out_h
 
 

@@ -551,8 +551,18 @@ static inline vec3 clamp_box(vec3 color, vec3 lo, vec3 hi, bool aabb)
 }
 } // namespace
 
+// color_b10g11r11: the resolved colour goes to a B10G11R11_UFLOAT_PACK32 attachment (temporal.cpp:211-213: the reference's
+// choice wherever the format is renderable); out_color then holds the packed values as their exact RGBA16F texels.  The history
+// stays RGBA16F (temporal.cpp:216).
+void orc_taa_resolve_fmt(const uint16_t *current, const float *depth, const uint16_t *mv_rg16f, const uint16_t *history_in, int w, int h,
+                         const float *reproj16, int quality, uint16_t *out_color, uint16_t *out_history, int color_b10g11r11);
 void orc_taa_resolve(const uint16_t *current, const float *depth, const uint16_t *mv_rg16f, const uint16_t *history_in, int w, int h,
                      const float *reproj16, int quality, uint16_t *out_color, uint16_t *out_history)
+{
+	orc_taa_resolve_fmt(current, depth, mv_rg16f, history_in, w, h, reproj16, quality, out_color, out_history, 0);
+}
+void orc_taa_resolve_fmt(const uint16_t *current, const float *depth, const uint16_t *mv_rg16f, const uint16_t *history_in, int w, int h,
+                         const float *reproj16, int quality, uint16_t *out_color, uint16_t *out_history, int color_b10g11r11)
 {
 	Tex16F cur{current, w, h};
 	Tex16F hist{history_in, w, h};
@@ -693,7 +703,10 @@ void orc_taa_resolve(const uint16_t *current, const float *depth, const uint16_t
 				hist_c = mixed;
 				out_c = taa_to_hdr(mixed);
 			}
-			store_rgba16f(out_color, w, x, y, V4(out_c, 1.0f));
+			if (color_b10g11r11)
+				store_rgba16f_as_b10g11r11(out_color, w, x, y, V4(out_c, 1.0f));
+			else
+				store_rgba16f(out_color, w, x, y, V4(out_c, 1.0f));
 			store_rgba16f(out_history, w, x, y, V4(hist_c, 1.0f));
 		}
 }

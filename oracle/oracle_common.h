@@ -249,6 +249,71 @@ static inline uint8_t float_to_srgb8(float linear)
 }
 static inline float srgb8_to_float(uint8_t v) { return srgb_decode(float(v) / 255.0f); }
 
+// B10G11R11_UFLOAT_PACK32 (the reference's default HDR target, scene_viewer_application.cpp:881-883 with renderTargetFp16 =
+// false, and its TAA output, temporal.cpp:211-213): R = bits 0..10 and G = bits 11..21 as unsigned 11-bit floats (5 exponent
+// bits, bias 15, 6 mantissa bits), B = bits 22..31 as an unsigned 10-bit float (5 mantissa bits); no alpha (reads give 1).
+// Every value is exactly a half float.  Conversion from fp32, as the Vulkan / OpenGL packed-float rules have it: finite values
+// round to the closest representable FINITE value (ties to even here; > max -> max: 65024 / 64512), negative values and -inf
+// -> 0, +inf -> +inf, NaN -> NaN.  `mant_bits` = 6 (R, G) or 5 (B).
+static inline uint32_t float_to_ufloat(float f, int mant_bits)
+{
+	const uint32_t u = f2u(f);
+	const uint32_t a = u & 0x7fffffffu;
+	const uint32_t inf = 31u << mant_bits, max_finite = inf - 1u;
+	if (a > 0x7f800000u) // NaN (either sign)
+		return inf | 1u;
+	if (u & 0x80000000u) // negative, -0, -inf
+		return 0u;
+	if (a == 0x7f800000u)
+		return inf;
+	const int shift = 23 - mant_bits;
+	if (a < 0x38800000u) // < 2^-14: denormal of the packed format (or zero)
+	{
+		const uint32_t e = a >> 23;
+		if (e < uint32_t(127 - 14 - mant_bits - 1))
+			return 0u; // below half of the smallest denormal
+		const uint32_t m = (a & 0x7fffffu) | 0x800000u;
+		const uint32_t sh = uint32_t(shift) + (113u - e); // value = m * 2^(e - 150); unit = 2^(-14 - mant_bits)
+		uint32_t q = m >> sh;
+		const uint32_t rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1u);
+		if (rem > half || (rem == half && (q & 1u)))
+			q++;
+		return q; // a carry into 1 << mant_bits is the smallest normal: the right encoding
+	}
+	uint32_t q = (((a >> 23) - 112u) << mant_bits) | ((a & 0x7fffffu) >> shift);
+	const uint32_t rem = a & ((1u << shift) - 1u), half = 1u << (shift - 1);
+	if (rem > half || (rem == half && (q & 1u)))
+		q++;
+	return q > max_finite ? max_finite : q;
+}
+static inline float ufloat_to_float(uint32_t v, int mant_bits)
+{
+	const uint32_t e = v >> mant_bits, m = v & ((1u << mant_bits) - 1u);
+	if (e == 0)
+		return float(m) * (mant_bits == 6 ? 0x1p-20f : 0x1p-19f);
+	if (e == 31)
+		return u2f(0x7f800000u | (m << (23 - mant_bits)));
+	return u2f(((e + 112u) << 23) | (m << (23 - mant_bits)));
+}
+static inline uint32_t pack_b10g11r11(float r, float g, float b)
+{
+	return float_to_ufloat(r, 6) | (float_to_ufloat(g, 6) << 11) | (float_to_ufloat(b, 5) << 22);
+}
+static inline vec4 unpack_b10g11r11(uint32_t p)
+{
+	return {ufloat_to_float(p & 0x7ffu, 6), ufloat_to_float((p >> 11) & 0x7ffu, 6), ufloat_to_float(p >> 22, 5), 1.0f};
+}
+// What a B10G11R11 attachment holds after a store of (r, g, b): the same texel seen as RGBA16F (exact), alpha 1.
+static inline void store_rgba16f_as_b10g11r11(uint16_t *img, int w, int x, int y, vec4 v)
+{
+	const vec4 q = unpack_b10g11r11(pack_b10g11r11(v.x, v.y, v.z));
+	uint16_t *p = img + (size_t(y) * w + x) * 4;
+	p[0] = float_to_half_rne(q.x);
+	p[1] = float_to_half_rne(q.y);
+	p[2] = float_to_half_rne(q.z);
+	p[3] = 0x3c00u;
+}
+
 // A2B10G10R10_UNORM_PACK32: R bits 0..9, G 10..19, B 20..29, A 30..31.
 static inline vec4 unpack_a2b10g10r10(uint32_t p)
 {

@@ -799,7 +799,18 @@ struct OrcLightingArgs
 	int32_t wave_tile;        // 0/1: exact per-pixel light set; N>1: N x N pixel tile emulating the subgroup union (clusterer_bindless.h:49-56)
 	const uint8_t *ambient_occlusion; // AMBIENT_OCCLUSION (renderer.cpp:1050-1051, directional.frag:52-64): R8_UNORM or NULL
 	int32_t ao_width, ao_height;
+	// 1: the target is a B10G11R11_UFLOAT_PACK32 attachment (renderTargetFp16 = false, scene_viewer_application.cpp:881-883).
+	// `hdr` still holds RGBA16F texels -- every packed value is exactly a half float -- but each blend rounds to the packed format.
+	int32_t hdr_b10g11r11;
 };
+
+static inline void store_hdr(const OrcLightingArgs *a, int x, int y, vec4 v)
+{
+	if (a->hdr_b10g11r11)
+		store_rgba16f_as_b10g11r11(a->hdr, a->width, x, y, v);
+	else
+		store_rgba16f(a->hdr, a->width, x, y, v);
+}
 
 // textureLod(uAmbientOcclusion, gl_FragCoord.xy * inv_resolution, 0).x with StockSampler::LinearClamp (renderer.cpp:611-612).
 static float sample_ambient_occlusion(const OrcLightingArgs *a, float u, float v)
@@ -905,7 +916,7 @@ void orc_lighting(const OrcLightingArgs *a)
 						lit = lit + base_ambient * m.base * V3(0.05f);
 					}
 					vec4 dst = load_rgba16f(a->hdr, W, x, y);
-					store_rgba16f(a->hdr, W, x, y, V4(dst.x + lit.x, dst.y + lit.y, dst.z + lit.z, dst.w));
+					store_hdr(a, x, y, V4(dst.x + lit.x, dst.y + lit.y, dst.z + lit.z, dst.w));
 				}
 		}
 
@@ -959,7 +970,7 @@ void orc_lighting(const OrcLightingArgs *a)
 					if (!act[li])
 						continue;
 					vec4 dst = load_rgba16f(a->hdr, W, x, y);
-					store_rgba16f(a->hdr, W, x, y, V4(dst.x + acc[li].x, dst.y + acc[li].y, dst.z + acc[li].z, dst.w));
+					store_hdr(a, x, y, V4(dst.x + acc[li].x, dst.y + acc[li].y, dst.z + acc[li].z, dst.w));
 				}
 		}
 	}
@@ -1003,7 +1014,7 @@ void orc_lighting_bruteforce_clustered(const OrcLightingArgs *a)
 					acc += compute_spot_light(a->lights[index], m, pos, camera_pos);
 			}
 			vec4 dst = load_rgba16f(a->hdr, W, x, y);
-			store_rgba16f(a->hdr, W, x, y, V4(dst.x + acc.x, dst.y + acc.y, dst.z + acc.z, dst.w));
+			store_hdr(a, x, y, V4(dst.x + acc.x, dst.y + acc.y, dst.z + acc.z, dst.w));
 		}
 }
 }

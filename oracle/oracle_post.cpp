@@ -169,6 +169,29 @@ void orc_tonemap(const uint16_t *hdr, int w, int h, const uint16_t *bloom, int b
 }
 
 // ---- format helpers exported for the tests ---------------------------------------------------
+// B10G11R11_UFLOAT_PACK32 <-> its exact RGBA16F image (oracle_common.h); `count` texels.
+void orc_pack_b10g11r11_from_f32(const float *rgb, uint32_t *out, uint64_t count)
+{
+	for (uint64_t i = 0; i < count; i++)
+		out[i] = pack_b10g11r11(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+}
+void orc_pack_b10g11r11_from_rgba16f(const uint16_t *rgba16f, uint32_t *out, uint64_t count)
+{
+	for (uint64_t i = 0; i < count; i++)
+		out[i] = pack_b10g11r11(half_to_float(rgba16f[4 * i]), half_to_float(rgba16f[4 * i + 1]), half_to_float(rgba16f[4 * i + 2]));
+}
+void orc_unpack_b10g11r11_to_rgba16f(const uint32_t *in, uint16_t *rgba16f, uint64_t count)
+{
+	for (uint64_t i = 0; i < count; i++)
+	{
+		const vec4 v = unpack_b10g11r11(in[i]);
+		rgba16f[4 * i] = float_to_half_rne(v.x);
+		rgba16f[4 * i + 1] = float_to_half_rne(v.y);
+		rgba16f[4 * i + 2] = float_to_half_rne(v.z);
+		rgba16f[4 * i + 3] = 0x3c00u;
+	}
+}
+
 uint16_t orc_float_to_half(float f) { return float_to_half_rne(f); }
 float orc_half_to_float(uint16_t h) { return half_to_float(h); }
 uint16_t orc_float_to_half_muglm(float f) { return float_to_half_muglm(f); }

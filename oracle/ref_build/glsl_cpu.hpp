@@ -544,7 +544,7 @@ template <typename T> inline T subgroupBroadcastFirst(const T &v) { return v; }
 template <typename T> inline const T &nonuniformEXT(const T &v) { return v; }
 
 // ---- resources ------------------------------------------------------------------------------------------------------------
-enum class Format { RGBA16F, RGBA8_UNORM, RGBA8_SRGB, R32F, RG16F, RG8_UNORM, R8_UNORM, A2B10G10R10_UNORM, R16F };
+enum class Format { RGBA16F, RGBA8_UNORM, RGBA8_SRGB, R32F, RG16F, RG8_UNORM, R8_UNORM, A2B10G10R10_UNORM, R16F, B10G11R11_UFLOAT };
 enum class Filter { Linear, Nearest };
 
 struct Texture
@@ -597,6 +597,11 @@ struct Texture
 		}
 		case Format::R16F:
 			return vec4(orc::half_to_float(static_cast<const uint16_t *>(data)[i]), 0.0f, 0.0f, 1.0f);
+		case Format::B10G11R11_UFLOAT:
+		{
+			const orc::vec4 v = orc::unpack_b10g11r11(static_cast<const uint32_t *>(data)[i]);
+			return vec4(v.x, v.y, v.z, 1.0f);
+		}
 		}
 		return vec4();
 	}
@@ -675,6 +680,9 @@ inline void imageStore(Image &img, const ivec2 &p, const vec4 &v)
 		break;
 	case Format::R16F:
 		static_cast<uint16_t *>(img.data)[i] = orc::float_to_half_rne(v.x);
+		break;
+	case Format::B10G11R11_UFLOAT: // the packed-float store conversion, stated once (oracle_common.h: float_to_ufloat)
+		static_cast<uint32_t *>(img.data)[i] = orc::pack_b10g11r11(v.x, v.y, v.z);
 		break;
 	case Format::R8_UNORM:
 		static_cast<uint8_t *>(img.data)[i] = orc::float_to_unorm8(v.x);

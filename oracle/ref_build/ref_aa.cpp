@@ -4,6 +4,7 @@
 // reprojection.h / reprojection_color_space.h), re-spelled into gen/ at build time.  Bindings as renderer/post/fxaa.cpp:28-55
 // and renderer/post/temporal.cpp:199-266 make them: FXAA reads the UNORM alias of its input with LinearClamp; TAA binds the
 // current frame, depth and motion vectors NearestClamp and the history LinearClamp.  vUV = (pixel + 0.5) * (1 / size).
+#include <vector>
 #include "glsl_cpu.hpp"
 
 using namespace glsl;
@@ -120,10 +121,34 @@ void ref_fxaa(const uint8_t *in, int w, int h, uint8_t *out, int target_srgb)
 }
 
 // history == NULL: REPROJECTION_HISTORY = 0 (first frame).  Outputs: RGBA16F colour + history, alpha written as 1.
+// color_b10g11r11: the colour attachment is B10G11R11_UFLOAT_PACK32 (temporal.cpp:211-213); out_color receives its exact RGBA16F texels.
+void ref_taa_resolve_fmt(const uint16_t *current, const float *depth, const uint16_t *mv, const uint16_t *history, int w, int h,
+                         const float *reproj16, int quality, uint16_t *out_color, uint16_t *out_history, int color_b10g11r11);
 void ref_taa_resolve(const uint16_t *current, const float *depth, const uint16_t *mv, const uint16_t *history, int w, int h,
                      const float *reproj16, int quality, uint16_t *out_color, uint16_t *out_history)
 {
-	Image color_image = target(out_color, w, h, Format::RGBA16F), history_image = target(out_history, w, h, Format::RGBA16F);
+	ref_taa_resolve_fmt(current, depth, mv, history, w, h, reproj16, quality, out_color, out_history, 0);
+}
+void ref_taa_resolve_fmt(const uint16_t *current, const float *depth, const uint16_t *mv, const uint16_t *history, int w, int h,
+                         const float *reproj16, int quality, uint16_t *out_color, uint16_t *out_history, int color_b10g11r11)
+{
+	std::vector<uint32_t> packed(color_b10g11r11 ? size_t(w) * h : 0);
+	Image color_image = color_b10g11r11 ? target(packed.data(), w, h, Format::B10G11R11_UFLOAT) : target(out_color, w, h, Format::RGBA16F);
+	Image history_image = target(out_history, w, h, Format::RGBA16F);
+	struct Unpack
+	{
+		std::vector<uint32_t> &words;
+		uint16_t *out;
+		~Unpack()
+		{
+			for (size_t i = 0; i < words.size(); i++)
+			{
+				const orc::vec4 v = orc::unpack_b10g11r11(words[i]);
+				out[4 * i] = orc::float_to_half_rne(v.x), out[4 * i + 1] = orc::float_to_half_rne(v.y), out[4 * i + 2] = orc::float_to_half_rne(v.z);
+				out[4 * i + 3] = 0x3c00u;
+			}
+		}
+	} unpack_at_exit{packed, out_color};
 	if (!history)
 	{
 		namespace s = taa_first_frame;

@@ -87,6 +87,7 @@ struct LightingArgs
 	int32_t enable_directional, enable_clustered, ambient_fallback, wave_tile;
 	const uint8_t *ambient_occlusion;
 	int32_t ao_width, ao_height;
+	int32_t hdr_b10g11r11; // the target is a B10G11R11_UFLOAT_PACK32 attachment, held as its exact RGBA16F texels
 };
 
 Texture make(const void *data, int w, int h, Format f, Filter filter = Filter::Nearest)
@@ -110,11 +111,23 @@ mat4 load_mat4(const float *m)
 
 vec3 ld3(const float *v) { return vec3(v[0], v[1], v[2]); }
 
-void blend_one_one(uint16_t *hdr, int w, int x, int y, const vec3 &src)
+// ONE / ONE blend into the colour attachment: the sum is converted by the attachment's store (fp16 round to nearest even, or the
+// packed-float rule of B10G11R11_UFLOAT_PACK32).
+void blend_one_one(const LightingArgs *a, int x, int y, const vec3 &src)
 {
-	uint16_t *p = hdr + (size_t(y) * w + x) * 4;
-	for (int c = 0; c < 3; c++)
-		p[c] = orc::float_to_half_rne(orc::half_to_float(p[c]) + src.d[c]);
+	uint16_t *p = a->hdr + (size_t(y) * a->width + x) * 4;
+	const float r = orc::half_to_float(p[0]) + src.d[0], g = orc::half_to_float(p[1]) + src.d[1], b = orc::half_to_float(p[2]) + src.d[2];
+	if (a->hdr_b10g11r11)
+	{
+		Image target;
+		uint32_t word = 0;
+		target.data = &word, target.w = 1, target.h = 1, target.format = Format::B10G11R11_UFLOAT;
+		imageStore(target, ivec2(0, 0), vec4(r, g, b, 1.0f));
+		const orc::vec4 q = orc::unpack_b10g11r11(word);
+		p[0] = orc::float_to_half_rne(q.x), p[1] = orc::float_to_half_rne(q.y), p[2] = orc::float_to_half_rne(q.z), p[3] = 0x3c00u;
+		return;
+	}
+	p[0] = orc::float_to_half_rne(r), p[1] = orc::float_to_half_rne(g), p[2] = orc::float_to_half_rne(b);
 }
 
 template <typename Setup>
@@ -145,7 +158,7 @@ void bind_gbuffer(const LightingArgs *a, Setup set)
 				gl_FragCoord = vec4(float(x) + 0.5f, float(y) + 0.5f, 0.0f, 1.0f);                                  \
 				s::vClip = clip_at(x, y);                                                                           \
 				s::main();                                                                                          \
-				blend_one_one(a->hdr, W, x, y, s::FragColor);                                                       \
+				blend_one_one(a, x, y, s::FragColor);                                                       \
 			}                                                                                                       \
 	}
 
@@ -219,7 +232,7 @@ extern "C" void ref_lighting(const LightingArgs *a)
 				gl_FragCoord = vec4(float(x) + 0.5f, float(y) + 0.5f, 0.0f, 1.0f);
 				s::vClip = clip_at(x, y);
 				s::main();
-				blend_one_one(a->hdr, W, x, y, s::FragColor);
+				blend_one_one(a, x, y, s::FragColor);
 			}
 	}
 }
