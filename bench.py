@@ -29,6 +29,9 @@ WORKLOADS = {
     # BASELINE config 4: config 3 + TAA High in front of the post chain (previous-frame history) + SMAA Ultra behind the tonemap
     "config4_4k_smaa_taa": (3840, 2160, 4096, "3840x2160, 4096 clustered point+spot lights, TAA High (history feedback edge) + bloom pyramid + "
                                               "luminance + tonemap + SMAA Ultra; the camera translates 0.01 units per frame under the 16-phase TAA jitter, motion vectors 0 with a constant-motion region"),
+    # config 3 on the reference's default HDR format (viewer_config renderTargetFp16 = false): emissive / HDR-main are B10G11R11_UFLOAT_PACK32
+    "config3_4k_4096lights_b10g11r11": (3840, 2160, 4096, "3840x2160, 4096 clustered point+spot lights, bloom pyramid + luminance + tonemap; HDR targets "
+                                                           "B10G11R11_UFLOAT_PACK32 (renderTargetFp16 = false, the reference's shipped default)"),
     # BASELINE config 5 as stated: ONE 7680x4320 frame tiled into --gpus row bands (strong scaling; 1 GPU renders it whole)
     "config5_8k": (7680, 4320, 4096, "7680x4320 screen-tiled across the GPUs, 4096 clustered point+spot lights, bloom pyramid + luminance + tonemap"),
 }
@@ -43,8 +46,11 @@ ALGO_BYTES_PER_PX = {
     "chain": 56.66,
 }
 # SURVEY 8d table rows for the other configurations: post only 26.7 B/px; + SMAA (3 passes) 14 + 12; + TAA (RGBA16F everywhere) 24 + 16
-CHAIN_BYTES_PER_PX = {"config1_256_post_only": 26.7, "config4_4k_smaa_taa": 56.66 + 26.0 + 40.0}
-SINGLE_GPU_WORKLOADS = {"config1_256_post_only", "config4_4k_smaa_taa"}  # not tiled by bench.py: N ranks run N replicas
+# packed HDR targets: lighting 18 + 4, threshold 4 + 2, pyramid and luminance as before (3.33 + 0.008 + 0.82), tonemap 4.5 + 4
+CHAIN_BYTES_PER_PX = {"config1_256_post_only": 26.7, "config4_4k_smaa_taa": 56.66 + 26.0 + 40.0, "config3_4k_4096lights_b10g11r11": 40.66}
+PACKED_HDR_WORKLOADS = {"config3_4k_4096lights_b10g11r11"}
+ALGO_BYTES_PER_PX_PACKED = {"lighting": 18.0 + 4.0, "bloom_threshold": 4.0 + 2.0, "tonemap": 4.5 + 4.0}
+SINGLE_GPU_WORKLOADS = {"config1_256_post_only", "config4_4k_smaa_taa", "config3_4k_4096lights_b10g11r11"}  # not tiled by bench.py: N ranks run N replicas
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy); the run measures its own too
 VALU_SIMDS, VALU_CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 2.0  # 256 CUs x 4 SIMD-32, max clock, wave64 fp32 op
 BRACKET_EVERY = 8  # the dominant kernel keeps its hipEvent bracket on every 8th launch of the timed region (short runs: >= 16 brackets, or all)
@@ -204,6 +210,12 @@ def main():
             app.set_lights(descs)
             app.upload_gbuffer(gbuf, synth.make_motion_vectors(width, height))
             app.set_camera_motion((0.01, 0.0, 0.0))  # SURVEY 8d, config 4 extras: the camera translates 0.01 units per frame
+        elif args.workload in PACKED_HDR_WORKLOADS:
+            app = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True, compute_post=True,
+                                   rt_fp16=False)
+            app.set_render_parameters(cam.render_params())
+            app.set_lights(descs)
+            app.upload_gbuffer(dict(gbuf, emissive=synth.pack_b10g11r11(gbuf["emissive"])))
         else:
             app = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True,
                                    compute_post=True, **strips)
@@ -339,7 +351,7 @@ def main():
 
     dom_count, dom_ms = timed.get(dominant, (0, 0.0))
     dom_avg_s = (dom_ms / 1000.0) / max(dom_count, 1)
-    bpp = ALGO_BYTES_PER_PX.get(dominant)
+    bpp = (ALGO_BYTES_PER_PX_PACKED if args.workload in PACKED_HDR_WORKLOADS else ALGO_BYTES_PER_PX).get(dominant)
     roofline = None
     if bpp and dom_avg_s > 0:
         # rank 0's launch of the dominant kernel covers its own band only
@@ -407,7 +419,8 @@ def main():
                                    f"{world} row bands, RCCL all-gather of the 1/8 bloom level (in frame) and of the tonemapped bands as RGB888 (alpha is constant: 3/4 of the bytes per xGMI link; GRANITE_BENCH_GATHER_RGBA=1 sends RGBA8) "
                                    f"({'in frame' if os.environ.get('GRANITE_BENCH_GATHER', 'beside') == 'inframe' else 'beside the frame, own stream + communicator'})" if bands else
                                    f"{world} independent replicas ({'this workload is not tiled by bench.py' if args.workload in SINGLE_GPU_WORKLOADS else f'row-band set-up failed: {fallback_reason}'})"),
-                   "hdr_format": "R16G16B16A16_SFLOAT (fp16 storage, fp32 arithmetic)", "seed": synth.SEED,
+                   "hdr_format": ("B10G11R11_UFLOAT_PACK32 (packed-float storage, fp32 arithmetic)" if args.workload in PACKED_HDR_WORKLOADS
+                                  else "R16G16B16A16_SFLOAT (fp16 storage, fp32 arithmetic)"), "seed": synth.SEED,
                    "timed_region": {"config1_256_post_only": "bloom pyramid + luminance + tonemap, every frame; the HDR input is resident in HBM",
                                     "config4_4k_smaa_taa": "cluster build + per-frame light refresh + lighting + TAA resolve + bloom pyramid + luminance + "
                                                            "tonemap + SMAA (edges, weights, blend), every frame; the synthetic G-buffer is resident in HBM"}.get(

@@ -29,7 +29,8 @@ class Config(C.Structure):
                 ("strip_index", C.c_uint32), ("strip_count", C.c_uint32),
                 ("disable_image_aliasing", C.c_int32), ("depth_hierarchy", C.c_int32),
                 ("resolution_scale", C.c_float), ("resolution_scale_sharpen", C.c_int32), ("fsr_fp32", C.c_int32),
-                ("ambient_occlusion", C.c_int32), ("hdr10", C.c_int32), ("ssr", C.c_int32), ("aa_bench", C.c_int32), ("output_gather_rgba", C.c_int32)]
+                ("ambient_occlusion", C.c_int32), ("hdr10", C.c_int32), ("ssr", C.c_int32), ("aa_bench", C.c_int32), ("output_gather_rgba", C.c_int32),
+                ("hdr_packed_float", C.c_int32)]
 
 
 # void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream)
@@ -143,7 +144,9 @@ class Application:
                  alias_images: bool = True, depth_hierarchy: int = 0,
                  resolution_scale: float = 1.0, resolution_scale_sharpen: bool = True, fsr_fp16: bool = True,
                  ambient_occlusion: bool = False, hdr10: bool = False, ssr: bool = False, aa_bench: bool = False,
-                 output_gather_rgba: bool = False):
+                 output_gather_rgba: bool = False, rt_fp16: bool = True):
+        """rt_fp16 = False: viewer_config renderTargetFp16 = false (the reference's default): emissive / HDR-main and the TAA colour
+        output are B10G11R11_UFLOAT_PACK32; the emissive upload is then (h, w) uint32 words (oracle.pack_b10g11r11)."""
         self.lib = load_library()
         cfg = Config()
         cfg.device, cfg.width, cfg.height = device, width, height
@@ -165,6 +168,7 @@ class Application:
         cfg.ssr = int(ssr)
         cfg.aa_bench = int(aa_bench)
         cfg.output_gather_rgba = int(output_gather_rgba)
+        cfg.hdr_packed_float = int(not rt_fp16)
         if ssr:
             install_ssr_tables()
         self._exchange_ref = None
@@ -272,7 +276,7 @@ class Application:
             return raw.reshape(h, w, 2)
         if f in (capi.FORMAT_D32_SFLOAT, capi.FORMAT_R32_SFLOAT):
             return raw.view(np.float32).reshape(h, w)
-        if f == capi.FORMAT_A2B10G10R10_UNORM_PACK32:
+        if f in (capi.FORMAT_A2B10G10R10_UNORM_PACK32, capi.FORMAT_B10G11R11_UFLOAT_PACK32):
             return raw.view(np.uint32).reshape(h, w)
         if f == capi.FORMAT_R16G16_SFLOAT:
             return raw.view(np.uint16).reshape(h, w, 2)

@@ -26,6 +26,7 @@ FORMAT_R16_SFLOAT = 76
 FORMAT_R16G16_SFLOAT = 83
 FORMAT_R16G16B16A16_SFLOAT = 97
 FORMAT_R32_SFLOAT = 100
+FORMAT_B10G11R11_UFLOAT_PACK32 = 122
 FORMAT_D16_UNORM = 124
 FORMAT_D32_SFLOAT = 126
 
@@ -39,6 +40,7 @@ FORMAT_BPP = {
     FORMAT_R16G16_SFLOAT: 4,
     FORMAT_R16G16B16A16_SFLOAT: 8,
     FORMAT_R32_SFLOAT: 4,
+    FORMAT_B10G11R11_UFLOAT_PACK32: 4,
     FORMAT_D16_UNORM: 2,
     FORMAT_D32_SFLOAT: 4,
 }
@@ -267,6 +269,7 @@ def load_library() -> C.CDLL:
         "gr_get_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, vp]),
         "gr_spd_downsample": (C.c_int, [vp, vp, P(SpdArgs)]),
         "gr_debug_mix": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_uint32]),
+        "gr_pack_b10g11r11": (C.c_int, [vp, vp, vp, vp, C.c_uint32]),
         "gr_pq10_encode": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushPq10)]),
         "gr_fsr_upscale": (C.c_int, [vp, vp, P(Image), P(Image), C.c_int]),
         "gr_fsr_sharpen": (C.c_int, [vp, vp, P(Image), P(Image), C.c_float]),
@@ -288,7 +291,7 @@ EXPORTED_SYMBOLS = [
     "gr_bloom_threshold_rows", "gr_bloom_downsample_rows", "gr_bloom_upsample_rows", "gr_tonemap_rows",
     "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
     "gr_smaa_set_luts", "gr_fxaa", "gr_blit", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
-    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen", "gr_fill_byte", "gr_fill_u32", "gr_pq10_encode", "gr_get_device_info", "gr_spd_downsample", "gr_debug_mix",
+    "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen", "gr_fill_byte", "gr_fill_u32", "gr_pq10_encode", "gr_get_device_info", "gr_spd_downsample", "gr_debug_mix", "gr_pack_b10g11r11",
 ]
 
 
@@ -361,7 +364,7 @@ class DeviceImage:
             return out.reshape(self.height, self.width, 2)
         if self.format in (FORMAT_D32_SFLOAT, FORMAT_R32_SFLOAT):
             return out.view(np.float32).reshape(self.height, self.width)
-        if self.format == FORMAT_A2B10G10R10_UNORM_PACK32:
+        if self.format in (FORMAT_A2B10G10R10_UNORM_PACK32, FORMAT_B10G11R11_UFLOAT_PACK32):
             return out.view(np.uint32).reshape(self.height, self.width)
         if self.format == FORMAT_R16G16_SFLOAT:
             return out.view(np.uint16).reshape(self.height, self.width, 2)

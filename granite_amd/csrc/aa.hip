@@ -696,10 +696,11 @@ int gr_taa_resolve_rows(gr_ctx *ctx, gr_stream stream, const gr_image *current, 
 	GR_CHECK_ARG(ctx, quality >= 0 && quality <= 2);
 	const uint32_t w = current->width, h = current->height;
 	GR_CHECK_ARG(ctx, w && h);
-	GR_CHECK_ARG(ctx, check_image(current, 8, w, h) && current->format == GR_FORMAT_R16G16B16A16_SFLOAT);
+	const bool current_b10 = current->format == GR_FORMAT_B10G11R11_UFLOAT_PACK32, color_b10 = out_color->format == GR_FORMAT_B10G11R11_UFLOAT_PACK32;
+	GR_CHECK_ARG(ctx, check_image(current, current_b10 ? 4 : 8, w, h) && (current_b10 || current->format == GR_FORMAT_R16G16B16A16_SFLOAT));
 	GR_CHECK_ARG(ctx, check_image(depth, 4, w, h) && depth->format == GR_FORMAT_D32_SFLOAT);
 	GR_CHECK_ARG(ctx, check_image(mv, 4, w, h) && mv->format == GR_FORMAT_R16G16_SFLOAT);
-	GR_CHECK_ARG(ctx, check_image(out_color, 8, w, h) && out_color->format == GR_FORMAT_R16G16B16A16_SFLOAT);
+	GR_CHECK_ARG(ctx, check_image(out_color, color_b10 ? 4 : 8, w, h) && (color_b10 || out_color->format == GR_FORMAT_R16G16B16A16_SFLOAT));
 	GR_CHECK_ARG(ctx, check_image(out_history, 8, w, h) && out_history->format == GR_FORMAT_R16G16B16A16_SFLOAT);
 	GR_CHECK_ARG(ctx, !history || (check_image(history, 8, w, h) && history->format == GR_FORMAT_R16G16B16A16_SFLOAT && history->ptr != out_history->ptr));
 	const RowSpan span = resolve_rows(rows, h);
@@ -720,6 +721,8 @@ int gr_taa_resolve_rows(gr_ctx *ctx, gr_stream stream, const gr_image *current, 
 	im.out_history_pitch = out_history->pitch_bytes;
 	im.w = int(w);
 	im.h = int(h);
+	im.current_b10 = current_b10;
+	im.color_b10 = color_b10;
 	aa::TaaPush tp;
 	for (int i = 0; i < 16; i++)
 		tp.reproj[i] = push->reproj[i];

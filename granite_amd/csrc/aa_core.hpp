@@ -349,9 +349,11 @@ struct TaaPush
 // Tile: f4 cur(int ox, int oy) = (Y, Cg, Co, depth) of the clamped neighbour (x + ox, y + oy), |o| <= 1.
 // Mv:   uint32_t mv(int x, int y), the RG16F texel of the clamped pixel.
 // Hist: u2 texel(int x, int y), the RGBA16F history texel; coordinates arrive clamped to the image.
-// QUALITY 0 / 1 / 2 = TAAQuality Low / Medium / High.  Writes the resolved colour and the new history as RGBA16F texels.
+// QUALITY 0 / 1 / 2 = TAAQuality Low / Medium / High.  Writes the resolved colour and the new history as RGBA16F texels, and the
+// colour in fp32 as well.
 template <int QUALITY, typename Tile, typename Mv, typename Hist>
-AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int y, int w, int h, const TaaPush &P, u2 &out_color, u2 &out_history)
+AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int y, int w, int h, const TaaPush &P, u2 &out_color, u2 &out_history,
+                     f3 &out_color_f32)
 {
 	const float u = (float(x) + 0.5f) * P.rt[0], v = (float(y) + 0.5f) * P.rt[1];
 	const f4 c11 = t.cur(0, 0);
@@ -547,6 +549,7 @@ AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int 
 	const float oml = 1.0f - lerp_factor;
 	const f3 mixed = {hc.x * oml + c11.x * lerp_factor, hc.y * oml + c11.y * lerp_factor, hc.z * oml + c11.z * lerp_factor};
 	const f3 o = taa_to_hdr(mixed);
+	out_color_f32 = o; // for a colour target that is not RGBA16F (B10G11R11: rounded once, from fp32)
 	out_color = {pack_half2_rne(o.x, o.y), pack_half2_rne(o.z, 1.0f)};
 	out_history = {pack_half2_rne(mixed.x, mixed.y), pack_half2_rne(mixed.z, 1.0f)};
 }

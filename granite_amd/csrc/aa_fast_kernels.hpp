@@ -5,6 +5,7 @@
 // provide: threadIdx / blockIdx, __shared__, __syncthreads*, float4 / uint4, min / max.
 #pragma once
 #include "aa_core.hpp"
+#include "packed_float.hpp"
 #include "row_span.hpp"
 
 // ---- fast forms: pixel-centre taps as texel fetches (aa_core.hpp) ----------------------------------------------------------------
@@ -183,7 +184,22 @@ struct TaaImages
 	uint8_t *out_color, *out_history;
 	uint32_t current_pitch, depth_pitch, mv_pitch, history_pitch, out_color_pitch, out_history_pitch;
 	int w, h;
+	// B10G11R11_UFLOAT_PACK32 instead of RGBA16F: the input when the HDR targets are packed (renderTargetFp16 = false), the colour
+	// output as the reference declares it (temporal.cpp:211-213).  The history is RGBA16F either way (temporal.cpp:216).
+	int current_b10, color_b10;
 };
+
+// one texel of the current frame as RGBA16F dwords, whatever its storage
+__device__ __forceinline__ uint2 taa_load_current(const TaaImages &im, int x, int y)
+{
+	if (im.current_b10)
+	{
+		uint32_t rg, ba;
+		expand_b10g11r11(*reinterpret_cast<const uint32_t *>(im.current + (uint32_t(y) * im.current_pitch + uint32_t(x) * 4u)), rg, ba);
+		return make_uint2(rg, ba);
+	}
+	return *reinterpret_cast<const uint2 *>(im.current + (uint32_t(y) * im.current_pitch + uint32_t(x) * 8u));
+}
 
 struct TaaTile
 {
@@ -229,11 +245,14 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_taa_fast(TaaImages im, aa:
 		// first frame (REPROJECTION_HISTORY = 0): the colour goes through the resolve's colour space and back
 		if (x >= im.w || y >= int(rows.end))
 			return;
-		const uint2 t = *reinterpret_cast<const uint2 *>(im.current + (uint32_t(y) * im.current_pitch + uint32_t(x) * 8u));
+		const uint2 t = taa_load_current(im, x, y);
 		const aa::f3 c = aa::taa_from_hdr(aa::half_lo(t.x), aa::half_hi(t.x), aa::half_lo(t.y));
 		const aa::f3 o = aa::taa_to_hdr(c);
-		*reinterpret_cast<uint2 *>(im.out_color + (uint32_t(y) * im.out_color_pitch + uint32_t(x) * 8u)) =
-		    make_uint2(aa::pack_half2_rne(o.x, o.y), aa::pack_half2_rne(o.z, 1.0f));
+		if (im.color_b10)
+			*reinterpret_cast<uint32_t *>(im.out_color + (uint32_t(y) * im.out_color_pitch + uint32_t(x) * 4u)) = pack_b10g11r11(o.x, o.y, o.z);
+		else
+			*reinterpret_cast<uint2 *>(im.out_color + (uint32_t(y) * im.out_color_pitch + uint32_t(x) * 8u)) =
+			    make_uint2(aa::pack_half2_rne(o.x, o.y), aa::pack_half2_rne(o.z, 1.0f));
 		*reinterpret_cast<uint2 *>(im.out_history + (uint32_t(y) * im.out_history_pitch + uint32_t(x) * 8u)) =
 		    make_uint2(aa::pack_half2_rne(c.x, c.y), aa::pack_half2_rne(c.z, 1.0f));
 		return;
@@ -242,7 +261,7 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_taa_fast(TaaImages im, aa:
 	{
 		const int ty = i / TW, tx = i - ty * TW;
 		const int px = aa::clampi(bx + tx - 1, 0, im.w - 1), py = aa::clampi(by + ty - 1, 0, im.h - 1);
-		const uint2 t = *reinterpret_cast<const uint2 *>(im.current + (uint32_t(py) * im.current_pitch + uint32_t(px) * 8u));
+		const uint2 t = taa_load_current(im, px, py);
 		const aa::f3 c = aa::taa_from_hdr(aa::half_lo(t.x), aa::half_hi(t.x), aa::half_lo(t.y));
 		s_cur[i] = make_float4(c.x, c.y, c.z, *reinterpret_cast<const float *>(im.depth + (uint32_t(py) * im.depth_pitch + uint32_t(px) * 4u)));
 	}
@@ -253,7 +272,11 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_taa_fast(TaaImages im, aa:
 	const TaaMotion motion = {im.mv, im.mv_pitch, im.w, im.h};
 	const TaaHistory history = {im.history, im.history_pitch};
 	aa::u2 color, hist;
-	aa::taa_pixel<QUALITY>(tile, motion, history, x, y, im.w, im.h, push, color, hist);
-	*reinterpret_cast<uint2 *>(im.out_color + (uint32_t(y) * im.out_color_pitch + uint32_t(x) * 8u)) = make_uint2(color.x, color.y);
+	aa::f3 color_f;
+	aa::taa_pixel<QUALITY>(tile, motion, history, x, y, im.w, im.h, push, color, hist, color_f);
+	if (im.color_b10)
+		*reinterpret_cast<uint32_t *>(im.out_color + (uint32_t(y) * im.out_color_pitch + uint32_t(x) * 4u)) = pack_b10g11r11(color_f.x, color_f.y, color_f.z);
+	else
+		*reinterpret_cast<uint2 *>(im.out_color + (uint32_t(y) * im.out_color_pitch + uint32_t(x) * 8u)) = make_uint2(color.x, color.y);
 	*reinterpret_cast<uint2 *>(im.out_history + (uint32_t(y) * im.out_history_pitch + uint32_t(x) * 8u)) = make_uint2(hist.x, hist.y);
 }

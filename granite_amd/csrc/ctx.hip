@@ -470,6 +470,27 @@ int gr_debug_mix(gr_ctx *ctx, gr_stream stream, void *out, size_t out_dwords, co
 	return GR_OK;
 }
 
+// The attachment store conversion of B10G11R11_UFLOAT_PACK32 on its own (what the lighting and TAA kernels apply to their
+// results), so that it can be held to the oracle's statement word for word.
+__global__ void k_pack_b10g11r11(const float *rgb, uint32_t *out, uint32_t count)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < count)
+		out[i] = pack_b10g11r11(rgb[3u * i], rgb[3u * i + 1u], rgb[3u * i + 2u]);
+}
+
+int gr_pack_b10g11r11(gr_ctx *ctx, gr_stream stream, const float *rgb, uint32_t *out, uint32_t texels)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, rgb && out);
+	if (texels == 0)
+		return GR_OK;
+	hipLaunchKernelGGL(k_pack_b10g11r11, dim3((texels + 255u) / 256u), dim3(256), 0, gr_to_stream(stream), rgb, out, texels);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
 int gr_get_device_info(gr_ctx *ctx, char *name, size_t name_capacity, uint32_t *driver_version)
 {
 	if (!ctx)

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "packed_float.hpp"
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -63,6 +64,29 @@ __device__ __forceinline__ f16x4 pack_rgba16f(float4 v)
 __device__ __forceinline__ void store_rgba16f(const DevImageRW &img, int x, int y, float4 v)
 {
 	*reinterpret_cast<f16x4 *>(img.ptr + size_t(y) * img.pitch + size_t(x) * 8u) = pack_rgba16f(v);
+}
+
+// the value a channel holds after such a store (what the next blend reads back)
+template <int MB>
+__device__ __forceinline__ float round_to_ufloat(float f)
+{
+	return float(__builtin_bit_cast(_Float16, uint16_t(float_to_ufloat<MB>(f) << (10 - MB))));
+}
+
+// two packed texels -> the four dwords of two RGBA16F texels
+__device__ __forceinline__ u32x4 expand_b10g11r11_pair(uint32_t p0, uint32_t p1)
+{
+	uint32_t a, b, c, d;
+	expand_b10g11r11(p0, a, b);
+	expand_b10g11r11(p1, c, d);
+	return u32x4{a, b, c, d};
+}
+__device__ __forceinline__ float4 load_b10g11r11(const DevImage &img, int x, int y)
+{
+	uint32_t rg, ba;
+	expand_b10g11r11(*reinterpret_cast<const uint32_t *>(img.ptr + size_t(y) * img.pitch + size_t(x) * 4u), rg, ba);
+	const f16x4 h = __builtin_bit_cast(f16x4, u32x2{rg, ba});
+	return make_float4(float(h.x), float(h.y), float(h.z), float(h.w));
 }
 
 // acc + float(half) * w in ONE instruction (v_fma_mix_f32: the fp16 -> fp32 conversion is exact and folded into the

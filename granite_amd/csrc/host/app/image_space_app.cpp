@@ -41,6 +41,8 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 	if (config.hdr10 && (!config.enable_lighting || config.hdr_bloom || config.post_aa != GRA_POST_AA_NONE || config.pre_aa != GRA_POST_AA_NONE ||
 	                     config.strip_count > 1 || (config.resolution_scale > 0.0f && config.resolution_scale < 1.0f)))
 		throw std::logic_error("hdr10 needs enable_lighting and excludes hdr_bloom, anti-aliasing, resolution scaling and row bands.");
+	if (config.hdr_packed_float && (config.ssr || config.hdr10 || config.aa_bench))
+		throw std::logic_error("hdr_packed_float (renderTargetFp16 = false) is not available with ssr / hdr10 / aa_bench: those passes take the lit target as RGBA16F.");
 	if (config.aa_bench && (config.enable_lighting || config.hdr_bloom || config.hdr10 || config.ssr || config.strip_count > 1 || config.depth_hierarchy))
 		throw std::logic_error("aa_bench is a graph of its own: no lighting, bloom, hdr10, SSR, depth hierarchy or row bands.");
 	if (config.resolution_scale < 0.0f || config.resolution_scale > 1.0f)
@@ -112,7 +114,7 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 	for (unsigned i = 0; i < 4; i++)
 		swapchain.push_back(device.create_image(config.width, config.height, backbuffer_format(), "swapchain-" + std::to_string(i)));
 
-	src_emissive = device.create_image(render_width, render_height, VK_FORMAT_R16G16B16A16_SFLOAT, "src-emissive");
+	src_emissive = device.create_image(render_width, render_height, hdr_target_format(), "src-emissive");
 	if (config.enable_lighting)
 	{
 		src_albedo = device.create_image(render_width, render_height, VK_FORMAT_R8G8B8A8_SRGB, "src-albedo");
@@ -380,7 +382,7 @@ void ImageSpaceApplication::upload_gbuffer_gtx(const char *const paths[6])
 		VkFormat formats[2];
 	};
 	static const Slot slots[6] = {
-		{"emissive", {VK_FORMAT_R16G16B16A16_SFLOAT, VK_FORMAT_R16G16B16A16_SFLOAT}},
+		{"emissive", {hdr_target_format(), hdr_target_format()}},
 		{"albedo", {VK_FORMAT_R8G8B8A8_SRGB, VK_FORMAT_R8G8B8A8_UNORM}},
 		{"normal", {VK_FORMAT_A2B10G10R10_UNORM_PACK32, VK_FORMAT_A2B10G10R10_UNORM_PACK32}},
 		{"pbr", {VK_FORMAT_R8G8_UNORM, VK_FORMAT_R8G8_UNORM}},
@@ -432,7 +434,7 @@ void ImageSpaceApplication::save_image_gtx(HIP::Image &image, const std::string 
 void ImageSpaceApplication::add_hdr_input_pass(const std::string &tag)
 {
 	AttachmentInfo hdr;
-	hdr.format = VK_FORMAT_R16G16B16A16_SFLOAT;
+	hdr.format = hdr_target_format();
 	hdr.flags |= ATTACHMENT_INFO_INTERNAL_RETAINED_BIT; // filled once (needs_fill), never aliased
 	if (scaled())
 		hdr.size_x = hdr.size_y = config.resolution_scale;
@@ -496,7 +498,7 @@ void ImageSpaceApplication::add_mv_pass(const std::string &tag)
 void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
 {
 	AttachmentInfo emissive, albedo, normal, pbr, depth;
-	emissive.format = VK_FORMAT_R16G16B16A16_SFLOAT; // renderTargetFp16 (scene_viewer_application.cpp:881-883)
+	emissive.format = hdr_target_format(); // renderTargetFp16 ? RGBA16F : B10G11R11_UFLOAT_PACK32 (scene_viewer_application.cpp:881-883)
 	albedo.format = VK_FORMAT_R8G8B8A8_SRGB;
 	normal.format = VK_FORMAT_A2B10G10R10_UNORM_PACK32;
 	pbr.format = VK_FORMAT_R8G8_UNORM;

@@ -114,6 +114,8 @@ private:
 	std::vector<mat_affine> light_transforms;
 	PositionalLightList light_list;
 	HIP::ImageHandle src_emissive, src_albedo, src_normal, src_pbr, src_depth, src_mv, src_ao;
+	// scene_viewer_application.cpp:881-883: renderTargetFp16 ? R16G16B16A16_SFLOAT : B10G11R11_UFLOAT_PACK32
+	VkFormat hdr_target_format() const { return config.hdr_packed_float ? VK_FORMAT_B10G11R11_UFLOAT_PACK32 : VK_FORMAT_R16G16B16A16_SFLOAT; }
 	vec3 camera_motion = vec3(0.0f); // eye translation per frame (world units)
 	bool camera_moves = false;
 	HIP::ImageHandle bench_images[2]; // aa_bench: the two input images, alternating per frame

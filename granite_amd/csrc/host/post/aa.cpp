@@ -221,8 +221,12 @@ void setup_taa_resolve(RenderGraph &graph, TemporalJitter &jitter, float scaling
 	AttachmentInfo taa_output;
 	taa_output.size_class = SizeClass::InputRelative;
 	taa_output.size_relative_name = input;
-	taa_output.format = VK_FORMAT_R16G16B16A16_SFLOAT; // B10G11R11 colour attachments are not provided by this executor
+	// temporal.cpp:211-216: B10G11R11_UFLOAT_PACK32 where renderable, history RGBA16F.  Here the colour output takes the format of
+	// its input: packed when the HDR targets are (renderTargetFp16 = false), RGBA16F with the RGBA16F targets SURVEY 8d measures on.
+	const VkFormat input_format = graph.get_texture_resource(input).get_attachment_info().format;
+	taa_output.format = input_format == VK_FORMAT_B10G11R11_UFLOAT_PACK32 ? VK_FORMAT_B10G11R11_UFLOAT_PACK32 : VK_FORMAT_R16G16B16A16_SFLOAT;
 	AttachmentInfo taa_history = taa_output;
+	taa_history.format = VK_FORMAT_R16G16B16A16_SFLOAT;
 
 	auto &resolve = graph.add_pass("taa-resolve", RENDER_GRAPH_QUEUE_GRAPHICS_BIT);
 	auto &out_color = resolve.add_color_output(output, taa_output);

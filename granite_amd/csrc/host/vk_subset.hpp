@@ -24,6 +24,7 @@ enum VkFormat : uint32_t
 	VK_FORMAT_R16G16_SFLOAT = 83,
 	VK_FORMAT_R16G16B16A16_SFLOAT = 97,
 	VK_FORMAT_R32_SFLOAT = 100,
+	VK_FORMAT_B10G11R11_UFLOAT_PACK32 = 122,
 	VK_FORMAT_D16_UNORM = 124,
 	VK_FORMAT_D32_SFLOAT = 126
 };
@@ -86,6 +87,7 @@ static inline unsigned vk_format_block_size(VkFormat format)
 	case VK_FORMAT_R8G8B8A8_SRGB:
 	case VK_FORMAT_A2B10G10R10_UNORM_PACK32:
 	case VK_FORMAT_R16G16_SFLOAT:
+	case VK_FORMAT_B10G11R11_UFLOAT_PACK32:
 	case VK_FORMAT_R32_SFLOAT:
 	case VK_FORMAT_D32_SFLOAT: return 4;
 	case VK_FORMAT_R16G16B16A16_SFLOAT: return 8;

@@ -252,7 +252,9 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 
 // AO: the AMBIENT_OCCLUSION shader variant (renderer.cpp:1050-1051), a separate instantiation so that the default kernel keeps
 // its register budget.
-template <int PX, bool AO>
+// B10: emissive and the HDR target are B10G11R11_UFLOAT_PACK32 (the reference's default, renderTargetFp16 = false): 4-byte
+// texels, both blends round to the packed format (device_common.hpp: float_to_ufloat).
+template <int PX, bool AO, bool B10 = false>
 __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 {
 	__shared__ __attribute__((aligned(16))) f32x4 s_lights[LIGHT_WAVES][64 * (LIGHT_SLOT_BYTES / 16)];
@@ -300,7 +302,15 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 			const uint2 al = *reinterpret_cast<const uint2 *>(a.albedo.ptr + (uy * a.albedo.pitch + ux * 4u));
 			const uint2 nr = *reinterpret_cast<const uint2 *>(a.normal.ptr + (uy * a.normal.pitch + ux * 4u));
 			const uint32_t m2 = *reinterpret_cast<const uint32_t *>(a.pbr.ptr + (uy * a.pbr.pitch + ux * 2u));
-			const uint4 em = *reinterpret_cast<const uint4 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 8u));
+			uint4 em;
+			if constexpr (B10)
+			{
+				const uint2 packed = *reinterpret_cast<const uint2 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 4u));
+				const u32x4 e = expand_b10g11r11_pair(packed.x, packed.y);
+				em = make_uint4(e.x, e.y, e.z, e.w);
+			}
+			else
+				em = *reinterpret_cast<const uint4 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 8u));
 			depth_v[0] = d.x, depth_v[PX - 1] = d.y;
 			alb_v[0] = al.x, alb_v[PX - 1] = al.y;
 			nrm_v[0] = nr.x, nrm_v[PX - 1] = nr.y;
@@ -314,7 +324,14 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 			alb_v[0] = *reinterpret_cast<const uint32_t *>(a.albedo.ptr + (uy * a.albedo.pitch + ux * 4u));
 			nrm_v[0] = *reinterpret_cast<const uint32_t *>(a.normal.ptr + (uy * a.normal.pitch + ux * 4u));
 			mr_v[0] = *reinterpret_cast<const uint16_t *>(a.pbr.ptr + (uy * a.pbr.pitch + ux * 2u));
-			dst[0] = *reinterpret_cast<const f16x4 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 8u));
+			if constexpr (B10)
+			{
+				uint32_t rg, ba;
+				expand_b10g11r11(*reinterpret_cast<const uint32_t *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 4u)), rg, ba);
+				dst[0] = __builtin_bit_cast(f16x4, make_uint2(rg, ba));
+			}
+			else
+				dst[0] = *reinterpret_cast<const f16x4 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 8u));
 		}
 	}
 	__syncthreads(); // s_srgb
@@ -402,13 +419,17 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 			if (AO)
 				ambient *= sample_linear_r8(a.ao, (float(x) + 0.5f) * a.inv_resolution[0], (float(y) + 0.5f) * a.inv_resolution[1]);
 			lit = f3(fmaf(base[p].x, ambient, lit.x), fmaf(base[p].y, ambient, lit.y), fmaf(base[p].z, ambient, lit.z));
-			// blend ONE/ONE, attachment store rounds to fp16
-			accum[p] = f3(float(_Float16(accum[p].x + lit.x)), float(_Float16(accum[p].y + lit.y)), float(_Float16(accum[p].z + lit.z)));
+			// blend ONE/ONE, attachment store rounds to fp16 (or to the packed floats)
+			if constexpr (B10)
+				accum[p] = f3(round_to_ufloat<6>(accum[p].x + lit.x), round_to_ufloat<6>(accum[p].y + lit.y), round_to_ufloat<5>(accum[p].z + lit.z));
+			else
+				accum[p] = f3(float(_Float16(accum[p].x + lit.x)), float(_Float16(accum[p].y + lit.y)), float(_Float16(accum[p].z + lit.z)));
 		}
 	}
 
 	// ---- clustered quad (clusterer_bindless.h:29-84) ----
 	f16x4 out_h[PX];
+	float3_ out_f[PX]; // B10: the sums themselves, rounded by the packed store below
 	if ((a.flags & GR_LIGHTING_CLUSTERED_BIT) && a.cl_num_lights > 0)
 	{
 		float3_ result[PX];
@@ -577,9 +598,10 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 #pragma unroll
 		for (int p = 0; p < PX; p++)
 		{
-			out_h[p].x = _Float16(accum[p].x + result[p].x);
-			out_h[p].y = _Float16(accum[p].y + result[p].y);
-			out_h[p].z = _Float16(accum[p].z + result[p].z);
+			out_f[p] = f3(accum[p].x + result[p].x, accum[p].y + result[p].y, accum[p].z + result[p].z);
+			out_h[p].x = _Float16(out_f[p].x);
+			out_h[p].y = _Float16(out_f[p].y);
+			out_h[p].z = _Float16(out_f[p].z);
 		}
 	}
 	else
@@ -587,6 +609,7 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 #pragma unroll
 		for (int p = 0; p < PX; p++)
 		{
+			out_f[p] = accum[p];
 			out_h[p].x = _Float16(accum[p].x); // exact: accum holds fp16 values
 			out_h[p].y = _Float16(accum[p].y);
 			out_h[p].z = _Float16(accum[p].z);
@@ -608,6 +631,23 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		}
 	}
 	// In place (emissive == hdr) untouched pixels need no store; a pair with one lit pixel rewrites the other's own value.
+	if constexpr (B10)
+	{
+		if (any_active || a.emissive.ptr != a.hdr.ptr)
+		{
+			// an untouched pixel keeps its packed value: repacking the exact expansion is the identity
+			uint32_t words[PX];
+#pragma unroll
+			for (int p = 0; p < PX; p++)
+				words[p] = active[p] ? pack_b10g11r11(out_f[p].x, out_f[p].y, out_f[p].z) : pack_b10g11r11(float(dst[p].x), float(dst[p].y), float(dst[p].z));
+			uint8_t *out = a.hdr.ptr + (uint32_t(y) * a.hdr.pitch + uint32_t(x0) * 4u);
+			if constexpr (PX == 2)
+				*reinterpret_cast<uint2 *>(out) = make_uint2(words[0], words[PX - 1]);
+			else
+				*reinterpret_cast<uint32_t *>(out) = words[0];
+		}
+		return;
+	}
 	if (any_active || a.emissive.ptr != a.hdr.ptr)
 	{
 		uint8_t *out = a.hdr.ptr + (uint32_t(y) * a.hdr.pitch + uint32_t(x0) * 8u);
@@ -637,8 +677,11 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	GR_CHECK_ARG(ctx, args != nullptr);
 	const uint32_t W = args->hdr.width, H = args->hdr.height;
 	GR_CHECK_ARG(ctx, W != 0 && H != 0);
-	GR_CHECK_ARG(ctx, check_image(args->hdr, GR_FORMAT_R16G16B16A16_SFLOAT, 8, W, H));
-	GR_CHECK_ARG(ctx, check_image(args->emissive, GR_FORMAT_R16G16B16A16_SFLOAT, 8, W, H));
+	// HDR target and emissive share a format: RGBA16F, or B10G11R11_UFLOAT_PACK32 (renderTargetFp16 = false in the reference)
+	const bool b10 = args->hdr.format == GR_FORMAT_B10G11R11_UFLOAT_PACK32;
+	const uint32_t hdr_format = b10 ? uint32_t(GR_FORMAT_B10G11R11_UFLOAT_PACK32) : uint32_t(GR_FORMAT_R16G16B16A16_SFLOAT), hdr_bpp = b10 ? 4u : 8u;
+	GR_CHECK_ARG(ctx, check_image(args->hdr, hdr_format, hdr_bpp, W, H));
+	GR_CHECK_ARG(ctx, check_image(args->emissive, hdr_format, hdr_bpp, W, H));
 	GR_CHECK_ARG(ctx, check_image(args->albedo, GR_FORMAT_R8G8B8A8_SRGB, 4, W, H));
 	GR_CHECK_ARG(ctx, check_image(args->normal, GR_FORMAT_A2B10G10R10_UNORM_PACK32, 4, W, H));
 	GR_CHECK_ARG(ctx, check_image(args->pbr, GR_FORMAT_R8G8_UNORM, 2, W, H));
@@ -721,8 +764,9 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	}();
 	const bool pairs_aligned = (W & 1u) == 0 && (args->depth.pitch_bytes & 7u) == 0 && (args->albedo.pitch_bytes & 7u) == 0 &&
 	                           (args->normal.pitch_bytes & 7u) == 0 && (args->pbr.pitch_bytes & 3u) == 0 &&
-	                           (args->emissive.pitch_bytes & 15u) == 0 && (args->hdr.pitch_bytes & 15u) == 0 &&
-	                           (reinterpret_cast<uintptr_t>(args->emissive.ptr) & 15u) == 0 && (reinterpret_cast<uintptr_t>(args->hdr.ptr) & 15u) == 0 &&
+	                           (args->emissive.pitch_bytes & (2u * hdr_bpp - 1u)) == 0 && (args->hdr.pitch_bytes & (2u * hdr_bpp - 1u)) == 0 &&
+	                           (reinterpret_cast<uintptr_t>(args->emissive.ptr) & (2u * hdr_bpp - 1u)) == 0 &&
+	                           (reinterpret_cast<uintptr_t>(args->hdr.ptr) & (2u * hdr_bpp - 1u)) == 0 &&
 	                           (reinterpret_cast<uintptr_t>(args->depth.ptr) & 7u) == 0 && (reinterpret_cast<uintptr_t>(args->albedo.ptr) & 7u) == 0 &&
 	                           (reinterpret_cast<uintptr_t>(args->normal.ptr) & 7u) == 0 && (reinterpret_cast<uintptr_t>(args->pbr.ptr) & 3u) == 0;
 	const int px = pairs_aligned ? px_pref : 1;
@@ -750,7 +794,18 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	const size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "lighting"};
 	const bool ao = (args->flags & GR_LIGHTING_AMBIENT_OCCLUSION_BIT) != 0;
-	if (px == 2 && ao)
+	if (b10)
+	{
+		if (px == 2 && ao)
+			hipLaunchKernelGGL((k_lighting<2, true, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+		else if (px == 2)
+			hipLaunchKernelGGL((k_lighting<2, false, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+		else if (ao)
+			hipLaunchKernelGGL((k_lighting<1, true, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+		else
+			hipLaunchKernelGGL((k_lighting<1, false, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+	}
+	else if (px == 2 && ao)
 		hipLaunchKernelGGL((k_lighting<2, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
 	else if (px == 2)
 		hipLaunchKernelGGL((k_lighting<2, false>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);

@@ -38,7 +38,7 @@ template <bool DYNAMIC_EXPOSURE>
 __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold(DevImage hdr, DevImageRW out,
                                                                                 const gr_luminance_data *lum,
                                                                                 gr_push_bloom_threshold push, uint32_t y_first,
-                                                                                uint32_t y_end)
+                                                                                uint32_t y_end, bool hdr_b10)
 {
 	post_wave_priority();
 	const int x = blockIdx.x * POST_BLOCK_X + threadIdx.x;
@@ -48,7 +48,8 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold(
 
 	const float u = (float(x) + 0.5f) * push.inv_output_size[0];
 	const float v = (float(y) + 0.5f) * push.inv_output_size[1];
-	const float4 c = sample_linear_rgba16f(hdr, u, v);
+	const float4 c = hdr_b10 ? sample_linear_with([&hdr](int tx, int ty) { return load_b10g11r11(hdr, tx, ty); }, hdr.w, hdr.h, u, v)
+	                         : sample_linear_rgba16f(hdr, u, v);
 
 	float luminance = fmaxf(fmaxf(c.x, c.y), c.z) + 0.0001f;
 	const float loglum = __log2f(luminance);
@@ -72,16 +73,28 @@ template <bool DYNAMIC_EXPOSURE>
 __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold_2to1(DevImage hdr, DevImageRW out,
                                                                                      const gr_luminance_data *lum, uint32_t pairs_x,
                                                                                      float inv_out_w, float inv_out_h, uint32_t y_first,
-                                                                                     uint32_t y_end)
+                                                                                     uint32_t y_end, bool hdr_b10)
 {
 	post_wave_priority();
 	const uint32_t xp = blockIdx.x * POST_BLOCK_X + threadIdx.x; // output pixels 2 xp, 2 xp + 1
 	const uint32_t y = y_first + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
 	if (xp >= pairs_x || y >= y_end)
 		return;
-	const uint8_t *row0 = hdr.ptr + size_t(2u * y) * hdr.pitch + size_t(xp) * 32u;
-	const u32x4 a0 = *reinterpret_cast<const u32x4 *>(row0), a1 = *reinterpret_cast<const u32x4 *>(row0 + 16);
-	const u32x4 b0 = *reinterpret_cast<const u32x4 *>(row0 + hdr.pitch), b1 = *reinterpret_cast<const u32x4 *>(row0 + hdr.pitch + 16);
+	u32x4 a0, a1, b0, b1; // four HDR texels per row as RGBA16F dwords
+	if (hdr_b10)
+	{
+		// B10G11R11 target: 16 bytes per row hold the four texels; each expands exactly into its RGBA16F dwords
+		const uint8_t *row0 = hdr.ptr + size_t(2u * y) * hdr.pitch + size_t(xp) * 16u;
+		const u32x4 pa = *reinterpret_cast<const u32x4 *>(row0), pb = *reinterpret_cast<const u32x4 *>(row0 + hdr.pitch);
+		a0 = expand_b10g11r11_pair(pa.x, pa.y), a1 = expand_b10g11r11_pair(pa.z, pa.w);
+		b0 = expand_b10g11r11_pair(pb.x, pb.y), b1 = expand_b10g11r11_pair(pb.z, pb.w);
+	}
+	else
+	{
+		const uint8_t *row0 = hdr.ptr + size_t(2u * y) * hdr.pitch + size_t(xp) * 32u;
+		a0 = *reinterpret_cast<const u32x4 *>(row0), a1 = *reinterpret_cast<const u32x4 *>(row0 + 16);
+		b0 = *reinterpret_cast<const u32x4 *>(row0 + hdr.pitch), b1 = *reinterpret_cast<const u32x4 *>(row0 + hdr.pitch + 16);
+	}
 	// fractional sampler coordinate: ((p + 0.5) * inv_out) * size - 0.5, minus its floor (= 2 p)
 	auto fraction = [](uint32_t p, float inv_out, int size) {
 		const float f = __fsub_rn(__fmul_rn(__fmul_rn(float(p) + 0.5f, inv_out), float(size)), 0.5f);
@@ -508,7 +521,7 @@ constexpr int TONEMAP_ROW_GROUPS = 8; // a workgroup walks 8 x TONEMAP_BLOCK_Y r
 template <bool DYNAMIC_EXPOSURE, bool SRGB, bool QUARTER_BLOOM>
 __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(DevImage hdr, DevImage bloom, DevImageRW out,
                                                                               const gr_luminance_data *lum, const uint2 *encode_lut,
-                                                                              gr_push_tonemap push, uint32_t y_first, uint32_t y_end)
+                                                                              gr_push_tonemap push, uint32_t y_first, uint32_t y_end, bool hdr_b10)
 {
 	post_wave_priority();
 	// *_SRGB output: the curve and the store's encode are one table lookup per channel (tonemap_srgb8_lut), staged in LDS.
@@ -539,7 +552,30 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 		uint32_t packed[TONEMAP_PX];
 		const bool full = (x0 + TONEMAP_PX <= hdr.w) && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
 		f16x4 texels[TONEMAP_PX];
-		if (full)
+		if (hdr_b10)
+		{
+			// B10G11R11 target: 16 bytes per lane; every texel expands exactly into the RGBA16F texel the code below reads
+			uint32_t words[TONEMAP_PX];
+			if (full)
+			{
+				const u32x4 t = *reinterpret_cast<const u32x4 *>(row + size_t(x0) * 4u);
+				words[0] = t.x, words[1] = t.y, words[2] = t.z, words[3] = t.w;
+			}
+			else
+			{
+#pragma unroll
+				for (int i = 0; i < TONEMAP_PX; i++)
+					words[i] = *reinterpret_cast<const uint32_t *>(row + size_t(min(x0 + i, hdr.w - 1)) * 4u);
+			}
+#pragma unroll
+			for (int i = 0; i < TONEMAP_PX; i++)
+			{
+				uint32_t rg, ba;
+				expand_b10g11r11(words[i], rg, ba);
+				texels[i] = __builtin_bit_cast(f16x4, u32x2{rg, ba});
+			}
+		}
+		else if (full)
 		{
 			// 32 contiguous bytes per lane, 2 KiB per wave per row.
 			const u32x4 lo = *reinterpret_cast<const u32x4 *>(row + size_t(x0) * 8u);
@@ -650,6 +686,13 @@ static bool is_rgba16f(const gr_image *img)
 	return img && img->ptr && img->format == GR_FORMAT_R16G16B16A16_SFLOAT && img->width && img->height &&
 	       img->pitch_bytes >= img->width * 8u && (img->pitch_bytes & 7u) == 0;
 }
+static bool is_b10g11r11(const gr_image *img)
+{
+	return img && img->ptr && img->format == GR_FORMAT_B10G11R11_UFLOAT_PACK32 && img->width && img->height &&
+	       img->pitch_bytes >= img->width * 4u && (img->pitch_bytes & 3u) == 0;
+}
+// an HDR colour target as the passes that only read it take it: RGBA16F, or the reference's default B10G11R11_UFLOAT_PACK32
+static bool is_hdr_target(const gr_image *img) { return is_rgba16f(img) || is_b10g11r11(img); }
 // What gr_bloom_downsample / gr_bloom_upsample pick for a level: the constant-weight stencil when it is exactly 2:1 / 1:2.
 static bool downsample_is_exact(const gr_image *in, const gr_push_bloom_downsample *push)
 {
@@ -683,8 +726,9 @@ int gr_bloom_threshold_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, 
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, push != nullptr);
-	GR_CHECK_ARG(ctx, is_rgba16f(hdr) && is_rgba16f(out));
+	GR_CHECK_ARG(ctx, is_hdr_target(hdr) && is_rgba16f(out));
 	GR_CHECK_ARG(ctx, push->threads[0] <= out->width && push->threads[1] <= out->height);
+	const bool b10 = hdr->format == GR_FORMAT_B10G11R11_UFLOAT_PACK32;
 	if (push->threads[0] == 0 || push->threads[1] == 0)
 		return GR_OK;
 	const RowSpan span = resolve_rows(rows, push->threads[1]);
@@ -703,16 +747,16 @@ int gr_bloom_threshold_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, 
 		const uint32_t pairs = push->threads[0] / 2u;
 		dim3 grid2(gr_div_up(pairs, POST_BLOCK_X), gr_div_up(span.count(), POST_BLOCK_Y));
 		if (lum)
-			hipLaunchKernelGGL(k_bloom_threshold_2to1<true>, grid2, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, pairs, push->inv_output_size[0], push->inv_output_size[1], span.first, span.end);
+			hipLaunchKernelGGL(k_bloom_threshold_2to1<true>, grid2, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, pairs, push->inv_output_size[0], push->inv_output_size[1], span.first, span.end, b10);
 		else
-			hipLaunchKernelGGL(k_bloom_threshold_2to1<false>, grid2, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, pairs, push->inv_output_size[0], push->inv_output_size[1], span.first, span.end);
+			hipLaunchKernelGGL(k_bloom_threshold_2to1<false>, grid2, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, pairs, push->inv_output_size[0], push->inv_output_size[1], span.first, span.end, b10);
 	}
 	else if (lum)
 		hipLaunchKernelGGL(k_bloom_threshold<true>, grid, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, *push,
-		                   span.first, span.end);
+		                   span.first, span.end, b10);
 	else
 		hipLaunchKernelGGL(k_bloom_threshold<false>, grid, block, 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(out), lum, *push,
-		                   span.first, span.end);
+		                   span.first, span.end, b10);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
@@ -886,7 +930,7 @@ int gr_tonemap_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, push != nullptr);
-	GR_CHECK_ARG(ctx, is_rgba16f(hdr) && is_rgba16f(bloom));
+	GR_CHECK_ARG(ctx, is_hdr_target(hdr) && is_rgba16f(bloom));
 	GR_CHECK_ARG(ctx, out && out->ptr && out->width == hdr->width && out->height == hdr->height &&
 	                       out->pitch_bytes >= out->width * 4u);
 	const bool srgb = out->format == GR_FORMAT_R8G8B8A8_SRGB;
@@ -901,7 +945,8 @@ int gr_tonemap_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr
 	hipStream_t s = gr_to_stream(stream);
 	const bool quarter = hdr->width == 4u * bloom->width && hdr->height == 4u * bloom->height;
 	auto launch = [&](auto kernel) {
-		hipLaunchKernelGGL(kernel, grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, ctx->tonemap_srgb8_lut, *push, span.first, span.end);
+		hipLaunchKernelGGL(kernel, grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, ctx->tonemap_srgb8_lut, *push, span.first, span.end,
+		                   hdr->format == GR_FORMAT_B10G11R11_UFLOAT_PACK32);
 	};
 	if (quarter)
 	{

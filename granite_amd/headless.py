@@ -45,7 +45,7 @@ POST_AA = {"none": gapp.POST_AA_NONE, "fxaa": gapp.POST_AA_FXAA, "smaaLow": gapp
 UNSUPPORTED_AA = ("fxaa2phase", "smaaUltraT2X", "taaFSR2")
 IGNORED_KEYS = ("directionalLightShadows", "directionalLightShadowsCascaded", "directionalLightShadowsVSM", "PCFKernelWide",
                 "clusteredLightsShadows", "clusteredLightsShadowsResolution", "clusteredLightsShadowsVSM", "showUi",
-                "forwardDepthPrepass", "shadowMapResolution", "renderTargetFp16", "rescaleScene", "lodBias", "debugProbes",
+                "forwardDepthPrepass", "shadowMapResolution", "rescaleScene", "lodBias", "debugProbes",
                 "cameraIndex", "clusteredLightsBindless", "maxSpotLights", "maxPointLights", "volumetricFog",
                 "volumetricDiffuse", "deferredClusteredStencilCulling")
 
@@ -88,6 +88,10 @@ def viewer_config_to_kwargs(doc: dict) -> dict:
             kw["ambient_occlusion"] = bool(value)
         elif key == "ssr":
             kw["ssr"] = bool(value)  # setup_ssr_pass on the deferred path (scene_viewer_application.cpp:1206-1212)
+        elif key == "renderTargetFp16":
+            # false = the viewer's default: emissive / HDR-main as B10G11R11_UFLOAT_PACK32 (scene_viewer_application.cpp:881-883).
+            # Without the key the runner follows the scene's emissive.gtx (a dump carries its format); the synthetic scene is RGBA16F.
+            kw["rt_fp16"] = bool(value)
         elif key in IGNORED_KEYS:
             continue
         else:
@@ -219,6 +223,9 @@ def main(argv=None) -> int:
             with open(os.path.join(scene_dir, "camera.json")) as f:
                 cam_doc = json.load(f)
 
+    if "rt_fp16" not in kw and scene_dir and os.path.exists(os.path.join(scene_dir, "emissive.gtx")):
+        from . import gtx
+        kw["rt_fp16"] = gtx.probe(os.path.join(scene_dir, "emissive.gtx")).format != capi.FORMAT_B10G11R11_UFLOAT_PACK32
     try:
         app = gapp.Application(args.width, args.height, device=args.device, timestamps=args.timestamp,
                                frame_time=args.time_step, **kw)
@@ -238,7 +245,10 @@ def main(argv=None) -> int:
         app.upload_gbuffer_gtx(**paths, motion_vectors=mv if os.path.exists(mv) else None)
         app.set_lights(descs if descs is not None else np.zeros(0, synth.LIGHT_DESC_DTYPE))
     else:
-        app.upload_gbuffer(synth.make_gbuffer(cam), motion_vectors=synth.make_motion_vectors(rw, rh))
+        gbuf = synth.make_gbuffer(cam)
+        if not kw.get("rt_fp16", True):
+            gbuf["emissive"] = synth.pack_b10g11r11(gbuf["emissive"])
+        app.upload_gbuffer(gbuf, motion_vectors=synth.make_motion_vectors(rw, rh))
         app.set_lights(synth.make_lights(cam, 4096 if args.lights < 0 else args.lights))
 
     gpu, driver_version = device_info(app)

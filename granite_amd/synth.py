@@ -211,3 +211,23 @@ def make_ldr_pattern(width: int, height: int, seed: int = SEED) -> np.ndarray:
     rgba[..., :3] = np.clip(np.rint(img * 255.0), 0, 255).astype(np.uint8)
     rgba[..., 3] = 255
     return rgba
+
+
+def pack_b10g11r11(rgba16f_bits: np.ndarray) -> np.ndarray:
+    """RGBA16F bits (h, w, 4) -> B10G11R11_UFLOAT_PACK32 words (h, w): the G-buffer's emissive attachment as the reference declares
+    it with renderTargetFp16 = false (scene_viewer_application.cpp:881-883).  A half float and the packed floats share exponent
+    width and bias, so the conversion is a mantissa rounding of the half's bits (to nearest, ties to even; the closest FINITE value:
+    above the largest finite packed value -> it); negative values -> 0; +inf and NaN stay."""
+    hb = np.asarray(rgba16f_bits, np.uint16).astype(np.uint32)
+
+    def channel(h, mant_bits):
+        drop = 10 - mant_bits
+        v = h & 0x7fff
+        q = (v + (1 << (drop - 1)) - 1 + ((v >> drop) & 1)) >> drop
+        inf = 31 << mant_bits
+        q = np.minimum(q, inf - 1)
+        q = np.where(v == 0x7c00, inf, q)
+        q = np.where(v > 0x7c00, inf | 1, q)
+        return np.where((h & 0x8000) != 0, np.where(v > 0x7c00, inf | 1, 0), q).astype(np.uint32)
+
+    return channel(hb[..., 0], 6) | (channel(hb[..., 1], 6) << 11) | (channel(hb[..., 2], 5) << 22)

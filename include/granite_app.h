@@ -92,6 +92,13 @@ typedef struct gra_config
 	 * all-gather; the alpha byte of a tonemapped / FXAA'd frame is 255) -- 3/4 of the bytes per xGMI link.  1 = send the RGBA8 rows
 	 * as they are (A/B).  An SMAA output always travels as RGBA8. */
 	int32_t output_gather_rgba;
+	/* viewer_config "renderTargetFp16" = false, the reference's shipped default (viewer/viewer_config.json:15,
+	 * scene_viewer_application.cpp:881-883): emissive / HDR-main are B10G11R11_UFLOAT_PACK32 instead of R16G16B16A16_SFLOAT
+	 * (4 bytes per texel; both lighting blends round to the packed floats), and a TAA resolve in front of the post chain writes
+	 * its colour in the same format (temporal.cpp:211-213; its history stays RGBA16F).  The emissive upload is then one
+	 * 32-bit word per texel.  0 = RGBA16F everywhere (SURVEY.md 8d fixes the headline configuration on it).  Not with ssr / hdr10
+	 * (those passes read-modify-write the lit target as RGBA16F here). */
+	int32_t hdr_packed_float;
 } gra_config;
 
 /* Scene-level light description (one PositionalLight + its node transform). */

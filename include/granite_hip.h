@@ -49,6 +49,7 @@ typedef enum gr_format
 	GR_FORMAT_R16G16_SFLOAT = 83,
 	GR_FORMAT_R16G16B16A16_SFLOAT = 97,
 	GR_FORMAT_R32_SFLOAT = 100,
+	GR_FORMAT_B10G11R11_UFLOAT_PACK32 = 122, /* HDR targets with renderTargetFp16 = false (scene_viewer_application.cpp:881-883), TAA colour (temporal.cpp:211-213) */
 	GR_FORMAT_D16_UNORM = 124,
 	GR_FORMAT_D32_SFLOAT = 126
 } gr_format;
@@ -563,6 +564,9 @@ int gr_fill_u32(gr_ctx *ctx, gr_stream stream, void *dst, uint32_t value, size_t
 /* Executor self-test operation (no counterpart in the reference): out[i] = hash(i, salt, one dword of each of up to four
  * inputs).  Used by tests/cpp/graph_cases.cpp --execute to run random frame graphs on the three-stream executor and compare the
  * swapchain image with a serial run. */
+/* fp32 (r, g, b) triples -> B10G11R11_UFLOAT_PACK32 words: the attachment store conversion the lighting and TAA kernels apply
+ * when their target has that format (closest finite packed value, ties to even; negative -> 0; +inf -> +inf; NaN -> NaN). */
+int gr_pack_b10g11r11(gr_ctx *ctx, gr_stream stream, const float *rgb, uint32_t *out, uint32_t texels);
 int gr_debug_mix(gr_ctx *ctx, gr_stream stream, void *out, size_t out_dwords, const void *const *inputs, const size_t *input_dwords,
                  uint32_t input_count, uint32_t salt);
 /* VkPhysicalDeviceProperties::deviceName / driverVersion as the headless runner reports them in its --stat file

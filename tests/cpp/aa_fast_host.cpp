@@ -56,14 +56,25 @@ void aah_smaa_blend(const uint8_t *color, const uint8_t *weights, int w, int h, 
 		            1.0f / float(h), rows);
 }
 
+void aah_taa_fmt(const uint8_t *current, const uint8_t *depth, const uint8_t *mv, const uint8_t *history, int w, int h, const float *reproj16, int quality,
+                 uint8_t *out_color, uint8_t *out_history, int row_first, int row_count, int current_b10, int color_b10);
 void aah_taa(const uint8_t *current, const uint8_t *depth, const uint8_t *mv, const uint8_t *history, int w, int h, const float *reproj16, int quality,
              uint8_t *out_color, uint8_t *out_history, int row_first, int row_count)
+{
+	aah_taa_fmt(current, depth, mv, history, w, h, reproj16, quality, out_color, out_history, row_first, row_count, 0, 0);
+}
+// current_b10 / color_b10: the current frame / the resolved colour are B10G11R11_UFLOAT_PACK32 words (4 bytes per texel)
+void aah_taa_fmt(const uint8_t *current, const uint8_t *depth, const uint8_t *mv, const uint8_t *history, int w, int h, const float *reproj16, int quality,
+                 uint8_t *out_color, uint8_t *out_history, int row_first, int row_count, int current_b10, int color_b10)
 {
 	const RowSpan rows = span_of(h, row_first, row_count);
 	TaaImages im = {};
 	im.current = current, im.depth = depth, im.mv = mv, im.history = history;
 	im.out_color = out_color, im.out_history = out_history;
-	im.current_pitch = im.history_pitch = im.out_color_pitch = im.out_history_pitch = uint32_t(w * 8);
+	im.history_pitch = im.out_history_pitch = uint32_t(w * 8);
+	im.current_pitch = uint32_t(w * (current_b10 ? 4 : 8));
+	im.out_color_pitch = uint32_t(w * (color_b10 ? 4 : 8));
+	im.current_b10 = current_b10, im.color_b10 = color_b10;
 	im.depth_pitch = im.mv_pitch = uint32_t(w * 4);
 	im.w = w, im.h = h;
 	aa::TaaPush push;

@@ -188,3 +188,28 @@ def test_smaa_weight_kernel_row_band(host):
     host.aah_smaa_weights(p(edges), w, h, p(area), p(search), 3, p(out), 130, 41)
     np.testing.assert_array_equal(out[130:171], ref[130:171])
     assert (out[:130] == 0x77).all() and (out[171:] == 0x77).all()
+
+
+@pytest.mark.parametrize("quality", [0, 2])
+def test_taa_kernel_with_b10g11r11_input_and_colour_output(host, quality):
+    """renderTargetFp16 = false: the current frame comes in as B10G11R11_UFLOAT_PACK32 words and the resolved colour goes out in the
+    same format (rounded once, from fp32: the store conversion is exact integer code -- wherever the fp32 colour agrees the words
+    are equal); history RGBA16F."""
+    from util import assert_rgba16f_close
+    w, h = 80, 45
+    cur16, depth, mv, reproj = taa_inputs(w, h)
+    cur16 = orc.quantize_b10g11r11(cur16)
+    cur = orc.pack_b10g11r11(cur16)
+    prev = orc.taa_resolve(synth.make_hdr(w, h, seed=11), depth, mv, None, reproj, quality)[1]
+    col, hist = np.zeros((h, w), np.uint32), np.zeros((h, w, 4), np.uint16)
+    host.aah_taa_fmt(p(cur), p(depth), p(mv), p(prev), w, h, p(reproj), quality, p(col), p(hist), 0, 0, 1, 1)
+    ref_c, ref_h = orc.taa_resolve(cur16, depth, mv, prev, reproj, quality, color_b10g11r11=True)
+    assert_rgba16f_close(hist, ref_h, ulps=3.0, abs_tol=2e-4, what="history")
+    got_c = orc.unpack_b10g11r11(col)
+    assert np.array_equal(orc.pack_b10g11r11(got_c), col)
+    # a neighbouring code of a channel only where the fp32 colour (a few ulps apart between kernel and oracle) sits on a tie
+    want = orc.pack_b10g11r11(ref_c)
+    for shift, bits in ((0, 11), (11, 11), (22, 10)):
+        a, b = (col >> shift) & ((1 << bits) - 1), (want >> shift) & ((1 << bits) - 1)
+        assert np.abs(a.astype(np.int64) - b.astype(np.int64)).max() <= 1
+    assert (col == want).mean() > 0.98

@@ -1,0 +1,168 @@
+"""GPU parity for B10G11R11_UFLOAT_PACK32 HDR targets -- the reference's default (viewer_config renderTargetFp16 = false,
+scene_viewer_application.cpp:881-883) -- through the C ABI: the store conversion word for word against the oracle, lighting into a
+packed target, threshold / tonemap reading one, the TAA resolve with packed input and colour output, and whole frames of the
+executor with `rt_fp16=False`.
+
+A packed value is exactly a half float, so passes that only READ the target must give the bytes they give on the expanded RGBA16F
+image; passes that WRITE it round an fp32 result that is a few fp32 ulps from the oracle's, i.e. the same packed code except on
+a tie (one code apart, 2^-6 relative: 16 to 32 half-float ulps)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from granite_amd import app as gapp, capi, synth
+from oracle import oracle as orc
+from gpu_scene import Scene
+from util import assert_rgba16f_close, assert_rgba8_close
+
+pytestmark = pytest.mark.gpu
+
+F16, B10 = capi.FORMAT_R16G16B16A16_SFLOAT, capi.FORMAT_B10G11R11_UFLOAT_PACK32
+
+
+def codes_close(got, want, what, min_equal=0.995):
+    for shift, bits in ((0, 11), (11, 11), (22, 10)):
+        a, b = (got >> shift) & ((1 << bits) - 1), (want >> shift) & ((1 << bits) - 1)
+        worst = np.abs(a.astype(np.int64) - b.astype(np.int64)).max()
+        assert worst <= 1, f"{what}: a channel {worst} packed codes away from the oracle"
+    equal = (got == want).mean()
+    assert equal > min_equal, f"{what}: only {equal:.4f} of the words equal the oracle's"
+
+
+def test_store_conversion_word_for_word(gr):
+    r = np.random.default_rng(1)
+    x = np.concatenate([np.exp2(r.uniform(-27, 17, 300000)), r.uniform(0, 3, 100000), -np.exp2(r.uniform(-20, 10, 1000)),
+                        [0.0, -0.0, 65024.0, 65279.9, 65280.0, 1e9, 64512.0, 65023.9, np.inf, -np.inf, np.nan, 2.0 ** -14, 2.0 ** -20, 2.0 ** -21]]).astype(np.float32)
+    # ties of both mantissa widths, in the normal and the denormal range
+    ties = np.array([(1 + (2 * k + 1) / 128.0) * 2.0 ** e for k in range(64) for e in (-14, -3, 0, 9)] +
+                    [(1 + (2 * k + 1) / 64.0) * 2.0 ** e for k in range(32) for e in (-14, 0, 7)] +
+                    [(2 * k + 1) * 2.0 ** -21 for k in range(40)] + [(2 * k + 1) * 2.0 ** -20 for k in range(20)], np.float32)
+    x = np.concatenate([x, ties])
+    x = np.resize(x, (x.size // 3) * 3)
+    rgb = np.ascontiguousarray(x.reshape(-1, 3))
+    n = rgb.shape[0]
+    src = capi.DeviceBuffer(gr, rgb.nbytes).upload(rgb)
+    dst = capi.DeviceBuffer(gr, n * 4)
+    gr.check(gr.lib.gr_pack_b10g11r11(gr.handle, None, src.ptr, dst.ptr, n))
+    gr.sync()
+    got = dst.download(np.uint32)[:n]
+    want = np.zeros(n, np.uint32)
+    orc.lib().orc_pack_b10g11r11_from_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    orc.lib().orc_pack_b10g11r11_from_f32(rgb.ctypes.data, want.ctypes.data, n)
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("w,h,lights", [(256, 144, 300), (130, 75, 64)])
+def test_lighting_into_a_packed_target(gr, w, h, lights):
+    sc = Scene(w, h, lights)
+    sc.gbuf["emissive"] = orc.quantize_b10g11r11(sc.gbuf["emissive"])
+    ref_c = orc.cluster_build(sc.rp, sc.prm, sc.lights, sc.model, sc.type_mask, sc.n, sc.res[2])
+    dev = sc.build_clusters_gpu(gr)
+    flags = capi.LIGHTING_DIRECTIONAL_BIT | capi.LIGHTING_CLUSTERED_BIT | capi.LIGHTING_AMBIENT_FALLBACK_BIT
+    args, imgs = sc.lighting_args(gr, dev, flags)
+    packed = capi.DeviceImage(gr, w, h, B10).upload(orc.pack_b10g11r11(sc.gbuf["emissive"]))
+    args.hdr = packed.desc
+    args.emissive = packed.desc
+    gr.check(gr.lib.gr_lighting(gr.handle, None, args))
+    gr.sync()
+    want = orc.lighting(sc.gbuf, sc.rp, sc.prm, sc.lights, sc.type_mask, ref_c["bitmask"], ref_c["range"], synth.DIRECTIONAL_COLOR,
+                        synth.DIRECTIONAL_DIRECTION, b10g11r11=True)
+    codes_close(packed.download(), orc.pack_b10g11r11(want), f"lighting {w}x{h}")
+    # sky pixels keep their packed emissive word
+    sky = sc.gbuf["depth"] == 0.0
+    np.testing.assert_array_equal(packed.download()[sky], orc.pack_b10g11r11(sc.gbuf["emissive"])[sky])
+
+
+@pytest.mark.parametrize("w,h", [(256, 144), (250, 142), (67, 35)])
+def test_threshold_and_tonemap_read_a_packed_target_like_its_rgba16f_expansion(gr, w, h):
+    hdr16 = orc.quantize_b10g11r11(synth.make_hdr(w, h))
+    d16 = capi.DeviceImage(gr, w, h, F16).upload(hdr16)
+    d10 = capi.DeviceImage(gr, w, h, B10).upload(orc.pack_b10g11r11(hdr16))
+    tw, th = orc.level_size(w, h, 0.5)
+    lum = capi.DeviceBuffer(gr, 12).upload(np.array([0.1, 1.07, 0.93], np.float32))
+    t16, t10 = capi.DeviceImage(gr, tw, th, F16), capi.DeviceImage(gr, tw, th, F16)
+    gr.bloom_threshold(d16, t16, lum.ptr)
+    gr.bloom_threshold(d10, t10, lum.ptr)
+    bw, bh = orc.level_size(w, h, 0.25)
+    bloom = capi.DeviceImage(gr, bw, bh, F16).upload(synth.make_hdr(bw, bh, seed=9))
+    o16, o10 = capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8B8A8_SRGB), capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8B8A8_SRGB)
+    gr.tonemap(d16, bloom, o16, lum.ptr)
+    gr.tonemap(d10, bloom, o10, lum.ptr)
+    gr.sync()
+    np.testing.assert_array_equal(t10.download(), t16.download())
+    np.testing.assert_array_equal(o10.download(), o16.download())
+    assert_rgba16f_close(t10.download(), orc.bloom_threshold(hdr16, tw, th, np.array([0.1, 1.07, 0.93], np.float32)), what="threshold vs oracle")
+
+
+@pytest.mark.parametrize("quality", [0, 2])
+def test_taa_resolve_with_packed_input_and_colour_output(gr, quality):
+    w, h = 240, 135
+    cam = synth.Camera(w, h)
+    depth = synth.make_gbuffer(cam, 3)["depth"]
+    cur16 = orc.quantize_b10g11r11(synth.make_hdr(w, h, 3))
+    mv = synth.make_motion_vectors(w, h)
+    V2 = synth.look_at((0.01, 2.0, 8.0), (0.01, 1.0, 0.0))
+    T = np.eye(4); T[0, 0] = T[1, 1] = 0.5; T[0, 3] = T[1, 3] = 0.5
+    reproj = np.ascontiguousarray((T @ (cam.P @ V2) @ cam.invVP).T, np.float32).reshape(16)
+    prev = orc.taa_resolve(synth.make_hdr(w, h, seed=11), depth, mv, None, reproj, quality)[1]
+    dcur = capi.DeviceImage(gr, w, h, B10).upload(orc.pack_b10g11r11(cur16))
+    ddepth = capi.DeviceImage(gr, w, h, capi.FORMAT_D32_SFLOAT).upload(depth)
+    dmv = capi.DeviceImage(gr, w, h, capi.FORMAT_R16G16_SFLOAT).upload(mv)
+    dprev = capi.DeviceImage(gr, w, h, F16).upload(prev)
+    dcol, dhist = capi.DeviceImage(gr, w, h, B10), capi.DeviceImage(gr, w, h, F16)
+    for history in (None, dprev):
+        gr.taa_resolve(dcur, ddepth, dmv, history, dcol, dhist, reproj, quality)
+        gr.sync()
+        ref_c, ref_h = orc.taa_resolve(cur16, depth, mv, None if history is None else prev, reproj, quality, color_b10g11r11=True)
+        assert_rgba16f_close(dhist.download(), ref_h, ulps=3.0, abs_tol=2e-4, what="history")
+        codes_close(dcol.download(), orc.pack_b10g11r11(ref_c), f"taa q{quality} colour", min_equal=0.98)
+
+
+@pytest.mark.parametrize("pre_aa", [gapp.POST_AA_NONE, gapp.POST_AA_TAA_HIGH])
+def test_executor_frames_with_packed_hdr_targets(pre_aa):
+    """rt_fp16 = False through the application: emissive / HDR-main (and the TAA colour output) are B10G11R11 attachments; every
+    stage against the oracle fed with the device's own input of that stage."""
+    w, h, n = 320, 180, 300
+    cam = synth.Camera(w, h)
+    gbuf = synth.make_gbuffer(cam)
+    gbuf16 = dict(gbuf, emissive=orc.quantize_b10g11r11(gbuf["emissive"]))
+    descs = synth.make_lights(cam, n)
+    a = gapp.Application(w, h, rt_fp16=False, pre_aa=pre_aa)
+    if pre_aa:
+        a.set_camera(np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16))
+    else:
+        a.set_render_parameters(cam.render_params())
+    a.set_lights(descs)
+    mv = synth.make_motion_vectors(w, h)
+    a.upload_gbuffer(dict(gbuf, emissive=orc.pack_b10g11r11(gbuf16["emissive"])), mv if pre_aa else None)
+    assert a.resource("HDR-main").format == B10 and a.resource("emissive-main").format == B10
+    state, hist = {}, None
+    for frame in range(3):
+        a.render_frames(1)
+        rp = a.get_render_parameters()
+        count, lights, model, tmask, _ = orc.pack_lights(descs, rp[99:102])
+        prm = orc.cluster_params(rp, *synth.CLUSTER_RESOLUTION, count)
+        cb = orc.cluster_build(rp, prm, lights, model, tmask, count, synth.CLUSTER_RESOLUTION[2])
+        want = orc.lighting(gbuf16, rp, prm, lights, tmask, cb["bitmask"], cb["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION,
+                            b10g11r11=True)
+        lit = a.read("HDR-main").copy()
+        codes_close(lit, orc.pack_b10g11r11(want), f"frame {frame} HDR-main")
+        post_in = orc.unpack_b10g11r11(lit)
+        if pre_aa:
+            assert a.resource("HDR-resolved").format == B10
+            ref_c, ref_h = orc.taa_resolve(post_in, gbuf["depth"], mv, hist, a.taa_reprojection(), 2, color_b10g11r11=True)
+            resolved = a.read("HDR-resolved").copy()
+            codes_close(resolved, orc.pack_b10g11r11(ref_c), f"frame {frame} HDR-resolved", min_equal=0.98)
+            hist = a.read("HDR-resolved-history").copy()
+            assert_rgba16f_close(hist, ref_h, ulps=3.0, abs_tol=2e-4, what=f"frame {frame} TAA history")
+            post_in = orc.unpack_b10g11r11(resolved)
+        chain = orc.hdr_chain(post_in, state)
+        assert_rgba16f_close(a.read("threshold"), chain["threshold"], what=f"frame {frame} threshold")
+        assert_rgba8_close(a.read_backbuffer(), chain["tonemapped"], 1, what=f"frame {frame} backbuffer")
+    a.close()
+
+
+def test_packed_targets_are_refused_where_a_pass_takes_rgba16f():
+    with pytest.raises(capi.GraniteHipError):
+        gapp.Application(64, 64, rt_fp16=False, ssr=True)

@@ -380,3 +380,12 @@ def test_pq10_known_answers():
     ui[...] = (255, 255, 255, 0)
     out = orc.pq10_encode(hdr.view(np.uint16), ui, ident, 500.0, 400.0, 1000.0)[0]
     assert np.abs((out & 1023).astype(int) - round(1023 * pq(400.0))).max() <= 1
+
+
+def test_product_side_packed_float_encoder_equals_the_oracle_on_every_half():
+    """granite_amd/synth.py packs the synthetic emissive image for renderTargetFp16 = false set-ups (bench, headless runner) without the
+    oracle: every half-float bit pattern, in each channel position, must give the oracle's packed word."""
+    h = np.arange(65536, dtype=np.uint16)
+    img = np.zeros((65536, 1, 4), np.uint16)
+    img[:, 0, 0], img[:, 0, 1], img[:, 0, 2] = h, h[::-1], np.roll(h, 12345)
+    np.testing.assert_array_equal(synth.pack_b10g11r11(img), orc.pack_b10g11r11(img))
