@@ -190,7 +190,17 @@ gr_ctx *gr_create(int device)
 	static const int encode_table_status = gr_srgb_encode_table(encode_table, SRGB_ENCODE_ENTRIES);
 	static uint32_t tonemap_table[2 * TONEMAP_TABLE_ENTRIES];
 	static const int tonemap_table_status = gr_tonemap_srgb8_table(tonemap_table, TONEMAP_TABLE_ENTRIES);
+	// cos / sin of phi = 2 * M_PI_SIC * (byte / 255), the expression of sssr_util.h's SampleGGXVNDF for its second random number
+	float2 azimuth[256];
+	for (volatile int i = 0; i < 256; i++)
+	{
+		const float u2 = float(int(i)) / 255.0f;
+		volatile float phi = 2.0f * 3.1415628f * u2;
+		azimuth[i] = make_float2(cosf(phi), sinf(phi));
+	}
 	if (encode_table_status != 0 || tonemap_table_status != 0 ||
+	    hipMalloc(reinterpret_cast<void **>(&ctx->ssr_azimuth_lut), sizeof(azimuth)) != hipSuccess ||
+	    hipMemcpy(ctx->ssr_azimuth_lut, azimuth, sizeof(azimuth), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->tonemap_srgb8_lut), sizeof(tonemap_table)) != hipSuccess ||
 	    hipMemcpy(ctx->tonemap_srgb8_lut, tonemap_table, sizeof(tonemap_table), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->srgb_decode_lut), sizeof(lut)) != hipSuccess ||
@@ -223,6 +233,8 @@ void gr_destroy(gr_ctx *ctx)
 		(void)hipFree(ctx->srgb_encode_lut);
 	if (ctx->tonemap_srgb8_lut)
 		(void)hipFree(ctx->tonemap_srgb8_lut);
+	if (ctx->ssr_azimuth_lut)
+		(void)hipFree(ctx->ssr_azimuth_lut);
 	if (ctx->smaa_area)
 		(void)hipFree(ctx->smaa_area);
 	if (ctx->smaa_search)

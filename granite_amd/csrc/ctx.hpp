@@ -29,6 +29,9 @@ struct gr_ctx
 	uint2 *srgb_encode_lut = nullptr;
 	// Exposed colour -> tonemapped sRGB8 staircase (device_common.hpp: tonemap_srgb8_lut).
 	uint2 *tonemap_srgb8_lut = nullptr;
+	// SSR (ssr.hip): cos / sin of the 256 azimuths 2 pi u / 255 the dither texture's byte can select (sssr_util.h: SampleGGXVNDF),
+	// evaluated once on the host: the traced directions then do not depend on the device's trigonometric approximations.
+	float2 *ssr_azimuth_lut = nullptr;
 
 	// SMAA lookup tables (assets/textures/smaa/{area,search}.gtx payloads), uploaded through gr_smaa_set_luts.
 	void *smaa_area = nullptr;   // 160 x 560 x 2 floats (the RG8 area texture, decoded)

@@ -54,6 +54,7 @@ struct SSRParams
 	uint32_t hier_offset[16]; // float offset of level l
 	DevImage pbr, normal, light;
 	const uint16_t *noise; // RG8, 128 x 128 x 64
+	const float2 *azimuth; // (cos, sin) of 2 pi u / 255 for the 256 values of the dither texture's second byte, from the host's libm
 	int frame;
 	float vp[16], inv_vp[16]; // column-major
 	float camera[3];
@@ -278,18 +279,18 @@ __global__ __launch_bounds__(256) void k_ssr_classify_emit(SSRParams p)
 }
 
 // ---- sssr_util.h:55-143 ---------------------------------------------------------------------------------------------------
-constexpr float M_PI_SIC = 3.1415628f;
 
-__device__ __forceinline__ float3_ sample_ggx_vndf(float3_ Ve, float alpha_x, float alpha_y, float U1, float U2)
+// U2 enters only through cos / sin of phi = 2 pi U2, and U2 is a byte / 255: `trig` is (cos phi, sin phi) from the host-built table,
+// so no device approximation of a transcendental is on the path that decides where a ray goes (sqrtf and / are correctly rounded).
+__device__ __forceinline__ float3_ sample_ggx_vndf(float3_ Ve, float alpha_x, float alpha_y, float U1, float2 trig)
 {
 	const float3_ Vh = normalize3(f3(alpha_x * Ve.x, alpha_y * Ve.y, Ve.z));
 	const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
 	const float3_ T1 = lensq > 0.0f ? f3(-Vh.y, Vh.x, 0.0f) * (1.0f / sqrtf(lensq)) : f3(1.0f, 0.0f, 0.0f);
 	const float3_ T2 = cross3(Vh, T1);
 	const float r = sqrtf(U1);
-	const float phi = 2.0f * M_PI_SIC * U2;
-	const float t1 = r * cosf(phi);
-	float t2 = r * sinf(phi);
+	const float t1 = r * trig.x;
+	float t2 = r * trig.y;
 	const float s = 0.5f * (1.0f + Vh.z);
 	t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
 	const float3_ Nh = t1 * T1 + t2 * T2 + sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
@@ -314,8 +315,8 @@ __device__ __forceinline__ float3_ sample_reflection_vector(const SSRParams &p, 
 	const float3_ nv = -view_direction;
 	const float3_ view_tbn = f3(dot3(nv, c0), dot3(nv, c1), dot3(nv, c2)); // vector * matrix
 	const uint16_t noise = p.noise[(size_t(p.frame) * 128u + size_t(py & 127)) * 128u + size_t(px & 127)];
-	const float u1 = float(noise & 255u) / 255.0f, u2 = float(noise >> 8) / 255.0f;
-	const float3_ sampled = sample_ggx_vndf(view_tbn, roughness, roughness, u1, u2);
+	const float u1 = float(noise & 255u) / 255.0f;
+	const float3_ sampled = sample_ggx_vndf(view_tbn, roughness, roughness, u1, p.azimuth[noise >> 8]);
 	const float3_ incident = -view_tbn;
 	const float3_ reflected_tbn = incident - sampled * (2.0f * dot3(sampled, incident)); // reflect(I, N)
 	float3_ r = c0 * reflected_tbn.x; // matrix * vector
@@ -624,6 +625,7 @@ int gr_ssr_trace(gr_ctx *ctx, gr_stream stream, const gr_ssr_args *args)
 	p.normal = dev(args->normal);
 	p.light = dev(args->light);
 	p.noise = static_cast<const uint16_t *>(args->dither_lut);
+	p.azimuth = ctx->ssr_azimuth_lut;
 	p.frame = int(args->frame);
 	for (int i = 0; i < 16; i++)
 	{

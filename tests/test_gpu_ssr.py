@@ -48,14 +48,13 @@ def test_ray_list_and_traced_images_match_the_oracle(gr, w, h, frame):
     # pixels no ray wrote keep the cleared value on both sides
     untouched = (ref["output"] == 0).all(axis=2) & (ref["confidence"] == 0)
     assert (got_out[untouched] == 0).all()
-    # confidence: identical up to the rare traversal that took another branch
-    conf_diff = np.abs(got_conf.astype(np.int16) - ref["confidence"].astype(np.int16))
-    assert (conf_diff > 1).mean() < 2e-3, (conf_diff > 1).mean()
-    agree = conf_diff <= 1
-    bad = rgba16f_mismatch(got_out, ref["output"], 2.0, 1e-4).any(axis=2) & agree
-    assert bad.mean() < 2e-3, bad.mean()
+    # The traversal takes ~100 cell decisions per ray; every operation on that path is correctly rounded on both sides (the azimuth
+    # of the sampled normal comes from a host-built table of its 256 possible values), so every ray lands where the oracle's does:
+    # confidence identical, colour and ray length within the storage tolerance on EVERY pixel.
+    np.testing.assert_array_equal(got_conf, ref["confidence"])
+    assert not rgba16f_mismatch(got_out, ref["output"], 2.0, 1e-4).any()
     len_bad = np.abs(half_bits_to_f32(got_len) - half_bits_to_f32(ref["ray_length"])) > 1e-2 * (1.0 + np.abs(half_bits_to_f32(ref["ray_length"])))
-    assert (len_bad & agree).mean() < 2e-3
+    assert not len_bad.any()
     assert (ref["confidence"] > 0).sum() > 30, "some rays must hit with confidence"
 
 
@@ -110,12 +109,12 @@ def test_ssr_in_the_graph_matches_the_oracle_pipeline():
         np.testing.assert_array_equal(counter, ref["ray_counter"])
         np.testing.assert_array_equal(a.read("ssr-ray-list").view(np.uint32)[:int(counter[5])], ref["ray_list"])
         conf = a.read("SSR-confidence").reshape(h, -1)[:, :w]
-        assert (np.abs(conf.astype(np.int16) - ref["confidence"].astype(np.int16)) > 1).mean() < 2e-3
+        np.testing.assert_array_equal(conf, ref["confidence"])
         sssr = a.read("SSR-sssr")
-        # the lit target differs from the oracle's by an ulp in a few texels; a reflected texel carries that along
-        assert rgba16f_mismatch(sssr, ref["output"], 3.0, 1e-4).any(axis=2).mean() < 3e-3
+        # the lit target differs from the oracle's by an ulp in a few texels; a reflected texel carries that along: 3 ulp, every pixel
+        assert not rgba16f_mismatch(sssr, ref["output"], 3.0, 1e-4).any()
         want = orc.ssr_apply(lit, sssr, albedo, normal, pbr, depth, lut, rp[80:96], rp[96:99])
-        assert rgba16f_mismatch(a.read("SSR"), want, 3.0, 1e-4).any(axis=2).mean() < 1e-3
+        assert not rgba16f_mismatch(a.read("SSR"), want, 3.0, 1e-4).any()
         assert (ref["confidence"] > 0).sum() > 100
     # the post chain consumes the reflected target
     assert (a.read_backbuffer()[..., :3] > 0).any()
