@@ -119,6 +119,14 @@ class PushZRange(C.Structure):
     _fields_ = [("num_volumes", C.c_uint32), ("num_volumes_128", C.c_uint32), ("num_ranges", C.c_uint32)]
 
 
+class ClusterFrontArgs(C.Structure):
+    """gr_cluster_front_args (include/granite_hip.h): uploads + spot_transform + setup + z_range as one launch."""
+    _fields_ = [("transforms", C.c_void_p), ("src_lights", C.c_void_p), ("src_models", C.c_void_p), ("src_type_mask", C.c_void_p),
+                ("transformed_spots", C.c_void_p), ("cull_setup", C.c_void_p), ("params", C.c_void_p), ("spot_push", C.c_void_p),
+                ("setup_push", C.c_void_p), ("src_ranges", C.c_void_p), ("light_ranges", C.c_void_p), ("range_out", C.c_void_p),
+                ("z_push", C.c_void_p)]
+
+
 class PushDirectional(C.Structure):
     _fields_ = [("inv_view_proj_col2", C.c_float * 4), ("color", C.c_float * 3), ("environment_intensity", C.c_float),
                 ("camera_pos", C.c_float * 3), ("environment_mipscale", C.c_float), ("direction", C.c_float * 3),
@@ -255,6 +263,9 @@ def load_library() -> C.CDLL:
         "gr_cluster_setup": (C.c_int, [vp, vp, vp, vp, vp, P(ClusterParams), P(PushClusterSetup)]),
         "gr_cluster_binning": (C.c_int, [vp, vp, vp, vp, vp, P(ClusterParams)]),
         "gr_cluster_z_range": (C.c_int, [vp, vp, vp, vp, P(PushZRange)]),
+        "gr_cluster_front": (C.c_int, [vp, vp, P(ClusterFrontArgs)]),
+        "gr_alloc_host": (C.c_int, [vp, C.c_size_t, P(vp)]),
+        "gr_free_host": (C.c_int, [vp, vp]),
         "gr_lighting": (C.c_int, [vp, vp, P(LightingArgs)]),
         "gr_smaa_set_luts": (C.c_int, [vp, vp, vp]),
         "gr_fxaa": (C.c_int, [vp, vp, P(Image), P(Image), P(PushFxaa)]),
@@ -289,7 +300,7 @@ EXPORTED_SYMBOLS = [
     "gr_download", "gr_copy", "gr_fill_zero", "gr_upload_batch", "gr_alloc_host", "gr_free_host", "gr_timing_enable", "gr_timing_set_filter", "gr_timing_reset", "gr_timing_query",
     "gr_bloom_threshold", "gr_bloom_downsample", "gr_bloom_upsample", "gr_luminance", "gr_tonemap",
     "gr_bloom_threshold_rows", "gr_bloom_downsample_rows", "gr_bloom_upsample_rows", "gr_tonemap_rows",
-    "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_lighting",
+    "gr_cluster_spot_transform", "gr_cluster_setup", "gr_cluster_binning", "gr_cluster_z_range", "gr_cluster_front", "gr_lighting",
     "gr_smaa_set_luts", "gr_fxaa", "gr_blit", "gr_smaa_edge_detection", "gr_smaa_blend_weight", "gr_smaa_neighbor_blend", "gr_taa_resolve",
     "gr_hiz", "gr_mip_chain_offset", "gr_mip_chain_size", "gr_fsr_upscale", "gr_fsr_sharpen", "gr_fill_byte", "gr_fill_u32", "gr_pq10_encode", "gr_get_device_info", "gr_spd_downsample", "gr_debug_mix", "gr_pack_b10g11r11",
 ]

@@ -39,12 +39,9 @@ __device__ __forceinline__ const uint32_t *type_mask_of(const void *transforms)
 }
 
 // ---- spot_transform.comp:38-73 -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_spot_transform(const void *transforms, TransformedSpot *out, gr_push_spot_transform push)
+__device__ __forceinline__ TransformedSpot spot_transform_of(const gr_mat_affine &m, const gr_push_spot_transform &push)
 {
-	const uint32_t index = blockIdx.x * 64u + threadIdx.x;
-	if (index >= push.num_lights)
-		return;
-	const gr_mat_affine m = models_of(transforms)[index];
+	TransformedSpot result;
 	v3 p[5];
 	p[0] = mk3(m.rows[0][3], m.rows[1][3], m.rows[2][3]);
 	const v3 pz = p[0] + mk3(-m.rows[0][2], -m.rows[1][2], -m.rows[2][2]);
@@ -75,8 +72,17 @@ __global__ __launch_bounds__(64) void k_spot_transform(const void *transforms, T
 		cull = 1.0f;
 #pragma unroll
 	for (int i = 0; i < 5; i++)
-		out[index].clip[i] = mul_mat4(push.vp, mk4(p[i].x, p[i].y, p[i].z, 1.0f));
-	out[index].z = mk4(cull, z_lo, z_hi, 0.0f);
+		result.clip[i] = mul_mat4(push.vp, mk4(p[i].x, p[i].y, p[i].z, 1.0f));
+	result.z = mk4(cull, z_lo, z_hi, 0.0f);
+	return result;
+}
+
+__global__ __launch_bounds__(64) void k_spot_transform(const void *transforms, TransformedSpot *out, gr_push_spot_transform push)
+{
+	const uint32_t index = blockIdx.x * 64u + threadIdx.x;
+	if (index >= push.num_lights)
+		return;
+	out[index] = spot_transform_of(models_of(transforms)[index], push);
 }
 
 // ---- setup.comp ------------------------------------------------------------------------------------------------------
@@ -210,17 +216,11 @@ __device__ void clip_w_and_project(CullSetup &cs, uint32_t &num_triangles, v4 c0
 	}
 }
 
-__global__ __launch_bounds__(64) void k_cluster_setup(const void *transforms, const TransformedSpot *spots, CullSetup *setup,
-                                                      gr_cluster_params params, gr_push_cluster_setup push)
+__device__ __forceinline__ void cluster_setup_of(bool point, const gr_light_info &li, const TransformedSpot &spot, CullSetup &cs,
+                                                 const gr_cluster_params &params, const gr_push_cluster_setup &push)
 {
-	const uint32_t index = blockIdx.x * 64u + threadIdx.x;
-	if (index >= push.num_lights)
-		return;
-	const bool point = (type_mask_of(transforms)[index >> 5u] & (1u << (index & 31u))) != 0u;
-	CullSetup &cs = setup[index];
 	if (point)
 	{
-		const gr_light_info &li = lights_of(transforms)[index];
 		const float radius = 1.0f / li.inv_radius;
 		const v4 v4d = mul_mat4(push.view, mk4(li.position[0], li.position[1], li.position[2], 1.0f));
 		const v3 view = mk3(v4d.x, -v4d.y, -v4d.z);
@@ -253,12 +253,12 @@ __global__ __launch_bounds__(64) void k_cluster_setup(const void *transforms, co
 	}
 	else
 	{
-		const v4 z = spots[index].z;
+		const v4 z = spot.z;
 		if (z.x != 0.0f)
 		{
 			uint32_t n = 0u;
-			const v4 c0 = spots[index].clip[0], c1 = spots[index].clip[1], c2 = spots[index].clip[2];
-			const v4 c3 = spots[index].clip[3], c4 = spots[index].clip[4];
+			const v4 c0 = spot.clip[0], c1 = spot.clip[1], c2 = spot.clip[2];
+			const v4 c3 = spot.clip[3], c4 = spot.clip[4];
 			clip_w_and_project(cs, n, c0, c1, c2, z.x);
 			clip_w_and_project(cs, n, c0, c2, c3, z.x);
 			clip_w_and_project(cs, n, c0, c3, c4, z.x);
@@ -270,6 +270,16 @@ __global__ __launch_bounds__(64) void k_cluster_setup(const void *transforms, co
 		else
 			cs.data[0].w = __uint_as_float(0xffffffffu);
 	}
+}
+
+__global__ __launch_bounds__(64) void k_cluster_setup(const void *transforms, const TransformedSpot *spots, CullSetup *setup,
+                                                      gr_cluster_params params, gr_push_cluster_setup push)
+{
+	const uint32_t index = blockIdx.x * 64u + threadIdx.x;
+	if (index >= push.num_lights)
+		return;
+	const bool point = (type_mask_of(transforms)[index >> 5u] & (1u << (index & 31u))) != 0u;
+	cluster_setup_of(point, lights_of(transforms)[index], spots[index], setup[index], params, push);
 }
 
 // ---- binning.comp -------------------------------------------------------------------------------------------------------
@@ -402,9 +412,11 @@ __device__ __forceinline__ uint32_t zr_wave_max(uint32_t v)
 	return v;
 }
 
-__global__ __launch_bounds__(ZR_THREADS) void k_cluster_z_range(const uint2 *light_ranges, uint2 *out, gr_push_z_range push)
+// The work of one z-range workgroup (ZR_SLICES slices from slice_block * ZR_SLICES); `copy_out`, when given, also receives the
+// intervals (the fused launch reads them from the pinned staging area and keeps the "light-ranges" buffer in step).
+__device__ __forceinline__ void z_range_block(const uint2 *light_ranges, uint2 *out, const gr_push_z_range &push, uint32_t slice_block, uint8_t *smem,
+                                              uint2 *copy_out)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	const uint32_t num_groups = (push.num_volumes + 63u) / 64u;
 	uint2 *ranges = reinterpret_cast<uint2 *>(smem);        // num_groups * 64 entries, padded with empty intervals
 	uint2 *group_bounds = ranges + size_t(num_groups) * 64u; // num_groups entries
@@ -415,6 +427,8 @@ __global__ __launch_bounds__(ZR_THREADS) void k_cluster_z_range(const uint2 *lig
 		const uint32_t i = g * 64u + lane;
 		const uint2 r = i < push.num_volumes ? light_ranges[i] : make_uint2(0xffffffffu, 0u);
 		ranges[i] = r;
+		if (copy_out && i < push.num_volumes)
+			copy_out[i] = r;
 		// an empty interval (lo > hi) must not widen the group's bounds
 		const bool valid = r.x <= r.y;
 		const uint32_t glo = zr_wave_min(valid ? r.x : 0xffffffffu), ghi = zr_wave_max(valid ? r.y : 0u);
@@ -425,7 +439,7 @@ __global__ __launch_bounds__(ZR_THREADS) void k_cluster_z_range(const uint2 *lig
 
 	for (uint32_t s = 0; s < ZR_SLICES_PER_WAVE; s++)
 	{
-		const uint32_t z = blockIdx.x * ZR_SLICES + wave * ZR_SLICES_PER_WAVE + s;
+		const uint32_t z = slice_block * ZR_SLICES + wave * ZR_SLICES_PER_WAVE + s;
 		if (z >= push.num_ranges)
 			break;
 		uint32_t first = 0xffffffffu, last = 0u;
@@ -470,6 +484,67 @@ __global__ __launch_bounds__(ZR_THREADS) void k_cluster_z_range(const uint2 *lig
 			out[z] = make_uint2(first, last);
 	}
 }
+
+__global__ __launch_bounds__(ZR_THREADS) void k_cluster_z_range(const uint2 *light_ranges, uint2 *out, gr_push_z_range push)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	z_range_block(light_ranges, out, push, blockIdx.x, smem, nullptr);
+}
+
+// ---- the front of the cluster build as ONE launch ------------------------------------------------------------------------------
+// What clusterer.cpp:1178-1207,1302 (four cmd.update_buffer), :1463-1510 (spot_transform.comp, setup.comp) and :1277-1346
+// (z_range.comp) record as four transfers and three dispatches: every one of them depends on this frame's CPU-packed light data
+// only, so one grid does them all -- workgroups [0, light_blocks) take 256 lights each (copy the light's records from the pinned
+// staging area into the transforms buffer, transform, set up the cull data), the following workgroups are z-range workgroups
+// reading the slice intervals from staging.  Only the binning pass, which needs every light's cull data, stays a launch of its
+// own.  Same device functions as the separate launches: the buffers come out bit-identical.
+struct ClusterFrontArgs
+{
+	void *transforms;                 // HBM: lights, model matrices, type mask at their GR_TRANSFORMS_OFFSET_*
+	const gr_light_info *src_lights;  // pinned staging (or the transforms buffer itself: nothing is copied then)
+	const gr_mat_affine *src_models;
+	const uint32_t *src_type_mask;
+	TransformedSpot *spots;
+	CullSetup *setup;
+	gr_cluster_params params;
+	gr_push_spot_transform spot_push;
+	gr_push_cluster_setup setup_push;
+	const uint2 *src_ranges; // pinned staging or the HBM buffer
+	uint2 *light_ranges;     // HBM copy of the intervals (null or == src_ranges: not written)
+	uint2 *range_out;
+	gr_push_z_range z_push;
+	uint32_t light_blocks;
+};
+
+__global__ __launch_bounds__(ZR_THREADS) void k_cluster_front(ClusterFrontArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	if (blockIdx.x >= a.light_blocks)
+	{
+		z_range_block(a.src_ranges, a.range_out, a.z_push, blockIdx.x - a.light_blocks, smem,
+		              (blockIdx.x == a.light_blocks && a.light_ranges != a.src_ranges) ? a.light_ranges : nullptr);
+		return;
+	}
+	const uint32_t index = blockIdx.x * ZR_THREADS + threadIdx.x;
+	uint8_t *t = static_cast<uint8_t *>(a.transforms);
+	uint32_t *dst_mask = reinterpret_cast<uint32_t *>(t + GR_TRANSFORMS_OFFSET_TYPE_MASK);
+	if (a.src_type_mask != dst_mask && index < uint32_t(a.params.num_lights_32))
+		dst_mask[index] = a.src_type_mask[index];
+	if (index >= a.spot_push.num_lights)
+		return;
+	const gr_light_info li = a.src_lights[index];
+	const gr_mat_affine m = a.src_models[index];
+	gr_light_info *dst_lights = reinterpret_cast<gr_light_info *>(t + GR_TRANSFORMS_OFFSET_LIGHTS);
+	gr_mat_affine *dst_models = reinterpret_cast<gr_mat_affine *>(t + GR_TRANSFORMS_OFFSET_MODEL);
+	if (a.src_lights != dst_lights)
+		dst_lights[index] = li;
+	if (a.src_models != dst_models)
+		dst_models[index] = m;
+	const bool point = (a.src_type_mask[index >> 5u] & (1u << (index & 31u))) != 0u;
+	const TransformedSpot spot = spot_transform_of(m, a.spot_push);
+	a.spots[index] = spot;
+	cluster_setup_of(point, li, spot, a.setup[index], a.params, a.setup_push);
+}
 } // namespace
 
 extern "C" {
@@ -503,6 +578,39 @@ int gr_cluster_setup(gr_ctx *ctx, gr_stream stream, const void *transforms, cons
 	hipLaunchKernelGGL(k_cluster_setup, dim3(gr_div_up(push->num_lights, 64)), dim3(64), 0, gr_to_stream(stream), transforms,
 	                   static_cast<const TransformedSpot *>(transformed_spots), static_cast<CullSetup *>(cull_setup), *params,
 	                   *push);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_cluster_front(gr_ctx *ctx, gr_stream stream, const gr_cluster_front_args *args)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, args && args->transforms && args->transformed_spots && args->cull_setup && args->params && args->spot_push && args->setup_push);
+	GR_CHECK_ARG(ctx, args->light_ranges && args->range_out && args->z_push);
+	const uint32_t n = args->spot_push->num_lights;
+	GR_CHECK_ARG(ctx, n >= 1 && n <= GR_MAX_LIGHTS_BINDLESS && n == args->setup_push->num_lights && int(n) == args->params->num_lights);
+	GR_CHECK_ARG(ctx, args->z_push->num_volumes >= 1 && args->z_push->num_volumes <= GR_MAX_LIGHTS_BINDLESS && args->z_push->num_ranges > 0);
+	uint8_t *t = static_cast<uint8_t *>(args->transforms);
+	ClusterFrontArgs a = {};
+	a.transforms = args->transforms;
+	a.src_lights = args->src_lights ? static_cast<const gr_light_info *>(args->src_lights) : reinterpret_cast<const gr_light_info *>(t + GR_TRANSFORMS_OFFSET_LIGHTS);
+	a.src_models = args->src_models ? static_cast<const gr_mat_affine *>(args->src_models) : reinterpret_cast<const gr_mat_affine *>(t + GR_TRANSFORMS_OFFSET_MODEL);
+	a.src_type_mask = args->src_type_mask ? static_cast<const uint32_t *>(args->src_type_mask) : reinterpret_cast<const uint32_t *>(t + GR_TRANSFORMS_OFFSET_TYPE_MASK);
+	a.spots = static_cast<TransformedSpot *>(args->transformed_spots);
+	a.setup = static_cast<CullSetup *>(args->cull_setup);
+	a.params = *args->params;
+	a.spot_push = *args->spot_push;
+	a.setup_push = *args->setup_push;
+	a.light_ranges = reinterpret_cast<uint2 *>(args->light_ranges);
+	a.src_ranges = args->src_ranges ? static_cast<const uint2 *>(args->src_ranges) : a.light_ranges;
+	a.range_out = reinterpret_cast<uint2 *>(args->range_out);
+	a.z_push = *args->z_push;
+	a.light_blocks = gr_div_up(n, ZR_THREADS);
+	const uint32_t num_groups = (a.z_push.num_volumes + 63u) / 64u;
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "cluster_front"};
+	hipLaunchKernelGGL(k_cluster_front, dim3(a.light_blocks + gr_div_up(a.z_push.num_ranges, ZR_SLICES)), dim3(ZR_THREADS),
+	                   size_t(num_groups) * 65u * sizeof(uint2), gr_to_stream(stream), a);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

@@ -132,6 +132,13 @@ void CommandBuffer::update_buffers(const BufferUpdate *updates, unsigned count)
 		check(gr_upload_batch(get_context(), stream, ranges, n), "update_buffers");
 }
 
+const void *CommandBuffer::stage(const void *data, size_t size)
+{
+	void *staging = device.allocate_staging(size);
+	memcpy(staging, data, size);
+	return staging;
+}
+
 void CommandBuffer::replayable(const char *site, const LaunchKey &key, std::initializer_list<const char *> kernel_names,
                                const std::function<void()> &record)
 {

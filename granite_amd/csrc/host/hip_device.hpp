@@ -100,6 +100,9 @@ public:
 		const void *data;
 	};
 	void update_buffers(const BufferUpdate *updates, unsigned count);
+	// Copies `size` bytes into this frame's slot of the pinned staging ring and returns the device-visible pointer: for a kernel
+	// that consumes CPU-packed data where it lies instead of waiting for an upload launch.
+	const void *stage(const void *data, size_t size);
 	void fill_buffer(const Buffer &dst, size_t offset, size_t size);
 	void copy_image(const Image &dst, const Image &src);
 	void clear_image(const Image &dst);

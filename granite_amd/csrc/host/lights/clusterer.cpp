@@ -1,6 +1,7 @@
 // Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
 // THIRD_PARTY_NOTICES.md at the repository root.
 #include "clusterer.hpp"
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 
@@ -413,20 +414,62 @@ void LightClusterer::update_bindless_range_buffer_gpu(HIP::CommandBuffer &cmd)
 
 void LightClusterer::build_cluster_bindless_gpu(HIP::CommandBuffer &cmd)
 {
-	update_bindless_data(cmd); // reads this frame's slot of the pinned staging ring: launched directly
-	cmd.barrier(VK_PIPELINE_STAGE_2_COPY_BIT, VK_ACCESS_TRANSFER_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
-	// The four build kernels depend on the buffers, the light count and the camera only: under a camera that stands still (or
-	// a jitter sequence that repeats) they are replayed as one pre-recorded sequence; a moving camera launches them directly.
-	auto &rp = context->get_render_parameters();
-	HIP::CommandBuffer::LaunchKey key;
-	key.add(bindless.transforms_buffer->get_device_pointer()).add(bindless.transformed_spots->get_device_pointer());
-	key.add(bindless.cull_data->get_device_pointer()).add(bindless.bitmask_buffer->get_device_pointer());
-	key.add(bindless.light_ranges->get_device_pointer()).add(bindless.range_buffer->get_device_pointer());
-	key.add(packed.parameters).add(uint32_t(packed.volume_index_range.size())).add(resolution_x).add(resolution_y).add(resolution_z);
-	key.add(rp.view_projection).add(rp.view).add(rp.camera_position).add(rp.camera_front).add(rp.z_near).add(rp.z_far);
-	cmd.replayable("clustering-bindless", key, {"cluster_spot_transform", "cluster_setup", "cluster_binning", "cluster_z_range"}, [&]() {
+	uint32_t local_count = uint32_t(packed.parameters.num_lights);
+	static const bool separate = getenv("GRANITE_CLUSTER_SEPARATE_LAUNCHES") != nullptr; // A/B: the reference's dispatch-by-dispatch form
+	if (separate || local_count == 0 || packed.volume_index_range.empty())
+	{
+		update_bindless_data(cmd); // reads this frame's slot of the pinned staging ring: launched directly
+		cmd.barrier(VK_PIPELINE_STAGE_2_COPY_BIT, VK_ACCESS_TRANSFER_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
 		update_bindless_mask_buffer_gpu(cmd);
 		update_bindless_range_buffer_gpu(cmd);
-	});
+		return;
+	}
+	// Two launches instead of the reference's four transfers + four dispatches (clusterer.cpp:1178-1207,1277-1346,1463-1562): the
+	// uploads, spot_transform, setup and z_range depend on this frame's CPU-packed light data only and run as one grid that
+	// reads it from the pinned staging ring (gr_cluster_front); binning, which needs every light's cull data, follows.
+	if ((resolution_z & 63) != 0)
+		throw std::logic_error("Cluster Z resolution must be a multiple of 64.");
+	if ((resolution_x & 7) != 0 || (resolution_y & 7) != 0)
+		throw std::logic_error("Cluster resolution must be a multiple of 8 in X and Y.");
+	auto &rp = context->get_render_parameters();
+	auto &ranges = packed.volume_index_range;
+	gr_push_spot_transform spot_push = {};
+	memcpy(spot_push.vp, rp.view_projection.data(), sizeof(spot_push.vp));
+	for (int i = 0; i < 3; i++)
+	{
+		spot_push.camera_pos[i] = rp.camera_position[i];
+		spot_push.camera_front[i] = rp.camera_front[i];
+	}
+	spot_push.num_lights = local_count;
+	spot_push.z_near = rp.z_near;
+	spot_push.z_far = rp.z_far;
+	gr_push_cluster_setup setup_push = {};
+	memcpy(setup_push.view, rp.view.data(), sizeof(setup_push.view));
+	setup_push.num_lights = local_count;
+	gr_push_z_range z_push = {};
+	z_push.num_volumes = uint32_t(ranges.size());
+	z_push.num_volumes_128 = (z_push.num_volumes + 127) / 128;
+	z_push.num_ranges = resolution_z;
+
+	gr_cluster_front_args front = {};
+	front.transforms = bindless.transforms_buffer->get_device_pointer();
+	front.src_lights = cmd.stage(packed.lights.data(), local_count * sizeof(PositionalFragmentInfo));
+	front.src_models = cmd.stage(packed.model.data(), local_count * sizeof(mat_affine));
+	front.src_type_mask = cmd.stage(packed.type_mask, packed.parameters.num_lights_32 * sizeof(uint32_t));
+	front.transformed_spots = bindless.transformed_spots->get_device_pointer();
+	front.cull_setup = bindless.cull_data->get_device_pointer();
+	front.params = &packed.parameters;
+	front.spot_push = &spot_push;
+	front.setup_push = &setup_push;
+	front.src_ranges = cmd.stage(ranges.data(), ranges.size() * sizeof(uvec2));
+	front.light_ranges = static_cast<uint32_t *>(bindless.light_ranges->get_device_pointer());
+	front.range_out = static_cast<uint32_t *>(bindless.range_buffer->get_device_pointer());
+	front.z_push = &z_push;
+	cmd.check(gr_cluster_front(cmd.get_context(), cmd.get_stream(), &front), "cluster_front");
+	cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
+	            VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
+	cmd.check(gr_cluster_binning(cmd.get_context(), cmd.get_stream(), front.transforms, front.cull_setup,
+	                             static_cast<uint32_t *>(bindless.bitmask_buffer->get_device_pointer()), &packed.parameters),
+	          "cluster_binning");
 }
 } // namespace Granite

@@ -315,6 +315,29 @@ typedef struct gr_push_z_range
 int gr_cluster_z_range(gr_ctx *ctx, gr_stream stream, const uint32_t *light_ranges, uint32_t *out,
                        const gr_push_z_range *push);
 
+/* The front of the cluster build as ONE launch: the four cmd.update_buffer of clusterer.cpp:1178-1207,1302, spot_transform.comp +
+ * setup.comp (clusterer.cpp:1463-1510) and z_range.comp (:1277-1346) all depend on the frame's CPU-packed light data only.
+ * src_* are the packed arrays in pinned host memory (gr_alloc_host) -- the launch copies them into `transforms` / `light_ranges`
+ * as it reads them -- or NULL when the buffers already hold them.  Results are bit-identical to the separate launches above;
+ * only gr_cluster_binning remains to be launched after it. */
+typedef struct gr_cluster_front_args
+{
+	void *transforms;               /* device: GR_TRANSFORMS_SIZE bytes */
+	const void *src_lights;         /* pinned: num_lights gr_light_info, or NULL */
+	const void *src_models;         /* pinned: num_lights gr_mat_affine, or NULL */
+	const void *src_type_mask;      /* pinned: num_lights_32 words, or NULL */
+	void *transformed_spots;        /* device, out */
+	void *cull_setup;               /* device, out */
+	const gr_cluster_params *params;
+	const gr_push_spot_transform *spot_push;
+	const gr_push_cluster_setup *setup_push;
+	const void *src_ranges;         /* pinned: z_push->num_volumes uvec2 slice intervals, or NULL */
+	uint32_t *light_ranges;         /* device copy of the intervals */
+	uint32_t *range_out;            /* device, out: uvec2[num_ranges] */
+	const gr_push_z_range *z_push;
+} gr_cluster_front_args;
+int gr_cluster_front(gr_ctx *ctx, gr_stream stream, const gr_cluster_front_args *args);
+
 /* DeferredLightRenderer::render_light (renderer.cpp:1004-1156): directional quad (directional.frag) then clustered quad
  * (clustering.frag), both additively blended into the RGBA16F HDR target with depth test NOT_EQUAL against z = 0.
  * One fused kernel; the intermediate blend result is rounded to fp16 exactly where the two reference draws round it:

@@ -57,6 +57,51 @@ class Scene:
         gr.sync()
         return {"transforms": transforms, "spots": spots, "setup": setup, "bitmask": bitmask, "range": ranges, "zr": zr}
 
+    def build_clusters_gpu_fused(self, gr, pinned: bool):
+        """The same build as two launches: gr_cluster_front (uploads + spot_transform + setup + z_range) and gr_cluster_binning.
+        pinned: the CPU-packed arrays are read from pinned host memory by the launch itself (what the executor does), else they
+        are uploaded into the transforms buffer first and the launch takes them from there."""
+        lib, h = gr.lib, gr.handle
+        prm = self.cluster_params_struct()
+        transforms = capi.DeviceBuffer(gr, capi.TRANSFORMS_SIZE) if pinned else self.upload_transforms(gr)
+        spots = capi.DeviceBuffer(gr, capi.TRANSFORMED_SPOT_BYTES_PER_LIGHT * 4096)
+        setup = capi.DeviceBuffer(gr, capi.CULL_SETUP_BYTES_PER_LIGHT * 4096)
+        bitmask = capi.DeviceBuffer(gr, self.res[0] * self.res[1] * 512)
+        ranges = capi.DeviceBuffer(gr, self.res[2] * 8)
+        zr = orc.light_z_ranges(self.rp, self.lights, self.model, self.type_mask, self.n, self.res[2])
+        zr_buf = capi.DeviceBuffer(gr, zr.nbytes)
+        push = capi.PushSpotTransform()
+        push.vp[:] = self.rp[32:48]
+        push.camera_pos[:] = self.rp[96:99]
+        push.num_lights = self.n
+        push.camera_front[:] = self.rp[99:102]
+        push.z_near, push.z_far = self.rp[102], self.rp[103]
+        ps = capi.PushClusterSetup()
+        ps.view[:] = self.rp[16:32]
+        ps.num_lights = self.n
+        pz = capi.PushZRange(len(zr), (len(zr) + 127) // 128, self.res[2])
+        a = capi.ClusterFrontArgs()
+        a.transforms, a.transformed_spots, a.cull_setup = transforms.ptr, spots.ptr, setup.ptr
+        a.params, a.spot_push, a.setup_push, a.z_push = C.addressof(prm), C.addressof(push), C.addressof(ps), C.addressof(pz)
+        a.light_ranges, a.range_out = zr_buf.ptr, ranges.ptr
+        host = []
+        if pinned:
+            for field, arr in (("src_lights", self.lights.view(np.uint8)[:self.n * 48]), ("src_models", self.model.view(np.uint8).reshape(-1)[:self.n * 48]),
+                               ("src_type_mask", self.type_mask.view(np.uint8)[:4 * ((self.n + 31) // 32)]), ("src_ranges", zr.view(np.uint8).reshape(-1))):
+                ptr = C.c_void_p()
+                gr.check(lib.gr_alloc_host(h, max(arr.size, 16), C.byref(ptr)))
+                C.memmove(ptr.value, np.ascontiguousarray(arr).ctypes.data, arr.size)
+                setattr(a, field, ptr.value)
+                host.append(ptr)
+        else:
+            zr_buf.upload(zr)
+        gr.check(lib.gr_cluster_front(h, None, a))
+        gr.check(lib.gr_cluster_binning(h, None, transforms.ptr, setup.ptr, bitmask.ptr, prm))
+        gr.sync()
+        for ptr in host:
+            gr.check(lib.gr_free_host(h, ptr))
+        return {"transforms": transforms, "spots": spots, "setup": setup, "bitmask": bitmask, "range": ranges, "zr": zr, "zr_buf": zr_buf}
+
     def lighting_args(self, gr, dev, flags, alias_emissive=True):
         w, h = self.w, self.h
         imgs = {

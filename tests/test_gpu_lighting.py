@@ -31,6 +31,20 @@ def test_cluster_build_bit_exact(gr, num_lights):
     np.testing.assert_array_equal(got_mask, ref["bitmask"])
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("num_lights", [1, 300, 4096])
+def test_cluster_front_as_one_launch_equals_the_separate_launches(gr, num_lights, pinned):
+    """gr_cluster_front (the four uploads + spot_transform + setup + z_range in one grid) + gr_cluster_binning: every buffer
+    bit-identical to the launch-by-launch build, whether the packed light data is read from the transforms buffer or from pinned
+    host memory (and then copied into the buffers by the launch itself)."""
+    sc = Scene(480, 270, num_lights)
+    a, b = sc.build_clusters_gpu(gr), sc.build_clusters_gpu_fused(gr, pinned)
+    for key in ("spots", "setup", "bitmask", "range", "transforms"):
+        np.testing.assert_array_equal(b[key].download(np.uint32), a[key].download(np.uint32), err_msg=key)
+    zr = np.ascontiguousarray(b["zr"]).view(np.uint32).reshape(-1)
+    np.testing.assert_array_equal(b["zr_buf"].download(np.uint32)[:zr.size], zr)  # the intervals reached their buffer either way
+
+
 @pytest.mark.parametrize("w,h,num_lights", [(480, 270, 256), (480, 270, 4096), (333, 77, 700), (1920, 1080, 256)])
 def test_lighting_matches_oracle(gr, w, h, num_lights):
     sc = Scene(w, h, num_lights)

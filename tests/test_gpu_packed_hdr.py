@@ -136,10 +136,10 @@ def test_executor_frames_with_packed_hdr_targets(pre_aa):
     a.set_lights(descs)
     mv = synth.make_motion_vectors(w, h)
     a.upload_gbuffer(dict(gbuf, emissive=orc.pack_b10g11r11(gbuf16["emissive"])), mv if pre_aa else None)
-    assert a.resource("HDR-main").format == B10 and a.resource("emissive-main").format == B10
     state, hist = {}, None
     for frame in range(3):
         a.render_frames(1)
+        assert a.resource("HDR-main").format == B10 and a.resource("emissive-main").format == B10
         rp = a.get_render_parameters()
         count, lights, model, tmask, _ = orc.pack_lights(descs, rp[99:102])
         prm = orc.cluster_params(rp, *synth.CLUSTER_RESOLUTION, count)

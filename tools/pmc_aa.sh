@@ -10,3 +10,5 @@ run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACT
 run sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS
 python "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
 grep -E "taa|fxaa|smaa" "$OUT/summary.txt" | head -40
+# the raw per-dispatch CSVs are tens of MiB per pass: gpurun copies at most 64 MiB back, the summaries are what is kept
+find "$OUT" -name "*counter_collection.csv" -delete; find "$OUT" -name "*kernel_trace.csv" -delete

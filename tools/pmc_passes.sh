@@ -20,3 +20,5 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 python "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
+# the raw per-dispatch CSVs are tens of MiB per pass: gpurun copies at most 64 MiB back, the summaries are what is kept
+find "$OUT" -name "*counter_collection.csv" -delete; find "$OUT" -name "*kernel_trace.csv" -delete
