@@ -61,7 +61,7 @@ EXPORTED_SYMBOLS = [
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
     "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_prefetched_refreshes", "gra_get_launch_graph_replays", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
     "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_upload_aa_bench_images", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan", "gra_get_strip_plan_aa",
-    "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_init_output", "gra_install_ssr_tables", "gra_reset_timestamps", "gra_set_directional_light", "gra_generate_mipmaps",
+    "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_init_output", "gra_install_ssr_tables", "gra_reset_timestamps", "gra_set_directional_light", "gra_set_fog", "gra_generate_mipmaps",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -116,6 +116,7 @@ def load_library() -> C.CDLL:
         "gra_reset_timestamps": (C.c_int, [vp]),
         "gra_generate_mipmaps": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
         "gra_set_directional_light": (C.c_int, [vp, vp, vp]),
+        "gra_set_fog": (C.c_int, [vp, vp, C.c_float]),
         "gra_set_exchange_callback": (C.c_int, [vp, EXCHANGE_FN, vp]),
         "gra_get_strip_plan": (C.c_int, [vp, vp]),
         "gra_get_strip_plan_aa": (C.c_int, [vp, vp]),
@@ -361,6 +362,11 @@ class Application:
     def set_directional(self, direction, color):
         d, c = np.asarray(direction, np.float32), np.asarray(color, np.float32)
         self._check(self.lib.gra_set_directional_light(self.handle, d.ctypes.data, c.ctypes.data))
+
+    def set_fog(self, color, falloff: float):
+        """LightingParameters::fog: render_light's fog quad (renderer.cpp:1179-1196) when falloff > 0."""
+        c = np.ascontiguousarray(color, np.float32)
+        self._check(self.lib.gra_set_fog(self.handle, c.ctypes.data, float(falloff)))
 
     # ---- row-band tiling ---------------------------------------------------------------------------------------------
     def set_exchange_callback(self, fn):

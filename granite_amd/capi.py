@@ -144,7 +144,8 @@ class LightingArgs(C.Structure):
                 ("hdr", Image),
                 ("inv_view_projection", C.c_float * 16), ("directional", PushDirectional), ("clustering", PushClustering),
                 ("cluster", ClusterParams), ("transforms", C.c_void_p), ("bitmask", C.c_void_p), ("range", C.c_void_p),
-                ("flags", C.c_uint32), ("rows", C.c_uint32 * 2), ("ambient_occlusion", Image)]
+                ("flags", C.c_uint32), ("rows", C.c_uint32 * 2), ("ambient_occlusion", Image),
+                ("fog_color", C.c_float * 3), ("fog_falloff", C.c_float)]
 
 
 class Rows(C.Structure):

@@ -147,8 +147,10 @@ static inline unsigned gr_div_up(unsigned a, unsigned b) { return (a + b - 1) / 
 // Resolves a render area (gr_rows) against `height` output rows: [first, end), empty when the band lies outside the image.
 static inline RowSpan resolve_rows(const gr_rows *rows, uint32_t height)
 {
-	if (!rows || rows->count == 0)
+	if (!rows)
 		return {0, height};
+	if (rows->count == 0)
+		return {0, 0}; // an empty band: the launcher returns without launching
 	const uint32_t first = rows->first < height ? rows->first : height;
 	const uint64_t end = uint64_t(rows->first) + rows->count;
 	return {first, end < height ? uint32_t(end) : height};

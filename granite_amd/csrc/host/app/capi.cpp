@@ -607,6 +607,19 @@ int gra_set_directional_light(gra_app *app, const float direction[3], const floa
 	return 0;
 }
 
+int gra_set_fog(gra_app *app, const float color[3], float falloff)
+{
+	if (!app)
+		return -1;
+	if (!color)
+	{
+		app->error = "gra_set_fog: null argument";
+		return -1;
+	}
+	app->app->set_fog(color, falloff);
+	return 0;
+}
+
 int gra_collect_timestamps(gra_app *app, gra_timestamp *entries, int max_entries)
 {
 	if (!app)

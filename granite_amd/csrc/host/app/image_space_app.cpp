@@ -201,6 +201,14 @@ void ImageSpaceApplication::init_collective(const uint8_t *id128, int rank, int 
 	get_device().make_current(); // the communicator binds to the calling thread's current device
 	collective.init(id128, rank, ranks);
 	strip_plan.exchange = [this](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *tag) {
+		// With the output gather on its own communicator and stream (init_output_collective), the kernels of the two communicators
+		// must run in ONE order on every rank, or ranks can wait on each other across communicators (RCCL / NCCL: concurrent
+		// collectives of different communicators on one device are only safe in a consistent order).  The order is made explicit:
+		// an in-frame collective of frame N + 1 runs behind the output gather of frame N (this wait), the output gather of frame
+		// N + 1 behind the band's last pass and with it behind every in-frame collective of that frame (its own event hand-over).
+		if (last_output_gather_event && hipEventQuery(static_cast<hipEvent_t>(last_output_gather_event)) != hipSuccess)
+			if (hipStreamWaitEvent(static_cast<hipStream_t>(cmd.get_stream()), static_cast<hipEvent_t>(last_output_gather_event), 0) != hipSuccess)
+				throw std::runtime_error("hipStreamWaitEvent failed");
 		if (output_packs(image, tag))
 		{
 			pack_output_band(cmd, image, chunk_rows);
@@ -260,6 +268,7 @@ void ImageSpaceApplication::init_output_collective(const uint8_t *id128, int ran
 		}
 		if (hipEventRecord(static_cast<hipEvent_t>(done), gather_stream) != hipSuccess)
 			throw std::runtime_error("hipEventRecord failed");
+		last_output_gather_event = done; // what the next in-frame collective orders itself behind
 	};
 }
 
@@ -805,5 +814,11 @@ void ImageSpaceApplication::set_directional_light(const float direction[3], cons
 {
 	lighting.directional.color = vec3(color[0], color[1], color[2]);
 	lighting.directional.direction = normalize(vec3(direction[0], direction[1], direction[2]));
+}
+
+void ImageSpaceApplication::set_fog(const float color[3], float falloff)
+{
+	lighting.fog.color = vec3(color[0], color[1], color[2]);
+	lighting.fog.falloff = falloff;
 }
 } // namespace Granite

@@ -47,6 +47,7 @@ public:
 	}
 	// DirectionalLightComponent of the scene (read_lights, scene_viewer_application.cpp:58-77); direction need not be normalised.
 	void set_directional_light(const float direction[3], const float color[3]);
+	void set_fog(const float color[3], float falloff);
 	RenderGraph &get_graph() { return graph; }
 	RenderContext &get_context() { return context; }
 	TemporalJitter &get_jitter() { return jitter; }
@@ -98,6 +99,7 @@ private:
 	HIP::Collective collective, output_collective;
 	// per output image: the event its last beside-the-frame gather records on the collective stream
 	std::unordered_map<const void *, void *> output_gather_done;
+	void *last_output_gather_event = nullptr; // hipEvent_t of the newest output gather (one of output_gather_done)
 	// 24-bit transport form of the output bands (one buffer per output image, rank_count * chunk_rows rows of width * 3 bytes)
 	std::unordered_map<const void *, HIP::BufferHandle> packed_output;
 	using BandTransport = std::function<void(void *base, size_t chunk_bytes, void *stream)>;

@@ -424,9 +424,13 @@ void LightClusterer::build_cluster_bindless_gpu(HIP::CommandBuffer &cmd)
 		update_bindless_range_buffer_gpu(cmd);
 		return;
 	}
-	// Two launches instead of the reference's four transfers + four dispatches (clusterer.cpp:1178-1207,1277-1346,1463-1562): the
-	// uploads, spot_transform, setup and z_range depend on this frame's CPU-packed light data only and run as one grid that
-	// reads it from the pinned staging ring (gr_cluster_front); binning, which needs every light's cull data, follows.
+	// Three launches instead of the reference's four transfers + four dispatches (clusterer.cpp:1178-1207,1277-1346,1463-1562): one
+	// upload kernel for the four CPU-packed arrays, then spot_transform, setup and z_range -- which depend on those arrays only --
+	// as one grid (gr_cluster_front), then binning, which needs every light's cull data.  (gr_cluster_front can also read the
+	// arrays from the pinned staging ring itself and save the upload launch; measured, that form is slower: each of its 256
+	// z-range workgroups then fetches the 32 KB of slice intervals across PCIe.)
+	update_bindless_data(cmd);
+	cmd.barrier(VK_PIPELINE_STAGE_2_COPY_BIT, VK_ACCESS_TRANSFER_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
 	if ((resolution_z & 63) != 0)
 		throw std::logic_error("Cluster Z resolution must be a multiple of 64.");
 	if ((resolution_x & 7) != 0 || (resolution_y & 7) != 0)
@@ -453,15 +457,11 @@ void LightClusterer::build_cluster_bindless_gpu(HIP::CommandBuffer &cmd)
 
 	gr_cluster_front_args front = {};
 	front.transforms = bindless.transforms_buffer->get_device_pointer();
-	front.src_lights = cmd.stage(packed.lights.data(), local_count * sizeof(PositionalFragmentInfo));
-	front.src_models = cmd.stage(packed.model.data(), local_count * sizeof(mat_affine));
-	front.src_type_mask = cmd.stage(packed.type_mask, packed.parameters.num_lights_32 * sizeof(uint32_t));
 	front.transformed_spots = bindless.transformed_spots->get_device_pointer();
 	front.cull_setup = bindless.cull_data->get_device_pointer();
 	front.params = &packed.parameters;
 	front.spot_push = &spot_push;
 	front.setup_push = &setup_push;
-	front.src_ranges = cmd.stage(ranges.data(), ranges.size() * sizeof(uvec2));
 	front.light_ranges = static_cast<uint32_t *>(bindless.light_ranges->get_device_pointer());
 	front.range_out = static_cast<uint32_t *>(bindless.range_buffer->get_device_pointer());
 	front.z_push = &z_push;

@@ -81,6 +81,14 @@ void DeferredLightRenderer::render_light(HIP::CommandBuffer &cmd, const RenderCo
 		args.clustering.inv_resolution[1] = inv_h;
 	}
 
+	// renderer.cpp:1179-1196: the fog quad when light.fog.falloff > 0 (volumetric fog is outside the path)
+	if (light && light->fog.falloff > 0.0f)
+	{
+		for (int i = 0; i < 3; i++)
+			args.fog_color[i] = light->fog.color[i];
+		args.fog_falloff = light->fog.falloff;
+	}
+
 	if (att.rows && !att.rows->whole)
 	{
 		if (att.rows->count == 0)

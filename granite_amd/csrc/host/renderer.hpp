@@ -25,7 +25,7 @@ class DeferredLightRenderer
 {
 public:
 	using RendererOptionFlags = uint32_t;
-	// renderer.cpp:1004-1197: directional quad, clustered quad (fog quads are not part of the synthetic chain).
+	// renderer.cpp:1004-1197: directional quad, clustered quad, and the fog quad when LightingParameters::fog.falloff > 0 (the volumetric-fog quad is outside the path).
 	static void render_light(HIP::CommandBuffer &cmd, const RenderContext &context, const DeferredLightAttachments &attachments,
 	                         RendererOptionFlags flags = 0);
 };

@@ -29,7 +29,7 @@ struct RowRange
 // RowRange -> the C ABI's render area.  Returns false when the band is empty (nothing to launch on this rank).
 inline bool to_rows(const RowRange *range, gr_rows &rows)
 {
-	rows = {0, 0};
+	rows = {0, 0xffffffffu}; // the whole image (a launcher clamps the end to the image height; count == 0 would be "no rows")
 	if (!range || range->whole)
 		return true;
 	if (range->count == 0)

@@ -84,6 +84,7 @@ struct KernelArgs
 	const uint2 *__restrict__ range;
 	const float *__restrict__ srgb_lut;
 	uint32_t flags;
+	float fog_color[3], fog_falloff; // the fog quad behind the clustered one (renderer.cpp:1179-1196); falloff <= 0: none
 	int blocks_x, num_blocks, blocks_per_xcd;
 	int row_first, row_end, block_row0; // render area rows [row_first, row_end); first block row = row_first / 8
 };
@@ -630,6 +631,25 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 			o[p].z = out_h[p].z;
 		}
 	}
+	// ---- fog quad (fog.frag:17-25, fog.h:4-8): a third blend, src * (1 - src.a) + dst * src.a on colour and alpha, onto what the
+	// second blend stored (its rounded value), rounded by the store once more.  Uniform branch: no fog, no instruction. ----
+	if (a.fog_falloff > 0.0f)
+	{
+#pragma unroll
+		for (int p = 0; p < PX; p++)
+			if (active[p])
+			{
+				const float3_ eye = s[p].pos - f3(a.camera_pos[0], a.camera_pos[1], a.camera_pos[2]);
+				const float f = __builtin_amdgcn_exp2f(-dot(eye, eye) * a.fog_falloff), omf = 1.0f - f;
+				const float3_ lit = B10 ? f3(round_to_ufloat<6>(out_f[p].x), round_to_ufloat<6>(out_f[p].y), round_to_ufloat<5>(out_f[p].z))
+				                        : f3(float(o[p].x), float(o[p].y), float(o[p].z));
+				out_f[p] = f3(fmaf(lit.x, f, a.fog_color[0] * omf), fmaf(lit.y, f, a.fog_color[1] * omf), fmaf(lit.z, f, a.fog_color[2] * omf));
+				o[p].x = _Float16(out_f[p].x);
+				o[p].y = _Float16(out_f[p].y);
+				o[p].z = _Float16(out_f[p].z);
+				o[p].w = _Float16(fmaf(float(dst[p].w), f, f * omf));
+			}
+	}
 	// In place (emissive == hdr) untouched pixels need no store; a pair with one lit pixel rewrites the other's own value.
 	if constexpr (B10)
 	{
@@ -741,6 +761,9 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	}
 	k.srgb_lut = ctx->srgb_decode_lut;
 	k.flags = args->flags;
+	for (int i = 0; i < 3; i++)
+		k.fog_color[i] = args->fog_color[i];
+	k.fog_falloff = args->fog_falloff > 0.0f ? args->fog_falloff : 0.0f;
 
 	// Render area: tiles stay aligned to multiples of 8 rows of the full target, rows outside the band are masked.
 	uint32_t row_first = 0, row_end = H;

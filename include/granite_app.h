@@ -211,6 +211,9 @@ int gra_reset_timestamps(gra_app *app);
 /* The scene's DirectionalLightComponent (read_lights, scene_viewer_application.cpp:58-77): replaces the values of
  * gra_config for the frames that follow; direction is normalised here. */
 int gra_set_directional_light(gra_app *app, const float direction[3], const float color[3]);
+/* LightingParameters::fog (renderer/lights/lights.hpp; the scene's "fog" entry in Granite): with falloff > 0 render_light ends with
+ * the fog quad (renderer.cpp:1179-1196).  falloff = 0 switches it off again. */
+int gra_set_fog(gra_app *app, const float color[3], float falloff);
 /* T(.5,.5,0) S(.5,.5,1) VP_prev inv(VP_cur) as pushed to the last taa-resolve (temporal.cpp:239-243). */
 int gra_get_taa_reprojection(gra_app *app, float *reproj16);
 /* SMAA AreaTex (160x560 RG8) / SearchTex (64x16 R8) payloads, host pointers; needed before a frame with an SMAA pass. */

@@ -127,7 +127,9 @@ int gr_timing_set_sampling(gr_ctx *ctx, uint32_t every_nth);
 int gr_timing_reset(gr_ctx *ctx);
 int gr_timing_query(gr_ctx *ctx, gr_timing_entry *entries, int max_entries); /* returns number of entries; syncs */
 
-/* Render area of one launch: output rows [first, first + count) only; count == 0 (or a NULL pointer) = the whole image.
+/* Render area of one launch: output rows [first, first + count) only.  A NULL pointer = the whole image; count == 0 = no rows
+ * (the launcher returns GR_OK without launching: a rank whose band is empty must not touch the image).  The one embedded use,
+ * gr_lighting_args.rows, keeps {0, 0} = whole image, as a zero-initialised argument struct has it.
  * The reference restricts draws with VkRect2D render areas / scissors (vulkan/command_buffer.cpp set_scissor); the
  * executor uses row bands to tile one frame across GPUs.  Coordinates stay those of the full image, so a
  * band computes bit-identical values to the same rows of a whole-image launch. */
@@ -393,6 +395,11 @@ typedef struct gr_lighting_args
 	gr_rows rows;                  /* render area; {0, 0} = whole target */
 	gr_image ambient_occlusion;    /* R8_UNORM, any size, sampled LinearClamp at the pixel centre (LightingParameters::
 	                                  ambient_occlusion, renderer.cpp:611-612); read only with the AMBIENT_OCCLUSION bit */
+	/* The fog quad render_light draws last when LightingParameters::fog.falloff > 0 (renderer.cpp:1179-1196, lights/fog.{vert,frag},
+	 * fog.h): src = (fog_color, exp2(-|world_pos - camera_pos|^2 * falloff)) blended ONE_MINUS_SRC_ALPHA / SRC_ALPHA into the target
+	 * (colour and alpha), under the lighting quads' depth test.  falloff <= 0 = no fog (a zeroed struct). */
+	float fog_color[3];
+	float fog_falloff;
 } gr_lighting_args;
 int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args);
 

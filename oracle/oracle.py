@@ -48,7 +48,7 @@ class LightingArgs(C.Structure):
                 ("range", C.c_void_p), ("dir_color", C.c_float * 3), ("dir_direction", C.c_float * 3),
                 ("enable_directional", C.c_int32), ("enable_clustered", C.c_int32), ("ambient_fallback", C.c_int32),
                 ("wave_tile", C.c_int32), ("ambient_occlusion", C.c_void_p), ("ao_width", C.c_int32), ("ao_height", C.c_int32),
-                ("hdr_b10g11r11", C.c_int32)]
+                ("hdr_b10g11r11", C.c_int32), ("fog_color", C.c_float * 3), ("fog_falloff", C.c_float)]
 
 
 def build(force: bool = False) -> str:
@@ -256,7 +256,7 @@ def quantize_b10g11r11(rgba16f: np.ndarray) -> np.ndarray:
 
 def lighting(gbuf: dict, rp, prm, lights, type_mask, bitmask, ranges, dir_color, dir_direction, directional=True,
              clustered=True, ambient_fallback=True, wave_tile=0, bruteforce=False, ambient_occlusion=None, entry=None,
-             b10g11r11=False) -> np.ndarray:
+             b10g11r11=False, fog=None) -> np.ndarray:
     """Returns the HDR target (RGBA16F bits) after DeferredLightRenderer::render_light on gbuf['emissive'].
     entry: another implementation taking the same OrcLightingArgs (oracle/_ref's ref_lighting: the reference's own shaders).
     b10g11r11: the target is a B10G11R11_UFLOAT_PACK32 attachment (renderTargetFp16 = false): gbuf['emissive'] must hold packed-
@@ -277,6 +277,9 @@ def lighting(gbuf: dict, rp, prm, lights, type_mask, bitmask, ranges, dir_color,
     a.enable_directional, a.enable_clustered = int(directional), int(clustered)
     a.ambient_fallback, a.wave_tile = int(ambient_fallback), int(wave_tile)
     a.hdr_b10g11r11 = int(b10g11r11)
+    if fog is not None:  # ((r, g, b), falloff): the fog quad of render_light behind the clustered quad (renderer.cpp:1179-1196)
+        a.fog_color = (C.c_float * 3)(*[float(v) for v in fog[0]])
+        a.fog_falloff = float(fog[1])
     if ambient_occlusion is not None:  # AMBIENT_OCCLUSION variant: R8_UNORM image of any size
         ao = np.ascontiguousarray(ambient_occlusion, np.uint8)
         keep.append(ao)

@@ -802,6 +802,10 @@ struct OrcLightingArgs
 	// 1: the target is a B10G11R11_UFLOAT_PACK32 attachment (renderTargetFp16 = false, scene_viewer_application.cpp:881-883).
 	// `hdr` still holds RGBA16F texels -- every packed value is exactly a half float -- but each blend rounds to the packed format.
 	int32_t hdr_b10g11r11;
+	// The fog quad behind the clustered one (renderer.cpp:1179-1196, lights/fog.{vert,frag}, fog.h), when fog_falloff > 0:
+	// src = (fog_color, exp2(-|pos - camera|^2 falloff)) blended ONE_MINUS_SRC_ALPHA / SRC_ALPHA, under the same depth test.
+	float fog_color[3];
+	float fog_falloff;
 };
 
 static inline void store_hdr(const OrcLightingArgs *a, int x, int y, vec4 v)
@@ -971,6 +975,26 @@ void orc_lighting(const OrcLightingArgs *a)
 						continue;
 					vec4 dst = load_rgba16f(a->hdr, W, x, y);
 					store_hdr(a, x, y, V4(dst.x + acc[li].x, dst.y + acc[li].y, dst.z + acc[li].z, dst.w));
+				}
+		}
+
+		// Fog quad (fog.frag:17-25, fog.h:4-8): FragColor = (color, fog_factor); the blend unit computes, per channel and for alpha,
+		// src * (1 - src.a) + dst * src.a and the attachment store rounds once more.
+		if (a->fog_falloff > 0.0f)
+		{
+			const vec3 fog = ld3(a->fog_color);
+			for (int y = y0; y < y1; y++)
+				for (int x = x0; x < x1; x++)
+				{
+					int li = (y - y0) * tile + (x - x0);
+					if (!act[li])
+						continue;
+					const vec3 eye_vec = poss[li] - camera_pos;
+					const float distance = dot(eye_vec, eye_vec);
+					const float f = exp2f(-distance * a->fog_falloff);
+					const vec4 dst = load_rgba16f(a->hdr, W, x, y);
+					store_hdr(a, x, y, V4(fog.x * (1.0f - f) + dst.x * f, fog.y * (1.0f - f) + dst.y * f, fog.z * (1.0f - f) + dst.z * f,
+					                      f * (1.0f - f) + dst.w * f));
 				}
 		}
 	}

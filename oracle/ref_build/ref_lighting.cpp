@@ -20,6 +20,10 @@ namespace clustering
 {
 #include "gen/clustering.inc"
 }
+namespace fog_quad
+{
+#include "gen/fog.inc"
+}
 namespace directional_plain
 {
 #include "gen/directional.inc"
@@ -88,6 +92,8 @@ struct LightingArgs
 	const uint8_t *ambient_occlusion;
 	int32_t ao_width, ao_height;
 	int32_t hdr_b10g11r11; // the target is a B10G11R11_UFLOAT_PACK32 attachment, held as its exact RGBA16F texels
+	float fog_color[3];    // the fog quad of render_light (renderer.cpp:1179-1196), drawn when fog_falloff > 0
+	float fog_falloff;
 };
 
 Texture make(const void *data, int w, int h, Format f, Filter filter = Filter::Nearest)
@@ -128,6 +134,28 @@ void blend_one_one(const LightingArgs *a, int x, int y, const vec3 &src)
 		return;
 	}
 	p[0] = orc::float_to_half_rne(r), p[1] = orc::float_to_half_rne(g), p[2] = orc::float_to_half_rne(b);
+}
+
+// ONE_MINUS_SRC_ALPHA / SRC_ALPHA on colour and alpha (cmd.set_blend_factors sets both): src * (1 - src.a) + dst * src.a, converted
+// by the attachment's store.
+void blend_fog(const LightingArgs *a, int x, int y, const vec4 &src)
+{
+	uint16_t *p = a->hdr + (size_t(y) * a->width + x) * 4;
+	float out[4];
+	for (int c = 0; c < 4; c++)
+		out[c] = src.d[c] * (1.0f - src.d[3]) + orc::half_to_float(p[c]) * src.d[3];
+	Image target;
+	if (a->hdr_b10g11r11)
+	{
+		uint32_t word = 0;
+		target.data = &word, target.w = 1, target.h = 1, target.format = Format::B10G11R11_UFLOAT;
+		imageStore(target, ivec2(0, 0), vec4(out[0], out[1], out[2], out[3]));
+		const orc::vec4 q = orc::unpack_b10g11r11(word);
+		p[0] = orc::float_to_half_rne(q.x), p[1] = orc::float_to_half_rne(q.y), p[2] = orc::float_to_half_rne(q.z), p[3] = 0x3c00u;
+		return;
+	}
+	target.data = p, target.w = 1, target.h = 1, target.format = Format::RGBA16F;
+	imageStore(target, ivec2(0, 0), vec4(out[0], out[1], out[2], out[3]));
 }
 
 template <typename Setup>
@@ -233,6 +261,26 @@ extern "C" void ref_lighting(const LightingArgs *a)
 				s::vClip = clip_at(x, y);
 				s::main();
 				blend_one_one(a, x, y, s::FragColor);
+			}
+	}
+
+	if (a->fog_falloff > 0.0f)
+	{
+		namespace s = fog_quad;
+		s::Depth = make(a->depth, W, H, Format::R32F);
+		s::registers.inverse_view_projection = inv_vp;
+		s::registers.camera_pos = ld3(a->rp->camera_position);
+		s::registers.color = ld3(a->fog_color);
+		s::registers.falloff = a->fog_falloff;
+		for (int y = 0; y < H; y++)
+			for (int x = 0; x < W; x++)
+			{
+				if (a->depth[size_t(y) * W + x] == 0.0f)
+					continue; // the depth state of the lighting quads (NOT_EQUAL against z = 0) is still bound
+				gl_FragCoord = vec4(float(x) + 0.5f, float(y) + 0.5f, 0.0f, 1.0f);
+				s::vClip = clip_at(x, y); // fog.vert: inverse_view_projection * (Position, 0, 1), interpolated = evaluated at the centre
+				s::main();
+				blend_fog(a, x, y, s::FragColor);
 			}
 	}
 }

@@ -210,3 +210,41 @@ def test_lights_smaller_than_the_distance_clamp(gr):
     for yy, xx in zip(ys, xs):
         near[yy - 2:yy + 3, xx - 2:xx + 3] = True
     assert (lit & near).sum() > 200
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_fog_quad_behind_the_clustered_quad(gr, packed):
+    """render_light's fog quad (renderer.cpp:1179-1196, fog.frag): the third blend fused behind the lighting store, into an
+    RGBA16F target (colour + alpha) and into a B10G11R11 one; sky pixels untouched; falloff 0 = no fog."""
+    w, h = 256, 144
+    sc = Scene(w, h, 300)
+    if packed:
+        sc.gbuf["emissive"] = orc.quantize_b10g11r11(sc.gbuf["emissive"])
+    ref_c = orc.cluster_build(sc.rp, sc.prm, sc.lights, sc.model, sc.type_mask, sc.n, sc.res[2])
+    dev = sc.build_clusters_gpu(gr)
+    fog = ((0.35, 0.4, 0.55), 0.012)
+    want = orc.lighting(sc.gbuf, sc.rp, sc.prm, sc.lights, sc.type_mask, ref_c["bitmask"], ref_c["range"], synth.DIRECTIONAL_COLOR,
+                        synth.DIRECTIONAL_DIRECTION, b10g11r11=packed, fog=fog)
+    args, imgs = sc.lighting_args(gr, dev, ALL)
+    if packed:
+        target = capi.DeviceImage(gr, w, h, capi.FORMAT_B10G11R11_UFLOAT_PACK32).upload(orc.pack_b10g11r11(sc.gbuf["emissive"]))
+        args.hdr = target.desc
+        args.emissive = target.desc
+    else:
+        target = imgs["hdr"]
+    args.fog_color[:] = fog[0]
+    args.fog_falloff = fog[1]
+    gr.check(gr.lib.gr_lighting(gr.handle, None, args))
+    gr.sync()
+    got = target.download()
+    if packed:
+        want_words = orc.pack_b10g11r11(want)
+        for shift, bits in ((0, 11), (11, 11), (22, 10)):
+            a, b = (got >> shift) & ((1 << bits) - 1), (want_words >> shift) & ((1 << bits) - 1)
+            assert np.abs(a.astype(np.int64) - b.astype(np.int64)).max() <= 1
+        assert (got == want_words).mean() > 0.995
+    else:
+        assert_rgba16f_close(got, want, ulps=2.0, what="fogged HDR")
+        sky = sc.gbuf["depth"] == 0.0
+        np.testing.assert_array_equal(got[sky], sc.gbuf["emissive"][sky])
+        assert (got[~sky][:, 3] != sc.gbuf["emissive"][~sky][:, 3]).mean() > 0.9  # the blend factors apply to alpha as well

@@ -500,3 +500,31 @@ def test_taa_resolve_into_a_b10g11r11_colour_target_reference_shader(ref, qualit
         np.testing.assert_array_equal(got_h, want_h)
         assert np.array_equal(orc.quantize_b10g11r11(want_c), want_c)
         history = want_h
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_fog_quad_behind_the_lighting_quads_reference_shader(ref, packed):
+    """render_light's last quad (renderer.cpp:1179-1196): lights/fog.{vert,frag} + fog.h executed and blended ONE_MINUS_SRC_ALPHA /
+    SRC_ALPHA (colour and alpha) == the oracle, bit for bit, into an RGBA16F and into a B10G11R11 target; sky pixels untouched."""
+    w, h, n = 64, 36, 96
+    cam = synth.Camera(w, h)
+    gbuf = synth.make_gbuffer(cam, seed=5)
+    if packed:
+        gbuf["emissive"] = orc.quantize_b10g11r11(gbuf["emissive"])
+    rp = cam.render_params()
+    count, lights, model, tmask, _ = orc.pack_lights(synth.make_lights(cam, n, seed=5), rp[99:102])
+    prm = orc.cluster_params(rp, *synth.CLUSTER_RESOLUTION, count)
+    cb = orc.cluster_build(rp, prm, lights, model, tmask, count, synth.CLUSTER_RESOLUTION[2])
+    args = (gbuf, rp, prm, lights, tmask, cb["bitmask"], cb["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
+    fog = ((0.35, 0.4, 0.55), 0.012)
+    want = orc.lighting(*args, b10g11r11=packed, fog=fog)
+    got = orc.lighting(*args, b10g11r11=packed, fog=fog, entry=ref.ref_lighting)
+    np.testing.assert_array_equal(got, want)
+    plain = orc.lighting(*args, b10g11r11=packed)
+    lit = gbuf["depth"] != 0.0
+    assert (want[lit] != plain[lit]).any(axis=-1).mean() > 0.9
+    np.testing.assert_array_equal(want[~lit], plain[~lit])
+    # known answer: f = exp2(-|pos - eye|^2 falloff) pulls a lit pixel towards the fog colour
+    f32 = orc.half_to_float
+    towards = np.abs(f32(want)[lit][:, :3] - np.array(fog[0], np.float32)) <= np.abs(f32(plain)[lit][:, :3] - np.array(fog[0], np.float32)) + 2e-3
+    assert towards.mean() > 0.99

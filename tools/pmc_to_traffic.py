@@ -7,7 +7,8 @@ import hashlib, json, os, sys
 
 summary, out, rnd = sys.argv[1], sys.argv[2], int(sys.argv[3])
 table = json.load(open(summary))
-want = {"lighting": "k_lighting<2, false>", "tonemap": "k_tonemap<true, true, true>", "bloom_threshold": "k_bloom_threshold_2to1<true>"}
+# kernel names as tools/pmc_summary.py shortens them; the first dispatched instantiation whose name starts with the prefix
+want = {"lighting": "k_lighting<2, false", "tonemap": "k_tonemap<true, true, true>", "bloom_threshold": "k_bloom_threshold_2to1<true>"}
 correction = ("FETCH_SIZE doubled (gfx950 rocprofv3 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section); "
               "WRITE_SIZE as reported")
 classes = {"fma_f32": "SQ_INSTS_VALU_FMA_F32", "mul_f32": "SQ_INSTS_VALU_MUL_F32", "add_f32": "SQ_INSTS_VALU_ADD_F32",
@@ -19,9 +20,10 @@ def sha256(path):
     return hashlib.sha256(open(os.path.join(ROOT, path), "rb").read()).hexdigest()
 kernels = {}
 for key, name in want.items():
-    vals = table.get(name)
-    if not vals:
+    matches = sorted(k for k in table if k.startswith(name))
+    if not matches:
         continue
+    name, vals = matches[0], table[matches[0]]
     entry = {"kernel": name, "source_file": sources[key], "source_sha256": sha256(sources[key]), "FETCH_SIZE_KB": vals.get("FETCH_SIZE"), "WRITE_SIZE_KB": vals.get("WRITE_SIZE"), "correction": correction}
     if vals.get("FETCH_SIZE") is not None and vals.get("WRITE_SIZE") is not None:
         entry["hbm_bytes_per_launch"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
