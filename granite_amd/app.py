@@ -45,6 +45,13 @@ def install_ssr_tables():
         raise capi.GraniteHipError("gra_install_ssr_tables failed")
 
 
+class FrameState(C.Structure):
+    """gra_frame_state: the host-side state a frame inherits (checkpoint / replay)."""
+    _fields_ = [("frames", C.c_uint64), ("elapsed", C.c_double), ("swapchain_index", C.c_uint32), ("jitter_phase", C.c_uint32),
+                ("base_view", C.c_float * 16), ("jittered_projection", C.c_float * 16), ("view_proj", (C.c_float * 16) * 16),
+                ("inv_view_proj", (C.c_float * 16) * 16), ("jittered_view_proj", (C.c_float * 16) * 16)]
+
+
 class ResourceInfo(C.Structure):
     _fields_ = [("device_ptr", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32),
                 ("size_bytes", C.c_uint64), ("physical_index", C.c_int32), ("levels", C.c_uint32)]
@@ -61,7 +68,7 @@ EXPORTED_SYMBOLS = [
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
     "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_prefetched_refreshes", "gra_get_launch_graph_replays", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
     "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_upload_aa_bench_images", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan", "gra_get_strip_plan_aa",
-    "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_init_output", "gra_install_ssr_tables", "gra_reset_timestamps", "gra_set_directional_light", "gra_set_fog", "gra_generate_mipmaps",
+    "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_init_output", "gra_install_ssr_tables", "gra_reset_timestamps", "gra_set_directional_light", "gra_set_fog", "gra_generate_mipmaps", "gra_write_resource", "gra_get_frame_state", "gra_set_frame_state",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -117,6 +124,9 @@ def load_library() -> C.CDLL:
         "gra_generate_mipmaps": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
         "gra_set_directional_light": (C.c_int, [vp, vp, vp]),
         "gra_set_fog": (C.c_int, [vp, vp, C.c_float]),
+        "gra_write_resource": (C.c_int, [vp, C.c_char_p, vp, C.c_uint64]),
+        "gra_get_frame_state": (C.c_int, [vp, P(FrameState)]),
+        "gra_set_frame_state": (C.c_int, [vp, P(FrameState)]),
         "gra_set_exchange_callback": (C.c_int, [vp, EXCHANGE_FN, vp]),
         "gra_get_strip_plan": (C.c_int, [vp, vp]),
         "gra_get_strip_plan_aa": (C.c_int, [vp, vp]),
@@ -290,6 +300,19 @@ class Application:
         if info.levels > 1:
             return raw
         return self._shape(info, raw) if info.width else raw
+
+    def write(self, name: str, data: np.ndarray):
+        """The write-side twin of read(): what a later frame reads as the previous frame's value of `name`."""
+        a = np.ascontiguousarray(data)
+        self._check(self.lib.gra_write_resource(self.handle, name.encode(), a.ctypes.data, a.nbytes))
+
+    def frame_state(self) -> "FrameState":
+        st = FrameState()
+        self._check(self.lib.gra_get_frame_state(self.handle, st))
+        return st
+
+    def set_frame_state(self, st: "FrameState"):
+        self._check(self.lib.gra_set_frame_state(self.handle, st))
 
     def read_mip_chain(self, name: str):
         """Levels of a mip-chain attachment (R32_SFLOAT), finest first."""

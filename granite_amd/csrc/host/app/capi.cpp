@@ -441,6 +441,41 @@ int gra_read_resource(gra_app *app, const char *name, void *dst_host, uint64_t s
 	});
 }
 
+int gra_write_resource(gra_app *app, const char *name, const void *src_host, uint64_t size_bytes)
+{
+	return guarded(app, [&]() {
+		if (!src_host)
+			throw std::logic_error("gra_write_resource: null source");
+		app->app->prepare_resources_for_write();
+		gra_resource_info info;
+		lookup_resource(app, name, &info);
+		if (size_bytes != info.size_bytes)
+			throw std::logic_error("gra_write_resource: the size must be the resource's (" + std::to_string(info.size_bytes) + " bytes)");
+		app->app->wait_idle();
+		auto *ctx = app->app->get_device().get_context();
+		if (gr_upload(ctx, nullptr, info.device_ptr, src_host, size_bytes) < 0 || gr_sync(ctx, nullptr) < 0)
+			throw std::runtime_error(gr_last_error(ctx));
+	});
+}
+
+int gra_get_frame_state(gra_app *app, gra_frame_state *state)
+{
+	return guarded(app, [&]() {
+		if (!state)
+			throw std::logic_error("gra_get_frame_state: null argument");
+		app->app->get_frame_state(*state);
+	});
+}
+
+int gra_set_frame_state(gra_app *app, const gra_frame_state *state)
+{
+	return guarded(app, [&]() {
+		if (!state)
+			throw std::logic_error("gra_set_frame_state: null argument");
+		app->app->set_frame_state(*state);
+	});
+}
+
 int gra_save_resource_gtx(gra_app *app, const char *name, const char *path)
 {
 	return guarded(app, [&]() {

@@ -821,4 +821,58 @@ void ImageSpaceApplication::set_fog(const float color[3], float falloff)
 	lighting.fog.color = vec3(color[0], color[1], color[2]);
 	lighting.fog.falloff = falloff;
 }
+
+// A fresh application has no physical resources before its first frame: bake and allocate them now, so that inherited state can be
+// written.  The extra setup_attachments() only rotates empty slots; the first frame's own swap then turns what was written into
+// an image with a history copy into that frame's history.
+void ImageSpaceApplication::prepare_resources_for_write()
+{
+	if (need_bake)
+		bake_render_graph();
+	if (host_frames == 0 && !resources_prepared)
+	{
+		graph.setup_attachments(get_device(), swapchain[swapchain_index].get());
+		resources_prepared = true;
+	}
+}
+
+void ImageSpaceApplication::get_frame_state(gra_frame_state &state) const
+{
+	state = {};
+	state.frames = host_frames;
+	state.elapsed = elapsed;
+	state.swapchain_index = swapchain_index;
+	memcpy(state.base_view, base_view.data(), sizeof(state.base_view));
+	const TemporalJitter::State j = jitter.get_state();
+	state.jitter_phase = j.phase;
+	memcpy(state.jittered_projection, j.jittered_projection.data(), sizeof(state.jittered_projection));
+	for (size_t i = 0; i < j.view_proj.size() && i < 16; i++)
+	{
+		memcpy(state.view_proj[i], j.view_proj[i].data(), 64);
+		memcpy(state.inv_view_proj[i], j.inv_view_proj[i].data(), 64);
+		memcpy(state.jittered_view_proj[i], j.jittered_view_proj[i].data(), 64);
+	}
+}
+
+void ImageSpaceApplication::set_frame_state(const gra_frame_state &state)
+{
+	if (state.swapchain_index >= swapchain.size())
+		throw std::logic_error("gra_set_frame_state: swapchain index out of range");
+	elapsed = state.elapsed;
+	swapchain_index = state.swapchain_index;
+	memcpy(base_view.data(), state.base_view, sizeof(state.base_view));
+	TemporalJitter::State j = jitter.get_state();
+	j.phase = state.jitter_phase;
+	memcpy(j.jittered_projection.data(), state.jittered_projection, sizeof(state.jittered_projection));
+	for (size_t i = 0; i < j.view_proj.size() && i < 16; i++)
+	{
+		memcpy(j.view_proj[i].data(), state.view_proj[i], 64);
+		memcpy(j.inv_view_proj[i].data(), state.inv_view_proj[i], 64);
+		memcpy(j.jittered_view_proj[i].data(), state.jittered_view_proj[i], 64);
+	}
+	jitter.set_state(j);
+	if (has_base_camera)
+		context.set_camera(jitter.get_jitter_type() != TemporalJitter::Type::None ? jitter.get_jittered_projection() : base_projection, base_view);
+	cluster.invalidate_prefetch();
+}
 } // namespace Granite

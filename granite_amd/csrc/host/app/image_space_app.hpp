@@ -48,6 +48,10 @@ public:
 	// DirectionalLightComponent of the scene (read_lights, scene_viewer_application.cpp:58-77); direction need not be normalised.
 	void set_directional_light(const float direction[3], const float color[3]);
 	void set_fog(const float color[3], float falloff);
+	// checkpoint / replay (include/granite_app.h: gra_write_resource, gra_frame_state)
+	void prepare_resources_for_write();
+	void get_frame_state(gra_frame_state &state) const;
+	void set_frame_state(const gra_frame_state &state);
 	RenderGraph &get_graph() { return graph; }
 	RenderContext &get_context() { return context; }
 	TemporalJitter &get_jitter() { return jitter; }
@@ -133,6 +137,7 @@ private:
 	unsigned swapchain_index = 0;
 	HIP::Image *last_backbuffer = nullptr;
 	bool need_bake = true;
+	bool resources_prepared = false; // prepare_resources_for_write() ran before the first frame
 	double elapsed = 0.0;
 	uint64_t host_frames = 0;
 	double host_seconds = 0.0;

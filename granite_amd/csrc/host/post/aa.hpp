@@ -47,6 +47,24 @@ public:
 	const mat4 &get_history_inv_view_proj(int frames) const { return saved_inv_view_proj[get_offset_phase(frames)]; }
 	const mat4 &get_history_jittered_view_proj(int frames) const { return saved_jittered_view_proj[get_offset_phase(frames)]; }
 	unsigned get_jitter_phase() const { return phase; }
+	// checkpoint / replay: the phase and the saved matrices of the last jitter_count frames
+	struct State
+	{
+		unsigned phase = 0;
+		std::vector<mat4> jittered_view_proj, view_proj, inv_view_proj;
+		mat4 jittered_projection;
+	};
+	State get_state() const { return {phase, saved_jittered_view_proj, saved_view_proj, saved_inv_view_proj, saved_jittered_projection}; }
+	void set_state(const State &s)
+	{
+		if (s.view_proj.size() != saved_view_proj.size())
+			throw std::logic_error("TemporalJitter::set_state: jitter sequence length differs");
+		phase = s.phase;
+		saved_jittered_view_proj = s.jittered_view_proj;
+		saved_view_proj = s.view_proj;
+		saved_inv_view_proj = s.inv_view_proj;
+		saved_jittered_projection = s.jittered_projection;
+	}
 	unsigned get_jitter_count() const { return jitter_count; }
 	Type get_jitter_type() const { return type; }
 

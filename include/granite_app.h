@@ -178,6 +178,27 @@ typedef struct gra_resource_info
 } gra_resource_info;
 int gra_get_resource(gra_app *app, const char *name, gra_resource_info *info);
 int gra_read_resource(gra_app *app, const char *name, void *dst_host, uint64_t size_bytes);
+/* The write-side twin of gra_read_resource: replaces the contents of a graph resource with `size_bytes` of host data (the whole
+ * resource).  Meant for the state a frame inherits from the one before it -- "average-luminance" (exposure adaptation),
+ * "downsample-3" (bloom feedback), "<output>-history" of a TAA resolve: what gra_read_resource returned after frame N, written into
+ * a fresh application before its first frame (or into a running one), is what frame N + 1 reads as "previous" (persistent
+ * buffers in place; an image with a history copy becomes the history at the next frame's swap, render_graph.cpp:2704-2708).
+ * Together with gra_get / set_frame_state a run can be resumed bit for bit (checkpoint / replay). */
+int gra_write_resource(gra_app *app, const char *name, const void *src_host, uint64_t size_bytes);
+/* Host-side state a frame inherits: elapsed time, swapchain ring position, the (moving) camera's view matrix and the temporal
+ * jitter's phase with its saved view-projection ring (temporal.cpp:40-196). */
+typedef struct gra_frame_state
+{
+	uint64_t frames;
+	double elapsed;
+	uint32_t swapchain_index;
+	uint32_t jitter_phase;
+	float base_view[16];
+	float jittered_projection[16];
+	float view_proj[16][16], inv_view_proj[16][16], jittered_view_proj[16][16]; /* first jitter_count entries */
+} gra_frame_state;
+int gra_get_frame_state(gra_app *app, gra_frame_state *state);
+int gra_set_frame_state(gra_app *app, const gra_frame_state *state);
 /* The swapchain image the last frame was rendered into (external to the graph, 4-image ring). */
 int gra_get_backbuffer(gra_app *app, gra_resource_info *info);
 int gra_read_backbuffer(gra_app *app, void *dst_host, uint64_t size_bytes);

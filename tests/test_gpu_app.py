@@ -346,3 +346,51 @@ m.close()
     graphs = np.load(out)
     for key, want in direct.items():
         np.testing.assert_array_equal(graphs[key], want, err_msg=key)
+
+
+@pytest.mark.parametrize("temporal", [False, True])
+def test_saved_state_restores_into_a_fresh_application(temporal):
+    """Checkpoint / replay: after 8 frames the state a frame inherits -- exposure adaptation, bloom feedback level, TAA
+    history (device side: gra_read_resource / gra_write_resource) and the frame state (elapsed time, swapchain position, moving
+    camera, jitter ring: gra_get / set_frame_state) -- goes into a FRESH application, whose next four frames equal frames 9-12 of
+    the original run byte for byte."""
+    w, h, n = 320, 180, 200
+    cam = synth.Camera(w, h)
+    gbuf, descs, mv = synth.make_gbuffer(cam), synth.make_lights(cam, n), synth.make_motion_vectors(w, h)
+    P, V = np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16)
+
+    def make():
+        a = gapp.Application(w, h, pre_aa=gapp.POST_AA_TAA_HIGH if temporal else gapp.POST_AA_NONE)
+        a.set_camera(P, V)
+        a.set_lights(descs)
+        a.upload_gbuffer(gbuf, mv if temporal else None)
+        a.set_camera_motion((0.01, 0.0, 0.0))
+        return a
+
+    inherited = ["average-luminance", "downsample-3"] + (["HDR-resolved-history"] if temporal else [])
+    a = make()
+    a.render_frames(8)
+    saved = {name: a.read(name).copy() for name in inherited}
+    state = a.frame_state()
+    want = []
+    for _ in range(4):
+        a.render_frames(1)
+        want.append((a.read_backbuffer().copy(), a.read("average-luminance").copy(), a.read("HDR-main").copy()))
+    a.close()
+
+    b = make()
+    b.set_frame_state(state)
+    for name, data in saved.items():
+        b.write(name, data)
+    for frame in range(4):
+        b.render_frames(1)
+        np.testing.assert_array_equal(b.read_backbuffer(), want[frame][0], err_msg=f"backbuffer of resumed frame {9 + frame}")
+        np.testing.assert_array_equal(b.read("average-luminance"), want[frame][1])
+        np.testing.assert_array_equal(b.read("HDR-main"), want[frame][2])
+    # and a fresh application WITHOUT the inherited state does differ (the comparison sees the state)
+    c = make()
+    c.set_frame_state(state)
+    c.render_frames(1)
+    assert (c.read_backbuffer() != want[0][0]).any()
+    b.close()
+    c.close()
