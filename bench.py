@@ -340,10 +340,15 @@ def main():
             sus = float(t.item())
         sustained = {"steps": n_sus, "seconds": sus, "ms_per_step": 1000.0 * sus / n_sus}
 
+    rank_ms = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own clock over the same K steps: the spread says whether one rank (or one link) holds the others up
+        mine = torch.tensor([elapsed], dtype=torch.float64)
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        rank_ms = {"min": 1000.0 * float(lo.item()) / args.steps, "max": 1000.0 * float(hi.item()) / args.steps}
+        elapsed = float(hi.item())
 
     # one frame per step: at N > 1 its row bands are spread over the ranks; in the replicas fallback every rank renders its own
     pixels_per_step = width * height * (1 if bands or world == 1 else world)
@@ -435,6 +440,14 @@ def main():
     if bands:
         # the assembled frame == the same frames of one executor rendering the whole target (null = check skipped / not possible)
         result["bands_checked"] = bands_checked
+        # what the communicator itself says: did RCCL see N ranks, which library version, how many bytes each rank sends per frame
+        info = application.comm_info()
+        out_rows = plan["out_chunk_rows"] if "out_chunk_rows" in plan else -(-height // world)
+        packed_rgb = os.environ.get("GRANITE_BENCH_GATHER_RGBA", "0") != "1"
+        info.update({"output_bytes_per_rank": int(out_rows) * width * (3 if packed_rgb else 4),
+                     "bloom_level_bytes_per_rank": int(plan["d1_chunk_rows"]) * (width // 8) * 8 if "d1_chunk_rows" in plan else None,
+                     "ms_per_step_over_ranks": rank_ms})
+        result["rccl"] = info
     if sustained:
         sustained["value"] = pixels_per_step * sustained["steps"] / sustained["seconds"] / 1e6
         sustained["unit"] = "Mpixels/s"

@@ -68,7 +68,7 @@ EXPORTED_SYMBOLS = [
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
     "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_prefetched_refreshes", "gra_get_launch_graph_replays", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
     "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_upload_aa_bench_images", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan", "gra_get_strip_plan_aa",
-    "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_init_output", "gra_install_ssr_tables", "gra_reset_timestamps", "gra_set_directional_light", "gra_set_fog", "gra_generate_mipmaps", "gra_write_resource", "gra_get_frame_state", "gra_set_frame_state",
+    "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_info", "gra_comm_init_output", "gra_install_ssr_tables", "gra_reset_timestamps", "gra_set_directional_light", "gra_set_fog", "gra_generate_mipmaps", "gra_write_resource", "gra_get_frame_state", "gra_set_frame_state",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -132,6 +132,7 @@ def load_library() -> C.CDLL:
         "gra_get_strip_plan_aa": (C.c_int, [vp, vp]),
         "gra_comm_create_unique_id": (C.c_int, [vp]),
         "gra_comm_init": (C.c_int, [vp, vp, C.c_int32, C.c_int32]),
+        "gra_comm_info": (C.c_int, [vp, P(C.c_int32), P(C.c_int32), P(C.c_int32)]),
         "gra_comm_init_output": (C.c_int, [vp, vp, C.c_int32, C.c_int32]),
     }
     for name, (res, args) in sigs.items():
@@ -418,6 +419,12 @@ class Application:
         assert len(unique_id) == 128
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self.lib.gra_comm_init(self.handle, buf, rank, ranks))
+
+    def comm_info(self) -> dict:
+        """What the in-frame communicator says about itself (for run records): ncclCommCount, ncclGetVersion, stand-in or RCCL."""
+        n, v, s_ = C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
+        self._check(self.lib.gra_comm_info(self.handle, C.byref(n), C.byref(v), C.byref(s_)))
+        return {"nranks": n.value, "version": v.value, "library": "test stand-in (GRANITE_RCCL_LIBRARY)" if s_.value else "librccl.so.1"}
 
     def comm_init_output(self, unique_id: bytes, rank: int, ranks: int):
         """Second communicator: the tonemapped bands are gathered beside the frame, on a stream of their own."""

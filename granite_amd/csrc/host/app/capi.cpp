@@ -287,6 +287,21 @@ int gra_comm_init(gra_app *app, const uint8_t *id128, int32_t rank, int32_t rank
 	});
 }
 
+int gra_comm_info(gra_app *app, int32_t *nranks, int32_t *version, int32_t *stand_in)
+{
+	return guarded(app, [&]() {
+		auto &c = app->app->get_collective();
+		if (!c.is_initialized())
+			throw std::logic_error("gra_comm_info: no communicator (gra_comm_init)");
+		if (nranks)
+			*nranks = c.communicator_ranks();
+		if (version)
+			*version = HIP::Collective::library_version();
+		if (stand_in)
+			*stand_in = HIP::Collective::is_stand_in() ? 1 : 0;
+	});
+}
+
 int gra_comm_init_output(gra_app *app, const uint8_t *id128, int32_t rank, int32_t ranks)
 {
 	return guarded(app, [&]() {

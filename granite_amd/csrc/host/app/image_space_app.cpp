@@ -200,6 +200,23 @@ void ImageSpaceApplication::init_collective(const uint8_t *id128, int rank, int 
 		throw std::logic_error("Collective rank / size must match the strip plan of this instance.");
 	get_device().make_current(); // the communicator binds to the calling thread's current device
 	collective.init(id128, rank, ranks);
+	{
+		// Every rank must pack (or not pack) the finished bands the same way: a first, tiny all-gather of the setting itself.
+		auto &device = get_device();
+		auto words = device.create_buffer(size_t(ranks) * 4u, VK_BUFFER_USAGE_STORAGE_BUFFER_BIT, "collective-settings");
+		const uint32_t mine = config.output_gather_rgba ? 1u : 0u;
+		auto *ctx = device.get_context();
+		auto *base = static_cast<uint8_t *>(words->get_device_pointer());
+		std::vector<uint32_t> all(size_t(ranks), 0u);
+		if (gr_upload(ctx, nullptr, base + size_t(rank) * 4u, &mine, 4) < 0 || gr_sync(ctx, nullptr) < 0)
+			throw std::runtime_error(gr_last_error(ctx));
+		collective.all_gather_in_place(base, 4, nullptr);
+		if (gr_sync(ctx, nullptr) < 0 || gr_download(ctx, nullptr, all.data(), base, size_t(ranks) * 4u) < 0)
+			throw std::runtime_error(gr_last_error(ctx));
+		for (uint32_t v : all)
+			if (v != mine)
+				throw std::logic_error("Row bands: the ranks disagree on output_gather_rgba (every rank must transport the finished bands the same way).");
+	}
 	strip_plan.exchange = [this](HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows, const char *tag) {
 		// With the output gather on its own communicator and stream (init_output_collective), the kernels of the two communicators
 		// must run in ONE order on every rank, or ranks can wait on each other across communicators (RCCL / NCCL: concurrent

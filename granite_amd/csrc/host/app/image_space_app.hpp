@@ -55,6 +55,7 @@ public:
 	RenderGraph &get_graph() { return graph; }
 	RenderContext &get_context() { return context; }
 	TemporalJitter &get_jitter() { return jitter; }
+	HIP::Collective &get_collective() { return collective; }
 	// Camera as the application sees it (un-jittered); with a temporal AA active each frame renders with
 	// jitter.get_jittered_projection() like SceneViewerApplication::update_scene (scene_viewer_application.cpp:1431-1433).
 	void set_base_camera(const mat4 &projection, const mat4 &view);

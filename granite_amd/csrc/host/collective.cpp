@@ -16,6 +16,8 @@ using CommInitRankFn = int (*)(void **comm, int nranks, UniqueId id, int rank);
 using CommDestroyFn = int (*)(void *comm);
 using AllGatherFn = int (*)(const void *send, void *recv, size_t count, int datatype, void *comm, void *stream);
 using GetErrorStringFn = const char *(*)(int);
+using CommCountFn = int (*)(void *comm, int *count);
+using GetVersionFn = int (*)(int *version);
 constexpr int kUint8 = 1; // ncclUint8
 
 struct Api
@@ -25,6 +27,9 @@ struct Api
 	CommDestroyFn comm_destroy = nullptr;
 	AllGatherFn all_gather = nullptr;
 	GetErrorStringFn get_error_string = nullptr;
+	CommCountFn comm_count = nullptr;   // optional: reporting only
+	GetVersionFn get_version = nullptr; // optional: reporting only
+	bool stand_in = false;              // GRANITE_RCCL_LIBRARY: not RCCL
 };
 
 const Api &api()
@@ -36,6 +41,12 @@ const Api &api()
 		if (const char *other = getenv("GRANITE_RCCL_LIBRARY"))
 		{
 			// Another implementation of the same five entry points (tests/rccl_shim: several ranks on ONE GPU, which RCCL refuses).
+			// A test facility: a stale variable in a production environment must not silently replace RCCL, so it only counts
+			// together with GRANITE_RCCL_LIBRARY_IS_A_TEST_STAND_IN=1, and every record made through it says so (is_stand_in()).
+			const char *ack = getenv("GRANITE_RCCL_LIBRARY_IS_A_TEST_STAND_IN");
+			if (!ack || ack[0] != '1')
+				throw std::runtime_error("GRANITE_RCCL_LIBRARY is set without GRANITE_RCCL_LIBRARY_IS_A_TEST_STAND_IN=1: refusing to replace librccl.so.1");
+			table.stand_in = true;
 			fprintf(stderr, "[granite-hip] note: collectives go through %s (GRANITE_RCCL_LIBRARY), not librccl.so.1\n", other);
 			lib = dlopen(other, RTLD_NOW | RTLD_LOCAL);
 			if (!lib)
@@ -52,6 +63,8 @@ const Api &api()
 		table.comm_destroy = reinterpret_cast<CommDestroyFn>(dlsym(lib, "ncclCommDestroy"));
 		table.all_gather = reinterpret_cast<AllGatherFn>(dlsym(lib, "ncclAllGather"));
 		table.get_error_string = reinterpret_cast<GetErrorStringFn>(dlsym(lib, "ncclGetErrorString"));
+		table.comm_count = reinterpret_cast<CommCountFn>(dlsym(lib, "ncclCommCount"));
+		table.get_version = reinterpret_cast<GetVersionFn>(dlsym(lib, "ncclGetVersion"));
 		if (!table.get_unique_id || !table.comm_init_rank || !table.comm_destroy || !table.all_gather || !table.get_error_string)
 			throw std::runtime_error("librccl.so.1 lacks an expected entry point");
 	});
@@ -92,6 +105,24 @@ void Collective::init(const uint8_t id[UniqueIdBytes], int rank_, int ranks_)
 	rank = rank_;
 	ranks = ranks_;
 }
+
+int Collective::communicator_ranks() const
+{
+	int count = -1;
+	if (comm && api().comm_count && api().comm_count(comm, &count) == 0)
+		return count;
+	return -1;
+}
+
+int Collective::library_version()
+{
+	int version = -1;
+	if (api().get_version && api().get_version(&version) == 0)
+		return version;
+	return -1;
+}
+
+bool Collective::is_stand_in() { return api().stand_in; }
 
 void Collective::all_gather_in_place(void *base, size_t chunk_bytes, void *stream)
 {

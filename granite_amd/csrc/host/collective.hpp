@@ -24,6 +24,11 @@ public:
 	bool is_initialized() const { return comm != nullptr; }
 	int get_rank() const { return rank; }
 	int get_ranks() const { return ranks; }
+	// For run records: what the communicator itself says (ncclCommCount; -1 if the library has no such entry point), the
+	// library's version code (ncclGetVersion; -1 likewise), and whether the library is a test stand-in (GRANITE_RCCL_LIBRARY).
+	int communicator_ranks() const;
+	static int library_version();
+	static bool is_stand_in();
 
 	// base points at ranks * chunk_bytes bytes; this rank's chunk is already at base + rank * chunk_bytes.
 	void all_gather_in_place(void *base, size_t chunk_bytes, void *stream);

@@ -254,6 +254,9 @@ int gra_comm_init(gra_app *app, const uint8_t *id128, int32_t rank, int32_t rank
 /* Optional second communicator (its own id from gra_comm_create_unique_id, after gra_comm_init): the all-gather of the
  * tonemapped bands then runs on a stream of its own behind each frame's tonemap and overlaps the following frames instead of
  * sitting on the back-of-frame stream.  gra_sync / readbacks wait for it. */
+/* What the in-frame communicator reports about itself, for run records: nranks = ncclCommCount, version = ncclGetVersion (each -1
+ * when the loaded library has no such entry point), stand_in = 1 when GRANITE_RCCL_LIBRARY replaced librccl.so.1. */
+int gra_comm_info(gra_app *app, int32_t *nranks, int32_t *version, int32_t *stand_in);
 int gra_comm_init_output(gra_app *app, const uint8_t *id128, int32_t rank, int32_t ranks);
 /* The band plan of this instance: out[0..3] = index, count, width, height; then {whole, first, count} for lighting,
  * threshold, downsample-0, downsample-1, upsample-0, tonemap; then d1_chunk_rows, out_chunk_rows (24 values). */

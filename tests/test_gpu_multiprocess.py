@@ -21,7 +21,7 @@ SHIM = os.path.join(ROOT, "tests", "rccl_shim", "libgranite_rccl_shim.so")
 def launch(world, script_args, port, extra_env=None, timeout=420):
     if not os.path.exists(SHIM):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(SHIM)])
-    env = dict(os.environ, GRANITE_RCCL_LIBRARY=SHIM, GRANITE_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    env = dict(os.environ, GRANITE_RCCL_LIBRARY=SHIM, GRANITE_RCCL_LIBRARY_IS_A_TEST_STAND_IN="1", GRANITE_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
     env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), *script_args]
