@@ -516,10 +516,15 @@ AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int 
 		}
 		else
 		{
-#define TAA_M1(C) ((c00.C + 2.0f * c01.C + c02.C + 2.0f * c10.C + 4.0f * c11.C + 2.0f * c12.C + c20.C + 2.0f * c21.C + c22.C) * (1.0f / 16.0f))
-#define TAA_M2(C)                                                                                                                           \
-	(c00.C * c00.C + 2.0f * c01.C * c01.C + c02.C * c02.C + 2.0f * c10.C * c10.C + 4.0f * c11.C * c11.C + 2.0f * c12.C * c12.C + c20.C * c20.C + \
-	 2.0f * c21.C * c21.C + c22.C * c22.C)
+			// m1 = (c00 + 2 c01 + c02 + 2 c10 + 4 c11 + 2 c12 + c20 + 2 c21 + c22) / 16 and m2 = the same sum over the squares, in the
+			// shader's order.  A product by 2 or 4 is exact, so acc + 2 c is ONE rounding either way: fma(2, c, acc) is the shader's
+			// mul + add bit for bit, and 2 * c * c == fma-free 2 * (c * c) likewise (scaling by a power of two commutes with rounding).
+#define TAA_M1(C) \
+	(fmaf(2.0f, c21.C, fmaf(2.0f, c12.C, fmaf(4.0f, c11.C, fmaf(2.0f, c10.C, fmaf(2.0f, c01.C, c00.C) + c02.C))) + c20.C) + c22.C) * (1.0f / 16.0f)
+#define TAA_M2(C)                                                                                                                                      \
+	(fmaf(2.0f, c21.C * c21.C, fmaf(2.0f, c12.C * c12.C, fmaf(4.0f, c11.C * c11.C, fmaf(2.0f, c10.C * c10.C, fmaf(2.0f, c01.C * c01.C, c00.C * c00.C) + c02.C * c02.C))) + \
+	      c20.C * c20.C) +                                                                                                                             \
+	 c22.C * c22.C)
 			const f3 m1 = {TAA_M1(x), TAA_M1(y), TAA_M1(z)};
 			const f3 m2 = {TAA_M2(x), TAA_M2(y), TAA_M2(z)};
 #undef TAA_M1
