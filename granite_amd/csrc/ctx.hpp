@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -77,8 +78,11 @@ struct gr_ctx
 			event_pool.pop_back();
 			return e;
 		}
+		// timing brackets order nothing and publish nothing to the host: no system-scope fence (GRANITE_TIMING_EVENT_SYSTEM_FENCE=1
+		// restores the default event)
+		static const unsigned flags = getenv("GRANITE_TIMING_EVENT_SYSTEM_FENCE") ? unsigned(hipEventDefault) : unsigned(hipEventDisableSystemFence);
 		hipEvent_t e;
-		if (hipEventCreate(&e) != hipSuccess)
+		if (hipEventCreateWithFlags(&e, flags) != hipSuccess)
 			return nullptr;
 		return e;
 	}

@@ -875,6 +875,9 @@ void ImageSpaceApplication::set_frame_state(const gra_frame_state &state)
 {
 	if (state.swapchain_index >= swapchain.size())
 		throw std::logic_error("gra_set_frame_state: swapchain index out of range");
+	// baking re-initialises the jitter sequence (as the reference's setup_*_postprocess do): bake before the saved phase goes in
+	if (need_bake)
+		bake_render_graph();
 	elapsed = state.elapsed;
 	swapchain_index = state.swapchain_index;
 	memcpy(base_view.data(), state.base_view, sizeof(state.base_view));

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <sstream>
 
 namespace Granite
@@ -1412,7 +1413,9 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		if (!event)
 		{
 			hipEvent_t e;
-			if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+			// ordering between streams of this device only: no system-scope fence (GRANITE_SYNC_EVENT_SYSTEM_FENCE=1 restores it)
+			static const unsigned flags = hipEventDisableTiming | (getenv("GRANITE_SYNC_EVENT_SYSTEM_FENCE") ? 0u : unsigned(hipEventDisableSystemFence));
+			if (hipEventCreateWithFlags(&e, flags) != hipSuccess)
 				throw std::runtime_error("hipEventCreate failed");
 			event = e;
 		}

@@ -315,22 +315,43 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k
 // Summation order is fixed (deterministic across runs and ranks) but differs from the reference's tree: covered by the
 // stated fp32 tolerance on LuminanceData.
 constexpr int LUM_THREADS = 1024;
-// Called by all LUM_THREADS threads of a workgroup (thread = 0 .. LUM_THREADS - 1); wave_partial: LUM_THREADS / 64 floats of LDS.
+// Called by all THREADS threads of a workgroup (thread = 0 .. THREADS - 1); wave_partial: LUM_THREADS / 64 floats of LDS.  A
+// workgroup narrower than LUM_THREADS plays LUM_THREADS / THREADS virtual threads per lane (virtual thread = thread + THREADS * k:
+// same lane of its wave, so the shuffles pair the same partial sums): every sum is taken in the order of the LUM_THREADS-wide
+// workgroup and the result is the same bit for bit.
+template <int THREADS>
 __device__ __forceinline__ void luminance_block(const DevImage &in, gr_luminance_data *lum, const gr_push_luminance &push, int thread,
                                                 float *wave_partial)
 {
+	static_assert(LUM_THREADS % THREADS == 0 && THREADS % 64 == 0, "whole waves of virtual threads");
+	constexpr int V = LUM_THREADS / THREADS;
 	const int sx = int(push.size[0]), sy = int(push.size[1]);
 	const float inv_x = 1.0f / float(sx), inv_y = 1.0f / float(sy);
 	const int total = sx * sy;
-	float sum = 0.0f;
-	for (int i = thread; i < total; i += LUM_THREADS)
+	float sum[V];
+#pragma unroll
+	for (int k = 0; k < V; k++)
+		sum[k] = 0.0f;
+	for (int base = thread; base < total; base += LUM_THREADS)
 	{
-		const int py = i / sx, px = i - py * sx;
-		sum += sample_linear_rgba16f(in, (float(px) + 0.5f) * inv_x, (float(py) + 0.5f) * inv_y).w;
+#pragma unroll
+		for (int k = 0; k < V; k++)
+		{
+			const int i = base + THREADS * k;
+			if (i < total)
+			{
+				const int py = i / sx, px = i - py * sx;
+				sum[k] += sample_linear_rgba16f(in, (float(px) + 0.5f) * inv_x, (float(py) + 0.5f) * inv_y).w;
+			}
+		}
 	}
-	sum = wave_sum(sum);
-	if ((thread & 63) == 0)
-		wave_partial[thread >> 6] = sum;
+#pragma unroll
+	for (int k = 0; k < V; k++)
+	{
+		const float s = wave_sum(sum[k]);
+		if ((thread & 63) == 0)
+			wave_partial[(thread >> 6) + (THREADS / 64) * k] = s;
+	}
 	__syncthreads();
 	if (thread == 0)
 	{
@@ -352,7 +373,7 @@ __global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_lumin
 {
 	post_wave_priority();
 	__shared__ float wave_partial[LUM_THREADS / 64];
-	luminance_block(in, lum, push, int(threadIdx.x), wave_partial);
+	luminance_block<LUM_THREADS>(in, lum, push, int(threadIdx.x), wave_partial);
 }
 
 // ---- the coarse end of the pyramid in two launches --------------------------------------------------------------------------
@@ -363,9 +384,9 @@ __global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_lumin
 //   k_bloom_down_tail: a workgroup makes an 8 x 8 tile of downsample-3; it first makes the patch of downsample-2 under that
 //     tile's tent taps (2:1 stencil from downsample-1), stores it (LDS as fp16, and to the downsample-2 image: neighbouring
 //     workgroups write identical values into the overlap), then filters the patch.
-//   k_bloom_up_tail: a workgroup of 1024 threads makes a 32 x 32 tile of upsample-1 from the 20 x 20 patch of upsample-2
-//     under it, which it first makes from downsample-3; workgroup 0 also runs the luminance reduction (same 1024-thread
-//     order as k_luminance).
+//   k_bloom_up_tail: a workgroup of 256 threads makes a 16 x 16 tile of upsample-1 from the 12 x 12 patch of upsample-2
+//     under it, which it first makes from downsample-3; workgroup 0 also runs the luminance reduction (in k_luminance's
+//     1024-thread order, four virtual threads per lane).
 // D3_EXACT / U2_EXACT mirror what the separate launchers would pick for that level (2:1 / 1:2 stencil or the generic tent).
 constexpr int TAIL_TILE = 8;
 constexpr int TAIL_PATCH = 24; // rows / columns of downsample-2 under an 8 x 8 tile of downsample-3 (<= 2 * 8 + 4 + slack)
@@ -451,12 +472,19 @@ __global__ __launch_bounds__(256) void k_bloom_down_tail(DevImage d1, DevImageRW
 	store_rgba16f(d3, x, y, value);
 }
 
-constexpr int UP_TILE = 32;
-constexpr int UP_PATCH = UP_TILE / 2 + 4; // upsample-2 texels under 32 outputs of upsample-1: k - 2 .. k + 2 for k = x / 2
-template <bool U2_EXACT, bool LUMINANCE>
-__global__ __launch_bounds__(LUM_THREADS) void k_bloom_up_tail(DevImage d3, DevImageRW u2, DevImageRW u1, gr_luminance_data *lum,
-                                                               gr_push_bloom_upsample push2, gr_push_luminance push_lum)
+// UP_THREADS = 1024 (a 32 x 32 tile) is what runs.  The 256-thread form (16 x 16 tiles, one wave per SIMD: finds room on a CU beside
+// the resident lighting waves, where a 1024-thread workgroup waits for a whole CU to drain -- 15 us instead of 60-100 us inside the
+// 4K frame) was built for VERDICT r2 item 5 and measured on one box against the wide form: the FRAME gets slower with it, 0.2426 vs
+// 0.2295 ms sustained (profiles/r03_up_tail_shape_ab.txt): the back chain then runs beside the lighting kernel for all of its
+// length and lighting, which sets the frame period, loses more than the chain gains (211 -> 220 us in-frame; tonemap 26 -> 36 us).
+// Nothing waits for the back chain, so its starved tail is free.  GRANITE_UP_TAIL_NARROW=1 selects the 256-thread form.
+template <int UP_THREADS, bool U2_EXACT, bool LUMINANCE>
+__global__ __launch_bounds__(UP_THREADS) POST_VGPR_BUDGET void k_bloom_up_tail(DevImage d3, DevImageRW u2, DevImageRW u1, gr_luminance_data *lum,
+                                                                              gr_push_bloom_upsample push2, gr_push_luminance push_lum)
 {
+	constexpr int UP_TILE = UP_THREADS == 1024 ? 32 : 16;
+	constexpr int UP_PATCH = UP_TILE / 2 + 4; // upsample-2 texels under UP_TILE outputs of upsample-1: k - 2 .. k + 2 for k = x / 2
+	static_assert(UP_PATCH * UP_PATCH <= UP_THREADS && UP_TILE * UP_TILE == UP_THREADS, "one patch texel and one output per thread");
 	post_wave_priority();
 	__shared__ f16x4 s_patch[UP_PATCH * UP_PATCH];
 	__shared__ float wave_partial[LUM_THREADS / 64];
@@ -494,7 +522,7 @@ __global__ __launch_bounds__(LUM_THREADS) void k_bloom_up_tail(DevImage d3, DevI
 	}
 	// hdr.cpp:368-371 records the luminance pass between downsample-3 and upsample-2; nothing in between reads its result
 	if (LUMINANCE && blockIdx.x == 0 && blockIdx.y == 0)
-		luminance_block(d3, lum, push_lum, thread, wave_partial);
+		luminance_block<UP_THREADS>(d3, lum, push_lum, thread, wave_partial);
 }
 
 // ---- tonemap (tonemap.frag:30-66) -----------------------------------------------------------------------------------
@@ -889,18 +917,27 @@ int gr_bloom_up_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr
 	GR_CHECK_ARG(ctx, upsample_is_exact(u2, push_u1) && push_u1->threads[0] == u1->width && push_u1->threads[1] == u1->height);
 	GR_CHECK_ARG(ctx, push_u2->threads[0] == u2->width && push_u2->threads[1] == u2->height);
 	GR_CHECK_ARG(ctx, !push_lum || (push_lum->size[0] != 0 && push_lum->size[1] != 0));
-	dim3 grid(gr_div_up(u1->width, UP_TILE), gr_div_up(u1->height, UP_TILE));
+	static const bool wide = getenv("GRANITE_UP_TAIL_NARROW") == nullptr;
+	const uint32_t tile = wide ? 32 : 16, threads = wide ? 1024 : 256;
+	dim3 grid(gr_div_up(u1->width, tile), gr_div_up(u1->height, tile));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_up_tail"};
 	const gr_push_luminance no_lum = {};
 	const bool exact = upsample_is_exact(d3, push_u2);
 	auto launch = [&](auto kernel) {
-		hipLaunchKernelGGL(kernel, grid, dim3(LUM_THREADS), 0, gr_to_stream(stream), to_dev(d3), to_dev_rw(u2), to_dev_rw(u1), lum, *push_u2,
+		hipLaunchKernelGGL(kernel, grid, dim3(threads), 0, gr_to_stream(stream), to_dev(d3), to_dev_rw(u2), to_dev_rw(u1), lum, *push_u2,
 		                   push_lum ? *push_lum : no_lum);
 	};
-	if (exact && lum) launch(k_bloom_up_tail<true, true>);
-	else if (exact) launch(k_bloom_up_tail<true, false>);
-	else if (lum) launch(k_bloom_up_tail<false, true>);
-	else launch(k_bloom_up_tail<false, false>);
+	auto pick = [&](auto width) {
+		constexpr int T = decltype(width)::value;
+		if (exact && lum) launch(k_bloom_up_tail<T, true, true>);
+		else if (exact) launch(k_bloom_up_tail<T, true, false>);
+		else if (lum) launch(k_bloom_up_tail<T, false, true>);
+		else launch(k_bloom_up_tail<T, false, false>);
+	};
+	if (wide)
+		pick(std::integral_constant<int, 1024>{});
+	else
+		pick(std::integral_constant<int, 256>{});
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
