@@ -293,11 +293,9 @@ def main():
         except Exception:  # noqa: BLE001 - e.g. not enough free HBM beside an 8K frame: the spec peak stands alone
             return None, None
 
-    late_probe = os.environ.get("GRANITE_BENCH_ORDER", "late-probe") == "late-probe"
-    if not late_probe:
-        copy_gbs, triad_gbs = hbm_probe()
+    copy_gbs, triad_gbs = hbm_probe()
 
-    # ---- discovery frames: every launcher bracketed, finds the dominant kernel and the in-frame time of each kernel ----
+    # ---- warm-up (also finds the dominant kernel with every launcher bracketed) ----
     kctx.timing_set_sampling(1)
     kctx.timing_enable(True)
     kctx.timing_set_filter(None)
@@ -315,15 +313,7 @@ def main():
     kctx.timing_set_filter(dominant)
     kctx.timing_set_sampling(max(1, min(BRACKET_EVERY, args.steps // MIN_BRACKETS)))
     kctx.timing_reset()
-    if late_probe:
-        # The device drops its clocks within a host-side pause and takes ~10 ms of load to come back (the first ~30 frames after an
-        # idle gap run ~7 % slower: profiles/r03_short_run_ramp.txt).  So the HBM probe (~10 ms of copies) runs here, and the W warm-up
-        # frames follow it without a host pause, un-bracketed; the barrier below is the only idle moment before the timed frames.
-        copy_gbs, triad_gbs = hbm_probe()
-        kctx.timing_enable(False)
-        application.render_frames(max(args.warmup, 1), sync=False)
     barrier()
-    kctx.timing_enable(True)
     t0 = time.perf_counter()
     hs0 = application.host_stats()
     application.render_frames(args.steps, sync=False)

@@ -30,7 +30,7 @@ class Config(C.Structure):
                 ("disable_image_aliasing", C.c_int32), ("depth_hierarchy", C.c_int32),
                 ("resolution_scale", C.c_float), ("resolution_scale_sharpen", C.c_int32), ("fsr_fp32", C.c_int32),
                 ("ambient_occlusion", C.c_int32), ("hdr10", C.c_int32), ("ssr", C.c_int32), ("aa_bench", C.c_int32), ("output_gather_rgba", C.c_int32),
-                ("hdr_packed_float", C.c_int32)]
+                ("hdr_packed_float", C.c_int32), ("taa_history_reach_rows", C.c_uint32)]
 
 
 # void (*gra_exchange_fn)(void *user, const char *tag, void *device_ptr, uint64_t chunk_bytes, uint32_t rank_count, void *stream)
@@ -67,7 +67,7 @@ EXPORTED_SYMBOLS = [
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
     "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_prefetched_refreshes", "gra_get_launch_graph_replays", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
-    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_upload_aa_bench_images", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan", "gra_get_strip_plan_aa",
+    "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_upload_aa_bench_images", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan", "gra_get_strip_plan_aa", "gra_get_strip_plan_taa_history",
     "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_info", "gra_comm_init_output", "gra_install_ssr_tables", "gra_reset_timestamps", "gra_set_directional_light", "gra_set_fog", "gra_generate_mipmaps", "gra_write_resource", "gra_get_frame_state", "gra_set_frame_state",
 ]
 
@@ -130,6 +130,7 @@ def load_library() -> C.CDLL:
         "gra_set_exchange_callback": (C.c_int, [vp, EXCHANGE_FN, vp]),
         "gra_get_strip_plan": (C.c_int, [vp, vp]),
         "gra_get_strip_plan_aa": (C.c_int, [vp, vp]),
+        "gra_get_strip_plan_taa_history": (C.c_int, [vp, vp]),
         "gra_comm_create_unique_id": (C.c_int, [vp]),
         "gra_comm_init": (C.c_int, [vp, vp, C.c_int32, C.c_int32]),
         "gra_comm_info": (C.c_int, [vp, P(C.c_int32), P(C.c_int32), P(C.c_int32)]),
@@ -156,8 +157,9 @@ class Application:
                  alias_images: bool = True, depth_hierarchy: int = 0,
                  resolution_scale: float = 1.0, resolution_scale_sharpen: bool = True, fsr_fp16: bool = True,
                  ambient_occlusion: bool = False, hdr10: bool = False, ssr: bool = False, aa_bench: bool = False,
-                 output_gather_rgba: bool = False, rt_fp16: bool = True):
-        """rt_fp16 = False: viewer_config renderTargetFp16 = false (the reference's default): emissive / HDR-main and the TAA colour
+                 output_gather_rgba: bool = False, rt_fp16: bool = True, taa_history_reach_rows: int = 0):
+        """taa_history_reach_rows > 0 (row bands + TAA): the history bands exchange boundary rows with their neighbours only; a pixel
+        that reaches further makes the next render / sync / read raise.  rt_fp16 = False: viewer_config renderTargetFp16 = false (the reference's default): emissive / HDR-main and the TAA colour
         output are B10G11R11_UFLOAT_PACK32; the emissive upload is then (h, w) uint32 words (oracle.pack_b10g11r11)."""
         self.lib = load_library()
         cfg = Config()
@@ -181,6 +183,7 @@ class Application:
         cfg.aa_bench = int(aa_bench)
         cfg.output_gather_rgba = int(output_gather_rgba)
         cfg.hdr_packed_float = int(not rt_fp16)
+        cfg.taa_history_reach_rows = int(taa_history_reach_rows)
         if ssr:
             install_ssr_tables()
         self._exchange_ref = None
@@ -445,6 +448,10 @@ class Application:
         for i, name in enumerate(("taa", "smaa_edges", "smaa_weights", "aa_out")):
             whole, first, count = (int(v) for v in aa[3 * i:3 * i + 3])
             plan[name] = None if whole else (first, count)
+        th = np.zeros(5, np.uint32)
+        self._check(self.lib.gra_get_strip_plan_taa_history(self.handle, th.ctypes.data))
+        plan["taa_history_reach_rows"], plan["taa_exchange_rows"] = int(th[0]), int(th[1])
+        plan["taa_history_held"] = None if th[2] else (int(th[3]), int(th[4]))
         return plan
 
     def host_stats(self) -> dict:

@@ -690,6 +690,13 @@ int gr_taa_resolve(gr_ctx *ctx, gr_stream stream, const gr_image *current, const
 int gr_taa_resolve_rows(gr_ctx *ctx, gr_stream stream, const gr_image *current, const gr_image *depth, const gr_image *mv, const gr_image *history,
                         const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality, const gr_rows *rows)
 {
+	return gr_taa_resolve_band(ctx, stream, current, depth, mv, history, out_color, out_history, push, quality, rows, nullptr, nullptr);
+}
+
+int gr_taa_resolve_band(gr_ctx *ctx, gr_stream stream, const gr_image *current, const gr_image *depth, const gr_image *mv, const gr_image *history,
+                        const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality, const gr_rows *rows,
+                        const gr_rows *history_rows, uint32_t *reach_flag)
+{
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, push && current && depth && mv && out_color && out_history);
@@ -723,6 +730,14 @@ int gr_taa_resolve_rows(gr_ctx *ctx, gr_stream stream, const gr_image *current, 
 	im.h = int(h);
 	im.current_b10 = current_b10;
 	im.color_b10 = color_b10;
+	GR_CHECK_ARG(ctx, (history_rows == nullptr) == (reach_flag == nullptr));
+	if (history_rows)
+	{
+		const RowSpan held = resolve_rows(history_rows, h);
+		im.hist_first = int(held.first);
+		im.hist_end = int(held.end);
+		im.reach_flag = reach_flag;
+	}
 	aa::TaaPush tp;
 	for (int i = 0; i < 16; i++)
 		tp.reproj[i] = push->reproj[i];

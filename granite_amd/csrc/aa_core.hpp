@@ -350,10 +350,11 @@ struct TaaPush
 // Mv:   uint32_t mv(int x, int y), the RG16F texel of the clamped pixel.
 // Hist: u2 texel(int x, int y), the RGBA16F history texel; coordinates arrive clamped to the image.
 // QUALITY 0 / 1 / 2 = TAAQuality Low / Medium / High.  Writes the resolved colour and the new history as RGBA16F texels, and the
-// colour in fp32 as well.
+// colour in fp32 as well; hist_row_first / hist_row_last = the first and last history row the pixel fetched (row bands: a rank
+// only holds the history rows around its band).
 template <int QUALITY, typename Tile, typename Mv, typename Hist>
 AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int y, int w, int h, const TaaPush &P, u2 &out_color, u2 &out_history,
-                     f3 &out_color_f32)
+                     f3 &out_color_f32, int &hist_row_first, int &hist_row_last)
 {
 	const float u = (float(x) + 0.5f) * P.rt[0], v = (float(y) + 0.5f) * P.rt[1];
 	const f4 c11 = t.cur(0, 0);
@@ -469,6 +470,8 @@ AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int 
 				b = mad_half_lo(tx.y, wgt, b);
 			}
 		hc = {r, g, b};
+		hist_row_first = row[0];
+		hist_row_last = row[3];
 	}
 	else
 	{
@@ -483,6 +486,8 @@ AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int 
 		const float top_g = mad_half_hi(t10.x, a, mad_half_hi(t00.x, oma, 0.0f)), bot_g = mad_half_hi(t11.x, a, mad_half_hi(t01.x, oma, 0.0f));
 		const float top_b = mad_half_lo(t10.y, a, mad_half_lo(t00.y, oma, 0.0f)), bot_b = mad_half_lo(t11.y, a, mad_half_lo(t01.y, oma, 0.0f));
 		hc = {fmaf(bot_r, b, top_r * omb), fmaf(bot_g, b, top_g * omb), fmaf(bot_b, b, top_b * omb)};
+		hist_row_first = y0;
+		hist_row_last = y1;
 	}
 
 	const float mv_length = approx_sqrt(mvx * mvx + mvy * mvy);

@@ -187,6 +187,11 @@ struct TaaImages
 	// B10G11R11_UFLOAT_PACK32 instead of RGBA16F: the input when the HDR targets are packed (renderTargetFp16 = false), the colour
 	// output as the reference declares it (temporal.cpp:211-213).  The history is RGBA16F either way (temporal.cpp:216).
 	int current_b10, color_b10;
+	// Row bands: history rows [hist_first, hist_end) hold last frame's values on this rank; a pixel whose reprojection fetches a row
+	// outside sets *reach_flag (host-visible memory) -- the frame is then not the single-device frame and the executor says so.
+	// reach_flag == nullptr: the whole history is there, nothing to check.
+	int hist_first, hist_end;
+	uint32_t *reach_flag;
 };
 
 // one texel of the current frame as RGBA16F dwords, whatever its storage
@@ -273,7 +278,10 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_taa_fast(TaaImages im, aa:
 	const TaaHistory history = {im.history, im.history_pitch};
 	aa::u2 color, hist;
 	aa::f3 color_f;
-	aa::taa_pixel<QUALITY>(tile, motion, history, x, y, im.w, im.h, push, color, hist, color_f);
+	int row_first, row_last;
+	aa::taa_pixel<QUALITY>(tile, motion, history, x, y, im.w, im.h, push, color, hist, color_f, row_first, row_last);
+	if (im.reach_flag && (row_first < im.hist_first || row_last >= im.hist_end))
+		*im.reach_flag = 1u;
 	if (im.color_b10)
 		*reinterpret_cast<uint32_t *>(im.out_color + (uint32_t(y) * im.out_color_pitch + uint32_t(x) * 4u)) = pack_b10g11r11(color_f.x, color_f.y, color_f.z);
 	else

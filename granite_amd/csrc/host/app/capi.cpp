@@ -346,6 +346,20 @@ int gra_get_strip_plan_aa(gra_app *app, uint32_t *out12)
 	});
 }
 
+int gra_get_strip_plan_taa_history(gra_app *app, uint32_t *out5)
+{
+	return guarded(app, [&]() {
+		if (!out5)
+			throw std::logic_error("gra_get_strip_plan_taa_history: null output");
+		auto &p = app->app->get_strip_plan();
+		out5[0] = p.aa.taa_history_reach;
+		out5[1] = p.taa_exchange_rows;
+		out5[2] = p.taa_history_held.whole ? 1u : 0u;
+		out5[3] = p.taa_history_held.first;
+		out5[4] = p.taa_history_held.count;
+	});
+}
+
 int gra_get_host_stats(gra_app *app, double *out3)
 {
 	return guarded(app, [&]() {

@@ -94,6 +94,7 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 		strip_aa.smaa_search_steps = smaa_search_steps(post_type);
 	}
 	strip_aa.temporal = pre_type == PostAAType::TAA_Low || pre_type == PostAAType::TAA_Medium || pre_type == PostAAType::TAA_High;
+	strip_aa.taa_history_reach = strip_aa.temporal ? config.taa_history_reach_rows : 0u;
 	strip_plan = StripPlan::build(config.strip_index, config.strip_count, config.width, config.height, strip_aa);
 	hdr_options.strip = &strip_plan;
 
@@ -109,6 +110,15 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 		return;
 	auto &device = *device_holder;
 	device.set_image_row_granularity(config.strip_count);
+	if (strip_plan.taa_exchange_rows)
+	{
+		void *word = nullptr;
+		if (hipHostMalloc(&word, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+			throw std::runtime_error("hipHostMalloc failed");
+		taa_reach_flag = static_cast<uint32_t *>(word);
+		*taa_reach_flag = 0;
+		strip_plan.taa_reach_flag = taa_reach_flag;
+	}
 
 	// External swapchain: 4 images R8G8B8A8_SRGB, cycled per frame.
 	for (unsigned i = 0; i < 4; i++)
@@ -127,11 +137,23 @@ ImageSpaceApplication::ImageSpaceApplication(const gra_config &config_) : config
 ImageSpaceApplication::~ImageSpaceApplication()
 {
 	cluster.invalidate_prefetch(); // no helper-thread job may outlive the light objects it reads
-	wait_idle();
+	if (device_holder)
+		device_holder->wait_idle();
 	for (auto &e : output_gather_done)
 		(void)hipEventDestroy(static_cast<hipEvent_t>(e.second));
 	if (output_ready_event)
 		(void)hipEventDestroy(static_cast<hipEvent_t>(output_ready_event));
+	if (taa_reach_flag)
+		(void)hipHostFree(taa_reach_flag);
+}
+
+void ImageSpaceApplication::check_taa_history_reach()
+{
+	if (taa_reach_flag && *static_cast<volatile uint32_t *>(taa_reach_flag))
+		throw std::runtime_error("taa-resolve: a pixel's reprojection fetched history rows this rank does not hold (reach of more than " +
+		                         std::to_string(config.taa_history_reach_rows) +
+		                         " rows): frames since then are not the single-device frames.  Raise gra_config.taa_history_reach_rows, or set it to 0 "
+		                         "(whole history bands are all-gathered).");
 }
 
 // ---- the frame's output bands on the wire --------------------------------------------------------------------------------------
@@ -768,6 +790,7 @@ void ImageSpaceApplication::render_frame()
 {
 	auto &device = get_device();
 	const auto host_t0 = std::chrono::steady_clock::now();
+	check_taa_history_reach();
 	if (need_bake)
 		bake_render_graph();
 

@@ -35,7 +35,10 @@ public:
 	{
 		if (device_holder)
 			device_holder->wait_idle();
+		check_taa_history_reach();
 	}
+	// Row bands with a bounded TAA history reach: throws once a resolve has reported a fetch outside the rows this rank holds.
+	void check_taa_history_reach();
 	// Composes and bakes the graph without touching a GPU (config.device < 0 creates no device): used by CPU tests.
 	void bake_only() { bake_render_graph(); }
 
@@ -112,6 +115,7 @@ private:
 	void pack_output_band(HIP::CommandBuffer &cmd, HIP::Image &image, uint32_t chunk_rows);
 	void gather_packed_output(HIP::Image &image, uint32_t chunk_rows, void *stream, const BandTransport &transport);
 	void *output_ready_event = nullptr;
+	uint32_t *taa_reach_flag = nullptr; // pinned host word the band resolve writes (strip_plan.taa_reach_flag)
 	TemporalJitter jitter;
 	mat4 base_projection, base_view;
 	bool has_base_camera = false;

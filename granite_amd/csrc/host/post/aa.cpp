@@ -1,8 +1,10 @@
 // Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
 // THIRD_PARTY_NOTICES.md at the repository root.
 #include "aa.hpp"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 
 namespace Granite
 {
@@ -236,8 +238,12 @@ void setup_taa_resolve(RenderGraph &graph, TemporalJitter &jitter, float scaling
 	auto &input_depth_res = resolve.add_texture_input(input_depth);
 	auto &history = resolve.add_history_input(output + "-history");
 
+	// Row bands with a bounded history reach: the boundary blocks of every rank's history chunk travel through this image (rank g's
+	// rows [2 X g, 2 X g + X) = the first X rows of its chunk, the next X rows = the last X), one all-gather per frame.
+	auto halo_staging = std::make_shared<HIP::ImageHandle>();
+
 	resolve.set_build_render_pass(
-	    [&graph, &jitter, &out_color, &out_history, &input_res, &input_res_mv, &input_depth_res, &history, q = int(quality), plan](HIP::CommandBuffer &cmd) {
+	    [&graph, &jitter, &out_color, &out_history, &input_res, &input_res_mv, &input_depth_res, &history, q = int(quality), plan, halo_staging](HIP::CommandBuffer &cmd) {
 		    const StripPlan *strip = live(plan);
 		    auto &image = graph.get_physical_texture_resource(input_res);
 		    auto &image_mv = graph.get_physical_texture_resource(input_res_mv);
@@ -254,16 +260,52 @@ void setup_taa_resolve(RenderGraph &graph, TemporalJitter &jitter, float scaling
 		    push.rt_metrics[1] = 1.0f / float(image.get_height());
 		    push.rt_metrics[2] = float(image.get_width());
 		    push.rt_metrics[3] = float(image.get_height());
-		    gr_rows rows;
+		    gr_rows rows, held;
+		    const bool bounded = strip && strip->exchange && strip->taa_exchange_rows != 0;
 		    if (to_rows(strip ? &strip->taa : nullptr, rows))
-			    cmd.check(gr_taa_resolve_rows(cmd.get_context(), cmd.get_stream(), &image.get_view(), &depth.get_view(), &image_mv.get_view(),
-			                                  prev ? &prev->get_view() : nullptr, &color.get_view(), &hist.get_view(), &push, q, &rows),
-			              "taa-resolve");
-		    // Row bands: next frame's reprojection may read the history anywhere, so the bands meet in every rank's history
-		    // image (same chunking as the output image; rows a rank resolved beyond its chunk are overwritten with the
-		    // owner's identical values).
-		    if (strip && strip->exchange)
+		    {
+			    if (bounded && prev && to_rows(&strip->taa_history_held, held))
+				    cmd.check(gr_taa_resolve_band(cmd.get_context(), cmd.get_stream(), &image.get_view(), &depth.get_view(), &image_mv.get_view(),
+				                                  &prev->get_view(), &color.get_view(), &hist.get_view(), &push, q, &rows, &held, strip->taa_reach_flag),
+				              "taa-resolve");
+			    else
+				    cmd.check(gr_taa_resolve_rows(cmd.get_context(), cmd.get_stream(), &image.get_view(), &depth.get_view(), &image_mv.get_view(),
+				                                  prev ? &prev->get_view() : nullptr, &color.get_view(), &hist.get_view(), &push, q, &rows),
+				              "taa-resolve");
+		    }
+		    if (!strip || !strip->exchange)
+			    return;
+		    if (!bounded)
+		    {
+			    // Next frame's reprojection may read the history anywhere: the bands meet in every rank's history image (same
+			    // chunking as the output image; rows a rank resolved beyond its chunk are overwritten with the owner's
+			    // identical values).
 			    strip->exchange(cmd, hist, strip->out_chunk_rows, "taa-history");
+			    return;
+		    }
+		    // Bounded reach: only the boundary blocks travel.  X rows from either end of every chunk into the staging image, one
+		    // all-gather, the upper neighbour's last block above the own chunk and the lower neighbour's first block below it.
+		    const uint32_t X = strip->taa_exchange_rows, C = strip->out_chunk_rows, H = hist.get_height(), g = strip->index;
+		    const size_t pitch = hist.get_view().pitch_bytes;
+		    auto &staging = *halo_staging;
+		    if (!staging || staging->get_width() != hist.get_width() || staging->get_height() != strip->count * 2 * X)
+			    staging = cmd.get_device().create_image(hist.get_width(), strip->count * 2 * X, hist.get_format(), "taa-history-halo");
+		    auto *base = static_cast<uint8_t *>(hist.get_device_pointer());
+		    auto *stage = static_cast<uint8_t *>(staging->get_device_pointer());
+		    auto copy_rows = [&](uint8_t *dst, const uint8_t *src, uint32_t count) {
+			    cmd.check(gr_copy(cmd.get_context(), cmd.get_stream(), dst, src, size_t(count) * pitch), "taa-history-halo");
+		    };
+		    const uint32_t own_first = std::min(g * C, H), own_end = std::min(own_first + C, H);
+		    if (own_end - own_first >= X)
+		    {
+			    copy_rows(stage + size_t(2 * X * g) * pitch, base + size_t(own_first) * pitch, X);
+			    copy_rows(stage + size_t(2 * X * g + X) * pitch, base + size_t(own_end - X) * pitch, X);
+		    }
+		    strip->exchange(cmd, *staging, 2 * X, "taa-history-halo");
+		    if (g > 0 && own_first >= X)
+			    copy_rows(base + size_t(own_first - X) * pitch, stage + size_t(2 * X * (g - 1) + X) * pitch, X);
+		    if (g + 1 < strip->count && own_end + X <= H)
+			    copy_rows(base + size_t(own_end) * pitch, stage + size_t(2 * X * (g + 1)) * pitch, X);
 	    });
 }
 

@@ -137,6 +137,29 @@ StripPlan StripPlan::build(unsigned index, unsigned count, uint32_t width, uint3
 		plan.taa = to_range(hdr_rows);
 		hdr_rows = grown(hdr_rows, 1 + 1, height);
 	}
+	if (aa.temporal && aa.taa_history_reach > 0 && plan.taa.count > 0)
+	{
+		// One exchange depth for all ranks (the all-gather's chunks are uniform): the deepest halo any rank resolves beyond its
+		// chunk, plus the reach.  Every rank must own that many rows, or the neighbour alone could not supply them.
+		StripAA whole_gather = aa;
+		whole_gather.taa_history_reach = 0;
+		int64_t depth = 0, thinnest = int64_t(height);
+		for (unsigned g = 0; g < count; g++)
+		{
+			const StripPlan other = g == index ? plan : build(g, count, width, height, whole_gather);
+			const Span c = chunk_of(g, plan.out_chunk_rows, height);
+			thinnest = std::min(thinnest, c.hi - c.lo + 1);
+			if (other.taa.count == 0 || c.hi < c.lo)
+				continue;
+			depth = std::max(depth, std::max<int64_t>(c.lo - int64_t(other.taa.first), int64_t(other.taa.first + other.taa.count) - 1 - c.hi));
+		}
+		depth += int64_t(aa.taa_history_reach);
+		if (depth <= thinnest)
+		{
+			plan.taa_exchange_rows = uint32_t(depth);
+			plan.taa_history_held = to_range(grown(chunk, depth, height));
+		}
+	}
 	plan.lighting = to_range(hdr_rows);
 	plan.u0 = out.hi >= out.lo ? to_range(footprint(out, height, plan.h_u0, 0.0)) : to_range({0, -1});
 	return plan;

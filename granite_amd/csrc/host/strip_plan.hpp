@@ -46,6 +46,9 @@ struct StripAA
 	Post post = Post::None;          // after the tonemap: reads the tonemapped image above and below its band
 	unsigned smaa_search_steps = 0;  // SMAA_MAX_SEARCH_STEPS of the preset (4 / 8 / 16 / 32)
 	bool temporal = false;           // TAA resolve between lighting and the post chain
+	// Rows a resolved pixel's history fetch may lie away from the pixel (motion + the 4 x 4 filter footprint).  > 0: the history
+	// bands meet their neighbours' boundary rows only; 0: whole bands are all-gathered (any motion).
+	unsigned taa_history_reach = 0;
 };
 
 struct StripPlan
@@ -69,6 +72,12 @@ struct StripPlan
 	// history is the exception -- reprojection may reach any row, so the history bands are all-gathered every frame.
 	StripAA aa;
 	RowRange taa;          // rows the temporal resolve writes (= the HDR rows the post chain reads on this rank)
+	// TAA history under a bounded reach: every rank contributes the first and the last taa_exchange_rows rows of its chunk to one
+	// all-gather and takes its neighbours' blocks; afterwards it holds taa_history_held, which covers every row the resolve of
+	// `taa` can fetch within the reach.  taa_exchange_rows == 0: the bands are all-gathered whole (reach 0, or bands too thin).
+	uint32_t taa_exchange_rows = 0;
+	RowRange taa_history_held;
+	uint32_t *taa_reach_flag = nullptr; // host-visible word the resolve sets when a fetch leaves taa_history_held (owned by the app)
 	RowRange smaa_edges;   // rows of "smaa-edge" the weight pass searches through
 	RowRange smaa_weights; // rows of "smaa-weights" the blend pass reads
 	RowRange aa_out;       // rows of the post-AA output: exactly this rank's all-gather chunk

@@ -67,10 +67,11 @@ def weak_scaled_frame(world: int, base=(3840, 2160)) -> Tuple[int, int]:
     return w, h
 
 
-def plan_numpy(index: int, count: int, width: int, height: int, post_aa: int = 0, pre_aa: int = 0) -> dict:
+def plan_numpy(index: int, count: int, width: int, height: int, post_aa: int = 0, pre_aa: int = 0, taa_history_reach_rows: int = 0) -> dict:
     """StripPlan::build through the C ABI without a GPU (dry application); post_aa / pre_aa = app.POST_AA_* values."""
     from . import app as gapp
-    a = gapp.Application(width, height, device=-1, strip_index=index, strip_count=count, post_aa=post_aa, pre_aa=pre_aa)
+    a = gapp.Application(width, height, device=-1, strip_index=index, strip_count=count, post_aa=post_aa, pre_aa=pre_aa,
+                         taa_history_reach_rows=taa_history_reach_rows)
     try:
         return a.strip_plan()
     finally:

@@ -99,6 +99,13 @@ typedef struct gra_config
 	 * 32-bit word per texel.  0 = RGBA16F everywhere (SURVEY.md 8d fixes the headline configuration on it).  Not with ssr / hdr10
 	 * (those passes read-modify-write the lit target as RGBA16F here). */
 	int32_t hdr_packed_float;
+	/* Row bands with a TAA resolve (no reference analogue): > 0 = how many rows a resolved pixel's history fetch may
+	 * lie away from the pixel (vertical motion in rows + 3 for the Catmull-Rom footprint).  The history bands then only exchange
+	 * their boundary rows with their neighbours (gra_get_strip_plan_taa_history says how many) instead of meeting whole in every
+	 * rank.  A frame in which some pixel reaches further is NOT the single-device frame: the resolve notices (gr_taa_resolve_band),
+	 * and the next gra_render_frame / gra_sync / read-back fails with an error that says so.  0 = whole bands are all-gathered
+	 * (any motion).  Every rank must be given the same value. */
+	uint32_t taa_history_reach_rows;
 } gra_config;
 
 /* Scene-level light description (one PositionalLight + its node transform). */
@@ -265,6 +272,10 @@ int gra_get_strip_plan(gra_app *app, uint32_t *out24);
  * smaa-edge, smaa-weights and the post-AA output band (12 values).  The tonemap and lighting ranges of gra_get_strip_plan
  * already include the rows these passes read around the band. */
 int gra_get_strip_plan_aa(gra_app *app, uint32_t *out12);
+/* The TAA history under row bands: out[0] = config.taa_history_reach_rows, out[1] = rows every rank hands to each neighbour per
+ * frame (0 = the bands are all-gathered whole: reach 0, or bands thinner than the exchange), out[2..4] = {whole, first, count} of
+ * the history rows this rank holds after the exchange. */
+int gra_get_strip_plan_taa_history(gra_app *app, uint32_t *out5);
 
 /* Host-side frame-loop cost since creation: out[0] = frames, out[1] = seconds spent inside the frame loop (light
  * refresh + graph execution = launches), out[2] = seconds of those spent blocked on GPU back-pressure. */

@@ -466,6 +466,13 @@ int gr_taa_resolve(gr_ctx *ctx, gr_stream stream, const gr_image *current, const
 int gr_taa_resolve_rows(gr_ctx *ctx, gr_stream stream, const gr_image *current, const gr_image *depth, const gr_image *mv,
                         const gr_image *history, const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality,
                         const gr_rows *rows);
+/* Row bands whose history only holds the rows around the band (no reference analogue): history_rows = the rows of
+ * `history` that carry last frame's values on this device.  A resolved pixel whose reprojection (motion vector, or depth + reproj)
+ * fetches a history row outside them stores 1 to *reach_flag, which must be memory the device can write and the host can read
+ * (gr_alloc_host): such a frame is not the single-device frame, and the caller has to say so.  Both NULL = gr_taa_resolve_rows. */
+int gr_taa_resolve_band(gr_ctx *ctx, gr_stream stream, const gr_image *current, const gr_image *depth, const gr_image *mv,
+                        const gr_image *history, const gr_image *out_color, const gr_image *out_history, const gr_push_taa *push, int quality,
+                        const gr_rows *rows, const gr_rows *history_rows, uint32_t *reach_flag);
 
 /* ---- depth hierarchy ---------------------------------------------------------------------------------------------------
  * HiZPassState::build_render_pass (renderer/post/spd.cpp:141-194) + assets/shaders/post/hiz.comp: turns the depth

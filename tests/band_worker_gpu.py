@@ -17,10 +17,12 @@ def main():
     w, h, lights, frames, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     post_aa = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     pre_aa = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+    reach = int(sys.argv[8]) if len(sys.argv) > 8 else 0  # gra_config.taa_history_reach_rows
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
     cam = synth.Camera(w, h)
-    a = gapp.Application(w, h, device=0, strip_index=rank, strip_count=world, post_aa=post_aa, pre_aa=pre_aa)
+    a = gapp.Application(w, h, device=0, strip_index=rank, strip_count=world, post_aa=post_aa, pre_aa=pre_aa, taa_history_reach_rows=reach)
+    assert not reach or a.strip_plan()["taa_exchange_rows"] > 0
     if pre_aa:  # the temporal resolve jitters the projection: it needs the camera, and motion vectors
         a.set_camera(np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16))
     else:

@@ -64,11 +64,22 @@ void aah_taa(const uint8_t *current, const uint8_t *depth, const uint8_t *mv, co
 	aah_taa_fmt(current, depth, mv, history, w, h, reproj16, quality, out_color, out_history, row_first, row_count, 0, 0);
 }
 // current_b10 / color_b10: the current frame / the resolved colour are B10G11R11_UFLOAT_PACK32 words (4 bytes per texel)
+void aah_taa_band(const uint8_t *current, const uint8_t *depth, const uint8_t *mv, const uint8_t *history, int w, int h, const float *reproj16, int quality,
+                  uint8_t *out_color, uint8_t *out_history, int row_first, int row_count, int current_b10, int color_b10, int hist_first, int hist_count,
+                  uint32_t *reach_flag);
 void aah_taa_fmt(const uint8_t *current, const uint8_t *depth, const uint8_t *mv, const uint8_t *history, int w, int h, const float *reproj16, int quality,
                  uint8_t *out_color, uint8_t *out_history, int row_first, int row_count, int current_b10, int color_b10)
 {
+	aah_taa_band(current, depth, mv, history, w, h, reproj16, quality, out_color, out_history, row_first, row_count, current_b10, color_b10, 0, 0, nullptr);
+}
+// history rows [hist_first, hist_first + hist_count) are the ones a band holds; *reach_flag is set when a pixel fetches another row
+void aah_taa_band(const uint8_t *current, const uint8_t *depth, const uint8_t *mv, const uint8_t *history, int w, int h, const float *reproj16, int quality,
+                  uint8_t *out_color, uint8_t *out_history, int row_first, int row_count, int current_b10, int color_b10, int hist_first, int hist_count,
+                  uint32_t *reach_flag)
+{
 	const RowSpan rows = span_of(h, row_first, row_count);
 	TaaImages im = {};
+	im.hist_first = hist_first, im.hist_end = hist_first + hist_count, im.reach_flag = reach_flag;
 	im.current = current, im.depth = depth, im.mv = mv, im.history = history;
 	im.out_color = out_color, im.out_history = out_history;
 	im.history_pitch = im.out_history_pitch = uint32_t(w * 8);

@@ -37,6 +37,25 @@ def gather_rows(img: np.ndarray, rank: int, world: int, chunk_rows: int) -> np.n
     return padded[:h]
 
 
+def gather_halo(img: np.ndarray, rank: int, world: int, chunk_rows: int, depth: int) -> np.ndarray:
+    """The TAA history under a bounded reach, as host/post/aa.cpp does it: every rank's first and last `depth` rows of its chunk
+    meet in one all-gather of 2 * depth rows per rank; a rank takes its upper neighbour's last block and its lower neighbour's
+    first block.  Everything else outside the own chunk is poison afterwards."""
+    h = img.shape[0]
+    own_first, own_end = min(rank * chunk_rows, h), min((rank + 1) * chunk_rows, h)
+    staging = np.zeros((world * 2 * depth,) + img.shape[1:], img.dtype)
+    staging[2 * depth * rank:2 * depth * rank + depth] = img[own_first:own_first + depth]
+    staging[2 * depth * rank + depth:2 * depth * (rank + 1)] = img[own_end - depth:own_end]
+    staging = gather_rows(staging, rank, world, 2 * depth)
+    out = np.full_like(img, POISON16)
+    out[own_first:own_end] = img[own_first:own_end]
+    if rank > 0:
+        out[own_first - depth:own_first] = staging[2 * depth * (rank - 1) + depth:2 * depth * rank]
+    if rank + 1 < world:
+        out[own_end:own_end + depth] = staging[2 * depth * (rank + 1):2 * depth * (rank + 1) + depth]
+    return out
+
+
 def edgy_hdr(width: int, height: int) -> np.ndarray:
     """The synthetic HDR frame with long edges laid over it, in three column regions: flat background with nearly vertical
     bars that step sideways by one texel every 66 rows (Z patterns whose far end is 2 x 32 texels away: SMAA's vertical
@@ -69,7 +88,9 @@ def aa_inputs(width: int, height: int):
     return depth, mv, np.ascontiguousarray(reproj.T).reshape(-1)  # column-major, as the push constant
 
 
-MODES = {"none": (0, 0), "fxaa": ("POST_AA_FXAA", 0), "smaa+taa": ("POST_AA_SMAA_ULTRA", "POST_AA_TAA_HIGH")}
+MODES = {"none": (0, 0), "fxaa": ("POST_AA_FXAA", 0), "smaa+taa": ("POST_AA_SMAA_ULTRA", "POST_AA_TAA_HIGH"),
+         "smaa+taa-halo": ("POST_AA_SMAA_ULTRA", "POST_AA_TAA_HIGH")}
+TAA_REACH_ROWS = 5  # make_motion_vectors moves by one row at most, + 3 for the 4 x 4 Catmull-Rom footprint and its rounding
 
 
 def main():
@@ -83,8 +104,11 @@ def main():
     mode = sys.argv[5] if len(sys.argv) > 5 else "none"
     post_aa, pre_aa = (getattr(gapp, v) if isinstance(v, str) else v for v in MODES[mode])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    plan = multigpu.plan_numpy(rank, world, width, height, post_aa=post_aa, pre_aa=pre_aa)
+    halo = mode.endswith("-halo")
+    mode = mode.replace("-halo", "")
+    plan = multigpu.plan_numpy(rank, world, width, height, post_aa=post_aa, pre_aa=pre_aa, taa_history_reach_rows=TAA_REACH_ROWS if halo else 0)
     assert plan["count"] == world and plan["index"] == rank
+    assert not halo or plan["taa_exchange_rows"] > 0
 
     hdr = edgy_hdr(width, height)
     if mode == "smaa+taa":
@@ -100,7 +124,12 @@ def main():
         if mode == "smaa+taa":
             color, hist = orc.taa_resolve(lit, depth, mv, taa_history, reproj, 2)
             lit = keep_rows(color, plan["taa"], POISON16)
-            taa_history = gather_rows(keep_rows(hist, plan["taa"], POISON16), rank, world, plan["out_chunk_rows"])
+            if halo:
+                taa_history = gather_halo(keep_rows(hist, plan["taa"], POISON16), rank, world, plan["out_chunk_rows"], plan["taa_exchange_rows"])
+                held = plan["taa_history_held"]
+                assert (taa_history[held[0]:held[0] + held[1]] != POISON16).any(axis=(1, 2)).all()
+            else:
+                taa_history = gather_rows(keep_rows(hist, plan["taa"], POISON16), rank, world, plan["out_chunk_rows"])
         t = keep_rows(orc.bloom_threshold(lit, *sz[0], lum3=lum), plan["threshold"], POISON16)
         d0 = keep_rows(orc.bloom_downsample(t, *sz[1]), plan["d0"], POISON16)
         d1 = keep_rows(orc.bloom_downsample(d0, *sz[2]), plan["d1"], POISON16)

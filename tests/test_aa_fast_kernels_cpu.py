@@ -151,6 +151,36 @@ def test_taa_kernel_within_the_resolve_tolerance(host, w, h, quality):
     assert (band[:7] == 0x1234).all() and (band[27:] == 0x1234).all()
 
 
+@pytest.mark.parametrize("quality", [0, 2])
+def test_taa_band_says_when_a_pixel_reaches_outside_the_history_rows_it_holds(host, quality):
+    """Row bands with a halo of history rows (gr_taa_resolve_band): the band's pixels equal the whole-frame launch as long as every
+    fetched history row is among the rows held -- rows outside them are poisoned here -- and the flag is raised, by exactly the
+    launches whose motion reaches further than the halo, otherwise."""
+    w, h = 64, 96
+    cur, depth, _, reproj = taa_inputs(w, h)
+    prev = orc.taa_resolve(synth.make_hdr(w, h, seed=11), depth, np.zeros((h, w, 2), np.uint16), None, reproj, quality)[1]
+    first, count = 32, 32
+    for rows_of_motion, halo, expect_flag in ((3.0, 8, False), (3.0, 2, True), (-6.5, 9, False), (-6.5, 5, True), (0.0, 3, False)):
+        mv = np.zeros((h, w, 2), np.float32)
+        mv[..., 1] = rows_of_motion / h  # history position = v - mv: rows_of_motion rows up (or down) everywhere
+        mv[0, 0, 1] = 1e-3               # (a pixel outside the band may point anywhere)
+        mv16 = mv.astype(np.float16).view(np.uint16)
+        full_c, full_h = np.zeros((h, w, 4), np.uint16), np.zeros((h, w, 4), np.uint16)
+        host.aah_taa(p(cur), p(depth), p(mv16), p(prev), w, h, p(reproj), quality, p(full_c), p(full_h), 0, 0)
+        held_first, held_end = max(first - halo, 0), min(first + count + halo, h)
+        poisoned = prev.copy()
+        poisoned[:held_first] = 0x7bff
+        poisoned[held_end:] = 0x7bff
+        band_c, band_h = np.zeros_like(full_c), np.zeros_like(full_h)
+        flag = np.zeros(1, np.uint32)
+        host.aah_taa_band(p(cur), p(depth), p(mv16), p(poisoned), w, h, p(reproj), quality, p(band_c), p(band_h), first, count, 0, 0,
+                          held_first, held_end - held_first, p(flag))
+        assert bool(flag[0]) == expect_flag, (rows_of_motion, halo, int(flag[0]))
+        if not expect_flag:
+            np.testing.assert_array_equal(band_c[first:first + count], full_c[first:first + count])
+            np.testing.assert_array_equal(band_h[first:first + count], full_h[first:first + count])
+
+
 def stair_card(w, h):
     """Long straight and stair-stepped edges, so that the orthogonal searches run to their limit (32 steps at Ultra) and the
     diagonal ones find real diagonals; plus the test card's features."""

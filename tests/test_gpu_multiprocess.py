@@ -28,12 +28,14 @@ def launch(world, script_args, port, extra_env=None, timeout=420):
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
 
 
-@pytest.mark.parametrize("world,w,h,post_aa,pre_aa", [(2, 480, 272, 0, 0), (3, 512, 250, 0, 0), (2, 480, 272, gapp.POST_AA_FXAA, 0),
-                                                       (2, 480, 272, gapp.POST_AA_SMAA_ULTRA, gapp.POST_AA_TAA_HIGH)])
-def test_ranks_in_separate_processes_assemble_the_single_process_frame(tmp_path, world, w, h, post_aa, pre_aa):
+@pytest.mark.parametrize("world,w,h,post_aa,pre_aa,reach", [(2, 480, 272, 0, 0, 0), (3, 512, 250, 0, 0, 0), (2, 480, 272, gapp.POST_AA_FXAA, 0, 0),
+                                                             (2, 480, 272, gapp.POST_AA_SMAA_ULTRA, gapp.POST_AA_TAA_HIGH, 0),
+                                                             (3, 320, 600, gapp.POST_AA_FXAA, gapp.POST_AA_TAA_HIGH, 6)])
+def test_ranks_in_separate_processes_assemble_the_single_process_frame(tmp_path, world, w, h, post_aa, pre_aa, reach):
+    """reach > 0: the TAA history bands exchange boundary rows only (gra_config.taa_history_reach_rows)."""
     frames, lights = 6, 200
     out = str(tmp_path / "rank{rank}.npz")
-    r = launch(world, [os.path.join(ROOT, "tests", "band_worker_gpu.py"), str(w), str(h), str(lights), str(frames), out, str(post_aa), str(pre_aa)],
+    r = launch(world, [os.path.join(ROOT, "tests", "band_worker_gpu.py"), str(w), str(h), str(lights), str(frames), out, str(post_aa), str(pre_aa), str(reach)],
                29600 + (os.getpid() % 300))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     cam = synth.Camera(w, h)

@@ -23,9 +23,9 @@ def make_app(w, h, cam, gbuf, descs, mv=None, **kw):
     return a
 
 
-def run_emulated_ranks(world, frames, make, reads):
+def run_emulated_ranks(world, frames, make, reads, expect_errors=False):
     """`world` instances on the one device, one thread each, bands meeting through LocalExchange; returns got[rank][frame] =
-    tuple of the `reads` resources (backbuffer first) and the plans."""
+    tuple of the `reads` resources (backbuffer first) and the plans (expect_errors: the errors the ranks raised instead)."""
     lib = capi.load_library()
     lib.gr_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.gr_sync.argtypes = [C.c_void_p, C.c_void_p]
@@ -58,6 +58,10 @@ def run_emulated_ranks(world, frames, make, reads):
         t.start()
     for t in threads:
         t.join(timeout=180)
+    if expect_errors:
+        for a in apps:
+            a.close()
+        return errors
     assert not errors, errors
     plans = [a.strip_plan() for a in apps]
     for a in apps:
@@ -95,6 +99,49 @@ def test_emulated_ranks_with_anti_aliasing_reproduce_the_single_device_frame(wor
         for f in range(frames):
             for i, name in enumerate(["backbuffer"] + reads):
                 np.testing.assert_array_equal(got[rank][f][i], want[f][i], err_msg=f"rank {rank} frame {f}: {name}")
+
+
+@pytest.mark.parametrize("world,w,h,post,quality", [(2, 480, 544, "POST_AA_SMAA_LOW", "POST_AA_TAA_HIGH"), (3, 320, 600, "POST_AA_FXAA", "POST_AA_TAA_LOW"),
+                                                    (4, 256, 1024, 0, "POST_AA_TAA_MEDIUM")])
+def test_taa_history_meets_its_neighbours_rows_only_under_a_bounded_reach(world, w, h, post, quality):
+    """gra_config.taa_history_reach_rows: the history bands exchange their boundary rows with the neighbouring
+    ranks in one small all-gather instead of meeting whole in every rank; frames (backbuffer, exposure) are still the
+    single-instance frames bit for bit over 5 frames, and each rank's history is the single instance's on the rows it holds."""
+    frames, reach = 5, 6  # make_motion_vectors moves by one row; + the Catmull-Rom footprint, + the jitter
+    kw = dict(post_aa=getattr(gapp, post) if post else 0, pre_aa=getattr(gapp, quality))
+    cam = synth.Camera(w, h)
+    gbuf, descs, mv = synth.make_gbuffer(cam), synth.make_lights(cam, 150), synth.make_motion_vectors(w, h)
+    reads = ["average-luminance", "HDR-resolved-history"]
+    ref = make_app(w, h, cam, gbuf, descs, mv, **kw)
+    want = []
+    for _ in range(frames):
+        ref.render_frames(1)
+        want.append(tuple([ref.read_backbuffer().copy()] + [ref.read(name).copy() for name in reads]))
+    ref.close()
+    got, plans = run_emulated_ranks(world, frames, lambda **strip: make_app(w, h, cam, gbuf, descs, mv, taa_history_reach_rows=reach, **kw, **strip), reads)
+    for rank in range(world):
+        depth, held = plans[rank]["taa_exchange_rows"], plans[rank]["taa_history_held"]
+        assert 0 < depth < plans[rank]["out_chunk_rows"] and held is not None
+        rows = slice(held[0], held[0] + held[1])
+        for f in range(frames):
+            np.testing.assert_array_equal(got[rank][f][0], want[f][0], err_msg=f"rank {rank} frame {f}: backbuffer")
+            np.testing.assert_array_equal(got[rank][f][1], want[f][1], err_msg=f"rank {rank} frame {f}: exposure")
+            np.testing.assert_array_equal(got[rank][f][2][rows], want[f][2][rows], err_msg=f"rank {rank} frame {f}: history rows held")
+
+
+@pytest.mark.filterwarnings("ignore::pytest.PytestUnraisableExceptionWarning")  # the other rank's barrier breaks inside its callback
+def test_motion_beyond_the_history_reach_is_reported_not_rendered_silently():
+    """A pixel whose motion vector points further than taa_history_reach_rows fetches history rows its rank does not hold: the
+    resolve notices, and the next frame / sync / read-back of that rank fails with an error that names the setting."""
+    world, w, h, reach = 2, 256, 512, 6
+    cam = synth.Camera(w, h)
+    gbuf, descs = synth.make_gbuffer(cam), synth.make_lights(cam, 50)
+    mv = np.zeros((h, w, 2), np.float32)
+    mv[:, :, 1] = -40.0 / h  # history 40 rows further down: the upper band's last rows reach into the lower band
+    mv16 = mv.astype(np.float16).view(np.uint16)
+    errors = run_emulated_ranks(world, 4, lambda **strip: make_app(w, h, cam, gbuf, descs, mv16, pre_aa=gapp.POST_AA_TAA_HIGH, taa_history_reach_rows=reach, **strip),
+                                [], expect_errors=True)
+    assert errors and any("taa_history_reach_rows" in message for _, message in errors), errors
 
 
 @pytest.mark.parametrize("world,w,h,lights", [(2, 480, 272, 300), (3, 333, 250, 200), (4, 512, 512, 64)])

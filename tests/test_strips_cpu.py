@@ -49,19 +49,21 @@ def test_weak_scaled_frames():
 
 
 @pytest.mark.parametrize("mode,width,height", [("none", 256, 192), ("none", 200, 150), ("fxaa", 200, 150), ("smaa+taa", 256, 384),
-                                               ("smaa+taa", 200, 150)])
+                                               ("smaa+taa", 200, 150), ("smaa+taa-halo", 256, 384)])
 def test_two_rank_gloo_bands_equal_single_process_frame(tmp_path, mode, width, height):
     """Two processes, one band each, everything a rank did not compute itself poisoned before the next stage reads it: the
     halos StripPlan keeps for the bloom pyramid, for FXAA, for SMAA Ultra's 32-step searches (the frame carries long straight
     and diagonal edges through the band boundary) and for the TAA neighbourhood must be enough, and the all-gathers (1/8
-    level, TAA history, output) must land the chunks where they belong."""
+    level, TAA history, output) must land the chunks where they belong.  "-halo": the history bands exchange boundary rows
+    with the neighbour only (taa_history_reach_rows), every other row of the history is poison on that rank."""
     import strip_worker
     from granite_amd.data import load_smaa_luts
+    worker_mode, mode = mode, mode.replace("-halo", "")
     frames = 3 if mode == "smaa+taa" else 2
     out = str(tmp_path / "rank{rank}.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() % 2000)), WORLD_SIZE="2",
                OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "strip_worker.py"), str(width), str(height), str(frames), out, mode],
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "strip_worker.py"), str(width), str(height), str(frames), out, worker_mode],
                               env=dict(env, RANK=str(r))) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
@@ -128,3 +130,36 @@ def test_plan_with_anti_aliasing(world, width, height, post, pre):
             assert u0[0] <= max((tm[0] + 0.5) * 0.25 - 0.5, 0) and u0[0] + u0[1] - 1 >= min(int((tm[0] + tm[1] - 0.5) * 0.25 - 0.5) + 1, p["height"] // 4 - 1)
     if post:
         assert (covered == 1).all()
+
+
+@pytest.mark.parametrize("world,width,height,post,reach", [(2, 3840, 2160, "POST_AA_SMAA_ULTRA", 12), (8, 7680, 8640, "POST_AA_SMAA_ULTRA", 40),
+                                                           (3, 333, 250, 0, 5), (4, 512, 512, "POST_AA_SMAA_LOW", 8), (8, 64, 40, 0, 4)])
+def test_plan_of_the_taa_history_exchange_under_a_bounded_reach(world, width, height, post, reach):
+    """gra_config.taa_history_reach_rows: one exchange depth for all ranks (the chunks of the all-gather are uniform) = the deepest
+    halo any rank resolves beyond its chunk + the reach; what a rank holds afterwards covers every row its resolve band can fetch
+    within the reach; bands thinner than that depth fall back to whole-band all-gathers (depth 0), on every rank alike."""
+    from granite_amd import app as gapp
+    post_v = getattr(gapp, post) if post else 0
+    plans = [multigpu.plan_numpy(r, world, width, height, post_aa=post_v, pre_aa=gapp.POST_AA_TAA_HIGH, taa_history_reach_rows=reach) for r in range(world)]
+    depths = {p["taa_exchange_rows"] for p in plans}
+    assert len(depths) == 1
+    depth = depths.pop()
+    chunk = plans[0]["out_chunk_rows"]
+    thinnest = min(min(chunk, height - r * chunk) for r in range(world))
+    if depth == 0:
+        halo = max(max(r * chunk - p["taa"][0], p["taa"][0] + p["taa"][1] - min((r + 1) * chunk, height)) for r, p in enumerate(plans))
+        assert halo + reach > thinnest  # only then
+        assert all(p["taa_history_held"] is None for p in plans)
+        return
+    assert depth <= thinnest
+    for r, p in enumerate(plans):
+        assert p["taa_history_reach_rows"] == reach
+        first, count = p["taa_history_held"]
+        taa_first, taa_count = p["taa"]
+        assert first <= max(taa_first - reach, 0) and first + count >= min(taa_first + taa_count + reach, height)
+        # ... and it is the own chunk grown by the depth: the neighbours alone supply the rest
+        own_first, own_end = r * chunk, min((r + 1) * chunk, height)
+        assert (first, first + count) == (max(own_first - depth, 0), min(own_end + depth, height))
+    # without a reach nothing changes
+    plain = multigpu.plan_numpy(0, world, width, height, post_aa=post_v, pre_aa=gapp.POST_AA_TAA_HIGH)
+    assert plain["taa_exchange_rows"] == 0 and plain["taa"] == plans[0]["taa"] and plain["lighting"] == plans[0]["lighting"]
