@@ -399,6 +399,23 @@ static bool centre_taps_exact(gr_ctx *ctx, uint32_t n, float inv)
 	ctx->centre_taps_exact[key] = ok;
 	return ok;
 }
+// Cached per context: do the diagonal searches' coordinate walks (up to 17 steps either way; in x also from a quarter texel beside the
+// centre) land on texels along an axis of n texels?
+static bool diag_walk_exact(gr_ctx *ctx, uint32_t n, float inv, bool with_quarter)
+{
+	const uint64_t key = (uint64_t(n) << 32) | __builtin_bit_cast(uint32_t, inv);
+	auto &cache = with_quarter ? ctx->diag_walk_exact_x : ctx->diag_walk_exact_y;
+	{
+		std::lock_guard<std::mutex> holder{ctx->lock};
+		auto it = cache.find(key);
+		if (it != cache.end())
+			return it->second;
+	}
+	const bool ok = aa::axis_walk_exact(int(n), inv, 17, false) && (!with_quarter || aa::axis_walk_exact(int(n), inv, 17, true));
+	std::lock_guard<std::mutex> holder{ctx->lock};
+	cache[key] = ok;
+	return ok;
+}
 static bool use_fast_aa(gr_ctx *ctx, uint32_t w, uint32_t h, float inv_w, float inv_h)
 {
 	static const bool forced_generic = gr_measurement_switch("GRANITE_AA_GENERIC") != nullptr;
@@ -624,7 +641,10 @@ int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edg
 		const int tile_last = min(planes.col_words - 1, (int(span.end) + FAST_BH + 192 + SMAA_BITS_PAD) >> 6);
 		const int tiles = planes.row_words * (tile_last - tile_first + 1);
 		SmaaWeightsBitsArgs B = {static_cast<const uint8_t *>(edges->ptr), edges->pitch_bytes, int(edges->width), int(edges->height), planes, S.area, S.search, S.rt, S.P,
-		                         centre_taps_exact(ctx, edges->width, push->rt_metrics[0]) && centre_taps_exact(ctx, edges->height, push->rt_metrics[1])};
+		                         centre_taps_exact(ctx, edges->width, push->rt_metrics[0]) && centre_taps_exact(ctx, edges->height, push->rt_metrics[1]), 0};
+		static const bool float_walks = gr_measurement_switch("GRANITE_SMAA_FLOAT_DIAG_WALKS") != nullptr;
+		B.diag_walks_exact = S.P.diag && B.centres_snap && !float_walks && diag_walk_exact(ctx, edges->width, push->rt_metrics[0], true) &&
+		                     diag_walk_exact(ctx, edges->height, push->rt_metrics[1], false);
 		gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_blend_weight"};
 		hipLaunchKernelGGL(k_smaa_pack_edges, dim3(tiles), dim3(256), 0, gr_to_stream(stream), B.edges, B.edges_pitch, B.w, B.h, planes,
 		                   tile_first, tile_last - tile_first + 1);

@@ -19,6 +19,13 @@
 #else
 #define AA_HD inline
 #endif
+// A value every lane of the wave holds alike (a wave index, a workgroup-wide count read from LDS): on the device it is moved to a
+// scalar register, so what is computed from it runs on the scalar unit.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AA_WAVE_UNIFORM(v) uint32_t(__builtin_amdgcn_readfirstlane(int(v)))
+#else
+#define AA_WAVE_UNIFORM(v) uint32_t(v)
+#endif
 
 namespace aa
 {
@@ -83,6 +90,32 @@ inline bool axis_taps_exact(int n, float inv, const int *ks, int nk)
 				return false;
 		}
 	}
+	return true;
+}
+
+// The diagonal searches of SMAA (SMAA.hlsl:831-868) walk a coordinate by one texel per step from a pixel centre -- in x from the
+// centre itself or from a quarter of a texel beside it (SMAASearchDiag2: coord.x += 0.25 * rt.x) -- with one fma per step.  For an
+// axis of n texels: does step k = 1 .. steps of either direction, from every pixel p, resolve to texel p +- k with the weight the
+// search's decode expects (0: the texel itself; about 0.25: SMAADecodeDiagBilinearAccess rounds the pair to (R of the next texel,
+// G of this one) for any weight in [0.2, 0.3])?  Then the walk can be done on integer texel positions.
+inline bool axis_walk_exact(int n, float inv, int steps, bool quarter)
+{
+	for (int p = 0; p < n; p++)
+		for (int dir = -1; dir <= 1; dir += 2)
+		{
+			float c = (float(p) + 0.5f) * inv;
+			if (quarter)
+				c += 0.25f * inv;
+			for (int k = 1; k <= steps; k++)
+			{
+				c = fmaf(inv, float(dir), c);
+				int i0;
+				float a;
+				linear_axis(c * float(n) - 0.5f, i0, a);
+				if (i0 != p + dir * k || (quarter ? fabsf(a - 0.25f) > 0.05f : a != 0.0f))
+					return false;
+			}
+		}
 	return true;
 }
 

@@ -47,12 +47,28 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_fxaa_fast(const uint8_t *i
 	__shared__ uint32_t s_wave_count[WAVES];
 	const int bx = blockIdx.x * FAST_BW, by = int(rows.first) + blockIdx.y * FAST_BH;
 	const int tid = threadIdx.y * FAST_BW + threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	// A workgroup whose tile (halo included) lies inside the image -- all but the frame of workgroups along the border -- needs no
+	// clamping: neighbours at constant offsets from one address, the tile staged two texels per 8-byte load.
+	const bool interior = bx >= HALO && by >= HALO && bx + FAST_BW + HALO <= w && by + FAST_BH + HALO <= h && (in_pitch & 7u) == 0u &&
+	                      (reinterpret_cast<uintptr_t>(in) & 7u) == 0u;
 	{
 		const int x = bx + threadIdx.x, y = by + threadIdx.y;
 		const bool inside = x < w && y < int(rows.end);
-		const uint32_t centre = load_rgba8_clamped(in, in_pitch, w, h, x, y);
-		const bool flat = aa::fxaa_corners_equal(load_rgba8_clamped(in, in_pitch, w, h, x - 1, y - 1), load_rgba8_clamped(in, in_pitch, w, h, x + 1, y - 1),
-		                                         load_rgba8_clamped(in, in_pitch, w, h, x - 1, y + 1), load_rgba8_clamped(in, in_pitch, w, h, x + 1, y + 1));
+		uint32_t centre;
+		bool flat;
+		if (interior)
+		{
+			const uint8_t *p = in + (uint32_t(y) * in_pitch + uint32_t(x) * 4u);
+			centre = *reinterpret_cast<const uint32_t *>(p);
+			flat = aa::fxaa_corners_equal(*reinterpret_cast<const uint32_t *>(p - in_pitch - 4), *reinterpret_cast<const uint32_t *>(p - in_pitch + 4),
+			                              *reinterpret_cast<const uint32_t *>(p + in_pitch - 4), *reinterpret_cast<const uint32_t *>(p + in_pitch + 4));
+		}
+		else
+		{
+			centre = load_rgba8_clamped(in, in_pitch, w, h, x, y);
+			flat = aa::fxaa_corners_equal(load_rgba8_clamped(in, in_pitch, w, h, x - 1, y - 1), load_rgba8_clamped(in, in_pitch, w, h, x + 1, y - 1),
+			                              load_rgba8_clamped(in, in_pitch, w, h, x - 1, y + 1), load_rgba8_clamped(in, in_pitch, w, h, x + 1, y + 1));
+		}
 		const bool work = inside && !flat;
 		const uint64_t mine = __ballot(work);
 		if (lane == 0)
@@ -63,25 +79,41 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_fxaa_fast(const uint8_t *i
 		uint32_t total = 0, before = 0;
 		for (int i = 0; i < WAVES; i++)
 		{
-			before += i < wave ? s_wave_count[i] : 0u;
-			total += s_wave_count[i];
+			const uint32_t count = AA_WAVE_UNIFORM(s_wave_count[i]);
+			before += i < int(AA_WAVE_UNIFORM(wave)) ? count : 0u;
+			total += count;
 		}
 		if (total == 0u)
 			return;
 		if (work)
 			s_list[before + uint32_t(__popcll(mine & ((1ull << lane) - 1ull)))] = uint16_t(tid);
 	}
-	for (int i = tid; i < TW * TH; i += THREADS)
-	{
-		const int ty = i / TW, tx = i - ty * TW;
-		const uint32_t t = load_rgba8_clamped(in, in_pitch, w, h, bx - HALO + tx, by - HALO + ty);
+	const auto decode = [](uint32_t t) {
 		const float r = aa::unorm8_decode(t & 255u), g = aa::unorm8_decode((t >> 8) & 255u), b = aa::unorm8_decode((t >> 16) & 255u);
-		s_dec[i] = make_float4(r, g, b, aa::luma_of(r, g, b, aa::FXAA_LUMA_R, aa::FXAA_LUMA_G, aa::FXAA_LUMA_B));
+		return make_float4(r, g, b, aa::luma_of(r, g, b, aa::FXAA_LUMA_R, aa::FXAA_LUMA_G, aa::FXAA_LUMA_B));
+	};
+	if (interior)
+	{
+		static_assert(TW % 2 == 0, "two texels per load");
+		const uint8_t *origin = in + (uint32_t(by - HALO) * in_pitch + uint32_t(bx - HALO) * 4u);
+		for (int i = tid; i < (TW / 2) * TH; i += THREADS)
+		{
+			const int ty = i / (TW / 2), tx = 2 * (i - ty * (TW / 2));
+			const uint2 t = *reinterpret_cast<const uint2 *>(origin + (uint32_t(ty) * in_pitch + uint32_t(tx) * 4u));
+			s_dec[ty * TW + tx] = decode(t.x);
+			s_dec[ty * TW + tx + 1] = decode(t.y);
+		}
 	}
+	else
+		for (int i = tid; i < TW * TH; i += THREADS)
+		{
+			const int ty = i / TW, tx = i - ty * TW;
+			s_dec[i] = decode(load_rgba8_clamped(in, in_pitch, w, h, bx - HALO + tx, by - HALO + ty));
+		}
 	__syncthreads();
 	uint32_t total = 0;
 	for (int i = 0; i < WAVES; i++)
-		total += s_wave_count[i];
+		total += AA_WAVE_UNIFORM(s_wave_count[i]);
 	const FxaaTile tile = {s_dec, bx - HALO, by - HALO};
 	for (uint32_t i = uint32_t(tid); i < total; i += uint32_t(THREADS))
 	{

@@ -46,7 +46,7 @@ struct gr_ctx
 	std::map<void *, SmaaBits> smaa_bits;
 
 	// aa.hip: (axis length, 1 / length bits) -> "pixel-centre taps along this axis are texel fetches" (aa_core.hpp: axis_taps_exact)
-	std::map<uint64_t, bool> centre_taps_exact;
+	std::map<uint64_t, bool> centre_taps_exact, diag_walk_exact_x, diag_walk_exact_y;
 
 	bool timing_enabled = false;
 	std::string timing_filter; // empty = every launcher

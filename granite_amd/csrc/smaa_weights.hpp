@@ -79,8 +79,32 @@ struct SmaaWeights
 		e.z = e.z * fabsf(5.0f * e.z - 5.0f * 0.75f);
 		return mk4(roundf(e.x), roundf(e.y), roundf(e.z), roundf(e.w));
 	}
+	// The same walks on integer texel positions, for an accessor that holds the edge flags as bits and an image whose walks are
+	// proven to land on texels (aa_core.hpp: axis_walk_exact).  SECOND: the tap sits a quarter of a texel to the right of a
+	// centre, and the decoded sample is (R of the texel to the right, G of this one).
+	template <bool SECOND>
+	__device__ __forceinline__ v2 search_diag_bits(v2 dir, v2 &e) const
+	{
+		int x = px, y = py;
+		const int dx = int(dir.x), dy = int(dir.y);
+		float z = -1.0f, wsum = 1.0f;
+		while (z < float(P.max_search_steps_diag - 1) && wsum > 0.9f)
+		{
+			x += dx;
+			y += dy;
+			z += 1.0f;
+			e = edges.template texel<false>(x, y);
+			if (SECOND)
+				e.x = edges.template texel<false>(x + 1, y).x;
+			wsum = dot2(e, mk2(0.5f, 0.5f));
+		}
+		return mk2(z, wsum);
+	}
 	__device__ v2 search_diag1(v2 texcoord, v2 dir, v2 &e) const
 	{
+		if constexpr (Edges::HAS_RUNS)
+			if (edges.diag_exact)
+				return search_diag_bits<false>(dir, e);
 		v4 coord = mk4(texcoord.x, texcoord.y, -1.0f, 1.0f);
 		while (coord.z < float(P.max_search_steps_diag - 1) && coord.w > 0.9f)
 		{
@@ -94,6 +118,9 @@ struct SmaaWeights
 	}
 	__device__ v2 search_diag2(v2 texcoord, v2 dir, v2 &e) const
 	{
+		if constexpr (Edges::HAS_RUNS)
+			if (edges.diag_exact)
+				return search_diag_bits<true>(dir, e);
 		v4 coord = mk4(texcoord.x, texcoord.y, -1.0f, 1.0f);
 		coord.x += 0.25f * rt.x;
 		while (coord.z < float(P.max_search_steps_diag - 1) && coord.w > 0.9f)
@@ -527,6 +554,7 @@ struct EdgeBitTiles
 	int x0, y0, col_y0;
 	int w, h;
 	bool centres_snap; // pixel-centre coordinates of this image resolve to texel fetches (aa_core.hpp: axis_taps_exact)
+	bool diag_exact;   // ... and so does every step of the diagonal searches' coordinate walks (aa_core.hpp: axis_walk_exact)
 
 	// 64 bits starting at bit p of a staged row / column
 	__device__ __forceinline__ static uint64_t window(const uint32_t *words, int p)
@@ -666,6 +694,7 @@ struct SmaaWeightsBitsArgs
 	v4 rt;
 	SmaaPreset P;
 	int centres_snap;
+	int diag_walks_exact;
 };
 
 // SMAABlendingWeightCalculationPS over the bit planes.  The reference runs the quad under a depth mask EQUAL to the edge pass's
@@ -698,8 +727,9 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_weights_bits(SmaaWeig
 		uint32_t total = 0, before = 0;
 		for (int i = 0; i < WAVES; i++)
 		{
-			before += i < wave ? s_wave_count[i] : 0u;
-			total += s_wave_count[i];
+			const uint32_t count = AA_WAVE_UNIFORM(s_wave_count[i]);
+			before += i < int(AA_WAVE_UNIFORM(wave)) ? count : 0u;
+			total += count;
 		}
 		if (total == 0u)
 			return;
@@ -731,8 +761,8 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_weights_bits(SmaaWeig
 	__syncthreads();
 	uint32_t total = 0;
 	for (int i = 0; i < WAVES; i++)
-		total += s_wave_count[i];
-	SmaaWeights<EdgeBitTiles> S = {{s_row_r, s_row_g, s_col_r, s_col_g, bx, by, col_y0, A.w, A.h, A.centres_snap != 0}, A.area, A.search, A.rt, A.P};
+		total += AA_WAVE_UNIFORM(s_wave_count[i]);
+	SmaaWeights<EdgeBitTiles> S = {{s_row_r, s_row_g, s_col_r, s_col_g, bx, by, col_y0, A.w, A.h, A.centres_snap != 0, A.diag_walks_exact != 0}, A.area, A.search, A.rt, A.P};
 	for (uint32_t i = uint32_t(tid); i < total; i += uint32_t(THREADS))
 	{
 		const int t = s_list[i], x = bx + (t & (FAST_BW - 1)), y = by + (t / FAST_BW);

@@ -24,6 +24,7 @@ static RowSpan span_of(int h, int first, int count)
 }
 
 extern "C" {
+int aah_diag_walk_exact(int n, float inv, int quarter) { return aa::axis_walk_exact(n, inv, 17, quarter != 0) ? 1 : 0; }
 int aah_centre_taps_exact(int n, float inv)
 {
 	static const int ks[] = {-2, -1, 0, 1, 2};
@@ -136,7 +137,9 @@ void aah_smaa_weights(const uint8_t *edges, int w, int h, const uint8_t *area_rg
 	emu::launch(k_smaa_pack_edges, dim3(tiles), dim3(256), edges, uint32_t(w * 2), w, h, planes, tile_first, tile_last - tile_first + 1);
 	SmaaWeightsBitsArgs B = {edges, uint32_t(w * 2), w, h, planes, {area.data(), 160, 560}, {search.data(), 64, 16},
 	                         v4{1.0f / float(w), 1.0f / float(h), float(w), float(h)}, preset_of(quality),
-	                         aah_centre_taps_exact(w, 1.0f / float(w)) && aah_centre_taps_exact(h, 1.0f / float(h)) && !getenv("AAH_NO_CENTRE_SNAP")};
+	                         aah_centre_taps_exact(w, 1.0f / float(w)) && aah_centre_taps_exact(h, 1.0f / float(h)) && !getenv("AAH_NO_CENTRE_SNAP"), 0};
+	B.diag_walks_exact = B.centres_snap && !getenv("AAH_FLOAT_DIAG_WALKS") && aa::axis_walk_exact(w, 1.0f / float(w), 17, false) &&
+	                     aa::axis_walk_exact(w, 1.0f / float(w), 17, true) && aa::axis_walk_exact(h, 1.0f / float(h), 17, false);
 	emu::launch(k_smaa_weights_bits, dim3(div_up(w, FAST_BW), div_up(rows.count(), FAST_BH)), dim3(FAST_BW, FAST_BH), B, out, uint32_t(w * 4), rows);
 }
 }

@@ -59,7 +59,21 @@ def test_pixel_centre_taps_are_texel_fetches_at_every_size_in_use(host):
     assert not host.aah_centre_taps_exact(100000, np.float32(1.0) / np.float32(100000))
 
 
-@pytest.mark.parametrize("w,h,kind", SIZES)
+def test_diagonal_search_walks_land_on_texels_at_every_size_in_use(host):
+    """aa_core.hpp: axis_walk_exact -- 17 fma steps of one texel from any pixel centre (in x also from a quarter texel beside it)
+    resolve to the texel the integer walk of the weight kernel reads, for every axis up to 4K; beyond (7680: seventeen roundings
+    of a coordinate near 1.0 add up to more than the sampler's snap radius of 1/256 texel) the kernel keeps the float walk."""
+    host.aah_diag_walk_exact.argtypes = [C.c_int, C.c_float, C.c_int]
+    host.aah_diag_walk_exact.restype = C.c_int
+    for n in list(range(1, 300)) + [333, 480, 512, 1080, 1920, 2160, 3840, 4320]:
+        inv = np.float32(1.0) / np.float32(n)
+        assert host.aah_diag_walk_exact(n, inv, 0) and host.aah_diag_walk_exact(n, inv, 1), n
+    assert not host.aah_diag_walk_exact(7680, np.float32(1.0) / np.float32(7680), 0)
+
+
+# (134, 70) and (140, 64): workgroups whose tile lies inside the image (unclamped neighbours, two texels per load); (101, 60): the
+# same geometry with rows that are not 8-byte multiples, i.e. the clamped path everywhere
+@pytest.mark.parametrize("w,h,kind", SIZES + [(134, 70, "noise"), (140, 64, "pattern"), (101, 60, "noise")])
 def test_fxaa_kernel_equals_oracle(host, w, h, kind):
     src = source(w, h, kind)
     out = np.zeros_like(src)
@@ -67,8 +81,8 @@ def test_fxaa_kernel_equals_oracle(host, w, h, kind):
     np.testing.assert_array_equal(out, orc.fxaa(src, False))
 
 
-def test_fxaa_kernel_row_band(host):
-    w, h = 70, 61
+@pytest.mark.parametrize("w,h", [(70, 61), (134, 90)])
+def test_fxaa_kernel_row_band(host, w, h):
     src = noisy(w, h, 3)
     ref = orc.fxaa(src, False)
     out = np.full_like(src, 0xAB)
