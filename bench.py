@@ -54,7 +54,8 @@ SINGLE_GPU_WORKLOADS = {"config1_256_post_only", "config4_4k_smaa_taa", "config3
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy); the run measures its own too
 VALU_SIMDS, VALU_CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 2.0  # 256 CUs x 4 SIMD-32, max clock, wave64 fp32 op
 BRACKET_EVERY = 8  # the dominant kernel keeps its hipEvent bracket on every 8th launch of the timed region (short runs: >= 16 brackets, or all)
-MIN_BRACKETS = int(os.environ.get("GRANITE_BENCH_MIN_BRACKETS", "16"))
+MIN_BRACKETS = 16
+SETTLE_MS = float(os.environ.get("GRANITE_BENCH_SETTLE_MS", "40"))  # of untimed, un-bracketed load immediately in front of the timed region
 
 
 def parse_args():
@@ -300,7 +301,9 @@ def main():
     kctx.timing_enable(True)
     kctx.timing_set_filter(None)
     kctx.timing_reset()
+    t_warm = time.perf_counter()
     application.render_frames(max(args.warmup, 1), sync=True)
+    warm_ms_per_frame = 1000.0 * (time.perf_counter() - t_warm) / max(args.warmup, 1)
     per_kernel = kctx.timing_query()
     # the dominant kernel = the longest single-launch kernel among those whose algorithmic bytes SURVEY 8d states
     known = {k: v for k, v in per_kernel.items() if k in ALGO_BYTES_PER_PX and k != "chain" and v[0]}
@@ -313,7 +316,29 @@ def main():
     kctx.timing_set_filter(dominant)
     kctx.timing_set_sampling(max(1, min(BRACKET_EVERY, args.steps // MIN_BRACKETS)))
     kctx.timing_reset()
+    # ---- clock settle: the device reaches its sustained clocks only after tens of milliseconds of uninterrupted load, and the host-side
+    # pause above (the warm-up's per-kernel read-out) is enough to lose them again: a timed region that starts cold runs its first ~30
+    # frames 7 % slower (profiles/r03_launch_gap_experiments.txt: 20 frames at 0.260 ms cold, 0.248 after 40 frames of load, 0.242 after
+    # 160).  So the SAME frames run, un-bracketed and untimed, for about SETTLE_MS right up to the barrier that opens the timed region.
+    # They are warm-up beyond the W the command line asks for and are reported as such ("clock_settle"); GRANITE_BENCH_SETTLE_MS=0 = off.
+    settle_frames = 0
+    if SETTLE_MS > 0:
+        kctx.timing_enable(False)
+        if dist is None:
+            # the host runs at most three frames ahead of the device (staging ring), so its clock follows the device's load
+            t_settle = time.perf_counter()
+            while 1000.0 * (time.perf_counter() - t_settle) < SETTLE_MS and settle_frames < 8000:
+                application.render_frames(16, sync=False)
+                settle_frames += 16
+        else:
+            # the ranks render the same number of frames (a frame is a collective): a count agreed on beforehand
+            settle_frames = int(min(4000, max(100, -(-SETTLE_MS // max(warm_ms_per_frame, 1e-3)))))
+            t = torch.tensor([settle_frames], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            settle_frames = int(t.item())
+            application.render_frames(settle_frames, sync=False)
     barrier()
+    kctx.timing_enable(True)
     t0 = time.perf_counter()
     hs0 = application.host_stats()
     application.render_frames(args.steps, sync=False)
@@ -439,6 +464,9 @@ def main():
                   "algorithmic_bytes_per_frame": chain_bytes},
         "kernels_warmup": warm_breakdown,
         "host_busy_ms_per_step": 1000.0 * host_busy / args.steps,
+        # untimed frames in front of the timed region beyond --warmup (see "clock settle" above); 0 frames = switched off
+        "clock_settle": {"frames": settle_frames, "target_ms_of_load": SETTLE_MS,
+                         "why": "the device needs tens of ms of uninterrupted load to reach its sustained clocks; the warm-up's host-side read-out loses them again"},
     }
     if bands:
         # the assembled frame == the same frames of one executor rendering the whole target (null = check skipped / not possible)
