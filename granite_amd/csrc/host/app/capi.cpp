@@ -1,5 +1,6 @@
 // extern "C" surface of the harness (include/granite_app.h).  Exceptions from the C++ layer stop here.
 #include "image_space_app.hpp"
+#include "../timeline_trace.hpp"
 #include "../post/ssr.hpp"
 #include "../post/spd.hpp"
 #include "../gtx.hpp"
@@ -89,6 +90,7 @@ gra_app *gra_create(const gra_config *config, char *error, size_t error_size)
 void gra_destroy(gra_app *app)
 {
 	delete app;
+	Granite::TimelineTrace::get().flush(); // GRANITE_TIMELINE_TRACE: what the threads recorded goes to the file
 }
 
 const char *gra_last_error(gra_app *app)
@@ -412,7 +414,10 @@ int gra_get_allocated_bytes(gra_app *app, uint64_t *out)
 
 int gra_sync(gra_app *app)
 {
-	return guarded(app, [&]() { app->app->wait_idle(); });
+	return guarded(app, [&]() {
+		app->app->wait_idle();
+		Granite::TimelineTrace::get().flush();
+	});
 }
 
 static void fill_image_info(gra_resource_info *info, HIP::Image &img, int phys)

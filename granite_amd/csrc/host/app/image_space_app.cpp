@@ -1,6 +1,7 @@
 // Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
 // THIRD_PARTY_NOTICES.md at the repository root.
 #include "image_space_app.hpp"
+#include "../timeline_trace.hpp"
 #include <hip/hip_runtime_api.h>
 #include "../gtx.hpp"
 #include "../post/spd.hpp"
@@ -651,6 +652,7 @@ void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
 
 void ImageSpaceApplication::bake_render_graph()
 {
+	GRANITE_SCOPED_TIMELINE_EVENT("bake-render-graph");
 	// Keep feedback buffers (average luminance) alive across re-bakes (scene_viewer_application.cpp:1169,1315).
 	auto physical_buffers = graph.consume_physical_buffers();
 	graph.reset();
@@ -788,6 +790,7 @@ void ImageSpaceApplication::bake_render_graph()
 
 void ImageSpaceApplication::render_frame()
 {
+	GRANITE_SCOPED_TIMELINE_EVENT("render-frame");
 	auto &device = get_device();
 	const auto host_t0 = std::chrono::steady_clock::now();
 	check_taa_history_reach();

@@ -1,4 +1,5 @@
 #include "hip_device.hpp"
+#include "timeline_trace.hpp"
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <chrono>
@@ -336,7 +337,10 @@ void Device::next_frame_context()
 		if (hipEventQuery(static_cast<hipEvent_t>(fence)) != hipSuccess)
 		{
 			auto t0 = std::chrono::steady_clock::now();
-			throw_hip(hipEventSynchronize(static_cast<hipEvent_t>(fence)), "hipEventSynchronize");
+			{
+				GRANITE_SCOPED_TIMELINE_EVENT("wait-for-frame-in-flight"); // back-pressure: the host is three frames ahead
+				throw_hip(hipEventSynchronize(static_cast<hipEvent_t>(fence)), "hipEventSynchronize");
+			}
 			blocked_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 		}
 	}
@@ -345,6 +349,7 @@ void Device::next_frame_context()
 
 void Device::wait_idle()
 {
+	GRANITE_SCOPED_TIMELINE_EVENT("wait-idle");
 	for (auto &s : streams)
 		throw_hip(hipStreamSynchronize(static_cast<hipStream_t>(s)), "hipStreamSynchronize");
 	if (collective_stream)

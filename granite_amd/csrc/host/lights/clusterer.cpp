@@ -1,6 +1,7 @@
 // Follows MIT-licensed work (Granite, (c) 2017-2026 Hans-Kristian Arntzen; FidelityFX parts (c) 2021 Advanced Micro Devices, Inc.): see
 // THIRD_PARTY_NOTICES.md at the repository root.
 #include "clusterer.hpp"
+#include "../timeline_trace.hpp"
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
@@ -73,6 +74,7 @@ static bool same_parameters(const RenderParameters &a, const RenderParameters &b
 
 void LightClusterer::refresh(const RenderContext &context_, TaskComposer &)
 {
+	GRANITE_SCOPED_TIMELINE_EVENT("clusterer-refresh");
 	const RenderParameters &rp = context_.get_render_parameters();
 	{
 		std::unique_lock<std::mutex> holder{ahead.lock};
@@ -91,6 +93,7 @@ void LightClusterer::refresh(const RenderContext &context_, TaskComposer &)
 		}
 		ahead.result_valid = false;
 	}
+	GRANITE_SCOPED_TIMELINE_EVENT("light-sort-and-pack");
 	sort_and_pack(rp, sort_state, packed);
 }
 
@@ -143,6 +146,9 @@ void LightClusterer::wait_for_workers(std::unique_lock<std::mutex> &holder)
 
 void LightClusterer::worker_main(unsigned id)
 {
+	static const char *const names[] = {"light-worker-0", "light-worker-1", "light-worker-2", "light-worker-3"};
+	if (TimelineTrace::get().enabled())
+		TimelineTrace::get().set_thread_name(names[id & 3]);
 	uint64_t seen = 0;
 	for (;;)
 	{
@@ -156,8 +162,10 @@ void LightClusterer::worker_main(unsigned id)
 			rp = ahead.parameters;
 		}
 		// scene_lights is only modified after invalidate_prefetch() has seen this job finish
+		GRANITE_SCOPED_TIMELINE_EVENT("prefetch-next-frame-lights");
 		if (id == 0)
 		{
+			GRANITE_SCOPED_TIMELINE_EVENT("light-sort");
 			sort_lights(rp, ahead.sort_state);
 			begin_pack(rp, ahead.sort_state, ahead.result);
 			ahead.num_chunks = int((unsigned(ahead.result.parameters.num_lights) + PackChunk - 1) / PackChunk);

@@ -3,6 +3,7 @@
 // Granite::RenderGraph on HIP streams — see render_graph.hpp for what is kept from / dropped against
 // renderer/render_graph.cpp.  Reference line numbers are cited per function.
 #include "render_graph.hpp"
+#include "timeline_trace.hpp"
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <cmath>
@@ -864,6 +865,7 @@ void RenderGraph::setup_physical_image(HIP::Device &device_, unsigned attachment
 
 void RenderGraph::setup_attachments(HIP::Device &device_, HIP::ImageView *swapchain)
 {
+	GRANITE_SCOPED_TIMELINE_EVENT("setup-attachments");
 	const size_t count = physical_dimensions.size();
 	physical_attachments.assign(count, nullptr);
 	physical_buffers.resize(count);
@@ -1361,6 +1363,7 @@ void RenderGraph::build_aliases()
 
 void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &composer)
 {
+	GRANITE_SCOPED_TIMELINE_EVENT("enqueue-render-passes");
 	const size_t ring_slot = size_t(frame_counter++ % EventRing);
 	if (pass_done_event.size() < (passes.size() + 1) * EventRing)
 		pass_done_event.resize((passes.size() + 1) * EventRing, nullptr);
@@ -1507,7 +1510,11 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 			}
 		}
 
-		pass.build_render_pass(cmd, 0);
+		{
+			// one event per pass, named like the pass (render_graph.cpp:2261: cmd.begin_region(pass name))
+			ScopedTimelineEvent pass_event{TimelineTrace::get().enabled() ? TimelineTrace::get().intern(pass.get_name()) : ""};
+			pass.build_render_pass(cmd, 0);
+		}
 
 		if (enabled_timestamps)
 		{

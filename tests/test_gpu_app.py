@@ -394,3 +394,36 @@ def test_saved_state_restores_into_a_fresh_application(temporal):
     assert (c.read_backbuffer() != want[0][0]).any()
     b.close()
     c.close()
+
+
+def test_cpu_timeline_trace_of_a_few_frames(tmp_path):
+    """GRANITE_TIMELINE_TRACE=<file> (the reference's switch, threading/thread_group.cpp:174): the host layer writes a chrome://tracing
+    timeline -- frames, graph passes by name, the clusterer's refresh, the helper threads' prefetch, waits -- in the event shape of
+    util/timeline_trace_file.cpp.  Read by the environment once per process, hence the subprocess."""
+    import json, os, subprocess, sys
+    trace = str(tmp_path / "timeline.json")
+    code = ("import numpy as np\n"
+            "from granite_amd import app as gapp, synth\n"
+            "cam = synth.Camera(320, 180)\n"
+            "a = gapp.Application(320, 180)\n"
+            "a.set_render_parameters(cam.render_params())\n"
+            "a.set_lights(synth.make_lights(cam, 100))\n"
+            "a.upload_gbuffer(synth.make_gbuffer(cam))\n"
+            "a.render_frames(6, sync=True)\n"
+            "a.close()\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GRANITE_TIMELINE_TRACE=trace), cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    events = [e for e in json.load(open(trace)) if e["ph"] in "BE"]
+    begun = {}
+    for e in events:
+        if e["ph"] == "B":
+            begun.setdefault((e["tid"], e["name"]), 0)
+            begun[(e["tid"], e["name"])] += 1
+    count = lambda name: sum(n for (tid, nm), n in begun.items() if nm == name)  # noqa: E731
+    assert count("render-frame") == 6 and count("enqueue-render-passes") == 6 and count("clusterer-refresh") == 6
+    for pass_name in ("clustering-bindless", "lighting-main", "bloom-compute", "tonemap"):
+        assert count(pass_name) == 6, (pass_name, sorted({nm for _, nm in begun}))
+    assert count("bake-render-graph") == 1 and count("wait-idle") >= 1
+    assert any(tid.startswith("light-worker-") for tid, _ in begun)
+    assert sum(1 for e in events if e["ph"] == "B") == sum(1 for e in events if e["ph"] == "E")

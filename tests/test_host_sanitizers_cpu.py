@@ -28,9 +28,37 @@ def test_threaded_light_refresh_under_sanitizer(tmp_path, sanitizer):
                            "-I/opt/rocm/include", "-I" + CSRC, os.path.join(ROOT, "tests", "cpp", "clusterer_threads.cpp"), "-o", exe,
                            "-L" + out, "-lgranite_host", "-lgranite_hip", "-Wl,-rpath," + out, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
                            "-lamdhip64", "-pthread"])
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", ASAN_OPTIONS="detect_leaks=0 exitcode=66")
+    trace = str(tmp_path / "timeline.json")
+    # GRANITE_TIMELINE_TRACE: the CPU timeline writer (host/timeline_trace.hpp) records from the same threads, under the same sanitizer
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", ASAN_OPTIONS="detect_leaks=0 exitcode=66", GRANITE_TIMELINE_TRACE=trace)
     r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.returncode, r.stderr[-3000:], r.stdout[-500:])
     result = json.loads(r.stdout.strip().splitlines()[-1])
     assert result["mismatches"] == 0 and result["prefetch_hits"] >= 20, result
     assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr
+    check_timeline(trace, frames=60, prefetch_hits=result["prefetch_hits"])
+
+
+def check_timeline(path, frames, prefetch_hits):
+    """The trace is chrome://tracing JSON in the reference's event shape (util/timeline_trace_file.cpp:126-131: "B" / "E" pairs, tid and
+    pid as strings, ts in microseconds): every refresh of the main thread, the helper threads' jobs under their own thread names."""
+    events = json.load(open(path))
+    spans = {}
+    for tid in {e["tid"] for e in events}:
+        stack, last = [], -1.0
+        for e in (e for e in events if e["tid"] == tid and e["ph"] in "BE"):
+            assert isinstance(e["pid"], str) and isinstance(e["ts"], float)
+            if e["ph"] == "B":
+                stack.append(e)
+            else:
+                b = stack.pop()
+                assert b["name"] == e["name"] and e["ts"] >= b["ts"] >= 0.0
+                spans.setdefault((tid, e["name"]), []).append((b["ts"], e["ts"]))
+        assert not stack, (tid, stack)
+    names = {name for _, name in spans}
+    assert {"clusterer-refresh", "light-sort-and-pack", "prefetch-next-frame-lights", "light-sort"} <= names, names
+    # the program refreshes two clusterers per frame: the threaded one and a synchronous one it compares with
+    assert len(spans[("main", "clusterer-refresh")]) == 2 * frames
+    assert len(spans[("main", "light-sort-and-pack")]) == 2 * frames - prefetch_hits  # every refresh that did not adopt a prefetched result
+    assert len(spans[("light-worker-0", "light-sort")]) >= prefetch_hits
+    assert any(tid.startswith("light-worker-") and tid != "light-worker-0" for tid, _ in spans)
