@@ -137,6 +137,9 @@ __device__ __forceinline__ void linear_axis(float f, int &i0, float &weight)
 template <typename Fetch>
 __device__ __forceinline__ float4 sample_linear_with(Fetch fetch, int w, int h, float u, float v)
 {
+	// no contraction: a * b - c stays a product and a difference in every kernel this is inlined into, so that the same tap gives the
+	// same bits whichever kernel takes it (the fused pyramid tails must equal the separate launches byte for byte)
+#pragma clang fp contract(off)
 	int ix, iy;
 	float a, b;
 	linear_axis(u * float(w) - 0.5f, ix, a);

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold_
 template <typename Sample>
 __device__ __forceinline__ float4 tent9_with(Sample sample, float u, float v, float ox, float oy)
 {
+#pragma clang fp contract(off)
 	float4 value = sample(u, v) * 0.25f;
 	value = fma4(sample(u - ox, v + oy), 0.0625f, value);
 	value = fma4(sample(u, v + oy), 0.125f, value);
@@ -145,11 +146,23 @@ __device__ __forceinline__ float4 tent9(const DevImage &in, float u, float v, fl
 {
 	return tent9_with([&in](float su, float sv) { return sample_linear_rgba16f(in, su, sv); }, u, v, ox, oy);
 }
+// Centre and tap offsets of output texel (x, y) of a level, from the pass's push constants -- stated once (and without contraction)
+// for the separate kernels and the fused tails alike.  REACH: 1.75 input texels for the downsample, 0.875 for the upsample.
+struct TentTaps
+{
+	float u, v, ox, oy;
+};
+__device__ __forceinline__ TentTaps tent_taps(int x, int y, const float inv_output_size[2], const float inv_input_size[2], float reach)
+{
+#pragma clang fp contract(off)
+	return {(float(x) + 0.5f) * inv_output_size[0], (float(y) + 0.5f) * inv_output_size[1], reach * inv_input_size[0], reach * inv_input_size[1]};
+}
 
 // Temporal feedback of the last downsample level (hdr.cpp:160-166): NearestClamp fetch of the previous frame's level at the
 // same texel, mix(history, value, vec4(lerp, lerp, lerp, 1)).
 __device__ __forceinline__ float4 apply_feedback(float4 value, const DevImage &history, float u, float v, float l)
 {
+#pragma clang fp contract(off)
 	const int hx = clampi(int(floorf(u * float(history.w))), 0, history.w - 1);
 	const int hy = clampi(int(floorf(v * float(history.h))), 0, history.h - 1);
 	const float4 h = load_rgba16f(history, hx, hy);
@@ -166,11 +179,10 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_downsample
 	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
 	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
 		return;
-	const float u = (float(x) + 0.5f) * push.inv_output_size[0];
-	const float v = (float(y) + 0.5f) * push.inv_output_size[1];
-	float4 value = tent9(in, u, v, 1.75f * push.inv_input_size[0], 1.75f * push.inv_input_size[1]);
+	const TentTaps t = tent_taps(x, y, push.inv_output_size, push.inv_input_size, 1.75f);
+	float4 value = tent9(in, t.u, t.v, t.ox, t.oy);
 	if (FEEDBACK)
-		value = apply_feedback(value, history, u, v, push.lerp);
+		value = apply_feedback(value, history, t.u, t.v, push.lerp);
 	store_rgba16f(out, x, y, value);
 }
 
@@ -183,9 +195,8 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_upsample(D
 	const int y = int(y_first) + blockIdx.y * POST_BLOCK_Y + threadIdx.y;
 	if (uint32_t(x) >= push.threads[0] || uint32_t(y) >= y_end)
 		return;
-	const float u = (float(x) + 0.5f) * push.inv_output_size[0];
-	const float v = (float(y) + 0.5f) * push.inv_output_size[1];
-	store_rgba16f(out, x, y, tent9(in, u, v, 0.875f * push.inv_input_size[0], 0.875f * push.inv_input_size[1]));
+	const TentTaps t = tent_taps(x, y, push.inv_output_size, push.inv_input_size, 0.875f);
+	store_rgba16f(out, x, y, tent9(in, t.u, t.v, t.ox, t.oy));
 }
 
 // ---- exact 2:1 / 1:2 forms of the tent filters -----------------------------------------------------------------------------
@@ -384,10 +395,11 @@ __global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_lumin
 //   k_bloom_down_tail: a workgroup makes an 8 x 8 tile of downsample-3; it first makes the patch of downsample-2 under that
 //     tile's tent taps (2:1 stencil from downsample-1), stores it (LDS as fp16, and to the downsample-2 image: neighbouring
 //     workgroups write identical values into the overlap), then filters the patch.
-//   k_bloom_up_tail: a workgroup of 256 threads makes a 16 x 16 tile of upsample-1 from the 12 x 12 patch of upsample-2
-//     under it, which it first makes from downsample-3; workgroup 0 also runs the luminance reduction (in k_luminance's
-//     1024-thread order, four virtual threads per lane).
-// D3_EXACT / U2_EXACT mirror what the separate launchers would pick for that level (2:1 / 1:2 stencil or the generic tent).
+//   k_bloom_up_tail: a workgroup of 1024 threads makes a 32 x 32 tile of upsample-1 from the patch of upsample-2 under it (20 x 20
+//     when the level is exactly twice its input, up to 24 x 24 under the generic taps), which it first makes from downsample-3;
+//     workgroup 0 also runs the luminance reduction (same 1024-thread order as k_luminance).
+// D2_EXACT / D3_EXACT / U2_EXACT / U1_EXACT mirror what the separate launchers would pick for that level (2:1 / 1:2 stencil where the
+// level is exactly half / twice its input, the nine generic taps else: the odd level sizes of 1080p).
 constexpr int TAIL_TILE = 8;
 constexpr int TAIL_PATCH = 24; // rows / columns of downsample-2 under an 8 x 8 tile of downsample-3 (<= 2 * 8 + 4 + slack)
 struct TailPatch
@@ -406,9 +418,9 @@ __device__ __forceinline__ void tap_span(int lo, int hi, int out_n, int in_n, fl
 	last = clampi(int(floorf((float(hi) + 0.5f) * scale - 0.5f + reach)) + 2, 0, in_n - 1);
 }
 
-template <bool D3_EXACT>
+template <bool D2_EXACT, bool D3_EXACT>
 __global__ __launch_bounds__(256) void k_bloom_down_tail(DevImage d1, DevImageRW d2, DevImageRW d3, DevImage history,
-                                                         gr_push_bloom_downsample push3)
+                                                         gr_push_bloom_downsample push2, gr_push_bloom_downsample push3)
 {
 	post_wave_priority();
 	__shared__ f16x4 s_patch[TAIL_PATCH * TAIL_PATCH];
@@ -430,7 +442,9 @@ __global__ __launch_bounds__(256) void k_bloom_down_tail(DevImage d1, DevImageRW
 	for (int i = threadIdx.x; i < pw * ph; i += 256)
 	{
 		const int ly = i / pw, lx = i - ly * pw;
-		const f16x4 texel = pack_rgba16f(downsample_2to1_value<6>(d1, px0 + lx, py0 + ly));
+		// downsample-2 exactly half of downsample-1: the 2:1 stencil; else the nine taps of the generic kernel (odd level sizes: 1080p)
+		const TentTaps t2 = tent_taps(px0 + lx, py0 + ly, push2.inv_output_size, push2.inv_input_size, 1.75f);
+		const f16x4 texel = pack_rgba16f(D2_EXACT ? downsample_2to1_value<6>(d1, px0 + lx, py0 + ly) : tent9(d1, t2.u, t2.v, t2.ox, t2.oy));
 		s_patch[i] = texel;
 		*reinterpret_cast<f16x4 *>(d2.ptr + size_t(py0 + ly) * d2.pitch + size_t(px0 + lx) * 8u) = texel;
 	}
@@ -441,7 +455,8 @@ __global__ __launch_bounds__(256) void k_bloom_down_tail(DevImage d1, DevImageRW
 	if (x >= d3.w || y >= d3.h)
 		return;
 	const TailPatch patch{s_patch, px0, py0, pw, ph};
-	const float u = (float(x) + 0.5f) * push3.inv_output_size[0], v = (float(y) + 0.5f) * push3.inv_output_size[1];
+	const TentTaps t3 = tent_taps(x, y, push3.inv_output_size, push3.inv_input_size, 1.75f);
+	const float u = t3.u, v = t3.v;
 	float4 value;
 	if (D3_EXACT)
 	{
@@ -466,34 +481,44 @@ __global__ __launch_bounds__(256) void k_bloom_down_tail(DevImage d1, DevImageRW
 		const auto sample = [&](float su, float sv) {
 			return sample_linear_with([&patch](int tx, int ty) { return patch.fetch(tx, ty); }, d2_read.w, d2_read.h, su, sv);
 		};
-		value = tent9_with(sample, u, v, 1.75f * push3.inv_input_size[0], 1.75f * push3.inv_input_size[1]);
+		value = tent9_with(sample, u, v, t3.ox, t3.oy);
 	}
 	value = apply_feedback(value, history, u, v, push3.lerp);
 	store_rgba16f(d3, x, y, value);
 }
 
-// UP_THREADS = 1024 (a 32 x 32 tile) is what runs.  The 256-thread form (16 x 16 tiles, one wave per SIMD: finds room on a CU beside
-// the resident lighting waves, where a 1024-thread workgroup waits for a whole CU to drain -- 15 us instead of 60-100 us inside the
-// 4K frame) was built for VERDICT r2 item 5 and measured on one box against the wide form: the FRAME gets slower with it, 0.2426 vs
-// 0.2295 ms sustained (profiles/r03_up_tail_shape_ab.txt): the back chain then runs beside the lighting kernel for all of its
-// length and lighting, which sets the frame period, loses more than the chain gains (211 -> 220 us in-frame; tonemap 26 -> 36 us).
-// Nothing waits for the back chain, so its starved tail is free.  GRANITE_UP_TAIL_NARROW=1 selects the 256-thread form.
-template <int UP_THREADS, bool U2_EXACT, bool LUMINANCE>
-__global__ __launch_bounds__(UP_THREADS) POST_VGPR_BUDGET void k_bloom_up_tail(DevImage d3, DevImageRW u2, DevImageRW u1, gr_luminance_data *lum,
-                                                                              gr_push_bloom_upsample push2, gr_push_luminance push_lum)
+// A 256-thread form (16 x 16 tiles, one wave per SIMD: finds room on a CU beside the resident lighting waves, where a 1024-thread
+// workgroup waits for a whole CU to drain -- 15 us instead of 60-100 us inside the 4K frame) was built for VERDICT r2 item 5 and
+// measured on one box against this one: the FRAME gets slower with it, 0.2426 vs 0.2295 ms sustained (profiles/r03_up_tail_shape_ab.txt):
+// the back chain then runs beside the lighting kernel for all of its length and lighting, which sets the frame period, loses more
+// than the chain gains.  Nothing waits for the back chain, so its starved tail is free; the wide form stays.
+constexpr int UP_TILE = 32;
+constexpr int UP_PATCH = UP_TILE / 2 + 8; // upsample-2 texels under 32 outputs of upsample-1: k - 2 .. k + 2 for k = x / 2 when the level is
+                                          // exactly twice its input, a few more under the generic taps of an odd-sized level
+static_assert(UP_PATCH * UP_PATCH <= LUM_THREADS && UP_TILE * UP_TILE == LUM_THREADS, "one patch texel and one output per thread");
+template <bool U2_EXACT, bool U1_EXACT, bool LUMINANCE>
+__global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_tail(DevImage d3, DevImageRW u2, DevImageRW u1, gr_luminance_data *lum,
+                                                                               gr_push_bloom_upsample push2, gr_push_bloom_upsample push1,
+                                                                               gr_push_luminance push_lum)
 {
-	constexpr int UP_TILE = UP_THREADS == 1024 ? 32 : 16;
-	constexpr int UP_PATCH = UP_TILE / 2 + 4; // upsample-2 texels under UP_TILE outputs of upsample-1: k - 2 .. k + 2 for k = x / 2
-	static_assert(UP_PATCH * UP_PATCH <= UP_THREADS && UP_TILE * UP_TILE == UP_THREADS, "one patch texel and one output per thread");
 	post_wave_priority();
 	__shared__ f16x4 s_patch[UP_PATCH * UP_PATCH];
 	__shared__ float wave_partial[LUM_THREADS / 64];
 	const int thread = int(threadIdx.x);
 	const int tile_x0 = blockIdx.x * UP_TILE, tile_y0 = blockIdx.y * UP_TILE;
 	const int tile_x1 = min(tile_x0 + UP_TILE, u1.w) - 1, tile_y1 = min(tile_y0 + UP_TILE, u1.h) - 1;
-	const int px0 = clampi((tile_x0 >> 1) - 2, 0, u2.w - 1), px1 = clampi((tile_x1 >> 1) + 2, 0, u2.w - 1);
-	const int py0 = clampi((tile_y0 >> 1) - 2, 0, u2.h - 1), py1 = clampi((tile_y1 >> 1) + 2, 0, u2.h - 1);
-	const int pw = px1 - px0 + 1, ph = py1 - py0 + 1;
+	int px0, px1, py0, py1;
+	if (U1_EXACT)
+	{
+		px0 = clampi((tile_x0 >> 1) - 2, 0, u2.w - 1), px1 = clampi((tile_x1 >> 1) + 2, 0, u2.w - 1);
+		py0 = clampi((tile_y0 >> 1) - 2, 0, u2.h - 1), py1 = clampi((tile_y1 >> 1) + 2, 0, u2.h - 1);
+	}
+	else
+	{
+		tap_span(tile_x0, tile_x1, u1.w, u2.w, 0.875f, px0, px1);
+		tap_span(tile_y0, tile_y1, u1.h, u2.h, 0.875f, py0, py1);
+	}
+	const int pw = px1 - px0 + 1, ph = py1 - py0 + 1; // <= UP_PATCH (the launcher checks the level sizes)
 	if (thread < pw * ph)
 	{
 		const int ly = thread / pw, lx = thread - ly * pw;
@@ -505,8 +530,10 @@ __global__ __launch_bounds__(UP_THREADS) POST_VGPR_BUDGET void k_bloom_up_tail(D
 			value = upsample_1to2_value(texel, d3.w, d3.h, x, y);
 		}
 		else
-			value = tent9(d3, (float(x) + 0.5f) * push2.inv_output_size[0], (float(y) + 0.5f) * push2.inv_output_size[1],
-			              0.875f * push2.inv_input_size[0], 0.875f * push2.inv_input_size[1]);
+		{
+			const TentTaps t = tent_taps(x, y, push2.inv_output_size, push2.inv_input_size, 0.875f);
+			value = tent9(d3, t.u, t.v, t.ox, t.oy);
+		}
 		const f16x4 texel16 = pack_rgba16f(value);
 		s_patch[thread] = texel16;
 		*reinterpret_cast<f16x4 *>(u2.ptr + size_t(y) * u2.pitch + size_t(x) * 8u) = texel16;
@@ -516,13 +543,27 @@ __global__ __launch_bounds__(UP_THREADS) POST_VGPR_BUDGET void k_bloom_up_tail(D
 		const int x = tile_x0 + (thread & (UP_TILE - 1)), y = tile_y0 + thread / UP_TILE;
 		if (x < u1.w && y < u1.h)
 		{
-			const auto texel = [&](int tx, int ty) { return __builtin_bit_cast(u32x2, s_patch[(ty - py0) * pw + (tx - px0)]); };
-			store_rgba16f(u1, x, y, upsample_1to2_value(texel, u2.w, u2.h, x, y));
+			if (U1_EXACT)
+			{
+				const auto texel = [&](int tx, int ty) { return __builtin_bit_cast(u32x2, s_patch[(ty - py0) * pw + (tx - px0)]); };
+				store_rgba16f(u1, x, y, upsample_1to2_value(texel, u2.w, u2.h, x, y));
+			}
+			else
+			{
+				// the nine taps of the generic kernel over the patch (sample_linear_with clamps the indices to the level as the sampler does)
+				const TailPatch patch{s_patch, px0, py0, pw, ph};
+				const int level_w = u2.w, level_h = u2.h;
+				const auto sample = [&](float su, float sv) {
+					return sample_linear_with([&patch](int tx, int ty) { return patch.fetch(tx, ty); }, level_w, level_h, su, sv);
+				};
+				const TentTaps t = tent_taps(x, y, push1.inv_output_size, push1.inv_input_size, 0.875f);
+				store_rgba16f(u1, x, y, tent9_with(sample, t.u, t.v, t.ox, t.oy));
+			}
 		}
 	}
 	// hdr.cpp:368-371 records the luminance pass between downsample-3 and upsample-2; nothing in between reads its result
 	if (LUMINANCE && blockIdx.x == 0 && blockIdx.y == 0)
-		luminance_block<UP_THREADS>(d3, lum, push_lum, thread, wave_partial);
+		luminance_block<LUM_THREADS>(d3, lum, push_lum, thread, wave_partial);
 }
 
 // ---- tonemap (tonemap.frag:30-66) -----------------------------------------------------------------------------------
@@ -873,11 +914,14 @@ int gr_bloom_tail_supported(const gr_image *d1, const gr_image *d2, const gr_ima
 		return 0;
 	if (!push_d2 || !push_d3 || !push_u2 || !push_u1)
 		return 0;
-	// whole levels only, downsample-2 and upsample-1 in their exact forms, upsample-2 the size of downsample-2
+	// whole levels only, upsample-2 the size of downsample-2 (the 2:1 / 1:2 stencils where a level is exactly half / twice its input, the nine taps else)
 	if (push_d2->threads[0] != d2->width || push_d2->threads[1] != d2->height || push_d3->threads[0] != d3->width || push_d3->threads[1] != d3->height ||
 	    push_u2->threads[0] != u2->width || push_u2->threads[1] != u2->height || push_u1->threads[0] != u1->width || push_u1->threads[1] != u1->height)
 		return 0;
-	if (!downsample_is_exact(d1, push_d2) || !upsample_is_exact(u2, push_u1) || u2->width != d2->width || u2->height != d2->height)
+	if (u2->width != d2->width || u2->height != d2->height)
+		return 0;
+	// upsample-1 at most twice upsample-2 (+ 1: a level is ceil(half) of the one above), or its patch would not fit the kernel's LDS
+	if (u1->width > 2 * u2->width || u1->height > 2 * u2->height || 2 * u2->width > u1->width + 1 || 2 * u2->height > u1->height + 1)
 		return 0;
 	// the patch of downsample-2 under an 8 x 8 tile of downsample-3 must fit the kernel's LDS patch
 	if (d3->width == 0 || d3->height == 0 || float(d2->width) > 2.3f * float(d3->width) || float(d2->height) > 2.3f * float(d3->height))
@@ -893,16 +937,20 @@ int gr_bloom_down_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d1, const 
 	GR_CHECK_ARG(ctx, push_d2 != nullptr && push_d3 != nullptr);
 	GR_CHECK_ARG(ctx, is_rgba16f(d1) && is_rgba16f(d2) && is_rgba16f(d3));
 	GR_CHECK_ARG(ctx, !history || (is_rgba16f(history) && history->ptr != d3->ptr));
-	GR_CHECK_ARG(ctx, downsample_is_exact(d1, push_d2) && push_d2->threads[0] == d2->width && push_d2->threads[1] == d2->height);
+	GR_CHECK_ARG(ctx, push_d2->threads[0] == d2->width && push_d2->threads[1] == d2->height);
 	GR_CHECK_ARG(ctx, push_d3->threads[0] == d3->width && push_d3->threads[1] == d3->height);
 	GR_CHECK_ARG(ctx, float(d2->width) <= 2.3f * float(d3->width) && float(d2->height) <= 2.3f * float(d3->height));
 	GR_CHECK_ARG(ctx, history != nullptr); // the last level of the pyramid always carries the temporal feedback (hdr.cpp:366)
 	dim3 grid(gr_div_up(d3->width, TAIL_TILE), gr_div_up(d3->height, TAIL_TILE));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_down_tail"};
-	if (downsample_is_exact(d2, push_d3))
-		hipLaunchKernelGGL(k_bloom_down_tail<true>, grid, dim3(256), 0, gr_to_stream(stream), to_dev(d1), to_dev_rw(d2), to_dev_rw(d3), to_dev(history), *push_d3);
-	else
-		hipLaunchKernelGGL(k_bloom_down_tail<false>, grid, dim3(256), 0, gr_to_stream(stream), to_dev(d1), to_dev_rw(d2), to_dev_rw(d3), to_dev(history), *push_d3);
+	auto launch = [&](auto kernel) {
+		hipLaunchKernelGGL(kernel, grid, dim3(256), 0, gr_to_stream(stream), to_dev(d1), to_dev_rw(d2), to_dev_rw(d3), to_dev(history), *push_d2, *push_d3);
+	};
+	const bool d2_exact = downsample_is_exact(d1, push_d2), d3_exact = downsample_is_exact(d2, push_d3);
+	if (d2_exact && d3_exact) launch(k_bloom_down_tail<true, true>);
+	else if (d2_exact) launch(k_bloom_down_tail<true, false>);
+	else if (d3_exact) launch(k_bloom_down_tail<false, true>);
+	else launch(k_bloom_down_tail<false, false>);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
@@ -914,30 +962,29 @@ int gr_bloom_up_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, push_u2 != nullptr && push_u1 != nullptr && (lum == nullptr) == (push_lum == nullptr));
 	GR_CHECK_ARG(ctx, is_rgba16f(d3) && is_rgba16f(u2) && is_rgba16f(u1));
-	GR_CHECK_ARG(ctx, upsample_is_exact(u2, push_u1) && push_u1->threads[0] == u1->width && push_u1->threads[1] == u1->height);
+	GR_CHECK_ARG(ctx, push_u1->threads[0] == u1->width && push_u1->threads[1] == u1->height);
 	GR_CHECK_ARG(ctx, push_u2->threads[0] == u2->width && push_u2->threads[1] == u2->height);
+	GR_CHECK_ARG(ctx, u1->width <= 2 * u2->width && u1->height <= 2 * u2->height && 2 * u2->width <= u1->width + 1 && 2 * u2->height <= u1->height + 1);
 	GR_CHECK_ARG(ctx, !push_lum || (push_lum->size[0] != 0 && push_lum->size[1] != 0));
-	static const bool wide = getenv("GRANITE_UP_TAIL_NARROW") == nullptr;
-	const uint32_t tile = wide ? 32 : 16, threads = wide ? 1024 : 256;
-	dim3 grid(gr_div_up(u1->width, tile), gr_div_up(u1->height, tile));
+	dim3 grid(gr_div_up(u1->width, UP_TILE), gr_div_up(u1->height, UP_TILE));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_up_tail"};
 	const gr_push_luminance no_lum = {};
-	const bool exact = upsample_is_exact(d3, push_u2);
+	const bool u2_exact = upsample_is_exact(d3, push_u2), u1_exact = upsample_is_exact(u2, push_u1);
 	auto launch = [&](auto kernel) {
-		hipLaunchKernelGGL(kernel, grid, dim3(threads), 0, gr_to_stream(stream), to_dev(d3), to_dev_rw(u2), to_dev_rw(u1), lum, *push_u2,
+		hipLaunchKernelGGL(kernel, grid, dim3(LUM_THREADS), 0, gr_to_stream(stream), to_dev(d3), to_dev_rw(u2), to_dev_rw(u1), lum, *push_u2, *push_u1,
 		                   push_lum ? *push_lum : no_lum);
 	};
-	auto pick = [&](auto width) {
-		constexpr int T = decltype(width)::value;
-		if (exact && lum) launch(k_bloom_up_tail<T, true, true>);
-		else if (exact) launch(k_bloom_up_tail<T, true, false>);
-		else if (lum) launch(k_bloom_up_tail<T, false, true>);
-		else launch(k_bloom_up_tail<T, false, false>);
+	auto pick = [&](auto u2e, auto u1e) {
+		constexpr bool A = decltype(u2e)::value, B = decltype(u1e)::value;
+		if (lum) launch(k_bloom_up_tail<A, B, true>);
+		else launch(k_bloom_up_tail<A, B, false>);
 	};
-	if (wide)
-		pick(std::integral_constant<int, 1024>{});
-	else
-		pick(std::integral_constant<int, 256>{});
+	using T = std::true_type;
+	using F = std::false_type;
+	if (u2_exact && u1_exact) pick(T{}, T{});
+	else if (u2_exact) pick(T{}, F{});
+	else if (u1_exact) pick(F{}, T{});
+	else pick(F{}, F{});
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

@@ -202,8 +202,8 @@ int gr_luminance(gr_ctx *ctx, gr_stream stream, const gr_image *in, gr_luminance
 /* The coarse end of the pyramid as recorded by hdr.cpp:364-377 -- downsample-2, downsample-3 (+ feedback), luminance,
  * upsample-2, upsample-1 -- in two launches instead of five: every texel is computed by the same code as the separate entry
  * points above (values and fp16 roundings between levels are identical), the intermediate levels are still written.
- * gr_bloom_tail_supported() says whether a pyramid qualifies (whole levels, downsample-2 / upsample-1 exactly 2:1 / 1:2 of
- * their inputs); otherwise the five separate calls are the path. */
+ * gr_bloom_tail_supported() says whether a pyramid qualifies (whole levels, each level ceil(half) of the one above as
+ * render_graph.cpp's InputRelative sizes are: 4K, 1080p, odd sizes alike); otherwise the five separate calls are the path. */
 int gr_bloom_tail_supported(const gr_image *d1, const gr_image *d2, const gr_image *d3, const gr_image *u2, const gr_image *u1,
                             const gr_push_bloom_downsample *push_d2, const gr_push_bloom_downsample *push_d3,
                             const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1);

@@ -156,14 +156,14 @@ def test_argument_validation(gr):
         gr.tonemap(hdr, hdr, capi.DeviceImage(gr, 8, 8, capi.FORMAT_R8G8B8A8_SRGB))
 
 
-@pytest.mark.parametrize("w,h", [(3840, 2160), (7680, 4320), (2048, 2048), (2560, 1440), (1280, 720), (256, 256)])
+@pytest.mark.parametrize("w,h", [(3840, 2160), (7680, 4320), (2048, 2048), (2560, 1440), (1280, 720), (256, 256), (1920, 1080), (1000, 808), (333, 250)])
 def test_fused_pyramid_tail_equals_the_five_separate_launches(gr, w, h):
     """gr_bloom_down_tail + gr_bloom_up_tail (downsample-2 -> downsample-3 + feedback -> luminance -> upsample-2 -> upsample-1
     through LDS, two launches) must leave the very bytes of the five separate launches in every level and in the luminance
     buffer: 4K and 1440p (downsample-3 and upsample-2 on the generic tent: 135 -> 68, 90 -> 45 exact but 45 -> 23), sizes where
-    both are exact 2:1 / 1:2, small ones with partial tiles."""
+    both are exact 2:1 / 1:2, small ones with partial tiles; 1080p (135 -> 68: downsample-2 and upsample-1 on the nine generic taps
+    as well) and two odd-sized pyramids where no step is exact."""
     sz = [orc.level_size(w, h, s) for s in (0.125, 0.0625, 0.03125)]
-    assert sz[0] == (2 * sz[1][0], 2 * sz[1][1]), "test sizes are those whose 1/8 -> 1/16 step is exact"
     rng = np.random.default_rng(w * 31 + h)
     d1_bits = np.exp2(rng.uniform(-8, 6, (sz[0][1], sz[0][0], 4))).astype(np.float16).view(np.uint16)
     hist_bits = np.exp2(rng.uniform(-8, 4, (sz[2][1], sz[2][0], 4))).astype(np.float16).view(np.uint16)
@@ -192,9 +192,10 @@ def test_fused_pyramid_tail_equals_the_five_separate_launches(gr, w, h):
 
 
 def test_fused_pyramid_tail_declines_what_it_does_not_cover(gr):
-    """Levels that are not 2:1 / 1:2 where the fused kernels need them to be fall back to the separate launches."""
+    """A level that is not ceil(half) of the one above (not a pyramid of render_graph.cpp's InputRelative sizes: the patch of upsample-2
+    under a tile of upsample-1 would not fit the kernel's LDS) falls back to the separate launches."""
     d1 = capi.DeviceImage(gr, 101, 57, F16)
-    d2, u2 = capi.DeviceImage(gr, 51, 29, F16), capi.DeviceImage(gr, 51, 29, F16)   # 101 -> 51 is not exact
-    d3, hist = capi.DeviceImage(gr, 26, 15, F16), capi.DeviceImage(gr, 26, 15, F16)
+    d2, u2 = capi.DeviceImage(gr, 80, 40, F16), capi.DeviceImage(gr, 80, 40, F16)   # 101 -> 80
+    d3, hist = capi.DeviceImage(gr, 40, 20, F16), capi.DeviceImage(gr, 40, 20, F16)
     u1 = capi.DeviceImage(gr, 101, 57, F16)
     assert not gr.bloom_tail(d1, d2, d3, hist, u2, u1, 0.1)
