@@ -326,43 +326,22 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k
 // Summation order is fixed (deterministic across runs and ranks) but differs from the reference's tree: covered by the
 // stated fp32 tolerance on LuminanceData.
 constexpr int LUM_THREADS = 1024;
-// Called by all THREADS threads of a workgroup (thread = 0 .. THREADS - 1); wave_partial: LUM_THREADS / 64 floats of LDS.  A
-// workgroup narrower than LUM_THREADS plays LUM_THREADS / THREADS virtual threads per lane (virtual thread = thread + THREADS * k:
-// same lane of its wave, so the shuffles pair the same partial sums): every sum is taken in the order of the LUM_THREADS-wide
-// workgroup and the result is the same bit for bit.
-template <int THREADS>
+// Called by all LUM_THREADS threads of a workgroup (thread = 0 .. LUM_THREADS - 1); wave_partial: LUM_THREADS / 64 floats of LDS.
 __device__ __forceinline__ void luminance_block(const DevImage &in, gr_luminance_data *lum, const gr_push_luminance &push, int thread,
                                                 float *wave_partial)
 {
-	static_assert(LUM_THREADS % THREADS == 0 && THREADS % 64 == 0, "whole waves of virtual threads");
-	constexpr int V = LUM_THREADS / THREADS;
 	const int sx = int(push.size[0]), sy = int(push.size[1]);
 	const float inv_x = 1.0f / float(sx), inv_y = 1.0f / float(sy);
 	const int total = sx * sy;
-	float sum[V];
-#pragma unroll
-	for (int k = 0; k < V; k++)
-		sum[k] = 0.0f;
-	for (int base = thread; base < total; base += LUM_THREADS)
+	float sum = 0.0f;
+	for (int i = thread; i < total; i += LUM_THREADS)
 	{
-#pragma unroll
-		for (int k = 0; k < V; k++)
-		{
-			const int i = base + THREADS * k;
-			if (i < total)
-			{
-				const int py = i / sx, px = i - py * sx;
-				sum[k] += sample_linear_rgba16f(in, (float(px) + 0.5f) * inv_x, (float(py) + 0.5f) * inv_y).w;
-			}
-		}
+		const int py = i / sx, px = i - py * sx;
+		sum += sample_linear_rgba16f(in, (float(px) + 0.5f) * inv_x, (float(py) + 0.5f) * inv_y).w;
 	}
-#pragma unroll
-	for (int k = 0; k < V; k++)
-	{
-		const float s = wave_sum(sum[k]);
-		if ((thread & 63) == 0)
-			wave_partial[(thread >> 6) + (THREADS / 64) * k] = s;
-	}
+	sum = wave_sum(sum);
+	if ((thread & 63) == 0)
+		wave_partial[thread >> 6] = sum;
 	__syncthreads();
 	if (thread == 0)
 	{
@@ -384,7 +363,7 @@ __global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_lumin
 {
 	post_wave_priority();
 	__shared__ float wave_partial[LUM_THREADS / 64];
-	luminance_block<LUM_THREADS>(in, lum, push, int(threadIdx.x), wave_partial);
+	luminance_block(in, lum, push, int(threadIdx.x), wave_partial);
 }
 
 // ---- the coarse end of the pyramid in two launches --------------------------------------------------------------------------
@@ -563,7 +542,7 @@ __global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_tail(
 	}
 	// hdr.cpp:368-371 records the luminance pass between downsample-3 and upsample-2; nothing in between reads its result
 	if (LUMINANCE && blockIdx.x == 0 && blockIdx.y == 0)
-		luminance_block<LUM_THREADS>(d3, lum, push_lum, thread, wave_partial);
+		luminance_block(d3, lum, push_lum, thread, wave_partial);
 }
 
 // ---- tonemap (tonemap.frag:30-66) -----------------------------------------------------------------------------------
