@@ -251,6 +251,8 @@ def load_library() -> C.CDLL:
         "gr_bloom_tail_supported": (C.c_int, [P(Image), P(Image), P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample),
                                               P(PushBloomUpsample), P(PushBloomUpsample)]),
         "gr_bloom_down_tail": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample)]),
+        "gr_bloom_down_mid_supported": (C.c_int, [P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample)]),
+        "gr_bloom_down_mid": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample), P(Rows)]),
         "gr_bloom_up_tail": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushBloomUpsample), P(PushBloomUpsample), P(PushLuminance)]),
         "gr_tonemap": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushTonemap)]),
         "gr_bloom_threshold_rows": (C.c_int, [vp, vp, P(Image), P(Image), vp, P(PushBloomThreshold), P(Rows)]),
@@ -455,6 +457,16 @@ class Context:
         self.check(self.lib.gr_bloom_down_tail(self.handle, stream, d1.desc, d2.desc, d3.desc, history.desc, p_d2, p_d3))
         p_lum = PushLuminance((d3.width // 2, d3.height // 2), lum_lerp, -3.0, 2.0) if lum_ptr is not None else None
         self.check(self.lib.gr_bloom_up_tail(self.handle, stream, d3.desc, u2.desc, u1.desc, lum_ptr, p_u2, p_u1, p_lum))
+        return True
+
+    def bloom_down_mid(self, threshold: DeviceImage, d0: DeviceImage, d1: DeviceImage, stream=None, rows=None) -> bool:
+        """downsample-0 and downsample-1 as one launch (rows restricts downsample-1); False (nothing launched) when the levels do not qualify."""
+        def down(out, src):
+            return PushBloomDownsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height), (1.0 / src.width, 1.0 / src.height), 0.0)
+        p_d0, p_d1 = down(d0, threshold), down(d1, d0)
+        if not self.lib.gr_bloom_down_mid_supported(threshold.desc, d0.desc, d1.desc, p_d0, p_d1):
+            return False
+        self.check(self.lib.gr_bloom_down_mid(self.handle, stream, threshold.desc, d0.desc, d1.desc, p_d0, p_d1, self._rows(rows)))
         return True
 
     def luminance(self, d3: DeviceImage, lum_ptr, lerp: float, min_loglum: float = -3.0, max_loglum: float = 2.0, stream=None):

@@ -161,6 +161,25 @@ bool record_pyramid_tail(HIP::CommandBuffer &cmd, const FrameParameters &frame, 
 	return true;
 }
 
+// The dispatches of downsample-0 and downsample-1 (hdr.cpp:358-362) as one fused launch of the C ABI when the levels qualify; returns
+// false otherwise and records nothing.  Under row bands the launch is restricted to this rank's rows of downsample-1; downsample-0
+// is written under their taps (StripPlan::d0 is that footprint).
+bool record_pyramid_middle(HIP::CommandBuffer &cmd, const FrameParameters &frame, RenderGraph &graph, const RenderTextureResource &t_res,
+                           const RenderTextureResource &d0_res, const RenderTextureResource &d1_res, const RowRange *rows_d1)
+{
+	auto &t = graph.get_physical_texture_resource(t_res);
+	auto &d0 = graph.get_physical_texture_resource(d0_res);
+	auto &d1 = graph.get_physical_texture_resource(d1_res);
+	const gr_push_bloom_downsample push_d0 = downsample_push(frame, d0, t), push_d1 = downsample_push(frame, d1, d0);
+	if (!gr_bloom_down_mid_supported(&t.get_view(), &d0.get_view(), &d1.get_view(), &push_d0, &push_d1))
+		return false;
+	gr_rows rows;
+	if (to_rows(rows_d1, rows))
+		cmd.check(gr_bloom_down_mid(cmd.get_context(), cmd.get_stream(), &t.get_view(), &d0.get_view(), &d1.get_view(), &push_d0, &push_d1, &rows),
+		          "bloom_down_mid");
+	return true;
+}
+
 // tonemap_build_render_pass (hdr.cpp:283-306)
 void record_tonemap(RenderPass &pass, HIP::CommandBuffer &cmd, const RenderTextureResource &hdr_res, const RenderTextureResource &bloom_res,
                     const RenderBufferResource *ubo, const HDRDynamicExposureInterface *iface, const StripPlan *strip = nullptr)
@@ -239,9 +258,12 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 			};
 			record_threshold(cmd, graph, t, hdr, ubo, strip ? &strip->threshold : nullptr);
 			compute_to_compute();
-			record_downsample(cmd, frame, graph, d0, t, nullptr, strip ? &strip->d0 : nullptr);
-			compute_to_compute();
-			record_downsample(cmd, frame, graph, d1, d0, nullptr, strip ? &strip->d1 : nullptr);
+			if (!record_pyramid_middle(cmd, frame, graph, t, d0, d1, strip ? &strip->d1 : nullptr))
+			{
+				record_downsample(cmd, frame, graph, d0, t, nullptr, strip ? &strip->d0 : nullptr);
+				compute_to_compute();
+				record_downsample(cmd, frame, graph, d1, d0, nullptr, strip ? &strip->d1 : nullptr);
+			}
 			if (strip && strip->exchange)
 				strip->exchange(cmd, graph.get_physical_texture_resource(d1), strip->d1_chunk_rows, "downsample-1");
 			compute_to_compute();
@@ -276,7 +298,7 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 		key.add(ubo ? graph.get_physical_buffer_resource(*ubo).get_device_pointer() : nullptr);
 		key.add(frame.frame_time);
 		cmd.replayable("bloom-compute", key,
-		               {"bloom_threshold", "bloom_downsample", "bloom_down_tail", "bloom_up_tail", "luminance", "bloom_upsample"}, record);
+		               {"bloom_threshold", "bloom_downsample", "bloom_down_mid", "bloom_down_tail", "bloom_up_tail", "luminance", "bloom_upsample"}, record);
 	});
 
 	{

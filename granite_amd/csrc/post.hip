@@ -371,7 +371,7 @@ __global__ __launch_bounds__(LUM_THREADS) void k_luminance(DevImage in, gr_lumin
 // dependent launches they are a third of the back-of-frame chain's latency (each pays a dispatch, a fill of the machine and
 // a drain for a few microseconds of work).  Fused through LDS, with every texel computed by the very functions the separate
 // kernels use (so the values, their fp16 roundings between levels included, are the same):
-//   k_bloom_down_tail: a workgroup makes an 8 x 8 tile of downsample-3; it first makes the patch of downsample-2 under that
+//   k_bloom_down_pair (gr_bloom_down_tail): a workgroup makes an 8 x 8 tile of downsample-3; it first makes the patch of downsample-2 under that
 //     tile's tent taps (2:1 stencil from downsample-1), stores it (LDS as fp16, and to the downsample-2 image: neighbouring
 //     workgroups write identical values into the overlap), then filters the patch.
 //   k_bloom_up_tail: a workgroup of 1024 threads makes a 32 x 32 tile of upsample-1 from the patch of upsample-2 under it (20 x 20
@@ -397,47 +397,50 @@ __device__ __forceinline__ void tap_span(int lo, int hi, int out_n, int in_n, fl
 	last = clampi(int(floorf((float(hi) + 0.5f) * scale - 0.5f + reach)) + 2, 0, in_n - 1);
 }
 
-template <bool D2_EXACT, bool D3_EXACT>
-__global__ __launch_bounds__(256) void k_bloom_down_tail(DevImage d1, DevImageRW d2, DevImageRW d3, DevImage history,
-                                                         gr_push_bloom_downsample push2, gr_push_bloom_downsample push3)
+// Two consecutive downsample levels in one launch: `lower` (level B, rows [y_first, y_end)) from `upper` (level A), which the
+// workgroup first makes from `src` -- and stores -- under its tile's taps.  Instantiated for downsample-0 / downsample-1 (from the
+// threshold level; row bands restrict level B) and for downsample-2 / downsample-3 (+ the temporal feedback).
+template <bool A_EXACT, bool B_EXACT, bool FEEDBACK>
+__global__ __launch_bounds__(256) void k_bloom_down_pair(DevImage src, DevImageRW upper, DevImageRW lower, DevImage history,
+                                                         gr_push_bloom_downsample push_a, gr_push_bloom_downsample push_b, uint32_t y_first,
+                                                         uint32_t y_end)
 {
 	post_wave_priority();
 	__shared__ f16x4 s_patch[TAIL_PATCH * TAIL_PATCH];
-	const int tile_x0 = blockIdx.x * TAIL_TILE, tile_y0 = blockIdx.y * TAIL_TILE;
-	const int tile_x1 = min(tile_x0 + TAIL_TILE, d3.w) - 1, tile_y1 = min(tile_y0 + TAIL_TILE, d3.h) - 1;
+	const int tile_x0 = blockIdx.x * TAIL_TILE, tile_y0 = int(y_first) + blockIdx.y * TAIL_TILE;
+	const int tile_x1 = min(tile_x0 + TAIL_TILE, lower.w) - 1, tile_y1 = min(tile_y0 + TAIL_TILE, int(y_end)) - 1;
 	int px0, px1, py0, py1;
-	if (D3_EXACT)
+	if (B_EXACT)
 	{
-		px0 = clampi(2 * tile_x0 - 2, 0, d2.w - 1), px1 = clampi(2 * tile_x1 + 3, 0, d2.w - 1);
-		py0 = clampi(2 * tile_y0 - 2, 0, d2.h - 1), py1 = clampi(2 * tile_y1 + 3, 0, d2.h - 1);
+		px0 = clampi(2 * tile_x0 - 2, 0, upper.w - 1), px1 = clampi(2 * tile_x1 + 3, 0, upper.w - 1);
+		py0 = clampi(2 * tile_y0 - 2, 0, upper.h - 1), py1 = clampi(2 * tile_y1 + 3, 0, upper.h - 1);
 	}
 	else
 	{
-		tap_span(tile_x0, tile_x1, d3.w, d2.w, 1.75f, px0, px1);
-		tap_span(tile_y0, tile_y1, d3.h, d2.h, 1.75f, py0, py1);
+		tap_span(tile_x0, tile_x1, lower.w, upper.w, 1.75f, px0, px1);
+		tap_span(tile_y0, tile_y1, lower.h, upper.h, 1.75f, py0, py1);
 	}
 	const int pw = px1 - px0 + 1, ph = py1 - py0 + 1; // <= TAIL_PATCH (checked by the launcher)
-	const DevImage d2_read{d2.ptr, d2.w, d2.h, d2.pitch};
+	const int upper_w = upper.w, upper_h = upper.h;
 	for (int i = threadIdx.x; i < pw * ph; i += 256)
 	{
 		const int ly = i / pw, lx = i - ly * pw;
-		// downsample-2 exactly half of downsample-1: the 2:1 stencil; else the nine taps of the generic kernel (odd level sizes: 1080p)
-		const TentTaps t2 = tent_taps(px0 + lx, py0 + ly, push2.inv_output_size, push2.inv_input_size, 1.75f);
-		const f16x4 texel = pack_rgba16f(D2_EXACT ? downsample_2to1_value<6>(d1, px0 + lx, py0 + ly) : tent9(d1, t2.u, t2.v, t2.ox, t2.oy));
+		// level A exactly half of its input: the 2:1 stencil; else the nine taps of the generic kernel (odd level sizes: 1080p)
+		const TentTaps ta = tent_taps(px0 + lx, py0 + ly, push_a.inv_output_size, push_a.inv_input_size, 1.75f);
+		const f16x4 texel = pack_rgba16f(A_EXACT ? downsample_2to1_value<6>(src, px0 + lx, py0 + ly) : tent9(src, ta.u, ta.v, ta.ox, ta.oy));
 		s_patch[i] = texel;
-		*reinterpret_cast<f16x4 *>(d2.ptr + size_t(py0 + ly) * d2.pitch + size_t(px0 + lx) * 8u) = texel;
+		*reinterpret_cast<f16x4 *>(upper.ptr + size_t(py0 + ly) * upper.pitch + size_t(px0 + lx) * 8u) = texel;
 	}
 	__syncthreads();
 	if (threadIdx.x >= TAIL_TILE * TAIL_TILE)
 		return;
 	const int x = tile_x0 + int(threadIdx.x & (TAIL_TILE - 1)), y = tile_y0 + int(threadIdx.x / TAIL_TILE);
-	if (x >= d3.w || y >= d3.h)
+	if (x >= lower.w || y > tile_y1)
 		return;
 	const TailPatch patch{s_patch, px0, py0, pw, ph};
-	const TentTaps t3 = tent_taps(x, y, push3.inv_output_size, push3.inv_input_size, 1.75f);
-	const float u = t3.u, v = t3.v;
+	const TentTaps tb = tent_taps(x, y, push_b.inv_output_size, push_b.inv_input_size, 1.75f);
 	float4 value;
-	if (D3_EXACT)
+	if (B_EXACT)
 	{
 		// the 2:1 stencil of downsample_2to1_value over the patch (same weights, same order; the patch covers every clamped index)
 		const float wt[6] = {0.0625f, 0.1875f, 0.25f, 0.25f, 0.1875f, 0.0625f};
@@ -445,11 +448,11 @@ __global__ __launch_bounds__(256) void k_bloom_down_tail(DevImage d1, DevImageRW
 #pragma unroll 1
 		for (int r = 0; r < 6; r++)
 		{
-			const int iy = clampi(2 * y - 2 + r, 0, d2.h - 1);
-			float4 h = mul4(patch.fetch(clampi(2 * x - 2, 0, d2.w - 1), iy), wt[0]);
+			const int iy = clampi(2 * y - 2 + r, 0, upper_h - 1);
+			float4 h = mul4(patch.fetch(clampi(2 * x - 2, 0, upper_w - 1), iy), wt[0]);
 #pragma unroll
 			for (int c = 1; c < 6; c++)
-				h = fma4(patch.fetch(clampi(2 * x - 2 + c, 0, d2.w - 1), iy), wt[c], h);
+				h = fma4(patch.fetch(clampi(2 * x - 2 + c, 0, upper_w - 1), iy), wt[c], h);
 			const float wr = r == 0 || r == 5 ? 0.0625f : (r == 1 || r == 4 ? 0.1875f : 0.25f);
 			acc = fma4(h, wr, acc);
 		}
@@ -458,12 +461,13 @@ __global__ __launch_bounds__(256) void k_bloom_down_tail(DevImage d1, DevImageRW
 	else
 	{
 		const auto sample = [&](float su, float sv) {
-			return sample_linear_with([&patch](int tx, int ty) { return patch.fetch(tx, ty); }, d2_read.w, d2_read.h, su, sv);
+			return sample_linear_with([&patch](int tx, int ty) { return patch.fetch(tx, ty); }, upper_w, upper_h, su, sv);
 		};
-		value = tent9_with(sample, u, v, t3.ox, t3.oy);
+		value = tent9_with(sample, tb.u, tb.v, tb.ox, tb.oy);
 	}
-	value = apply_feedback(value, history, u, v, push3.lerp);
-	store_rgba16f(d3, x, y, value);
+	if (FEEDBACK)
+		value = apply_feedback(value, history, tb.u, tb.v, push_b.lerp);
+	store_rgba16f(lower, x, y, value);
 }
 
 // A 256-thread form (16 x 16 tiles, one wave per SIMD: finds room on a CU beside the resident lighting waves, where a 1024-thread
@@ -884,6 +888,54 @@ int gr_bloom_upsample_rows(gr_ctx *ctx, gr_stream stream, const gr_image *in, co
 	return GR_OK;
 }
 
+int gr_bloom_down_mid_supported(const gr_image *threshold, const gr_image *d0, const gr_image *d1, const gr_push_bloom_downsample *push_d0,
+                                const gr_push_bloom_downsample *push_d1)
+{
+	static const bool allow_fusion = gr_measurement_switch("GR_NO_MID_FUSION") == nullptr; // A/B switch for measurements
+	if (!allow_fusion || !threshold || !d0 || !d1 || !push_d0 || !push_d1 || !is_rgba16f(threshold) || !is_rgba16f(d0) || !is_rgba16f(d1))
+		return 0;
+	if (push_d0->threads[0] != d0->width || push_d0->threads[1] != d0->height || push_d1->threads[0] != d1->width || push_d1->threads[1] != d1->height)
+		return 0;
+	// the patch of downsample-0 under an 8 x 8 tile of downsample-1 must fit the kernel's LDS patch
+	if (d1->width == 0 || d1->height == 0 || float(d0->width) > 2.3f * float(d1->width) || float(d0->height) > 2.3f * float(d1->height))
+		return 0;
+	// Worth it only where the chain of launches, not the arithmetic, sets the pace: the fused form recomputes 56 % of downsample-0
+	// (overlapping patches).  Measured on one box: 1080p frame 0.0748 -> 0.0725 ms, 256 x 256 post chain 0.0622 -> 0.0587 ms, but the
+	// 4K frame 0.2323 -> 0.2389 ms (the extra work runs beside the lighting kernel).  Hence a size limit: up to a 1440p frame's level.
+	static const bool any_size = gr_measurement_switch("GR_MID_FUSION_ANY_SIZE") != nullptr;
+	if (!any_size && uint64_t(d1->width) * d1->height > 65536u)
+		return 0;
+	return 1;
+}
+
+int gr_bloom_down_mid(gr_ctx *ctx, gr_stream stream, const gr_image *threshold, const gr_image *d0, const gr_image *d1,
+                      const gr_push_bloom_downsample *push_d0, const gr_push_bloom_downsample *push_d1, const gr_rows *rows_d1)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, threshold && d0 && d1 && push_d0 && push_d1);
+	GR_CHECK_ARG(ctx, is_rgba16f(threshold) && is_rgba16f(d0) && is_rgba16f(d1) && d0->ptr != d1->ptr && threshold->ptr != d0->ptr);
+	GR_CHECK_ARG(ctx, push_d0->threads[0] == d0->width && push_d0->threads[1] == d0->height);
+	GR_CHECK_ARG(ctx, push_d1->threads[0] == d1->width && push_d1->threads[1] == d1->height);
+	GR_CHECK_ARG(ctx, float(d0->width) <= 2.3f * float(d1->width) && float(d0->height) <= 2.3f * float(d1->height));
+	const RowSpan span = resolve_rows(rows_d1, d1->height);
+	if (span.count() == 0 || d1->width == 0)
+		return GR_OK;
+	dim3 grid(gr_div_up(d1->width, TAIL_TILE), gr_div_up(span.count(), TAIL_TILE));
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_down_mid"};
+	auto launch = [&](auto kernel) {
+		hipLaunchKernelGGL(kernel, grid, dim3(256), 0, gr_to_stream(stream), to_dev(threshold), to_dev_rw(d0), to_dev_rw(d1), DevImage{}, *push_d0, *push_d1,
+		                   span.first, span.end);
+	};
+	const bool d0_exact = downsample_is_exact(threshold, push_d0), d1_exact = downsample_is_exact(d0, push_d1);
+	if (d0_exact && d1_exact) launch(k_bloom_down_pair<true, true, false>);
+	else if (d0_exact) launch(k_bloom_down_pair<true, false, false>);
+	else if (d1_exact) launch(k_bloom_down_pair<false, true, false>);
+	else launch(k_bloom_down_pair<false, false, false>);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
 int gr_bloom_tail_supported(const gr_image *d1, const gr_image *d2, const gr_image *d3, const gr_image *u2, const gr_image *u1,
                             const gr_push_bloom_downsample *push_d2, const gr_push_bloom_downsample *push_d3,
                             const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1)
@@ -923,13 +975,14 @@ int gr_bloom_down_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d1, const 
 	dim3 grid(gr_div_up(d3->width, TAIL_TILE), gr_div_up(d3->height, TAIL_TILE));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_down_tail"};
 	auto launch = [&](auto kernel) {
-		hipLaunchKernelGGL(kernel, grid, dim3(256), 0, gr_to_stream(stream), to_dev(d1), to_dev_rw(d2), to_dev_rw(d3), to_dev(history), *push_d2, *push_d3);
+		hipLaunchKernelGGL(kernel, grid, dim3(256), 0, gr_to_stream(stream), to_dev(d1), to_dev_rw(d2), to_dev_rw(d3), to_dev(history), *push_d2, *push_d3, 0u,
+		                   d3->height);
 	};
 	const bool d2_exact = downsample_is_exact(d1, push_d2), d3_exact = downsample_is_exact(d2, push_d3);
-	if (d2_exact && d3_exact) launch(k_bloom_down_tail<true, true>);
-	else if (d2_exact) launch(k_bloom_down_tail<true, false>);
-	else if (d3_exact) launch(k_bloom_down_tail<false, true>);
-	else launch(k_bloom_down_tail<false, false>);
+	if (d2_exact && d3_exact) launch(k_bloom_down_pair<true, true, true>);
+	else if (d2_exact) launch(k_bloom_down_pair<true, false, true>);
+	else if (d3_exact) launch(k_bloom_down_pair<false, true, true>);
+	else launch(k_bloom_down_pair<false, false, true>);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

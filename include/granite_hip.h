@@ -210,6 +210,16 @@ int gr_bloom_tail_supported(const gr_image *d1, const gr_image *d2, const gr_ima
 int gr_bloom_down_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d1, const gr_image *d2, const gr_image *d3,
                        const gr_image *history, const gr_push_bloom_downsample *push_d2,
                        const gr_push_bloom_downsample *push_d3);
+/* downsample-0 and downsample-1 (hdr.cpp:358-362) in one launch, the same way: a workgroup makes an 8 x 8 tile of downsample-1 from
+ * the patch of downsample-0 under its taps, which it first makes from the threshold level and stores.  rows_d1 restricts
+ * downsample-1 (row bands; downsample-0 is written under those rows' taps).  Values in both levels are those of two
+ * gr_bloom_downsample calls, byte for byte.  gr_bloom_down_mid_supported(): whole levels whose patch fits (any pyramid of
+ * InputRelative sizes) and a downsample-1 of at most 65536 texels -- frames up to 1440p, where the chain of dependent launches sets
+ * the pace; above, the recomputed overlap costs more than the launch it saves (measured at 4K). */
+int gr_bloom_down_mid_supported(const gr_image *threshold, const gr_image *d0, const gr_image *d1, const gr_push_bloom_downsample *push_d0,
+                                const gr_push_bloom_downsample *push_d1);
+int gr_bloom_down_mid(gr_ctx *ctx, gr_stream stream, const gr_image *threshold, const gr_image *d0, const gr_image *d1,
+                      const gr_push_bloom_downsample *push_d0, const gr_push_bloom_downsample *push_d1, const gr_rows *rows_d1);
 /* lum / push_lum both NULL: no dynamic exposure, no luminance reduction. */
 int gr_bloom_up_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_image *u2, const gr_image *u1,
                      gr_luminance_data *lum, const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1,

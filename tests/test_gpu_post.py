@@ -191,6 +191,48 @@ def test_fused_pyramid_tail_equals_the_five_separate_launches(gr, w, h):
     assert got[True][4][0] != lum0[0]
 
 
+@pytest.mark.parametrize("w,h", [(1920, 1080), (2560, 1440), (1000, 808), (333, 250), (256, 256), (70, 38)])
+def test_fused_pyramid_middle_equals_the_two_separate_launches(gr, w, h):
+    """gr_bloom_down_mid (downsample-0 and downsample-1 through LDS, one launch) must leave the very bytes of two gr_bloom_downsample
+    calls in both levels -- exact 2:1 levels (1440p's 640 x 360 -> 320 x 180, 256 x 256), odd ones on the nine generic taps (1080p's 135
+    rows, 1000 x 808, 333 x 250), partial tiles -- and, restricted to a band of downsample-1 rows, in those rows and in the rows of
+    downsample-0 under their taps.  (Frames above 1440p keep the two launches: gr_bloom_down_mid_supported.)"""
+    sz = [orc.level_size(w, h, s) for s in (0.5, 0.25, 0.125)]
+    rng = np.random.default_rng(w * 17 + h)
+    t_bits = np.exp2(rng.uniform(-8, 6, (sz[0][1], sz[0][0], 4))).astype(np.float16).view(np.uint16)
+    t = capi.DeviceImage(gr, *sz[0], F16).upload(t_bits)
+    want_d0, want_d1 = capi.DeviceImage(gr, *sz[1], F16), capi.DeviceImage(gr, *sz[2], F16)
+    gr.bloom_downsample(t, want_d0)
+    gr.bloom_downsample(want_d0, want_d1)
+    d0, d1 = capi.DeviceImage(gr, *sz[1], F16), capi.DeviceImage(gr, *sz[2], F16)
+    assert gr.bloom_down_mid(t, d0, d1), "a pyramid of InputRelative sizes must qualify (GR_MID_FUSION_ANY_SIZE: also above 1440p)"
+    gr.sync()
+    ref0, ref1 = want_d0.download(), want_d1.download()
+    np.testing.assert_array_equal(d0.download(), ref0, err_msg="downsample-0")
+    np.testing.assert_array_equal(d1.download(), ref1, err_msg="downsample-1")
+    # a band of downsample-1 rows: those rows, and downsample-0 at least under their taps (1.75 texels either side), nothing of
+    # downsample-1 outside the band
+    h1, h0 = sz[2][1], sz[1][1]
+    first, count = h1 // 3, max(h1 // 4, 1)
+    poison = np.full((h1, sz[2][0], 4), 0x7bff, np.uint16)
+    b0, b1 = capi.DeviceImage(gr, *sz[1], F16), capi.DeviceImage(gr, *sz[2], F16).upload(poison)
+    assert gr.bloom_down_mid(t, b0, b1, rows=(first, count))
+    gr.sync()
+    got1, got0 = b1.download(), b0.download()
+    np.testing.assert_array_equal(got1[first:first + count], ref1[first:first + count])
+    assert (got1[:first] == 0x7bff).all() and (got1[first + count:] == 0x7bff).all()
+    scale = h0 / h1
+    lo = max(int(np.floor((first + 0.5) * scale - 0.5 - 1.75)), 0)
+    hi = min(int(np.floor((first + count - 0.5) * scale - 0.5 + 1.75)) + 1, h0 - 1)
+    np.testing.assert_array_equal(got0[lo:hi + 1], ref0[lo:hi + 1])
+
+
+def test_fused_pyramid_middle_is_for_launch_bound_frames_only(gr):
+    """At 4K the fused form recomputes more than the saved launch is worth (measured: the frame gets 3 % slower): not offered."""
+    t, d0, d1 = (capi.DeviceImage(gr, *orc.level_size(3840, 2160, s), F16) for s in (0.5, 0.25, 0.125))
+    assert not gr.bloom_down_mid(t, d0, d1)
+
+
 def test_fused_pyramid_tail_declines_what_it_does_not_cover(gr):
     """A level that is not ceil(half) of the one above (not a pyramid of render_graph.cpp's InputRelative sizes: the patch of upsample-2
     under a tile of upsample-1 would not fit the kernel's LDS) falls back to the separate launches."""
