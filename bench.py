@@ -176,7 +176,18 @@ def main():
         # Control plane only (barriers, the max-over-ranks reduction, shipping the RCCL id): gloo on the host.  The data
         # path's collectives are RCCL all-gathers issued by the executor itself on its own stream (gra_comm_init).
         import torch.distributed as dist
-        dist.init_process_group("gloo")
+        # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): the one line this script owes its caller
+        # on stdout is the JSON line, so stdout points at stderr while the group comes up and meets for the first time
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from granite_amd import app as gapp, multigpu, synth
 

@@ -64,6 +64,8 @@ def test_bench_runs_as_the_driver_launches_it_with_two_ranks():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    # ... and nothing else on stdout (gloo's connection banner goes to stderr)
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines, r.stdout[-2000:]
     doc = json.loads(lines[0])
     assert doc["n_gpus"] == 2 and doc["steps"] == 12 and doc["warmup"] == 3 and doc["scaling"] == "weak"
     assert "2 row bands" in doc["config"]["parallelism"] and "RGB888" in doc["config"]["parallelism"], doc["config"]["parallelism"]
