@@ -39,6 +39,10 @@ a.render_frames(2, sync=True)
 noisy = a.read_backbuffer().copy()
 a.close()
 inputs = {"test card": synth.make_ldr_pattern(w, h), "tonemapped noise": noisy}
+# AA_TIME_INPUT=card|noise: one input only (for profiler runs, whose per-kernel means would otherwise mix the two)
+only = os.environ.get("AA_TIME_INPUT")
+if only:
+    inputs = {k: v for k, v in inputs.items() if only in k}
 print(f"{w}x{h}")
 for title, ldr in inputs.items():
     src = capi.DeviceImage(gr, w, h, RGBA8).upload(ldr)
