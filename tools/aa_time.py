@@ -16,8 +16,8 @@ gr.smaa_set_luts(*load_smaa_luts())
 RGBA8, F16 = capi.FORMAT_R8G8B8A8_UNORM, capi.FORMAT_R16G16B16A16_SFLOAT
 
 
-def timed(label, names, fn, algo_bytes, reps=20):
-    for _ in range(3):
+def timed(label, names, fn, algo_bytes, reps=int(os.environ.get("AA_TIME_REPS", "20"))):  # AA_TIME_REPS: fewer launches under a counter pass
+    for _ in range(min(3, reps)):
         fn()
     gr.sync()
     gr.timing_reset(); gr.timing_enable(True)
