@@ -420,27 +420,44 @@ def main():
                 pmc = json.load(f)
             entry = pmc["kernels"].get(dominant)
             if entry and args.workload == "config3_4k_4096lights" and world == 1:
-                # counters of another build of the kernel say nothing about this one
+                # Counters of another build of the kernel: the HBM traffic figure is not quoted for it; the instruction counts are, marked
+                # stale (they move by a few per cent between builds, the binding resource does not).
                 import hashlib
                 src = entry.get("source_file")
                 current = hashlib.sha256(open(os.path.join(ROOT, src), "rb").read()).hexdigest() if src else None
-                if current is None or current != entry.get("source_sha256"):
+                stale = current is None or current != entry.get("source_sha256")
+                if stale:
                     roofline["traffic_source"] = (f"profiles/pmc_traffic.json is stale: {src or 'the kernel source'} changed since the counters were "
                                                   "collected (tools/pmc_passes.sh regenerates it); traffic not quoted")
-                    entry = None
-            if entry and args.workload == "config3_4k_4096lights" and world == 1:
-                roofline["traffic"] = entry["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/pmc_traffic.json (" + pmc["source"] + "; " + entry["correction"] + ")"
+                else:
+                    roofline["traffic"] = entry["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = "profiles/pmc_traffic.json (" + pmc["source"] + "; " + entry["correction"] + ")"
                 valu = entry.get("SQ_INSTS_VALU")
                 roofline["valu_instructions_per_launch"] = valu
                 if valu:
-                    # The kernel is VALU-issue-bound on this workload, not HBM-bound (traffic == algorithmic bytes): wave64
-                    # fp32 instructions issued per launch x 2 cycles against 1024 SIMDs at the 2.4 GHz maximum clock.
-                    roofline["valu_issue"] = {"frac": valu * VALU_CYCLES_PER_INST / (VALU_SIMDS * VALU_CLOCK_HZ * dom_avg_s),
+                    # wave64 VALU instructions issued per launch x 2 cycles against 1024 SIMDs at the 2.4 GHz maximum clock
+                    valu_peak_us = 1e6 * valu * VALU_CYCLES_PER_INST / (VALU_SIMDS * VALU_CLOCK_HZ)
+                    roofline["valu_peak_us"] = valu_peak_us
+                    roofline["valu_issue"] = {"frac": valu_peak_us / (1e6 * dom_avg_s),
                                               "peak": "1024 SIMD-32 x 2.4 GHz, 2 cycles per wave64 fp32 instruction",
-                                              "class_histogram": entry.get("valu_class_histogram")}
+                                              "class_histogram": entry.get("valu_class_histogram"), "counters_stale": stale}
+                    # Class-weighted issue time: the measured cost of each opcode class on this chip (profiles/r02_valu_issue_rates.txt,
+                    # cycles per wave64 instruction at the ~2.0 GHz a dense fp32 loop sustains) x the PMC class counts.
+                    hist = entry.get("valu_class_histogram") or {}
+                    if hist:
+                        cost = {"fma_f32": 2.3, "mul_f32": 2.3, "add_f32": 2.3, "transcendental_f32": 7.2, "cvt": 3.5, "int32": 2.2}
+                        cycles = sum(n * cost.get(k, 3.7) for k, n in hist.items())
+                        roofline["valu_issue"]["class_weighted_model_us"] = 1e6 * cycles / (VALU_SIMDS * 2.0e9)
+                        roofline["valu_issue"]["class_weighted_model"] = ("sum over PMC instruction classes of count x measured issue cycles (fp32 fma/mul/add 2.3, "
+                                                                         "transcendental 7.2, cvt 3.5, int 2.2, others 3.7) / 1024 SIMDs / 2.0 GHz sustained")
         except (OSError, KeyError, ValueError):
             pass
+        # The binding resource of the dominant kernel: whichever ceiling it sits closer to.  `frac` stays the HBM fraction the metric asks for.
+        vf = (roofline.get("valu_issue") or {}).get("frac")
+        roofline["hbm_frac"] = roofline["frac"]
+        if vf is not None and vf > roofline["frac"]:
+            roofline["bound"] = "valu"
+            roofline["bound_detail"] = ("VALU issue: %.2f of the 2-cycle issue peak against %.2f of the HBM peak; traffic == algorithmic bytes" % (vf, roofline["frac"]))
     chain_bytes = CHAIN_BYTES_PER_PX.get(args.workload, ALGO_BYTES_PER_PX["chain"]) * width * height
     chain_gbs = chain_bytes * args.steps / elapsed / 1e9
 

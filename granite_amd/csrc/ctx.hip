@@ -198,7 +198,17 @@ gr_ctx *gr_create(int device)
 		volatile float phi = 2.0f * 3.1415628f * u2;
 		azimuth[i] = make_float2(cosf(phi), sinf(phi));
 	}
+	hipDeviceProp_t props{};
+	if (hipGetDeviceProperties(&props, device) == hipSuccess)
+	{
+		ctx->compute_units = props.multiProcessorCount;
+		// One MI355X in SPX mode: 8 XCDs x 32 CUs behind one agent, workgroups dealt to the XCDs in turn.
+		ctx->eight_xcd_partition = props.multiProcessorCount == 256 && strncmp(props.gcnArchName, "gfx950", 6) == 0;
+	}
+	const size_t queue_bytes = size_t(gr_ctx::LIGHTING_QUEUE_SLOTS) * gr_ctx::LIGHTING_QUEUE_SLOT_BYTES;
 	if (encode_table_status != 0 || tonemap_table_status != 0 ||
+	    hipMalloc(reinterpret_cast<void **>(&ctx->lighting_queues), queue_bytes) != hipSuccess ||
+	    hipMemset(ctx->lighting_queues, 0, queue_bytes) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->ssr_azimuth_lut), sizeof(azimuth)) != hipSuccess ||
 	    hipMemcpy(ctx->ssr_azimuth_lut, azimuth, sizeof(azimuth), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->tonemap_srgb8_lut), sizeof(tonemap_table)) != hipSuccess ||
@@ -229,6 +239,8 @@ void gr_destroy(gr_ctx *ctx)
 		(void)hipEventDestroy(e);
 	if (ctx->srgb_decode_lut)
 		(void)hipFree(ctx->srgb_decode_lut);
+	if (ctx->lighting_queues)
+		(void)hipFree(ctx->lighting_queues);
 	if (ctx->srgb_encode_lut)
 		(void)hipFree(ctx->srgb_encode_lut);
 	if (ctx->tonemap_srgb8_lut)

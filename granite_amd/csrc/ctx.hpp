@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -33,6 +34,15 @@ struct gr_ctx
 	// SSR (ssr.hip): cos / sin of the 256 azimuths 2 pi u / 255 the dither texture's byte can select (sssr_util.h: SampleGGXVNDF),
 	// evaluated once on the host: the traced directions then do not depend on the device's trigonometric approximations.
 	float2 *ssr_azimuth_lut = nullptr;
+
+	// Lighting (lighting.hip, persistent form): a ring of ticket-queue sets ({epoch | ticket} words, one cache line per queue, one
+	// queue per workgroup of the launch, at most 1024), zero-initialised once; a launch takes the next slot and a fresh epoch, so launches in flight on different
+	// streams never share a counter and nothing is ever reset.  compute_units / xcds describe the device the context sits on.
+	static constexpr unsigned LIGHTING_QUEUE_SLOTS = 32, LIGHTING_QUEUE_SLOT_BYTES = 1024 * 128;
+	unsigned long long *lighting_queues = nullptr;
+	std::atomic<uint64_t> lighting_launches{0};
+	int compute_units = 0;
+	bool eight_xcd_partition = false;
 
 	// SMAA lookup tables (assets/textures/smaa/{area,search}.gtx payloads), uploaded through gr_smaa_set_luts.
 	void *smaa_area = nullptr;   // 160 x 560 x 2 floats (the RG8 area texture, decoded)

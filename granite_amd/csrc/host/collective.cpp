@@ -38,6 +38,9 @@ const Api &api()
 	static std::once_flag once;
 	std::call_once(once, []() {
 		void *lib = nullptr;
+#ifdef GRANITE_TEST_HOOKS
+		// Test builds only (make testhooks -> granite_amd/lib_testhooks, -DGRANITE_TEST_HOOKS): the product library does not contain this
+		// branch and cannot be pointed at anything but librccl.so.1.
 		if (const char *other = getenv("GRANITE_RCCL_LIBRARY"))
 		{
 			// Another implementation of the same five entry points (tests/rccl_shim: several ranks on ONE GPU, which RCCL refuses).
@@ -52,6 +55,10 @@ const Api &api()
 			if (!lib)
 				throw std::runtime_error(std::string("cannot load GRANITE_RCCL_LIBRARY: ") + dlerror());
 		}
+#else
+		if (getenv("GRANITE_RCCL_LIBRARY"))
+			fprintf(stderr, "[granite-hip] note: GRANITE_RCCL_LIBRARY is ignored: this library was built without GRANITE_TEST_HOOKS\n");
+#endif
 		if (!lib)
 			lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
 		if (!lib)

@@ -30,6 +30,7 @@
 // The BRDF is algebraically the reference's; normalisations are folded (dot products on the unnormalised light vector,
 // H.V = |V+L|/2, one rcp for G*D) to cut the per-light VALU count.
 #include <cstdlib>
+#include <cstring>
 #include "ctx.hpp"
 #include "device_common.hpp"
 
@@ -85,7 +86,11 @@ struct KernelArgs
 	const float *__restrict__ srgb_lut;
 	uint32_t flags;
 	float fog_color[3], fog_falloff; // the fog quad behind the clustered one (renderer.cpp:1179-1196); falloff <= 0: none
-	int blocks_x, num_blocks, blocks_per_xcd;
+	int blocks_x, num_blocks, blocks_per_xcd, banded; // static form
+	int tiles_x, num_tiles;                            // persistent form: wave tiles of 8 PX x 8 pixels over the render area
+	int tiles_per_queue, tiles_remainder;              // num_tiles = tiles_per_queue * gridDim.x + tiles_remainder
+	unsigned long long *queues;                        // LIGHT_QUEUES ticket words, one cache line each
+	uint32_t epoch;
 	int row_first, row_end, block_row0; // render area rows [row_first, row_end); first block row = row_first / 8
 };
 
@@ -251,37 +256,86 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 	}
 }
 
-// AO: the AMBIENT_OCCLUSION shader variant (renderer.cpp:1050-1051), a separate instantiation so that the default kernel keeps
-// its register budget.
-// B10: emissive and the HDR target are B10G11R11_UFLOAT_PACK32 (the reference's default, renderTargetFp16 = false): 4-byte
-// texels, both blends round to the packed format (device_common.hpp: float_to_ufloat).
-template <int PX, bool AO, bool B10 = false>
-__global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
+// What a lane reads of its PX pixels, as loaded: the persistent kernel holds the NEXT tile's words in these registers while it
+// shades the current one (11 VGPRs for PX = 2, RGBA16F).
+template <int PX, bool B10>
+struct RawTile
 {
-	__shared__ __attribute__((aligned(16))) f32x4 s_lights[LIGHT_WAVES][64 * (LIGHT_SLOT_BYTES / 16)];
-	__shared__ float s_srgb[256];
-	constexpr int TILE_W = LIGHT_TILE * PX;
+	float depth[PX];
+	uint32_t alb[PX], nrm[PX];
+	uint32_t mr;                     // PX == 2: both pixels' (metallic, roughness) byte pairs
+	uint32_t em[B10 ? PX : 2 * PX];  // emissive texels, packed as stored
+};
 
-	// XCD-aware tile order: block b runs on XCD b % 8; give each XCD one contiguous band of the screen so the cluster
-	// words and light records a band needs stay in that XCD's L2.
-	const int logical = int(blockIdx.x & 7u) * a.blocks_per_xcd + int(blockIdx.x >> 3);
-	if (logical >= a.num_blocks)
+// Attachment loads of one tile, all issued back to back.  Byte offsets are 32-bit (images < 4 GiB, checked by the launcher), so
+// every load is base SGPR pair + one VGPR offset.  PX == 2 is only launched for even widths and pitches that keep the pair of
+// texels naturally aligned: the lane's two pixels are inside or outside together and come in with one load per attachment.
+// Lanes outside the render area keep depth 0 (= "not lit").
+template <int PX, bool B10>
+__device__ __forceinline__ void load_raw(const KernelArgs &a, int x0, int y, RawTile<PX, B10> &r)
+{
+#pragma unroll
+	for (int p = 0; p < PX; p++)
+	{
+		r.depth[p] = 0.0f;
+		r.alb[p] = r.nrm[p] = 0u;
+	}
+	r.mr = 0u;
+#pragma unroll
+	for (int i = 0; i < (B10 ? PX : 2 * PX); i++)
+		r.em[i] = 0u;
+	if (!(y >= a.row_first && y < a.row_end && x0 < a.hdr.w))
 		return;
-	// sRGB8 -> linear table into LDS: one entry per thread (64 * LIGHT_WAVES = 256), the only workgroup-wide step.
-	s_srgb[threadIdx.x] = a.srgb_lut[threadIdx.x];
-	const int block_x = logical % a.blocks_x, block_y = a.block_row0 + logical / a.blocks_x;
-	const int wave = threadIdx.x >> 6;
-	const int lane = threadIdx.x & 63;
-	const int tile_x0 = (block_x * LIGHT_WAVES + wave) * TILE_W, tile_y0 = block_y * LIGHT_TILE;
+	const uint32_t uy = uint32_t(y), ux = uint32_t(x0);
+	if constexpr (PX == 2)
+	{
+		const float2 d = *reinterpret_cast<const float2 *>(a.depth.ptr + (uy * a.depth.pitch + ux * 4u));
+		const uint2 al = *reinterpret_cast<const uint2 *>(a.albedo.ptr + (uy * a.albedo.pitch + ux * 4u));
+		const uint2 nr = *reinterpret_cast<const uint2 *>(a.normal.ptr + (uy * a.normal.pitch + ux * 4u));
+		r.mr = *reinterpret_cast<const uint32_t *>(a.pbr.ptr + (uy * a.pbr.pitch + ux * 2u));
+		if constexpr (B10)
+		{
+			const uint2 packed = *reinterpret_cast<const uint2 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 4u));
+			r.em[0] = packed.x, r.em[1] = packed.y;
+		}
+		else
+		{
+			const uint4 em = *reinterpret_cast<const uint4 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 8u));
+			r.em[0] = em.x, r.em[1] = em.y, r.em[2] = em.z, r.em[3] = em.w;
+		}
+		r.depth[0] = d.x, r.depth[PX - 1] = d.y;
+		r.alb[0] = al.x, r.alb[PX - 1] = al.y;
+		r.nrm[0] = nr.x, r.nrm[PX - 1] = nr.y;
+	}
+	else
+	{
+		r.depth[0] = *reinterpret_cast<const float *>(a.depth.ptr + (uy * a.depth.pitch + ux * 4u));
+		r.alb[0] = *reinterpret_cast<const uint32_t *>(a.albedo.ptr + (uy * a.albedo.pitch + ux * 4u));
+		r.nrm[0] = *reinterpret_cast<const uint32_t *>(a.normal.ptr + (uy * a.normal.pitch + ux * 4u));
+		r.mr = *reinterpret_cast<const uint16_t *>(a.pbr.ptr + (uy * a.pbr.pitch + ux * 2u));
+		if constexpr (B10)
+			r.em[0] = *reinterpret_cast<const uint32_t *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 4u));
+		else
+		{
+			const uint2 em = *reinterpret_cast<const uint2 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 8u));
+			r.em[0] = em.x, r.em[1] = em.y;
+		}
+	}
+}
+
+// One wave, one tile of 8 PX x 8 pixels whose attachment words are in `raw`: both quads, the fog quad, the store.
+// `prefetch` is called exactly once, at the point where the tile has consumed its own gather loads and only the light walk is
+// left: whatever it loads (the persistent kernel: the next tile's attachments) returns under the walk.
+template <int PX, bool AO, bool B10, typename Prefetch>
+__device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x0, const int tile_y0, const int lane, const RawTile<PX, B10> &raw,
+                                           f32x4 *const slots, const float *s_srgb, Prefetch &&prefetch)
+{
+	constexpr int TILE_W = LIGHT_TILE * PX;
 	const int x0 = tile_x0 + (lane & (LIGHT_TILE - 1)) * PX;
 	const int y = tile_y0 + (lane >> 3);
 	const int W = a.hdr.w, H = a.hdr.h;
 	const bool row_inside = y >= a.row_first && y < a.row_end; // row_end <= H
 
-	// ---- attachment loads, all issued before the first use.  Byte offsets are 32-bit (images < 4 GiB, checked by the
-	// launcher), so every load is base SGPR pair + one VGPR offset.  PX == 2 is only launched for even widths and pitches
-	// that keep the pair of texels naturally aligned: the lane's two pixels are inside or outside together and come in
-	// with one load per attachment. ----
 	bool inside[PX], active[PX];
 	f16x4 dst[PX];
 	float depth_v[PX];
@@ -290,52 +344,20 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 	for (int p = 0; p < PX; p++)
 	{
 		inside[p] = row_inside && x0 + p < W;
-		depth_v[p] = 0.0f;
-		alb_v[p] = nrm_v[p] = mr_v[p] = 0u;
-		dst[p] = f16x4{0, 0, 0, 0};
-	}
-	if (inside[0])
-	{
-		const uint32_t uy = uint32_t(y), ux = uint32_t(x0);
-		if constexpr (PX == 2)
+		depth_v[p] = raw.depth[p];
+		alb_v[p] = raw.alb[p];
+		nrm_v[p] = raw.nrm[p];
+		mr_v[p] = PX == 2 ? (p == 0 ? raw.mr & 0xffffu : raw.mr >> 16) : raw.mr;
+		if constexpr (B10)
 		{
-			const float2 d = *reinterpret_cast<const float2 *>(a.depth.ptr + (uy * a.depth.pitch + ux * 4u));
-			const uint2 al = *reinterpret_cast<const uint2 *>(a.albedo.ptr + (uy * a.albedo.pitch + ux * 4u));
-			const uint2 nr = *reinterpret_cast<const uint2 *>(a.normal.ptr + (uy * a.normal.pitch + ux * 4u));
-			const uint32_t m2 = *reinterpret_cast<const uint32_t *>(a.pbr.ptr + (uy * a.pbr.pitch + ux * 2u));
-			uint4 em;
-			if constexpr (B10)
-			{
-				const uint2 packed = *reinterpret_cast<const uint2 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 4u));
-				const u32x4 e = expand_b10g11r11_pair(packed.x, packed.y);
-				em = make_uint4(e.x, e.y, e.z, e.w);
-			}
-			else
-				em = *reinterpret_cast<const uint4 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 8u));
-			depth_v[0] = d.x, depth_v[PX - 1] = d.y;
-			alb_v[0] = al.x, alb_v[PX - 1] = al.y;
-			nrm_v[0] = nr.x, nrm_v[PX - 1] = nr.y;
-			mr_v[0] = m2 & 0xffffu, mr_v[PX - 1] = m2 >> 16;
-			dst[0] = __builtin_bit_cast(f16x4, make_uint2(em.x, em.y));
-			dst[PX - 1] = __builtin_bit_cast(f16x4, make_uint2(em.z, em.w));
+			uint32_t rg, ba;
+			expand_b10g11r11(raw.em[p], rg, ba);
+			dst[p] = __builtin_bit_cast(f16x4, make_uint2(rg, ba));
 		}
 		else
-		{
-			depth_v[0] = *reinterpret_cast<const float *>(a.depth.ptr + (uy * a.depth.pitch + ux * 4u));
-			alb_v[0] = *reinterpret_cast<const uint32_t *>(a.albedo.ptr + (uy * a.albedo.pitch + ux * 4u));
-			nrm_v[0] = *reinterpret_cast<const uint32_t *>(a.normal.ptr + (uy * a.normal.pitch + ux * 4u));
-			mr_v[0] = *reinterpret_cast<const uint16_t *>(a.pbr.ptr + (uy * a.pbr.pitch + ux * 2u));
-			if constexpr (B10)
-			{
-				uint32_t rg, ba;
-				expand_b10g11r11(*reinterpret_cast<const uint32_t *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 4u)), rg, ba);
-				dst[0] = __builtin_bit_cast(f16x4, make_uint2(rg, ba));
-			}
-			else
-				dst[0] = *reinterpret_cast<const f16x4 *>(a.emissive.ptr + (uy * a.emissive.pitch + ux * 8u));
-		}
+			dst[p] = __builtin_bit_cast(f16x4, make_uint2(raw.em[2 * p], raw.em[2 * p + 1]));
 	}
-	__syncthreads(); // s_srgb
+	bool prefetched = false;
 
 	// ---- position reconstruction (clustering.vert:10-13, clustering.frag:37-39): clip = invVP * (ndc.xy, depth, 1),
 	// pos = clip.xyz / clip.w.  Evaluated with fused multiply-adds and a Newton-refined reciprocal; a pixel that lands
@@ -489,7 +511,6 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 			const float tile_radius =
 			    __builtin_amdgcn_sqrtf(__builtin_bit_cast(float, wave_minmax_u32<true>(__builtin_bit_cast(uint32_t, off2)))) * 1.0001f + CULL_SLACK;
 
-			f32x4 *const slots = s_lights[wave];
 			const int chunk_lo = int(win_lo >> 6u), chunk_hi = int(win_hi >> 6u);
 			for (int chunk = chunk_lo; chunk <= chunk_hi; chunk++)
 			{
@@ -570,6 +591,13 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 					}
 				}
 				__builtin_amdgcn_wave_barrier(); // LDS is wave-private: in-order DS execution is the only ordering needed
+				// The first chunk's bitmask words and light records are in: nothing this tile still has to wait for was issued
+				// before this point (vmcnt returns in order), so the caller's loads go out here and come back under the walk.
+				if (!prefetched)
+				{
+					prefetch();
+					prefetched = true;
+				}
 
 				// ---- shade: PX pixels per lane, lights broadcast from LDS ----
 				const f32x4 *slot = slots;
@@ -617,6 +645,8 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		}
 	}
 
+	if (!prefetched)
+		prefetch();
 	if (!inside[0])
 		return;
 	f16x4 o[PX];
@@ -678,6 +708,235 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		}
 		else
 			*reinterpret_cast<f16x4 *>(out) = o[0];
+	}
+}
+
+#ifdef LV_STAMP
+// Measurement build only (make OUT=../lib_stamp EXTRA_lighting=-DLV_STAMP, tools/lighting_stamps.py): one record per wave tile,
+// {start, end} of the 100 MHz s_memrealtime counter, the shader-clock cycles in between, and where the wave ran.
+__device__ uint4 *g_lighting_stamps;
+__device__ uint32_t g_lighting_stamp_records; // second half of the array: per-tile ticket wait
+struct StampScope
+{
+	uint4 *rec;
+	uint64_t t0, c0;
+	__device__ __forceinline__ StampScope(uint32_t tile)
+	{
+		rec = g_lighting_stamps ? g_lighting_stamps + tile : nullptr;
+		t0 = __builtin_amdgcn_s_memrealtime();
+		c0 = __builtin_amdgcn_s_memtime();
+	}
+	__device__ __forceinline__ ~StampScope()
+	{
+		__builtin_amdgcn_s_waitcnt(0); // the tile's stores have left
+		const uint64_t t1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
+		uint32_t xcc, hw;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+		if (rec && (threadIdx.x & 63u) == 0u)
+			*rec = make_uint4(uint32_t(t0), uint32_t(t1), uint32_t(c1 - c0), (xcc << 28) | (hw & 0x0fffffffu));
+	}
+};
+#define LV_STAMP_SCOPE(tile) StampScope stamp_scope__{uint32_t(tile)}
+// cycles the wave waits for its next ticket (the atomic asked for at the top of the tile), into the second half of the record array
+#define LV_STAMP_WAIT_BEGIN() const uint64_t wait_c0__ = __builtin_amdgcn_s_memtime()
+#define LV_STAMP_WAIT_END()                                                                                   \
+	do                                                                                                        \
+	{                                                                                                         \
+		const uint64_t wait_c1__ = __builtin_amdgcn_s_memtime();                                              \
+		if (stamp_scope__.rec && lane == 0)                                                                   \
+			stamp_scope__.rec[g_lighting_stamp_records] = make_uint4(uint32_t(wait_c1__ - wait_c0__), 0u, 0u, 0u); \
+	} while (0)
+#else
+#define LV_STAMP_SCOPE(tile)
+#define LV_STAMP_WAIT_BEGIN()
+#define LV_STAMP_WAIT_END()
+#endif
+
+// AO: the AMBIENT_OCCLUSION shader variant (renderer.cpp:1050-1051), a separate instantiation so that the default kernel keeps
+// its register budget.
+// B10: emissive and the HDR target are B10G11R11_UFLOAT_PACK32 (the reference's default, renderTargetFp16 = false): 4-byte
+// texels, both blends round to the packed format (device_common.hpp: float_to_ufloat).
+//
+// Static form: the grid is the tile list, four waves side by side per workgroup (a 32 PX x 8 block).  Kept for devices that are not
+// one 8-XCD partition and for the A/B (GR_LIGHTING_STATIC=1).
+template <int PX, bool AO, bool B10 = false>
+__global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
+{
+	__shared__ __attribute__((aligned(16))) f32x4 s_lights[LIGHT_WAVES][64 * (LIGHT_SLOT_BYTES / 16)];
+	__shared__ float s_srgb[256];
+	constexpr int TILE_W = LIGHT_TILE * PX;
+
+	// Tile order.  Block b runs on XCD b % 8.  banded: each XCD gets one contiguous band of the screen (cluster words and light
+	// records of a band stay in that XCD's L2, but the bands' light counts differ: the slowest XCD is the launch);
+	// otherwise blocks in screen order, i.e. every XCD takes every eighth block.
+	int logical = int(blockIdx.x);
+	if (a.banded)
+		logical = int(blockIdx.x & 7u) * a.blocks_per_xcd + int(blockIdx.x >> 3);
+	if (logical >= a.num_blocks)
+		return;
+	// sRGB8 -> linear table into LDS: one entry per thread (64 * LIGHT_WAVES = 256), the only workgroup-wide step.
+	s_srgb[threadIdx.x] = a.srgb_lut[threadIdx.x];
+	const int block_x = logical % a.blocks_x, block_y = a.block_row0 + logical / a.blocks_x;
+	const int wave = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const int tile_x0 = (block_x * LIGHT_WAVES + wave) * TILE_W, tile_y0 = block_y * LIGHT_TILE;
+	RawTile<PX, B10> raw;
+	load_raw<PX, B10>(a, tile_x0 + (lane & (LIGHT_TILE - 1)) * PX, tile_y0 + (lane >> 3), raw);
+	__syncthreads(); // s_srgb
+	LV_STAMP_SCOPE(logical * LIGHT_WAVES + wave);
+	shade_tile<PX, AO, B10>(a, tile_x0, tile_y0, lane, raw, s_lights[wave], s_srgb, []() {});
+}
+
+// Persistent form: the grid is the machine (as many workgroups as stay resident), and every WAVE deals itself tiles until the frame
+// is done.
+//   * Tiles cost between a copy (sky) and several light chunks.  A static grid holds a workgroup's four wave slots until its slowest
+//     tile is done and pays the launch prologue (argument loads, the table, a barrier) 16 200 times: measured, 27 % of the wave-slot
+//     time of the static launch is spent outside tiles (profiles/r04_lighting_tiles_static_screen_order.txt).  Here a wave that
+//     finishes takes its next tile at once.
+//   * One queue per workgroup, tile t in queue t % Q.  A queue is a ticket counter in its own cache line: four waves take about one
+//     ticket every 2 us from it.  (Eight queues for the chip -- one per XCD, 8 100 tickets each per launch -- were tried first: the
+//     same-address atomics serialise in the L2 and the waves queue up behind the counter, 227 us against 181 us for the static grid,
+//     profiles/r04_lighting_tiles_persistent_8queues.txt.)
+//   * A workgroup whose queue has run dry reads all counters at once (16 loads per lane in flight, one round trip) and moves to the
+//     nearest queue that still has tiles -- queue ids are XCD-major, so that is a neighbour on its own XCD while there is one.  The
+//     counters are ordinary agent-scope atomics: which queue a wave serves is a matter of speed, never of correctness.
+//   * A queue word is {epoch : 32 | next ticket : 32}.  A wave first raises the word to {this launch's epoch, 0} (atomic max,
+//     idempotent), then adds: no reset pass, no assumption about who else has seen the queue.  Epochs grow per slot; concurrent
+//     launches (two frames' fronts on two streams) use different slots of the ring in gr_ctx.
+//   * While a tile's lights are walked the next tile's attachment words (ticket taken at the top of this tile) are already on
+//     their way into registers: the G-buffer latency of a tile is hidden under its predecessor's arithmetic.
+constexpr int LIGHT_MAX_QUEUES = 1024;  // = the largest persistent grid (gr_ctx::LIGHTING_QUEUE_SLOT_BYTES)
+constexpr int LIGHT_QUEUE_STRIDE = 16;  // uint64 words = 128 B: one queue per cache line
+
+// The compiler must not know that two tiles read the same argument block (see the loop below).
+typedef const KernelArgs __attribute__((address_space(4))) *ConstantArgsPtr;
+__device__ __forceinline__ const KernelArgs *launder_arguments()
+{
+	// the kernel's only parameter is the block itself: it sits at the start of the kernel-argument segment
+	ConstantArgsPtr p = (ConstantArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(p));
+	return (const KernelArgs *)p;
+}
+
+template <int PX, bool AO, bool B10 = false>
+__global__ __launch_bounds__(64 * LIGHT_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lighting_persistent(const KernelArgs a_)
+{
+	const KernelArgs &a = a_;
+	__shared__ __attribute__((aligned(16))) f32x4 s_lights[LIGHT_WAVES][64 * (LIGHT_SLOT_BYTES / 16)];
+	__shared__ float s_srgb[256];
+	constexpr int TILE_W = LIGHT_TILE * PX;
+	s_srgb[threadIdx.x] = a.srgb_lut[threadIdx.x];
+	const int wave = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	f32x4 *const slots = s_lights[wave];
+	__syncthreads(); // s_srgb; the waves never meet again
+
+	const uint64_t epoch_word = uint64_t(a.epoch) << 32;
+	const int tiles_x = a.tiles_x;
+	const int num_queues = int(gridDim.x);
+	const int tiles_quotient = a.tiles_per_queue, tiles_remainder = a.tiles_remainder; // num_tiles = quotient Q + remainder
+	auto tiles_of_queue = [tiles_quotient, tiles_remainder](int queue) { return tiles_quotient + (queue < tiles_remainder ? 1 : 0); }; // t = queue + Q k < num_tiles
+	// Workgroup b runs on XCD b % 8: XCD-major queue ids put the queues of one XCD side by side (the order a thief looks in).
+	const int home = (num_queues & 7) == 0 ? int(blockIdx.x & 7u) * (num_queues >> 3) + int(blockIdx.x >> 3) : int(blockIdx.x);
+
+	int q = home;
+	for (;;)
+	{
+		const int queue_tiles = tiles_of_queue(q);
+		unsigned long long *const word = a.queues + q * LIGHT_QUEUE_STRIDE;
+		// One lane talks to the queue; the ticket travels to the others through an SGPR.
+		auto ticket_of = [&](uint64_t w) -> int {
+			const uint32_t k = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(w))));
+			return k < uint32_t(queue_tiles) ? int(k) * num_queues + q : -1;
+		};
+		uint64_t taken = 0;
+		if (lane == 0)
+		{
+			__hip_atomic_fetch_max(word, epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			taken = __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		int tile = ticket_of(taken);
+		RawTile<PX, B10> raw;
+		if (tile >= 0)
+		{
+			const int tx = tile % tiles_x, ty = tile / tiles_x;
+			load_raw<PX, B10>(a, tx * TILE_W + (lane & (LIGHT_TILE - 1)) * PX, (a.block_row0 + ty) * LIGHT_TILE + (lane >> 3), raw);
+		}
+		while (tile >= 0)
+		{
+			// The argument block (~100 dwords) is read from the kernel-argument segment where it is used, every tile anew, as the static
+			// form does once per workgroup: held in SGPRs across the loop it does not fit and spills into VGPR lanes (v_writelane /
+			// v_readlane pairs inside the walk).  s_load hits the scalar cache and costs no vector issue slot.
+			const KernelArgs &a = *launder_arguments();
+			LV_STAMP_SCOPE(tile);
+			const int tx = tile % tiles_x, ty = tile / tiles_x;
+			// the next ticket: asked for now, looked at when this tile's gather is through
+			uint64_t next_taken = 0;
+			if (lane == 0)
+				next_taken = __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			int next_tile = -1;
+			RawTile<PX, B10> next_raw;
+			shade_tile<PX, AO, B10>(a, tx * TILE_W, (a.block_row0 + ty) * LIGHT_TILE, lane, raw, slots, s_srgb, [&]() {
+				LV_STAMP_WAIT_BEGIN();
+				next_tile = ticket_of(next_taken);
+				LV_STAMP_WAIT_END();
+				if (next_tile >= 0)
+				{
+					const int nx = next_tile % tiles_x, ny = next_tile / tiles_x;
+					load_raw<PX, B10>(a, nx * TILE_W + (lane & (LIGHT_TILE - 1)) * PX, (a.block_row0 + ny) * LIGHT_TILE + (lane >> 3), next_raw);
+				}
+			});
+			raw = next_raw;
+			tile = next_tile;
+		}
+		// This queue is dry.  All counters at once, then the nearest queue after this wave's home that still has tiles or that nobody has
+		// opened in this launch.
+		uint64_t seen[LIGHT_MAX_QUEUES / 64];
+		unsigned long long *scan_base = a.queues + lane * LIGHT_QUEUE_STRIDE;
+		asm volatile("" : "+v"(scan_base)); // the sixteen addresses are made here, not kept in registers across the tile loop
+#pragma unroll
+		for (int c = 0; c < LIGHT_MAX_QUEUES / 64; c++)
+		{
+			seen[c] = ~0ull;
+			if (c * 64 + lane < num_queues)
+				seen[c] = __hip_atomic_load(scan_base + c * 64 * LIGHT_QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		int victim = -1, best_distance = 0x7fffffff;
+#pragma unroll
+		for (int c = 0; c < LIGHT_MAX_QUEUES / 64; c++)
+		{
+			const int candidate = c * 64 + lane;
+			const bool open = candidate < num_queues && !(uint32_t(seen[c] >> 32) == a.epoch && uint32_t(seen[c]) >= uint32_t(tiles_of_queue(candidate)));
+			const uint64_t open_mask = __ballot(open);
+			if (open_mask == 0ull)
+				continue;
+			// distance walking upwards from home, wrapping: the chunk's nearest open queue
+			const int base = c * 64;
+			const int from = home - base; // home's position relative to this chunk
+			uint64_t ahead = from >= 64 ? 0ull : (from <= 0 ? open_mask : open_mask & (~0ull << from));
+			int nearest, distance;
+			if (ahead != 0ull)
+			{
+				nearest = base + __builtin_ctzll(ahead);
+				distance = nearest - home;
+				if (distance < 0)
+					distance += num_queues;
+			}
+			else
+			{
+				nearest = base + __builtin_ctzll(open_mask);
+				distance = nearest - home + num_queues;
+			}
+			if (distance < best_distance)
+			{
+				best_distance = distance;
+				victim = nearest;
+			}
+		}
+		if (victim < 0)
+			break;
+		q = victim;
 	}
 }
 
@@ -796,9 +1055,11 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	// 32-bit byte offsets inside the kernel.
 	GR_CHECK_ARG(ctx, uint64_t(args->hdr.pitch_bytes) * H <= 0xffffffffull && uint64_t(args->emissive.pitch_bytes) * H <= 0xffffffffull);
 	k.blocks_x = int(gr_div_up(W, LIGHT_TILE * px * LIGHT_WAVES));
-	k.num_blocks = k.blocks_x * (int(gr_div_up(row_end, LIGHT_TILE)) - k.block_row0);
+	const int block_rows = int(gr_div_up(row_end, LIGHT_TILE)) - k.block_row0;
+	k.num_blocks = k.blocks_x * block_rows;
 	k.blocks_per_xcd = (k.num_blocks + 7) / 8;
-	dim3 grid(unsigned(k.blocks_per_xcd) * 8u);
+	k.tiles_x = int(gr_div_up(W, LIGHT_TILE * px));
+	k.num_tiles = k.tiles_x * block_rows;
 	// Residency cap.  The kernel is VALU-bound; at full occupancy it owns every wave slot of the chip for the whole launch
 	// and the executor's other streams (the previous frame's bloom / tonemap, the next frame's cluster build) cannot get
 	// a single wave in.  Padding the workgroup's LDS footprint so that only `max_wgs` workgroups fit per CU leaves the
@@ -815,28 +1076,73 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	// must be able to start beside resident lighting workgroups instead of waiting for one to retire.
 	const size_t per_wg = ((160u - 8u) * 1024u / unsigned(max_wgs)) & ~size_t(1023);
 	const size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
+	// Form of the launch: persistent waves dealing themselves tiles (one 8-XCD partition; GR_LIGHTING_STATIC=1 / =banded select the
+	// static grid in screen order / in XCD bands for the A/B), the static grid elsewhere.
+	static const int static_env = []() {
+		const char *env = gr_measurement_switch("GR_LIGHTING_STATIC");
+		return !env ? 0 : (strcmp(env, "banded") == 0 ? 2 : 1);
+	}();
+	const bool persistent = static_env == 0 && ctx->eight_xcd_partition && ctx->lighting_queues != nullptr;
+	k.banded = static_env == 2 ? 1 : 0;
+	dim3 grid(unsigned(k.blocks_per_xcd) * 8u);
+	if (persistent)
+	{
+		// Every workgroup of the grid is resident from the start: no more of them than the residency cap admits, and no more waves
+		// than there are tiles.
+		const unsigned resident = min(unsigned(ctx->compute_units) * unsigned(max_wgs), unsigned(LIGHT_MAX_QUEUES));
+		grid = dim3(min(resident, gr_div_up(unsigned(k.num_tiles), LIGHT_WAVES)));
+		k.tiles_per_queue = k.num_tiles / int(grid.x);
+		k.tiles_remainder = k.num_tiles % int(grid.x);
+		uint64_t launch = ctx->lighting_launches.fetch_add(1) + 1;
+		k.epoch = uint32_t(launch / gr_ctx::LIGHTING_QUEUE_SLOTS) + 1u; // grows per slot; 2^32 uses of one slot = 2.7e11 launches
+		k.queues = ctx->lighting_queues + (launch % gr_ctx::LIGHTING_QUEUE_SLOTS) * (gr_ctx::LIGHTING_QUEUE_SLOT_BYTES / sizeof(unsigned long long));
+	}
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "lighting"};
 	const bool ao = (args->flags & GR_LIGHTING_AMBIENT_OCCLUSION_BIT) != 0;
+	const dim3 block(64 * LIGHT_WAVES);
+	const hipStream_t s = gr_to_stream(stream);
+#define GR_LAUNCH_LIGHTING(PX_, AO_, B10_)                                                              \
+	do                                                                                                  \
+	{                                                                                                   \
+		if (persistent)                                                                                 \
+			hipLaunchKernelGGL((k_lighting_persistent<PX_, AO_, B10_>), grid, block, pad_lds, s, k);   \
+		else                                                                                            \
+			hipLaunchKernelGGL((k_lighting<PX_, AO_, B10_>), grid, block, pad_lds, s, k);              \
+	} while (0)
 	if (b10)
 	{
 		if (px == 2 && ao)
-			hipLaunchKernelGGL((k_lighting<2, true, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+			GR_LAUNCH_LIGHTING(2, true, true);
 		else if (px == 2)
-			hipLaunchKernelGGL((k_lighting<2, false, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+			GR_LAUNCH_LIGHTING(2, false, true);
 		else if (ao)
-			hipLaunchKernelGGL((k_lighting<1, true, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+			GR_LAUNCH_LIGHTING(1, true, true);
 		else
-			hipLaunchKernelGGL((k_lighting<1, false, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+			GR_LAUNCH_LIGHTING(1, false, true);
 	}
 	else if (px == 2 && ao)
-		hipLaunchKernelGGL((k_lighting<2, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+		GR_LAUNCH_LIGHTING(2, true, false);
 	else if (px == 2)
-		hipLaunchKernelGGL((k_lighting<2, false>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+		GR_LAUNCH_LIGHTING(2, false, false);
 	else if (ao)
-		hipLaunchKernelGGL((k_lighting<1, true>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+		GR_LAUNCH_LIGHTING(1, true, false);
 	else
-		hipLaunchKernelGGL((k_lighting<1, false>), grid, dim3(64 * LIGHT_WAVES), pad_lds, gr_to_stream(stream), k);
+		GR_LAUNCH_LIGHTING(1, false, false);
+#undef GR_LAUNCH_LIGHTING
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }
+
+#ifdef LV_STAMP
+// Measurement build only: where the next launches write their per-tile records (nullptr: nowhere).
+int gr_debug_lighting_stamps(gr_ctx *ctx, void *records, uint32_t count)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	uint4 *p = static_cast<uint4 *>(records);
+	GR_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_lighting_stamps), &p, sizeof(p)));
+	GR_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_lighting_stamp_records), &count, sizeof(count)));
+	return GR_OK;
+}
+#endif
 }

@@ -620,6 +620,82 @@ int gr_debug_mix(gr_ctx *ctx, gr_stream stream, void *out, size_t out_dwords, co
  * (application_headless.cpp:634-635): HIP device name and hipDriverGetVersion. */
 int gr_get_device_info(gr_ctx *ctx, char *name, size_t name_capacity, uint32_t *driver_version);
 
+/* ---- layout contracts, checked where the structs are declared: the push-constant blocks and the
+ * cluster UBO are byte-identical to what the reference's host code pushes and its shaders declare. ------------------------------------ */
+#include <stddef.h>
+#ifdef __cplusplus
+#define GR_STATIC_ASSERT(cond, what) static_assert(cond, what)
+#else
+#define GR_STATIC_ASSERT(cond, what) _Static_assert(cond, what)
+#endif
+#define GR_ASSERT_SIZE(type, bytes) GR_STATIC_ASSERT(sizeof(type) == (bytes), #type ": size differs from the reference's block")
+#define GR_ASSERT_OFFSET(type, member, bytes) GR_STATIC_ASSERT(offsetof(type, member) == (bytes), #type "." #member ": offset differs from the reference's block")
+GR_ASSERT_SIZE(gr_luminance_data, 12);        /* luminance.comp:4-9 */
+GR_ASSERT_SIZE(gr_push_luminance, 20);        /* hdr.cpp:85-96 */
+GR_ASSERT_OFFSET(gr_push_luminance, lerp, 8);
+GR_ASSERT_OFFSET(gr_push_luminance, min_loglum, 12);
+GR_ASSERT_OFFSET(gr_push_luminance, max_loglum, 16);
+GR_ASSERT_SIZE(gr_push_bloom_threshold, 16);  /* hdr.cpp:133-142 */
+GR_ASSERT_OFFSET(gr_push_bloom_threshold, inv_output_size, 8);
+GR_ASSERT_SIZE(gr_push_bloom_downsample, 28); /* hdr.cpp:169-185 */
+GR_ASSERT_OFFSET(gr_push_bloom_downsample, inv_output_size, 8);
+GR_ASSERT_OFFSET(gr_push_bloom_downsample, inv_input_size, 16);
+GR_ASSERT_OFFSET(gr_push_bloom_downsample, lerp, 24);
+GR_ASSERT_SIZE(gr_push_bloom_upsample, 24);   /* hdr.cpp:202-214 */
+GR_ASSERT_OFFSET(gr_push_bloom_upsample, inv_input_size, 16);
+GR_ASSERT_SIZE(gr_push_tonemap, 4);           /* hdr.cpp:297-302 */
+GR_ASSERT_SIZE(gr_push_fxaa, 8);              /* fxaa.cpp:45-47 */
+GR_ASSERT_SIZE(gr_push_smaa, 16);             /* smaa.cpp:129-133 */
+GR_ASSERT_SIZE(gr_push_taa, 80);              /* temporal.cpp:232-250 */
+GR_ASSERT_OFFSET(gr_push_taa, rt_metrics, 64);
+GR_ASSERT_SIZE(gr_push_clustering, 48);       /* renderer.cpp:1110-1121: 40 B used, 48 in C++ */
+GR_ASSERT_OFFSET(gr_push_clustering, camera_pos, 16);
+GR_ASSERT_OFFSET(gr_push_clustering, inv_resolution, 32);
+GR_ASSERT_SIZE(gr_push_directional, 96);      /* renderer.cpp:1073-1103: 88 B used */
+GR_ASSERT_OFFSET(gr_push_directional, color, 16);
+GR_ASSERT_OFFSET(gr_push_directional, environment_intensity, 28);
+GR_ASSERT_OFFSET(gr_push_directional, camera_pos, 32);
+GR_ASSERT_OFFSET(gr_push_directional, environment_mipscale, 44);
+GR_ASSERT_OFFSET(gr_push_directional, direction, 48);
+GR_ASSERT_OFFSET(gr_push_directional, cascade_log_bias, 60);
+GR_ASSERT_OFFSET(gr_push_directional, camera_front, 64);
+GR_ASSERT_OFFSET(gr_push_directional, inv_resolution, 80);
+GR_ASSERT_SIZE(gr_push_spot_transform, 100);  /* clusterer.cpp:1477-1493 */
+GR_ASSERT_OFFSET(gr_push_spot_transform, camera_pos, 64);
+GR_ASSERT_OFFSET(gr_push_spot_transform, num_lights, 76);
+GR_ASSERT_OFFSET(gr_push_spot_transform, camera_front, 80);
+GR_ASSERT_OFFSET(gr_push_spot_transform, z_near, 92);
+GR_ASSERT_OFFSET(gr_push_spot_transform, z_far, 96);
+GR_ASSERT_SIZE(gr_push_cluster_setup, 68);    /* clusterer.cpp:1502-1509 */
+GR_ASSERT_OFFSET(gr_push_cluster_setup, num_lights, 64);
+GR_ASSERT_SIZE(gr_push_z_range, 12);          /* clusterer.cpp:1291-1300 */
+GR_ASSERT_SIZE(gr_light_info, 48);            /* light_info.hpp:35-44 */
+GR_ASSERT_OFFSET(gr_light_info, spot_scale_bias, 12);
+GR_ASSERT_OFFSET(gr_light_info, position, 16);
+GR_ASSERT_OFFSET(gr_light_info, offset_radius, 28);
+GR_ASSERT_OFFSET(gr_light_info, direction, 32);
+GR_ASSERT_OFFSET(gr_light_info, inv_radius, 44);
+GR_ASSERT_SIZE(gr_mat_affine, 48);            /* muglm.hpp:899-958 */
+GR_ASSERT_SIZE(gr_cluster_params, 176);       /* clusterer_data.h:20-39, std140 */
+GR_ASSERT_OFFSET(gr_cluster_params, clip_scale, 64);
+GR_ASSERT_OFFSET(gr_cluster_params, camera_base, 80);
+GR_ASSERT_OFFSET(gr_cluster_params, camera_front, 96);
+GR_ASSERT_OFFSET(gr_cluster_params, xy_scale, 112);
+GR_ASSERT_OFFSET(gr_cluster_params, resolution_xy, 120);
+GR_ASSERT_OFFSET(gr_cluster_params, inv_resolution_xy, 128);
+GR_ASSERT_OFFSET(gr_cluster_params, num_lights, 136);
+GR_ASSERT_OFFSET(gr_cluster_params, num_lights_32, 140);
+GR_ASSERT_OFFSET(gr_cluster_params, num_decals, 144);
+GR_ASSERT_OFFSET(gr_cluster_params, decals_texture_offset, 152);
+GR_ASSERT_OFFSET(gr_cluster_params, z_max_index, 156);
+GR_ASSERT_OFFSET(gr_cluster_params, z_scale, 160);
+GR_ASSERT_SIZE(gr_push_pq10, 80);             /* hdr.cpp:626-633 */
+GR_STATIC_ASSERT(GR_TRANSFORMS_OFFSET_SHADOW == GR_MAX_LIGHTS_BINDLESS * 48u, "ClustererBindlessTransforms: lights[4096] of 48 B");
+GR_STATIC_ASSERT(GR_TRANSFORMS_OFFSET_MODEL + GR_MAX_LIGHTS_BINDLESS * 48u == GR_TRANSFORMS_OFFSET_TYPE_MASK, "ClustererBindlessTransforms: model[4096] of 48 B");
+GR_STATIC_ASSERT(GR_TRANSFORMS_OFFSET_TYPE_MASK + GR_MAX_LIGHTS_BINDLESS / 8u == GR_TRANSFORMS_OFFSET_DECALS, "ClustererBindlessTransforms: type_mask[128]");
+#undef GR_ASSERT_SIZE
+#undef GR_ASSERT_OFFSET
+
 #ifdef __cplusplus
 }
 #endif

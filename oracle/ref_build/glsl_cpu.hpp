@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 #include "../oracle_common.h"
 
 namespace glsl
@@ -143,6 +144,8 @@ struct tvec4
 	tvec4(T x_, const tvec2<T> &v, T w_) : x(x_), y(v.x), z(v.y), w(w_) {}
 	tvec4(T x_, T y_, const tvec2<T> &v) : x(x_), y(y_), z(v.x), w(v.y) {}
 	template <typename U> explicit tvec4(const tvec4<U> &o) : x(T(o.x)), y(T(o.y)), z(T(o.z)), w(T(o.w)) {}
+	// GLSL's implicit conversion int -> uint, component-wise (an ivec4 passed where a uvec4 parameter is declared)
+	operator tvec4<uint32_t>() const requires std::is_same_v<T, int> { return tvec4<uint32_t>(uint32_t(x), uint32_t(y), uint32_t(z), uint32_t(w)); }
 	tvec4(const tvec4 &o) : x(o.x), y(o.y), z(o.z), w(o.w) {}
 	tvec4 &operator=(const tvec4 &o) { x = o.x; y = o.y; z = o.z; w = o.w; return *this; }
 	T &operator[](int i) { return d[i]; }
@@ -354,6 +357,8 @@ inline f16vec4 uint16BitsToHalf(const u16vec4 &a) { return f16vec4(uint16BitsToH
 	inline V operator<<(const V &a, int s) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] << s; return r; }                   \
 	inline V operator&(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] & b.d[i]; return r; }          \
 	inline V operator|(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] | b.d[i]; return r; }          \
+	inline V operator&(const V &a, V::scalar s) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] & s; return r; }               \
+	inline V operator|(const V &a, V::scalar s) { V r; for (int i = 0; i < N; i++) r.d[i] = a.d[i] | s; return r; }               \
 	inline V min(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = min(a.d[i], b.d[i]); return r; }             \
 	inline V max(const V &a, const V &b) { V r; for (int i = 0; i < N; i++) r.d[i] = max(a.d[i], b.d[i]); return r; }             \
 	inline V clamp(const V &v, const V &lo, const V &hi) { return min(max(v, lo), hi); }
@@ -451,6 +456,14 @@ GLSL_COMPARE(ivec2, bvec2, 2)
 GLSL_COMPARE(ivec3, bvec3, 3)
 GLSL_COMPARE(uvec2, bvec2, 2)
 GLSL_COMPARE(uvec3, bvec3, 3)
+GLSL_COMPARE(ivec4, bvec4, 4)
+GLSL_COMPARE(uvec4, bvec4, 4)
+inline ivec4 mix(const ivec4 &a, const ivec4 &b, const bvec4 &t) { return ivec4(t.x ? b.x : a.x, t.y ? b.y : a.y, t.z ? b.z : a.z, t.w ? b.w : a.w); }
+inline uvec4 mix(const uvec4 &a, const uvec4 &b, const bvec4 &t) { return uvec4(t.x ? b.x : a.x, t.y ? b.y : a.y, t.z ? b.z : a.z, t.w ? b.w : a.w); }
+// Shift of an unsigned vector by a signed per-component count.  GLSL leaves counts >= 32 undefined; the hardware the reference
+// runs on uses the low five bits, and so does this (clusterer_bindless_z_range_opt.comp replaces those lanes itself).
+inline uvec4 operator<<(const uvec4 &a, const ivec4 &s) { return uvec4(a.x << (s.x & 31), a.y << (s.y & 31), a.z << (s.z & 31), a.w << (s.w & 31)); }
+inline uvec4 operator>>(const uvec4 &a, const ivec4 &s) { return uvec4(a.x >> (s.x & 31), a.y >> (s.y & 31), a.z >> (s.z & 31), a.w >> (s.w & 31)); }
 inline bool any(const bvec2 &v) { return v.x || v.y; }
 inline bool any(const bvec3 &v) { return v.x || v.y || v.z; }
 inline bool any(const bvec4 &v) { return v.x || v.y || v.z || v.w; }
@@ -518,6 +531,8 @@ inline vec3 operator*(const vec3 &v, const mat3 &m) { return vec3(dot(v, m.c[0])
 inline int findLSB(uint v) { return v ? __builtin_ctz(v) : -1; }
 inline int findLSB(int v) { return findLSB(uint(v)); }
 inline int findMSB(uint v) { return v ? 31 - __builtin_clz(v) : -1; }
+inline ivec4 findLSB(const uvec4 &v) { return ivec4(findLSB(v.x), findLSB(v.y), findLSB(v.z), findLSB(v.w)); }
+inline ivec4 findMSB(const uvec4 &v) { return ivec4(findMSB(v.x), findMSB(v.y), findMSB(v.z), findMSB(v.w)); }
 inline int bitCount(uint v) { return __builtin_popcount(v); }
 inline vec2 unpackHalf2x16(uint v) { return vec2(orc::half_to_float(uint16_t(v & 0xffffu)), orc::half_to_float(uint16_t(v >> 16))); }
 inline uvec2 floatBitsToUint(const vec2 &v) { return uvec2(floatBitsToUint(v.x), floatBitsToUint(v.y)); }

@@ -1,7 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.
 //
 // Runs the REFERENCE's own cluster-build compute shaders on the CPU (lights/clusterer_bindless_{spot_transform,setup,binning,
-// z_range}.comp, re-spelled into gen/ at build time): push constants and buffers as LightClusterer's
+// z_range,z_range_opt}.comp, re-spelled into gen/ at build time): push constants and buffers as LightClusterer's
 // update_bindless_mask_buffer_gpu / update_bindless_range_buffer_gpu set them (renderer/lights/clusterer.cpp:1277-1346,
 // 1463-1562).  Workgroups that communicate (binning: shared memory + barrier in the plain form, subgroupBallot in the
 // SUBGROUPS form) run as teams of real threads, one per invocation; a subgroup is one team.
@@ -17,6 +17,7 @@ namespace
 {
 std::barrier<> *team_barrier = nullptr;
 uint team_ballot_bits[4];
+uvec4 team_exchange[128]; // one slot per invocation of the workgroup (subgroupShuffleXor)
 }
 static inline void barrier()
 {
@@ -36,6 +37,18 @@ static inline uvec4 subgroupBallot(bool value)
 		__atomic_fetch_or(&team_ballot_bits[lane >> 5], 1u << (lane & 31u), __ATOMIC_SEQ_CST);
 	barrier();
 	const uvec4 result(team_ballot_bits[0], team_ballot_bits[1], team_ballot_bits[2], team_ballot_bits[3]);
+	barrier();
+	return result;
+}
+
+// subgroupShuffleXor: every invocation of the workgroup publishes its value, then reads its partner's -- the lane of ITS OWN
+// subgroup whose index differs by `mask` (GL_KHR_shader_subgroup_shuffle).  Called in uniform control flow by the shader.
+static inline uvec4 subgroupShuffleXor(const uvec4 &value, uint mask)
+{
+	const uint self = gl_LocalInvocationIndex;
+	team_exchange[self] = value;
+	barrier();
+	const uvec4 result = team_exchange[gl_SubgroupID * gl_SubgroupSize + ((gl_SubgroupInvocationID ^ mask) % gl_SubgroupSize)];
 	barrier();
 	return result;
 }
@@ -63,6 +76,17 @@ namespace binning_subgroups
 namespace z_range
 {
 #include "gen/clusterer_bindless_z_range.inc"
+}
+
+// The shader the reference actually dispatches on subgroup-capable devices (clusterer.cpp:1305-1314): 128-thread workgroups,
+// 128 x 128 bit-matrix transpose through shared memory and subgroupShuffleXor.
+namespace z_range_opt
+{
+static constexpr struct
+{
+	unsigned x = 128, y = 1, z = 1;
+} gl_WorkGroupSize; // layout(local_size_x = 128) in;
+#include "gen/clusterer_bindless_z_range_opt.inc"
 }
 
 namespace
@@ -257,6 +281,21 @@ void ref_cluster_z_range(const uint32_t *light_ranges, int num_lights, int num_r
 		gl_GlobalInvocationID = uvec3(uint(z), 0u, 0u);
 		s::main();
 	}
+}
+
+// clusterer_bindless_z_range_opt.comp as update_bindless_range_buffer_gpu dispatches it (clusterer.cpp:1277-1346): push constants
+// {num_lights, num_lights_128 = ceil(num_lights / 128), num_ranges}, (num_ranges + 127) / 128 workgroups of 128 invocations, run as
+// teams of real threads in subgroups of `subgroup_size` lanes (32, 64 or 128: the sizes the shader's shuffle network is valid for).
+void ref_cluster_z_range_opt(const uint32_t *light_ranges, int num_lights, int num_ranges, uint32_t *out, int subgroup_size)
+{
+	namespace s = z_range_opt;
+	s::num_lights = num_lights;
+	s::num_lights_128 = (num_lights + 127) / 128;
+	s::num_ranges = uint(num_ranges);
+	s::z_ranges = reinterpret_cast<uvec2 *>(const_cast<uint32_t *>(light_ranges));
+	s::light_ranges = reinterpret_cast<uvec2 *>(out);
+	for (int group = 0; group < (num_ranges + 127) / 128; group++)
+		run_team(128, uvec3(uint(group), 0u, 0u), unsigned(subgroup_size), s::main);
 }
 
 } // extern "C"

@@ -69,3 +69,17 @@ def test_struct_layouts_match_reference_contracts():
     assert capi.TRANSFORMS_OFFSET_MODEL == 4096 * 48 + 4096 * 64
     assert capi.TRANSFORMS_OFFSET_TYPE_MASK == capi.TRANSFORMS_OFFSET_MODEL + 4096 * 48
     assert capi.TRANSFORMS_SIZE == capi.TRANSFORMS_OFFSET_DECALS + 4096 * 48
+
+
+def test_headers_assert_their_own_layouts_in_c_and_cxx(tmp_path):
+    """include/granite_hip.h carries static assertions on the size and member offsets of every push-constant block and of the cluster
+    UBO: a C11 and a C++17 translation unit that only includes the headers must compile."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "granite_hip.h"\n#include "granite_app.h"\nint main(void) { return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "abi_c.o")])
+    subprocess.check_call(["g++", "-std=c++17", "-x", "c++", "-Wall", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "abi_cxx.o")])
+    text = open(os.path.join(inc, "granite_hip.h")).read()
+    for struct in re.findall(r"typedef struct (gr_push_\w+|gr_cluster_params|gr_light_info|gr_luminance_data)", text):
+        assert f"GR_ASSERT_SIZE({struct}," in text, f"{struct} has no size assertion in the header"

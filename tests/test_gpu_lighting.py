@@ -31,6 +31,34 @@ def test_cluster_build_bit_exact(gr, num_lights):
     np.testing.assert_array_equal(got_mask, ref["bitmask"])
 
 
+@pytest.mark.parametrize("num_lights,num_ranges,case", [(4096, 4096, "all_empty"), (1, 64, "sorted"), (127, 128, "mixed"), (128, 128, "wide"), (129, 320, "sorted"),
+                                                        (1000, 1024, "mixed"), (4096, 4096, "sorted"), (4096, 1024, "wide"), (4096, 4096, "mixed")])
+def test_z_range_equals_the_executed_opt_shader(gr, num_lights, num_ranges, case):
+    """gr_cluster_z_range over arbitrary slice intervals -- from one light to the 4096-light maximum, unsorted and empty intervals, and
+    the all-empty input of the reference's tests/z_binning_test.cpp:56-96 -- bit for bit against the oracle and, where the library
+    of executed reference shaders travelled to this box (oracle/_ref), against clusterer_bindless_z_range_opt.comp itself run at
+    subgroup size 64 (the shader a subgroup-capable device dispatches, clusterer.cpp:1305-1314)."""
+    import ctypes as C
+    import os
+    from test_reference_shaders_cpu import REF_LIB, z_range_inputs
+    zr = z_range_inputs(case, num_lights, num_ranges, seed=num_lights * 7 + num_ranges)
+    want = np.zeros((num_ranges, 2), np.uint32)
+    orc.lib().orc_cluster_z_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    orc.lib().orc_cluster_z_range(zr.ctypes.data, num_lights, num_ranges, want.ctypes.data)
+    zr_buf = capi.DeviceBuffer(gr, zr.nbytes).upload(zr)
+    out = capi.DeviceBuffer(gr, num_ranges * 8).upload(np.full(num_ranges * 2, 0xdeadbeef, np.uint32))
+    gr.check(gr.lib.gr_cluster_z_range(gr.handle, None, zr_buf.ptr, out.ptr, capi.PushZRange(num_lights, (num_lights + 127) // 128, num_ranges)))
+    gr.sync()
+    got = out.download(np.uint32).reshape(-1, 2)
+    np.testing.assert_array_equal(got, want, err_msg="kernel vs oracle")
+    if os.path.exists(REF_LIB):
+        ref = C.CDLL(REF_LIB)
+        ref.ref_cluster_z_range_opt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        shader = np.zeros((num_ranges, 2), np.uint32)
+        ref.ref_cluster_z_range_opt(zr.ctypes.data, num_lights, num_ranges, shader.ctypes.data, 64)
+        np.testing.assert_array_equal(got, shader, err_msg="kernel vs clusterer_bindless_z_range_opt.comp, executed")
+
+
 @pytest.mark.parametrize("pinned", [False, True])
 @pytest.mark.parametrize("num_lights", [1, 300, 4096])
 def test_cluster_front_as_one_launch_equals_the_separate_launches(gr, num_lights, pinned):

@@ -21,7 +21,11 @@ SHIM = os.path.join(ROOT, "tests", "rccl_shim", "libgranite_rccl_shim.so")
 def launch(world, script_args, port, extra_env=None, timeout=420):
     if not os.path.exists(SHIM):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(SHIM)])
-    env = dict(os.environ, GRANITE_RCCL_LIBRARY=SHIM, GRANITE_RCCL_LIBRARY_IS_A_TEST_STAND_IN="1", GRANITE_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    hooks_lib = os.path.join(ROOT, "granite_amd", "lib_testhooks", "libgranite_host.so")
+    if not os.path.exists(hooks_lib):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "granite_amd", "csrc"), "testhooks"])
+    # the stand-in loader only exists in the -DGRANITE_TEST_HOOKS build of the host layer (granite_amd/lib_testhooks)
+    env = dict(os.environ, GRANITE_LIB_DIR="lib_testhooks", GRANITE_RCCL_LIBRARY=SHIM, GRANITE_RCCL_LIBRARY_IS_A_TEST_STAND_IN="1", GRANITE_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
     env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), *script_args]

@@ -171,6 +171,62 @@ def test_cluster_build_shaders_bit_for_bit(ref, num_lights, res, forms):
         np.testing.assert_array_equal(bitmask, cb["bitmask"], err_msg=f"cell bitmask, subgroup size {subgroup}")
         np.testing.assert_array_equal(ranges, cb["range"], err_msg="slice ranges")
         assert bitmask.any()
+    # ... and the shader a subgroup-capable device really dispatches for the ranges (clusterer.cpp:1305-1314): the 128-thread
+    # bit-matrix transpose, at every subgroup size the reference allows (set_subgroup_size_log2(true, 5, 7)).
+    ref.ref_cluster_z_range_opt.argtypes = [P, C.c_int, C.c_int, P, C.c_int]
+    for subgroup in (32, 64, 128):
+        ranges = np.full_like(cb["range"], 0xdeadbeef)
+        ref.ref_cluster_z_range_opt(ptr(cb["light_ranges"]), n, res[2], ptr(ranges), subgroup)
+        np.testing.assert_array_equal(ranges, cb["range"], err_msg=f"slice ranges, z_range_opt at subgroup size {subgroup}")
+
+
+def z_range_inputs(case, num_lights, num_ranges, seed):
+    """Slice intervals per light as compute_uint_range produces them (clusterer.cpp:1265-1275), plus the degenerate inputs."""
+    r = np.random.default_rng(seed)
+    if case == "all_empty":  # tests/z_binning_test.cpp:56-96: 4096 inputs of (1000000000, 0) over 4096 ranges
+        return np.tile(np.array([[1000000000, 0]], np.uint32), (num_lights, 1))
+    lo = r.integers(0, num_ranges, num_lights)
+    if case == "sorted":  # the clusterer sorts lights front to back: increasing first slice, short intervals
+        lo = np.sort(lo)
+        hi = np.minimum(lo + r.integers(0, max(num_ranges // 16, 2), num_lights), num_ranges - 1)
+    elif case == "wide":  # long, overlapping intervals incl. whole-range and single-slice ones; the last slice is resolution_z - 1 at most
+        # (compute_uint_range clamps it, clusterer.cpp:1273), the first may lie beyond it (a light behind the far plane: empty)
+        hi = np.minimum(lo + r.integers(0, 2 * num_ranges, num_lights), num_ranges - 1)
+        lo = np.where(r.random(num_lights) < 0.1, lo + num_ranges, lo)
+        whole = r.random(num_lights) < 0.05
+        lo, hi = np.where(whole, 0, lo), np.where(whole, num_ranges - 1, hi)
+    else:  # "mixed": random order, one light in eight empty (x > y)
+        hi = np.minimum(lo + r.integers(0, max(num_ranges // 4, 2), num_lights), num_ranges - 1)
+        empty = r.random(num_lights) < 0.125
+        hi = np.where(empty, 0, hi)
+        lo = np.where(empty, 1000000000, lo)
+    return np.stack([lo, hi], axis=1).astype(np.uint32)
+
+
+@pytest.mark.parametrize("num_lights,num_ranges,case", [(4096, 4096, "all_empty"), (0, 256, "mixed"), (1, 64, "sorted"), (127, 128, "mixed"), (128, 128, "wide"),
+                                                        (129, 300, "sorted"), (1000, 1000, "mixed"), (4096, 4096, "sorted"), (4096, 1024, "wide")])
+def test_z_range_opt_shader_bit_for_bit(ref, num_lights, num_ranges, case):
+    """clusterer_bindless_z_range_opt.comp (the shader the reference dispatches when subgroup shuffles exist, clusterer.cpp:1305-1314;
+    assets/shaders/lights/clusterer_bindless_z_range_opt.comp:16-179) executed as 128-thread teams with subgroups of 32, 64 and 128
+    lanes, against the oracle's range buffer and against the naive shader, bit for bit -- from no lights to the 4096-light maximum,
+    including the all-empty input of the reference's own tests/z_binning_test.cpp."""
+    ref.ref_cluster_z_range.argtypes = [P, C.c_int, C.c_int, P]
+    ref.ref_cluster_z_range_opt.argtypes = [P, C.c_int, C.c_int, P, C.c_int]
+    zr = z_range_inputs(case, num_lights, num_ranges, seed=num_lights * 7 + num_ranges)
+    if num_lights == 0:
+        zr = np.zeros((1, 2), np.uint32)  # a binding needs an address; never read
+    want = np.zeros((num_ranges, 2), np.uint32)
+    orc.lib().orc_cluster_z_range.argtypes = [P, C.c_int, C.c_int, P]
+    orc.lib().orc_cluster_z_range(ptr(zr), num_lights, num_ranges, ptr(want))
+    naive = np.zeros((num_ranges, 2), np.uint32)
+    ref.ref_cluster_z_range(ptr(zr), num_lights, num_ranges, ptr(naive))
+    np.testing.assert_array_equal(naive, want, err_msg="naive shader vs oracle")
+    for subgroup in (32, 64, 128):
+        got = np.full((num_ranges, 2), 0xdeadbeef, np.uint32)
+        ref.ref_cluster_z_range_opt(ptr(zr), num_lights, num_ranges, ptr(got), subgroup)
+        np.testing.assert_array_equal(got, want, err_msg=f"z_range_opt at subgroup size {subgroup}")
+    if case == "all_empty":
+        assert (want[:, 0] == 0xffffffff).all() and (want[:, 1] == 0).all()
 
 
 # ---- anti-aliasing: post/fxaa.frag, post/taa_resolve.frag (+ reprojection.h, reprojection_color_space.h) -----------------------
