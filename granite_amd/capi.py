@@ -149,7 +149,9 @@ class LightingArgs(C.Structure):
 
 
 class Rows(C.Structure):
-    """gr_rows: render area of one launch, output rows [first, first + count); count == 0 = whole image."""
+    """gr_rows: render area of one launch, output rows [first, first + count).  Passed by pointer: None (NULL) = the whole image,
+    count == 0 = NO rows (the launcher returns GR_OK without launching: an empty band must not touch the image).  The one embedded
+    use, LightingArgs.rows, keeps {0, 0} = whole target, as a zero-initialised argument struct has it (include/granite_hip.h)."""
     _fields_ = [("first", C.c_uint32), ("count", C.c_uint32)]
 
 

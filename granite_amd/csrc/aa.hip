@@ -466,9 +466,14 @@ __global__ __launch_bounds__(AA_BLOCK_X *AA_BLOCK_Y) void k_blit(BlitArgs a)
 		aa::linear_axis(uv.x * float(a.in.w) - 0.5f, x0, wa);
 		aa::linear_axis(uv.y * float(a.in.h) - 0.5f, y0, wb);
 		const v4 t00 = blit_texel(a, x0, y0), t10 = blit_texel(a, x0 + 1, y0), t01 = blit_texel(a, x0, y0 + 1), t11 = blit_texel(a, x0 + 1, y0 + 1);
-		const v4 top = t00 * (1.0f - wa) + t10 * wa;
-		const v4 bot = t01 * (1.0f - wa) + t11 * wa;
-		c = top * (1.0f - wb) + bot * wb;
+		// a weight that is exactly 0 (a tap on a texel centre) does not read its texel: no 0 * inf (oracle_common.h: linear_combine)
+		const v4 top = wa == 0.0f ? t00 : t00 * (1.0f - wa) + t10 * wa;
+		c = top;
+		if (wb != 0.0f)
+		{
+			const v4 bot = wa == 0.0f ? t01 : t01 * (1.0f - wa) + t11 * wa;
+			c = top * (1.0f - wb) + bot * wb;
+		}
 	}
 	else
 		c = blit_texel(a, int(floorf(uv.x * float(a.in.w))), int(floorf(uv.y * float(a.in.h))));

@@ -150,6 +150,17 @@ __device__ __forceinline__ float4 sample_linear_with(Fetch fetch, int w, int h, 
 	const float4 t01 = fetch(x0, y1), t11 = fetch(x1, y1);
 	const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
 	float4 r = t00 * w00;
+	// A tap on a texel centre (weight exactly 0 after the snap) does not read its neighbour: 0 * inf would turn an overflowed fp16
+	// texel next to the tap into NaN, where the oracle's linear_combine (oracle_common.h) and a hardware sampler return the texel.
+	// For finite texels the sums below are bit-identical with or without the skipped terms (fma(t, 0, r) == r).
+	if (a == 0.0f || b == 0.0f)
+	{
+		if (a != 0.0f)
+			r = fma4(t10, w10, r);
+		if (b != 0.0f)
+			r = fma4(t01, w01, r);
+		return r;
+	}
 	r = fma4(t10, w10, r);
 	r = fma4(t01, w01, r);
 	r = fma4(t11, w11, r);

@@ -906,6 +906,11 @@ void ImageSpaceApplication::set_frame_state(const gra_frame_state &state)
 		bake_render_graph();
 	elapsed = state.elapsed;
 	swapchain_index = state.swapchain_index;
+	// state.frames is informational (host_frames counts what THIS instance rendered; prepare_resources_for_write keys on it).  A
+	// restore is all or nothing: prepare_resources_for_write allocates and rotates EVERY attachment with a history, so the first frame
+	// after it takes the history paths (TAA resolve, bloom feedback, exposure) -- the caller writes back every inherited resource of
+	// the saved frame (gra_write_resource: HDR-resolved-history, downsample-3, average-luminance ...), not a subset; what is left
+	// unwritten is a zero history, which is neither frame 1 nor frame N + 1 of the original run.
 	memcpy(base_view.data(), state.base_view, sizeof(state.base_view));
 	TemporalJitter::State j = jitter.get_state();
 	j.phase = state.jitter_phase;

@@ -108,6 +108,11 @@ void LightClusterer::sort_and_pack(const RenderParameters &rp, SortState &sort, 
 
 void LightClusterer::prefetch(const RenderParameters &next_parameters)
 {
+	// Waking three helper threads and collecting their result costs the submitting thread 12-15 us per frame (futex round trips;
+	// measured on the device-less frame loop, tests/test_host_frame_loop_cpu.py); sorting and packing costs ~22 ns per light.  Below
+	// about a thousand lights the hand-over is the larger part: refresh() packs in place then.
+	if (!scene_lights || scene_lights->size() < PrefetchMinLights)
+		return;
 	std::unique_lock<std::mutex> holder{ahead.lock};
 	if (ahead.threads.empty())
 	{

@@ -132,6 +132,7 @@ private:
 
 	// One-frame-ahead refresh on helper threads: thread 0 sorts, then all of them pack chunks of PackChunk lights.
 	enum { PackChunk = 256 }; // a multiple of 32: a chunk owns whole words of the type mask
+	enum { PrefetchMinLights = 1024 }; // below this the hand-over to the helper threads costs more than the packing (prefetch())
 	struct
 	{
 		std::vector<std::thread> threads;

@@ -57,8 +57,11 @@ public:
 	State get_state() const { return {phase, saved_jittered_view_proj, saved_view_proj, saved_inv_view_proj, saved_jittered_projection}; }
 	void set_state(const State &s)
 	{
-		if (s.view_proj.size() != saved_view_proj.size())
+		if (s.view_proj.size() != saved_view_proj.size() || s.inv_view_proj.size() != saved_inv_view_proj.size() ||
+		    s.jittered_view_proj.size() != saved_jittered_view_proj.size())
 			throw std::logic_error("TemporalJitter::set_state: jitter sequence length differs");
+		if (jitter_count != 0 && s.phase >= jitter_count)
+			throw std::logic_error("TemporalJitter::set_state: phase outside the jitter sequence");
 		phase = s.phase;
 		saved_jittered_view_proj = s.jittered_view_proj;
 		saved_view_proj = s.view_proj;

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -70,11 +71,31 @@ public:
 				std::lock_guard<std::mutex> inner{buffer->lock};
 				events.swap(buffer->events);
 			}
+			// A scope is recorded when it EXITS, i.e. children before their parents.  The file carries "B" / "E" pairs in time order
+			// per thread, properly nested, as the reference's writer emits them while the scopes run (util/timeline_trace_file.cpp):
+			// scopes sorted by begin (the longer one first on a tie = the parent), ends emitted as soon as the next begin lies past them.
+			std::stable_sort(events.begin(), events.end(), [](const Event &a, const Event &b) {
+				return a.begin_ns != b.begin_ns ? a.begin_ns < b.begin_ns : a.end_ns > b.end_ns;
+			});
+			auto emit = [&](const Event &e, char phase, uint64_t ns) {
+				fprintf(file, "{ \"name\": \"%s\", \"ph\": \"%c\", \"tid\": \"%s\", \"pid\": \"0\", \"ts\": %f },\n", e.name, phase, buffer->tid.c_str(),
+				        double(int64_t(ns - base_ns)) * 1e-3);
+			};
+			std::vector<const Event *> open;
 			for (auto &e : events)
 			{
-				const double b = double(int64_t(e.begin_ns - base_ns)) * 1e-3, t = double(int64_t(e.end_ns - base_ns)) * 1e-3;
-				fprintf(file, "{ \"name\": \"%s\", \"ph\": \"B\", \"tid\": \"%s\", \"pid\": \"0\", \"ts\": %f },\n", e.name, buffer->tid.c_str(), b);
-				fprintf(file, "{ \"name\": \"%s\", \"ph\": \"E\", \"tid\": \"%s\", \"pid\": \"0\", \"ts\": %f },\n", e.name, buffer->tid.c_str(), t);
+				while (!open.empty() && open.back()->end_ns <= e.begin_ns && !(open.back()->end_ns == e.begin_ns && open.back()->begin_ns == e.begin_ns))
+				{
+					emit(*open.back(), 'E', open.back()->end_ns);
+					open.pop_back();
+				}
+				emit(e, 'B', e.begin_ns);
+				open.push_back(&e);
+			}
+			while (!open.empty())
+			{
+				emit(*open.back(), 'E', open.back()->end_ns);
+				open.pop_back();
 			}
 		}
 		fflush(file);

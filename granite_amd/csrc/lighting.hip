@@ -37,7 +37,10 @@
 namespace
 {
 constexpr int LIGHT_TILE = 8;  // wave tile edge
-constexpr int LIGHT_WAVES = 4; // waves per workgroup, side by side -> 32x8 block
+#ifndef LV_WAVES
+#define LV_WAVES 4
+#endif
+constexpr int LIGHT_WAVES = LV_WAVES; // waves per workgroup, side by side -> 32x8 block (A/B: 1, 2)
 constexpr int LIGHT_SLOT_BYTES = 64;
 
 constexpr float PI_SIC = 3.1415628f; // assets/shaders/lights/pbr.h:4-6 (sic)
@@ -60,6 +63,9 @@ constexpr float CULL_SLACK = 1e-3f;
 #endif
 #ifndef LV_GFOLD
 #define LV_GFOLD 1 // c0 folded into the per-pixel G constants
+#endif
+#ifndef LV_A2_SAT
+#define LV_A2_SAT 0 // 1 / max(len, 0.1)^2 = 100 sat(inv_d2 / 100): a full-rate multiply with clamp instead of a half-rate min; the 100 goes into the staged colour
 #endif
 
 struct KernelArgs
@@ -246,7 +252,7 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 	for (int p = 0; p < PX; p++)
 	{
 		// colour = light colour * atten / light_dist^2, light_dist^2 = max(len, 0.1)^2
-		const float a2 = atten[p] * fminf(inv_d2[p], 1.0f / (0.1f * 0.1f));
+		const float a2 = LV_A2_SAT ? atten[p] * sat(inv_d2[p] * (0.1f * 0.1f)) : atten[p] * fminf(inv_d2[p], 1.0f / (0.1f * 0.1f));
 		const float NdL = dot(s[p].N, Lf[p]) * inv_d[p];
 		// |V + L|^2 with L = Lf / len: |len V + Lf|^2 / len^2.  The vector sum keeps the relative error of hh at
 		// fp32 level when L is nearly -V, where 2 + 2 dot(V, L) would cancel.
@@ -565,7 +571,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 							}
 						}
 						r0 = f32x4{pq.x, pq.y, pq.z, radius * radius};
-						r1q = f32x4{c.x, c.y, c.z, 10.0f * d.w};
+						r1q = LV_A2_SAT ? f32x4{c.x * 100.0f, c.y * 100.0f, c.z * 100.0f, 10.0f * d.w} : f32x4{c.x, c.y, c.z, 10.0f * d.w};
 						r2 = f32x4{d.x, d.y, d.z, 0.0f};
 						r3 = f32x4{spot_scale, spot_bias, 0.0f, 0.0f};
 					}
@@ -775,8 +781,10 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 		logical = int(blockIdx.x & 7u) * a.blocks_per_xcd + int(blockIdx.x >> 3);
 	if (logical >= a.num_blocks)
 		return;
-	// sRGB8 -> linear table into LDS: one entry per thread (64 * LIGHT_WAVES = 256), the only workgroup-wide step.
-	s_srgb[threadIdx.x] = a.srgb_lut[threadIdx.x];
+	// sRGB8 -> linear table into LDS (one entry per thread of the four-wave workgroup), the only workgroup-wide step.
+#pragma unroll
+	for (int i = 0; i < 256; i += 64 * LIGHT_WAVES)
+		s_srgb[i + threadIdx.x] = a.srgb_lut[i + threadIdx.x];
 	const int block_x = logical % a.blocks_x, block_y = a.block_row0 + logical / a.blocks_x;
 	const int wave = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
@@ -826,7 +834,9 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) __attribute__((amdgpu_waves_per_e
 	__shared__ __attribute__((aligned(16))) f32x4 s_lights[LIGHT_WAVES][64 * (LIGHT_SLOT_BYTES / 16)];
 	__shared__ float s_srgb[256];
 	constexpr int TILE_W = LIGHT_TILE * PX;
-	s_srgb[threadIdx.x] = a.srgb_lut[threadIdx.x];
+#pragma unroll
+	for (int i = 0; i < 256; i += 64 * LIGHT_WAVES)
+		s_srgb[i + threadIdx.x] = a.srgb_lut[i + threadIdx.x];
 	const int wave = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
 	f32x4 *const slots = s_lights[wave];
@@ -1074,22 +1084,24 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	const size_t static_lds = sizeof(f32x4) * LIGHT_WAVES * 64 * (LIGHT_SLOT_BYTES / 16) + 256 * sizeof(float);
 	// 8 KiB of the CU's 160 KiB stay free: back-of-frame kernels that use a little LDS (luminance, the fused pyramid tail)
 	// must be able to start beside resident lighting workgroups instead of waiting for one to retire.
-	const size_t per_wg = ((160u - 8u) * 1024u / unsigned(max_wgs)) & ~size_t(1023);
+	const size_t per_wg = ((160u - 8u) * 1024u / unsigned(max_wgs * 4 / LIGHT_WAVES)) & ~size_t(1023); // max_wgs counts four-wave workgroups
 	const size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
-	// Form of the launch: persistent waves dealing themselves tiles (one 8-XCD partition; GR_LIGHTING_STATIC=1 / =banded select the
-	// static grid in screen order / in XCD bands for the A/B), the static grid elsewhere.
-	static const int static_env = []() {
+	// Form of the launch.  The static grid in screen order is the product path.  GR_LIGHTING_STATIC=banded restores the XCD bands of
+	// rounds 1-3, GR_LIGHTING_PERSISTENT=1 selects the persistent-wave kernel (one 8-XCD partition only): both measured slower
+	// (profiles/r04_lighting_tiles_*.txt) and kept for the A/B.
+	static const bool banded_env = []() {
 		const char *env = gr_measurement_switch("GR_LIGHTING_STATIC");
-		return !env ? 0 : (strcmp(env, "banded") == 0 ? 2 : 1);
+		return env && strcmp(env, "banded") == 0;
 	}();
-	const bool persistent = static_env == 0 && ctx->eight_xcd_partition && ctx->lighting_queues != nullptr;
-	k.banded = static_env == 2 ? 1 : 0;
+	static const bool persistent_env = gr_measurement_switch("GR_LIGHTING_PERSISTENT") != nullptr;
+	const bool persistent = persistent_env && ctx->eight_xcd_partition && ctx->lighting_queues != nullptr && px == 2;
+	k.banded = banded_env ? 1 : 0;
 	dim3 grid(unsigned(k.blocks_per_xcd) * 8u);
 	if (persistent)
 	{
 		// Every workgroup of the grid is resident from the start: no more of them than the residency cap admits, and no more waves
 		// than there are tiles.
-		const unsigned resident = min(unsigned(ctx->compute_units) * unsigned(max_wgs), unsigned(LIGHT_MAX_QUEUES));
+		const unsigned resident = min(unsigned(ctx->compute_units) * unsigned(max_wgs * 4 / LIGHT_WAVES), unsigned(LIGHT_MAX_QUEUES));
 		grid = dim3(min(resident, gr_div_up(unsigned(k.num_tiles), LIGHT_WAVES)));
 		k.tiles_per_queue = k.num_tiles / int(grid.x);
 		k.tiles_remainder = k.num_tiles % int(grid.x);

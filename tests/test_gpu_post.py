@@ -241,3 +241,25 @@ def test_fused_pyramid_tail_declines_what_it_does_not_cover(gr):
     d3, hist = capi.DeviceImage(gr, 40, 20, F16), capi.DeviceImage(gr, 40, 20, F16)
     u1 = capi.DeviceImage(gr, 101, 57, F16)
     assert not gr.bloom_tail(d1, d2, d3, hist, u2, u1, 0.1)
+
+
+def test_a_centre_tap_does_not_read_its_overflowed_neighbour(gr):
+    """Under the sampler statement (a coordinate within 2^-8 of a texel centre reads that texel alone) a tap on a pixel centre has
+    weight exactly 0 for its neighbours.  An fp16 +inf texel (an overflowed HDR value) one texel further on must not reach the result as
+    0 * inf = NaN: the oracle's linear_combine skips it, a hardware sampler returns the texel.  Upsample between equal sizes puts all
+    nine taps on texel centres: the 3 x 3 neighbourhood of the inf texel becomes inf, the ring around it must stay finite and equal
+    to the oracle's."""
+    w = h = 32
+    src = synth.make_hdr(w, h)
+    src[16, 16, :3] = 0x7c00  # +inf
+    dev_in = capi.DeviceImage(gr, w, h, capi.FORMAT_R16G16B16A16_SFLOAT).upload(src)
+    dev_out = capi.DeviceImage(gr, w, h, capi.FORMAT_R16G16B16A16_SFLOAT)
+    gr.bloom_upsample(dev_in, dev_out)
+    gr.sync()
+    got = dev_out.download().view(np.float16).astype(np.float32)
+    want = orc.bloom_upsample(src, w, h).view(np.float16).astype(np.float32)
+    assert not np.isnan(want).any() and np.isinf(want[15:18, 15:18, :3]).all() and np.isfinite(want[13, 13:20]).all()
+    assert not np.isnan(got).any(), f"{int(np.isnan(got).any(axis=2).sum())} pixels are NaN beside the overflowed texel"
+    np.testing.assert_array_equal(np.isinf(got), np.isinf(want))
+    finite = np.isfinite(want)
+    np.testing.assert_allclose(got[finite], want[finite], rtol=2e-3, atol=1e-4)

@@ -1,0 +1,74 @@
+"""CPU: the executor's whole frame loop without a GPU.
+
+tests/hip_stub is a device-less stand-in for the HIP runtime entry points the host layer and the C ABI call (preloaded in front of
+libamdhip64.so; kernels do not run, "device memory" is host memory).  What a frame ASKS the runtime to do is then countable and the
+framework's own host time per frame measurable on any machine: launches, event records, cross-stream waits, and that no wait is ever
+issued on an event that has not been recorded.  On the MI355X every one of those calls costs 2-4 us of host time, which is what
+bounds the small frames (BASELINE configs 1 and 2); this test holds the counts."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = os.path.join(ROOT, "tests", "hip_stub", "libhip_stub.so")
+
+WORKER = r'''
+import ctypes as C, json, sys, time
+sys.path.insert(0, %(root)r)
+from granite_amd import app as gapp, synth
+w, h, lights, pending = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+stub = C.CDLL(%(stub)r); stub.hip_stub_count.restype = C.c_uint64; stub.hip_stub_count.argtypes = [C.c_char_p]
+cam = synth.Camera(w, h)
+if lights:
+    a = gapp.Application(w, h); a.set_render_parameters(cam.render_params()); a.set_lights(synth.make_lights(cam, lights)); a.upload_gbuffer(synth.make_gbuffer(cam))
+else:
+    a = gapp.Application(w, h, lighting=False); a.upload_hdr(synth.make_hdr(w, h))
+a.render_frames(20, sync=True)
+keys = ["launches", "event_records", "stream_waits", "event_queries", "memcpys", "memsets", "waits_before_record"]
+c0 = {k: stub.hip_stub_count(k.encode()) for k in keys}
+frames = 400
+t0 = time.perf_counter(); a.render_frames(frames, sync=True); t = time.perf_counter() - t0
+c1 = {k: stub.hip_stub_count(k.encode()) for k in keys}
+print(json.dumps({"us_per_frame": 1e6 * t / frames, **{k: (c1[k] - c0[k]) / frames for k in keys}}))
+a.close()
+'''
+
+
+def run(w, h, lights, pending=False):
+    if not os.path.exists(STUB) or os.path.getmtime(STUB) < os.path.getmtime(os.path.join(os.path.dirname(STUB), "hip_stub.cpp")):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(STUB)])
+    env = dict(os.environ, LD_PRELOAD=STUB)
+    if pending:
+        env["HIP_STUB_EVENTS_PENDING"] = "1"  # a recorded event never reads as complete: every cross-stream dependency takes the wait path
+    r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT, "stub": STUB}, str(w), str(h), str(lights), "1" if pending else "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_post_only_frame_asks_for_six_launches():
+    """BASELINE config 1 (256 x 256 bloom + tonemap): threshold, downsample 0+1, downsample 2+3, upsample 2+1 + luminance, upsample 0,
+    tonemap.  The framework's own share of the frame is microseconds."""
+    r = run(256, 256, 0)
+    assert r["launches"] == 6 and r["memcpys"] == 0 and r["memsets"] == 0, r
+    assert r["event_records"] <= 5 and r["stream_waits"] == 0 and r["waits_before_record"] == 0, r
+    assert r["us_per_frame"] < 25.0, r
+
+
+def test_1080p_frame_asks_for_ten_launches_and_packs_its_lights_in_place():
+    """BASELINE config 2 (1080p, 256 lights): upload, cluster front, binning, lighting + the six of the post chain.  256 lights are
+    sorted and packed on the submitting thread (LightClusterer::prefetch: the helper threads only pay above ~1000 lights)."""
+    r = run(1920, 1080, 256)
+    assert r["launches"] == 10 and r["memcpys"] == 0 and r["memsets"] == 0, r
+    assert r["event_records"] <= 6 and r["waits_before_record"] == 0, r
+    assert r["us_per_frame"] < 60.0, r
+
+
+def test_every_cross_stream_wait_follows_its_record():
+    """With events that never read as complete every dependency between the three streams is a hipStreamWaitEvent: frames ahead of the
+    device must wait on the hand-over ring (WAR), the back of the frame on the front (RAW) -- and never on an event before its record."""
+    r = run(960, 540, 300, pending=True)
+    assert r["stream_waits"] >= 3 and r["waits_before_record"] == 0, r

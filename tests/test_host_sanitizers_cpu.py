@@ -48,6 +48,8 @@ def check_timeline(path, frames, prefetch_hits):
         stack, last = [], -1.0
         for e in (e for e in events if e["tid"] == tid and e["ph"] in "BE"):
             assert isinstance(e["pid"], str) and isinstance(e["ts"], float)
+            assert e["ts"] >= last, (tid, e, last)  # time order per thread: a parent's "B" stands before its children's
+            last = e["ts"]
             if e["ph"] == "B":
                 stack.append(e)
             else:
