@@ -136,6 +136,61 @@ def cpu_baseline(cam, gbuf, descs, width, height, sample_rows):
     }
 
 
+def cpu_baseline_reference_shaders(cam, gbuf, descs, width, height, band_rows=270):
+    """The nearest attainable stand-in for the reference's own CPU path (application_headless.cpp:581-654 on a software Vulkan device, which
+    this image cannot run): the reference's GLSL itself -- directional.frag, clustering.frag, the bloom shaders, luminance.comp, tonemap.frag
+    -- executed on the host's cores by oracle/_ref/libref_shaders.so (oracle/ref_build: the shader text compiled as C++ against a small
+    GLSL environment, rows of invocations spread over the cores by the runner).  Timed on a centred band of the workload's frame (lighting
+    + post chain; the cluster build, whose shaders run as teams of real threads there, is taken from the port's timing) and on the whole of
+    BASELINE config 1 (256 x 256 bloom + tonemap).  None when the library was not built (it needs /root/reference at build time)."""
+    from oracle import oracle as orc
+    from granite_amd import synth
+    if orc.reference_shader_library() is None:
+        return None
+    import ctypes as C
+    ref = orc.reference_shader_library()
+    cores = os.cpu_count() or 1
+    rp = cam.render_params()
+    band_rows = min(band_rows, height)
+    y0 = (height - band_rows) // 2
+    depth = np.zeros_like(gbuf["depth"])
+    depth[y0:y0 + band_rows] = gbuf["depth"][y0:y0 + band_rows]
+    full = dict(gbuf, depth=depth)
+    n, lights, model, tmask, _ = orc.pack_lights(descs, rp[99:102])
+    prm = orc.cluster_params(rp, *synth.CLUSTER_RESOLUTION, n)
+    t0 = time.perf_counter()
+    cb = orc.cluster_build(rp, prm, lights, model, tmask, n, synth.CLUSTER_RESOLUTION[2])
+    t_cluster = time.perf_counter() - t0
+    t_light = t_post = 0.0
+    frames, state, started = 0, {}, time.perf_counter()
+    while frames < 8 and (frames < 1 or time.perf_counter() - started < 8.0):
+        t0 = time.perf_counter()
+        hdr = orc.lighting(full, rp, prm, lights, tmask, cb["bitmask"], cb["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION,
+                           entry=ref.ref_lighting)
+        t_light += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        orc.hdr_chain_reference_shaders(np.ascontiguousarray(hdr[y0:y0 + band_rows]), state)
+        t_post += time.perf_counter() - t0
+        frames += 1
+    t_light, t_post = t_light / frames, t_post / frames
+    frame_s = t_cluster + (t_light + t_post) * (height / band_rows)
+    # BASELINE config 1 as the reference's headless runner renders it: 256 x 256, bloom + tonemap, whole frame
+    small, small_state, small_frames, t_small = synth.make_hdr(256, 256), {}, 0, 0.0
+    while small_frames < 20 and (small_frames < 2 or t_small < 1.0):
+        t0 = time.perf_counter()
+        orc.hdr_chain_reference_shaders(small, small_state)
+        t_small += time.perf_counter() - t0
+        small_frames += 1
+    return {
+        "value": width * height / frame_s / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "reference-shaders",
+        "name": "the reference's GLSL (assets/shaders/{lights,post}) executed on the host by oracle/_ref/libref_shaders.so",
+        "sample": f"{frames} frame(s): lighting {t_light:.2f}s + bloom/tonemap {t_post:.2f}s on a {width}x{band_rows} band (all {n} lights), x {height}/{band_rows}, "
+                  f"+ cluster build {t_cluster:.2f}s (the port's; the reference's cluster shaders run as thread teams there) on {cores} OpenMP threads",
+        "config1_256x256_post_chain": {"value": 256 * 256 / (t_small / small_frames) / 1e6, "unit": "Mpixels/s", "ms_per_frame": 1e3 * t_small / small_frames,
+                                        "frames": small_frames},
+    }
+
+
 def parity_check(cam, gbuf, descs, device, reference):
     """Outside the timed region: a fresh executor renders the frames the oracle rendered in cpu_baseline() and is held to
     the tolerances the tests state (lit HDR target 2 ulp fp16 + 1e-4, backbuffer +-1 LSB).  Returns (ok, detail)."""
@@ -515,6 +570,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload not in SINGLE_GPU_WORKLOADS:
         rows = args.cpu_sample_rows or height  # whole frame: ~4 s on a 256-thread host, ~20 s on 8 cores
         reference, result["cpu_baseline"] = cpu_baseline(cam, gbuf, descs, width, height, rows)
+        # beside it, never instead of it: the reference's own shader text executed on the same cores
+        result["cpu_baseline_reference_shaders"] = cpu_baseline_reference_shaders(cam, gbuf, descs, width, height)
         # the frame the baseline just rendered is what the GPU frame is compared with (outside the timed region)
         if reference is not None:
             ok, detail = parity_check(cam, gbuf, descs, local_rank, reference)
@@ -525,6 +582,7 @@ def main():
             result["parity_detail"] = {"reason": "the CPU baseline rendered a band of the frame only (--cpu-sample-rows)"}
     else:
         result["cpu_baseline"] = None
+        result["cpu_baseline_reference_shaders"] = None
         result["parity_checked"] = False
         result["parity_detail"] = {"reason": "no CPU baseline in this run (multi-GPU rank, --no-cpu-baseline, or a workload whose oracle comparison "
                                              "lives in tests/test_gpu_fullsize.py: config 1 / config 4)"}

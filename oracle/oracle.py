@@ -187,6 +187,62 @@ def hdr_chain(hdr: np.ndarray, state: dict, frame_time: float = 0.01, dynamic_ex
             "tonemapped": out}
 
 
+# ---- the same chain through the REFERENCE's executed shaders (oracle/_ref/libref_shaders.so, built by oracle/ref_build) -----------
+_REF = None
+
+
+def reference_shader_library():
+    """oracle/_ref/libref_shaders.so (the reference's own GLSL, compiled for the CPU by oracle/ref_build) or None if it was not
+    built (it needs /root/reference at build time; the built library travels).  Test infrastructure, like everything under oracle/."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_shaders.so")
+        if not os.path.exists(path):
+            return None
+        ref = C.CDLL(path)
+        P = C.c_void_p
+        ref.ref_bloom_threshold.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int, P]
+        ref.ref_bloom_downsample.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int, P, C.c_float]
+        ref.ref_bloom_upsample.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int]
+        ref.ref_luminance.argtypes = [P, C.c_int, C.c_int, P, C.c_float, C.c_float, C.c_float]
+        ref.ref_tonemap.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int, P, C.c_float, P]
+        _REF = ref
+    return _REF
+
+
+def hdr_chain_reference_shaders(hdr: np.ndarray, state: dict, frame_time: float = 0.01, dynamic_exposure: float = 1.0):
+    """hdr_chain() with every pass executed from the reference's shader text (bloom_threshold / bloom_downsample / bloom_upsample /
+    luminance.comp, tonemap.frag) instead of the restatement: same order, same push constants, same state dictionary."""
+    ref = reference_shader_library()
+    w, h = _img16(hdr)
+    lum_lerp, fb_lerp = frame_lerps(frame_time)
+    lum = np.array(state.setdefault("lum", np.zeros(3, np.float32)), np.float32, copy=True)
+    sz = [level_size(w, h, s) for s in (0.5, 0.25, 0.125, 0.0625, 0.03125)]
+
+    def level(size):
+        return np.zeros((size[1], size[0], 4), np.uint16)
+
+    def ptr(a):
+        return None if a is None else a.ctypes.data
+
+    hdr = np.ascontiguousarray(hdr, np.uint16)
+    t, d0, d1, d2, d3 = (level(s) for s in sz)
+    ref.ref_bloom_threshold(ptr(hdr), w, h, ptr(t), *sz[0], ptr(lum))
+    for src, dst, s_src, s_dst in ((t, d0, sz[0], sz[1]), (d0, d1, sz[1], sz[2]), (d1, d2, sz[2], sz[3])):
+        ref.ref_bloom_downsample(ptr(src), *s_src, ptr(dst), *s_dst, None, 0.0)
+    ref.ref_bloom_downsample(ptr(d2), *sz[3], ptr(d3), *sz[4], ptr(state.get("d3_history")), fb_lerp)
+    ref.ref_luminance(ptr(d3), *sz[4], ptr(lum), lum_lerp, -3.0, 2.0)
+    state["lum"] = lum
+    u2, u1, u0 = level(sz[3]), level(sz[2]), level(sz[1])
+    ref.ref_bloom_upsample(ptr(d3), *sz[4], ptr(u2), *sz[3])
+    ref.ref_bloom_upsample(ptr(u2), *sz[3], ptr(u1), *sz[2])
+    ref.ref_bloom_upsample(ptr(u1), *sz[2], ptr(u0), *sz[1])
+    out = np.zeros((h, w, 4), np.uint8)
+    ref.ref_tonemap(ptr(hdr), w, h, ptr(u0), *sz[1], ptr(lum), dynamic_exposure, ptr(out))
+    state["d3_history"] = d3
+    return {"threshold": t, "d0": d0, "d1": d1, "d2": d2, "d3": d3, "u2": u2, "u1": u1, "u0": u0, "lum": lum.copy(), "tonemapped": out}
+
+
 # ---- lighting -------------------------------------------------------------------------------------------------------
 def pack_lights(descs: np.ndarray, camera_front):
     descs = np.ascontiguousarray(descs, LIGHT_DESC_DTYPE)

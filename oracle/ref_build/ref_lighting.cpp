@@ -178,6 +178,7 @@ void bind_gbuffer(const LightingArgs *a, Setup set)
 		s::registers.camera_pos = ld3(a->rp->camera_position);                                                      \
 		s::registers.camera_front = ld3(a->rp->camera_front);                                                       \
 		s::registers.inv_resolution = inv_resolution;                                                               \
+		_Pragma("omp parallel for schedule(dynamic, 4)")                                                            \
 		for (int y = 0; y < H; y++)                                                                                 \
 			for (int x = 0; x < W; x++)                                                                             \
 			{                                                                                                       \
@@ -252,6 +253,9 @@ extern "C" void ref_lighting(const LightingArgs *a)
 		s::registers.inverse_view_projection_col2 = inv_vp.c[2];
 		s::registers.camera_pos = ld3(a->rp->camera_position);
 		s::registers.inv_resolution = inv_resolution;
+		// rows of fragments on the host's cores: per-fragment state (gl_FragCoord, vClip, FragColor) is thread_local, the bound
+		// resources are only read, a fragment blends into its own texel
+#pragma omp parallel for schedule(dynamic, 4)
 		for (int y = 0; y < H; y++)
 			for (int x = 0; x < W; x++)
 			{
@@ -272,6 +276,7 @@ extern "C" void ref_lighting(const LightingArgs *a)
 		s::registers.camera_pos = ld3(a->rp->camera_position);
 		s::registers.color = ld3(a->fog_color);
 		s::registers.falloff = a->fog_falloff;
+#pragma omp parallel for schedule(dynamic, 4)
 		for (int y = 0; y < H; y++)
 			for (int x = 0; x < W; x++)
 			{

@@ -96,11 +96,14 @@ Image img16(uint16_t *data, int w, int h)
 	return i;
 }
 
-// One invocation per thread of every 8 x 8 workgroup covering w x h (the shaders bounds-check themselves).
+// One invocation per thread of every 8 x 8 workgroup covering w x h (the shaders bounds-check themselves).  Rows of invocations run on
+// the host's cores (OpenMP in the RUNNER: per-invocation state -- gl_*, stage inputs / outputs -- is thread_local, resources are bound
+// before the loop and only read inside it, every invocation stores to its own texel; the shader text is not touched).
 template <typename Main>
 void dispatch_8x8(int w, int h, Main main_fn)
 {
 	const int gw = (w + 7) & ~7, gh = (h + 7) & ~7;
+#pragma omp parallel for schedule(dynamic, 4)
 	for (int y = 0; y < gh; y++)
 		for (int x = 0; x < gw; x++)
 		{
@@ -214,21 +217,31 @@ void ref_tonemap(const uint16_t *hdr, int w, int h, const uint16_t *bloom, int b
 	target.w = w;
 	target.h = h;
 	target.format = Format::RGBA8_SRGB;
+	const bool dynamic = lum3 != nullptr;
+	if (dynamic)
+	{
+		namespace s = tonemap_dynamic;
+		s::average_log_luminance = lum3[0], s::average_linear_luminance = lum3[1], s::average_inv_linear_luminance = lum3[2];
+		s::uHDR = tex16(hdr, w, h);
+		s::uBloom = tex16(bloom, bw, bh);
+		s::registers.dynamic_exposure = dynamic_exposure;
+	}
+	else
+	{
+		namespace s = tonemap_static;
+		s::uHDR = tex16(hdr, w, h);
+		s::uBloom = tex16(bloom, bw, bh);
+		s::registers.dynamic_exposure = dynamic_exposure;
+	}
+#pragma omp parallel for schedule(dynamic, 4)
 	for (int y = 0; y < h; y++)
 		for (int x = 0; x < w; x++)
 		{
 			const vec2 uv = (vec2(float(x), float(y)) + vec2(0.5f, 0.5f)) * vec2(1.0f / float(w), 1.0f / float(h));
 			vec3 color;
-			if (lum3)
+			if (dynamic)
 			{
 				namespace s = tonemap_dynamic;
-				if (!x && !y)
-				{
-					s::average_log_luminance = lum3[0], s::average_linear_luminance = lum3[1], s::average_inv_linear_luminance = lum3[2];
-					s::uHDR = tex16(hdr, w, h);
-					s::uBloom = tex16(bloom, bw, bh);
-					s::registers.dynamic_exposure = dynamic_exposure;
-				}
 				s::vUV = uv;
 				s::main();
 				color = s::FragColor;
@@ -236,12 +249,6 @@ void ref_tonemap(const uint16_t *hdr, int w, int h, const uint16_t *bloom, int b
 			else
 			{
 				namespace s = tonemap_static;
-				if (!x && !y)
-				{
-					s::uHDR = tex16(hdr, w, h);
-					s::uBloom = tex16(bloom, bw, bh);
-					s::registers.dynamic_exposure = dynamic_exposure;
-				}
 				s::vUV = uv;
 				s::main();
 				color = s::FragColor;
