@@ -249,35 +249,38 @@ def main():
     base_width, base_height, num_lights, base_desc = WORKLOADS[args.workload]
     fixed_frame = args.workload in FIXED_FRAME_WORKLOADS
 
-    def build(bands: bool):
+    def build(bands: bool, workload: str = None):
         """One frame tiled into `world` row bands (bands=True) or this rank's own base frame (single GPU / fallback)."""
-        width, height, desc, name = base_width, base_height, base_desc, args.workload
+        workload = workload or args.workload
+        base_width, base_height, num_lights, base_desc = WORKLOADS[workload]
+        fixed_frame = workload in FIXED_FRAME_WORKLOADS
+        width, height, desc, name = base_width, base_height, base_desc, workload
         if bands and fixed_frame:
             # BASELINE config 5 as stated: the same 7680x4320 frame whatever the number of ranks (strong scaling).
-            name = f"{args.workload}_{world}_rowbands"
+            name = f"{workload}_{world}_rowbands"
             desc = f"{width}x{height} tiled into {world} row bands (one per GPU), {num_lights} clustered lights, bloom pyramid + luminance + tonemap"
         elif bands:
             # Weak scaling: one base frame's worth of pixels per rank, the frame tiled into `world` row bands
             # (7680x4320 at 4 ranks is BASELINE config 5's frame); same camera, same 4096 lights, same cluster grid.
             width, height = multigpu.weak_scaled_frame(world, (width, height))
-            name = f"{args.workload}_x{world}_rowbands_{width}x{height}"
+            name = f"{workload}_x{world}_rowbands_{width}x{height}"
             desc = f"{width}x{height} tiled into {world} row bands (one per GPU), {num_lights} clustered lights, bloom pyramid + luminance + tonemap"
         cam = synth.Camera(width, height)
         gbuf = synth.make_gbuffer(cam)
         descs = synth.make_lights(cam, num_lights, spot_fraction=0.25 if num_lights > 256 else 0.0)
         strips = dict(strip_index=rank if bands else 0, strip_count=world if bands else 1,
                       output_gather_rgba=os.environ.get("GRANITE_BENCH_GATHER_RGBA", "0") == "1")
-        if args.workload == "config1_256_post_only":
+        if workload == "config1_256_post_only":
             app = gapp.Application(width, height, device=local_rank, lighting=False, hdr_bloom=True, dynamic_exposure=True, compute_post=True)
             app.upload_hdr(gbuf["emissive"])
-        elif args.workload == "config4_4k_smaa_taa":
+        elif workload == "config4_4k_smaa_taa":
             app = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True, compute_post=True,
                                    pre_aa=gapp.POST_AA_TAA_HIGH, post_aa=gapp.POST_AA_SMAA_ULTRA)
             app.set_camera(np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16))
             app.set_lights(descs)
             app.upload_gbuffer(gbuf, synth.make_motion_vectors(width, height))
             app.set_camera_motion((0.01, 0.0, 0.0))  # SURVEY 8d, config 4 extras: the camera translates 0.01 units per frame
-        elif args.workload in PACKED_HDR_WORKLOADS:
+        elif workload in PACKED_HDR_WORKLOADS:
             app = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True, compute_post=True,
                                    rt_fp16=False)
             app.set_render_parameters(cam.render_params())
@@ -375,6 +378,13 @@ def main():
     known = {k: v for k, v in per_kernel.items() if k in ALGO_BYTES_PER_PX and k != "chain" and v[0]}
     dominant = max(known.items(), key=lambda kv: kv[1][1] / kv[1][0])[0] if known else "lighting"
     warm_breakdown = {k: {"launches": c, "avg_us": 1000.0 * ms / max(c, 1)} for k, (c, ms) in per_kernel.items()}
+    # Row bands: device time of the two collectives on their streams (hipEvent brackets like every launcher's; "inframe_gather" = the
+    # 1/8 bloom level inside the frame, "output_gather" = the finished bands beside it), from these fully bracketed warm-up frames.
+    gather_us = {}
+    for name in ("inframe_gather", "output_gather"):
+        if name in per_kernel and per_kernel[name][0]:
+            gather_us[name] = {"mean": 1000.0 * per_kernel[name][1] / per_kernel[name][0], "max": 1000.0 * kctx.timing_max_ms(name),
+                               "brackets": int(per_kernel[name][0])}
 
     # ---- timed region: only the dominant kernel keeps its hipEvent bracket, on every BRACKET_EVERY-th launch.  (An event
     # pair around a kernel stops the command processor from overlapping it with its neighbours on the stream: bracketing
@@ -405,10 +415,12 @@ def main():
             application.render_frames(settle_frames, sync=False)
     barrier()
     kctx.timing_enable(True)
+    og0 = application.output_gather_stats()
     t0 = time.perf_counter()
     hs0 = application.host_stats()
     application.render_frames(args.steps, sync=False)
     hs1 = application.host_stats()
+    og1 = application.output_gather_stats()
     # host side of the frame loop (light sort/pack + launches), excluding time blocked on GPU back-pressure
     host_busy = (hs1["seconds"] - hs0["seconds"]) - (hs1["blocked_seconds"] - hs0["blocked_seconds"])
     barrier()
@@ -561,6 +573,19 @@ def main():
         info.update({"output_bytes_per_rank": int(out_rows) * width * (3 if packed_rgb else 4),
                      "bloom_level_bytes_per_rank": int(plan["d1_chunk_rows"]) * (width // 8) * 8 if "d1_chunk_rows" in plan else None,
                      "ms_per_step_over_ranks": rank_ms})
+        # Per-collective device time, mean on this rank and the max over the ranks (one slow link shows up as the max), and whether
+        # the output gather stayed hidden: `waits` = times a pass of a later frame found the gather of the image it was about to
+        # overwrite still in flight during the timed steps (0 = every gather had finished before its image was needed again).
+        for name, key in (("inframe_gather", "inframe_gather_us"), ("output_gather", "output_gather_us")):
+            mine = gather_us.get(name)
+            t = torch.tensor([mine["mean"] if mine else -1.0, mine["max"] if mine else -1.0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            info[key] = None if mine is None and float(t[0]) < 0 else {"mean_rank0": mine["mean"] if mine else None, "mean_max_over_ranks": float(t[0]),
+                                                                        "max_over_ranks": float(t[1]), "source": "hipEvent brackets on the collective's stream, warm-up frames"}
+        waits = torch.tensor([og1["waits"] - og0["waits"], og1["acquires"] - og0["acquires"]], dtype=torch.int64)
+        dist.all_reduce(waits, op=dist.ReduceOp.MAX)
+        info["output_gather_waits_in_timed_steps"] = int(waits[0])
+        info["overlapped"] = bool(int(waits[1]) > 0 and int(waits[0]) == 0) if os.environ.get("GRANITE_BENCH_GATHER", "beside") != "inframe" else False
         result["rccl"] = info
     if sustained:
         sustained["value"] = pixels_per_step * sustained["steps"] / sustained["seconds"] / 1e6
@@ -588,6 +613,35 @@ def main():
                                              "lives in tests/test_gpu_fullsize.py: config 1 / config 4)"}
 
     application.close()
+    # ---- BASELINE config 5 beside the default workload (N > 1): the default line is weak scaling (one 4K frame's worth of pixels per
+    # rank); the configuration BASELINE.json names for the multi-GPU case is ONE 7680x4320 frame over the ranks -- strong scaling.  Same
+    # contract on a second executor: W warm-up frames, then exactly K frames between two barriers, max over the ranks.
+    if bands and args.workload == "config3_4k_4096lights" and os.environ.get("GRANITE_BENCH_CONFIG5", "1") == "1":
+        sub = None
+        try:
+            app5, _, _, _, w5, h5, desc5, name5 = build(True, "config5_8k")
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            app5, ok, sub = None, 0, {"error": f"{type(e).__name__}: {e}"}
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            application = app5  # barrier() syncs the executor it finds under this name
+            application.render_frames(max(args.warmup, 1), sync=True)
+            application.render_frames(max(args.steps, 40), sync=False)  # clocks (see "clock settle")
+            barrier()
+            t0 = time.perf_counter()
+            application.render_frames(args.steps, sync=False)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sub = {"workload": name5, "description": desc5, "width": w5, "height": h5, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": 1000.0 * float(t.item()) / args.steps, "value": w5 * h5 * args.steps / float(t.item()) / 1e6, "unit": "Mpixels/s",
+                   "scaling": "strong"}
+            app5.close()
+        elif app5 is not None:
+            app5.close()
+        result["config5_8k"] = sub or {"error": "another rank could not set up the 8K frame"}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -66,7 +66,7 @@ EXPORTED_SYMBOLS = [
     "gra_get_render_parameters", "gra_set_lights", "gra_upload_gbuffer", "gra_render_frames", "gra_sync",
     "gra_get_resource", "gra_read_resource", "gra_get_backbuffer", "gra_read_backbuffer", "gra_get_cluster_state",
     "gra_dump_graph", "gra_collect_timestamps", "gra_get_kernel_context", "gra_get_stream", "gra_get_taa_reprojection",
-    "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_prefetched_refreshes", "gra_get_launch_graph_replays", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
+    "gra_set_smaa_luts", "gra_get_host_stats", "gra_get_output_gather_stats", "gra_get_prefetched_refreshes", "gra_get_launch_graph_replays", "gra_get_allocated_bytes", "gra_gtx_probe", "gra_gtx_read", "gra_gtx_write",
     "gra_upload_gbuffer_gtx", "gra_save_resource_gtx", "gra_get_render_size", "gra_upload_ambient_occlusion", "gra_upload_aa_bench_images", "gra_compute_rec709_to_display", "gra_set_exchange_callback", "gra_get_strip_plan", "gra_get_strip_plan_aa", "gra_get_strip_plan_taa_history",
     "gra_comm_create_unique_id", "gra_comm_init", "gra_comm_info", "gra_comm_init_output", "gra_install_ssr_tables", "gra_reset_timestamps", "gra_set_directional_light", "gra_set_fog", "gra_generate_mipmaps", "gra_write_resource", "gra_get_frame_state", "gra_set_frame_state",
 ]
@@ -107,6 +107,7 @@ def load_library() -> C.CDLL:
         "gra_get_taa_reprojection": (C.c_int, [vp, vp]),
         "gra_set_smaa_luts": (C.c_int, [vp, vp, vp]),
         "gra_get_host_stats": (C.c_int, [vp, vp]),
+        "gra_get_output_gather_stats": (C.c_int, [vp, vp]),
         "gra_install_ssr_tables": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32]),
         "gra_get_prefetched_refreshes": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "gra_get_launch_graph_replays": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
@@ -459,6 +460,12 @@ class Application:
         self._check(self.lib.gra_get_host_stats(self.handle, out.ctypes.data))
         return {"frames": int(out[0]), "seconds": float(out[1]), "blocked_seconds": float(out[2])}
 
+    def output_gather_stats(self) -> dict:
+        """Output gather beside the frame: how often the next writer of an output image found its gather still in flight."""
+        out = np.zeros(2, np.uint64)
+        self._check(self.lib.gra_get_output_gather_stats(self.handle, out.ctypes.data))
+        return {"acquires": int(out[0]), "waits": int(out[1])}
+
     def launch_graph_replays(self) -> int:
         """Pre-recorded launch sequences replayed so far (one hipGraph launch instead of one API call per kernel)."""
         out = C.c_uint64(0)
@@ -518,3 +525,10 @@ class KernelContextView:
         if n < 0:
             raise capi.GraniteHipError(self.lib.gr_last_error(self.handle).decode())
         return {arr[i].name.decode(): (int(arr[i].count), float(arr[i].total_ms)) for i in range(n)}
+
+    def timing_max_ms(self, name: str) -> float:
+        """Longest single bracket recorded under `name` since the last reset (a collective that stalled once shows here, not in the mean)."""
+        out = C.c_double(0.0)
+        if self.lib.gr_timing_max_ms(self.handle, name.encode(), C.byref(out)) < 0:
+            raise capi.GraniteHipError(self.lib.gr_last_error(self.handle).decode())
+        return float(out.value)

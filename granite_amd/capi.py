@@ -240,6 +240,9 @@ def load_library() -> C.CDLL:
         "gr_timing_enable": (C.c_int, [vp, C.c_int]),
         "gr_timing_set_filter": (C.c_int, [vp, C.c_char_p]),
         "gr_timing_set_sampling": (C.c_int, [vp, C.c_uint32]),
+        "gr_timing_max_ms": (C.c_int, [vp, C.c_char_p, vp]),
+        "gr_timing_span_begin": (C.c_int, [vp, vp, C.c_char_p, vp]),
+        "gr_timing_span_end": (C.c_int, [vp, vp, vp]),
         "gr_bandwidth_probe": (C.c_int, [vp, C.c_size_t, C.c_int, P(C.c_double), P(C.c_double)]),
         "gr_timing_reset": (C.c_int, [vp]),
         "gr_timing_query": (C.c_int, [vp, P(TimingEntry), C.c_int]),
@@ -414,6 +417,12 @@ class Context:
     # ---- timing -----------------------------------------------------------------------------------------------
     def timing_enable(self, enable: bool):
         self.check(self.lib.gr_timing_enable(self.handle, int(enable)))
+
+    def timing_max_ms(self, name: str) -> float:
+        """Longest single bracket recorded under `name` since the last reset."""
+        out = C.c_double(0.0)
+        self.check(self.lib.gr_timing_max_ms(self.handle, name.encode(), C.byref(out)))
+        return float(out.value)
 
     def timing_reset(self):
         self.check(self.lib.gr_timing_reset(self.handle))

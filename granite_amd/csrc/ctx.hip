@@ -1,6 +1,7 @@
 // Context, memory and timing entry points of the C ABI (include/granite_hip.h).
 #include "ctx.hpp"
 #include "device_common.hpp"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -649,7 +650,7 @@ int gr_timing_brackets(gr_ctx *ctx, const char *name)
 {
 	if (!ctx || !name)
 		return 0;
-	return ctx->timing_enabled && (ctx->timing_filter.empty() || ctx->timing_filter == name) ? 1 : 0;
+	return ctx->timing_enabled && ctx->timing_matches(name) ? 1 : 0;
 }
 
 int gr_timing_set_sampling(gr_ctx *ctx, uint32_t every_nth)
@@ -691,6 +692,7 @@ static int drain_spans(gr_ctx *ctx)
 		}
 		itr->second.count++;
 		itr->second.ms += ms;
+		itr->second.max_ms = std::max(itr->second.max_ms, double(ms));
 		if (s.start != origin)
 			ctx->event_pool.push_back(s.start);
 		ctx->event_pool.push_back(s.stop);
@@ -698,6 +700,54 @@ static int drain_spans(gr_ctx *ctx)
 	if (dump)
 		fflush(dump);
 	ctx->spans.clear();
+	return GR_OK;
+}
+
+// A bracket around work that is not one of this library's launches (a collective on its stream, a copy): the same hipEvent pair, the
+// same accumulator, under the caller's name.  `name` must outlive the context (a string literal).
+int gr_timing_span_begin(gr_ctx *ctx, gr_stream stream, const char *name, void **span)
+{
+	if (!ctx || !name || !span)
+		return GR_ERR_INVALID_ARGUMENT;
+	*span = nullptr;
+	if (!ctx->timing_enabled || !ctx->timing_matches(name))
+		return GR_OK;
+	std::lock_guard<std::mutex> holder{ctx->lock};
+	auto *s = new gr_timing_span{name, ctx->get_event(), ctx->get_event()};
+	if (!s->start || !s->stop)
+	{
+		delete s;
+		return GR_OK;
+	}
+	(void)hipEventRecord(s->start, gr_to_stream(stream));
+	*span = s;
+	return GR_OK;
+}
+
+int gr_timing_span_end(gr_ctx *ctx, gr_stream stream, void *span)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	if (!span)
+		return GR_OK;
+	auto *s = static_cast<gr_timing_span *>(span);
+	(void)hipEventRecord(s->stop, gr_to_stream(stream));
+	std::lock_guard<std::mutex> holder{ctx->lock};
+	ctx->spans.push_back(*s);
+	delete s;
+	return GR_OK;
+}
+
+// Longest single bracket recorded under `name` since the last reset (gr_timing_query drains the pending brackets first).
+int gr_timing_max_ms(gr_ctx *ctx, const char *name, double *max_ms)
+{
+	if (!ctx || !name || !max_ms)
+		return GR_ERR_INVALID_ARGUMENT;
+	int ret = drain_spans(ctx);
+	if (ret < 0)
+		return ret;
+	auto itr = ctx->accum.find(name);
+	*max_ms = itr == ctx->accum.end() ? 0.0 : itr->second.max_ms;
 	return GR_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -64,7 +65,24 @@ struct gr_ctx
 	unsigned timing_seen = 0;
 	std::vector<gr_timing_span> spans;
 	std::vector<hipEvent_t> event_pool;
-	struct Accum { uint64_t count = 0; double ms = 0.0; };
+	struct Accum { uint64_t count = 0; double ms = 0.0, max_ms = 0.0; };
+	// timing_filter: empty = every name; otherwise a comma-separated list of the names that get a bracket
+	bool timing_matches(const char *name) const
+	{
+		if (timing_filter.empty())
+			return true;
+		const size_t n = strlen(name);
+		for (size_t at = 0; at <= timing_filter.size();)
+		{
+			size_t end = timing_filter.find(',', at);
+			if (end == std::string::npos)
+				end = timing_filter.size();
+			if (end - at == n && timing_filter.compare(at, n, name) == 0)
+				return true;
+			at = end + 1;
+		}
+		return false;
+	}
 	std::map<std::string, Accum> accum;
 	std::vector<std::string> accum_order;
 
@@ -109,7 +127,7 @@ struct gr_scoped_timing
 	{
 		if (!ctx->timing_enabled)
 			return;
-		if (!ctx->timing_filter.empty() && ctx->timing_filter != name)
+		if (!ctx->timing_matches(name))
 			return;
 		std::lock_guard<std::mutex> holder{ctx->lock};
 		if (ctx->timing_every > 1 && (ctx->timing_seen++ % ctx->timing_every) != 0)

@@ -371,6 +371,15 @@ int gra_get_host_stats(gra_app *app, double *out3)
 	});
 }
 
+int gra_get_output_gather_stats(gra_app *app, uint64_t *out2)
+{
+	return guarded(app, [&]() {
+		if (!out2)
+			throw std::logic_error("gra_get_output_gather_stats: null output");
+		app->app->get_output_gather_stats(out2);
+	});
+}
+
 int gra_install_ssr_tables(const uint8_t *blue_noise_128x128_rg8, const uint16_t *brdf_lut_rg16f, uint32_t brdf_width, uint32_t brdf_height)
 {
 	try

@@ -249,6 +249,9 @@ void ImageSpaceApplication::init_collective(const uint8_t *id128, int rank, int 
 		if (last_output_gather_event && hipEventQuery(static_cast<hipEvent_t>(last_output_gather_event)) != hipSuccess)
 			if (hipStreamWaitEvent(static_cast<hipStream_t>(cmd.get_stream()), static_cast<hipEvent_t>(last_output_gather_event), 0) != hipSuccess)
 				throw std::runtime_error("hipStreamWaitEvent failed");
+		// device time of the collective on its stream, when somebody asked (gr_timing_*: "inframe_gather")
+		void *span = nullptr;
+		(void)gr_timing_span_begin(cmd.get_context(), cmd.get_stream(), "inframe_gather", &span);
 		if (output_packs(image, tag))
 		{
 			pack_output_band(cmd, image, chunk_rows);
@@ -257,6 +260,7 @@ void ImageSpaceApplication::init_collective(const uint8_t *id128, int rank, int 
 		}
 		else
 			collective.all_gather_in_place(image.get_device_pointer(), size_t(chunk_rows) * image.get_view().pitch_bytes, cmd.get_stream());
+		(void)gr_timing_span_end(cmd.get_context(), cmd.get_stream(), span);
 	};
 }
 
@@ -278,9 +282,13 @@ void ImageSpaceApplication::init_output_collective(const uint8_t *id128, int ran
 	// that gather is normally long finished) ...
 	strip_plan.acquire_output = [this](HIP::CommandBuffer &cmd, HIP::Image &image) {
 		auto itr = output_gather_done.find(image.get_device_pointer());
+		output_acquires++;
 		if (itr != output_gather_done.end() && hipEventQuery(static_cast<hipEvent_t>(itr->second)) != hipSuccess)
+		{
+			output_acquire_waits++; // the gather of this image was still in flight when its next writer was enqueued: not hidden
 			if (hipStreamWaitEvent(static_cast<hipStream_t>(cmd.get_stream()), static_cast<hipEvent_t>(itr->second), 0) != hipSuccess)
 				throw std::runtime_error("hipStreamWaitEvent failed");
+		}
 	};
 	// ... and the gather itself runs on the collective stream behind the band's last pass, beside whatever the executor's
 	// streams do next (the following frames' cluster build, lighting and bloom chain).
@@ -294,10 +302,13 @@ void ImageSpaceApplication::init_output_collective(const uint8_t *id128, int ran
 		    hipStreamWaitEvent(gather_stream, ready_event, 0) != hipSuccess)
 			throw std::runtime_error("output gather: event hand-over failed");
 		const BandTransport rccl = [this](void *base, size_t chunk_bytes, void *stream) { output_collective.all_gather_in_place(base, chunk_bytes, stream); };
+		void *span = nullptr;
+		(void)gr_timing_span_begin(cmd.get_context(), gather_stream, "output_gather", &span);
 		if (packs)
 			gather_packed_output(image, chunk_rows, gather_stream, rccl);
 		else
 			rccl(image.get_device_pointer(), size_t(chunk_rows) * image.get_view().pitch_bytes, gather_stream);
+		(void)gr_timing_span_end(cmd.get_context(), gather_stream, span);
 		void *&done = output_gather_done[image.get_device_pointer()];
 		if (!done)
 		{

@@ -82,6 +82,13 @@ public:
 		out[1] = host_seconds;
 		out[2] = device_holder ? device_holder->get_blocked_seconds() : 0.0;
 	}
+	// The output gather beside the frame (init_output_collective): out[0] = times a pass was about to overwrite an output image, out[1] =
+	// of those, how often the gather that last read the image was still in flight (the pass then waits: the gather was NOT hidden).
+	void get_output_gather_stats(uint64_t out[2]) const
+	{
+		out[0] = output_acquires;
+		out[1] = output_acquire_waits;
+	}
 	// G-buffer attachments from .gtx files (any may be null); the frame written back as .gtx.
 	void upload_gbuffer_gtx(const char *const paths[6]);
 	void set_camera_motion(const vec3 &translation_per_frame);
@@ -145,6 +152,7 @@ private:
 	bool resources_prepared = false; // prepare_resources_for_write() ran before the first frame
 	double elapsed = 0.0;
 	uint64_t host_frames = 0;
+	uint64_t output_acquires = 0, output_acquire_waits = 0;
 	double host_seconds = 0.0;
 
 	void bake_render_graph();

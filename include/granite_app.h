@@ -283,6 +283,10 @@ int gra_get_strip_plan_taa_history(gra_app *app, uint32_t *out5);
  * R16G16_SFLOAT split-sum BRDF table (width x height texels); see csrc/host/post/ssr.hpp. */
 int gra_install_ssr_tables(const uint8_t *blue_noise_128x128_rg8, const uint16_t *brdf_lut_rg16f, uint32_t brdf_width, uint32_t brdf_height);
 int gra_get_host_stats(gra_app *app, double *out3);
+/* Row bands with the output gather beside the frame (gra_comm_init_output): out[0] = times a pass was about to overwrite an output
+ * image, out[1] = of those, how often the all-gather that last read it was still in flight (the pass waits: the gather was not hidden
+ * behind the following frames).  The collectives' device times are gr_timing_* names "inframe_gather" / "output_gather". */
+int gra_get_output_gather_stats(gra_app *app, uint64_t *out2);
 /* Frames whose light sort + pack (LightClusterer::refresh) had already been done by the clusterer's helper thread while the
  * previous frame was being enqueued (the reference runs its refreshes as TaskComposer tasks beside command recording). */
 int gra_get_prefetched_refreshes(gra_app *app, uint64_t *out);

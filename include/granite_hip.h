@@ -124,6 +124,13 @@ int gr_timing_brackets(gr_ctx *ctx, const char *name);
  * overlapping that launch with its neighbours on the stream; sampling keeps a timed loop close to its unbracketed speed
  * while the launch duration is still measured live inside it. */
 int gr_timing_set_sampling(gr_ctx *ctx, uint32_t every_nth);
+/* Restrict bracketing to several launchers: gr_timing_set_filter also takes a comma-separated list ("lighting,output_gather").
+ * gr_timing_span_begin / _end bracket work that is not one of this library's launches (a collective on its stream) under the caller's
+ * name, into the same accumulator; *span is NULL when the name is not being timed (then _end is a no-op).  gr_timing_max_ms: the
+ * longest single bracket under a name since the last reset. */
+int gr_timing_span_begin(gr_ctx *ctx, gr_stream stream, const char *name, void **span);
+int gr_timing_span_end(gr_ctx *ctx, gr_stream stream, void *span);
+int gr_timing_max_ms(gr_ctx *ctx, const char *name, double *max_ms);
 int gr_timing_reset(gr_ctx *ctx);
 int gr_timing_query(gr_ctx *ctx, gr_timing_entry *entries, int max_entries); /* returns number of entries; syncs */
 

@@ -1,0 +1,57 @@
+"""fp16-ulp histogram of the TAA resolve against the oracle at 4K: which tolerance does the kernel hold, per quality,
+for the resolved colour and for the history target, on the first frame (no history) and with a history -- and where the channels that
+leave SURVEY 8a's 2 ulp + 1e-4 sit.  Usage (GPU box): python tools/taa_ulp_hist.py [W H] -> JSON."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from granite_amd import capi, synth
+from oracle import oracle as orc
+from util import half_bits_to_f32, ulp_fp16, rgba16f_mismatch
+from test_gpu_aa import taa_inputs
+
+w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
+F16 = capi.FORMAT_R16G16B16A16_SFLOAT
+gr = capi.Context(0)
+cur, depth, mv, reproj = taa_inputs(w, h)
+dcur = capi.DeviceImage(gr, w, h, F16).upload(cur)
+ddepth = capi.DeviceImage(gr, w, h, capi.FORMAT_D32_SFLOAT).upload(depth)
+dmv = capi.DeviceImage(gr, w, h, capi.FORMAT_R16G16_SFLOAT).upload(mv)
+dcol = capi.DeviceImage(gr, w, h, F16)
+dh = [capi.DeviceImage(gr, w, h, F16), capi.DeviceImage(gr, w, h, F16)]
+
+
+def hist(got, want):
+    a = half_bits_to_f32(got).astype(np.float64); b = half_bits_to_f32(want).astype(np.float64)
+    fin = np.isfinite(a) & np.isfinite(b)
+    d = np.where(fin, np.abs(a - b) / ulp_fp16(np.maximum(np.abs(a), np.abs(b))), 0.0)
+    edges = [0, 0.5, 1.5, 2.5, 3.5, 1e9]
+    counts, _ = np.histogram(d, edges)
+    out = {"channels": int(d.size), "ulp_0": int(counts[0]), "ulp_1": int(counts[1]), "ulp_2": int(counts[2]), "ulp_3": int(counts[3]), "ulp_gt3": int(counts[4]),
+           "max_ulp": float(d.max()), "beyond_2ulp_plus_1e-4": int(rgba16f_mismatch(got, want, 2.0, 1e-4).sum()),
+           "beyond_3ulp_plus_2e-4": int(rgba16f_mismatch(got, want, 3.0, 2e-4).sum())}
+    bad = rgba16f_mismatch(got, want, 2.0, 1e-4)
+    if bad.any():
+        # what the offending channels look like: magnitude of the values and of the absolute difference
+        va, vb = a[bad], b[bad]
+        out["offenders"] = {"value_min": float(np.minimum(np.abs(va), np.abs(vb)).min()), "value_median": float(np.median(np.abs(vb))),
+                            "abs_diff_max": float(np.abs(va - vb).max()), "abs_diff_median": float(np.median(np.abs(va - vb))),
+                            "by_channel": [int(bad[..., c].sum()) for c in range(4)],
+                            "in_motion_vector_region": float(np.mean(np.any(bad, axis=-1)[:, int(0.45 * w):int(0.55 * w)].sum() / max(np.any(bad, axis=-1).sum(), 1)))}
+    return out
+
+
+result = {"size": [w, h]}
+for q, name in enumerate(("low", "medium", "high")):
+    gr.taa_resolve(dcur, ddepth, dmv, None, dcol, dh[0], reproj, q); gr.sync()
+    ref_c, ref_h = orc.taa_resolve(cur, depth, mv, None, reproj, q)
+    r = {"frame0_colour": hist(dcol.download(), ref_c), "frame0_history": hist(dh[0].download(), ref_h)}
+    cur2 = synth.make_hdr(w, h, seed=11)
+    dcur.upload(cur2); dh[0].upload(ref_h)
+    gr.taa_resolve(dcur, ddepth, dmv, dh[0], dcol, dh[1], reproj, q); gr.sync()
+    ref_c2, ref_h2 = orc.taa_resolve(cur2, depth, mv, ref_h, reproj, q)
+    r["frame1_colour"] = hist(dcol.download(), ref_c2); r["frame1_history"] = hist(dh[1].download(), ref_h2)
+    dcur.upload(cur)
+    result[name] = r
+print(json.dumps(result))
+gr.close()
