@@ -111,7 +111,12 @@ void LightClusterer::prefetch(const RenderParameters &next_parameters)
 	// Waking three helper threads and collecting their result costs the submitting thread 12-15 us per frame (futex round trips;
 	// measured on the device-less frame loop, tests/test_host_frame_loop_cpu.py); sorting and packing costs ~22 ns per light.  Below
 	// about a thousand lights the hand-over is the larger part: refresh() packs in place then.
-	if (!scene_lights || scene_lights->size() < PrefetchMinLights)
+	// GRANITE_LIGHT_PREFETCH_MIN=<n> moves the threshold (tests run the threaded path on small scenes with 0).
+	static const size_t min_lights = []() {
+		const char *env = getenv("GRANITE_LIGHT_PREFETCH_MIN");
+		return env ? size_t(strtoul(env, nullptr, 10)) : size_t(PrefetchMinLights);
+	}();
+	if (!scene_lights || scene_lights->size() < min_lights)
 		return;
 	std::unique_lock<std::mutex> holder{ahead.lock};
 	if (ahead.threads.empty())

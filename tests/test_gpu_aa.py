@@ -114,8 +114,8 @@ def test_taa_resolve(gr, quality):
         gr.taa_resolve(dcur, ddepth, dmv, dh[f & 1], dcol, dh[(f & 1) ^ 1], reproj, quality)
         gr.sync()
         ref_c, ref_h2 = orc.taa_resolve(cur2, depth, mv, hist, reproj, quality)
-        assert_rgba16f_close(dcol.download(), ref_c, ulps=3.0, abs_tol=2e-4, what=f"taa q{quality} f{f + 1} colour")
-        assert_rgba16f_close(dh[(f & 1) ^ 1].download(), ref_h2, ulps=3.0, abs_tol=2e-4, what=f"taa q{quality} f{f + 1} history")
+        assert_rgba16f_close(dcol.download(), ref_c, ulps=2.0, abs_tol=1e-4, what=f"taa q{quality} f{f + 1} colour")
+        assert_rgba16f_close(dh[(f & 1) ^ 1].download(), ref_h2, ulps=2.0, abs_tol=1e-4, what=f"taa q{quality} f{f + 1} history")
         hist = ref_h2
 
 
@@ -178,9 +178,9 @@ def test_application_with_aa_matches_oracle_pipeline(luts, post_aa, pre_aa):
             # feed the device's lit HDR + previous device history to the oracle: this checks the TAA pass, not carried error
             cur = a.read("HDR-main").copy()
             ref_c, ref_h = orc.taa_resolve(cur, gbuf["depth"], mv, taa_hist, a.taa_reprojection(), taa_q)
-            assert_rgba16f_close(a.read("HDR-resolved"), ref_c, ulps=3.0, abs_tol=2e-4, what=f"frame {frame} HDR-resolved")
+            assert_rgba16f_close(a.read("HDR-resolved"), ref_c, ulps=2.0, abs_tol=1e-4, what=f"frame {frame} HDR-resolved")
             got_h = a.read("HDR-resolved-history").copy()
-            assert_rgba16f_close(got_h, ref_h, ulps=3.0, abs_tol=2e-4, what=f"frame {frame} history")
+            assert_rgba16f_close(got_h, ref_h, ulps=2.0, abs_tol=1e-4, what=f"frame {frame} history")
             taa_hist = got_h
             chain_in = a.read("HDR-resolved").copy()
         else:

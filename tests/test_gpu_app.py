@@ -1,5 +1,7 @@
 """GPU parity, end to end: frames rendered by the RenderGraph executor (C++ host layer + HIP kernels) vs the CPU oracle
 driven in the reference's recorded order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -20,6 +22,11 @@ def oracle_frames(cam, gbuf, descs, frames, res=synth.CLUSTER_RESOLUTION):
     for _ in range(frames):
         out = orc.hdr_chain(hdr, state)
     return {"n": n, "lights": lights, "model": model, "type_mask": tmask, "prm": prm, "cluster": cb, "hdr": hdr, "chain": out}
+
+
+# The one-frame-ahead light refresh only uses the helper threads from ~1000 lights up (LightClusterer::prefetch); the tests of that
+# path keep their small scenes and lower the threshold.  Read once per process, so it is set before the first application exists.
+os.environ.setdefault("GRANITE_LIGHT_PREFETCH_MIN", "0")
 
 
 @pytest.fixture(scope="module")

@@ -236,9 +236,9 @@ def test_config4_smaa_taa_sequence_matches_oracle_at_4k():
         assert_rgba16f_close_but_for_ill_conditioned_pixels(a.read("HDR-main"), hdr, ulps=2.0, what=f"4K frame {frame} HDR-main")
         cur = a.read("HDR-main").copy()
         ref_c, ref_h = orc.taa_resolve(cur, gbuf["depth"], mv, taa_hist, a.taa_reprojection(), 2)
-        assert_rgba16f_close(a.read("HDR-resolved"), ref_c, ulps=3.0, abs_tol=2e-4, what=f"4K frame {frame} HDR-resolved")
+        assert_rgba16f_close(a.read("HDR-resolved"), ref_c, ulps=2.0, abs_tol=1e-4, what=f"4K frame {frame} HDR-resolved")
         got_h = a.read("HDR-resolved-history").copy()
-        assert_rgba16f_close(got_h, ref_h, ulps=3.0, abs_tol=2e-4, what=f"4K frame {frame} TAA history")
+        assert_rgba16f_close(got_h, ref_h, ulps=2.0, abs_tol=1e-4, what=f"4K frame {frame} TAA history")
         taa_hist = got_h
         chain = orc.hdr_chain(a.read("HDR-resolved").copy(), state)
         tm = np.ascontiguousarray(a.read("tonemapped"))
