@@ -22,9 +22,13 @@ constexpr int FAST_BW = 32, FAST_BH = 16; // 512 threads: 8 waves of two 32-pixe
 // XCD AA_XCD_ROWS whole tile rows at a time (XCD x takes rows 8 G k + G x ... + G - 1 of every group of 8 G, left to right), so a
 // tile's left and right neighbours -- and, for G > 1, the rows above / below inside the run -- read the shared lines out of the
 // same L2; interleaving the runs keeps the eight XCDs on the same part of the image (content-dependent cost stays balanced).  The
-// rows beyond the last whole group keep screen order.  AA_XCD_ROWS = 0: screen order everywhere (the A/B).
+// rows beyond the last whole group keep screen order.
+// MEASURED (round 4, profiles/r04_aa_tile_order_ab.txt): nothing to gain -- TAA High 161.1 (screen order) / 158.6 (1 row per XCD) /
+// 160.2 (2) / 160.5 us (4), SMAA edges 24.6 / 25.5 / 26.1 / 26.1, FXAA on the test card 38.9 / 44.9 / 46.0 / 53.2 (whole rows of flat or
+// busy tiles land on one XCD).  What FETCH_SIZE counts as fetched twice comes out of the 256 MB memory-side cache, not out of HBM.
+// The default is therefore screen order (AA_XCD_ROWS = 0); the order and its tests stay for a chip where the second fetch is not free.
 #ifndef AA_XCD_ROWS
-#define AA_XCD_ROWS 1
+#define AA_XCD_ROWS 0
 #endif
 __device__ __forceinline__ void xcd_tile_of_workgroup(unsigned &tile_x, unsigned &tile_y)
 {

@@ -64,9 +64,6 @@ constexpr float CULL_SLACK = 1e-3f;
 #ifndef LV_GFOLD
 #define LV_GFOLD 1 // c0 folded into the per-pixel G constants
 #endif
-#ifndef LV_PACKED
-#define LV_PACKED 1 // two pixels per lane: the walk written on float2 values, one v_pk_* instruction for both pixels wherever the ISA has one
-#endif
 #ifndef LV_A2_SAT
 #define LV_A2_SAT 0 // 1 / max(len, 0.1)^2 = 100 sat(inv_d2 / 100): a full-rate multiply with clamp instead of a half-rate min; the 100 goes into the staged colour
 #endif
@@ -265,87 +262,11 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 	}
 }
 
-// ---- the same walk on float2 values: component p = the lane's pixel p ---------------------------------------------------------------
-// gfx950 has v_pk_{fma,mul,add}_f32 (two fp32 operations per lane and instruction, 4.2 issue cycles against 2 x 2.4 for the scalar
-// forms); what it has no packed form of -- rsq / rcp, min / max / med3, the clamp modifier on a packed result -- stays one instruction per
-// pixel.  The SLP vectoriser finds about a third of the pairs on its own; written out, everything that can pair does, because the two
-// pixels' operands sit in adjacent registers from the start (Surface2 is the structure-of-arrays form of Surface[2]).  Operation by
-// operation this is shade_positional / brdf_accumulate: same products, same sums, same order -- the results are bit-identical.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 rsq2(f32x2 v) { return f32x2{rsq(v.x), rsq(v.y)}; }
-__device__ __forceinline__ f32x2 rcp2(f32x2 v) { return f32x2{rcp(v.x), rcp(v.y)}; }
-__device__ __forceinline__ f32x2 dot2(f32x2 ax, f32x2 ay, f32x2 az, f32x2 bx, f32x2 by, f32x2 bz) { return fma2(az, bz, fma2(ay, by, ax * bx)); }
-
-struct Surface2
-{
-	f32x2 px, py, pz, Nx, Ny, Nz, Vx, Vy, Vz, F0x, F0y, F0z, D1x, D1y, D1z;
-	f32x2 NdV, m2m1, gA, gB;
-};
-__device__ __forceinline__ Surface2 pair_surfaces(const Surface &a, const Surface &b)
-{
-	Surface2 s;
-	s.px = f32x2{a.pos.x, b.pos.x}, s.py = f32x2{a.pos.y, b.pos.y}, s.pz = f32x2{a.pos.z, b.pos.z};
-	s.Nx = f32x2{a.N.x, b.N.x}, s.Ny = f32x2{a.N.y, b.N.y}, s.Nz = f32x2{a.N.z, b.N.z};
-	s.Vx = f32x2{a.V.x, b.V.x}, s.Vy = f32x2{a.V.y, b.V.y}, s.Vz = f32x2{a.V.z, b.V.z};
-	s.F0x = f32x2{a.F0.x, b.F0.x}, s.F0y = f32x2{a.F0.y, b.F0.y}, s.F0z = f32x2{a.F0.z, b.F0.z};
-	s.D1x = f32x2{a.D1.x, b.D1.x}, s.D1y = f32x2{a.D1.y, b.D1.y}, s.D1z = f32x2{a.D1.z, b.D1.z};
-	s.NdV = f32x2{a.NdV, b.NdV}, s.m2m1 = f32x2{a.m2m1, b.m2m1}, s.gA = f32x2{a.gA, b.gA}, s.gB = f32x2{a.gB, b.gB};
-	return s;
-}
-
-// brdf_accumulate for both pixels (LV_SAT_NOH, LV_GFOLD forms).
-__device__ __forceinline__ void brdf_accumulate2(const Surface2 &s, f32x2 NdL, f32x2 hh, f32x2 scale, float cr, float cg, float cb, f32x2 &rx, f32x2 &ry, f32x2 &rz)
-{
-	const f32x2 NoL = f32x2{med3(NdL.x, 0.001f, 1.0f), med3(NdL.y, 0.001f, 1.0f)};
-	const f32x2 inv_h = rsq2(hh);
-	const f32x2 mh = hh * splat(-0.5f);
-	const f32x2 omh = f32x2{sat(fmaf(mh.x, inv_h.x, 1.001f)), sat(fmaf(mh.y, inv_h.y, 1.001f))} - splat(0.001f); // 1 - clamp(HoV, 0.001, 1)
-	const f32x2 sum = s.NdV + NdL;
-	const f32x2 NoH = f32x2{sat(sum.x * inv_h.x), sat(sum.y * inv_h.y)};
-	const f32x2 omh2 = omh * omh;
-	const f32x2 f = omh2 * omh2 * omh; // pow(1 - HoV, 5)
-	const f32x2 d = fma2(NoH * NoH, s.m2m1, splat(1.0f));
-	const f32x2 g = fma2(NoL, s.gA, s.gB);
-	const f32x2 GD = rcp2(d * d * g);
-	const f32x2 w = NoL * scale;
-	const f32x2 cw = fma2(-f, w, w); // (1 - f) w
-	const f32x2 fw = f * GD * w;
-	rx = fma2(splat(cr), fma2(fma2(GD, s.F0x, s.D1x), cw, fw), rx);
-	ry = fma2(splat(cg), fma2(fma2(GD, s.F0y, s.D1y), cw, fw), ry);
-	rz = fma2(splat(cb), fma2(fma2(GD, s.F0z, s.D1z), cw, fw), rz);
-}
-
-template <int KIND> // 0 = point light, 1 = spot light
-__device__ __forceinline__ void shade_positional2(const Surface2 &s, const f32x4 *slot, f32x2 &rx, f32x2 &ry, f32x2 &rz)
-{
-	const f32x4 q0 = slot[0], q1 = slot[1];
-	const f32x2 Lx = splat(q0.x) - s.px, Ly = splat(q0.y) - s.py, Lz = splat(q0.z) - s.pz; // light_pos - world_pos
-	const f32x2 d2 = fma2(Lz, Lz, fma2(Ly, Ly, fma2(Lx, Lx, splat(1e-30f))));             // > 0: no inf / nan downstream
-	if (LV_NEAR_TEST && !__any(fminf(d2.x, d2.y) < q0.w))
-		return;
-	const f32x2 inv_d = rsq2(d2);
-	const f32x2 len = d2 * inv_d;
-	const f32x2 inv_d2 = inv_d * inv_d;
-	// 1 - smoothstep(0.9, 1.0, max(len, 0.1) * inv_radius)
-	const f32x2 t = f32x2{sat(fmaf(fmaxf(0.1f, len.x), q1.w, -9.0f)), sat(fmaf(fmaxf(0.1f, len.y), q1.w, -9.0f))};
-	f32x2 atten = fma2(-(t * t), fma2(splat(-2.0f), t, splat(3.0f)), splat(1.0f));
-	if (KIND == 1)
-	{
-		const f32x4 q2 = slot[2], q3 = slot[3];
-		const f32x2 cone_angle = -dot2(Lx, Ly, Lz, splat(q2.x), splat(q2.y), splat(q2.z)) * inv_d;
-		const f32x2 cone = f32x2{sat(fmaf(cone_angle.x, q3.x, q3.y)), sat(fmaf(cone_angle.y, q3.x, q3.y))};
-		atten *= cone * cone;
-		if (!__any(fmaxf(atten.x, atten.y) > 0.0f))
-			return;
-	}
-	const f32x2 a2 = atten * f32x2{fminf(inv_d2.x, 1.0f / (0.1f * 0.1f)), fminf(inv_d2.y, 1.0f / (0.1f * 0.1f))};
-	const f32x2 NdL = dot2(s.Nx, s.Ny, s.Nz, Lx, Ly, Lz) * inv_d;
-	const f32x2 Hx = fma2(s.Vx, len, Lx), Hy = fma2(s.Vy, len, Ly), Hz = fma2(s.Vz, len, Lz);
-	const f32x2 hh = fma2(Hz, Hz, fma2(Hy, Hy, fma2(Hx, Hx, splat(1e-30f)))) * inv_d2;
-	brdf_accumulate2(s, NdL, hh, a2, q1.x, q1.y, q1.z, rx, ry, rz);
-}
+// A form of this walk written on float2 values (one v_pk_{fma,mul,add}_f32 for both pixels of the lane wherever the ISA has one: 47 packed
+// + 6 scalar fp32 instructions per point-light iteration instead of 27 + 44) was built and measured in round 4: 237 us against 182 us
+// alone.  A packed instruction whose operand is the result of the packed instruction before it waits (the assembler's s_nop between
+// them is the visible part), and a BRDF is a chain of such pairs; the third of the pairs the SLP vectoriser forms on its own sit where
+// they do not depend on each other.  Removed again (commit "lighting walk on float2 values" has it).
 
 // What a lane reads of its PX pixels, as loaded: the persistent kernel holds the NEXT tile's words in these registers while it
 // shades the current one (11 VGPRs for PX = 2, RGBA16F).
@@ -603,11 +524,6 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 			    __builtin_amdgcn_sqrtf(__builtin_bit_cast(float, wave_minmax_u32<true>(__builtin_bit_cast(uint32_t, off2)))) * 1.0001f + CULL_SLACK;
 
 			const int chunk_lo = int(win_lo >> 6u), chunk_hi = int(win_hi >> 6u);
-			// the walk's view of the lane's two pixels (LV_PACKED): component p of every float2 = pixel p
-			Surface2 s2;
-			f32x2 r2x = splat(0.0f), r2y = splat(0.0f), r2z = splat(0.0f);
-			if constexpr (PX == 2)
-				s2 = pair_surfaces(s[0], s[PX - 1]);
 			for (int chunk = chunk_lo; chunk <= chunk_hi; chunk++)
 			{
 				// ---- gather + cull: one light per lane ----
@@ -697,15 +613,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 
 				// ---- shade: PX pixels per lane, lights broadcast from LDS ----
 				const f32x4 *slot = slots;
-				if constexpr (PX == 2 && LV_PACKED && LV_LOOP && LV_SAT_NOH && LV_GFOLD && !LV_A2_SAT)
-				{
-					for (int i = 0; i < num_first; i++, slot += LIGHT_SLOT_BYTES / 16)
-						shade_positional2<0>(s2, slot, r2x, r2y, r2z);
-					const int num_spots = __builtin_popcountll(spots);
-					for (int i = 0; i < num_spots; i++, slot += LIGHT_SLOT_BYTES / 16)
-						shade_positional2<1>(s2, slot, r2x, r2y, r2z);
-				}
-				else if (LV_LOOP)
+				if (LV_LOOP)
 				{
 					for (int i = 0; i < num_first; i++, slot += LIGHT_SLOT_BYTES / 16)
 						shade_positional<PX, 0>(s, slot, false, result);
@@ -725,11 +633,6 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 					}
 				}
 				__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
-			}
-			if constexpr (PX == 2 && LV_PACKED && LV_LOOP && LV_SAT_NOH && LV_GFOLD && !LV_A2_SAT)
-			{
-				result[0] = f3(r2x.x, r2y.x, r2z.x);
-				result[PX - 1] = f3(r2x.y, r2y.y, r2z.y);
 			}
 		}
 		// second blend: the attachment store rounds once more, straight into the halves that are written out
