@@ -14,41 +14,10 @@
 // aa::axis_taps_exact() holds for both axes of the image (any size below ~16K), the *_generic ones above otherwise.
 constexpr int FAST_BW = 32, FAST_BH = 16; // 512 threads: 8 waves of two 32-pixel rows
 
-// Which tile a workgroup works on.  The chip is eight XCDs with an L2 each, and workgroups are dealt to them in turn (workgroup L of
-// the flattened grid runs on XCD L % 8).  In screen order horizontally adjacent tiles therefore sit on different XCDs, and the halo
-// columns a tile shares with its neighbours (one 128-byte line on either side of every tile row: as much as the row itself for
-// RGBA8, half as much for RGBA16F) are fetched from HBM once per XCD: measured, FETCH_SIZE of k_fxaa_fast and k_smaa_edges_fast
-// 2.9 x and of k_taa_fast 2.1 x their algorithmic reads (profiles/r04_aa_traffic_fetch_write_test_card.txt).  This order gives an
-// XCD AA_XCD_ROWS whole tile rows at a time (XCD x takes rows 8 G k + G x ... + G - 1 of every group of 8 G, left to right), so a
-// tile's left and right neighbours -- and, for G > 1, the rows above / below inside the run -- read the shared lines out of the
-// same L2; interleaving the runs keeps the eight XCDs on the same part of the image (content-dependent cost stays balanced).  The
-// rows beyond the last whole group keep screen order.
-// MEASURED (round 4, profiles/r04_aa_tile_order_ab.txt): nothing to gain -- TAA High 161.1 (screen order) / 158.6 (1 row per XCD) /
-// 160.2 (2) / 160.5 us (4), SMAA edges 24.6 / 25.5 / 26.1 / 26.1, FXAA on the test card 38.9 / 44.9 / 46.0 / 53.2 (whole rows of flat or
-// busy tiles land on one XCD).  What FETCH_SIZE counts as fetched twice comes out of the 256 MB memory-side cache, not out of HBM.
-// The default is therefore screen order (AA_XCD_ROWS = 0); the order and its tests stay for a chip where the second fetch is not free.
-#ifndef AA_XCD_ROWS
-#define AA_XCD_ROWS 0
-#endif
-__device__ __forceinline__ void xcd_tile_of_workgroup(unsigned &tile_x, unsigned &tile_y)
-{
-	tile_x = blockIdx.x;
-	tile_y = blockIdx.y;
-	if (AA_XCD_ROWS == 0)
-		return;
-	constexpr unsigned G = AA_XCD_ROWS > 0 ? AA_XCD_ROWS : 1;
-	const unsigned gx = gridDim.x, gy = gridDim.y;
-	const unsigned linear = blockIdx.y * gx + blockIdx.x;
-	const unsigned grouped_rows = gy - gy % (8u * G);
-	if (linear >= grouped_rows * gx)
-		return;
-	const unsigned xcd = linear & 7u, k = linear >> 3;  // k-th workgroup of this XCD
-	const unsigned run = G * gx;                         // tiles of one XCD in one group of 8 G rows
-	const unsigned group = k / run, r = k - group * run;
-	const unsigned row = r / gx;
-	tile_y = group * 8u * G + xcd * G + row;
-	tile_x = r - row * gx;
-}
+// Tile order.  Workgroups take tiles in screen order.  An order that keeps whole tile rows on one XCD (so that the halo columns of
+// horizontally adjacent tiles come out of one L2 instead of being fetched once per XCD: FETCH_SIZE is 2.1 - 2.9 x the algorithmic
+// reads for these kernels) was built and measured in round 4 (profiles/r04_aa_tile_order_ab.txt): no kernel got faster, FXAA on the
+// test card slower -- the second fetch is served by the memory-side cache.  Not kept.
 
 __device__ __forceinline__ uint32_t load_rgba8_clamped(const uint8_t *ptr, uint32_t pitch, int w, int h, int x, int y)
 {
@@ -81,9 +50,7 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_fxaa_fast(const uint8_t *i
 	__shared__ float4 s_dec[TW * TH];
 	__shared__ uint16_t s_list[THREADS];
 	__shared__ uint32_t s_wave_count[WAVES];
-	unsigned tile_x, tile_y;
-	xcd_tile_of_workgroup(tile_x, tile_y);
-	const int bx = int(tile_x) * FAST_BW, by = int(rows.first) + int(tile_y) * FAST_BH;
+	const int bx = blockIdx.x * FAST_BW, by = int(rows.first) + blockIdx.y * FAST_BH;
 	const int tid = threadIdx.y * FAST_BW + threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	// A workgroup whose tile (halo included) lies inside the image -- all but the frame of workgroups along the border -- needs no
 	// clamping: neighbours at constant offsets from one address, the tile staged two texels per 8-byte load.
@@ -173,9 +140,7 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_edges_fast(const uint
 {
 	constexpr int TW = EdgeLumaTile::W, TH = EdgeLumaTile::H;
 	__shared__ float s_luma[TW * TH];
-	unsigned tile_x, tile_y;
-	xcd_tile_of_workgroup(tile_x, tile_y);
-	const int bx = int(tile_x) * FAST_BW, by = int(rows.first) + int(tile_y) * FAST_BH;
+	const int bx = blockIdx.x * FAST_BW, by = int(rows.first) + blockIdx.y * FAST_BH;
 	for (int i = threadIdx.y * FAST_BW + threadIdx.x; i < TW * TH; i += FAST_BW * FAST_BH)
 	{
 		const int ty = i / TW, tx = i - ty * TW;
@@ -315,9 +280,7 @@ __global__ __launch_bounds__(FAST_BW *FAST_BH) void k_taa_fast(TaaImages im, aa:
 {
 	constexpr int TW = TaaTile::W, TH = TaaTile::H;
 	__shared__ float4 s_cur[TW * TH];
-	unsigned tile_x, tile_y;
-	xcd_tile_of_workgroup(tile_x, tile_y);
-	const int bx = int(tile_x) * FAST_BW, by = int(rows.first) + int(tile_y) * FAST_BH;
+	const int bx = blockIdx.x * FAST_BW, by = int(rows.first) + blockIdx.y * FAST_BH;
 	const int x = bx + threadIdx.x, y = by + threadIdx.y;
 	if (!HISTORY)
 	{

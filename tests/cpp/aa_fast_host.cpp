@@ -31,17 +31,6 @@ int aah_centre_taps_exact(int n, float inv)
 	return aa::axis_taps_exact(n, inv, ks, 5) ? 1 : 0;
 }
 
-// xcd_tile_of_workgroup over a gx x gy grid: out[by * gx + bx] = tile_y * gx + tile_x of workgroup (bx, by).
-static __global__ void k_tile_order(uint32_t *out)
-{
-	unsigned tx, ty;
-	xcd_tile_of_workgroup(tx, ty);
-	if (threadIdx.x == 0 && threadIdx.y == 0)
-		out[blockIdx.y * gridDim.x + blockIdx.x] = ty * gridDim.x + tx;
-}
-void aah_tile_order(int gx, int gy, uint32_t *out) { emu::launch(k_tile_order, dim3(gx, gy), dim3(1, 1), out); }
-int aah_xcd_rows(void) { return AA_XCD_ROWS; }
-
 void aah_fxaa(const uint8_t *in, int w, int h, uint8_t *out, int row_first, int row_count)
 {
 	const RowSpan rows = span_of(h, row_first, row_count);

@@ -71,47 +71,6 @@ def test_diagonal_search_walks_land_on_texels_at_every_size_in_use(host):
     assert not host.aah_diag_walk_exact(7680, np.float32(1.0) / np.float32(7680), 0)
 
 
-@pytest.mark.parametrize("gx,gy", [(1, 1), (3, 7), (5, 8), (3, 19), (120, 135), (7, 64), (2, 17)])
-def test_xcd_tile_order_is_a_permutation_that_keeps_tile_rows_on_one_xcd(host, gx, gy):
-    """aa_fast_kernels.hpp: xcd_tile_of_workgroup.  Workgroup L of the flattened grid runs on XCD L % 8; the order hands every
-    workgroup one tile, every tile to one workgroup, and -- inside the whole groups of 8 * AA_XCD_ROWS rows -- all tiles of a tile row to
-    the same XCD (so that horizontally adjacent tiles share their halo columns through one L2); the rows beyond keep screen order."""
-    host.aah_tile_order.argtypes = [C.c_int, C.c_int, C.c_void_p]
-    out = np.zeros(gx * gy, np.uint32)
-    host.aah_tile_order(gx, gy, p(out))
-    assert sorted(out.tolist()) == list(range(gx * gy))
-    g = max(host.aah_xcd_rows(), 1)
-    grouped = gy - gy % (8 * g)
-    xcd_of_row = {}
-    for linear, tile in enumerate(out.tolist()):
-        row = tile // gx
-        if row < grouped:
-            assert xcd_of_row.setdefault(row, linear % 8) == linear % 8, (row, linear)
-            assert linear % 8 == (row // g) % 8
-        else:
-            assert tile == linear
-    if host.aah_xcd_rows() == 0:
-        assert out.tolist() == list(range(gx * gy))
-
-
-@pytest.mark.parametrize("w,h", [(70, 300), (40, 150)])
-def test_kernels_in_xcd_tile_order_equal_the_oracle(host, w, h):
-    """Images tall enough for whole groups of eight tile rows (19 resp. 10 rows of workgroups): FXAA and the SMAA edge pass with the
-    remapped tiles, a row band included (the order is over the LAUNCHED rows)."""
-    src = noisy(w, h, 5)
-    out = np.zeros_like(src)
-    host.aah_fxaa(p(src), w, h, p(out), 0, 0)
-    ref = orc.fxaa(src, False)
-    np.testing.assert_array_equal(out, ref)
-    band = np.full_like(src, 0xAB)
-    host.aah_fxaa(p(src), w, h, p(band), 5, 140)
-    np.testing.assert_array_equal(band[5:145], ref[5:145])
-    assert (band[:5] == 0xAB).all() and (band[145:] == 0xAB).all()
-    edges = np.full((h, w, 2), 0xCD, np.uint8)
-    host.aah_smaa_edges(p(src), w, h, p(edges), C.c_float(PRESET_THRESHOLD[3]), 0, 0)
-    np.testing.assert_array_equal(edges, orc.smaa_edges(src, 3))
-
-
 # (134, 70) and (140, 64): workgroups whose tile lies inside the image (unclamped neighbours, two texels per load); (101, 60): the
 # same geometry with rows that are not 8-byte multiples, i.e. the clamped path everywhere
 @pytest.mark.parametrize("w,h,kind", SIZES + [(134, 70, "noise"), (140, 64, "pattern"), (101, 60, "noise")])
