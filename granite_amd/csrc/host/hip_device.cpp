@@ -268,8 +268,11 @@ Device::Device(int device_index) : index(device_index)
 		throw_hip(hipHostMalloc(reinterpret_cast<void **>(&frame.base), StagingBytes, hipHostMallocDefault), "hipHostMalloc");
 		for (auto &fence : frame.fence)
 		{
+			// ordering between this device's streams and completion seen by the host: no system-scope release is needed for either (the
+			// executor's run events are created the same way, render_graph.cpp; GRANITE_SYNC_EVENT_SYSTEM_FENCE=1 restores the fence)
 			hipEvent_t e;
-			throw_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+			throw_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming | (getenv("GRANITE_SYNC_EVENT_SYSTEM_FENCE") ? 0u : unsigned(hipEventDisableSystemFence))),
+			          "hipEventCreate");
 			fence = e;
 		}
 	}
@@ -327,9 +330,15 @@ void Device::next_frame_context()
 	// Mark the copies of the frame just recorded, then make sure the slot we are about to reuse has drained.
 	// One fence per stream: a graph built through the public API may consume staging memory on a stream nothing on the
 	// generic stream depends on in that frame, so the generic stream's progress alone does not bound the host's lead.
+	// A stream nobody was handed since its last fence has nothing new to fence: the slot's event keeps an older record, which is
+	// complete by the time the slot comes round again (or was recorded by the executor behind this frame's work: record_frame_fence).
 	auto &done = staging[staging_index];
 	for (int i = 0; i < int(CommandBuffer::Type::Count); i++)
-		throw_hip(hipEventRecord(static_cast<hipEvent_t>(done.fence[i]), static_cast<hipStream_t>(streams[i])), "hipEventRecord");
+		if (stream_dirty[i])
+		{
+			throw_hip(hipEventRecord(static_cast<hipEvent_t>(done.fence[i]), static_cast<hipStream_t>(streams[i])), "hipEventRecord");
+			stream_dirty[i] = false;
+		}
 	staging_index = (staging_index + 1) % StagingFrames;
 	auto &next = staging[staging_index];
 	for (auto &fence : next.fence)
@@ -345,6 +354,12 @@ void Device::next_frame_context()
 		}
 	}
 	next.offset = 0;
+}
+
+void Device::record_frame_fence(CommandBuffer::Type type)
+{
+	throw_hip(hipEventRecord(static_cast<hipEvent_t>(staging[staging_index].fence[int(type)]), static_cast<hipStream_t>(streams[int(type)])), "hipEventRecord");
+	stream_dirty[int(type)] = false;
 }
 
 void Device::wait_idle()

@@ -153,7 +153,12 @@ public:
 	gr_ctx *get_context() const { return ctx; }
 	int get_device_index() const { return index; }
 	void make_current() const; // hipSetDevice for the calling thread
-	gr_stream get_stream(CommandBuffer::Type type) const { return streams[int(type)]; }
+	// Handing out a stream counts as enqueueing on it: the frame fence of that stream (below) is due again.
+	gr_stream get_stream(CommandBuffer::Type type) const
+	{
+		stream_dirty[int(type)] = true;
+		return streams[int(type)];
+	}
 	// A fourth in-order stream for collectives that run beside the frame (the output all-gather of row-band tiling):
 	// created on first use, drained by wait_idle() like the executor's own.
 	gr_stream get_collective_stream();
@@ -168,6 +173,12 @@ public:
 
 	// Pinned-host staging for update_buffer: N frames in flight, each with its own bump allocator.
 	void *allocate_staging(size_t size);
+	// The fence of the frame being enqueued for one stream (a hipEvent_t owned by the device, re-recorded StagingFrames frames later).
+	// The executor records it itself behind the last run of passes it puts on that stream and publishes the run's accesses under it
+	// (record_frame_fence): one record per stream and frame instead of the run's event plus the fence.  next_frame_context() records
+	// the fences of the streams that were handed out since (get_stream) and of no others -- an idle stream costs nothing.
+	void *frame_fence(CommandBuffer::Type type) const { return staging[staging_index].fence[int(type)]; }
+	void record_frame_fence(CommandBuffer::Type type);
 	void next_frame_context();
 	void wait_idle();
 
@@ -198,6 +209,7 @@ private:
 	static constexpr unsigned StagingFrames = 4;
 	StagingFrame staging[StagingFrames];
 	unsigned staging_index = 0;
+	mutable bool stream_dirty[int(CommandBuffer::Type::Count)] = {};
 	size_t allocated_bytes = 0;
 	double blocked_seconds = 0.0;
 	unsigned image_row_granularity = 1;

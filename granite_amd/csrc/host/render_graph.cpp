@@ -1445,20 +1445,53 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 	int run_stream = -1;        // stream of the run being enqueued
 	unsigned run_slot = 0;      // index of the run within the frame (event ring row)
 	bool run_published = false; // a pass of the run published accesses under the run's event
+	// The last run a frame puts on a stream publishes under the DEVICE's fence of that stream and frame (the staging ring's, same depth as
+	// EventRing) and records it here: the fence next_frame_context() would otherwise record right behind the run's own event.
+	// Which run that is: a dry pass over the frame's passes (need_render_pass is asked once per pass and frame).
+	std::vector<char> pass_runs(pass_stack.size(), 0);
+	int last_run_of_stream[3] = {-1, -1, -1};
+	{
+		int stream_of_run = -1, run = 0;
+		for (size_t i = 0; i < pass_stack.size(); i++)
+		{
+			auto &pass = *passes[pass_stack[i]];
+			pass_runs[i] = !(pass.may_not_need_render_pass() && !pass.need_render_pass());
+			if (!pass_runs[i])
+				continue;
+			if (int(get_pass_stream(pass_stack[i])) != stream_of_run)
+			{
+				stream_of_run = int(get_pass_stream(pass_stack[i]));
+				run++;
+			}
+			last_run_of_stream[stream_of_run] = run;
+		}
+	}
+	const bool blit_follows = swapchain_attachment && swapchain_physical_index == RenderResource::Unused;
+	auto run_event = [&]() -> void * {
+		// (the final blit goes behind the generic stream's last run: that run keeps its own event, the fence is recorded behind the blit)
+		if (int(run_slot) == last_run_of_stream[run_stream] && !(blit_follows && stream_types[run_stream] == HIP::CommandBuffer::Type::Generic))
+			return device_.frame_fence(stream_types[run_stream]);
+		void *&event = pass_done_event[run_slot * EventRing + ring_slot];
+		ensure_event(event);
+		return event;
+	};
 	auto close_run = [&]() {
 		if (run_stream >= 0 && run_published)
 		{
-			void *event = pass_done_event[run_slot * EventRing + ring_slot];
-			if (hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(device_.get_stream(stream_types[run_stream]))) != hipSuccess)
+			void *event = run_event();
+			if (event == device_.frame_fence(stream_types[run_stream]))
+				device_.record_frame_fence(stream_types[run_stream]);
+			else if (hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(device_.get_stream(stream_types[run_stream]))) != hipSuccess)
 				throw std::runtime_error("hipEventRecord failed");
 		}
 		run_published = false;
 	};
 
-	for (unsigned pass_index : pass_stack)
+	for (size_t stack_index = 0; stack_index < pass_stack.size(); stack_index++)
 	{
+		const unsigned pass_index = pass_stack[stack_index];
 		auto &pass = *passes[pass_index];
-		if (pass.may_not_need_render_pass() && !pass.need_render_pass())
+		if (!pass_runs[stack_index])
 			continue;
 		pass.prepare_render_pass(composer);
 
@@ -1523,9 +1556,7 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		}
 		if (sync)
 		{
-			ensure_event(pass_done_event[run_slot * EventRing + ring_slot]);
-			release(int(type), pass_done_event[run_slot * EventRing + ring_slot], pass_reads_physical[pass_index],
-			        pass_writes_physical[pass_index]);
+			release(int(type), run_event(), pass_reads_physical[pass_index], pass_writes_physical[pass_index]);
 			run_published = true;
 		}
 	}

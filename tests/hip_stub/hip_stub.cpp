@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -31,6 +32,32 @@ struct Stream
 	int priority = 0;
 };
 thread_local hipError_t last_error = hipSuccess;
+
+// HIP_STUB_TRACE=1: one line per stream call on stderr -- "L s<stream> <kernel>", "R s<stream> e<event>", "W s<stream> e<event>" -- the order
+// in which a frame hands its work to the runtime (streams and events numbered in creation order).
+const bool tracing = getenv("HIP_STUB_TRACE") != nullptr;
+std::mutex trace_lock;
+std::map<const void *, int> stream_ids, event_ids;
+std::map<const void *, std::string> kernel_names;
+int id_of(std::map<const void *, int> &ids, const void *p)
+{
+	auto it = ids.find(p);
+	if (it == ids.end())
+		it = ids.emplace(p, int(ids.size())).first;
+	return it->second;
+}
+void trace(const char *what, const void *stream, const void *event, const void *kernel)
+{
+	if (!tracing)
+		return;
+	std::lock_guard<std::mutex> holder{trace_lock};
+	if (kernel)
+		fprintf(stderr, "%s s%d %s\n", what, id_of(stream_ids, stream), kernel_names.count(kernel) ? kernel_names[kernel].c_str() : "?");
+	else if (event)
+		fprintf(stderr, "%s s%d e%d\n", what, id_of(stream_ids, stream), id_of(event_ids, event));
+	else
+		fprintf(stderr, "%s s%d\n", what, id_of(stream_ids, stream));
+}
 } // namespace
 
 extern "C" {
@@ -104,9 +131,10 @@ hipError_t hipStreamSynchronize(hipStream_t) { counters.syncs++; return hipSucce
 hipError_t hipEventCreate(hipEvent_t *e) { *e = reinterpret_cast<hipEvent_t>(new Event); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<Event *>(e); return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t)
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
 {
 	counters.event_records++;
+	trace("R", s, e, nullptr);
 	auto *ev = reinterpret_cast<Event *>(e);
 	ev->at = std::chrono::steady_clock::now();
 	ev->records++;
@@ -125,16 +153,22 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 	*ms = std::chrono::duration<float, std::milli>(reinterpret_cast<Event *>(b)->at - reinterpret_cast<Event *>(a)->at).count();
 	return hipSuccess;
 }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t e, unsigned)
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
 {
 	counters.stream_waits++;
+	trace("W", s, e, nullptr);
 	if (reinterpret_cast<Event *>(e)->records.load() == 0)
 		counters.waits_before_record++;
 	return hipSuccess;
 }
 
 // ---- launches ----------------------------------------------------------------------------------------------------------------------
-hipError_t hipLaunchKernel(const void *, dim3, dim3, void **, size_t, hipStream_t) { counters.launches++; return hipSuccess; }
+hipError_t hipLaunchKernel(const void *f, dim3, dim3, void **, size_t, hipStream_t s)
+{
+	counters.launches++;
+	trace("L", s, nullptr, f);
+	return hipSuccess;
+}
 struct CallConfig { dim3 grid, block; size_t shared; hipStream_t stream; };
 static thread_local CallConfig pushed;
 hipError_t __hipPushCallConfiguration(dim3 grid, dim3 block, size_t shared, hipStream_t stream) { pushed = {grid, block, shared, stream}; return hipSuccess; }
@@ -144,7 +178,11 @@ hipError_t __hipPopCallConfiguration(dim3 *grid, dim3 *block, size_t *shared, hi
 	return hipSuccess;
 }
 void **__hipRegisterFatBinary(const void *) { static void *handle[4]; return handle; }
-void __hipRegisterFunction(void **, const void *, char *, const char *, unsigned, void *, void *, void *, void *, int *) {}
+void __hipRegisterFunction(void **, const void *host_function, char *, const char *device_name, unsigned, void *, void *, void *, void *, int *)
+{
+	if (tracing)
+		kernel_names[host_function] = device_name;
+}
 void __hipRegisterVar(void **, void *, char *, const char *, int, size_t, int, int) {}
 void __hipUnregisterFatBinary(void **) {}
 

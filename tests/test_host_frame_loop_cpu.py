@@ -54,7 +54,9 @@ def test_post_only_frame_asks_for_six_launches():
     tonemap.  The framework's own share of the frame is microseconds."""
     r = run(256, 256, 0)
     assert r["launches"] == 6 and r["memcpys"] == 0 and r["memsets"] == 0, r
-    assert r["event_records"] <= 5 and r["stream_waits"] == 0 and r["waits_before_record"] == 0, r
+    # two runs of passes on two streams, each run's event doubling as its stream's frame fence (Device::record_frame_fence); the idle
+    # third stream records nothing
+    assert r["event_records"] <= 2 and r["stream_waits"] == 0 and r["waits_before_record"] == 0, r
     assert r["us_per_frame"] < 25.0, r
 
 
@@ -63,7 +65,7 @@ def test_1080p_frame_asks_for_ten_launches_and_packs_its_lights_in_place():
     sorted and packed on the submitting thread (LightClusterer::prefetch: the helper threads only pay above ~1000 lights)."""
     r = run(1920, 1080, 256)
     assert r["launches"] == 10 and r["memcpys"] == 0 and r["memsets"] == 0, r
-    assert r["event_records"] <= 6 and r["waits_before_record"] == 0, r
+    assert r["event_records"] <= 3 and r["waits_before_record"] == 0, r  # one per stream: cluster build, lighting, post chain
     assert r["us_per_frame"] < 60.0, r
 
 

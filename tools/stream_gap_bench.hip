@@ -19,6 +19,28 @@ __global__ __launch_bounds__(256) void k_busy(float *p, int iters)
 	if (a + b + c + d == 12345.678f)
 		p[blockIdx.x] = a;
 }
+// the same kernel announcing its own completion: the last workgroup to finish stores `seq` to a flag the other queue's packet processor polls
+// (hipStreamWaitValue32) -- no packet behind the launch on its own queue
+__global__ __launch_bounds__(256) void k_busy_flag(float *p, int iters, unsigned *counter, unsigned *flag, unsigned seq)
+{
+	float a = p[threadIdx.x], b = a * 0.5f + 1.0f, c = a + 2.0f, d = b - c;
+	for (int i = 0; i < iters; i++)
+	{
+		a = fmaf(a, b, c); b = fmaf(b, c, d); c = fmaf(c, d, a); d = fmaf(d, a, b);
+	}
+	if (a + b + c + d == 12345.678f)
+		p[blockIdx.x] = a;
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		__threadfence_system();
+		if (atomicAdd(counter, 1u) == gridDim.x - 1u)
+		{
+			*counter = 0u;
+			__hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
 __global__ void k_tiny(float *p) { if (threadIdx.x == 9999) p[0] = 1.0f; }
 
 int main()
@@ -60,6 +82,56 @@ int main()
 	run("both, alternating between two streams", [&]() {
 		for (int i = 0; i < n; i++) { hipStream_t st = (i & 1) ? s2 : s; hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, other, buf); hipEventRecord(dep[i], other); hipStreamWaitEvent(st, dep[i], 0); launch(st); hipEventRecord(rec[i], st); }
 	});
+	unsigned *flags_mem = nullptr, *counter = nullptr;
+	int can = 0;
+	hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0);
+	printf("hipDeviceAttributeCanUseStreamWaitValue = %d\n", can);
+	unsigned *flags_mem2 = nullptr; // signal memory comes in 8-byte allocations
+	if (hipExtMallocWithFlags(reinterpret_cast<void **>(&flags_mem), 8, hipMallocSignalMemory) != hipSuccess ||
+	    hipExtMallocWithFlags(reinterpret_cast<void **>(&flags_mem2), 8, hipMallocSignalMemory) != hipSuccess)
+	{
+		printf("no signal memory: %s\n", hipGetErrorString(hipGetLastError()));
+		flags_mem = nullptr;
+	}
+	hipMalloc(&counter, 4); hipMemset(counter, 0, 4);
+	unsigned *f_dep = flags_mem, *f_rec = flags_mem2;
+	unsigned seq_base = 0;
+	auto zero = [&]() { hipDeviceSynchronize(); seq_base += 1000; };
+	if (can && flags_mem)
+	{
+		hipMemset(flags_mem, 0, 8); hipMemset(flags_mem2, 0, 8);
+		run("stream write / wait values instead of events: front + behind + consumer", [&]() {
+			zero();
+			for (int i = 0; i < n; i++) { const unsigned q = seq_base + i + 1;
+				hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, other, buf); hipStreamWriteValue32(other, f_dep, q, 0); hipStreamWaitValue32(s, f_dep, q, hipStreamWaitValueGte, 0xffffffffu);
+				launch(s); hipStreamWriteValue32(s, f_rec, q, 0);
+				hipStreamWaitValue32(other, f_rec, q, hipStreamWaitValueGte, 0xffffffffu); hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, other, buf); }
+		});
+		run("kernel stores its completion flag, consumer waits on the value; event wait in front", [&]() {
+			zero();
+			for (int i = 0; i < n; i++) { const unsigned q = seq_base + i + 1;
+				hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, other, buf); hipEventRecord(dep[i], other); hipStreamWaitEvent(s, dep[i], 0);
+				hipLaunchKernelGGL(k_busy_flag, dim3(blocks), dim3(256), 0, s, buf, iters_kernel, counter, f_rec, q);
+				hipStreamWaitValue32(other, f_rec, q, hipStreamWaitValueGte, 0xffffffffu); hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, other, buf); }
+		});
+		run("kernel stores its completion flag, consumer waits on the value; value wait in front", [&]() {
+			zero();
+			for (int i = 0; i < n; i++) { const unsigned q = seq_base + i + 1;
+				hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, other, buf); hipStreamWriteValue32(other, f_dep, q, 0); hipStreamWaitValue32(s, f_dep, q, hipStreamWaitValueGte, 0xffffffffu);
+				hipLaunchKernelGGL(k_busy_flag, dim3(blocks), dim3(256), 0, s, buf, iters_kernel, counter, f_rec, q);
+				hipStreamWaitValue32(other, f_rec, q, hipStreamWaitValueGte, 0xffffffffu); hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, other, buf); }
+		});
+		run("kernel stores its completion flag, consumer waits on the value; nothing in front", [&]() {
+			zero();
+			for (int i = 0; i < n; i++) { const unsigned q = seq_base + i + 1;
+				hipLaunchKernelGGL(k_busy_flag, dim3(blocks), dim3(256), 0, s, buf, iters_kernel, counter, f_rec, q);
+				hipStreamWaitValue32(other, f_rec, q, hipStreamWaitValueGte, 0xffffffffu); hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, other, buf); }
+		});
+		run("plain back-to-back, the flag-storing kernel (cost of the counter)", [&]() {
+			zero();
+			for (int i = 0; i < n; i++) hipLaunchKernelGGL(k_busy_flag, dim3(blocks), dim3(256), 0, s, buf, iters_kernel, counter, f_rec, seq_base + i + 1);
+		});
+	}
 	run("plain, alternating between two streams", [&]() { for (int i = 0; i < n; i++) launch((i & 1) ? s2 : s); });
 	return 0;
 }
