@@ -340,20 +340,32 @@ void Device::next_frame_context()
 			stream_dirty[i] = false;
 		}
 	staging_index = (staging_index + 1) % StagingFrames;
-	auto &next = staging[staging_index];
+	// How far the host may run ahead.  The slot about to be reused belongs to the frame StagingFrames - 1 = 3 frames back: waiting for that one
+	// is all the staging ring needs.  The host waits for the frame 2 back instead: while it enqueues frame N it then knows frame N - 3 to be
+	// complete on every stream -- the frame whose ring copies (cluster buffers, HDR-main: three deep) frame N overwrites -- so the
+	// write-after-read waits against it are found complete by hipEventQuery and never become barrier packets in front of the cluster
+	// build and of the lighting kernel.  Two frames of queued work are 0.1 - 0.4 ms, several times what the host needs to enqueue one.
+	// Measured (round 4, profiles/r04_host_lead_ab.txt): 4K / 4096 lights 0.2224 -> 0.2195 ms sustained, config 4 0.662 -> 0.634,
+	// config 2 0.0703 -> 0.0668, config 1 0.0543 -> 0.0471 ms.  GRANITE_HOST_LEAD_FRAMES=3 restores the longer lead.
+	static const unsigned lead = []() {
+		const char *e = getenv("GRANITE_HOST_LEAD_FRAMES");
+		const unsigned v = e ? unsigned(atoi(e)) : 2u;
+		return v >= 1u && v <= StagingFrames - 1u ? v : 2u;
+	}();
+	auto &next = staging[(staging_index + StagingFrames - 1u - lead) % StagingFrames];
 	for (auto &fence : next.fence)
 	{
 		if (hipEventQuery(static_cast<hipEvent_t>(fence)) != hipSuccess)
 		{
 			auto t0 = std::chrono::steady_clock::now();
 			{
-				GRANITE_SCOPED_TIMELINE_EVENT("wait-for-frame-in-flight"); // back-pressure: the host is three frames ahead
+				GRANITE_SCOPED_TIMELINE_EVENT("wait-for-frame-in-flight"); // back-pressure: the host is `lead` frames ahead
 				throw_hip(hipEventSynchronize(static_cast<hipEvent_t>(fence)), "hipEventSynchronize");
 			}
 			blocked_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 		}
 	}
-	next.offset = 0;
+	staging[staging_index].offset = 0;
 }
 
 void Device::record_frame_fence(CommandBuffer::Type type)
