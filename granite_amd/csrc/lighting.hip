@@ -100,10 +100,6 @@ struct KernelArgs
 	int row_first, row_end, block_row0; // render area rows [row_first, row_end); first block row = row_first / 8
 };
 
-#ifndef LV_MFMA_ACC
-#define LV_MFMA_ACC 0 // 1: the per-light colour accumulation (9 fma per pixel-light) runs on the matrix pipe as three v_mfma_f32_4x4x1_16b_f32
-#endif
-
 struct float3_ { float x, y, z; };
 __device__ __forceinline__ float3_ f3(float x, float y, float z) { return {x, y, z}; }
 __device__ __forceinline__ float3_ operator+(float3_ a, float3_ b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -153,7 +149,7 @@ struct Surface
 //   * NoL = clamp(., 0.001, 1) is a med3: both bounds matter.
 //   * max(Gv Gl, 0.001) never engages: roughness = 0.25 + 0.75 r >= 0.25 gives k = (roughness + 1)^2 / 8 >= 0.195, and
 //     Gv, Gl = mix(k, 1, NoX) >= k, so Gv Gl >= 0.038.
-__device__ __forceinline__ void brdf_weights(const Surface &s, float NdL, float hh, float scale, float &GD, float &cw, float &fw)
+__device__ __forceinline__ void brdf_accumulate(const Surface &s, float NdL, float hh, float scale, float3_ colour, float3_ &acc)
 {
 	const float NoL = med3(NdL, 0.001f, 1.0f);
 	const float inv_h = rsq(hh);
@@ -165,39 +161,15 @@ __device__ __forceinline__ void brdf_weights(const Surface &s, float NdL, float 
 
 	const float d = fmaf(NoH * NoH, s.m2m1, 1.0f);     // (NoH m2 - NoH) NoH + 1
 	const float g = fmaf(NoL, s.gA, s.gB);             // Gv Gl / c0, c0 = m^2 / (4 PI): G D = 1 / (d^2 g)
-	GD = LV_GFOLD ? rcp(d * d * g) : s.c0 * rcp(d * d * g);
+	const float GD = LV_GFOLD ? rcp(d * d * g) : s.c0 * rcp(d * d * g);
 
 	const float w = NoL * scale;
-	cw = fmaf(-f, w, w); // (1 - f) w
-	fw = f * GD * w;
-}
-
-__device__ __forceinline__ void brdf_accumulate(const Surface &s, float NdL, float hh, float scale, float3_ colour, float3_ &acc)
-{
-	float GD, cw, fw;
-	brdf_weights(s, NdL, hh, scale, GD, cw, fw);
+	const float cw = fmaf(-f, w, w); // (1 - f) w
+	const float fw = f * GD * w;
 	acc.x = fmaf(colour.x, fmaf(fmaf(GD, s.F0.x, s.D1.x), cw, fw), acc.x);
 	acc.y = fmaf(colour.y, fmaf(fmaf(GD, s.F0.y, s.D1.y), cw, fw), acc.y);
 	acc.z = fmaf(colour.z, fmaf(fmaf(GD, s.F0.z, s.D1.z), cw, fw), acc.z);
 }
-
-// The sums of the clustered quad for one pixel.  Plain form: the three channel sums.  Matrix-pipe form (LV_MFMA_ACC): with
-//   F GD + (1 - F) diffuse = F0 (GD cw) + D1 cw + fw      (per channel; cw = (1 - f) w, fw = f GD w, see brdf_accumulate)
-// the result is F0 * sum_l colour_l (GD cw)_l + D1 * sum_l colour_l cw_l + sum_l colour_l fw_l: F0 and D1 belong to the pixel, so the
-// walk only has to form three sums of (light colour) x (one scalar of this pixel and light) per channel.  v_mfma_f32_4x4x1_16b_f32
-// computes, for each of its 16 blocks of four lanes, D[i][j] += A[i] B[j] with A[i] read from lane 4 b + i, B[j] from lane 4 b + j
-// and D[i][j] kept in lane 4 b + j, register i: with A = the light's colour channel (lane & 3) (one ds_read_b32 of the staged
-// record per lane) and B = the lane's own scalar, register i of every lane accumulates channel i of ITS pixel -- nothing crosses lanes
-// that is not wave-uniform, the product and sum are the fused fp32 ones, and the nine fma of the plain form become one multiply and
-// three 8-cycle issues on the matrix pipe, which this kernel does not otherwise use.  Register 3 (lane & 3 == 3 reads 10 / r) is unused.
-struct ClusterSums
-{
-#if LV_MFMA_ACC
-	f32x4 x, y, z;
-#else
-	float3_ rgb;
-#endif
-};
 
 // clusterer_bindless_buffers.h:17-27 for one light index instead of one 32-bit word.
 __device__ __forceinline__ bool index_in_range(uint32_t index, uint32_t range_x, uint32_t range_y)
@@ -230,16 +202,9 @@ __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t v)
 // streams while this kernel runs (see gr_lighting).
 // KIND: 0 = point light, 1 = spot light, 2 = decided at run time by `is_spot` (one list holding both).
 template <int PX, int KIND>
-__device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f32x4 *slot, bool is_spot, ClusterSums (&result)[PX], int lane)
+__device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f32x4 *slot, bool is_spot, float3_ (&result)[PX])
 {
-	const f32x4 q0 = slot[0];
-#if LV_MFMA_ACC
-	const float *q1f = reinterpret_cast<const float *>(slot + 1);
-	const float colour_of_lane = q1f[lane & 3]; // A operand: channel (lane & 3) of the light's colour
-	struct { float w; } q1 = {q1f[3]};
-#else
-	const f32x4 q1 = slot[1];
-#endif
+	const f32x4 q0 = slot[0], q1 = slot[1];
 	float3_ Lf[PX];
 	float d2[PX];
 	bool near_any = false;
@@ -293,15 +258,7 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 		// fp32 level when L is nearly -V, where 2 + 2 dot(V, L) would cancel.
 		const float3_ Hs = f3(fmaf(s[p].V.x, len[p], Lf[p].x), fmaf(s[p].V.y, len[p], Lf[p].y), fmaf(s[p].V.z, len[p], Lf[p].z));
 		const float hh = fmaf(Hs.z, Hs.z, fmaf(Hs.y, Hs.y, fmaf(Hs.x, Hs.x, 1e-30f))) * inv_d2[p];
-#if LV_MFMA_ACC
-		float GD, cw, fw;
-		brdf_weights(s[p], NdL, hh, a2, GD, cw, fw);
-		result[p].x = __builtin_amdgcn_mfma_f32_4x4x1f32(colour_of_lane, GD * cw, result[p].x, 0, 0, 0);
-		result[p].y = __builtin_amdgcn_mfma_f32_4x4x1f32(colour_of_lane, cw, result[p].y, 0, 0, 0);
-		result[p].z = __builtin_amdgcn_mfma_f32_4x4x1f32(colour_of_lane, fw, result[p].z, 0, 0, 0);
-#else
-		brdf_accumulate(s[p], NdL, hh, a2, f3(q1.x, q1.y, q1.z), result[p].rgb);
-#endif
+		brdf_accumulate(s[p], NdL, hh, a2, f3(q1.x, q1.y, q1.z), result[p]);
 	}
 }
 
@@ -310,6 +267,15 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 // alone.  A packed instruction whose operand is the result of the packed instruction before it waits (the assembler's s_nop between
 // them is the visible part), and a BRDF is a chain of such pairs; the third of the pairs the SLP vectoriser forms on its own sit where
 // they do not depend on each other.  Removed again (commit "lighting walk on float2 values" has it).
+
+// The colour accumulation on the matrix pipe was built and measured in round 4 as well.  With F GD + (1 - F) diffuse = F0 (GD cw) + D1 cw + fw
+// the walk only has to form three sums of (light colour) x (one scalar of this pixel and light) per channel, and
+// v_mfma_f32_4x4x1_16b_f32 (D[i][j] += A[i] B[j] per block of four lanes, A[i] from lane 4 b + i, D[i][j] in lane 4 b + j register i) does
+// that without anything crossing lanes: A = colour channel (lane & 3) of the staged light, B = the lane's own scalar.  Nine fma per
+// pixel-light become one multiply and three matrix instructions; results within the same 2 ulp (58 GPU tests green).  196 us against
+// 182 us alone, 0.2545 against 0.2357 ms per frame: a 4x4x1 costs the wave ~14 cycles of issue, more than the fma it replaces, and the
+// pipe that runs beside the VALU for OTHER waves does not do so for the wave that issued it.  Removed (commit "lighting colour
+// accumulation on the matrix pipe" has it; profiles/r04_lighting_variants_ab.txt).
 
 // What a lane reads of its PX pixels, as loaded: the persistent kernel holds the NEXT tile's words in these registers while it
 // shades the current one (11 VGPRs for PX = 2, RGBA16F).
@@ -510,16 +476,12 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 	float3_ out_f[PX]; // B10: the sums themselves, rounded by the packed store below
 	if ((a.flags & GR_LIGHTING_CLUSTERED_BIT) && a.cl_num_lights > 0)
 	{
-		ClusterSums result[PX];
+		float3_ result[PX];
 		uint32_t lane_lo = 0xffffffffu, lane_hi = 0u;
 #pragma unroll
 		for (int p = 0; p < PX; p++)
 		{
-#if LV_MFMA_ACC
-			result[p].x = result[p].y = result[p].z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#else
-			result[p].rgb = f3(0.0f, 0.0f, 0.0f);
-#endif
+			result[p] = f3(0.0f, 0.0f, 0.0f);
 			// Slice lookup (clusterer_bindless.h:43-47).
 			const float z = dot(s[p].pos - f3(a.cl_camera_base[0], a.cl_camera_base[1], a.cl_camera_base[2]),
 			                    f3(a.cl_camera_front[0], a.cl_camera_front[1], a.cl_camera_front[2]));
@@ -663,10 +625,10 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 				if (LV_LOOP)
 				{
 					for (int i = 0; i < num_first; i++, slot += LIGHT_SLOT_BYTES / 16)
-						shade_positional<PX, 0>(s, slot, false, result, lane);
+						shade_positional<PX, 0>(s, slot, false, result);
 					const int num_spots = __builtin_popcountll(spots);
 					for (int i = 0; i < num_spots; i++, slot += LIGHT_SLOT_BYTES / 16)
-						shade_positional<PX, 1>(s, slot, true, result, lane);
+						shade_positional<PX, 1>(s, slot, true, result);
 				}
 				else
 				{
@@ -675,7 +637,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 					{
 						const int src_lane = __builtin_ctzll(todo);
 						todo &= todo - 1ull;
-						shade_positional<PX, 2>(s, slot, ((spots >> src_lane) & 1ull) != 0ull, result, lane);
+						shade_positional<PX, 2>(s, slot, ((spots >> src_lane) & 1ull) != 0ull, result);
 						slot += LIGHT_SLOT_BYTES / 16;
 					}
 				}
@@ -686,14 +648,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 #pragma unroll
 		for (int p = 0; p < PX; p++)
 		{
-#if LV_MFMA_ACC
-			const float3_ lit = f3(fmaf(s[p].F0.x, result[p].x.x, fmaf(s[p].D1.x, result[p].y.x, result[p].z.x)),
-			                       fmaf(s[p].F0.y, result[p].x.y, fmaf(s[p].D1.y, result[p].y.y, result[p].z.y)),
-			                       fmaf(s[p].F0.z, result[p].x.z, fmaf(s[p].D1.z, result[p].y.z, result[p].z.z)));
-#else
-			const float3_ lit = result[p].rgb;
-#endif
-			out_f[p] = f3(accum[p].x + lit.x, accum[p].y + lit.y, accum[p].z + lit.z);
+			out_f[p] = f3(accum[p].x + result[p].x, accum[p].y + result[p].y, accum[p].z + result[p].z);
 			out_h[p].x = _Float16(out_f[p].x);
 			out_h[p].y = _Float16(out_f[p].y);
 			out_h[p].z = _Float16(out_f[p].z);
