@@ -258,6 +258,8 @@ def load_library() -> C.CDLL:
         "gr_bloom_down_tail": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample)]),
         "gr_bloom_down_mid_supported": (C.c_int, [P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample)]),
         "gr_bloom_down_mid": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample), P(Rows)]),
+        "gr_bloom_down_head_supported": (C.c_int, [P(Image), P(Image), P(Image), P(Image), P(PushBloomThreshold), P(PushBloomDownsample), P(PushBloomDownsample)]),
+        "gr_bloom_down_head": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), vp, P(PushBloomThreshold), P(PushBloomDownsample), P(PushBloomDownsample)]),
         "gr_bloom_up_tail": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushBloomUpsample), P(PushBloomUpsample), P(PushLuminance)]),
         "gr_tonemap": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushTonemap)]),
         "gr_bloom_threshold_rows": (C.c_int, [vp, vp, P(Image), P(Image), vp, P(PushBloomThreshold), P(Rows)]),
@@ -478,6 +480,17 @@ class Context:
         if not self.lib.gr_bloom_down_mid_supported(threshold.desc, d0.desc, d1.desc, p_d0, p_d1):
             return False
         self.check(self.lib.gr_bloom_down_mid(self.handle, stream, threshold.desc, d0.desc, d1.desc, p_d0, p_d1, self._rows(rows)))
+        return True
+
+    def bloom_down_head(self, hdr: DeviceImage, threshold: DeviceImage, d0: DeviceImage, d1: DeviceImage, lum_ptr=None, stream=None) -> bool:
+        """threshold, downsample-0 and downsample-1 as one launch; False (nothing launched) when the frame does not qualify."""
+        def down(out, src):
+            return PushBloomDownsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height), (1.0 / src.width, 1.0 / src.height), 0.0)
+        p_t = PushBloomThreshold((threshold.width, threshold.height), (1.0 / threshold.width, 1.0 / threshold.height))
+        p_d0, p_d1 = down(d0, threshold), down(d1, d0)
+        if not self.lib.gr_bloom_down_head_supported(hdr.desc, threshold.desc, d0.desc, d1.desc, p_t, p_d0, p_d1):
+            return False
+        self.check(self.lib.gr_bloom_down_head(self.handle, stream, hdr.desc, threshold.desc, d0.desc, d1.desc, lum_ptr, p_t, p_d0, p_d1))
         return True
 
     def luminance(self, d3: DeviceImage, lum_ptr, lerp: float, min_loglum: float = -3.0, max_loglum: float = 2.0, stream=None):

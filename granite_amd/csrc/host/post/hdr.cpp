@@ -180,6 +180,31 @@ bool record_pyramid_middle(HIP::CommandBuffer &cmd, const FrameParameters &frame
 	return true;
 }
 
+// The threshold dispatch and the dispatches of downsample-0 and downsample-1 (hdr.cpp:354-362) as ONE fused launch of the C ABI when the
+// frame qualifies (gr_bloom_down_head_supported: every level exactly half of its input, up to 1440p); returns false otherwise and
+// records nothing.  Whole images only: row bands keep the band-limited launches.
+bool record_pyramid_head(HIP::CommandBuffer &cmd, const FrameParameters &frame, RenderGraph &graph, const RenderTextureResource &hdr_res,
+                         const RenderTextureResource &t_res, const RenderTextureResource &d0_res, const RenderTextureResource &d1_res,
+                         const RenderBufferResource *ubo)
+{
+	auto &hdr = graph.get_physical_texture_resource(hdr_res);
+	auto &t = graph.get_physical_texture_resource(t_res);
+	auto &d0 = graph.get_physical_texture_resource(d0_res);
+	auto &d1 = graph.get_physical_texture_resource(d1_res);
+	gr_push_bloom_threshold push_t = {};
+	push_t.threads[0] = t.get_width();
+	push_t.threads[1] = t.get_height();
+	push_t.inv_output_size[0] = 1.0f / float(push_t.threads[0]);
+	push_t.inv_output_size[1] = 1.0f / float(push_t.threads[1]);
+	const gr_push_bloom_downsample push_d0 = downsample_push(frame, d0, t), push_d1 = downsample_push(frame, d1, d0);
+	if (!gr_bloom_down_head_supported(&hdr.get_view(), &t.get_view(), &d0.get_view(), &d1.get_view(), &push_t, &push_d0, &push_d1))
+		return false;
+	cmd.check(gr_bloom_down_head(cmd.get_context(), cmd.get_stream(), &hdr.get_view(), &t.get_view(), &d0.get_view(), &d1.get_view(),
+	                             luminance_ptr(graph, ubo), &push_t, &push_d0, &push_d1),
+	          "bloom_down_head");
+	return true;
+}
+
 // tonemap_build_render_pass (hdr.cpp:283-306)
 void record_tonemap(RenderPass &pass, HIP::CommandBuffer &cmd, const RenderTextureResource &hdr_res, const RenderTextureResource &bloom_res,
                     const RenderBufferResource *ubo, const HDRDynamicExposureInterface *iface, const StripPlan *strip = nullptr)
@@ -256,13 +281,16 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 				cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
 				            VK_ACCESS_2_SHADER_SAMPLED_READ_BIT);
 			};
-			record_threshold(cmd, graph, t, hdr, ubo, strip ? &strip->threshold : nullptr);
-			compute_to_compute();
-			if (!record_pyramid_middle(cmd, frame, graph, t, d0, d1, strip ? &strip->d1 : nullptr))
+			if (strip || !record_pyramid_head(cmd, frame, graph, hdr, t, d0, d1, ubo))
 			{
-				record_downsample(cmd, frame, graph, d0, t, nullptr, strip ? &strip->d0 : nullptr);
+				record_threshold(cmd, graph, t, hdr, ubo, strip ? &strip->threshold : nullptr);
 				compute_to_compute();
-				record_downsample(cmd, frame, graph, d1, d0, nullptr, strip ? &strip->d1 : nullptr);
+				if (!record_pyramid_middle(cmd, frame, graph, t, d0, d1, strip ? &strip->d1 : nullptr))
+				{
+					record_downsample(cmd, frame, graph, d0, t, nullptr, strip ? &strip->d0 : nullptr);
+					compute_to_compute();
+					record_downsample(cmd, frame, graph, d1, d0, nullptr, strip ? &strip->d1 : nullptr);
+				}
 			}
 			if (strip && strip->exchange)
 				strip->exchange(cmd, graph.get_physical_texture_resource(d1), strip->d1_chunk_rows, "downsample-1");
@@ -298,7 +326,7 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 		key.add(ubo ? graph.get_physical_buffer_resource(*ubo).get_device_pointer() : nullptr);
 		key.add(frame.frame_time);
 		cmd.replayable("bloom-compute", key,
-		               {"bloom_threshold", "bloom_downsample", "bloom_down_mid", "bloom_down_tail", "bloom_up_tail", "luminance", "bloom_upsample"}, record);
+		               {"bloom_threshold", "bloom_downsample", "bloom_down_head", "bloom_down_mid", "bloom_down_tail", "bloom_up_tail", "luminance", "bloom_upsample"}, record);
 	});
 
 	{

@@ -69,6 +69,32 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold(
 // 1e-4 at 4K), which the log-luminance channel -- log2 of a value near 1 over much of a frame -- is sensitive to, so they
 // are computed exactly as the sampler does (uncontracted).  One lane makes two adjacent outputs from 2 x 32 contiguous bytes
 // per row and stores 16 bytes; conversions ride on v_fma_mix_f32.
+// fractional sampler coordinate of output p: ((p + 0.5) * inv_out) * size - 0.5, minus its floor (= 2 p)
+__device__ __forceinline__ float threshold_fraction(uint32_t p, float inv_out, int size)
+{
+	const float f = __fsub_rn(__fmul_rn(__fmul_rn(float(p) + 0.5f, inv_out), float(size)), 0.5f);
+	return f - floorf(f);
+}
+// One threshold texel from the 2 x 2 HDR texels under it (`top`, `bottom`: left and right texel of the row as RGBA16F dwords), the
+// right / bottom weights of the sampler and the luminance to subtract.  Shared by the stand-alone kernel and the fused head of the
+// pyramid (k_bloom_down_head): the bytes are the same.
+__device__ __forceinline__ f16x4 threshold_of_quad(u32x4 top, u32x4 bottom, float wr, float wb, float threshold)
+{
+	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	const float wl = 1.0f - wr, wt = 1.0f - wb;
+	// sampler order: (t00 (1-a) + t10 a) (1-b) + (t01 (1-a) + t11 a) b
+	const float4 row_t = fma_mix_texel(top.z, top.w, wr, fma_mix_texel(top.x, top.y, wl, zero));
+	const float4 row_b = fma_mix_texel(bottom.z, bottom.w, wr, fma_mix_texel(bottom.x, bottom.y, wl, zero));
+	const float4 c = fma4(row_b, wb, row_t * wt);
+	float luminance = fmaxf(fmaxf(c.x, c.y), c.z) + 0.0001f;
+	const float loglum = __log2f(luminance);
+	float inv = __builtin_amdgcn_rcpf(luminance);
+	inv = inv * fmaf(-luminance, inv, 2.0f); // one Newton step: the quotient to within an fp32 ulp
+	luminance = __fsub_rn(luminance, threshold); // (and the caller's 8 x average as __fmul_rn: no contraction into one fma, wherever this is inlined)
+	const float gain = inv * luminance;
+	return pack_rgba16f(make_float4(fmaxf(c.x * gain, 0.0f), fmaxf(c.y * gain, 0.0f), fmaxf(c.z * gain, 0.0f), loglum));
+}
+
 template <bool DYNAMIC_EXPOSURE>
 __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold_2to1(DevImage hdr, DevImageRW out,
                                                                                      const gr_luminance_data *lum, uint32_t pairs_x,
@@ -95,32 +121,12 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) void k_bloom_threshold_
 		a0 = *reinterpret_cast<const u32x4 *>(row0), a1 = *reinterpret_cast<const u32x4 *>(row0 + 16);
 		b0 = *reinterpret_cast<const u32x4 *>(row0 + hdr.pitch), b1 = *reinterpret_cast<const u32x4 *>(row0 + hdr.pitch + 16);
 	}
-	// fractional sampler coordinate: ((p + 0.5) * inv_out) * size - 0.5, minus its floor (= 2 p)
-	auto fraction = [](uint32_t p, float inv_out, int size) {
-		const float f = __fsub_rn(__fmul_rn(__fmul_rn(float(p) + 0.5f, inv_out), float(size)), 0.5f);
-		return f - floorf(f);
-	};
-	const float wb = fraction(y, inv_out_h, hdr.h), wt = 1.0f - wb;
-	const float threshold = DYNAMIC_EXPOSURE ? 8.0f * lum->average_linear_luminance : 8.0f;
-	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	const float wb = threshold_fraction(y, inv_out_h, hdr.h);
+	const float threshold = DYNAMIC_EXPOSURE ? __fmul_rn(8.0f, lum->average_linear_luminance) : 8.0f;
 	f16x4 result[2];
 #pragma unroll
 	for (int i = 0; i < 2; i++)
-	{
-		const u32x4 top = i ? a1 : a0, bottom = i ? b1 : b0;
-		const float wr = fraction(2u * xp + uint32_t(i), inv_out_w, hdr.w), wl = 1.0f - wr;
-		// sampler order: (t00 (1-a) + t10 a) (1-b) + (t01 (1-a) + t11 a) b
-		const float4 row_t = fma_mix_texel(top.z, top.w, wr, fma_mix_texel(top.x, top.y, wl, zero));
-		const float4 row_b = fma_mix_texel(bottom.z, bottom.w, wr, fma_mix_texel(bottom.x, bottom.y, wl, zero));
-		const float4 c = fma4(row_b, wb, row_t * wt);
-		float luminance = fmaxf(fmaxf(c.x, c.y), c.z) + 0.0001f;
-		const float loglum = __log2f(luminance);
-		float inv = __builtin_amdgcn_rcpf(luminance);
-		inv = inv * fmaf(-luminance, inv, 2.0f); // one Newton step: the quotient to within an fp32 ulp
-		luminance -= threshold;
-		const float gain = inv * luminance;
-		result[i] = pack_rgba16f(make_float4(fmaxf(c.x * gain, 0.0f), fmaxf(c.y * gain, 0.0f), fmaxf(c.z * gain, 0.0f), loglum));
-	}
+		result[i] = threshold_of_quad(i ? a1 : a0, i ? b1 : b0, threshold_fraction(2u * xp + uint32_t(i), inv_out_w, hdr.w), wb, threshold);
 	const u32x2 lo = __builtin_bit_cast(u32x2, result[0]), hi = __builtin_bit_cast(u32x2, result[1]);
 	*reinterpret_cast<u32x4 *>(out.ptr + size_t(y) * out.pitch + size_t(xp) * 16u) = u32x4{lo.x, lo.y, hi.x, hi.y};
 }
@@ -397,6 +403,25 @@ __device__ __forceinline__ void tap_span(int lo, int hi, int out_n, int in_n, fl
 	last = clampi(int(floorf((float(hi) + 0.5f) * scale - 0.5f + reach)) + 2, 0, in_n - 1);
 }
 
+// the 2:1 stencil of downsample_2to1_value over a patch in LDS (same weights, same order; the patch covers every clamped index)
+__device__ __forceinline__ float4 downsample_2to1_from_patch(const TailPatch &patch, int x, int y, int in_w, int in_h)
+{
+	const float wt[6] = {0.0625f, 0.1875f, 0.25f, 0.25f, 0.1875f, 0.0625f};
+	float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll 1
+	for (int r = 0; r < 6; r++)
+	{
+		const int iy = clampi(2 * y - 2 + r, 0, in_h - 1);
+		float4 h = mul4(patch.fetch(clampi(2 * x - 2, 0, in_w - 1), iy), wt[0]);
+#pragma unroll
+		for (int c = 1; c < 6; c++)
+			h = fma4(patch.fetch(clampi(2 * x - 2 + c, 0, in_w - 1), iy), wt[c], h);
+		const float wr = r == 0 || r == 5 ? 0.0625f : (r == 1 || r == 4 ? 0.1875f : 0.25f);
+		acc = fma4(h, wr, acc);
+	}
+	return acc;
+}
+
 // Two consecutive downsample levels in one launch: `lower` (level B, rows [y_first, y_end)) from `upper` (level A), which the
 // workgroup first makes from `src` -- and stores -- under its tile's taps.  Instantiated for downsample-0 / downsample-1 (from the
 // threshold level; row bands restrict level B) and for downsample-2 / downsample-3 (+ the temporal feedback).
@@ -441,23 +466,7 @@ __global__ __launch_bounds__(256) void k_bloom_down_pair(DevImage src, DevImageR
 	const TentTaps tb = tent_taps(x, y, push_b.inv_output_size, push_b.inv_input_size, 1.75f);
 	float4 value;
 	if (B_EXACT)
-	{
-		// the 2:1 stencil of downsample_2to1_value over the patch (same weights, same order; the patch covers every clamped index)
-		const float wt[6] = {0.0625f, 0.1875f, 0.25f, 0.25f, 0.1875f, 0.0625f};
-		float4 acc = make_float4(0, 0, 0, 0);
-#pragma unroll 1
-		for (int r = 0; r < 6; r++)
-		{
-			const int iy = clampi(2 * y - 2 + r, 0, upper_h - 1);
-			float4 h = mul4(patch.fetch(clampi(2 * x - 2, 0, upper_w - 1), iy), wt[0]);
-#pragma unroll
-			for (int c = 1; c < 6; c++)
-				h = fma4(patch.fetch(clampi(2 * x - 2 + c, 0, upper_w - 1), iy), wt[c], h);
-			const float wr = r == 0 || r == 5 ? 0.0625f : (r == 1 || r == 4 ? 0.1875f : 0.25f);
-			acc = fma4(h, wr, acc);
-		}
-		value = acc;
-	}
+		value = downsample_2to1_from_patch(patch, x, y, upper_w, upper_h);
 	else
 	{
 		const auto sample = [&](float su, float sv) {
@@ -468,6 +477,69 @@ __global__ __launch_bounds__(256) void k_bloom_down_pair(DevImage src, DevImageR
 	if (FEEDBACK)
 		value = apply_feedback(value, history, tb.u, tb.v, push_b.lerp);
 	store_rgba16f(lower, x, y, value);
+}
+
+// The head of the pyramid in one launch: threshold -> downsample-0 -> downsample-1, for frames whose chain of launches, not their
+// arithmetic, sets the pace (up to 1440p: gr_bloom_down_head_supported) and whose three levels are exactly half of their inputs.  A
+// workgroup makes an 8 x 8 tile of downsample-1; under it the <= 20 x 20 patch of downsample-0, under that the <= 44 x 44 patch of
+// the threshold level, each texel by the function the separate kernels use (threshold_of_quad, the 2:1 stencil over a patch), rounded
+// to fp16 between the levels as the stores round them, and stored: neighbouring workgroups write identical values into the overlap.
+// 1.9 x the threshold level and 1.56 x downsample-0 are computed; one launch and one fill / drain of the machine less than
+// gr_bloom_threshold + gr_bloom_down_mid.
+constexpr int HEAD_D0_PATCH = 2 * TAIL_TILE + 4;       // 20
+constexpr int HEAD_T_PATCH = 2 * HEAD_D0_PATCH + 4;    // 44
+template <bool DYNAMIC_EXPOSURE>
+__global__ __launch_bounds__(256) void k_bloom_down_head(DevImage hdr, DevImageRW thr, DevImageRW d0, DevImageRW d1, const gr_luminance_data *lum,
+                                                         float inv_thr_w, float inv_thr_h, bool hdr_b10)
+{
+	post_wave_priority();
+	__shared__ f16x4 s_thr[HEAD_T_PATCH * HEAD_T_PATCH];
+	__shared__ f16x4 s_d0[HEAD_D0_PATCH * HEAD_D0_PATCH];
+	const int tile_x0 = blockIdx.x * TAIL_TILE, tile_y0 = blockIdx.y * TAIL_TILE;
+	const int tile_x1 = min(tile_x0 + TAIL_TILE, d1.w) - 1, tile_y1 = min(tile_y0 + TAIL_TILE, d1.h) - 1;
+	const int px0 = clampi(2 * tile_x0 - 2, 0, d0.w - 1), px1 = clampi(2 * tile_x1 + 3, 0, d0.w - 1);
+	const int py0 = clampi(2 * tile_y0 - 2, 0, d0.h - 1), py1 = clampi(2 * tile_y1 + 3, 0, d0.h - 1);
+	const int qx0 = clampi(2 * px0 - 2, 0, thr.w - 1), qx1 = clampi(2 * px1 + 3, 0, thr.w - 1);
+	const int qy0 = clampi(2 * py0 - 2, 0, thr.h - 1), qy1 = clampi(2 * py1 + 3, 0, thr.h - 1);
+	const int pw = px1 - px0 + 1, ph = py1 - py0 + 1, qw = qx1 - qx0 + 1, qh = qy1 - qy0 + 1;
+	const float threshold = DYNAMIC_EXPOSURE ? __fmul_rn(8.0f, lum->average_linear_luminance) : 8.0f;
+	for (int i = threadIdx.x; i < qw * qh; i += 256)
+	{
+		const int ly = i / qw, lx = i - ly * qw;
+		const uint32_t x = uint32_t(qx0 + lx), y = uint32_t(qy0 + ly);
+		u32x4 top, bottom; // the HDR texels (2 x, 2 y) .. (2 x + 1, 2 y + 1) as RGBA16F dwords
+		if (hdr_b10)
+		{
+			const uint8_t *row0 = hdr.ptr + size_t(2u * y) * hdr.pitch + size_t(x) * 8u;
+			const u32x2 pa = *reinterpret_cast<const u32x2 *>(row0), pb = *reinterpret_cast<const u32x2 *>(row0 + hdr.pitch);
+			top = expand_b10g11r11_pair(pa.x, pa.y), bottom = expand_b10g11r11_pair(pb.x, pb.y);
+		}
+		else
+		{
+			const uint8_t *row0 = hdr.ptr + size_t(2u * y) * hdr.pitch + size_t(x) * 16u;
+			top = *reinterpret_cast<const u32x4 *>(row0), bottom = *reinterpret_cast<const u32x4 *>(row0 + hdr.pitch);
+		}
+		const f16x4 texel = threshold_of_quad(top, bottom, threshold_fraction(x, inv_thr_w, hdr.w), threshold_fraction(y, inv_thr_h, hdr.h), threshold);
+		s_thr[i] = texel;
+		*reinterpret_cast<f16x4 *>(thr.ptr + size_t(y) * thr.pitch + size_t(x) * 8u) = texel;
+	}
+	__syncthreads();
+	const TailPatch thr_patch{s_thr, qx0, qy0, qw, qh};
+	for (int i = threadIdx.x; i < pw * ph; i += 256)
+	{
+		const int ly = i / pw, lx = i - ly * pw;
+		const f16x4 texel = pack_rgba16f(downsample_2to1_from_patch(thr_patch, px0 + lx, py0 + ly, thr.w, thr.h));
+		s_d0[i] = texel;
+		*reinterpret_cast<f16x4 *>(d0.ptr + size_t(py0 + ly) * d0.pitch + size_t(px0 + lx) * 8u) = texel;
+	}
+	__syncthreads();
+	if (threadIdx.x >= TAIL_TILE * TAIL_TILE)
+		return;
+	const int x = tile_x0 + int(threadIdx.x & (TAIL_TILE - 1)), y = tile_y0 + int(threadIdx.x / TAIL_TILE);
+	if (x >= d1.w || y > tile_y1)
+		return;
+	const TailPatch d0_patch{s_d0, px0, py0, pw, ph};
+	store_rgba16f(d1, x, y, downsample_2to1_from_patch(d0_patch, x, y, d0.w, d0.h));
 }
 
 // A 256-thread form (16 x 16 tiles, one wave per SIMD: finds room on a CU beside the resident lighting waves, where a 1024-thread
@@ -932,6 +1004,50 @@ int gr_bloom_down_mid(gr_ctx *ctx, gr_stream stream, const gr_image *threshold, 
 	else if (d0_exact) launch(k_bloom_down_pair<true, false, false>);
 	else if (d1_exact) launch(k_bloom_down_pair<false, true, false>);
 	else launch(k_bloom_down_pair<false, false, false>);
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_bloom_down_head_supported(const gr_image *hdr, const gr_image *threshold, const gr_image *d0, const gr_image *d1,
+                                 const gr_push_bloom_threshold *push_t, const gr_push_bloom_downsample *push_d0, const gr_push_bloom_downsample *push_d1)
+{
+	static const bool allow_fusion = gr_measurement_switch("GR_NO_HEAD_FUSION") == nullptr; // A/B switch for measurements
+	if (!allow_fusion || !hdr || !push_t || !gr_bloom_down_mid_supported(threshold, d0, d1, push_d0, push_d1))
+		return 0;
+	if (!is_hdr_target(hdr) || !downsample_is_exact(threshold, push_d0) || !downsample_is_exact(d0, push_d1))
+		return 0;
+	// the threshold level as the 2:1 form of gr_bloom_threshold takes it
+	return hdr->width == 2u * push_t->threads[0] && hdr->height == 2u * push_t->threads[1] && threshold->width == push_t->threads[0] &&
+	       threshold->height == push_t->threads[1] && (hdr->pitch_bytes & 15u) == 0 && (reinterpret_cast<uintptr_t>(hdr->ptr) & 15u) == 0 &&
+	       push_t->inv_output_size[0] == 1.0f / float(push_t->threads[0]) && push_t->inv_output_size[1] == 1.0f / float(push_t->threads[1]);
+}
+
+int gr_bloom_down_head(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *threshold, const gr_image *d0, const gr_image *d1,
+                       const gr_luminance_data *lum, const gr_push_bloom_threshold *push_t, const gr_push_bloom_downsample *push_d0,
+                       const gr_push_bloom_downsample *push_d1)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, hdr && threshold && d0 && d1 && push_t && push_d0 && push_d1);
+	GR_CHECK_ARG(ctx, is_hdr_target(hdr) && is_rgba16f(threshold) && is_rgba16f(d0) && is_rgba16f(d1));
+	GR_CHECK_ARG(ctx, hdr->ptr != threshold->ptr && threshold->ptr != d0->ptr && d0->ptr != d1->ptr);
+	// every level exactly half of its input (what gr_bloom_down_head_supported answers, whatever the size)
+	GR_CHECK_ARG(ctx, hdr->width == 2u * threshold->width && hdr->height == 2u * threshold->height && threshold->width == 2u * d0->width &&
+	                      threshold->height == 2u * d0->height && d0->width == 2u * d1->width && d0->height == 2u * d1->height);
+	GR_CHECK_ARG(ctx, push_t->threads[0] == threshold->width && push_t->threads[1] == threshold->height && downsample_is_exact(threshold, push_d0) &&
+	                      downsample_is_exact(d0, push_d1) && push_d0->threads[0] == d0->width && push_d1->threads[0] == d1->width);
+	GR_CHECK_ARG(ctx, (hdr->pitch_bytes & 15u) == 0 && (reinterpret_cast<uintptr_t>(hdr->ptr) & 15u) == 0);
+	if (d1->width == 0 || d1->height == 0)
+		return GR_OK;
+	const dim3 grid(gr_div_up(d1->width, TAIL_TILE), gr_div_up(d1->height, TAIL_TILE));
+	const bool b10 = hdr->format == GR_FORMAT_B10G11R11_UFLOAT_PACK32;
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_down_head"};
+	if (lum)
+		hipLaunchKernelGGL(k_bloom_down_head<true>, grid, dim3(256), 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(threshold), to_dev_rw(d0), to_dev_rw(d1), lum,
+		                   push_t->inv_output_size[0], push_t->inv_output_size[1], b10);
+	else
+		hipLaunchKernelGGL(k_bloom_down_head<false>, grid, dim3(256), 0, gr_to_stream(stream), to_dev(hdr), to_dev_rw(threshold), to_dev_rw(d0), to_dev_rw(d1), lum,
+		                   push_t->inv_output_size[0], push_t->inv_output_size[1], b10);
 	GR_CHECK_LAUNCH(ctx);
 	return GR_OK;
 }

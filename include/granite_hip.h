@@ -227,6 +227,17 @@ int gr_bloom_down_mid_supported(const gr_image *threshold, const gr_image *d0, c
                                 const gr_push_bloom_downsample *push_d1);
 int gr_bloom_down_mid(gr_ctx *ctx, gr_stream stream, const gr_image *threshold, const gr_image *d0, const gr_image *d1,
                       const gr_push_bloom_downsample *push_d0, const gr_push_bloom_downsample *push_d1, const gr_rows *rows_d1);
+/* The threshold dispatch with downsample-0 and downsample-1 (hdr.cpp:354-362) in one launch: a workgroup makes an 8 x 8 tile of
+ * downsample-1, under it the patch of downsample-0, under that the patch of the threshold level from the HDR target, every texel by the
+ * code of the separate entry points (all three levels are written, byte for byte what gr_bloom_threshold + gr_bloom_down_mid leave).
+ * gr_bloom_down_head_supported(): what gr_bloom_down_mid_supported() asks for, and every level exactly half of its input (the 2:1 forms
+ * of gr_bloom_threshold and gr_bloom_downsample).  lum NULL: no dynamic exposure.  Whole images (row bands use the separate calls). */
+int gr_bloom_down_head_supported(const gr_image *hdr, const gr_image *threshold, const gr_image *d0, const gr_image *d1,
+                                 const gr_push_bloom_threshold *push_t, const gr_push_bloom_downsample *push_d0,
+                                 const gr_push_bloom_downsample *push_d1);
+int gr_bloom_down_head(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_image *threshold, const gr_image *d0, const gr_image *d1,
+                       const gr_luminance_data *lum, const gr_push_bloom_threshold *push_t, const gr_push_bloom_downsample *push_d0,
+                       const gr_push_bloom_downsample *push_d1);
 /* lum / push_lum both NULL: no dynamic exposure, no luminance reduction. */
 int gr_bloom_up_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_image *u2, const gr_image *u1,
                      gr_luminance_data *lum, const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1,

@@ -227,6 +227,40 @@ def test_fused_pyramid_middle_equals_the_two_separate_launches(gr, w, h):
     np.testing.assert_array_equal(got0[lo:hi + 1], ref0[lo:hi + 1])
 
 
+@pytest.mark.parametrize("w,h,packed,dynamic", [(1920, 1080, False, True), (2560, 1440, False, False), (256, 256, False, True), (64, 48, False, True),
+                                                (1920, 1080, True, True), (328, 200, True, False)])
+def test_fused_pyramid_head_equals_threshold_and_the_two_downsamples(gr, w, h, packed, dynamic):
+    """gr_bloom_down_head (threshold, downsample-0, downsample-1 through LDS, one launch) must leave the very bytes of gr_bloom_threshold
+    and two gr_bloom_downsample calls in all three levels: RGBA16F and B10G11R11 HDR targets, with and without the exposure buffer,
+    partial tiles (1080p's 135 rows of downsample-1, 64 x 48)."""
+    sz = [orc.level_size(w, h, s) for s in (0.5, 0.25, 0.125)]
+    rng = np.random.default_rng(w * 31 + h)
+    hdr_f = np.exp2(rng.uniform(-6, 6, (h, w, 4))).astype(np.float32)
+    if packed:
+        hdr = capi.DeviceImage(gr, w, h, capi.FORMAT_B10G11R11_UFLOAT_PACK32).upload(orc.pack_b10g11r11(hdr_f[..., :3]))
+    else:
+        hdr = capi.DeviceImage(gr, w, h, F16).upload(hdr_f.astype(np.float16).view(np.uint16))
+    lum = capi.DeviceBuffer(gr, 12).upload(np.array([0.3, 1.7, 1.0 / 1.7], np.float32)) if dynamic else None  # (kept alive: .ptr alone would free it)
+    lum_ptr = lum.ptr if lum is not None else None
+    want = [capi.DeviceImage(gr, *s, F16) for s in sz]
+    gr.bloom_threshold(hdr, want[0], lum_ptr)
+    gr.bloom_downsample(want[0], want[1])
+    gr.bloom_downsample(want[1], want[2])
+    got = [capi.DeviceImage(gr, *s, F16) for s in sz]
+    assert gr.bloom_down_head(hdr, got[0], got[1], got[2], lum_ptr), "even sizes up to 1440p must qualify"
+    gr.sync()
+    for a, b, name in zip(got, want, ("threshold", "downsample-0", "downsample-1")):
+        np.testing.assert_array_equal(a.download(), b.download(), err_msg=name)
+
+
+def test_fused_pyramid_head_declines_what_it_does_not_cover(gr):
+    """Odd level sizes (the nine generic taps) and frames above 1440p keep the separate launches."""
+    for w, h in ((1002, 810), (3840, 2160)):
+        hdr = capi.DeviceImage(gr, w, h, F16)
+        t, d0, d1 = (capi.DeviceImage(gr, *orc.level_size(w, h, s), F16) for s in (0.5, 0.25, 0.125))
+        assert not gr.bloom_down_head(hdr, t, d0, d1)
+
+
 def test_fused_pyramid_middle_is_for_launch_bound_frames_only(gr):
     """At 4K the fused form recomputes more than the saved launch is worth (measured: the frame gets 3 % slower): not offered."""
     t, d0, d1 = (capi.DeviceImage(gr, *orc.level_size(3840, 2160, s), F16) for s in (0.5, 0.25, 0.125))
