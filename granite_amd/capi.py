@@ -260,6 +260,9 @@ def load_library() -> C.CDLL:
         "gr_bloom_down_mid": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample), P(Rows)]),
         "gr_bloom_down_head_supported": (C.c_int, [P(Image), P(Image), P(Image), P(Image), P(PushBloomThreshold), P(PushBloomDownsample), P(PushBloomDownsample)]),
         "gr_bloom_down_head": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), vp, P(PushBloomThreshold), P(PushBloomDownsample), P(PushBloomDownsample)]),
+        "gr_bloom_up_all_supported": (C.c_int, [P(Image), P(Image), P(Image), P(Image), P(PushBloomUpsample), P(PushBloomUpsample), P(PushBloomUpsample)]),
+        "gr_bloom_up_all": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), vp, P(PushBloomUpsample), P(PushBloomUpsample), P(PushBloomUpsample),
+                                      P(PushLuminance)]),
         "gr_bloom_up_tail": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushBloomUpsample), P(PushBloomUpsample), P(PushLuminance)]),
         "gr_tonemap": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushTonemap)]),
         "gr_bloom_threshold_rows": (C.c_int, [vp, vp, P(Image), P(Image), vp, P(PushBloomThreshold), P(Rows)]),
@@ -480,6 +483,17 @@ class Context:
         if not self.lib.gr_bloom_down_mid_supported(threshold.desc, d0.desc, d1.desc, p_d0, p_d1):
             return False
         self.check(self.lib.gr_bloom_down_mid(self.handle, stream, threshold.desc, d0.desc, d1.desc, p_d0, p_d1, self._rows(rows)))
+        return True
+
+    def bloom_up_all(self, d3: DeviceImage, u2: DeviceImage, u1: DeviceImage, u0: DeviceImage, lum_ptr=None, lum_lerp: float = 0.0, stream=None) -> bool:
+        """luminance, upsample-2, upsample-1 and upsample-0 as one launch; False (nothing launched) when the frame does not qualify."""
+        def up(out, src):
+            return PushBloomUpsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height), (1.0 / src.width, 1.0 / src.height))
+        p_u2, p_u1, p_u0 = up(u2, d3), up(u1, u2), up(u0, u1)
+        if not self.lib.gr_bloom_up_all_supported(d3.desc, u2.desc, u1.desc, u0.desc, p_u2, p_u1, p_u0):
+            return False
+        p_lum = PushLuminance((d3.width // 2, d3.height // 2), lum_lerp, -3.0, 2.0) if lum_ptr is not None else None
+        self.check(self.lib.gr_bloom_up_all(self.handle, stream, d3.desc, u2.desc, u1.desc, u0.desc, lum_ptr, p_u2, p_u1, p_u0, p_lum))
         return True
 
     def bloom_down_head(self, hdr: DeviceImage, threshold: DeviceImage, d0: DeviceImage, d1: DeviceImage, lum_ptr=None, stream=None) -> bool:

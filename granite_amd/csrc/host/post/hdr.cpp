@@ -123,10 +123,15 @@ gr_push_bloom_upsample upsample_push(HIP::ImageView &output, HIP::ImageView &inp
 // The dispatches hdr.cpp:364-377 records for downsample-2, downsample-3, the luminance reduction, upsample-2 and upsample-1,
 // as the two fused launches of the C ABI when the pyramid qualifies (gr_bloom_tail_supported); returns false otherwise and
 // records nothing.  Same values in every level either way.
+// u0_res (whole-image frames only): upsample-0 joins the second launch when the frame qualifies (gr_bloom_up_all_supported); *u0_done says
+// whether it did.
 bool record_pyramid_tail(HIP::CommandBuffer &cmd, const FrameParameters &frame, RenderGraph &graph, const RenderTextureResource &d1_res,
                          const RenderTextureResource &d2_res, const RenderTextureResource &d3_res, const RenderTextureResource &u2_res,
-                         const RenderTextureResource &u1_res, const RenderBufferResource *lum_res)
+                         const RenderTextureResource &u1_res, const RenderBufferResource *lum_res, const RenderTextureResource *u0_res = nullptr,
+                         bool *u0_done = nullptr)
 {
+	if (u0_done)
+		*u0_done = false;
 	auto &d1 = graph.get_physical_texture_resource(d1_res);
 	auto &d2 = graph.get_physical_texture_resource(d2_res);
 	auto &d3 = graph.get_physical_texture_resource(d3_res);
@@ -154,6 +159,20 @@ bool record_pyramid_tail(HIP::CommandBuffer &cmd, const FrameParameters &frame, 
 		push_lum.min_loglum = -3.0f;
 		push_lum.max_loglum = 2.0f;
 		lum = static_cast<gr_luminance_data *>(graph.get_physical_buffer_resource(*lum_res).get_device_pointer());
+	}
+	if (u0_res)
+	{
+		auto &u0 = graph.get_physical_texture_resource(*u0_res);
+		const gr_push_bloom_upsample push_u0 = upsample_push(u0, u1);
+		if (gr_bloom_up_all_supported(&d3.get_view(), &u2.get_view(), &u1.get_view(), &u0.get_view(), &push_u2, &push_u1, &push_u0))
+		{
+			cmd.check(gr_bloom_up_all(cmd.get_context(), cmd.get_stream(), &d3.get_view(), &u2.get_view(), &u1.get_view(), &u0.get_view(), lum, &push_u2,
+			                          &push_u1, &push_u0, lum ? &push_lum : nullptr),
+			          "bloom_up_all");
+			if (u0_done)
+				*u0_done = true;
+			return true;
+		}
 	}
 	cmd.check(gr_bloom_up_tail(cmd.get_context(), cmd.get_stream(), &d3.get_view(), &u2.get_view(), &u1.get_view(), lum, &push_u2, &push_u1,
 	                           lum ? &push_lum : nullptr),
@@ -295,7 +314,8 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 			if (strip && strip->exchange)
 				strip->exchange(cmd, graph.get_physical_texture_resource(d1), strip->d1_chunk_rows, "downsample-1");
 			compute_to_compute();
-			if (!record_pyramid_tail(cmd, frame, graph, d1, d2, d3, u2, u1, ubo))
+			bool u0_done = false;
+			if (!record_pyramid_tail(cmd, frame, graph, d1, d2, d3, u2, u1, ubo, strip ? nullptr : &u0, &u0_done))
 			{
 				record_downsample(cmd, frame, graph, d2, d1, nullptr);
 				compute_to_compute();
@@ -307,8 +327,11 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 				compute_to_compute();
 				record_upsample(cmd, graph, u1, u2);
 			}
-			compute_to_compute();
-			record_upsample(cmd, graph, u0, u1, strip ? &strip->u0 : nullptr);
+			if (!u0_done)
+			{
+				compute_to_compute();
+				record_upsample(cmd, graph, u0, u1, strip ? &strip->u0 : nullptr);
+			}
 		};
 		if (strip)
 		{
@@ -326,7 +349,7 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 		key.add(ubo ? graph.get_physical_buffer_resource(*ubo).get_device_pointer() : nullptr);
 		key.add(frame.frame_time);
 		cmd.replayable("bloom-compute", key,
-		               {"bloom_threshold", "bloom_downsample", "bloom_down_head", "bloom_down_mid", "bloom_down_tail", "bloom_up_tail", "luminance", "bloom_upsample"}, record);
+		               {"bloom_threshold", "bloom_downsample", "bloom_down_head", "bloom_down_mid", "bloom_down_tail", "bloom_up_tail", "bloom_up_all", "luminance", "bloom_upsample"}, record);
 	});
 
 	{

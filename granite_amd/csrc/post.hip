@@ -621,6 +621,101 @@ __global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_tail(
 		luminance_block(d3, lum, push_lum, thread, wave_partial);
 }
 
+// The whole upsample chain in one launch, for frames whose chain of launches sets the pace (gr_bloom_up_all_supported: up to 1440p, upsample-0
+// exactly twice upsample-1): a workgroup makes a 32 x 32 tile of upsample-0; under it the <= 20 x 20 patch of upsample-1, under that the patch of
+// upsample-2 (<= 14 x 14 on the 1:2 stencil, a few more under the generic taps of an odd-sized level), which it makes from downsample-3.
+// Every texel by the functions of k_bloom_up_tail / k_bloom_upsample_1to2, rounded to fp16 between the levels as the stores round them, all three
+// levels stored (neighbouring workgroups write identical values into the overlap); workgroup 0 also runs the luminance reduction.
+constexpr int UPALL_TILE = 32;               // one output per thread.  (64-wide tiles, a quarter of the workgroups: config 1 0.0393 against 0.0366 ms,
+                                             // config 2 0.063 against 0.058 ms -- these launches are latency, not arithmetic; profiles/r04_host_lead_ab.txt)
+constexpr int UPALL_P1 = UPALL_TILE / 2 + 4; // 20
+constexpr int UPALL_P2 = 18;                 // 1:2 stencil: P1 / 2 + 4 = 14; generic taps: (P1 - 0.5) * 0.514 + 6.75 < 17
+template <bool U2_EXACT, bool U1_EXACT, bool LUMINANCE>
+__global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_all(DevImage d3, DevImageRW u2, DevImageRW u1, DevImageRW u0, gr_luminance_data *lum,
+                                                                              gr_push_bloom_upsample push2, gr_push_bloom_upsample push1,
+                                                                              gr_push_luminance push_lum)
+{
+	post_wave_priority();
+	__shared__ f16x4 s_p2[UPALL_P2 * UPALL_P2];
+	__shared__ f16x4 s_p1[UPALL_P1 * UPALL_P1];
+	__shared__ float wave_partial[LUM_THREADS / 64];
+	const int thread = int(threadIdx.x);
+	const int tile_x0 = blockIdx.x * UPALL_TILE, tile_y0 = blockIdx.y * UPALL_TILE;
+	const int tile_x1 = min(tile_x0 + UPALL_TILE, u0.w) - 1, tile_y1 = min(tile_y0 + UPALL_TILE, u0.h) - 1;
+	// upsample-1 under the tile (1:2 stencil: k - 2 .. k + 2 for k = x / 2), upsample-2 under that
+	const int ax0 = clampi((tile_x0 >> 1) - 2, 0, u1.w - 1), ax1 = clampi((tile_x1 >> 1) + 2, 0, u1.w - 1);
+	const int ay0 = clampi((tile_y0 >> 1) - 2, 0, u1.h - 1), ay1 = clampi((tile_y1 >> 1) + 2, 0, u1.h - 1);
+	int bx0, bx1, by0, by1;
+	if (U1_EXACT)
+	{
+		bx0 = clampi((ax0 >> 1) - 2, 0, u2.w - 1), bx1 = clampi((ax1 >> 1) + 2, 0, u2.w - 1);
+		by0 = clampi((ay0 >> 1) - 2, 0, u2.h - 1), by1 = clampi((ay1 >> 1) + 2, 0, u2.h - 1);
+	}
+	else
+	{
+		tap_span(ax0, ax1, u1.w, u2.w, 0.875f, bx0, bx1);
+		tap_span(ay0, ay1, u1.h, u2.h, 0.875f, by0, by1);
+	}
+	const int aw = ax1 - ax0 + 1, ah = ay1 - ay0 + 1, bw = bx1 - bx0 + 1, bh = by1 - by0 + 1; // <= UPALL_P1, UPALL_P2 (the launcher checks the level sizes)
+	for (int i = thread; i < bw * bh; i += LUM_THREADS)
+	{
+		const int ly = i / bw, lx = i - ly * bw;
+		const int x = bx0 + lx, y = by0 + ly;
+		float4 value;
+		if (U2_EXACT)
+		{
+			const auto texel = [&d3](int tx, int ty) { return *reinterpret_cast<const u32x2 *>(d3.ptr + size_t(ty) * d3.pitch + size_t(tx) * 8u); };
+			value = upsample_1to2_value(texel, d3.w, d3.h, x, y);
+		}
+		else
+		{
+			const TentTaps t = tent_taps(x, y, push2.inv_output_size, push2.inv_input_size, 0.875f);
+			value = tent9(d3, t.u, t.v, t.ox, t.oy);
+		}
+		const f16x4 texel16 = pack_rgba16f(value);
+		s_p2[i] = texel16;
+		*reinterpret_cast<f16x4 *>(u2.ptr + size_t(y) * u2.pitch + size_t(x) * 8u) = texel16;
+	}
+	__syncthreads();
+	for (int i = thread; i < aw * ah; i += LUM_THREADS)
+	{
+		const int ly = i / aw, lx = i - ly * aw;
+		const int x = ax0 + lx, y = ay0 + ly;
+		float4 value;
+		if (U1_EXACT)
+		{
+			const auto texel = [&](int tx, int ty) { return __builtin_bit_cast(u32x2, s_p2[(ty - by0) * bw + (tx - bx0)]); };
+			value = upsample_1to2_value(texel, u2.w, u2.h, x, y);
+		}
+		else
+		{
+			const TailPatch patch{s_p2, bx0, by0, bw, bh};
+			const int level_w = u2.w, level_h = u2.h;
+			const auto sample = [&](float su, float sv) {
+				return sample_linear_with([&patch](int tx, int ty) { return patch.fetch(tx, ty); }, level_w, level_h, su, sv);
+			};
+			const TentTaps t = tent_taps(x, y, push1.inv_output_size, push1.inv_input_size, 0.875f);
+			value = tent9_with(sample, t.u, t.v, t.ox, t.oy);
+		}
+		const f16x4 texel16 = pack_rgba16f(value);
+		s_p1[i] = texel16;
+		*reinterpret_cast<f16x4 *>(u1.ptr + size_t(y) * u1.pitch + size_t(x) * 8u) = texel16;
+	}
+	__syncthreads();
+	const int tw = tile_x1 - tile_x0 + 1, th = tile_y1 - tile_y0 + 1;
+	for (int i = thread; i < UPALL_TILE * th; i += LUM_THREADS)
+	{
+		const int ly = i / UPALL_TILE, lx = i - ly * UPALL_TILE;
+		if (lx >= tw)
+			continue;
+		const int x = tile_x0 + lx, y = tile_y0 + ly;
+		const auto texel = [&](int tx, int ty) { return __builtin_bit_cast(u32x2, s_p1[(ty - ay0) * aw + (tx - ax0)]); };
+		store_rgba16f(u0, x, y, upsample_1to2_value(texel, u1.w, u1.h, x, y));
+	}
+	if (LUMINANCE && blockIdx.x == 0 && blockIdx.y == 0)
+		luminance_block(d3, lum, push_lum, thread, wave_partial);
+}
+
 // ---- tonemap (tonemap.frag:30-66) -----------------------------------------------------------------------------------
 // Per pixel this pass is 12.5 B of traffic but three filmic curves + three sRGB encodes, i.e. VALU-heavy; the arithmetic is
 // kept lean so that the kernel stays on the HBM side of its roofline: the filmic division is num * v_rcp_f32(den) (1 ulp),
@@ -1126,6 +1221,65 @@ int gr_bloom_up_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr
 		constexpr bool A = decltype(u2e)::value, B = decltype(u1e)::value;
 		if (lum) launch(k_bloom_up_tail<A, B, true>);
 		else launch(k_bloom_up_tail<A, B, false>);
+	};
+	using T = std::true_type;
+	using F = std::false_type;
+	if (u2_exact && u1_exact) pick(T{}, T{});
+	else if (u2_exact) pick(T{}, F{});
+	else if (u1_exact) pick(F{}, T{});
+	else pick(F{}, F{});
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_bloom_up_all_supported(const gr_image *d3, const gr_image *u2, const gr_image *u1, const gr_image *u0, const gr_push_bloom_upsample *push_u2,
+                              const gr_push_bloom_upsample *push_u1, const gr_push_bloom_upsample *push_u0)
+{
+	static const bool allow_fusion = gr_measurement_switch("GR_NO_UP_FUSION") == nullptr && gr_measurement_switch("GR_NO_TAIL_FUSION") == nullptr;
+	if (!allow_fusion || !d3 || !u2 || !u1 || !u0 || !push_u2 || !push_u1 || !push_u0)
+		return 0;
+	if (!is_rgba16f(d3) || !is_rgba16f(u2) || !is_rgba16f(u1) || !is_rgba16f(u0))
+		return 0;
+	if (push_u2->threads[0] != u2->width || push_u2->threads[1] != u2->height || push_u1->threads[0] != u1->width || push_u1->threads[1] != u1->height ||
+	    push_u0->threads[0] != u0->width || push_u0->threads[1] != u0->height)
+		return 0;
+	// upsample-1 at most twice upsample-2 (+ 1: a level is ceil(half) of the one above), as for gr_bloom_up_tail; upsample-0 on the 1:2 stencil
+	if (u1->width > 2 * u2->width || u1->height > 2 * u2->height || 2 * u2->width > u1->width + 1 || 2 * u2->height > u1->height + 1)
+		return 0;
+	if (!upsample_is_exact(u1, push_u0) || u1->width == 0 || u1->height == 0)
+		return 0;
+	// frames up to 1440p: above, the launches are long enough to hide their dispatch and the recomputed overlap is not free
+	return uint64_t(u0->width) * u0->height <= 262144u;
+}
+
+int gr_bloom_up_all(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_image *u2, const gr_image *u1, const gr_image *u0, gr_luminance_data *lum,
+                    const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1, const gr_push_bloom_upsample *push_u0,
+                    const gr_push_luminance *push_lum)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, d3 && u2 && u1 && u0 && push_u2 && push_u1 && push_u0 && (lum == nullptr) == (push_lum == nullptr));
+	GR_CHECK_ARG(ctx, is_rgba16f(d3) && is_rgba16f(u2) && is_rgba16f(u1) && is_rgba16f(u0));
+	GR_CHECK_ARG(ctx, push_u0->threads[0] == u0->width && push_u0->threads[1] == u0->height && upsample_is_exact(u1, push_u0));
+	GR_CHECK_ARG(ctx, push_u1->threads[0] == u1->width && push_u1->threads[1] == u1->height);
+	GR_CHECK_ARG(ctx, push_u2->threads[0] == u2->width && push_u2->threads[1] == u2->height);
+	GR_CHECK_ARG(ctx, u1->width <= 2 * u2->width && u1->height <= 2 * u2->height && 2 * u2->width <= u1->width + 1 && 2 * u2->height <= u1->height + 1);
+	GR_CHECK_ARG(ctx, u0->ptr != u1->ptr && u1->ptr != u2->ptr && u2->ptr != d3->ptr);
+	GR_CHECK_ARG(ctx, !push_lum || (push_lum->size[0] != 0 && push_lum->size[1] != 0));
+	if (u0->width == 0 || u0->height == 0)
+		return GR_OK;
+	dim3 grid(gr_div_up(u0->width, UPALL_TILE), gr_div_up(u0->height, UPALL_TILE));
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_up_all"};
+	const gr_push_luminance no_lum = {};
+	const bool u2_exact = upsample_is_exact(d3, push_u2), u1_exact = upsample_is_exact(u2, push_u1);
+	auto launch = [&](auto kernel) {
+		hipLaunchKernelGGL(kernel, grid, dim3(LUM_THREADS), 0, gr_to_stream(stream), to_dev(d3), to_dev_rw(u2), to_dev_rw(u1), to_dev_rw(u0), lum, *push_u2,
+		                   *push_u1, push_lum ? *push_lum : no_lum);
+	};
+	auto pick = [&](auto u2e, auto u1e) {
+		constexpr bool A = decltype(u2e)::value, B = decltype(u1e)::value;
+		if (lum) launch(k_bloom_up_all<A, B, true>);
+		else launch(k_bloom_up_all<A, B, false>);
 	};
 	using T = std::true_type;
 	using F = std::false_type;

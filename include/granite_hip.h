@@ -243,6 +243,17 @@ int gr_bloom_up_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr
                      gr_luminance_data *lum, const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1,
                      const gr_push_luminance *push_lum);
 
+/* The whole upsample chain -- luminance, upsample-2, upsample-1, upsample-0 (hdr.cpp:368-379) -- in one launch: a workgroup makes a 64 x 64
+ * tile of upsample-0 from the patch of upsample-1 under it, that from the patch of upsample-2, that from downsample-3; all three levels are
+ * written, byte for byte what gr_bloom_up_tail + gr_bloom_upsample leave.  gr_bloom_up_all_supported(): whole levels of a pyramid of
+ * InputRelative sizes, upsample-0 exactly twice upsample-1 and at most 262144 texels (frames up to 1440p).  lum / push_lum both NULL: no
+ * dynamic exposure, no luminance reduction. */
+int gr_bloom_up_all_supported(const gr_image *d3, const gr_image *u2, const gr_image *u1, const gr_image *u0, const gr_push_bloom_upsample *push_u2,
+                              const gr_push_bloom_upsample *push_u1, const gr_push_bloom_upsample *push_u0);
+int gr_bloom_up_all(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_image *u2, const gr_image *u1, const gr_image *u0,
+                    gr_luminance_data *lum, const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1,
+                    const gr_push_bloom_upsample *push_u0, const gr_push_luminance *push_lum);
+
 /* tonemap_build_render_pass (hdr.cpp:283-306) + tonemap.frag (full-screen quad).  out: R8G8B8A8_SRGB (linear value
  * is sRGB-encoded on store, as the attachment hardware does) or R8G8B8A8_UNORM.  lum NULL => DYNAMIC_EXPOSURE=0. */
 typedef struct gr_push_tonemap

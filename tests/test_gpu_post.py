@@ -253,6 +253,44 @@ def test_fused_pyramid_head_equals_threshold_and_the_two_downsamples(gr, w, h, p
         np.testing.assert_array_equal(a.download(), b.download(), err_msg=name)
 
 
+@pytest.mark.parametrize("w,h,dynamic", [(1920, 1080, True), (2560, 1440, True), (256, 256, True), (640, 360, False), (200, 136, True), (72, 40, False)])
+def test_fused_upsample_chain_equals_the_separate_launches(gr, w, h, dynamic):
+    """gr_bloom_up_all (luminance, upsample-2, upsample-1, upsample-0 through LDS, one launch) must leave the very bytes of gr_luminance
+    and three gr_bloom_upsample calls in all three levels and in the luminance buffer: 1080p (upsample-1 on the nine generic taps:
+    68 -> 135 rows), 1440p and 256 x 256 (every level on the 1:2 stencil), partial tiles, with and without the exposure buffer."""
+    sz = [orc.level_size(w, h, s) for s in (0.25, 0.125, 0.0625, 0.03125)]
+    rng = np.random.default_rng(w * 13 + h)
+    d3 = capi.DeviceImage(gr, *sz[3], F16).upload(np.exp2(rng.uniform(-8, 4, (sz[3][1], sz[3][0], 4))).astype(np.float16).view(np.uint16))
+    lum0 = np.array([0.25, 2.0 ** 0.25, 2.0 ** -0.25], np.float32)
+    lum_lerp, _ = orc.frame_lerps(0.01)
+    got = {}
+    for fused in (False, True):
+        u2, u1, u0 = (capi.DeviceImage(gr, *sz[i], F16) for i in (2, 1, 0))
+        lum = capi.DeviceBuffer(gr, 12).upload(lum0) if dynamic else None
+        lum_ptr = lum.ptr if lum is not None else None
+        if fused:
+            assert gr.bloom_up_all(d3, u2, u1, u0, lum_ptr, lum_lerp), "a pyramid of InputRelative sizes up to 1440p with an even quarter level must qualify"
+        else:
+            if dynamic:
+                gr.luminance(d3, lum_ptr, lum_lerp)
+            gr.bloom_upsample(d3, u2)
+            gr.bloom_upsample(u2, u1)
+            gr.bloom_upsample(u1, u0)
+        gr.sync()
+        got[fused] = (u2.download(), u1.download(), u0.download(), lum.download(np.float32) if dynamic else np.zeros(3, np.float32))
+    for a, b, name in zip(got[True], got[False], ("upsample-2", "upsample-1", "upsample-0", "luminance")):
+        np.testing.assert_array_equal(a, b, err_msg=name)
+    if dynamic:
+        assert got[True][3][0] != lum0[0]
+
+
+def test_fused_upsample_chain_declines_what_it_does_not_cover(gr):
+    """Frames above 1440p and a quarter level that is not exactly twice the eighth keep gr_bloom_up_tail + gr_bloom_upsample."""
+    for w, h in ((3840, 2160), (1004, 812)):
+        u0, u1, u2, d3 = (capi.DeviceImage(gr, *orc.level_size(w, h, s), F16) for s in (0.25, 0.125, 0.0625, 0.03125))
+        assert not gr.bloom_up_all(d3, u2, u1, u0)
+
+
 def test_fused_pyramid_head_declines_what_it_does_not_cover(gr):
     """Odd level sizes (the nine generic taps) and frames above 1440p keep the separate launches."""
     for w, h in ((1002, 810), (3840, 2160)):
