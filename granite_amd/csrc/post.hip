@@ -621,8 +621,7 @@ __global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_tail(
 		luminance_block(d3, lum, push_lum, thread, wave_partial);
 }
 
-// The whole upsample chain in one launch, for frames whose chain of launches sets the pace (gr_bloom_up_all_supported: up to 1440p, upsample-0
-// exactly twice upsample-1): a workgroup makes a 32 x 32 tile of upsample-0; under it the <= 20 x 20 patch of upsample-1, under that the patch of
+// The whole upsample chain in one launch (gr_bloom_up_all_supported: upsample-0 exactly twice upsample-1): a workgroup makes a 32 x 32 tile of upsample-0; under it the <= 20 x 20 patch of upsample-1, under that the patch of
 // upsample-2 (<= 14 x 14 on the 1:2 stencil, a few more under the generic taps of an odd-sized level), which it makes from downsample-3.
 // Every texel by the functions of k_bloom_up_tail / k_bloom_upsample_1to2, rounded to fp16 between the levels as the stores round them, all three
 // levels stored (neighbouring workgroups write identical values into the overlap); workgroup 0 also runs the luminance reduction.
@@ -1248,8 +1247,10 @@ int gr_bloom_up_all_supported(const gr_image *d3, const gr_image *u2, const gr_i
 		return 0;
 	if (!upsample_is_exact(u1, push_u0) || u1->width == 0 || u1->height == 0)
 		return 0;
-	// frames up to 1440p: above, the launches are long enough to hide their dispatch and the recomputed overlap is not free
-	return uint64_t(u0->width) * u0->height <= 262144u;
+	// No size limit: the levels involved are a quarter of the frame and coarser, so the recomputed overlap is small at any size.  Measured at 4K
+	// (profiles/r04_host_lead_ab.txt): config 3 0.2198 / 0.2192 -> 0.2197 / 0.2200 ms (the chain runs under the lighting kernel either way),
+	// config 4, whose post chain is the frame, 0.6264 / 0.6257 -> 0.6216 / 0.6212 ms.
+	return 1;
 }
 
 int gr_bloom_up_all(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_image *u2, const gr_image *u1, const gr_image *u0, gr_luminance_data *lum,
