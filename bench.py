@@ -214,6 +214,10 @@ def parity_check(cam, gbuf, descs, device, reference):
 
 def main():
     args = parse_args()
+    if os.environ.get("GRANITE_BENCH_WATCHDOG_S"):
+        # diagnosis of a run that does not come back: after so many seconds every thread's Python stack goes to stderr and the process exits
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["GRANITE_BENCH_WATCHDOG_S"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "GRANITE_BENCH_DEVICE" in os.environ:  # test hook: several ranks on one GPU (exercises the replicas fallback)
@@ -434,7 +438,13 @@ def main():
     # and it pays the executor's three-frame pipeline fill once per K frames. ----
     sustained = None
     if args.sustain_seconds > 0:
-        n_sus = max(args.steps, int(args.sustain_seconds / max(elapsed / args.steps, 1e-6)))
+        # every rank must render the SAME number of frames (each frame is a set of collectives): the count comes from the slowest rank's clock
+        agreed = elapsed
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            agreed = float(t.item())
+        n_sus = max(args.steps, int(args.sustain_seconds / max(agreed / args.steps, 1e-6)))
         barrier()
         ts0 = time.perf_counter()
         application.render_frames(n_sus, sync=False)
