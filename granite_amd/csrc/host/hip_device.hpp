@@ -178,6 +178,7 @@ public:
 	// (record_frame_fence): one record per stream and frame instead of the run's event plus the fence.  next_frame_context() records
 	// the fences of the streams that were handed out since (get_stream) and of no others -- an idle stream costs nothing.
 	void *frame_fence(CommandBuffer::Type type) const { return staging[staging_index].fence[int(type)]; }
+	static constexpr unsigned FrameFenceRing = 4; // = StagingFrames: a frame's fences are re-recorded this many frames later
 	void record_frame_fence(CommandBuffer::Type type);
 	void next_frame_context();
 	void wait_idle();
@@ -206,7 +207,7 @@ private:
 		void *fence[int(CommandBuffer::Type::Count)] = {};
 	};
 	static constexpr size_t StagingBytes = 4u << 20;
-	static constexpr unsigned StagingFrames = 4;
+	static constexpr unsigned StagingFrames = FrameFenceRing;
 	StagingFrame staging[StagingFrames];
 	unsigned staging_index = 0;
 	mutable bool stream_dirty[int(CommandBuffer::Type::Count)] = {};

@@ -1445,6 +1445,7 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 	int run_stream = -1;        // stream of the run being enqueued
 	unsigned run_slot = 0;      // index of the run within the frame (event ring row)
 	bool run_published = false; // a pass of the run published accesses under the run's event
+	static_assert(unsigned(EventRing) == HIP::Device::FrameFenceRing, "a run published under a device fence must stay named for as long as one under the graph's own events");
 	// The last run a frame puts on a stream publishes under the DEVICE's fence of that stream and frame (the staging ring's, same depth as
 	// EventRing) and records it here: the fence next_frame_context() would otherwise record right behind the run's own event.
 	// Which run that is: a dry pass over the frame's passes (need_render_pass is asked once per pass and frame).
