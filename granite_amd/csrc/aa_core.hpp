@@ -26,6 +26,13 @@
 #else
 #define AA_WAVE_UNIFORM(v) uint32_t(v)
 #endif
+// True when the condition holds on every lane of the wave (device: one branch for the wave; host emulation: the lane's own answer --
+// both sides of such a branch compute the same values, the condition only selects the cheaper form).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AA_WAVE_ALL(c) (__builtin_amdgcn_ballot_w64(!(c)) == 0ull)
+#else
+#define AA_WAVE_ALL(c) (c)
+#endif
 
 namespace aa
 {
@@ -381,7 +388,8 @@ struct TaaPush
 
 // Tile: f4 cur(int ox, int oy) = (Y, Cg, Co, depth) of the clamped neighbour (x + ox, y + oy), |o| <= 1.
 // Mv:   uint32_t mv(int x, int y), the RG16F texel of the clamped pixel.
-// Hist: u2 texel(int x, int y), the RGBA16F history texel; coordinates arrive clamped to the image.
+// Hist: u2 texel(int x, int y), the RGBA16F history texel; coordinates arrive clamped to the image.  row4(x, y, out): texels (x .. x + 3, y), all
+// inside the image (QUALITY 2: the footprint of a wave that touches no border).
 // QUALITY 0 / 1 / 2 = TAAQuality Low / Medium / High.  Writes the resolved colour and the new history as RGBA16F texels, and the
 // colour in fp32 as well; hist_row_first / hist_row_last = the first and last history row the pixel fetched (row bands: a rank
 // only holds the history rows around its band).
@@ -491,17 +499,41 @@ AA_HD void taa_pixel(const Tile &t, const Mv &mvs, const Hist &hist, int x, int 
 		// weight of texel column i / row i: its tap's Catmull-Rom weight times its share of the tap's lerp
 		const float cwx[4] = {wx[0], wx[1] * (1.0f - ax), wx[1] * ax, wx[2]}, cwy[4] = {wy[0], wy[1] * (1.0f - ay), wy[1] * ay, wy[2]};
 		float r = 0.0f, g = 0.0f, b = 0.0f;
+		// Where the 4 x 4 footprint of every lane of the wave lies inside the image -- everywhere but a frame of pixels whose reprojection
+		// touches the border -- nothing clamps and the four texels of a row are one run of 32 bytes from one address: Hist::row4.  Same
+		// texels, same sums.
+		const bool inside = k >= 1 && k + 2 <= w - 1 && j >= 1 && j + 2 <= h - 1;
+		if (AA_WAVE_ALL(inside))
+		{
 #pragma unroll
-		for (int jj = 0; jj < 4; jj++)
-#pragma unroll
-			for (int ii = 0; ii < 4; ii++)
+			for (int jj = 0; jj < 4; jj++)
 			{
-				const u2 tx = hist.texel(col[ii], row[jj]);
-				const float wgt = cwx[ii] * cwy[jj];
-				r = mad_half_lo(tx.x, wgt, r);
-				g = mad_half_hi(tx.x, wgt, g);
-				b = mad_half_lo(tx.y, wgt, b);
+				u2 run[4];
+				hist.row4(k - 1, j - 1 + jj, run);
+#pragma unroll
+				for (int ii = 0; ii < 4; ii++)
+				{
+					const float wgt = cwx[ii] * cwy[jj];
+					r = mad_half_lo(run[ii].x, wgt, r);
+					g = mad_half_hi(run[ii].x, wgt, g);
+					b = mad_half_lo(run[ii].y, wgt, b);
+				}
 			}
+		}
+		else
+		{
+#pragma unroll
+			for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+				for (int ii = 0; ii < 4; ii++)
+				{
+					const u2 tx = hist.texel(col[ii], row[jj]);
+					const float wgt = cwx[ii] * cwy[jj];
+					r = mad_half_lo(tx.x, wgt, r);
+					g = mad_half_hi(tx.x, wgt, g);
+					b = mad_half_lo(tx.y, wgt, b);
+				}
+		}
 		hc = {r, g, b};
 		hist_row_first = row[0];
 		hist_row_last = row[3];

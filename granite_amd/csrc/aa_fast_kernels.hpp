@@ -273,6 +273,19 @@ struct TaaHistory
 		const uint2 t = *reinterpret_cast<const uint2 *>(ptr + (uint32_t(y) * pitch + uint32_t(x) * 8u));
 		return {t.x, t.y};
 	}
+	// texels (x .. x + 3, y), all inside the image: two 16-byte loads from one address (8-byte aligned: the hardware takes it)
+	__device__ __forceinline__ void row4(int x, int y, aa::u2 (&out)[4]) const
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		typedef uint32_t words4 __attribute__((ext_vector_type(4), aligned(8)));
+		const words4 *p = reinterpret_cast<const words4 *>(ptr + (uint32_t(y) * pitch + uint32_t(x) * 8u));
+		const words4 a = p[0], b = p[1];
+		out[0] = {a.x, a.y}, out[1] = {a.z, a.w}, out[2] = {b.x, b.y}, out[3] = {b.z, b.w};
+#else
+		for (int i = 0; i < 4; i++)
+			out[i] = texel(x + i, y);
+#endif
+	}
 };
 
 template <int QUALITY, bool HISTORY>
