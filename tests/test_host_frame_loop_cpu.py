@@ -86,3 +86,37 @@ def test_every_cross_stream_wait_follows_its_record():
     device must wait on the hand-over ring (WAR), the back of the frame on the front (RAW) -- and never on an event before its record."""
     r = run(960, 540, 300, pending=True)
     assert r["stream_waits"] >= 3 and r["waits_before_record"] == 0, r
+
+
+def test_one_record_and_only_waits_sit_between_two_lighting_launches():
+    """HIP_STUB_TRACE=1 prints the order in which a frame hands its work to the runtime.  On the lighting kernel's stream nothing but one
+    event record (the run's event, which is also that stream's frame fence: Device::record_frame_fence) and the waits of the next frame
+    sit between two consecutive lighting launches -- every packet there is a command-processor round trip between the two longest
+    kernels of the frame -- and a frame records three events in all (round 3: six)."""
+    if not os.path.exists(STUB) or os.path.getmtime(STUB) < os.path.getmtime(os.path.join(os.path.dirname(STUB), "hip_stub.cpp")):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(STUB)])
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+from granite_amd import app as gapp, synth
+cam = synth.Camera(960, 540)
+a = gapp.Application(960, 540); a.set_render_parameters(cam.render_params()); a.set_lights(synth.make_lights(cam, 300)); a.upload_gbuffer(synth.make_gbuffer(cam))
+a.render_frames(8, sync=True)
+sys.stderr.write("=== steady\n"); a.render_frames(4, sync=False); sys.stderr.write("=== end\n")
+a.close()
+""" % ROOT
+    env = dict(os.environ, LD_PRELOAD=STUB, HIP_STUB_TRACE="1", HIP_STUB_EVENTS_PENDING="1")
+    env.pop("GRANITE_LIGHT_PREFETCH_MIN", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stderr.split("=== steady")[1].split("=== end")[0].splitlines()
+    ops = [l.split(None, 2) for l in lines if l[:2] in ("L ", "R ", "W ")]
+    lighting = [i for i, o in enumerate(ops) if o[0] == "L" and "k_lighting" in o[2]]
+    assert len(lighting) == 4, len(lighting)
+    stream = ops[lighting[0]][1]
+    for a_, b_ in zip(lighting, lighting[1:]):
+        between = [o[0] for o in ops[a_ + 1:b_] if o[1] == stream]
+        assert between.count("R") == 1 and between.count("L") == 0, between
+        assert between[0] == "R" and all(k == "W" for k in between[1:]), between
+    frame = ops[lighting[0]:lighting[1]]
+    assert sum(o[0] == "R" for o in frame) == 3, [o[:2] for o in frame]
