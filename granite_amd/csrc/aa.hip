@@ -555,6 +555,81 @@ int gr_smaa_edge_detection(gr_ctx *ctx, gr_stream stream, const gr_image *color,
 	return gr_smaa_edge_detection_rows(ctx, stream, color, edges, push, quality, nullptr);
 }
 
+// The bit planes of an edge texture of this size on this stream's allocation (grown on demand; one set per launch stream).
+static int smaa_planes_of(gr_ctx *ctx, gr_stream stream, uint32_t width, uint32_t height, SmaaBitPlanes &planes, gr_ctx::SmaaBits *&entry)
+{
+	planes = {};
+	planes.row_words = smaa_bit_words(int(width));
+	planes.col_words = smaa_bit_words(int(height));
+	const size_t row_plane = size_t(planes.rows()) * planes.row_words * 8u, col_plane = size_t(planes.cols()) * planes.col_words * 8u;
+	const size_t need = 2 * row_plane + 2 * col_plane;
+	uint8_t *memory = nullptr;
+	{
+		std::lock_guard<std::mutex> holder{ctx->lock};
+		gr_ctx::SmaaBits &bits = ctx->smaa_bits[stream];
+		if (bits.bytes < need)
+		{
+			// a replaced allocation may still be read by a launch in flight on this stream: drain it first
+			if (bits.memory)
+			{
+				(void)hipStreamSynchronize(gr_to_stream(stream));
+				(void)hipFree(bits.memory);
+				bits = {};
+			}
+			if (hipMalloc(&bits.memory, need) != hipSuccess)
+				bits = {};
+			else
+				bits.bytes = need;
+		}
+		memory = static_cast<uint8_t *>(bits.memory);
+		entry = &bits;
+	}
+	if (!memory) // (outside the lock: fail() takes it)
+		return ctx->fail(GR_ERR_OUT_OF_MEMORY, "SMAA: %zu bytes of edge bit planes", need);
+	planes.row_r = reinterpret_cast<uint64_t *>(memory);
+	planes.row_g = reinterpret_cast<uint64_t *>(memory + row_plane);
+	planes.col_r = reinterpret_cast<uint64_t *>(memory + 2 * row_plane);
+	planes.col_g = reinterpret_cast<uint64_t *>(memory + 2 * row_plane + col_plane);
+	return GR_OK;
+}
+
+int gr_smaa_edges_with_planes_supported(gr_ctx *ctx, const gr_image *color, const gr_push_smaa *push)
+{
+	static const bool forced_generic = gr_measurement_switch("GRANITE_AA_GENERIC") != nullptr, off = gr_measurement_switch("GR_NO_SMAA_PLANES_FUSION") != nullptr;
+	if (!ctx || !color || !push || forced_generic || off || !color->width || !color->height || color->width > 16384 || color->height > 16384)
+		return 0;
+	return use_fast_aa(ctx, color->width, color->height, push->rt_metrics[0], push->rt_metrics[1]) ? 1 : 0;
+}
+
+int gr_smaa_edges_with_planes(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *edges, const gr_push_smaa *push, int quality)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, push && color && edges && color->width && color->height);
+	GR_CHECK_ARG(ctx, quality >= 0 && quality <= 3);
+	GR_CHECK_ARG(ctx, check_image(color, 4, color->width, color->height) && is_rgba8(color->format));
+	GR_CHECK_ARG(ctx, check_image(edges, 2, color->width, color->height) && edges->format == GR_FORMAT_R8G8_UNORM);
+	if (!gr_smaa_edges_with_planes_supported(ctx, color, push))
+		return ctx->fail(GR_ERR_INVALID_ARGUMENT, "gr_smaa_edges_with_planes: not offered for this image (gr_smaa_edges_with_planes_supported)");
+	SmaaBitPlanes planes;
+	gr_ctx::SmaaBits *entry = nullptr;
+	const int code = smaa_planes_of(ctx, stream, color->width, color->height, planes, entry);
+	if (code != GR_OK)
+		return code;
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_edge_detection"};
+	hipLaunchKernelGGL(k_smaa_edges_planes, fast_grid(color->width, color->height), dim3(FAST_BW, FAST_BH), 0, gr_to_stream(stream),
+	                   static_cast<const uint8_t *>(color->ptr), color->pitch_bytes, int(color->width), int(color->height), static_cast<uint8_t *>(edges->ptr),
+	                   edges->pitch_bytes, smaa_preset(quality).threshold, planes);
+	GR_CHECK_LAUNCH(ctx);
+	{
+		std::lock_guard<std::mutex> holder{ctx->lock};
+		entry->current_edges = edges->ptr;
+		entry->current_width = edges->width;
+		entry->current_height = edges->height;
+	}
+	return GR_OK;
+}
+
 int gr_smaa_edge_detection_rows(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *edges, const gr_push_smaa *push, int quality,
                                 const gr_rows *rows)
 {
@@ -567,6 +642,13 @@ int gr_smaa_edge_detection_rows(gr_ctx *ctx, gr_stream stream, const gr_image *c
 	const RowSpan span = resolve_rows(rows, color->height);
 	if (span.count() == 0)
 		return GR_OK;
+	{
+		// this call rewrites the edge texture without its planes: whatever planes named it are stale
+		std::lock_guard<std::mutex> holder{ctx->lock};
+		for (auto &bits : ctx->smaa_bits)
+			if (bits.second.current_edges == edges->ptr)
+				bits.second.current_edges = nullptr;
+	}
 	const bool fast = use_fast_aa(ctx, color->width, color->height, push->rt_metrics[0], push->rt_metrics[1]);
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_edge_detection"};
 	if (fast)
@@ -585,8 +667,35 @@ int gr_smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, c
 	return gr_smaa_blend_weight_rows(ctx, stream, edges, weights, push, quality, nullptr);
 }
 
+static int smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality,
+                             const gr_rows *rows, bool planes_current);
+
 int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality,
                               const gr_rows *rows)
+{
+	return smaa_blend_weight(ctx, stream, edges, weights, push, quality, rows, false);
+}
+
+int gr_smaa_blend_weight_planes(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, edges != nullptr);
+	bool current = false;
+	{
+		std::lock_guard<std::mutex> holder{ctx->lock};
+		const auto itr = ctx->smaa_bits.find(stream);
+		current = itr != ctx->smaa_bits.end() && itr->second.current_edges == edges->ptr && itr->second.current_width == edges->width &&
+		          itr->second.current_height == edges->height;
+	}
+	if (!current) // (outside the lock: fail() takes it)
+		return ctx->fail(GR_ERR_INVALID_ARGUMENT, "gr_smaa_blend_weight_planes: this stream's bit planes do not hold this edge texture (gr_smaa_edges_with_planes "
+		                                          "must be the call that wrote it, on this stream)");
+	return smaa_blend_weight(ctx, stream, edges, weights, push, quality, nullptr, true);
+}
+
+static int smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality,
+                             const gr_rows *rows, bool planes_current)
 {
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
@@ -610,37 +719,17 @@ int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edg
 	static const bool forced_generic = gr_measurement_switch("GRANITE_AA_GENERIC") != nullptr;
 	if (!forced_generic && edges->width <= 16384 && edges->height <= 16384)
 	{
-		SmaaBitPlanes planes = {};
-		planes.row_words = smaa_bit_words(int(edges->width));
-		planes.col_words = smaa_bit_words(int(edges->height));
-		const size_t row_plane = size_t(planes.rows()) * planes.row_words * 8u, col_plane = size_t(planes.cols()) * planes.col_words * 8u;
-		const size_t need = 2 * row_plane + 2 * col_plane;
-		uint8_t *memory = nullptr;
+		SmaaBitPlanes planes;
+		gr_ctx::SmaaBits *entry = nullptr;
+		const int code = smaa_planes_of(ctx, stream, edges->width, edges->height, planes, entry);
+		if (code != GR_OK)
+			return code;
+		// planes_current: gr_smaa_blend_weight_planes -- the edge pass of this stream wrote them with the texture (checked there)
+		if (!planes_current)
 		{
 			std::lock_guard<std::mutex> holder{ctx->lock};
-			gr_ctx::SmaaBits &bits = ctx->smaa_bits[stream];
-			if (bits.bytes < need)
-			{
-				// a replaced allocation may still be read by a launch in flight on this stream: drain it first
-				if (bits.memory)
-				{
-					(void)hipStreamSynchronize(gr_to_stream(stream));
-					(void)hipFree(bits.memory);
-					bits = {};
-				}
-				if (hipMalloc(&bits.memory, need) != hipSuccess)
-				{
-					bits = {};
-					return ctx->fail(GR_ERR_OUT_OF_MEMORY, "gr_smaa_blend_weight: %zu bytes of edge bit planes", need);
-				}
-				bits.bytes = need;
-			}
-			memory = static_cast<uint8_t *>(bits.memory);
+			entry->current_edges = nullptr; // the pack launch below rewrites them (for a band of rows, possibly)
 		}
-		planes.row_r = reinterpret_cast<uint64_t *>(memory);
-		planes.row_g = reinterpret_cast<uint64_t *>(memory + row_plane);
-		planes.col_r = reinterpret_cast<uint64_t *>(memory + 2 * row_plane);
-		planes.col_g = reinterpret_cast<uint64_t *>(memory + 2 * row_plane + col_plane);
 		// tiles of 64 padded rows the band's workgroups stage from: rows first - 127 .. end + 175 (+ the block rounding)
 		const int tile_first = max(0, (int(span.first) - 128 + SMAA_BITS_PAD) >> 6);
 		const int tile_last = min(planes.col_words - 1, (int(span.end) + FAST_BH + 192 + SMAA_BITS_PAD) >> 6);
@@ -651,8 +740,9 @@ int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edg
 		B.diag_walks_exact = S.P.diag && B.centres_snap && !float_walks && diag_walk_exact(ctx, edges->width, push->rt_metrics[0], true) &&
 		                     diag_walk_exact(ctx, edges->height, push->rt_metrics[1], false);
 		gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_blend_weight"};
-		hipLaunchKernelGGL(k_smaa_pack_edges, dim3(tiles), dim3(256), 0, gr_to_stream(stream), B.edges, B.edges_pitch, B.w, B.h, planes,
-		                   tile_first, tile_last - tile_first + 1);
+		if (!planes_current)
+			hipLaunchKernelGGL(k_smaa_pack_edges, dim3(tiles), dim3(256), 0, gr_to_stream(stream), B.edges, B.edges_pitch, B.w, B.h, planes,
+			                   tile_first, tile_last - tile_first + 1);
 		hipLaunchKernelGGL(k_smaa_weights_bits, fast_grid(edges->width, span.count()), dim3(FAST_BW, FAST_BH), 0, gr_to_stream(stream), B,
 		                   static_cast<uint8_t *>(weights->ptr), weights->pitch_bytes, span);
 		GR_CHECK_LAUNCH(ctx);
