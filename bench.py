@@ -405,7 +405,7 @@ def main():
     if SETTLE_MS > 0:
         kctx.timing_enable(False)
         if dist is None:
-            # the host runs at most three frames ahead of the device (staging ring), so its clock follows the device's load
+            # the host runs at most two frames ahead of the device (Device::next_frame_context), so its clock follows the device's load
             t_settle = time.perf_counter()
             while 1000.0 * (time.perf_counter() - t_settle) < SETTLE_MS and settle_frames < 8000:
                 application.render_frames(16, sync=False)

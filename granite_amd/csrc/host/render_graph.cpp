@@ -1382,7 +1382,7 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		if (!event || std::find(waited.begin(), waited.end(), event) != waited.end())
 			return;
 		waited.push_back(event);
-		// The host runs one to three frames ahead of the GPU, so most cross-stream dependencies (anything on work of two
+		// The host runs one to two frames ahead of the GPU (Device::next_frame_context), so most cross-stream dependencies (anything on work of two
 		// frames ago, usually the cluster build as well) are already complete when they are looked at: no barrier packet
 		// is needed then, and each one costs the command processor several microseconds between two kernels.
 		if (hipEventQuery(static_cast<hipEvent_t>(event)) == hipSuccess)
