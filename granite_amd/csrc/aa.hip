@@ -595,7 +595,7 @@ static int smaa_planes_of(gr_ctx *ctx, gr_stream stream, uint32_t width, uint32_
 
 int gr_smaa_edges_with_planes_supported(gr_ctx *ctx, const gr_image *color, const gr_push_smaa *push)
 {
-	// OFF unless GR_SMAA_PLANES_FUSION=1: k_smaa_edges_planes equals the pack kernel byte for byte under the host emulation (13 sizes) and the
+	// OFF unless GR_SMAA_PLANES_FUSION=1: k_smaa_edges_planes equals the pack kernel byte for byte under the host emulation (9 sizes) and the
 	// entry points are exercised on the device-less runtime, but the round's GPU minutes ran out before the kernel ran on hardware
 	// (tests/test_gpu_aa.py has the test: it is skipped without the variable).  Expected: the pack launch (11 us at 4K) and one dispatch
 	// off the chain that is the frame when SMAA runs.
