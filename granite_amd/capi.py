@@ -285,9 +285,6 @@ def load_library() -> C.CDLL:
         "gr_blit": (C.c_int, [vp, vp, P(Image), P(Image), C.c_int]),
         "gr_smaa_edge_detection": (C.c_int, [vp, vp, P(Image), P(Image), P(PushSmaa), C.c_int]),
         "gr_smaa_blend_weight": (C.c_int, [vp, vp, P(Image), P(Image), P(PushSmaa), C.c_int]),
-        "gr_smaa_edges_with_planes_supported": (C.c_int, [vp, P(Image), P(PushSmaa)]),
-        "gr_smaa_edges_with_planes": (C.c_int, [vp, vp, P(Image), P(Image), P(PushSmaa), C.c_int]),
-        "gr_smaa_blend_weight_planes": (C.c_int, [vp, vp, P(Image), P(Image), P(PushSmaa), C.c_int]),
         "gr_smaa_neighbor_blend": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushSmaa)]),
         "gr_taa_resolve": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), P(Image), P(Image), P(PushTaa), C.c_int]),
         "gr_hiz": (C.c_int, [vp, vp, P(HizArgs)]),
@@ -539,17 +536,6 @@ class Context:
 
     def smaa_blend_weight(self, edges: DeviceImage, weights: DeviceImage, quality: int, stream=None):
         self.check(self.lib.gr_smaa_blend_weight(self.handle, stream, edges.desc, weights.desc, self._smaa_push(edges), quality))
-
-    def smaa_edges_with_planes(self, color: DeviceImage, edges: DeviceImage, quality: int, stream=None) -> bool:
-        """The edge pass writing the weight pass's bit planes with the edge texture; False (nothing launched) where it is not offered."""
-        if not self.lib.gr_smaa_edges_with_planes_supported(self.handle, color.desc, self._smaa_push(color)):
-            return False
-        self.check(self.lib.gr_smaa_edges_with_planes(self.handle, stream, color.desc, edges.desc, self._smaa_push(color), quality))
-        return True
-
-    def smaa_blend_weight_planes(self, edges: DeviceImage, weights: DeviceImage, quality: int, stream=None):
-        """The weight pass on the planes smaa_edges_with_planes wrote (raises unless that call wrote this edge texture on this stream)."""
-        self.check(self.lib.gr_smaa_blend_weight_planes(self.handle, stream, edges.desc, weights.desc, self._smaa_push(edges), quality))
 
     def smaa_neighbor_blend(self, color: DeviceImage, weights: DeviceImage, out: DeviceImage, stream=None):
         self.check(self.lib.gr_smaa_neighbor_blend(self.handle, stream, color.desc, weights.desc, out.desc, self._smaa_push(color)))

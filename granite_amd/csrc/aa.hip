@@ -556,7 +556,7 @@ int gr_smaa_edge_detection(gr_ctx *ctx, gr_stream stream, const gr_image *color,
 }
 
 // The bit planes of an edge texture of this size on this stream's allocation (grown on demand; one set per launch stream).
-static int smaa_planes_of(gr_ctx *ctx, gr_stream stream, uint32_t width, uint32_t height, SmaaBitPlanes &planes, gr_ctx::SmaaBits *&entry)
+static int smaa_planes_of(gr_ctx *ctx, gr_stream stream, uint32_t width, uint32_t height, SmaaBitPlanes &planes)
 {
 	planes = {};
 	planes.row_words = smaa_bit_words(int(width));
@@ -582,7 +582,6 @@ static int smaa_planes_of(gr_ctx *ctx, gr_stream stream, uint32_t width, uint32_
 				bits.bytes = need;
 		}
 		memory = static_cast<uint8_t *>(bits.memory);
-		entry = &bits;
 	}
 	if (!memory) // (outside the lock: fail() takes it)
 		return ctx->fail(GR_ERR_OUT_OF_MEMORY, "SMAA: %zu bytes of edge bit planes", need);
@@ -590,47 +589,6 @@ static int smaa_planes_of(gr_ctx *ctx, gr_stream stream, uint32_t width, uint32_
 	planes.row_g = reinterpret_cast<uint64_t *>(memory + row_plane);
 	planes.col_r = reinterpret_cast<uint64_t *>(memory + 2 * row_plane);
 	planes.col_g = reinterpret_cast<uint64_t *>(memory + 2 * row_plane + col_plane);
-	return GR_OK;
-}
-
-int gr_smaa_edges_with_planes_supported(gr_ctx *ctx, const gr_image *color, const gr_push_smaa *push)
-{
-	// OFF unless GR_SMAA_PLANES_FUSION=1: k_smaa_edges_planes equals the pack kernel byte for byte under the host emulation (9 sizes) and the
-	// entry points are exercised on the device-less runtime, but the round's GPU minutes ran out before the kernel ran on hardware
-	// (tests/test_gpu_aa.py has the test: it is skipped without the variable).  Expected: the pack launch (11 us at 4K) and one dispatch
-	// off the chain that is the frame when SMAA runs.
-	static const bool forced_generic = gr_measurement_switch("GRANITE_AA_GENERIC") != nullptr, on = gr_measurement_switch("GR_SMAA_PLANES_FUSION") != nullptr;
-	if (!ctx || !color || !push || forced_generic || !on || !color->width || !color->height || color->width > 16384 || color->height > 16384)
-		return 0;
-	return use_fast_aa(ctx, color->width, color->height, push->rt_metrics[0], push->rt_metrics[1]) ? 1 : 0;
-}
-
-int gr_smaa_edges_with_planes(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *edges, const gr_push_smaa *push, int quality)
-{
-	if (!ctx)
-		return GR_ERR_INVALID_ARGUMENT;
-	GR_CHECK_ARG(ctx, push && color && edges && color->width && color->height);
-	GR_CHECK_ARG(ctx, quality >= 0 && quality <= 3);
-	GR_CHECK_ARG(ctx, check_image(color, 4, color->width, color->height) && is_rgba8(color->format));
-	GR_CHECK_ARG(ctx, check_image(edges, 2, color->width, color->height) && edges->format == GR_FORMAT_R8G8_UNORM);
-	if (!gr_smaa_edges_with_planes_supported(ctx, color, push))
-		return ctx->fail(GR_ERR_INVALID_ARGUMENT, "gr_smaa_edges_with_planes: not offered for this image (gr_smaa_edges_with_planes_supported)");
-	SmaaBitPlanes planes;
-	gr_ctx::SmaaBits *entry = nullptr;
-	const int code = smaa_planes_of(ctx, stream, color->width, color->height, planes, entry);
-	if (code != GR_OK)
-		return code;
-	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_edge_detection"};
-	hipLaunchKernelGGL(k_smaa_edges_planes, fast_grid(color->width, color->height), dim3(FAST_BW, FAST_BH), 0, gr_to_stream(stream),
-	                   static_cast<const uint8_t *>(color->ptr), color->pitch_bytes, int(color->width), int(color->height), static_cast<uint8_t *>(edges->ptr),
-	                   edges->pitch_bytes, smaa_preset(quality).threshold, planes);
-	GR_CHECK_LAUNCH(ctx);
-	{
-		std::lock_guard<std::mutex> holder{ctx->lock};
-		entry->current_edges = edges->ptr;
-		entry->current_width = edges->width;
-		entry->current_height = edges->height;
-	}
 	return GR_OK;
 }
 
@@ -646,13 +604,6 @@ int gr_smaa_edge_detection_rows(gr_ctx *ctx, gr_stream stream, const gr_image *c
 	const RowSpan span = resolve_rows(rows, color->height);
 	if (span.count() == 0)
 		return GR_OK;
-	{
-		// this call rewrites the edge texture without its planes: whatever planes named it are stale
-		std::lock_guard<std::mutex> holder{ctx->lock};
-		for (auto &bits : ctx->smaa_bits)
-			if (bits.second.current_edges == edges->ptr)
-				bits.second.current_edges = nullptr;
-	}
 	const bool fast = use_fast_aa(ctx, color->width, color->height, push->rt_metrics[0], push->rt_metrics[1]);
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_edge_detection"};
 	if (fast)
@@ -671,35 +622,8 @@ int gr_smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, c
 	return gr_smaa_blend_weight_rows(ctx, stream, edges, weights, push, quality, nullptr);
 }
 
-static int smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality,
-                             const gr_rows *rows, bool planes_current);
-
 int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality,
                               const gr_rows *rows)
-{
-	return smaa_blend_weight(ctx, stream, edges, weights, push, quality, rows, false);
-}
-
-int gr_smaa_blend_weight_planes(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality)
-{
-	if (!ctx)
-		return GR_ERR_INVALID_ARGUMENT;
-	GR_CHECK_ARG(ctx, edges != nullptr);
-	bool current = false;
-	{
-		std::lock_guard<std::mutex> holder{ctx->lock};
-		const auto itr = ctx->smaa_bits.find(stream);
-		current = itr != ctx->smaa_bits.end() && itr->second.current_edges == edges->ptr && itr->second.current_width == edges->width &&
-		          itr->second.current_height == edges->height;
-	}
-	if (!current) // (outside the lock: fail() takes it)
-		return ctx->fail(GR_ERR_INVALID_ARGUMENT, "gr_smaa_blend_weight_planes: this stream's bit planes do not hold this edge texture (gr_smaa_edges_with_planes "
-		                                          "must be the call that wrote it, on this stream)");
-	return smaa_blend_weight(ctx, stream, edges, weights, push, quality, nullptr, true);
-}
-
-static int smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality,
-                             const gr_rows *rows, bool planes_current)
 {
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
@@ -724,16 +648,9 @@ static int smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edge
 	if (!forced_generic && edges->width <= 16384 && edges->height <= 16384)
 	{
 		SmaaBitPlanes planes;
-		gr_ctx::SmaaBits *entry = nullptr;
-		const int code = smaa_planes_of(ctx, stream, edges->width, edges->height, planes, entry);
+		const int code = smaa_planes_of(ctx, stream, edges->width, edges->height, planes);
 		if (code != GR_OK)
 			return code;
-		// planes_current: gr_smaa_blend_weight_planes -- the edge pass of this stream wrote them with the texture (checked there)
-		if (!planes_current)
-		{
-			std::lock_guard<std::mutex> holder{ctx->lock};
-			entry->current_edges = nullptr; // the pack launch below rewrites them (for a band of rows, possibly)
-		}
 		// tiles of 64 padded rows the band's workgroups stage from: rows first - 127 .. end + 175 (+ the block rounding)
 		const int tile_first = max(0, (int(span.first) - 128 + SMAA_BITS_PAD) >> 6);
 		const int tile_last = min(planes.col_words - 1, (int(span.end) + FAST_BH + 192 + SMAA_BITS_PAD) >> 6);
@@ -744,9 +661,8 @@ static int smaa_blend_weight(gr_ctx *ctx, gr_stream stream, const gr_image *edge
 		B.diag_walks_exact = S.P.diag && B.centres_snap && !float_walks && diag_walk_exact(ctx, edges->width, push->rt_metrics[0], true) &&
 		                     diag_walk_exact(ctx, edges->height, push->rt_metrics[1], false);
 		gr_scoped_timing timing{ctx, gr_to_stream(stream), "smaa_blend_weight"};
-		if (!planes_current)
-			hipLaunchKernelGGL(k_smaa_pack_edges, dim3(tiles), dim3(256), 0, gr_to_stream(stream), B.edges, B.edges_pitch, B.w, B.h, planes,
-			                   tile_first, tile_last - tile_first + 1);
+		hipLaunchKernelGGL(k_smaa_pack_edges, dim3(tiles), dim3(256), 0, gr_to_stream(stream), B.edges, B.edges_pitch, B.w, B.h, planes,
+		                   tile_first, tile_last - tile_first + 1);
 		hipLaunchKernelGGL(k_smaa_weights_bits, fast_grid(edges->width, span.count()), dim3(FAST_BW, FAST_BH), 0, gr_to_stream(stream), B,
 		                   static_cast<uint8_t *>(weights->ptr), weights->pitch_bytes, span);
 		GR_CHECK_LAUNCH(ctx);

@@ -286,22 +286,12 @@ int gr_alloc(gr_ctx *ctx, size_t bytes, void **dptr)
 	return GR_OK;
 }
 
-// Whoever rewrites or releases an edge texture ends the claim of SMAA bit planes to hold its bits (gr_smaa_edges_with_planes).
-static void drop_smaa_plane_claims(gr_ctx *ctx, const void *image)
-{
-	std::lock_guard<std::mutex> holder{ctx->lock};
-	for (auto &bits : ctx->smaa_bits)
-		if (bits.second.current_edges == image)
-			bits.second.current_edges = nullptr;
-}
-
 int gr_free(gr_ctx *ctx, void *dptr)
 {
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	if (dptr)
 	{
-		drop_smaa_plane_claims(ctx, dptr); // (the address may come back as another image)
 		GR_CHECK_HIP(ctx, hipFree(dptr));
 	}
 	return GR_OK;
@@ -312,7 +302,6 @@ int gr_upload(gr_ctx *ctx, gr_stream stream, void *dst, const void *src_host, si
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, dst && src_host);
-	drop_smaa_plane_claims(ctx, dst);
 	GR_CHECK_HIP(ctx, hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, gr_to_stream(stream)));
 	return GR_OK;
 }
@@ -418,7 +407,6 @@ int gr_copy(gr_ctx *ctx, gr_stream stream, void *dst, const void *src, size_t by
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, dst && src);
-	drop_smaa_plane_claims(ctx, dst);
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "copy"};
 	GR_CHECK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, gr_to_stream(stream)));
 	return GR_OK;
@@ -429,7 +417,6 @@ int gr_fill_zero(gr_ctx *ctx, gr_stream stream, void *dst, size_t bytes)
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, dst);
-	drop_smaa_plane_claims(ctx, dst);
 	GR_CHECK_HIP(ctx, hipMemsetAsync(dst, 0, bytes, gr_to_stream(stream)));
 	return GR_OK;
 }
@@ -439,7 +426,6 @@ int gr_fill_byte(gr_ctx *ctx, gr_stream stream, void *dst, int value, size_t byt
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, dst);
-	drop_smaa_plane_claims(ctx, dst);
 	GR_CHECK_HIP(ctx, hipMemsetAsync(dst, value & 0xff, bytes, gr_to_stream(stream)));
 	return GR_OK;
 }
@@ -485,7 +471,6 @@ int gr_fill_u32(gr_ctx *ctx, gr_stream stream, void *dst, uint32_t value, size_t
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
 	GR_CHECK_ARG(ctx, dst && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0);
-	drop_smaa_plane_claims(ctx, dst);
 	GR_CHECK_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dst), int(value), count, gr_to_stream(stream)));
 	return GR_OK;
 }

@@ -53,9 +53,6 @@ struct gr_ctx
 	{
 		void *memory = nullptr;
 		size_t bytes = 0;
-		// the edge texture whose bits the planes hold, when gr_smaa_edges_with_planes wrote them (gr_smaa_blend_weight_planes checks)
-		const void *current_edges = nullptr;
-		uint32_t current_width = 0, current_height = 0;
 	};
 	std::map<void *, SmaaBits> smaa_bits;
 

@@ -175,39 +175,22 @@ void setup_smaa_postprocess(RenderGraph &graph, TemporalJitter &jitter, float, c
 	// Both kernels write every pixel (0 where the shader would discard / be masked), which subsumes the reference's
 	// LOAD_OP_CLEAR to 0 (smaa.cpp:139-143,180-184): no get_clear_color callbacks are installed.
 	// Row bands (plan): each pass covers the rows the next one reads around this rank's output chunk (StripPlan::build).
-	// Whole-image frames: the edge pass writes the bit planes the weight pass searches together with the edge texture
-	// (gr_smaa_edges_with_planes), and the weight pass -- the next pass on the same stream -- skips its packing launch.  What the edge
-	// pass of this frame did travels to the weight pass in `planes_written`.
-	auto planes_written = std::make_shared<bool>(false);
-	smaa_edge.set_build_render_pass([&graph, &edge_input_res, &edge_output_res, metrics, q = smaa_quality, plan, planes_written](HIP::CommandBuffer &cmd) {
+	smaa_edge.set_build_render_pass([&graph, &edge_input_res, &edge_output_res, metrics, q = smaa_quality, plan](HIP::CommandBuffer &cmd) {
 		const StripPlan *strip = live(plan);
 		auto &input_image = graph.get_physical_texture_resource(edge_input_res);
 		auto &edges = graph.get_physical_texture_resource(edge_output_res);
 		auto push = metrics(input_image);
-		*planes_written = false;
-		if (!strip && gr_smaa_edges_with_planes_supported(cmd.get_context(), &input_image.get_view(), &push))
-		{
-			cmd.check(gr_smaa_edges_with_planes(cmd.get_context(), cmd.get_stream(), &input_image.get_view(), &edges.get_view(), &push, q), "smaa-edge");
-			*planes_written = true;
-			return;
-		}
 		gr_rows rows;
 		if (to_rows(strip ? &strip->smaa_edges : nullptr, rows))
 			cmd.check(gr_smaa_edge_detection_rows(cmd.get_context(), cmd.get_stream(), &input_image.get_view(), &edges.get_view(), &push, q, &rows),
 			          "smaa-edge");
 	});
 
-	smaa_weight.set_build_render_pass([&graph, &weight_input_res, &weight_output_res, metrics, q = smaa_quality, plan, planes_written](HIP::CommandBuffer &cmd) {
+	smaa_weight.set_build_render_pass([&graph, &weight_input_res, &weight_output_res, metrics, q = smaa_quality, plan](HIP::CommandBuffer &cmd) {
 		const StripPlan *strip = live(plan);
 		auto &edges = graph.get_physical_texture_resource(weight_input_res);
 		auto &weights = graph.get_physical_texture_resource(weight_output_res);
 		auto push = metrics(edges);
-		if (!strip && *planes_written)
-		{
-			*planes_written = false;
-			cmd.check(gr_smaa_blend_weight_planes(cmd.get_context(), cmd.get_stream(), &edges.get_view(), &weights.get_view(), &push, q), "smaa-weights");
-			return;
-		}
 		gr_rows rows;
 		if (to_rows(strip ? &strip->smaa_weights : nullptr, rows))
 			cmd.check(gr_smaa_blend_weight_rows(cmd.get_context(), cmd.get_stream(), &edges.get_view(), &weights.get_view(), &push, q, &rows),

@@ -541,101 +541,6 @@ __global__ __launch_bounds__(256) void k_smaa_pack_edges(const uint8_t *edges, u
 	}
 }
 
-// The edge pass of a WHOLE image writing the bit planes itself (gr_smaa_edges_with_planes): what k_smaa_pack_edges would read back
-// from the edge texture goes out with the texture, and the pack launch -- 11 us at 4K and one more dispatch on the chain that is the
-// frame when SMAA runs -- is not needed.  A 32 x 16 tile is half a 64-bit row word for sixteen rows and a quarter of a column word for
-// thirty-two columns; 192 is a multiple of both, so a tile's share of a plane is whole 32-bit / 16-bit units that nobody else writes.
-// The clamp-to-edge replicas the pack kernel makes by reading clamped belong to the tiles on the border of the image: the leftmost
-// tile of a tile row also writes the 192 pad columns in front of it (all ones or all zeros, after its first flag), the rightmost the
-// columns behind it up to the end of the plane (after its last flag, which in a partial tile is itself the replica of column w - 1:
-// every thread evaluates the pixel its coordinate clamps to), the top and bottom tiles repeat their first / last row through the pad
-// rows, corner tiles the products.  Every unit of every plane is written by exactly one workgroup, the same bits as k_smaa_pack_edges.
-static_assert(FAST_BW == 32 && FAST_BH == 16 && SMAA_BITS_PAD % FAST_BW == 0 && SMAA_BITS_PAD % FAST_BH == 0, "a tile's share of a plane is whole 32-bit / 16-bit units");
-__global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_edges_planes(const uint8_t *in, uint32_t in_pitch, int w, int h, uint8_t *edges, uint32_t edges_pitch,
-                                                                         float threshold, SmaaBitPlanes planes)
-{
-	constexpr int TW = EdgeLumaTile::W, TH = EdgeLumaTile::H, THREADS = FAST_BW * FAST_BH;
-	__shared__ float s_luma[TW * TH];
-	__shared__ uint8_t s_flags[FAST_BH][FAST_BW]; // bit 0: R (edge at the left), bit 1: G (edge at the top)
-	__shared__ uint32_t s_row[2][FAST_BH];        // [plane][tile row]: its 32 flags
-	__shared__ uint32_t s_col[2][FAST_BW];        // [plane][tile column]: its 16 flags
-	const int bx = blockIdx.x * FAST_BW, by = blockIdx.y * FAST_BH;
-	const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * FAST_BW + tx, lane = tid & 63, wave = tid >> 6;
-	for (int i = tid; i < TW * TH; i += THREADS)
-	{
-		const int ly = i / TW, lx = i - ly * TW;
-		const uint32_t t = load_rgba8_clamped(in, in_pitch, w, h, bx - 2 + lx, by - 2 + ly);
-		s_luma[i] = aa::luma_of(aa::unorm8_decode(t & 255u), aa::unorm8_decode((t >> 8) & 255u), aa::unorm8_decode((t >> 16) & 255u), aa::SMAA_LUMA_R,
-		                        aa::SMAA_LUMA_G, aa::SMAA_LUMA_B);
-	}
-	__syncthreads();
-	const int x = bx + tx, y = by + ty;
-	const EdgeLumaTile tile = {s_luma, bx - 2, by - 2};
-	const uint32_t e = aa::smaa_edges_pixel(tile, min(x, w - 1), min(y, h - 1), threshold); // beyond the image: the pixel the coordinate clamps to
-	if (x < w && y < h)
-		*reinterpret_cast<uint16_t *>(edges + (uint32_t(y) * edges_pitch + uint32_t(x) * 2u)) = uint16_t(e);
-	const bool er = (e & 255u) != 0u, eg = (e >> 8) != 0u;
-	s_flags[ty][tx] = uint8_t((er ? 1u : 0u) | (eg ? 2u : 0u));
-	const uint64_t word_r = __ballot(er), word_g = __ballot(eg); // a wave is two tile rows
-	if (lane == 0)
-	{
-		s_row[0][2 * wave] = uint32_t(word_r), s_row[0][2 * wave + 1] = uint32_t(word_r >> 32);
-		s_row[1][2 * wave] = uint32_t(word_g), s_row[1][2 * wave + 1] = uint32_t(word_g >> 32);
-	}
-	__syncthreads();
-	if (tid < 2 * FAST_BW)
-	{
-		const int plane = tid / FAST_BW, column = tid % FAST_BW;
-		uint32_t bits = 0;
-#pragma unroll
-		for (int r = 0; r < FAST_BH; r++)
-			bits |= ((uint32_t(s_flags[r][column]) >> plane) & 1u) << r;
-		s_col[plane][column] = bits;
-	}
-	__syncthreads();
-	const bool left = bx == 0, right = bx + FAST_BW >= w, top = by == 0, bottom = by + FAST_BH >= h;
-	{
-		// row planes as 32-bit words: word k of plane row r holds columns 32 k - PAD .. of image row r - PAD
-		uint32_t *const plane_words[2] = {reinterpret_cast<uint32_t *>(planes.row_r), reinterpret_cast<uint32_t *>(planes.row_g)};
-		const int stride = planes.row_words * 2, own = (bx + SMAA_BITS_PAD) >> 5;
-		const int k0 = left ? 0 : own, k1 = right ? stride - 1 : own;
-		const int r0 = top ? 0 : by + SMAA_BITS_PAD, r1 = bottom ? planes.rows() - 1 : by + SMAA_BITS_PAD + FAST_BH - 1;
-		const int nk = k1 - k0 + 1, count = nk * (r1 - r0 + 1);
-		for (int i = tid; i < count; i += THREADS)
-		{
-			const int r = r0 + i / nk, k = k0 + i % nk;
-			const int row_of_tile = aa::clampi(r - (by + SMAA_BITS_PAD), 0, FAST_BH - 1);
-#pragma unroll
-			for (int plane = 0; plane < 2; plane++)
-			{
-				const uint32_t flags = s_row[plane][row_of_tile];
-				const uint32_t value = k == own ? flags : (k < own ? ((flags & 1u) ? 0xffffffffu : 0u) : ((flags >> 31) ? 0xffffffffu : 0u));
-				plane_words[plane][size_t(r) * stride + k] = value;
-			}
-		}
-	}
-	{
-		// column planes as 16-bit units: unit u of plane column c holds rows 16 u - PAD .. of image column c - PAD
-		uint16_t *const plane_units[2] = {reinterpret_cast<uint16_t *>(planes.col_r), reinterpret_cast<uint16_t *>(planes.col_g)};
-		const int stride = planes.col_words * 4, own = (by + SMAA_BITS_PAD) >> 4;
-		const int u0 = top ? 0 : own, u1 = bottom ? stride - 1 : own;
-		const int c0 = left ? 0 : bx + SMAA_BITS_PAD, c1 = right ? planes.cols() - 1 : bx + SMAA_BITS_PAD + FAST_BW - 1;
-		const int nu = u1 - u0 + 1, count = nu * (c1 - c0 + 1);
-		for (int i = tid; i < count; i += THREADS)
-		{
-			const int c = c0 + i / nu, u = u0 + i % nu;
-			const int column_of_tile = aa::clampi(c - (bx + SMAA_BITS_PAD), 0, FAST_BW - 1);
-#pragma unroll
-			for (int plane = 0; plane < 2; plane++)
-			{
-				const uint32_t flags = s_col[plane][column_of_tile];
-				const uint32_t value = u == own ? flags : (u < own ? ((flags & 1u) ? 0xffffu : 0u) : (((flags >> (FAST_BH - 1)) & 1u) ? 0xffffu : 0u));
-				plane_units[plane][size_t(c) * stride + u] = uint16_t(value);
-			}
-		}
-	}
-}
-
 struct EdgeBitTiles
 {
 	static constexpr bool HAS_RUNS = true;

@@ -491,15 +491,6 @@ int gr_smaa_blend_weight_rows(gr_ctx *ctx, gr_stream stream, const gr_image *edg
                               int quality, const gr_rows *rows);
 int gr_smaa_neighbor_blend_rows(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *weights, const gr_image *out,
                                 const gr_push_smaa *push, const gr_rows *rows);
-/* smaa-edge and smaa-weights recorded back to back on one stream (smaa.cpp:95-190), whole images: the weight pass searches bit planes
- * of the edge texture, which gr_smaa_blend_weight first packs from it (a launch of its own).  gr_smaa_edges_with_planes writes them with
- * the texture (same bytes in the texture, same bits in the planes); gr_smaa_blend_weight_planes then skips the packing.  It fails
- * (GR_ERR_INVALID_ARGUMENT) unless the stream's planes hold exactly this edge texture, i.e. gr_smaa_edges_with_planes on this stream was
- * the call that wrote it.  ..._supported(): the sizes and sampler conditions the fast anti-aliasing kernels ask for. */
-int gr_smaa_edges_with_planes_supported(gr_ctx *ctx, const gr_image *color, const gr_push_smaa *push);
-int gr_smaa_edges_with_planes(gr_ctx *ctx, gr_stream stream, const gr_image *color, const gr_image *edges, const gr_push_smaa *push, int quality);
-int gr_smaa_blend_weight_planes(gr_ctx *ctx, gr_stream stream, const gr_image *edges, const gr_image *weights, const gr_push_smaa *push, int quality);
-
 /* setup_taa_resolve (temporal.cpp:199-266) + taa_resolve.frag.  quality 0..2 = TAAQuality Low/Medium/High.
  * history NULL => REPROJECTION_HISTORY = 0 (first frame).  current/out_color/history: R16G16B16A16_SFLOAT,
  * depth D32_SFLOAT, mv R16G16_SFLOAT.  reproj = T(.5,.5,0) S(.5,.5,1) VP_prev inv(VP_cur) (temporal.cpp:239-243). */

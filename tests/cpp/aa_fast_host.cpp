@@ -104,35 +104,6 @@ void aah_taa_band(const uint8_t *current, const uint8_t *depth, const uint8_t *m
 		emu::launch(k_taa_fast<2, true>, grid, block, im, push, rows);
 }
 
-// gr_smaa_edges_with_planes against gr_smaa_edge_detection + the pack kernel of gr_smaa_blend_weight: 0 when the edge textures and all
-// four bit planes agree byte for byte, else the 1-based index of the first buffer that differs (edges, row R, row G, column R, column G).
-int aah_smaa_edges_planes_check(const uint8_t *in, int w, int h, float threshold, uint8_t *edges_out)
-{
-	const RowSpan rows = span_of(h, 0, 0);
-	std::vector<uint8_t> edges(size_t(w) * h * 2, 0xCD);
-	emu::launch(k_smaa_edges_fast, dim3(div_up(w, FAST_BW), div_up(h, FAST_BH)), dim3(FAST_BW, FAST_BH), in, uint32_t(w * 4), w, h, edges.data(), uint32_t(w * 2),
-	            threshold, rows);
-	SmaaBitPlanes want = {}, got = {};
-	want.row_words = got.row_words = smaa_bit_words(w);
-	want.col_words = got.col_words = smaa_bit_words(h);
-	const size_t row_n = size_t(want.rows()) * want.row_words, col_n = size_t(want.cols()) * want.col_words;
-	std::vector<uint64_t> a_rr(row_n, 0xA5A5A5A5A5A5A5A5ull), a_rg(a_rr), a_cr(col_n, 0x5A5A5A5A5A5A5A5Aull), a_cg(a_cr);
-	std::vector<uint64_t> b_rr(row_n, 0x1111111111111111ull), b_rg(b_rr), b_cr(col_n, 0x2222222222222222ull), b_cg(b_cr);
-	want.row_r = a_rr.data(), want.row_g = a_rg.data(), want.col_r = a_cr.data(), want.col_g = a_cg.data();
-	got.row_r = b_rr.data(), got.row_g = b_rg.data(), got.col_r = b_cr.data(), got.col_g = b_cg.data();
-	emu::launch(k_smaa_pack_edges, dim3(want.row_words * want.col_words), dim3(256), edges.data(), uint32_t(w * 2), w, h, want, 0, want.col_words);
-	std::vector<uint8_t> edges2(size_t(w) * h * 2, 0xCD);
-	emu::launch(k_smaa_edges_planes, dim3(div_up(w, FAST_BW), div_up(h, FAST_BH)), dim3(FAST_BW, FAST_BH), in, uint32_t(w * 4), w, h, edges2.data(), uint32_t(w * 2),
-	            threshold, got);
-	memcpy(edges_out, edges2.data(), edges2.size());
-	if (edges != edges2) return 1;
-	if (a_rr != b_rr) return 2;
-	if (a_rg != b_rg) return 3;
-	if (a_cr != b_cr) return 4;
-	if (a_cg != b_cg) return 5;
-	return 0;
-}
-
 // SMAA.hlsl:304-324
 static SmaaPreset preset_of(int quality)
 {

@@ -102,20 +102,6 @@ def test_smaa_edge_kernel_equals_oracle(host, w, h, kind, quality):
     assert ref.any()
 
 
-@pytest.mark.parametrize("w,h,kind", [(70, 40, "pattern"), (67, 35, "noise"), (33, 17, "pattern"), (8, 8, "noise"), (64, 32, "noise"), (65, 33, "noise"),
-                                      (1, 1, "noise"), (200, 3, "noise"), (5, 120, "noise")])
-def test_edge_pass_that_writes_the_bit_planes_equals_edge_pass_plus_pack_kernel(host, w, h, kind):
-    """k_smaa_edges_planes (gr_smaa_edges_with_planes): the edge texture is the oracle's and the four bit planes -- the tile's own units,
-    the pad replicas written by the tiles on the image's border, partial tiles, images smaller than a tile -- are byte for byte what
-    k_smaa_pack_edges makes of that texture.  (Every unit is written: the two sets of planes start from different poison values.)"""
-    src = source(w, h, kind)
-    edges = np.full((h, w, 2), 0xCD, np.uint8)
-    host.aah_smaa_edges_planes_check.restype = C.c_int
-    differs = host.aah_smaa_edges_planes_check(p(src), w, h, C.c_float(PRESET_THRESHOLD[3]), p(edges))
-    assert differs == 0, ("edges", "row R", "row G", "column R", "column G")[differs - 1]
-    np.testing.assert_array_equal(edges, orc.smaa_edges(src, 3))
-
-
 @pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("w,h,kind", [(72, 40, "pattern"), (68, 36, "noise"), (8, 8, "noise"), (67, 35, "noise")])
 def test_smaa_blend_kernel_equals_oracle(host, w, h, kind, wide):

@@ -80,35 +80,6 @@ def test_smaa_passes(gr, luts, quality, w, h, kind):
         np.testing.assert_array_equal(dwt.download(), ref["weights"])
 
 
-@pytest.mark.skipif(os.environ.get("GR_SMAA_PLANES_FUSION") is None,
-                    reason="gr_smaa_edges_with_planes is off by default until it has run on hardware (GR_SMAA_PLANES_FUSION=1 turns it on and this test with it)")
-@pytest.mark.parametrize("quality,w,h,kind", [(3, 3840, 2160, "pattern"), (3, 1920, 1080, "noise"), (2, 253, 127, "pattern"), (0, 200, 120, "noise"), (3, 33, 17, "noise"),
-                                              (3, 8, 8, "pattern")])
-def test_smaa_edge_pass_that_writes_the_bit_planes(gr, luts, quality, w, h, kind):
-    """gr_smaa_edges_with_planes + gr_smaa_blend_weight_planes (the edge pass writes the weight pass's bit planes with the edge texture, no
-    packing launch) leave the bytes of gr_smaa_edge_detection + gr_smaa_blend_weight in both targets -- 4K, partial tiles, images smaller than
-    a tile -- and the weight pass refuses planes that do not hold its edge texture."""
-    gr.smaa_set_luts(*luts)
-    src = synth.make_ldr_pattern(w, h) if kind == "pattern" else tonemapped_like(w, h)
-    dsrc = capi.DeviceImage(gr, w, h, RGBA8).upload(src)
-    want_e, want_w = capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8_UNORM), capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8B8A8_UNORM)
-    gr.smaa_edge_detection(dsrc, want_e, quality)
-    gr.smaa_blend_weight(want_e, want_w, quality)
-    got_e, got_w = capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8_UNORM), capi.DeviceImage(gr, w, h, capi.FORMAT_R8G8B8A8_UNORM)
-    with pytest.raises(capi.GraniteHipError):
-        gr.smaa_blend_weight_planes(got_e, got_w, quality)  # nobody wrote planes for this texture
-    assert gr.smaa_edges_with_planes(dsrc, got_e, quality)
-    gr.smaa_blend_weight_planes(got_e, got_w, quality)
-    gr.sync()
-    np.testing.assert_array_equal(got_e.download(), want_e.download(), err_msg="edges")
-    np.testing.assert_array_equal(got_w.download(), want_w.download(), err_msg="weights")
-    assert want_w.download().any()
-    # the plain edge pass rewrites the texture without its planes: they are stale from then on
-    gr.smaa_edge_detection(dsrc, got_e, quality)
-    with pytest.raises(capi.GraniteHipError):
-        gr.smaa_blend_weight_planes(got_e, got_w, quality)
-
-
 def taa_inputs(w, h, seed=3):
     cam = synth.Camera(w, h)
     gbuf = synth.make_gbuffer(cam, seed)
