@@ -65,7 +65,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="config3_4k_4096lights", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sustain-seconds", type=float, default=1.0, help="length of the unbracketed run after the timed region (0 = off)")
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
+                    help="length of the unbracketed run after the timed region (0 = off); 6 s by default so that a 5 s utilisation sampler sees the GPU busy")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     return ap.parse_args()
 
@@ -333,25 +334,69 @@ def main():
     plan = application.strip_plan()
     kctx = application.kernel_context()
 
-    # ---- outside the timed region: the frame the bands assembled (4 set-up frames so far) against the same frames of ONE executor
-    # rendering the whole target on rank 0's GPU -- every byte of the backbuffer must agree (GRANITE_BENCH_CHECK_BANDS=0 skips it).
-    bands_checked = None
-    if bands and os.environ.get("GRANITE_BENCH_CHECK_BANDS", "1") == "1":
+    def check_bands(app, cam_, gbuf_, descs_, w_, h_):
+        """Outside the timed region: the frame the bands assembled (4 set-up frames so far) against the same frames of ONE executor rendering
+        the whole target on rank 0's GPU -- every byte of the backbuffer must agree (GRANITE_BENCH_CHECK_BANDS=0 skips it)."""
+        if os.environ.get("GRANITE_BENCH_CHECK_BANDS", "1") != "1":
+            return None
         verdict = torch.tensor([1], dtype=torch.int32)
         if rank == 0:
             try:
-                whole = gapp.Application(width, height, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True, compute_post=True)
-                whole.set_render_parameters(cam.render_params())
-                whole.set_lights(descs)
-                whole.upload_gbuffer(gbuf)
+                whole = gapp.Application(w_, h_, device=local_rank, lighting=True, hdr_bloom=True, dynamic_exposure=True, compute_post=True)
+                whole.set_render_parameters(cam_.render_params())
+                whole.set_lights(descs_)
+                whole.upload_gbuffer(gbuf_)
                 whole.render_frames(4, sync=True)
-                verdict[0] = int(np.array_equal(whole.read_backbuffer(), application.read_backbuffer()))
+                verdict[0] = int(np.array_equal(whole.read_backbuffer(), app.read_backbuffer()))
                 whole.close()
             except Exception as e:  # noqa: BLE001 - e.g. not enough HBM for the whole frame beside the band
                 print(f"[bench] band check not possible: {type(e).__name__}: {e}", file=sys.stderr)
                 verdict[0] = -1
         dist.broadcast(verdict, src=0)
-        bands_checked = None if int(verdict.item()) < 0 else bool(int(verdict.item()))
+        return None if int(verdict.item()) < 0 else bool(int(verdict.item()))
+
+    def gather_brackets(per_kernel_, kctx_):
+        """Row bands: device time of the two collectives on their streams (hipEvent brackets like every launcher's; "inframe_gather" = the
+        1/8 bloom level inside the frame, "output_gather" = the finished bands beside it), from fully bracketed warm-up frames."""
+        found = {}
+        for name in ("inframe_gather", "output_gather"):
+            if name in per_kernel_ and per_kernel_[name][0]:
+                found[name] = {"mean": 1000.0 * per_kernel_[name][1] / per_kernel_[name][0], "max": 1000.0 * kctx_.timing_max_ms(name),
+                               "brackets": int(per_kernel_[name][0])}
+        return found
+
+    def rccl_record(app, plan_, w_, h_, gather_us_, og0_, og1_, rank_ms_):
+        """What the communicator itself says (did RCCL see N ranks, which library version, how many bytes each rank sends per frame), the
+        per-collective device time -- mean on this rank and the max over the ranks: one slow link shows up as the max -- and whether the
+        output gather stayed hidden: `waits` = times a pass of a later frame found the gather of the image it was about to overwrite
+        still in flight during the timed steps (0 = every gather had finished before its image was needed again)."""
+        info = app.comm_info()
+        out_rows = plan_["out_chunk_rows"] if "out_chunk_rows" in plan_ else -(-h_ // world)
+        packed_rgb = os.environ.get("GRANITE_BENCH_GATHER_RGBA", "0") != "1"
+        info.update({"output_bytes_per_rank": int(out_rows) * w_ * (3 if packed_rgb else 4),
+                     "bloom_level_bytes_per_rank": int(plan_["d1_chunk_rows"]) * (w_ // 8) * 8 if "d1_chunk_rows" in plan_ else None,
+                     "ms_per_step_over_ranks": rank_ms_})
+        for name, key in (("inframe_gather", "inframe_gather_us"), ("output_gather", "output_gather_us")):
+            mine = gather_us_.get(name)
+            t = torch.tensor([mine["mean"] if mine else -1.0, mine["max"] if mine else -1.0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            info[key] = None if mine is None and float(t[0]) < 0 else {"mean_rank0": mine["mean"] if mine else None, "mean_max_over_ranks": float(t[0]),
+                                                                        "max_over_ranks": float(t[1]), "source": "hipEvent brackets on the collective's stream, warm-up frames"}
+        waits = torch.tensor([og1_["waits"] - og0_["waits"], og1_["acquires"] - og0_["acquires"]], dtype=torch.int64)
+        dist.all_reduce(waits, op=dist.ReduceOp.MAX)
+        info["output_gather_waits_in_timed_steps"] = int(waits[0])
+        info["overlapped"] = bool(int(waits[1]) > 0 and int(waits[0]) == 0) if os.environ.get("GRANITE_BENCH_GATHER", "beside") != "inframe" else False
+        return info
+
+    def over_ranks(seconds, steps):
+        """every rank's own clock over the same K steps: the spread says whether one rank (or one link) holds the others up"""
+        mine = torch.tensor([seconds], dtype=torch.float64)
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return {"min": 1000.0 * float(lo.item()) / steps, "max": 1000.0 * float(hi.item()) / steps}, float(hi.item())
+
+    bands_checked = check_bands(application, cam, gbuf, descs, width, height) if bands else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -382,13 +427,7 @@ def main():
     known = {k: v for k, v in per_kernel.items() if k in ALGO_BYTES_PER_PX and k != "chain" and v[0]}
     dominant = max(known.items(), key=lambda kv: kv[1][1] / kv[1][0])[0] if known else "lighting"
     warm_breakdown = {k: {"launches": c, "avg_us": 1000.0 * ms / max(c, 1)} for k, (c, ms) in per_kernel.items()}
-    # Row bands: device time of the two collectives on their streams (hipEvent brackets like every launcher's; "inframe_gather" = the
-    # 1/8 bloom level inside the frame, "output_gather" = the finished bands beside it), from these fully bracketed warm-up frames.
-    gather_us = {}
-    for name in ("inframe_gather", "output_gather"):
-        if name in per_kernel and per_kernel[name][0]:
-            gather_us[name] = {"mean": 1000.0 * per_kernel[name][1] / per_kernel[name][0], "max": 1000.0 * kctx.timing_max_ms(name),
-                               "brackets": int(per_kernel[name][0])}
+    gather_us = gather_brackets(per_kernel, kctx)
 
     # ---- timed region: only the dominant kernel keeps its hipEvent bracket, on every BRACKET_EVERY-th launch.  (An event
     # pair around a kernel stops the command processor from overlapping it with its neighbours on the stream: bracketing
@@ -458,13 +497,7 @@ def main():
 
     rank_ms = None
     if dist is not None:
-        # every rank's own clock over the same K steps: the spread says whether one rank (or one link) holds the others up
-        mine = torch.tensor([elapsed], dtype=torch.float64)
-        lo, hi = mine.clone(), mine.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        rank_ms = {"min": 1000.0 * float(lo.item()) / args.steps, "max": 1000.0 * float(hi.item()) / args.steps}
-        elapsed = float(hi.item())
+        rank_ms, elapsed = over_ranks(elapsed, args.steps)
 
     # one frame per step: at N > 1 its row bands are spread over the ranks; in the replicas fallback every rank renders its own
     pixels_per_step = width * height * (1 if bands or world == 1 else world)
@@ -576,26 +609,7 @@ def main():
     if bands:
         # the assembled frame == the same frames of one executor rendering the whole target (null = check skipped / not possible)
         result["bands_checked"] = bands_checked
-        # what the communicator itself says: did RCCL see N ranks, which library version, how many bytes each rank sends per frame
-        info = application.comm_info()
-        out_rows = plan["out_chunk_rows"] if "out_chunk_rows" in plan else -(-height // world)
-        packed_rgb = os.environ.get("GRANITE_BENCH_GATHER_RGBA", "0") != "1"
-        info.update({"output_bytes_per_rank": int(out_rows) * width * (3 if packed_rgb else 4),
-                     "bloom_level_bytes_per_rank": int(plan["d1_chunk_rows"]) * (width // 8) * 8 if "d1_chunk_rows" in plan else None,
-                     "ms_per_step_over_ranks": rank_ms})
-        # Per-collective device time, mean on this rank and the max over the ranks (one slow link shows up as the max), and whether
-        # the output gather stayed hidden: `waits` = times a pass of a later frame found the gather of the image it was about to
-        # overwrite still in flight during the timed steps (0 = every gather had finished before its image was needed again).
-        for name, key in (("inframe_gather", "inframe_gather_us"), ("output_gather", "output_gather_us")):
-            mine = gather_us.get(name)
-            t = torch.tensor([mine["mean"] if mine else -1.0, mine["max"] if mine else -1.0], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            info[key] = None if mine is None and float(t[0]) < 0 else {"mean_rank0": mine["mean"] if mine else None, "mean_max_over_ranks": float(t[0]),
-                                                                        "max_over_ranks": float(t[1]), "source": "hipEvent brackets on the collective's stream, warm-up frames"}
-        waits = torch.tensor([og1["waits"] - og0["waits"], og1["acquires"] - og0["acquires"]], dtype=torch.int64)
-        dist.all_reduce(waits, op=dist.ReduceOp.MAX)
-        info["output_gather_waits_in_timed_steps"] = int(waits[0])
-        info["overlapped"] = bool(int(waits[1]) > 0 and int(waits[0]) == 0) if os.environ.get("GRANITE_BENCH_GATHER", "beside") != "inframe" else False
+        info = rccl_record(application, plan, width, height, gather_us, og0, og1, rank_ms)
         result["rccl"] = info
     if sustained:
         sustained["value"] = pixels_per_step * sustained["steps"] / sustained["seconds"] / 1e6
@@ -629,7 +643,7 @@ def main():
     if bands and args.workload == "config3_4k_4096lights" and os.environ.get("GRANITE_BENCH_CONFIG5", "1") == "1":
         sub = None
         try:
-            app5, _, _, _, w5, h5, desc5, name5 = build(True, "config5_8k")
+            app5, cam5, gbuf5, descs5, w5, h5, desc5, name5 = build(True, "config5_8k")
             ok = 1
         except Exception as e:  # noqa: BLE001
             app5, ok, sub = None, 0, {"error": f"{type(e).__name__}: {e}"}
@@ -637,17 +651,25 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             application = app5  # barrier() syncs the executor it finds under this name
+            checked5 = check_bands(app5, cam5, gbuf5, descs5, w5, h5)
+            k5 = app5.kernel_context()
+            # warm-up with every launcher and both collectives bracketed (their device times), then the clocks (see "clock settle")
+            k5.timing_set_sampling(1); k5.timing_enable(True); k5.timing_set_filter(None); k5.timing_reset()
             application.render_frames(max(args.warmup, 1), sync=True)
-            application.render_frames(max(args.steps, 40), sync=False)  # clocks (see "clock settle")
+            gather5 = gather_brackets(k5.timing_query(), k5)
+            k5.timing_enable(False)
+            application.render_frames(max(args.steps, 40), sync=False)
             barrier()
+            og5_0 = app5.output_gather_stats()
             t0 = time.perf_counter()
             application.render_frames(args.steps, sync=False)
+            og5_1 = app5.output_gather_stats()
             barrier()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rank_ms5, slowest = over_ranks(time.perf_counter() - t0, args.steps)
             sub = {"workload": name5, "description": desc5, "width": w5, "height": h5, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                   "ms_per_step": 1000.0 * float(t.item()) / args.steps, "value": w5 * h5 * args.steps / float(t.item()) / 1e6, "unit": "Mpixels/s",
-                   "scaling": "strong"}
+                   "ms_per_step": 1000.0 * slowest / args.steps, "value": w5 * h5 * args.steps / slowest / 1e6, "unit": "Mpixels/s",
+                   "scaling": "strong", "bands_checked": checked5,
+                   "rccl": rccl_record(app5, app5.strip_plan(), w5, h5, gather5, og5_0, og5_1, rank_ms5)}
             app5.close()
         elif app5 is not None:
             app5.close()

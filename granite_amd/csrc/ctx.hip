@@ -206,10 +206,7 @@ gr_ctx *gr_create(int device)
 		// One MI355X in SPX mode: 8 XCDs x 32 CUs behind one agent, workgroups dealt to the XCDs in turn.
 		ctx->eight_xcd_partition = props.multiProcessorCount == 256 && strncmp(props.gcnArchName, "gfx950", 6) == 0;
 	}
-	const size_t queue_bytes = size_t(gr_ctx::LIGHTING_QUEUE_SLOTS) * gr_ctx::LIGHTING_QUEUE_SLOT_BYTES;
 	if (encode_table_status != 0 || tonemap_table_status != 0 ||
-	    hipMalloc(reinterpret_cast<void **>(&ctx->lighting_queues), queue_bytes) != hipSuccess ||
-	    hipMemset(ctx->lighting_queues, 0, queue_bytes) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->ssr_azimuth_lut), sizeof(azimuth)) != hipSuccess ||
 	    hipMemcpy(ctx->ssr_azimuth_lut, azimuth, sizeof(azimuth), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->tonemap_srgb8_lut), sizeof(tonemap_table)) != hipSuccess ||
@@ -240,8 +237,6 @@ void gr_destroy(gr_ctx *ctx)
 		(void)hipEventDestroy(e);
 	if (ctx->srgb_decode_lut)
 		(void)hipFree(ctx->srgb_decode_lut);
-	if (ctx->lighting_queues)
-		(void)hipFree(ctx->lighting_queues);
 	if (ctx->srgb_encode_lut)
 		(void)hipFree(ctx->srgb_encode_lut);
 	if (ctx->tonemap_srgb8_lut)

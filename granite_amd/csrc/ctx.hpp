@@ -36,12 +36,7 @@ struct gr_ctx
 	// evaluated once on the host: the traced directions then do not depend on the device's trigonometric approximations.
 	float2 *ssr_azimuth_lut = nullptr;
 
-	// Lighting (lighting.hip, persistent form): a ring of ticket-queue sets ({epoch | ticket} words, one cache line per queue, one
-	// queue per workgroup of the launch, at most 1024), zero-initialised once; a launch takes the next slot and a fresh epoch, so launches in flight on different
-	// streams never share a counter and nothing is ever reset.  compute_units / xcds describe the device the context sits on.
-	static constexpr unsigned LIGHTING_QUEUE_SLOTS = 32, LIGHTING_QUEUE_SLOT_BYTES = 1024 * 128;
-	unsigned long long *lighting_queues = nullptr;
-	std::atomic<uint64_t> lighting_launches{0};
+	// The device the context sits on.
 	int compute_units = 0;
 	bool eight_xcd_partition = false;
 

@@ -19,11 +19,12 @@
 //      concerned and contributes exactly 0 (point.h:38, spot.h:45); the reference's subgroup footprint cannot matter
 //      for the same reason (oracle: orc_lighting_bruteforce_clustered).
 //   2. cull + stage: each lane tests its light's sphere (1.001 r) against the tile's bounding sphere, and a spot's cone
-//      against the same sphere (most of a spot's sphere lies outside its cone); survivors are compacted in index order
-//      (ballot + mbcnt), point lights first, spot lights after them, into a wave-private LDS list together with per-light
-//      constants (10 / r, (1.001 r)^2, fp32 spot scale / bias) computed once per light instead of once per pixel.
-//   3. shade (one PIXEL per lane): each of the two lists is walked by its own loop with a straight-line body (no
-//      light-type branch) and broadcast ds_read_b128; every BRDF operand is a VGPR.
+//      against the same sphere (most of a spot's sphere lies outside its cone); a survivor writes its record -- with per-light
+//      constants (10 / r, (1.001 r)^2, fp32 spot scale / bias) computed once per light instead of once per pixel -- into
+//      the slot of its own lane in a wave-private LDS list.  Two ballots name the survivors: point lights, and the lights
+//      walked with the cone body (spots, and point lights small enough for the 0.1 distance floor to matter).
+//   3. shade (one PIXEL per lane): the set bits of each ballot are walked in index order by a loop with a straight-line body
+//      (no light-type branch) and broadcast ds_read_b128; every BRDF operand is a VGPR.
 //      On gfx950 fp32 fma / mul / add issue at full rate only with VGPR / literal / inline operands (measured: 1.2 ns per
 //      wave-instruction per SIMD vs 1.9 ns with an SGPR operand, 2.0 ns for min / max / med3 / cmp / cvt, 3.6 ns for
 //      rcp / rsq), which is what bounds this kernel on the 4096-light config, not HBM.
@@ -37,10 +38,7 @@
 namespace
 {
 constexpr int LIGHT_TILE = 8;  // wave tile edge
-#ifndef LV_WAVES
-#define LV_WAVES 4
-#endif
-constexpr int LIGHT_WAVES = LV_WAVES; // waves per workgroup, side by side -> 32x8 block (A/B: 1, 2)
+constexpr int LIGHT_WAVES = 4; // waves per workgroup, side by side: four 8 PX x 8 tiles in a row (2 / 1 measured slower in the frame, round 4)
 constexpr int LIGHT_SLOT_BYTES = 64;
 
 constexpr float PI_SIC = 3.1415628f; // assets/shaders/lights/pbr.h:4-6 (sic)
@@ -48,24 +46,25 @@ constexpr float PI_SIC = 3.1415628f; // assets/shaders/lights/pbr.h:4-6 (sic)
 constexpr float CULL_RADIUS_SCALE = 1.001f;
 constexpr float CULL_SLACK = 1e-3f;
 
-// A/B switches of the shading loop (tools/lighting_ab.sh: one library per combination, make OUT=../lib_<name> EXTRA_lighting=-D...).
-#ifndef LV_LOOP
-#define LV_LOOP 1 // 1: point lights and spot lights staged and walked as two lists (straight-line bodies); 0: one list, run-time type
-#endif
-#ifndef LV_NEAR_TEST
-#define LV_NEAR_TEST 1 // wave-uniform "no pixel inside the radius" early-out per light
-#endif
-#ifndef LV_CONE_CULL
-#define LV_CONE_CULL 1 // staging-time cone vs tile-sphere test for spots
-#endif
-#ifndef LV_SAT_NOH
-#define LV_SAT_NOH 1 // NoH clamp as sat modifier instead of med3
-#endif
-#ifndef LV_GFOLD
-#define LV_GFOLD 1 // c0 folded into the per-pixel G constants
-#endif
-#ifndef LV_A2_SAT
-#define LV_A2_SAT 0 // 1 / max(len, 0.1)^2 = 100 sat(inv_d2 / 100): a full-rate multiply with clamp instead of a half-rate min; the 100 goes into the staged colour
+// Measurement build only (-DLV_STAMP, tools/lighting_stamps.py): shader-clock marks at the phase boundaries of a tile.
+#ifdef LV_STAMP
+#define LV_STAMP_PARAM , uint32_t (&stamp_marks__)[4]
+#define LV_STAMP_ARG , stamp_scope__.marks
+#define LV_STAMP_MARK(k) stamp_marks__[k] = uint32_t(__builtin_amdgcn_s_memtime())
+#define LV_STAMP_LAP_BEGIN() uint32_t stamp_lap__ = uint32_t(__builtin_amdgcn_s_memtime())
+#define LV_STAMP_LAP(k)                                                          \
+	do                                                                           \
+	{                                                                            \
+		const uint32_t stamp_now__ = uint32_t(__builtin_amdgcn_s_memtime());     \
+		stamp_marks__[k] += stamp_now__ - stamp_lap__;                           \
+		stamp_lap__ = stamp_now__;                                               \
+	} while (0)
+#else
+#define LV_STAMP_PARAM
+#define LV_STAMP_ARG
+#define LV_STAMP_MARK(k)
+#define LV_STAMP_LAP_BEGIN()
+#define LV_STAMP_LAP(k)
 #endif
 
 struct KernelArgs
@@ -79,12 +78,10 @@ struct KernelArgs
 	float dir_direction[3];
 	float inv_resolution[2];
 	// cluster UBO subset
-	float cl_camera_base[3];
-	float cl_camera_front[3];
 	float cl_xy_scale[2];
 	int cl_res_x, cl_res_y;
 	int cl_num_lights, cl_num_lights_32, cl_z_max_index;
-	float cl_z_scale;
+	float cl_z_row[4]; // slice = int(dot(pos, cl_z_row.xyz) + cl_z_row.w): camera_front * z_scale and -dot(camera_base, camera_front) * z_scale
 	const gr_light_info *__restrict__ lights;
 	const uint32_t *__restrict__ type_mask;
 	const uint32_t *__restrict__ bitmask;
@@ -92,11 +89,6 @@ struct KernelArgs
 	const float *__restrict__ srgb_lut;
 	uint32_t flags;
 	float fog_color[3], fog_falloff; // the fog quad behind the clustered one (renderer.cpp:1179-1196); falloff <= 0: none
-	int blocks_x, num_blocks, blocks_per_xcd, banded; // static form
-	int tiles_x, num_tiles;                            // persistent form: wave tiles of 8 PX x 8 pixels over the render area
-	int tiles_per_queue, tiles_remainder;              // num_tiles = tiles_per_queue * gridDim.x + tiles_remainder
-	unsigned long long *queues;                        // LIGHT_QUEUES ticket words, one cache line each
-	uint32_t epoch;
 	int row_first, row_end, block_row0; // render area rows [row_first, row_end); first block row = row_first / 8
 };
 
@@ -110,6 +102,13 @@ __device__ __forceinline__ float rcp(float v) { return __builtin_amdgcn_rcpf(v);
 __device__ __forceinline__ float rsq(float v) { return __builtin_amdgcn_rsqf(v); }
 __device__ __forceinline__ float med3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); } // clamp
 __device__ __forceinline__ float sat(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); } // folds into a clamp modifier
+// clamp(v, 0, hi) with a wave-uniform hi >= 0 as one v_med3_i32 (the backend forms it only for constant bounds: v_max + v_min otherwise)
+__device__ __forceinline__ int clamp0_i32(int v, int hi)
+{
+	int r;
+	asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi));
+	return r;
+}
 
 // StockSampler::LinearClamp on an R8_UNORM image (the ambient-occlusion input).
 __device__ __forceinline__ float sample_linear_r8(const DevImage &img, float u, float v)
@@ -130,7 +129,6 @@ __device__ __forceinline__ float sample_linear_r8(const DevImage &img, float u, 
 struct Surface
 {
 	float3_ pos, N, V, F0, D1; // D1 = (1 - F0) * base * (1 - metallic) / PI: the diffuse term at f = 0
-	float c0;                  // only with LV_GFOLD == 0
 	float NdV, m2m1, gA, gB;   // NdV unclamped; m2m1 = m^2 - 1; Gv Gl / c0 = NoL gA + gB with Gv = NoV (1-k) + k, c0 = m^2 / (4 PI)
 };
 
@@ -154,14 +152,14 @@ __device__ __forceinline__ void brdf_accumulate(const Surface &s, float NdL, flo
 	const float NoL = med3(NdL, 0.001f, 1.0f);
 	const float inv_h = rsq(hh);
 	const float omh = sat(fmaf(-0.5f * hh, inv_h, 1.001f)) - 0.001f; // 1 - clamp(HoV, 0.001, 1)
-	const float NoH = LV_SAT_NOH ? sat((s.NdV + NdL) * inv_h) : med3((s.NdV + NdL) * inv_h, 0.0001f, 1.0f);
+	const float NoH = sat((s.NdV + NdL) * inv_h);
 
 	const float omh2 = omh * omh;
 	const float f = omh2 * omh2 * omh; // pow(1 - HoV, 5)
 
 	const float d = fmaf(NoH * NoH, s.m2m1, 1.0f);     // (NoH m2 - NoH) NoH + 1
 	const float g = fmaf(NoL, s.gA, s.gB);             // Gv Gl / c0, c0 = m^2 / (4 PI): G D = 1 / (d^2 g)
-	const float GD = LV_GFOLD ? rcp(d * d * g) : s.c0 * rcp(d * d * g);
+	const float GD = rcp(d * d * g);
 
 	const float w = NoL * scale;
 	const float cw = fmaf(-f, w, w); // (1 - f) w
@@ -177,32 +175,69 @@ __device__ __forceinline__ bool index_in_range(uint32_t index, uint32_t range_x,
 	return index >= range_x && index <= range_y;
 }
 
-// Wave64 min/max -> SGPR: 4 DPP steps reduce each row of 16 lanes, the 4 row results meet on the scalar unit.
+// Wave64 min / max -> SGPR in six DPP steps and one v_readlane: four steps reduce each row of 16 lanes (every lane of a row ends up with
+// the row's result), row_bcast:15 folds rows 0 / 2 into rows 1 / 3, row_bcast:31 folds row 1 into rows 2 / 3, lane 63 holds the wave's.
+// (Round 4 read the four row results back with four v_readlane and combined them through v_mov + v_max3: 13 VALU slots against 7.)
+// `old` of the two broadcast steps is the operation's identity: rows outside the row mask then compute op(v, identity) = v, and the
+// backend folds the v_mov_dpp into the v_min / v_max as its DPP source (it does so for an immediate identity only).
+template <bool IS_MAX>
+__device__ __forceinline__ uint32_t minmax_step(uint32_t v, uint32_t moved)
+{
+	return IS_MAX ? max(v, moved) : min(v, moved);
+}
+#define GR_DPP_STEP(IS_MAX, v, ctrl) v = minmax_step<IS_MAX>(v, uint32_t(__builtin_amdgcn_mov_dpp(int(v), ctrl, 0xf, 0xf, true)))
+#define GR_DPP_BCAST(IS_MAX, v, ctrl, rows) \
+	v = minmax_step<IS_MAX>(v, uint32_t(__builtin_amdgcn_update_dpp(IS_MAX ? 0 : -1, int(v), ctrl, rows, 0xf, false)))
 template <bool IS_MAX>
 __device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t v)
 {
-	auto op = [](uint32_t a, uint32_t b) { return IS_MAX ? max(a, b) : min(a, b); };
-	// mov_dpp (no `old` operand: every lane of these permutations reads a valid lane) folds into the min / max as a DPP source.
-	v = op(v, uint32_t(__builtin_amdgcn_mov_dpp(int(v), 0xB1, 0xf, 0xf, true)));  // quad_perm [1,0,3,2]
-	v = op(v, uint32_t(__builtin_amdgcn_mov_dpp(int(v), 0x4E, 0xf, 0xf, true)));  // quad_perm [2,3,0,1]
-	v = op(v, uint32_t(__builtin_amdgcn_mov_dpp(int(v), 0x141, 0xf, 0xf, true))); // row_half_mirror
-	v = op(v, uint32_t(__builtin_amdgcn_mov_dpp(int(v), 0x140, 0xf, 0xf, true))); // row_mirror
-	const uint32_t r0 = uint32_t(__builtin_amdgcn_readlane(int(v), 0)), r1 = uint32_t(__builtin_amdgcn_readlane(int(v), 16));
-	const uint32_t r2 = uint32_t(__builtin_amdgcn_readlane(int(v), 32)), r3 = uint32_t(__builtin_amdgcn_readlane(int(v), 48));
-	return op(op(r0, r1), op(r2, r3));
+	GR_DPP_STEP(IS_MAX, v, 0xB1);  // quad_perm [1,0,3,2]
+	GR_DPP_STEP(IS_MAX, v, 0x4E);  // quad_perm [2,3,0,1]
+	GR_DPP_STEP(IS_MAX, v, 0x141); // row_half_mirror
+	GR_DPP_STEP(IS_MAX, v, 0x140); // row_mirror
+	GR_DPP_BCAST(IS_MAX, v, 0x142, 0xa); // row_bcast:15 into rows 1, 3
+	GR_DPP_BCAST(IS_MAX, v, 0x143, 0xc); // row_bcast:31 into rows 2, 3
+	return uint32_t(__builtin_amdgcn_readlane(int(v), 63));
 }
+// min of one value and max of another, step by step side by side: each DPP read has the other reduction's instruction between it and
+// the write it depends on (a DPP source needs two wait states after the VALU write).
+__device__ __forceinline__ void wave_min_and_max_u32(uint32_t &lo, uint32_t &hi)
+{
+	GR_DPP_STEP(false, lo, 0xB1);
+	GR_DPP_STEP(true, hi, 0xB1);
+	GR_DPP_STEP(false, lo, 0x4E);
+	GR_DPP_STEP(true, hi, 0x4E);
+	GR_DPP_STEP(false, lo, 0x141);
+	GR_DPP_STEP(true, hi, 0x141);
+	GR_DPP_STEP(false, lo, 0x140);
+	GR_DPP_STEP(true, hi, 0x140);
+	GR_DPP_BCAST(false, lo, 0x142, 0xa);
+	GR_DPP_BCAST(true, hi, 0x142, 0xa);
+	GR_DPP_BCAST(false, lo, 0x143, 0xc);
+	GR_DPP_BCAST(true, hi, 0x143, 0xc);
+	lo = uint32_t(__builtin_amdgcn_readlane(int(lo), 63));
+	hi = uint32_t(__builtin_amdgcn_readlane(int(hi), 63));
+}
+#undef GR_DPP_STEP
+#undef GR_DPP_BCAST
 
 // One staged light = 4 x 16 B in wave-private LDS.
 //   q0: position.xyz, (1.001 r)^2        q1: colour.xyz, 10 / r
-//   q2: direction.xyz, -                 q3: spot scale, spot bias (fp32), -, -          (q2, q3 read for spots only)
+//   q2: direction.xyz, -                 q3: spot scale, spot bias (fp32), -, -          (q2, q3 read by the second list only)
 //
 // PX pixels per lane (horizontally adjacent): the light record, the tile-level early-outs and all of the wave-level
 // bookkeeping are shared by 64 * PX pixels, and the PX independent BRDF chains give the wave enough instruction-level
 // parallelism to saturate the VALU at half the resident waves -- which is what leaves wave slots to the executor's other
 // streams while this kernel runs (see gr_lighting).
-// KIND: 0 = point light, 1 = spot light, 2 = decided at run time by `is_spot` (one list holding both).
-template <int PX, int KIND>
-__device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f32x4 *slot, bool is_spot, float3_ (&result)[PX])
+//
+// Two lists, two straight-line bodies:
+//   CONE = false: point lights of radius >= 1 / 8.  light_dist = max(0.1, length) (point.h:36) feeds only the smoothstep
+//     t = sat(light_dist * 10 / r - 9): with 10 / r <= 80 a length below 0.1 gives t = sat(negative) = 0 with or without the
+//     floor, a length above it is untouched by it, so the half-rate v_max is not issued (bit-identical, by the argument above).
+//   CONE = true: spot lights -- and the point lights of radius < 1 / 8, staged with the neutral cone (direction 0, scale 0,
+//     bias 1: cone factor sat(-0 * 0 + 1)^2 = 1 exactly), for which the floor can reach the smoothstep.
+template <int PX, bool CONE>
+__device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f32x4 *slot, float3_ (&result)[PX])
 {
 	const f32x4 q0 = slot[0], q1 = slot[1];
 	float3_ Lf[PX];
@@ -216,7 +251,7 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 		near_any = near_any || d2[p] < q0.w;
 	}
 	// Falloff is exactly 0 once dist * inv_radius >= 1: skip the light when no pixel of the tile is inside 1.001 r.
-	if (LV_NEAR_TEST && !__any(near_any))
+	if (!__any(near_any))
 		return;
 
 	float inv_d[PX], len[PX], inv_d2[PX], atten[PX];
@@ -225,13 +260,13 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 	{
 		inv_d[p] = rsq(d2[p]);
 		len[p] = d2[p] * inv_d[p]; // length(light_dir_full)
-		const float dist = fmaxf(0.1f, len[p]); // light_dist = max(MIN_POINT_DIST, length) (point.h:36, spot.h:38)
+		const float dist = CONE ? fmaxf(0.1f, len[p]) : len[p]; // light_dist = max(MIN_POINT_DIST, length) (point.h:36, spot.h:38)
 		inv_d2[p] = inv_d[p] * inv_d[p];
 		// 1 - smoothstep(0.9, 1.0, dist * inv_radius)
 		const float t = sat(fmaf(dist, q1.w, -9.0f));
 		atten[p] = fmaf(-(t * t), fmaf(-2.0f, t, 3.0f), 1.0f);
 	}
-	if (KIND == 1 || (KIND == 2 && is_spot))
+	if (CONE)
 	{
 		// spot.h:41-46: cone = dot(normalize(world_pos - light_pos), direction) = -dot(Lf, direction) / |Lf|
 		const f32x4 q2 = slot[2], q3 = slot[3];
@@ -252,7 +287,7 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 	for (int p = 0; p < PX; p++)
 	{
 		// colour = light colour * atten / light_dist^2, light_dist^2 = max(len, 0.1)^2
-		const float a2 = LV_A2_SAT ? atten[p] * sat(inv_d2[p] * (0.1f * 0.1f)) : atten[p] * fminf(inv_d2[p], 1.0f / (0.1f * 0.1f));
+		const float a2 = atten[p] * fminf(inv_d2[p], 1.0f / (0.1f * 0.1f));
 		const float NdL = dot(s[p].N, Lf[p]) * inv_d[p];
 		// |V + L|^2 with L = Lf / len: |len V + Lf|^2 / len^2.  The vector sum keeps the relative error of hh at
 		// fp32 level when L is nearly -V, where 2 + 2 dot(V, L) would cancel.
@@ -262,23 +297,14 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 	}
 }
 
-// A form of this walk written on float2 values (one v_pk_{fma,mul,add}_f32 for both pixels of the lane wherever the ISA has one: 47 packed
-// + 6 scalar fp32 instructions per point-light iteration instead of 27 + 44) was built and measured in round 4: 237 us against 182 us
-// alone.  A packed instruction whose operand is the result of the packed instruction before it waits (the assembler's s_nop between
-// them is the visible part), and a BRDF is a chain of such pairs; the third of the pairs the SLP vectoriser forms on its own sit where
-// they do not depend on each other.  Removed again (commit "lighting walk on float2 values" has it).
+// Forms of this walk that were built, measured slower and removed in round 4 (profiles/r04_lighting_variants_ab.txt, with the commits):
+// the walk on float2 values (one v_pk_* for both pixels of the lane wherever the ISA has one: 237 us against 182 us -- a packed
+// instruction whose operand is the result of the packed instruction before it waits); the colour accumulation on the matrix pipe
+// (v_mfma_f32_4x4x1: 196 us against 182 us -- the pipe runs beside the VALU for OTHER waves, not for the wave that issued the instruction);
+// persistent waves dealing themselves tiles from ticket queues (227 us with a queue per XCD, 766 us with a queue per workgroup and stealing,
+// against 181 us for the static grid: the machine is VALU-bound, full wave slots lengthen every tile); XCD bands instead of screen order.
 
-// The colour accumulation on the matrix pipe was built and measured in round 4 as well.  With F GD + (1 - F) diffuse = F0 (GD cw) + D1 cw + fw
-// the walk only has to form three sums of (light colour) x (one scalar of this pixel and light) per channel, and
-// v_mfma_f32_4x4x1_16b_f32 (D[i][j] += A[i] B[j] per block of four lanes, A[i] from lane 4 b + i, D[i][j] in lane 4 b + j register i) does
-// that without anything crossing lanes: A = colour channel (lane & 3) of the staged light, B = the lane's own scalar.  Nine fma per
-// pixel-light become one multiply and three matrix instructions; results within the same 2 ulp (58 GPU tests green).  196 us against
-// 182 us alone, 0.2545 against 0.2357 ms per frame: a 4x4x1 costs the wave ~14 cycles of issue, more than the fma it replaces, and the
-// pipe that runs beside the VALU for OTHER waves does not do so for the wave that issued it.  Removed (commit "lighting colour
-// accumulation on the matrix pipe" has it; profiles/r04_lighting_variants_ab.txt).
-
-// What a lane reads of its PX pixels, as loaded: the persistent kernel holds the NEXT tile's words in these registers while it
-// shades the current one (11 VGPRs for PX = 2, RGBA16F).
+// What a lane reads of its PX pixels, as loaded (11 VGPRs for PX = 2, RGBA16F).
 template <int PX, bool B10>
 struct RawTile
 {
@@ -291,23 +317,12 @@ struct RawTile
 // Attachment loads of one tile, all issued back to back.  Byte offsets are 32-bit (images < 4 GiB, checked by the launcher), so
 // every load is base SGPR pair + one VGPR offset.  PX == 2 is only launched for even widths and pitches that keep the pair of
 // texels naturally aligned: the lane's two pixels are inside or outside together and come in with one load per attachment.
-// Lanes outside the render area keep depth 0 (= "not lit").
+// Lanes outside the target read the texels their coordinates clamp to (no exec-mask region, no zero-filled registers): what they
+// hold is never stored, and their depth is not looked at (`inside` gates `active`).
 template <int PX, bool B10>
 __device__ __forceinline__ void load_raw(const KernelArgs &a, int x0, int y, RawTile<PX, B10> &r)
 {
-#pragma unroll
-	for (int p = 0; p < PX; p++)
-	{
-		r.depth[p] = 0.0f;
-		r.alb[p] = r.nrm[p] = 0u;
-	}
-	r.mr = 0u;
-#pragma unroll
-	for (int i = 0; i < (B10 ? PX : 2 * PX); i++)
-		r.em[i] = 0u;
-	if (!(y >= a.row_first && y < a.row_end && x0 < a.hdr.w))
-		return;
-	const uint32_t uy = uint32_t(y), ux = uint32_t(x0);
+	const uint32_t uy = uint32_t(min(y, a.hdr.h - 1)), ux = uint32_t(min(x0, a.hdr.w - PX));
 	if constexpr (PX == 2)
 	{
 		const float2 d = *reinterpret_cast<const float2 *>(a.depth.ptr + (uy * a.depth.pitch + ux * 4u));
@@ -345,13 +360,10 @@ __device__ __forceinline__ void load_raw(const KernelArgs &a, int x0, int y, Raw
 }
 
 // One wave, one tile of 8 PX x 8 pixels whose attachment words are in `raw`: both quads, the fog quad, the store.
-// `prefetch` is called exactly once, at the point where the tile has consumed its own gather loads and only the light walk is
-// left: whatever it loads (the persistent kernel: the next tile's attachments) returns under the walk.
-template <int PX, bool AO, bool B10, typename Prefetch>
+template <int PX, bool AO, bool B10>
 __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x0, const int tile_y0, const int lane, const RawTile<PX, B10> &raw,
-                                           f32x4 *const slots, const float *s_srgb, Prefetch &&prefetch)
+                                           f32x4 *const slots, const float *s_srgb LV_STAMP_PARAM)
 {
-	constexpr int TILE_W = LIGHT_TILE * PX;
 	const int x0 = tile_x0 + (lane & (LIGHT_TILE - 1)) * PX;
 	const int y = tile_y0 + (lane >> 3);
 	const int W = a.hdr.w, H = a.hdr.h;
@@ -378,7 +390,6 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 		else
 			dst[p] = __builtin_bit_cast(f16x4, make_uint2(raw.em[2 * p], raw.em[2 * p + 1]));
 	}
-	bool prefetched = false;
 
 	// ---- position reconstruction (clustering.vert:10-13, clustering.frag:37-39): clip = invVP * (ndc.xy, depth, 1),
 	// pos = clip.xyz / clip.w.  Evaluated with fused multiply-adds and a Newton-refined reciprocal; a pixel that lands
@@ -441,8 +452,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 		const float r1 = roughness + 1.0f;
 		const float k = r1 * r1 * (1.0f / 8.0f);
 		const float omk = 1.0f - k;
-		s[p].c0 = m2 * (0.25f / PI_SIC);
-		const float Gv_over_c0 = LV_GFOLD ? fmaf(NoV, omk, k) * rcp(m2 * (0.25f / PI_SIC)) : fmaf(NoV, omk, k); // m2 >= 0.0039
+		const float Gv_over_c0 = fmaf(NoV, omk, k) * rcp(m2 * (0.25f / PI_SIC)); // m2 >= 0.0039
 		s[p].gA = Gv_over_c0 * omk;
 		s[p].gB = Gv_over_c0 * k;
 		const float kd = (1.0f - metallic) * (1.0f / PI_SIC);
@@ -471,6 +481,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 		}
 	}
 
+	LV_STAMP_MARK(0); // G-buffer decode, material terms and the directional quad are through
 	// ---- clustered quad (clusterer_bindless.h:29-84) ----
 	f16x4 out_h[PX];
 	float3_ out_f[PX]; // B10: the sums themselves, rounded by the packed store below
@@ -482,42 +493,40 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 		for (int p = 0; p < PX; p++)
 		{
 			result[p] = f3(0.0f, 0.0f, 0.0f);
-			// Slice lookup (clusterer_bindless.h:43-47).
-			const float z = dot(s[p].pos - f3(a.cl_camera_base[0], a.cl_camera_base[1], a.cl_camera_base[2]),
-			                    f3(a.cl_camera_front[0], a.cl_camera_front[1], a.cl_camera_front[2]));
-			const int z_index = clampi(int(z * a.cl_z_scale), 0, a.cl_z_max_index);
+			// Slice lookup (clusterer_bindless.h:43-47): int(dot(pos - camera_base, camera_front) * z_scale) with the scale and the
+			// base folded into the row by the launcher (three fma; a last-bit difference moves a pixel that sits on a slice boundary
+			// into the neighbouring slice, whose lights differ from its own only by ones at the very edge of their radius: see above).
+			const float zf = fmaf(s[p].pos.z, a.cl_z_row[2], fmaf(s[p].pos.y, a.cl_z_row[1], fmaf(s[p].pos.x, a.cl_z_row[0], a.cl_z_row[3])));
+			const uint32_t z_index = uint32_t(clamp0_i32(int(zf), a.cl_z_max_index)); // -> v_med3_i32
 			if (active[p])
 			{
-				const uint2 z_range = a.range[z_index];
+				const uint2 z_range = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(a.range) + (z_index << 3u));
 				lane_lo = min(lane_lo, z_range.x);
 				lane_hi = max(lane_hi, z_range.y);
 			}
 		}
 		// The wave's light-index window.
-		const uint32_t win_lo = wave_minmax_u32<false>(lane_lo);
-		const uint32_t win_hi = min(wave_minmax_u32<true>(lane_hi), uint32_t(a.cl_num_lights - 1));
+		wave_min_and_max_u32(lane_lo, lane_hi);
+		const uint32_t win_lo = lane_lo, win_hi = min(lane_hi, uint32_t(a.cl_num_lights - 1));
 
 		if (win_lo <= win_hi)
 		{
-			// Cluster cells the tile touches (clusterer_bindless.h:39-42 evaluated at the tile corners; the per-pixel
-			// formula is monotonic, so every lane's cell lies in this rectangle).
-			const int xe = min(tile_x0 + TILE_W - 1, W - 1), ye = min(tile_y0 + LIGHT_TILE - 1, H - 1);
+			// Cluster cells the tile touches (clusterer_bindless.h:39-42 at the tile's first and last pixel; the per-pixel formula is
+			// monotonic, so every lane's cell lies in this rectangle).  There is no scalar float unit: lane 0 evaluates the formula for
+			// the tile's first pixel, lane 63 for its last one (its second pixel, clamped into the image), and two v_readlane per axis
+			// fetch them -- instead of four wave-uniform evaluations on the vector unit.
 			auto cell = [](int p, float inv_res, float scale, int res) {
-				return clampi(int(__fmul_rn(__fmul_rn(float(p) + 0.5f, inv_res), scale)), 0, res - 1);
+				return clamp0_i32(int(__fmul_rn(__fmul_rn(float(p) + 0.5f, inv_res), scale)), res - 1);
 			};
-			const int cx0 = __builtin_amdgcn_readfirstlane(cell(tile_x0, a.inv_resolution[0], a.cl_xy_scale[0], a.cl_res_x));
-			const int cx1 = __builtin_amdgcn_readfirstlane(cell(xe, a.inv_resolution[0], a.cl_xy_scale[0], a.cl_res_x));
-			const int cy0 = __builtin_amdgcn_readfirstlane(cell(tile_y0, a.inv_resolution[1], a.cl_xy_scale[1], a.cl_res_y));
-			const int cy1 = __builtin_amdgcn_readfirstlane(cell(ye, a.inv_resolution[1], a.cl_xy_scale[1], a.cl_res_y));
+			const int my_cx = cell(min(x0 + (lane >> 5) * (PX - 1), W - 1), a.inv_resolution[0], a.cl_xy_scale[0], a.cl_res_x);
+			const int my_cy = cell(min(y, H - 1), a.inv_resolution[1], a.cl_xy_scale[1], a.cl_res_y);
+			const int cx0 = __builtin_amdgcn_readlane(my_cx, 0), cx1 = __builtin_amdgcn_readlane(my_cx, 63);
+			const int cy0 = __builtin_amdgcn_readlane(my_cy, 0), cy1 = __builtin_amdgcn_readlane(my_cy, 63);
 
 			// Bounding sphere of the tile's surface points: centre = first lit pixel, radius = farthest lit pixel from it.
 			const uint64_t lit = __ballot(any_active);
 			const int first = __builtin_ctzll(lit);
-			float3_ mine = s[0].pos;
-#pragma unroll
-			for (int p = PX - 1; p >= 0; p--)
-				if (active[p])
-					mine = s[p].pos;
+			const float3_ mine = PX == 2 && !active[0] ? s[PX - 1].pos : s[0].pos; // a lane in `lit` has one of them active
 			const float3_ centre = f3(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), first)),
 			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), first)),
 			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), first)));
@@ -526,12 +535,15 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 			for (int p = 0; p < PX; p++)
 			{
 				const float3_ off = s[p].pos - centre;
-				off2 = fmaxf(off2, active[p] ? dot(off, off) : 0.0f);
+				const float mine2 = active[p] ? dot(off, off) : 0.0f;
+				off2 = p == 0 ? mine2 : fmaxf(off2, mine2);
 			}
 			// v_sqrt_f32 (1 ulp) is well inside the 1.0001 + CULL_SLACK margin
 			const float tile_radius =
 			    __builtin_amdgcn_sqrtf(__builtin_bit_cast(float, wave_minmax_u32<true>(__builtin_bit_cast(uint32_t, off2)))) * 1.0001f + CULL_SLACK;
 
+			LV_STAMP_MARK(1); // slice window, cells, bounding sphere
+			LV_STAMP_LAP_BEGIN();
 			const int chunk_lo = int(win_lo >> 6u), chunk_hi = int(win_hi >> 6u);
 			for (int chunk = chunk_lo; chunk <= chunk_hi; chunk++)
 			{
@@ -539,8 +551,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 				const uint32_t light_index = uint32_t(chunk) * 64u + uint32_t(lane);
 				const int my_word = chunk * 2 + (lane >> 5);
 				bool keep = false;
-				bool is_spot = false;
-				f32x4 r0 = {0, 0, 0, 0}, r1q = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
+				bool second = false; // walked with the cone body: spot lights, and point lights of radius < 1 / 8
 				if (index_in_range(light_index, win_lo, win_hi))
 				{
 					uint32_t word = 0u;
@@ -559,7 +570,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 						const float reach = radius + tile_radius;
 						const float dist2 = dot(to_light, to_light);
 						keep = dist2 <= reach * reach;
-						is_spot = ((a.type_mask[light_index >> 5] >> (light_index & 31u)) & 1u) == 0u;
+						const bool is_spot = ((a.type_mask[light_index >> 5] >> (light_index & 31u)) & 1u) == 0u;
 						// unpackHalf2x16(spot_scale_bias).  The lane is copied to a scalar first: clang (ROCm 7.2) evaluates
 						// __builtin_bit_cast on a vector-component lvalue (v.w) at the address of the whole vector, i.e. as
 						// lane .x (observed: spots shaded with colour.x as scale | bias).
@@ -567,7 +578,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 						const uint32_t sb_bits = __builtin_bit_cast(uint32_t, sb_lane);
 						const float spot_scale = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits & 0xffffu)));
 						const float spot_bias = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits >> 16)));
-						if (LV_CONE_CULL && is_spot && keep && spot_scale > 0.0f)
+						if (is_spot && keep && spot_scale > 0.0f)
 						{
 							// Cone vs the tile's bounding sphere.  spot.h:44-45: the cone factor sat(cone_angle * scale + bias) is
 							// exactly 0 for cone_angle <= -bias / scale =: cos(theta).  With v = centre - light, a = dot(v, dir) and
@@ -585,62 +596,35 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 								keep = e <= tile_radius * 1.001f + CULL_SLACK;
 							}
 						}
-						r0 = f32x4{pq.x, pq.y, pq.z, radius * radius};
-						r1q = LV_A2_SAT ? f32x4{c.x * 100.0f, c.y * 100.0f, c.z * 100.0f, 10.0f * d.w} : f32x4{c.x, c.y, c.z, 10.0f * d.w};
-						r2 = f32x4{d.x, d.y, d.z, 0.0f};
-						r3 = f32x4{spot_scale, spot_bias, 0.0f, 0.0f};
+						// inv_radius > 8: the 0.1 distance floor can reach this light's smoothstep (shade_positional)
+						second = is_spot || d.w > 8.0f;
+						// A survivor stages its record in the slot of its own lane, here, where its registers are: nothing of a light
+						// lives across the ballots below (round 4 compacted the list with mbcnt after them, which kept sixteen
+						// zero-filled registers per lane alive on every path).  The walks visit the set bits of the ballots.
+						if (keep)
+						{
+							f32x4 *dst_slot = slots + lane * (LIGHT_SLOT_BYTES / 16);
+							dst_slot[0] = f32x4{pq.x, pq.y, pq.z, radius * radius};
+							dst_slot[1] = f32x4{c.x, c.y, c.z, 10.0f * d.w};
+							if (second)
+							{
+								dst_slot[2] = is_spot ? f32x4{d.x, d.y, d.z, 0.0f} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+								dst_slot[3] = is_spot ? f32x4{spot_scale, spot_bias, 0.0f, 0.0f} : f32x4{0.0f, 1.0f, 0.0f, 0.0f};
+							}
+						}
 					}
 				}
 				const uint64_t kept = __ballot(keep);
-				const uint64_t spots = __ballot(keep && is_spot);
-				// Survivors are compacted in index order (ballot + mbcnt); with LV_LOOP the point lights come first and the
-				// spot lights after them, so that each list is walked by a loop whose body has no light-type branch.
-				const uint64_t first_list = LV_LOOP ? kept & ~spots : kept;
-				const int num_first = __builtin_popcountll(first_list);
-				if (keep)
-				{
-					const uint64_t mine = (LV_LOOP && is_spot) ? spots : first_list;
-					const int slot = __builtin_amdgcn_mbcnt_hi(uint32_t(mine >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mine), 0u)) +
-					                 ((LV_LOOP && is_spot) ? num_first : 0);
-					f32x4 *dst_slot = slots + slot * (LIGHT_SLOT_BYTES / 16);
-					dst_slot[0] = r0;
-					dst_slot[1] = r1q;
-					if (is_spot)
-					{
-						dst_slot[2] = r2;
-						dst_slot[3] = r3;
-					}
-				}
+				const uint64_t seconds = __ballot(keep && second);
 				__builtin_amdgcn_wave_barrier(); // LDS is wave-private: in-order DS execution is the only ordering needed
-				// The first chunk's bitmask words and light records are in: nothing this tile still has to wait for was issued
-				// before this point (vmcnt returns in order), so the caller's loads go out here and come back under the walk.
-				if (!prefetched)
-				{
-					prefetch();
-					prefetched = true;
-				}
+				LV_STAMP_LAP(2); // gather + cull
 
-				// ---- shade: PX pixels per lane, lights broadcast from LDS ----
-				const f32x4 *slot = slots;
-				if (LV_LOOP)
-				{
-					for (int i = 0; i < num_first; i++, slot += LIGHT_SLOT_BYTES / 16)
-						shade_positional<PX, 0>(s, slot, false, result);
-					const int num_spots = __builtin_popcountll(spots);
-					for (int i = 0; i < num_spots; i++, slot += LIGHT_SLOT_BYTES / 16)
-						shade_positional<PX, 1>(s, slot, true, result);
-				}
-				else
-				{
-					uint64_t todo = kept;
-					while (todo != 0ull)
-					{
-						const int src_lane = __builtin_ctzll(todo);
-						todo &= todo - 1ull;
-						shade_positional<PX, 2>(s, slot, ((spots >> src_lane) & 1ull) != 0ull, result);
-						slot += LIGHT_SLOT_BYTES / 16;
-					}
-				}
+				// ---- shade: PX pixels per lane, lights broadcast from LDS; each list in index order, its body without a light-type branch ----
+				for (uint64_t todo = kept & ~seconds; todo != 0ull; todo &= todo - 1ull)
+					shade_positional<PX, false>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
+				for (uint64_t todo = seconds; todo != 0ull; todo &= todo - 1ull)
+					shade_positional<PX, true>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
+				LV_STAMP_LAP(3); // the two walks
 				__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
 			}
 		}
@@ -666,8 +650,6 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 		}
 	}
 
-	if (!prefetched)
-		prefetch();
 	if (!inside[0])
 		return;
 	f16x4 o[PX];
@@ -736,14 +718,14 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 // Measurement build only (make OUT=../lib_stamp EXTRA_lighting=-DLV_STAMP, tools/lighting_stamps.py): one record per wave tile,
 // {start, end} of the 100 MHz s_memrealtime counter, the shader-clock cycles in between, and where the wave ran.
 __device__ uint4 *g_lighting_stamps;
-__device__ uint32_t g_lighting_stamp_records; // second half of the array: per-tile ticket wait
 struct StampScope
 {
 	uint4 *rec;
 	uint64_t t0, c0;
+	uint32_t marks[4] = {0u, 0u, 0u, 0u};
 	__device__ __forceinline__ StampScope(uint32_t tile)
 	{
-		rec = g_lighting_stamps ? g_lighting_stamps + tile : nullptr;
+		rec = g_lighting_stamps ? g_lighting_stamps + 2u * tile : nullptr;
 		t0 = __builtin_amdgcn_s_memrealtime();
 		c0 = __builtin_amdgcn_s_memtime();
 	}
@@ -755,23 +737,16 @@ struct StampScope
 		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
 		if (rec && (threadIdx.x & 63u) == 0u)
-			*rec = make_uint4(uint32_t(t0), uint32_t(t1), uint32_t(c1 - c0), (xcc << 28) | (hw & 0x0fffffffu));
+		{
+			rec[0] = make_uint4(uint32_t(t0), uint32_t(t1), uint32_t(c1 - c0), (xcc << 28) | (hw & 0x0fffffffu));
+			// to the marks: cycles from the start of the tile (0: not passed); gather and walks: cycles summed over the chunks
+			rec[1] = make_uint4(marks[0] ? marks[0] - uint32_t(c0) : 0u, marks[1] ? marks[1] - uint32_t(c0) : 0u, marks[2], marks[3]);
+		}
 	}
 };
 #define LV_STAMP_SCOPE(tile) StampScope stamp_scope__{uint32_t(tile)}
-// cycles the wave waits for its next ticket (the atomic asked for at the top of the tile), into the second half of the record array
-#define LV_STAMP_WAIT_BEGIN() const uint64_t wait_c0__ = __builtin_amdgcn_s_memtime()
-#define LV_STAMP_WAIT_END()                                                                                   \
-	do                                                                                                        \
-	{                                                                                                         \
-		const uint64_t wait_c1__ = __builtin_amdgcn_s_memtime();                                              \
-		if (stamp_scope__.rec && lane == 0)                                                                   \
-			stamp_scope__.rec[g_lighting_stamp_records] = make_uint4(uint32_t(wait_c1__ - wait_c0__), 0u, 0u, 0u); \
-	} while (0)
 #else
 #define LV_STAMP_SCOPE(tile)
-#define LV_STAMP_WAIT_BEGIN()
-#define LV_STAMP_WAIT_END()
 #endif
 
 // AO: the AMBIENT_OCCLUSION shader variant (renderer.cpp:1050-1051), a separate instantiation so that the default kernel keeps
@@ -779,190 +754,27 @@ struct StampScope
 // B10: emissive and the HDR target are B10G11R11_UFLOAT_PACK32 (the reference's default, renderTargetFp16 = false): 4-byte
 // texels, both blends round to the packed format (device_common.hpp: float_to_ufloat).
 //
-// Static form: the grid is the tile list, four waves side by side per workgroup (a 32 PX x 8 block).  Kept for devices that are not
-// one 8-XCD partition and for the A/B (GR_LIGHTING_STATIC=1).
+// The grid is the tile list in screen order: blockIdx.x = block column (four wave tiles side by side, a 32 PX x 8 block), blockIdx.y =
+// block row.  Workgroups go to the XCDs round-robin in that order, so every XCD takes every eighth block and their finish times stay
+// within 4 % (contiguous XCD bands differed by up to 20 % with the scene's light density: profiles/r04_lighting_tiles_*.txt).
 template <int PX, bool AO, bool B10 = false>
 __global__ __launch_bounds__(64 * LIGHT_WAVES) void k_lighting(KernelArgs a)
 {
 	__shared__ __attribute__((aligned(16))) f32x4 s_lights[LIGHT_WAVES][64 * (LIGHT_SLOT_BYTES / 16)];
 	__shared__ float s_srgb[256];
 	constexpr int TILE_W = LIGHT_TILE * PX;
-
-	// Tile order.  Block b runs on XCD b % 8.  banded: each XCD gets one contiguous band of the screen (cluster words and light
-	// records of a band stay in that XCD's L2, but the bands' light counts differ: the slowest XCD is the launch);
-	// otherwise blocks in screen order, i.e. every XCD takes every eighth block.
-	int logical = int(blockIdx.x);
-	if (a.banded)
-		logical = int(blockIdx.x & 7u) * a.blocks_per_xcd + int(blockIdx.x >> 3);
-	if (logical >= a.num_blocks)
-		return;
 	// sRGB8 -> linear table into LDS (one entry per thread of the four-wave workgroup), the only workgroup-wide step.
 #pragma unroll
 	for (int i = 0; i < 256; i += 64 * LIGHT_WAVES)
 		s_srgb[i + threadIdx.x] = a.srgb_lut[i + threadIdx.x];
-	const int block_x = logical % a.blocks_x, block_y = a.block_row0 + logical / a.blocks_x;
 	const int wave = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
-	const int tile_x0 = (block_x * LIGHT_WAVES + wave) * TILE_W, tile_y0 = block_y * LIGHT_TILE;
+	const int tile_x0 = (int(blockIdx.x) * LIGHT_WAVES + wave) * TILE_W, tile_y0 = (a.block_row0 + int(blockIdx.y)) * LIGHT_TILE;
+	LV_STAMP_SCOPE((int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * LIGHT_WAVES + wave);
 	RawTile<PX, B10> raw;
 	load_raw<PX, B10>(a, tile_x0 + (lane & (LIGHT_TILE - 1)) * PX, tile_y0 + (lane >> 3), raw);
 	__syncthreads(); // s_srgb
-	LV_STAMP_SCOPE(logical * LIGHT_WAVES + wave);
-	shade_tile<PX, AO, B10>(a, tile_x0, tile_y0, lane, raw, s_lights[wave], s_srgb, []() {});
-}
-
-// Persistent form: the grid is the machine (as many workgroups as stay resident), and every WAVE deals itself tiles until the frame
-// is done.
-//   * Tiles cost between a copy (sky) and several light chunks.  A static grid holds a workgroup's four wave slots until its slowest
-//     tile is done and pays the launch prologue (argument loads, the table, a barrier) 16 200 times: measured, 27 % of the wave-slot
-//     time of the static launch is spent outside tiles (profiles/r04_lighting_tiles_static_screen_order.txt).  Here a wave that
-//     finishes takes its next tile at once.
-//   * One queue per workgroup, tile t in queue t % Q.  A queue is a ticket counter in its own cache line: four waves take about one
-//     ticket every 2 us from it.  (Eight queues for the chip -- one per XCD, 8 100 tickets each per launch -- were tried first: the
-//     same-address atomics serialise in the L2 and the waves queue up behind the counter, 227 us against 181 us for the static grid,
-//     profiles/r04_lighting_tiles_persistent_8queues.txt.)
-//   * A workgroup whose queue has run dry reads all counters at once (16 loads per lane in flight, one round trip) and moves to the
-//     nearest queue that still has tiles -- queue ids are XCD-major, so that is a neighbour on its own XCD while there is one.  The
-//     counters are ordinary agent-scope atomics: which queue a wave serves is a matter of speed, never of correctness.
-//   * A queue word is {epoch : 32 | next ticket : 32}.  A wave first raises the word to {this launch's epoch, 0} (atomic max,
-//     idempotent), then adds: no reset pass, no assumption about who else has seen the queue.  Epochs grow per slot; concurrent
-//     launches (two frames' fronts on two streams) use different slots of the ring in gr_ctx.
-//   * While a tile's lights are walked the next tile's attachment words (ticket taken at the top of this tile) are already on
-//     their way into registers: the G-buffer latency of a tile is hidden under its predecessor's arithmetic.
-constexpr int LIGHT_MAX_QUEUES = 1024;  // = the largest persistent grid (gr_ctx::LIGHTING_QUEUE_SLOT_BYTES)
-constexpr int LIGHT_QUEUE_STRIDE = 16;  // uint64 words = 128 B: one queue per cache line
-
-// The compiler must not know that two tiles read the same argument block (see the loop below).
-typedef const KernelArgs __attribute__((address_space(4))) *ConstantArgsPtr;
-__device__ __forceinline__ const KernelArgs *launder_arguments()
-{
-	// the kernel's only parameter is the block itself: it sits at the start of the kernel-argument segment
-	ConstantArgsPtr p = (ConstantArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-	asm volatile("" : "+s"(p));
-	return (const KernelArgs *)p;
-}
-
-template <int PX, bool AO, bool B10 = false>
-__global__ __launch_bounds__(64 * LIGHT_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lighting_persistent(const KernelArgs a_)
-{
-	const KernelArgs &a = a_;
-	__shared__ __attribute__((aligned(16))) f32x4 s_lights[LIGHT_WAVES][64 * (LIGHT_SLOT_BYTES / 16)];
-	__shared__ float s_srgb[256];
-	constexpr int TILE_W = LIGHT_TILE * PX;
-#pragma unroll
-	for (int i = 0; i < 256; i += 64 * LIGHT_WAVES)
-		s_srgb[i + threadIdx.x] = a.srgb_lut[i + threadIdx.x];
-	const int wave = threadIdx.x >> 6;
-	const int lane = threadIdx.x & 63;
-	f32x4 *const slots = s_lights[wave];
-	__syncthreads(); // s_srgb; the waves never meet again
-
-	const uint64_t epoch_word = uint64_t(a.epoch) << 32;
-	const int tiles_x = a.tiles_x;
-	const int num_queues = int(gridDim.x);
-	const int tiles_quotient = a.tiles_per_queue, tiles_remainder = a.tiles_remainder; // num_tiles = quotient Q + remainder
-	auto tiles_of_queue = [tiles_quotient, tiles_remainder](int queue) { return tiles_quotient + (queue < tiles_remainder ? 1 : 0); }; // t = queue + Q k < num_tiles
-	// Workgroup b runs on XCD b % 8: XCD-major queue ids put the queues of one XCD side by side (the order a thief looks in).
-	const int home = (num_queues & 7) == 0 ? int(blockIdx.x & 7u) * (num_queues >> 3) + int(blockIdx.x >> 3) : int(blockIdx.x);
-
-	int q = home;
-	for (;;)
-	{
-		const int queue_tiles = tiles_of_queue(q);
-		unsigned long long *const word = a.queues + q * LIGHT_QUEUE_STRIDE;
-		// One lane talks to the queue; the ticket travels to the others through an SGPR.
-		auto ticket_of = [&](uint64_t w) -> int {
-			const uint32_t k = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(w))));
-			return k < uint32_t(queue_tiles) ? int(k) * num_queues + q : -1;
-		};
-		uint64_t taken = 0;
-		if (lane == 0)
-		{
-			__hip_atomic_fetch_max(word, epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			taken = __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		int tile = ticket_of(taken);
-		RawTile<PX, B10> raw;
-		if (tile >= 0)
-		{
-			const int tx = tile % tiles_x, ty = tile / tiles_x;
-			load_raw<PX, B10>(a, tx * TILE_W + (lane & (LIGHT_TILE - 1)) * PX, (a.block_row0 + ty) * LIGHT_TILE + (lane >> 3), raw);
-		}
-		while (tile >= 0)
-		{
-			// The argument block (~100 dwords) is read from the kernel-argument segment where it is used, every tile anew, as the static
-			// form does once per workgroup: held in SGPRs across the loop it does not fit and spills into VGPR lanes (v_writelane /
-			// v_readlane pairs inside the walk).  s_load hits the scalar cache and costs no vector issue slot.
-			const KernelArgs &a = *launder_arguments();
-			LV_STAMP_SCOPE(tile);
-			const int tx = tile % tiles_x, ty = tile / tiles_x;
-			// the next ticket: asked for now, looked at when this tile's gather is through
-			uint64_t next_taken = 0;
-			if (lane == 0)
-				next_taken = __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			int next_tile = -1;
-			RawTile<PX, B10> next_raw;
-			shade_tile<PX, AO, B10>(a, tx * TILE_W, (a.block_row0 + ty) * LIGHT_TILE, lane, raw, slots, s_srgb, [&]() {
-				LV_STAMP_WAIT_BEGIN();
-				next_tile = ticket_of(next_taken);
-				LV_STAMP_WAIT_END();
-				if (next_tile >= 0)
-				{
-					const int nx = next_tile % tiles_x, ny = next_tile / tiles_x;
-					load_raw<PX, B10>(a, nx * TILE_W + (lane & (LIGHT_TILE - 1)) * PX, (a.block_row0 + ny) * LIGHT_TILE + (lane >> 3), next_raw);
-				}
-			});
-			raw = next_raw;
-			tile = next_tile;
-		}
-		// This queue is dry.  All counters at once, then the nearest queue after this wave's home that still has tiles or that nobody has
-		// opened in this launch.
-		uint64_t seen[LIGHT_MAX_QUEUES / 64];
-		unsigned long long *scan_base = a.queues + lane * LIGHT_QUEUE_STRIDE;
-		asm volatile("" : "+v"(scan_base)); // the sixteen addresses are made here, not kept in registers across the tile loop
-#pragma unroll
-		for (int c = 0; c < LIGHT_MAX_QUEUES / 64; c++)
-		{
-			seen[c] = ~0ull;
-			if (c * 64 + lane < num_queues)
-				seen[c] = __hip_atomic_load(scan_base + c * 64 * LIGHT_QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		int victim = -1, best_distance = 0x7fffffff;
-#pragma unroll
-		for (int c = 0; c < LIGHT_MAX_QUEUES / 64; c++)
-		{
-			const int candidate = c * 64 + lane;
-			const bool open = candidate < num_queues && !(uint32_t(seen[c] >> 32) == a.epoch && uint32_t(seen[c]) >= uint32_t(tiles_of_queue(candidate)));
-			const uint64_t open_mask = __ballot(open);
-			if (open_mask == 0ull)
-				continue;
-			// distance walking upwards from home, wrapping: the chunk's nearest open queue
-			const int base = c * 64;
-			const int from = home - base; // home's position relative to this chunk
-			uint64_t ahead = from >= 64 ? 0ull : (from <= 0 ? open_mask : open_mask & (~0ull << from));
-			int nearest, distance;
-			if (ahead != 0ull)
-			{
-				nearest = base + __builtin_ctzll(ahead);
-				distance = nearest - home;
-				if (distance < 0)
-					distance += num_queues;
-			}
-			else
-			{
-				nearest = base + __builtin_ctzll(open_mask);
-				distance = nearest - home + num_queues;
-			}
-			if (distance < best_distance)
-			{
-				best_distance = distance;
-				victim = nearest;
-			}
-		}
-		if (victim < 0)
-			break;
-		q = victim;
-	}
+	shade_tile<PX, AO, B10>(a, tile_x0, tile_y0, lane, raw, s_lights[wave], s_srgb LV_STAMP_ARG);
 }
 
 static bool check_image(const gr_image &img, uint32_t format, uint32_t bpp, uint32_t w, uint32_t h)
@@ -1022,8 +834,6 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 		k.camera_pos[i] = args->clustering.camera_pos[i];
 		k.dir_color[i] = args->directional.color[i];
 		k.dir_direction[i] = args->directional.direction[i];
-		k.cl_camera_base[i] = args->cluster.camera_base[i];
-		k.cl_camera_front[i] = args->cluster.camera_front[i];
 	}
 	k.inv_resolution[0] = args->clustering.inv_resolution[0];
 	k.inv_resolution[1] = args->clustering.inv_resolution[1];
@@ -1034,7 +844,13 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	k.cl_num_lights = clustered ? args->cluster.num_lights : 0;
 	k.cl_num_lights_32 = args->cluster.num_lights_32;
 	k.cl_z_max_index = args->cluster.z_max_index;
-	k.cl_z_scale = args->cluster.z_scale;
+	{
+		const float *front = args->cluster.camera_front, *camera = args->cluster.camera_base;
+		const float z_scale = args->cluster.z_scale;
+		for (int i = 0; i < 3; i++)
+			k.cl_z_row[i] = front[i] * z_scale;
+		k.cl_z_row[3] = -(camera[0] * front[0] + camera[1] * front[1] + camera[2] * front[2]) * z_scale;
+	}
 	if (clustered)
 	{
 		const uint8_t *t = static_cast<const uint8_t *>(args->transforms);
@@ -1079,63 +895,29 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	const int px = pairs_aligned ? px_pref : 1;
 	// 32-bit byte offsets inside the kernel.
 	GR_CHECK_ARG(ctx, uint64_t(args->hdr.pitch_bytes) * H <= 0xffffffffull && uint64_t(args->emissive.pitch_bytes) * H <= 0xffffffffull);
-	k.blocks_x = int(gr_div_up(W, LIGHT_TILE * px * LIGHT_WAVES));
-	const int block_rows = int(gr_div_up(row_end, LIGHT_TILE)) - k.block_row0;
-	k.num_blocks = k.blocks_x * block_rows;
-	k.blocks_per_xcd = (k.num_blocks + 7) / 8;
-	k.tiles_x = int(gr_div_up(W, LIGHT_TILE * px));
-	k.num_tiles = k.tiles_x * block_rows;
-	// Residency cap.  The kernel is VALU-bound; at full occupancy it owns every wave slot of the chip for the whole launch
-	// and the executor's other streams (the previous frame's bloom / tonemap, the next frame's cluster build) cannot get
-	// a single wave in.  Padding the workgroup's LDS footprint so that only `max_wgs` workgroups fit per CU leaves the
-	// remaining slots to them.  With two pixels per lane the wave has two independent BRDF chains in flight, so four
-	// workgroups (16 waves) per CU already keep the VALU busy.
+	const dim3 grid(gr_div_up(W, unsigned(LIGHT_TILE * px * LIGHT_WAVES)), gr_div_up(row_end, unsigned(LIGHT_TILE)) - unsigned(k.block_row0));
+	// Residency cap.  The kernel is bound by the vector pipe; at full occupancy it owns every wave slot of the chip for the whole launch
+	// and the executor's other streams (the previous frame's bloom / tonemap, the next frame's cluster build) cannot get a single wave
+	// in.  Padding the workgroup's LDS footprint so that only `max_wgs` workgroups fit per CU leaves the remaining slots to them.  With
+	// two pixels per lane (94 VGPRs) five workgroups per CU = five waves per SIMD: round 5, after the kernel's per-wave instruction
+	// diet, 171.7 / 168.7 us alone against 175.7 / 170.8 with four, the frame 0.2005-0.2010 against 0.2069-0.2076 ms (four was
+	// the round-2 choice, when a fifth wave measured nothing: profiles/r05_lighting_instruction_diet.txt).
 	static const int max_wgs_env = []() {
 		const char *env = gr_measurement_switch("GR_LIGHTING_WGS_PER_CU");
 		const int v = env ? atoi(env) : 0;
 		return v >= 1 && v <= 8 ? v : 0;
 	}();
-	const int max_wgs = max_wgs_env ? max_wgs_env : (px == 2 ? 4 : 7);
+	const int max_wgs = max_wgs_env ? max_wgs_env : (px == 2 ? 5 : 7);
 	const size_t static_lds = sizeof(f32x4) * LIGHT_WAVES * 64 * (LIGHT_SLOT_BYTES / 16) + 256 * sizeof(float);
 	// 8 KiB of the CU's 160 KiB stay free: back-of-frame kernels that use a little LDS (luminance, the fused pyramid tail)
 	// must be able to start beside resident lighting workgroups instead of waiting for one to retire.
 	const size_t per_wg = ((160u - 8u) * 1024u / unsigned(max_wgs * 4 / LIGHT_WAVES)) & ~size_t(1023); // max_wgs counts four-wave workgroups
 	const size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
-	// Form of the launch.  The static grid in screen order is the product path.  GR_LIGHTING_STATIC=banded restores the XCD bands of
-	// rounds 1-3, GR_LIGHTING_PERSISTENT=1 selects the persistent-wave kernel (one 8-XCD partition only): both measured slower
-	// (profiles/r04_lighting_tiles_*.txt) and kept for the A/B.
-	static const bool banded_env = []() {
-		const char *env = gr_measurement_switch("GR_LIGHTING_STATIC");
-		return env && strcmp(env, "banded") == 0;
-	}();
-	static const bool persistent_env = gr_measurement_switch("GR_LIGHTING_PERSISTENT") != nullptr;
-	const bool persistent = persistent_env && ctx->eight_xcd_partition && ctx->lighting_queues != nullptr && px == 2;
-	k.banded = banded_env ? 1 : 0;
-	dim3 grid(unsigned(k.blocks_per_xcd) * 8u);
-	if (persistent)
-	{
-		// Every workgroup of the grid is resident from the start: no more of them than the residency cap admits, and no more waves
-		// than there are tiles.
-		const unsigned resident = min(unsigned(ctx->compute_units) * unsigned(max_wgs * 4 / LIGHT_WAVES), unsigned(LIGHT_MAX_QUEUES));
-		grid = dim3(min(resident, gr_div_up(unsigned(k.num_tiles), LIGHT_WAVES)));
-		k.tiles_per_queue = k.num_tiles / int(grid.x);
-		k.tiles_remainder = k.num_tiles % int(grid.x);
-		uint64_t launch = ctx->lighting_launches.fetch_add(1) + 1;
-		k.epoch = uint32_t(launch / gr_ctx::LIGHTING_QUEUE_SLOTS) + 1u; // grows per slot; 2^32 uses of one slot = 2.7e11 launches
-		k.queues = ctx->lighting_queues + (launch % gr_ctx::LIGHTING_QUEUE_SLOTS) * (gr_ctx::LIGHTING_QUEUE_SLOT_BYTES / sizeof(unsigned long long));
-	}
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "lighting"};
 	const bool ao = (args->flags & GR_LIGHTING_AMBIENT_OCCLUSION_BIT) != 0;
 	const dim3 block(64 * LIGHT_WAVES);
 	const hipStream_t s = gr_to_stream(stream);
-#define GR_LAUNCH_LIGHTING(PX_, AO_, B10_)                                                              \
-	do                                                                                                  \
-	{                                                                                                   \
-		if (persistent)                                                                                 \
-			hipLaunchKernelGGL((k_lighting_persistent<PX_, AO_, B10_>), grid, block, pad_lds, s, k);   \
-		else                                                                                            \
-			hipLaunchKernelGGL((k_lighting<PX_, AO_, B10_>), grid, block, pad_lds, s, k);              \
-	} while (0)
+#define GR_LAUNCH_LIGHTING(PX_, AO_, B10_) hipLaunchKernelGGL((k_lighting<PX_, AO_, B10_>), grid, block, pad_lds, s, k)
 	if (b10)
 	{
 		if (px == 2 && ao)
@@ -1168,7 +950,6 @@ int gr_debug_lighting_stamps(gr_ctx *ctx, void *records, uint32_t count)
 		return GR_ERR_INVALID_ARGUMENT;
 	uint4 *p = static_cast<uint4 *>(records);
 	GR_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_lighting_stamps), &p, sizeof(p)));
-	GR_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_lighting_stamp_records), &count, sizeof(count)));
 	return GR_OK;
 }
 #endif

@@ -736,18 +736,68 @@ constexpr int TONEMAP_BLOCK_X = 64;
 constexpr int TONEMAP_BLOCK_Y = 4;
 constexpr int TONEMAP_ROW_GROUPS = 8; // a workgroup walks 8 x TONEMAP_BLOCK_Y rows: the 8 KiB curve table is staged once per 8192 pixels
 
+// v_fma_mix_f32: an fp32 fma whose operands may be fp16 halves of a 32-bit register, converted (exactly) on the way in.  The pass reads
+// fp16 texels and computes in fp32: a conversion per operand is a half-rate VALU slot that this instruction does not spend.  HALF = 0:
+// the low half of the word, 1: the high half.  Results are the ones of v_cvt_f32_f16 followed by the fp32 operation (one rounding each).
+template <int HALF>
+__device__ __forceinline__ float mix_sub(uint32_t a, uint32_t b) // float(half(a)) - float(half(b))
+{
+	float r;
+	if (HALF)
+		asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));
+	else
+		asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+template <int HALF>
+__device__ __forceinline__ float mix_fma(float x, float y, uint32_t c) // fmaf(x, y, float(half(c)))
+{
+	float r;
+	if (HALF)
+		asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(y), "v"(c));
+	else
+		asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(y), "v"(c));
+	return r;
+}
+template <int HALF>
+__device__ __forceinline__ float mix_add(uint32_t h, float b) // float(half(h)) + b
+{
+	float r;
+	if (HALF)
+		asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b));
+	else
+		asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b));
+	return r;
+}
+
+// The staircase of device_common.hpp (tonemap_srgb8_lut) as this kernel stages it: 1024 buckets rotated so that the bucket of x is at
+// (bits(x) >> 17) & 1023 -- no subtraction of the table's first float -- and 0xff000000 (the alpha byte) in every value word.  x is
+// clamped to [2^-12, 16): the curve is 255 from the white point 11.2 on, so the last bucket below 16 answers for everything above.
+constexpr uint32_t TONEMAP_TABLE_ROTATION = (TONEMAP_TABLE_MIN_BITS >> TONEMAP_TABLE_BUCKET_SHIFT) & 1023u;
+static_assert(TONEMAP_TABLE_ENTRIES == 1025u && TONEMAP_TABLE_BUCKET_SHIFT == 17u, "bucket index = 10 bits of the float");
+__device__ __forceinline__ uint32_t tonemap_srgb8_staged(float x, const uint2 *table)
+{
+	x = __builtin_amdgcn_fmed3f(x, 0x1p-12f, 0x1.fffffep+3f);
+	const uint32_t offset = (__builtin_bit_cast(uint32_t, x) >> (TONEMAP_TABLE_BUCKET_SHIFT - 3u)) & (1023u << 3u);
+	const uint2 e = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(table) + offset);
+	return e.y + (x >= __builtin_bit_cast(float, e.x) ? 1u : 0u);
+}
+
 template <bool DYNAMIC_EXPOSURE, bool SRGB, bool QUARTER_BLOOM>
 __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(DevImage hdr, DevImage bloom, DevImageRW out,
                                                                               const gr_luminance_data *lum, const uint2 *encode_lut,
                                                                               gr_push_tonemap push, uint32_t y_first, uint32_t y_end, bool hdr_b10)
 {
 	post_wave_priority();
-	// *_SRGB output: the curve and the store's encode are one table lookup per channel (tonemap_srgb8_lut), staged in LDS.
-	__shared__ uint2 s_table[SRGB ? TONEMAP_TABLE_ENTRIES : 1];
+	// *_SRGB output: the curve and the store's encode are one table lookup per channel (tonemap_srgb8_staged), staged in LDS.
+	__shared__ uint2 s_table[SRGB ? 1024 : 1];
 	if (SRGB)
 	{
-		for (uint32_t i = threadIdx.y * TONEMAP_BLOCK_X + threadIdx.x; i < TONEMAP_TABLE_ENTRIES; i += TONEMAP_BLOCK_X * TONEMAP_BLOCK_Y)
-			s_table[i] = encode_lut[i];
+		for (uint32_t i = threadIdx.y * TONEMAP_BLOCK_X + threadIdx.x; i < 1024u; i += TONEMAP_BLOCK_X * TONEMAP_BLOCK_Y)
+		{
+			const uint2 e = encode_lut[i];
+			s_table[(i + TONEMAP_TABLE_ROTATION) & 1023u] = make_uint2(e.x, e.y | 0xff000000u);
+		}
 		__syncthreads();
 	}
 	const int x0 = (blockIdx.x * TONEMAP_BLOCK_X + threadIdx.x) * TONEMAP_PX;
@@ -761,7 +811,8 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 #pragma unroll 1
 	for (int group = 0; group < TONEMAP_ROW_GROUPS; group++)
 	{
-		const int y = int(y_first) + (blockIdx.y * TONEMAP_ROW_GROUPS + group) * TONEMAP_BLOCK_Y + threadIdx.y;
+		// a wave is one row of the block (TONEMAP_BLOCK_X = 64): the row's base addresses are scalars, the lane adds a 32-bit offset
+		const int y = __builtin_amdgcn_readfirstlane(int(y_first) + (blockIdx.y * TONEMAP_ROW_GROUPS + group) * TONEMAP_BLOCK_Y + int(threadIdx.y));
 		if (uint32_t(y) >= y_end)
 			return;
 		const float v = (float(y) + 0.5f) * inv_h;
@@ -769,48 +820,48 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 		const uint8_t *row = hdr.ptr + size_t(y) * hdr.pitch;
 		uint32_t packed[TONEMAP_PX];
 		const bool full = (x0 + TONEMAP_PX <= hdr.w) && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
-		f16x4 texels[TONEMAP_PX];
+		u32x2 texels[TONEMAP_PX]; // RGBA16F words: {g:r, a:b}
 		if (hdr_b10)
 		{
 			// B10G11R11 target: 16 bytes per lane; every texel expands exactly into the RGBA16F texel the code below reads
 			uint32_t words[TONEMAP_PX];
 			if (full)
 			{
-				const u32x4 t = *reinterpret_cast<const u32x4 *>(row + size_t(x0) * 4u);
+				const u32x4 t = *reinterpret_cast<const u32x4 *>(row + uint32_t(x0) * 4u);
 				words[0] = t.x, words[1] = t.y, words[2] = t.z, words[3] = t.w;
 			}
 			else
 			{
 #pragma unroll
 				for (int i = 0; i < TONEMAP_PX; i++)
-					words[i] = *reinterpret_cast<const uint32_t *>(row + size_t(min(x0 + i, hdr.w - 1)) * 4u);
+					words[i] = *reinterpret_cast<const uint32_t *>(row + uint32_t(min(x0 + i, hdr.w - 1)) * 4u);
 			}
 #pragma unroll
 			for (int i = 0; i < TONEMAP_PX; i++)
 			{
 				uint32_t rg, ba;
 				expand_b10g11r11(words[i], rg, ba);
-				texels[i] = __builtin_bit_cast(f16x4, u32x2{rg, ba});
+				texels[i] = u32x2{rg, ba};
 			}
 		}
 		else if (full)
 		{
 			// 32 contiguous bytes per lane, 2 KiB per wave per row.
-			const u32x4 lo = *reinterpret_cast<const u32x4 *>(row + size_t(x0) * 8u);
-			const u32x4 hi = *reinterpret_cast<const u32x4 *>(row + size_t(x0) * 8u + 16u);
-			texels[0] = __builtin_bit_cast(f16x4, u32x2{lo.x, lo.y});
-			texels[1] = __builtin_bit_cast(f16x4, u32x2{lo.z, lo.w});
-			texels[2] = __builtin_bit_cast(f16x4, u32x2{hi.x, hi.y});
-			texels[3] = __builtin_bit_cast(f16x4, u32x2{hi.z, hi.w});
+			const u32x4 lo = *reinterpret_cast<const u32x4 *>(row + uint32_t(x0) * 8u);
+			const u32x4 hi = *reinterpret_cast<const u32x4 *>(row + uint32_t(x0) * 8u + 16u);
+			texels[0] = u32x2{lo.x, lo.y};
+			texels[1] = u32x2{lo.z, lo.w};
+			texels[2] = u32x2{hi.x, hi.y};
+			texels[3] = u32x2{hi.z, hi.w};
 		}
 		else
 		{
 #pragma unroll
 			for (int i = 0; i < TONEMAP_PX; i++)
-				texels[i] = *reinterpret_cast<const f16x4 *>(row + size_t(min(x0 + i, hdr.w - 1)) * 8u);
+				texels[i] = *reinterpret_cast<const u32x2 *>(row + uint32_t(min(x0 + i, hdr.w - 1)) * 8u);
 		}
 
-		// bloom * scale per pixel and channel (the exposure scale distributes over hdr + bloom)
+		// bloom per pixel and channel
 		float bloom_rgb[TONEMAP_PX][3];
 		if (QUARTER_BLOOM)
 		{
@@ -821,16 +872,17 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 			const int j = (y >> 2) - (((y & 3) < 2) ? 1 : 0);
 			const float wy = 0.125f + 0.25f * float((y + 2) & 3);
 			const int r0 = clampi(j, 0, bloom.h - 1), r1 = clampi(j + 1, 0, bloom.h - 1);
+			const uint8_t *row0 = bloom.ptr + size_t(r0) * bloom.pitch, *row1 = bloom.ptr + size_t(r1) * bloom.pitch;
 			float col[3][3];
 #pragma unroll
 			for (int c = 0; c < 3; c++)
 			{
-				const int cx = clampi(k - 1 + c, 0, bloom.w - 1);
-				const f16x4 t0 = *reinterpret_cast<const f16x4 *>(bloom.ptr + size_t(r0) * bloom.pitch + size_t(cx) * 8u);
-				const f16x4 t1 = *reinterpret_cast<const f16x4 *>(bloom.ptr + size_t(r1) * bloom.pitch + size_t(cx) * 8u);
-				col[c][0] = fmaf(float(t1.x) - float(t0.x), wy, float(t0.x));
-				col[c][1] = fmaf(float(t1.y) - float(t0.y), wy, float(t0.y));
-				col[c][2] = fmaf(float(t1.z) - float(t0.z), wy, float(t0.z));
+				const uint32_t cx = uint32_t(clampi(k - 1 + c, 0, bloom.w - 1)) * 8u;
+				const u32x2 t0 = *reinterpret_cast<const u32x2 *>(row0 + cx), t1 = *reinterpret_cast<const u32x2 *>(row1 + cx);
+				// fmaf(float(t1) - float(t0), wy, float(t0)) per channel
+				col[c][0] = mix_fma<0>(mix_sub<0>(t1.x, t0.x), wy, t0.x);
+				col[c][1] = mix_fma<1>(mix_sub<1>(t1.x, t0.x), wy, t0.x);
+				col[c][2] = mix_fma<0>(mix_sub<0>(t1.y, t0.y), wy, t0.y);
 			}
 #pragma unroll
 			for (int ch = 0; ch < 3; ch++)
@@ -854,25 +906,26 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 			}
 		}
 
+		// (hdr + bloom) * exposure
 		float x[TONEMAP_PX][3];
 		uint32_t top = 0u;
 #pragma unroll
 		for (int i = 0; i < TONEMAP_PX; i++)
 		{
-			x[i][0] = (float(texels[i].x) + bloom_rgb[i][0]) * scale;
-			x[i][1] = (float(texels[i].y) + bloom_rgb[i][1]) * scale;
-			x[i][2] = (float(texels[i].z) + bloom_rgb[i][2]) * scale;
+			x[i][0] = mix_add<0>(texels[i].x, bloom_rgb[i][0]) * scale;
+			x[i][1] = mix_add<1>(texels[i].x, bloom_rgb[i][1]) * scale;
+			x[i][2] = mix_add<0>(texels[i].y, bloom_rgb[i][2]) * scale;
 			if (SRGB)
-				top = max(top, max(__builtin_bit_cast(uint32_t, x[i][0]), max(__builtin_bit_cast(uint32_t, x[i][1]), __builtin_bit_cast(uint32_t, x[i][2]))));
+				top = max(max(top, __builtin_bit_cast(uint32_t, x[i][0])), max(__builtin_bit_cast(uint32_t, x[i][1]), __builtin_bit_cast(uint32_t, x[i][2])));
 		}
 		// The table covers finite x >= 0.  A negative, infinite or NaN colour (as an unsigned word: >= 0x7f800000) sends the
 		// wave through the formula, so that even then the bytes are the ones the shader's arithmetic produces.
 		if (SRGB && !__any(top >= 0x7f800000u))
 		{
+			// the value words carry the alpha byte; a channel's shift pushes it out of the word
 #pragma unroll
 			for (int i = 0; i < TONEMAP_PX; i++)
-				packed[i] = tonemap_srgb8_lut(x[i][0], s_table) | (tonemap_srgb8_lut(x[i][1], s_table) << 8) |
-				            (tonemap_srgb8_lut(x[i][2], s_table) << 16) | 0xff000000u;
+				packed[i] = tonemap_srgb8_staged(x[i][0], s_table) | (tonemap_srgb8_staged(x[i][1], s_table) << 8) | (tonemap_srgb8_staged(x[i][2], s_table) << 16);
 		}
 		else
 		{
@@ -889,11 +942,11 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 
 		uint8_t *orow = out.ptr + size_t(y) * out.pitch;
 		if (full && ((reinterpret_cast<uintptr_t>(orow) & 15u) == 0))
-			*reinterpret_cast<u32x4 *>(orow + size_t(x0) * 4u) = u32x4{packed[0], packed[1], packed[2], packed[3]};
+			*reinterpret_cast<u32x4 *>(orow + uint32_t(x0) * 4u) = u32x4{packed[0], packed[1], packed[2], packed[3]};
 		else
 		{
 			for (int i = 0; i < TONEMAP_PX && x0 + i < hdr.w; i++)
-				*reinterpret_cast<uint32_t *>(orow + size_t(x0 + i) * 4u) = packed[i];
+				*reinterpret_cast<uint32_t *>(orow + uint32_t(x0 + i) * 4u) = packed[i];
 		}
 	}
 }

@@ -150,8 +150,8 @@ def test_taa_kernel_within_the_resolve_tolerance(host, w, h, quality):
     for f in range(2):
         host.aah_taa(p(cur2), p(depth), p(mv), p(prev), w, h, p(reproj), quality, p(col), p(hist), 0, 0)
         ref_c, ref_h2 = orc.taa_resolve(cur2, depth, mv, prev, reproj, quality)
-        assert_rgba16f_close(col, ref_c, ulps=3.0, abs_tol=2e-4, what=f"q{quality} f{f + 1} colour")
-        assert_rgba16f_close(hist, ref_h2, ulps=3.0, abs_tol=2e-4, what=f"q{quality} f{f + 1} history")
+        assert_rgba16f_close(col, ref_c, ulps=2.0, abs_tol=1e-4, what=f"q{quality} f{f + 1} colour")
+        assert_rgba16f_close(hist, ref_h2, ulps=2.0, abs_tol=1e-4, what=f"q{quality} f{f + 1} history")
         same = (hist == ref_h2).mean()
         assert same > 0.9, same
         prev = ref_h2
@@ -264,7 +264,7 @@ def test_taa_kernel_with_b10g11r11_input_and_colour_output(host, quality):
     col, hist = np.zeros((h, w), np.uint32), np.zeros((h, w, 4), np.uint16)
     host.aah_taa_fmt(p(cur), p(depth), p(mv), p(prev), w, h, p(reproj), quality, p(col), p(hist), 0, 0, 1, 1)
     ref_c, ref_h = orc.taa_resolve(cur16, depth, mv, prev, reproj, quality, color_b10g11r11=True)
-    assert_rgba16f_close(hist, ref_h, ulps=3.0, abs_tol=2e-4, what="history")
+    assert_rgba16f_close(hist, ref_h, ulps=2.0, abs_tol=1e-4, what="history")
     got_c = orc.unpack_b10g11r11(col)
     assert np.array_equal(orc.pack_b10g11r11(got_c), col)
     # a neighbouring code of a channel only where the fp32 colour (a few ulps apart between kernel and oracle) sits on a tie

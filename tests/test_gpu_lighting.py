@@ -276,47 +276,3 @@ def test_fog_quad_behind_the_clustered_quad(gr, packed):
         sky = sc.gbuf["depth"] == 0.0
         np.testing.assert_array_equal(got[sky], sc.gbuf["emissive"][sky])
         assert (got[~sky][:, 3] != sc.gbuf["emissive"][~sky][:, 3]).mean() > 0.9  # the blend factors apply to alpha as well
-
-
-def test_launch_forms_give_the_same_bytes(tmp_path):
-    """The lighting launch has three forms: the static grid in screen order (the product path), the same grid in XCD bands
-    (GR_LIGHTING_STATIC=banded, rounds 1-3) and persistent waves dealing themselves tiles from per-workgroup ticket queues with
-    stealing (GR_LIGHTING_PERSISTENT=1); the last two are kept for the A/B (profiles/r04_lighting_tiles_*.txt).  Which tile a wave
-    shades when does not enter any pixel: all three must write the same bytes, in place as well as into a separate target, whole
-    frames and a row band.  The switches are read once per process, so each form runs in its own."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    worker = r'''
-import sys, hashlib, json
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import numpy as np
-from granite_amd import capi
-from gpu_scene import Scene
-gr = capi.Context(0)
-flags = capi.LIGHTING_DIRECTIONAL_BIT | capi.LIGHTING_CLUSTERED_BIT | capi.LIGHTING_AMBIENT_FALLBACK_BIT
-out = {}
-for w, h, n in ((640, 360, 900), (1920, 1080, 3000)):
-    sc = Scene(w, h, n); dev = sc.build_clusters_gpu(gr)
-    for alias in (True, False):
-        args, imgs = sc.lighting_args(gr, dev, flags, alias_emissive=alias)
-        for _ in range(3):  # several launches: the persistent form's ticket queues are reused slot by slot, epoch by epoch
-            if alias:
-                imgs["hdr"].upload(sc.gbuf["emissive"])
-            gr.check(gr.lib.gr_lighting(gr.handle, None, args)); gr.sync()
-        out["%%dx%%d alias %%d" %% (w, h, alias)] = hashlib.sha256(imgs["hdr"].download().tobytes()).hexdigest()
-    args, imgs = sc.lighting_args(gr, dev, flags, alias_emissive=False)
-    args.rows[0], args.rows[1] = 37, h // 3
-    gr.check(gr.lib.gr_lighting(gr.handle, None, args)); gr.sync()
-    out["%%dx%%d band" %% (w, h)] = hashlib.sha256(imgs["hdr"].download()[37:37 + h // 3].tobytes()).hexdigest()
-print(json.dumps(out))
-''' % (root, os.path.join(root, "tests"))
-    results = {}
-    for form, env in (("screen", {}), ("banded", {"GR_LIGHTING_STATIC": "banded"}), ("persistent", {"GR_LIGHTING_PERSISTENT": "1"})):
-        r = subprocess.run([sys.executable, "-c", worker], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, (form, r.stderr[-2000:])
-        results[form] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert results["banded"] == results["screen"]
-    assert results["persistent"] == results["screen"]

@@ -37,7 +37,7 @@ def assert_rgba16f_close(a_bits, b_bits, ulps=2.0, abs_tol=1e-4, what=""):
                              f"({ulps} ulp fp16 + {abs_tol}); first at {tuple(idx)}: {a} vs {b}")
 
 
-def assert_rgba16f_close_but_for_ill_conditioned_pixels(a_bits, b_bits, ulps=2.0, abs_tol=1e-4, max_pixels=4, outer_ulps=16.0, what=""):
+def assert_rgba16f_close_but_for_ill_conditioned_pixels(a_bits, b_bits, ulps=2.0, abs_tol=1e-4, max_pixels=4, outer_ulps=4.0, what=""):
     """The stated tolerance everywhere except at up to `max_pixels` pixels, which must still be within `outer_ulps`.  For lit
     frames of millions of pixels under a moving camera: a surface seen edge-on (N.V at its 0.001 clamp) with a light almost
     exactly behind it along the view ray (|V + L| -> 0) has a condition number of ~1e4 in its specular term -- one rounding of

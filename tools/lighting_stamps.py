@@ -2,7 +2,7 @@
 
 Needs the measurement build (records are written only there):
     make -C granite_amd/csrc OUT=../lib_stamp EXTRA_lighting=-DLV_STAMP
-    GRANITE_LIB_DIR=lib_stamp python tools/lighting_stamps.py [out.txt]      (GR_LIGHTING_STATIC=1 | banded for the static forms)
+    GRANITE_LIB_DIR=lib_stamp python tools/lighting_stamps.py [out.txt]      
 One record per wave tile (16 x 8 pixels): {start, end} on the 100 MHz s_memrealtime counter, shader cycles in between, XCC_ID | HW_ID.
 The stamps cost a few s_memtime / s_waitcnt per tile; launch times quoted elsewhere come from the un-stamped build."""
 import ctypes as C, os, sys
@@ -20,7 +20,7 @@ args, imgs = sc.lighting_args(gr, dev, flags, alias_emissive=False)
 tiles_x, tiles_y = (w + 15) // 16, (h + 7) // 8
 # the static grid pads the row of workgroups to 4 waves: index space = blocks * 4
 records = ((w + 63) // 64) * 4 * tiles_y
-buf = capi.DeviceBuffer(gr, 2 * records * 16)  # second half: cycles a wave waited for its next ticket (persistent form)
+buf = capi.DeviceBuffer(gr, 2 * records * 16)  # two records per tile: {start, end, cycles, where} and the cycles to each phase mark
 fn = gr.lib.gr_debug_lighting_stamps
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]; fn.restype = C.c_int
 for _ in range(5):
@@ -29,15 +29,14 @@ gr.sync()
 out = []
 def emit(*a):
     line = ' '.join(str(x) for x in a); print(line); out.append(line)
-form = os.environ.get('GR_LIGHTING_STATIC', 'persistent')
-emit('lighting tile timeline, %dx%d, %d lights, form: %s' % (w, h, nl, {'1': 'static grid, screen order', 'banded': 'static grid, XCD bands'}.get(form, form)))
+emit('lighting tile timeline, %dx%d, %d lights, static grid in screen order' % (w, h, nl))
 for rep in range(3):
     buf.upload(np.zeros(2 * records * 4, np.uint32))
     gr.check(fn(gr.handle, buf.ptr, records)); gr.check(gr.lib.gr_lighting(gr.handle, None, args)); gr.sync(); gr.check(fn(gr.handle, None, 0))
-    both = buf.download(np.uint32).reshape(-1, 4)
-    r, waits = both[:records], both[records:, 0]
+    both = buf.download(np.uint32).reshape(-1, 2, 4)
+    r, marks = both[:, 0], both[:, 1]
     valid = (r[:, 0] != 0) | (r[:, 1] != 0)
-    r, waits = r[valid], waits[valid]
+    r, marks = r[valid], marks[valid]
     t0 = r[:, 0].astype(np.int64); t1 = r[:, 1].astype(np.int64)
     base = t0.min(); t0 -= base; t1 -= base
     dur = (t1 - t0) * 0.01  # us
@@ -57,10 +56,14 @@ for rep in range(3):
         m = xcc == x
         if m.any():
             emit('    xcc %2d: %6d tiles  %9.0f wave-us  start %6.1f  end %6.1f' % (x, m.sum(), dur[m].sum(), t0[m].min() * 0.01, t1[m].max() * 0.01))
-    if waits.any():
-        wc = waits.astype(np.float64)
-        emit('  wait for the next ticket, shader cycles per tile: median %.0f  p95 %.0f  max %.0f  mean %.0f (= %.1f %% of the mean tile)' %
-             (np.median(wc), np.percentile(wc, 95), wc.max(), wc.mean(), 100.0 * wc.mean() / r[:, 2].mean()))
+    walked = marks[:, 1] != 0
+    if walked.any():
+        total = r[walked, 2].astype(np.float64); m = marks[walked].astype(np.float64)
+        parts = [('load + decode + directional quad', m[:, 0]), ('slice window, cells, bounding sphere', m[:, 1] - m[:, 0]),
+                 ('gather + cull, all chunks', m[:, 2]), ('walks, all chunks', m[:, 3]), ('blend + store', total - m[:, 1] - m[:, 2] - m[:, 3])]
+        emit('  shader cycles per tile by phase (tiles with lights: %d; mean %.0f cycles):' % (walked.sum(), total.mean()))
+        for name, c in parts:
+            emit('    %-40s mean %6.0f  (%4.1f %%)  median %6.0f' % (name, c.mean(), 100.0 * c.mean() / total.mean(), np.median(c)))
     slots = len(np.unique(r[:, 3]))
     emit('  wave slots seen (distinct XCC | HW_ID): %d; sum of tile time / (slots x span) = %.3f' % (slots, dur.sum() / (slots * span)))
 if len(sys.argv) > 1:
