@@ -330,19 +330,21 @@ void Device::next_frame_context()
 	// Mark the copies of the frame just recorded, then make sure the slot we are about to reuse has drained.
 	// One fence per stream: a graph built through the public API may consume staging memory on a stream nothing on the
 	// generic stream depends on in that frame, so the generic stream's progress alone does not bound the host's lead.
-	// A stream nobody was handed since its last fence has nothing new to fence: the slot's event keeps an older record, which is
-	// complete by the time the slot comes round again (or was recorded by the executor behind this frame's work: record_frame_fence).
+	// A stream nobody was handed since its last fence has nothing new to fence and records nothing: `fence_frame` says which frame each
+	// event of a slot was last recorded for, so an older record left in a slot is never mistaken for this frame's.
 	auto &done = staging[staging_index];
 	for (int i = 0; i < int(CommandBuffer::Type::Count); i++)
 		if (stream_dirty[i])
 		{
 			throw_hip(hipEventRecord(static_cast<hipEvent_t>(done.fence[i]), static_cast<hipStream_t>(streams[i])), "hipEventRecord");
+			done.fence_frame[i] = frame_number;
 			stream_dirty[i] = false;
 		}
 	staging_index = (staging_index + 1) % StagingFrames;
-	// How far the host may run ahead.  The slot about to be reused belongs to the frame StagingFrames - 1 = 3 frames back: waiting for that one
-	// is all the staging ring needs.  The host waits for the frame 2 back instead: while it enqueues frame N it then knows frame N - 3 to be
-	// complete on every stream -- the frame whose ring copies (cluster buffers, HDR-main: three deep) frame N overwrites -- so the
+	frame_number++;
+	// How far the host may run ahead.  The slot about to be reused belongs to the frame StagingFrames back: all the staging ring needs is
+	// that frame complete on every stream.  The host waits for the frame `lead` = 2 back instead: while it enqueues frame N it then knows
+	// frame N - 3 to be complete -- the frame whose ring copies (cluster buffers, HDR-main: three deep) frame N overwrites -- so the
 	// write-after-read waits against it are found complete by hipEventQuery and never become barrier packets in front of the cluster
 	// build and of the lighting kernel.  Two frames of queued work are 0.1 - 0.4 ms, several times what the host needs to enqueue one.
 	// Measured (round 4, profiles/r04_host_lead_ab.txt): 4K / 4096 lights 0.2224 -> 0.2195 ms sustained, config 4 0.662 -> 0.634,
@@ -352,25 +354,38 @@ void Device::next_frame_context()
 		const unsigned v = e ? unsigned(atoi(e)) : 2u;
 		return v >= 1u && v <= StagingFrames - 1u ? v : 2u;
 	}();
-	auto &next = staging[(staging_index + StagingFrames - 1u - lead) % StagingFrames];
-	for (auto &fence : next.fence)
-	{
-		if (hipEventQuery(static_cast<hipEvent_t>(fence)) != hipSuccess)
+	// Per stream: the newest record that is at least `lead` frames old -- streams are in order, so it covers everything the stream was
+	// given before it.  A stream that was not handed out in frame N - lead (a conditional pass, an API user's async stream) has no
+	// record there; its last one may sit in an older slot, down to the slot about to be reused (frame N - StagingFrames), and that is
+	// the one to wait for: the staging memory of that slot may still be read by the stream's copies.  Records older than
+	// the ring were waited for when their slot came round.  One hipEventQuery per stream that has been used within the ring, none
+	// for an idle stream.
+	for (int i = 0; i < int(CommandBuffer::Type::Count); i++)
+		for (unsigned back = lead; back <= StagingFrames && back < frame_number; back++)
 		{
-			auto t0 = std::chrono::steady_clock::now();
+			auto &slot = staging[(frame_number - back - 1u) % StagingFrames]; // frame f was enqueued into slot (f - 1) % StagingFrames
+			if (slot.fence_frame[i] != frame_number - back)
+				continue;
+			const auto fence = static_cast<hipEvent_t>(slot.fence[i]);
+			if (hipEventQuery(fence) != hipSuccess)
 			{
-				GRANITE_SCOPED_TIMELINE_EVENT("wait-for-frame-in-flight"); // back-pressure: the host is `lead` frames ahead
-				throw_hip(hipEventSynchronize(static_cast<hipEvent_t>(fence)), "hipEventSynchronize");
+				auto t0 = std::chrono::steady_clock::now();
+				{
+					GRANITE_SCOPED_TIMELINE_EVENT("wait-for-frame-in-flight"); // back-pressure: the host is `lead` frames ahead
+					throw_hip(hipEventSynchronize(fence), "hipEventSynchronize");
+				}
+				blocked_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 			}
-			blocked_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			break;
 		}
-	}
 	staging[staging_index].offset = 0;
 }
 
 void Device::record_frame_fence(CommandBuffer::Type type)
 {
-	throw_hip(hipEventRecord(static_cast<hipEvent_t>(staging[staging_index].fence[int(type)]), static_cast<hipStream_t>(streams[int(type)])), "hipEventRecord");
+	auto &frame = staging[staging_index];
+	throw_hip(hipEventRecord(static_cast<hipEvent_t>(frame.fence[int(type)]), static_cast<hipStream_t>(streams[int(type)])), "hipEventRecord");
+	frame.fence_frame[int(type)] = frame_number;
 	stream_dirty[int(type)] = false;
 }
 

@@ -205,11 +205,15 @@ private:
 		// the streams (the cluster pass's batched upload runs on the async-compute stream), so a slot is reusable only once
 		// every stream has passed the frame that used it.
 		void *fence[int(CommandBuffer::Type::Count)] = {};
+		// the frame (Device::frame_number) at which each fence was last recorded; 0: never.  An event whose record is older than the
+		// slot's current frame belongs to an earlier use of the slot and says nothing about this one.
+		uint64_t fence_frame[int(CommandBuffer::Type::Count)] = {};
 	};
 	static constexpr size_t StagingBytes = 4u << 20;
 	static constexpr unsigned StagingFrames = FrameFenceRing;
 	StagingFrame staging[StagingFrames];
 	unsigned staging_index = 0;
+	uint64_t frame_number = 1; // of the frame being enqueued (from 1); its slot is staging[staging_index] = staging[(frame_number - 1) % StagingFrames]
 	mutable bool stream_dirty[int(CommandBuffer::Type::Count)] = {};
 	size_t allocated_bytes = 0;
 	double blocked_seconds = 0.0;

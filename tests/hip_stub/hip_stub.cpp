@@ -33,7 +33,8 @@ struct Stream
 };
 thread_local hipError_t last_error = hipSuccess;
 
-// HIP_STUB_TRACE=1: one line per stream call on stderr -- "L s<stream> <kernel>", "R s<stream> e<event>", "W s<stream> e<event>" -- the order
+// HIP_STUB_TRACE=1: one line per stream call on stderr -- "L s<stream> <kernel>", "R s<stream> e<event>", "W s<stream> e<event>", and the host's
+// "Q s0 e<event>" (hipEventQuery) / "S s0 e<event>" (hipEventSynchronize) -- the order
 // in which a frame hands its work to the runtime (streams and events numbered in creation order).
 const bool tracing = getenv("HIP_STUB_TRACE") != nullptr;
 std::mutex trace_lock;
@@ -141,13 +142,19 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
 	return hipSuccess;
 }
 // HIP_STUB_EVENTS_PENDING=1: a recorded event never reads as complete, so every cross-stream dependency takes the wait path
-hipError_t hipEventQuery(hipEvent_t)
+hipError_t hipEventQuery(hipEvent_t e)
 {
 	counters.event_queries++;
+	trace("Q", nullptr, e, nullptr);
 	static const bool pending = getenv("HIP_STUB_EVENTS_PENDING") != nullptr;
 	return pending ? hipErrorNotReady : hipSuccess;
 }
-hipError_t hipEventSynchronize(hipEvent_t) { counters.syncs++; return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t e)
+{
+	counters.syncs++;
+	trace("S", nullptr, e, nullptr);
+	return hipSuccess;
+}
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 {
 	*ms = std::chrono::duration<float, std::milli>(reinterpret_cast<Event *>(b)->at - reinterpret_cast<Event *>(a)->at).count();

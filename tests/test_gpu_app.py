@@ -73,9 +73,13 @@ def test_frames_match_oracle(scene, compute_post):
     assert_rgba16f_close(a.read("HDR-main"), ref["hdr"], ulps=2.0, what="HDR-main")
     names = ({"threshold": "threshold", "downsample-3": "d3", "upsample-0": "u0"} if compute_post else
              {"threshold": "threshold", "bloom-downsample-3": "d3", "bloom-upsample-2": "u0"})
+    # the post chain stage by stage on the DEVICE's lit HDR target (static scene: the same target every frame), so that no lighting
+    # difference is carried into it: SURVEY 8a's 2 ulp + 1e-4 on every level (profiles/r05_pyramid_ulp_histogram_4k.json)
+    state, chain = {}, None
+    for _ in range(frames):
+        chain = orc.hdr_chain(a.read("HDR-main"), state)
     for res, key in names.items():
-        # error carried from the lighting tolerance through the pyramid: 4 ulp + 2e-4
-        assert_rgba16f_close(a.read(res), ref["chain"][key], ulps=4.0, abs_tol=2e-4, what=res)
+        assert_rgba16f_close(a.read(res), chain[key], ulps=2.0, abs_tol=1e-4, what=res)
     lum_name = "average-luminance" if compute_post else "average-luminance-updated"
     lum = a.read(lum_name).view(np.float32)
     np.testing.assert_allclose(lum[0], ref["chain"]["lum"][0], atol=2e-5)

@@ -195,8 +195,9 @@ def check_frame_against_oracle(W, H, tag):
         chain = orc.hdr_chain(hdr, state)
     assert_rgba16f_close(a.read("threshold"), chain["threshold"], ulps=2.0, what=f"{tag} threshold")
     for res, key in {"downsample-3": "d3", "upsample-0": "u0"}.items():
-        # rounding differences of the levels above are carried down and up the pyramid: 4 ulp + 2e-4
-        assert_rgba16f_close(a.read(res), chain[key], ulps=4.0, abs_tol=2e-4, what=f"{tag} {res}")
+        # rounding differences of the levels above are carried down and up the pyramid and stay inside SURVEY 8a's tolerance
+        # (profiles/r05_pyramid_ulp_histogram_4k.json: every level, no channel beyond 2 ulp + 1e-4)
+        assert_rgba16f_close(a.read(res), chain[key], ulps=2.0, abs_tol=1e-4, what=f"{tag} {res}")
     np.testing.assert_allclose(a.read("average-luminance").view(np.float32)[0], chain["lum"][0], atol=2e-5)
     got, want = a.read_backbuffer(), chain["tonemapped"]
     # tonemap.frag takes its HDR colour through LinearClamp at the pixel centre: a texel fetch at any width under the sampler

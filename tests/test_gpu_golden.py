@@ -33,9 +33,17 @@ def test_executor_matches_committed_fixtures():
     np.testing.assert_array_equal(bitmask[nz], ref["bitmask_nonzero_value"])
     np.testing.assert_array_equal(a.read("cluster-range").view(np.uint32).reshape(-1, 2), ref["range"])
     assert_rgba16f_close(a.read("HDR-main"), ref["hdr"], ulps=2.0, what="HDR-main")
-    assert_rgba16f_close(a.read("threshold"), ref["threshold"], ulps=4.0, abs_tol=2e-4, what="threshold")
-    assert_rgba16f_close(a.read("downsample-3"), ref["d3"], ulps=4.0, abs_tol=2e-4, what="downsample-3")
-    assert_rgba16f_close(a.read("upsample-0"), ref["u0"], ulps=4.0, abs_tol=2e-4, what="upsample-0")
-    np.testing.assert_allclose(a.read("average-luminance").view(np.float32)[0], ref["lum"][0], atol=2e-5)
     assert_rgba8_close(a.read_backbuffer(), ref["tonemapped"], 1, what="tonemapped")
     a.close()
+    # The post chain on the fixture's own HDR target (a second executor without the lighting pass): SURVEY 8a's 2 ulp + 1e-4 on every
+    # level -- nothing of the lighting tolerance is carried into it (profiles/r05_pyramid_ulp_histogram_4k.json: no channel of any level
+    # beyond 2 ulp + 1e-4 with every rounding difference carried down and up the pyramid).
+    b = gapp.Application(cam.width, cam.height, lighting=False)
+    b.upload_hdr(ref["hdr"])
+    b.render_frames(FRAMES)
+    assert_rgba16f_close(b.read("threshold"), ref["threshold"], ulps=2.0, abs_tol=1e-4, what="threshold")
+    assert_rgba16f_close(b.read("downsample-3"), ref["d3"], ulps=2.0, abs_tol=1e-4, what="downsample-3")
+    assert_rgba16f_close(b.read("upsample-0"), ref["u0"], ulps=2.0, abs_tol=1e-4, what="upsample-0")
+    np.testing.assert_allclose(b.read("average-luminance").view(np.float32)[0], ref["lum"][0], atol=2e-5)
+    assert_rgba8_close(b.read_backbuffer(), ref["tonemapped"], 1, what="tonemapped (post chain on the fixture's HDR)")
+    b.close()

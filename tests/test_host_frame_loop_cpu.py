@@ -120,3 +120,39 @@ a.close()
         assert between[0] == "R" and all(k == "W" for k in between[1:]), between
     frame = ops[lighting[0]:lighting[1]]
     assert sum(o[0] == "R" for o in frame) == 3, [o[:2] for o in frame]
+
+
+def test_staging_slot_is_not_reused_before_the_stream_that_read_it_is_through(tmp_path):
+    """ADVICE r4 (hip_device.cpp: next_frame_context).  A stream takes staging memory in frame 4 and is not handed out again.  The slot of
+    frame 4 comes round at frame 8: by then the host must have waited for that stream's fence of frame 4 -- the event recorded on the
+    async stream in frame 4 -- although the slots of frames 5 and 6, which pace the host, hold no record of the stream for those frames.
+    And an idle stream costs no call at all: once its last record has been waited for, nothing names its events again."""
+    if not os.path.exists(STUB) or os.path.getmtime(STUB) < os.path.getmtime(os.path.join(os.path.dirname(STUB), "hip_stub.cpp")):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(STUB)])
+    csrc = os.path.join(ROOT, "granite_amd", "csrc")
+    lib = os.path.join(ROOT, "granite_amd", "lib")
+    exe = str(tmp_path / "staging_fences")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "staging_fences.cpp"), "-o", exe, "-L" + lib, "-lgranite_host", "-lgranite_hip",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"])
+    env = dict(os.environ, LD_PRELOAD=STUB, HIP_STUB_TRACE="1", HIP_STUB_EVENTS_PENDING="1")
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-3000:]
+    frames = {}
+    for chunk in r.stderr.split("=== frame ")[1:]:
+        number, _, body = chunk.partition("\n")
+        frames[int(number)] = [l.split() for l in body.split("=== end")[0].splitlines() if l[:2] in ("R ", "Q ", "S ")]
+    # frame 4: two records, the generic stream's and the async stream's
+    records4 = [o for o in frames[4] if o[0] == "R"]
+    assert len(records4) == 2, frames[4]
+    async_stream = [o[1] for o in records4 if o[1] != [o2 for o2 in frames[3] if o2[0] == "R"][0][1]]
+    assert len(async_stream) == 1
+    async_event = [o[2] for o in records4 if o[1] == async_stream[0]][0]
+    # the host waits for it (query + synchronize under HIP_STUB_EVENTS_PENDING) in the frame that makes frame 4 two frames old, i.e.
+    # while it turns from frame 6 to frame 7 -- and in any case before frame 8 takes the slot
+    waited = [n for n in range(5, 8) if any(o[0] == "S" and o[2] == async_event for o in frames[n])]
+    assert waited, {n: frames[n] for n in range(4, 9)}
+    # afterwards the idle stream is not looked at again, and every frame still paces on the generic stream (one query, one wait)
+    for n in range(9, 13):
+        assert not any(o[2] == async_event for o in frames[n]), frames[n]
+        assert sum(o[0] == "Q" for o in frames[n]) == 1 and sum(o[0] == "S" for o in frames[n]) == 1, frames[n]
