@@ -49,6 +49,7 @@ LIGHTING_DIRECTIONAL_BIT = 1
 LIGHTING_CLUSTERED_BIT = 2
 LIGHTING_AMBIENT_FALLBACK_BIT = 4
 LIGHTING_AMBIENT_OCCLUSION_BIT = 8
+LIGHTING_SHARE_REGISTERS_BIT = 16  # scheduling hint only (include/granite_hip.h)
 
 MAX_LIGHTS_BINDLESS = 4096
 CULL_SETUP_BYTES_PER_LIGHT = 512

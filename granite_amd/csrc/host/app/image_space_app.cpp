@@ -654,7 +654,12 @@ void ImageSpaceApplication::add_main_pass_deferred(const std::string &tag)
 		att.hdr = &graph.get_physical_texture_resource(*hdr_out);
 		att.emissive = emissive_in ? &graph.get_physical_texture_resource(*emissive_in) : att.hdr;
 		att.rows = strip_plan.active() ? &strip_plan.lighting : nullptr;
-		DeferredLightRenderer::render_light(cmd, context, att);
+		// the resolve of a temporal pre-AA and the SMAA passes of the frame before run beside this launch on the generic stream
+		const PostAAType pre = to_post_aa_type(config.pre_aa), post = to_post_aa_type(config.post_aa);
+		const bool heavy_neighbours = pre == PostAAType::TAA_Low || pre == PostAAType::TAA_Medium || pre == PostAAType::TAA_High ||
+		                              post == PostAAType::SMAA_Low || post == PostAAType::SMAA_Medium || post == PostAAType::SMAA_High ||
+		                              post == PostAAType::SMAA_Ultra;
+		DeferredLightRenderer::render_light(cmd, context, att, heavy_neighbours ? DeferredLightRenderer::SHARE_REGISTERS_BIT : 0u);
 	});
 
 	// Scene::add_render_pass_dependencies(graph, lighting_pass, LIGHTING_BIT)

@@ -360,8 +360,9 @@ void Device::next_frame_context()
 	// the one to wait for: the staging memory of that slot may still be read by the stream's copies.  Records older than
 	// the ring were waited for when their slot came round.  One hipEventQuery per stream that has been used within the ring, none
 	// for an idle stream.
+	// (frame_number is the frame about to be enqueued; "lead frames old" counts from the frame just recorded, frame_number - 1.)
 	for (int i = 0; i < int(CommandBuffer::Type::Count); i++)
-		for (unsigned back = lead; back <= StagingFrames && back < frame_number; back++)
+		for (unsigned back = lead + 1u; back <= StagingFrames && back < frame_number; back++)
 		{
 			auto &slot = staging[(frame_number - back - 1u) % StagingFrames]; // frame f was enqueued into slot (f - 1) % StagingFrames
 			if (slot.fence_frame[i] != frame_number - back)

@@ -7,7 +7,7 @@
 namespace Granite
 {
 void DeferredLightRenderer::render_light(HIP::CommandBuffer &cmd, const RenderContext &context, const DeferredLightAttachments &att,
-                                         RendererOptionFlags)
+                                         RendererOptionFlags options)
 {
 	auto *light = context.get_lighting_parameters();
 	if (!light)
@@ -42,7 +42,7 @@ void DeferredLightRenderer::render_light(HIP::CommandBuffer &cmd, const RenderCo
 
 	// The directional quad is always drawn; VOLUMETRIC_DIFFUSE_FALLBACK is defined whenever the clusterer has no
 	// volumetric diffuse (renderer.cpp:1049-1055), which is always the case on this path.
-	args.flags = GR_LIGHTING_DIRECTIONAL_BIT;
+	args.flags = GR_LIGHTING_DIRECTIONAL_BIT | ((options & SHARE_REGISTERS_BIT) ? GR_LIGHTING_SHARE_REGISTERS_BIT : 0u);
 	bool cluster_volumetric_diffuse = light->cluster && light->cluster->clusterer_has_volumetric_diffuse();
 	if (!cluster_volumetric_diffuse)
 	{

@@ -25,6 +25,8 @@ class DeferredLightRenderer
 {
 public:
 	using RendererOptionFlags = uint32_t;
+	// Scheduling hint (GR_LIGHTING_SHARE_REGISTERS_BIT): register-heavy passes of other streams (TAA resolve, SMAA) run beside the lighting launch.
+	static constexpr RendererOptionFlags SHARE_REGISTERS_BIT = 1u;
 	// renderer.cpp:1004-1197: directional quad, clustered quad, and the fog quad when LightingParameters::fog.falloff > 0 (the volumetric-fog quad is outside the path).
 	static void render_light(HIP::CommandBuffer &cmd, const RenderContext &context, const DeferredLightAttachments &attachments,
 	                         RendererOptionFlags flags = 0);

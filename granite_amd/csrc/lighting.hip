@@ -907,7 +907,7 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 		const int v = env ? atoi(env) : 0;
 		return v >= 1 && v <= 8 ? v : 0;
 	}();
-	const int max_wgs = max_wgs_env ? max_wgs_env : (px == 2 ? 5 : 7);
+	const int max_wgs = max_wgs_env ? max_wgs_env : (px == 2 ? ((args->flags & GR_LIGHTING_SHARE_REGISTERS_BIT) ? 4 : 5) : 7);
 	const size_t static_lds = sizeof(f32x4) * LIGHT_WAVES * 64 * (LIGHT_SLOT_BYTES / 16) + 256 * sizeof(float);
 	// 8 KiB of the CU's 160 KiB stay free: back-of-frame kernels that use a little LDS (luminance, the fused pyramid tail)
 	// must be able to start beside resident lighting workgroups instead of waiting for one to retire.

@@ -276,3 +276,18 @@ def test_fog_quad_behind_the_clustered_quad(gr, packed):
         sky = sc.gbuf["depth"] == 0.0
         np.testing.assert_array_equal(got[sky], sc.gbuf["emissive"][sky])
         assert (got[~sky][:, 3] != sc.gbuf["emissive"][~sky][:, 3]).mean() > 0.9  # the blend factors apply to alpha as well
+
+
+def test_the_share_registers_hint_does_not_change_a_byte(gr):
+    """GR_LIGHTING_SHARE_REGISTERS_BIT only caps the launch's residency (four workgroups per CU instead of five: room for the
+    register-heavy passes of other streams); which workgroup runs when does not enter any pixel."""
+    sc = Scene(640, 360, 900)
+    dev = sc.build_clusters_gpu(gr)
+    base = capi.LIGHTING_DIRECTIONAL_BIT | capi.LIGHTING_CLUSTERED_BIT | capi.LIGHTING_AMBIENT_FALLBACK_BIT
+    out = []
+    for flags in (base, base | capi.LIGHTING_SHARE_REGISTERS_BIT):
+        args, imgs = sc.lighting_args(gr, dev, flags, alias_emissive=False)
+        gr.check(gr.lib.gr_lighting(gr.handle, None, args))
+        gr.sync()
+        out.append(imgs["hdr"].download().copy())
+    np.testing.assert_array_equal(out[0], out[1])

@@ -102,11 +102,18 @@ def test_ssr_in_the_graph_matches_the_oracle_pipeline():
     lit = orc.lighting(gbuf, rp, prm, lights, tmask, cb["bitmask"], cb["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
     levels = orc.hiz(depth, orc.hiz_z_transform(rp[48:64]))
     noise, lut = expand_sssr_dither(load_sssr_noise_base()), load_brdf_lut()
+    # The passes read the DEVICE's lit target, which the apply pass then overwrites in place: the same frame of a twin executor without
+    # SSR is what they saw (an ulp from the oracle's in a few texels: tests/test_gpu_lighting.py holds that step).
+    twin = gapp.Application(w, h)
+    twin.set_render_parameters(cam.render_params())
+    twin.set_lights(descs)
+    twin.upload_gbuffer(gbuf)
+    twin.render_frames(1)
+    lit_device = twin.read("HDR-main").copy()
+    twin.close()
+    assert_rgba16f_close(lit_device, lit, ulps=2.0, abs_tol=1e-4, what="lit target")
     for frame in (1, 2):
         a.render_frames(1)
-        # the passes read the DEVICE's lit target (an ulp from the oracle's in a few texels: tests/test_gpu_lighting.py holds that step)
-        lit_device = a.read("HDR-main").copy()
-        assert_rgba16f_close(lit_device, lit, ulps=2.0, abs_tol=1e-4, what="lit target")
         ref = orc.ssr_trace(levels, pbr, normal, lit_device, noise, frame, rp[32:48], rp[80:96], rp[96:99])
         counter = a.read("ssr-ray-counter").view(np.uint32)[:6]
         np.testing.assert_array_equal(counter, ref["ray_counter"])
