@@ -1300,9 +1300,13 @@ int gr_bloom_up_all_supported(const gr_image *d3, const gr_image *u2, const gr_i
 		return 0;
 	if (!upsample_is_exact(u1, push_u0) || u1->width == 0 || u1->height == 0)
 		return 0;
-	// No size limit: the levels involved are a quarter of the frame and coarser, so the recomputed overlap is small at any size.  Measured at 4K
-	// (profiles/r04_host_lead_ab.txt): config 3 0.2198 / 0.2192 -> 0.2197 / 0.2200 ms (the chain runs under the lighting kernel either way),
-	// config 4, whose post chain is the frame, 0.6264 / 0.6257 -> 0.6216 / 0.6212 ms.
+	// Up to the quarter level of a 4K frame.  The levels involved are a quarter of the frame and coarser, but a 32 x 32 tile of upsample-0
+	// recomputes its patches of the two levels under it (upsample-2 five times over all tiles): 3.05 M wave instructions at 4K against
+	// 1.17 M for the separate launches.  Measured, same box, alternating (profiles/r05_up_fusion_by_size.txt): config 3 (4K) 0.2019 / 0.2024
+	// fused against 0.2042 / 0.2029 ms, config 4 0.5922 / 0.5996 against 0.5994 / 0.5987, config 5 (8K whole on one GPU) 0.7552 / 0.7515
+	// against 0.7196 / 0.7189 ms: at 8K the recomputation costs more than the launch it saves.
+	if (uint64_t(u0->width) * u0->height > 960ull * 540ull)
+		return 0;
 	return 1;
 }
 

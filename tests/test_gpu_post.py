@@ -286,8 +286,11 @@ def test_fused_upsample_chain_equals_the_separate_launches(gr, w, h, dynamic):
 
 
 def test_fused_upsample_chain_declines_what_it_does_not_cover(gr):
-    """A quarter level that is not exactly twice the eighth keeps gr_bloom_up_tail + gr_bloom_upsample."""
+    """A quarter level that is not exactly twice the eighth keeps gr_bloom_up_tail + gr_bloom_upsample, and so does a frame above 4K
+    (the tiles' recomputed patches cost more than the launch they save there: profiles/r05_up_fusion_by_size.txt)."""
     u0, u1, u2, d3 = (capi.DeviceImage(gr, *orc.level_size(1004, 812, s), F16) for s in (0.25, 0.125, 0.0625, 0.03125))
+    assert not gr.bloom_up_all(d3, u2, u1, u0)
+    u0, u1, u2, d3 = (capi.DeviceImage(gr, *orc.level_size(7680, 4320, s), F16) for s in (0.25, 0.125, 0.0625, 0.03125))
     assert not gr.bloom_up_all(d3, u2, u1, u0)
 
 
