@@ -164,7 +164,7 @@ def test_config5_frame_whole_on_one_gpu_matches_oracle_at_8k():
 def check_frame_against_oracle(W, H, tag):
     """BASELINE config 3 through the executor (3840x2160, 4096 clustered point + spot lights, bloom pyramid + luminance +
     tonemap) against the oracle: cluster bitmask / ranges bit-exact, HDR-main, threshold, downsample-3, upsample-0 at the
-    stated fp16 tolerances, backbuffer +-1 LSB.  Exercises what only exists at this size: the XCD-banded block order,
+    stated fp16 tolerances, backbuffer +-1 LSB.  Exercises what only exists at this size: the screen-order grid of 16 200 workgroups,
     32-bit offsets over 66 MB targets, 8100-block grids, the all-2:1 stencil pyramid and the fused tail."""
     from test_gpu_app import oracle_frames
     from oracle import oracle as orc
