@@ -562,6 +562,24 @@ def main():
                                                                          "transcendental 7.2, cvt 3.5, int 2.2, others 3.7) / 1024 SIMDs / 2.0 GHz sustained")
         except (OSError, KeyError, ValueError):
             pass
+        # Config 4: what the anti-aliasing kernels fetch and write against their algorithmic bytes (tools/pmc_aa.sh -> profiles/aa_traffic.json;
+        # FETCH_SIZE / WRITE_SIZE passes over the kernels alone at 3840x2160), quoted while the kernels' sources hash to what was measured.
+        if args.workload == "config4_4k_smaa_taa" and world == 1:
+            try:
+                import hashlib
+                with open(os.path.join(ROOT, "profiles", "aa_traffic.json")) as f:
+                    aa = json.load(f)
+                fresh = all(hashlib.sha256(open(os.path.join(ROOT, src), "rb").read()).hexdigest() == digest for src, digest in aa["sources_sha256"].items())
+                if fresh:
+                    roofline["aa_kernels"] = {k: {"kernel": v["kernel"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                                                  "algorithmic_bytes_per_launch": v["algorithmic_read_bytes"] + v["algorithmic_write_bytes"],
+                                                  "fetch_over_algorithmic_reads": v["fetch_over_algorithmic_reads"],
+                                                  "write_over_algorithmic_writes": v["write_over_algorithmic_writes"]} for k, v in aa["kernels"].items()}
+                    roofline["aa_kernels_source"] = "profiles/aa_traffic.json (" + aa["source"] + "; " + aa["correction"] + ")"
+                else:
+                    roofline["aa_kernels_source"] = "profiles/aa_traffic.json is stale: an AA kernel source changed since the counters were collected (tools/pmc_aa.sh regenerates it)"
+            except (OSError, KeyError, ValueError):
+                pass
         # The binding resource of the dominant kernel: whichever ceiling it sits closer to.  `frac` stays the HBM fraction the metric asks for.
         vf = (roofline.get("valu_issue") or {}).get("frac")
         roofline["hbm_frac"] = roofline["frac"]

@@ -713,6 +713,11 @@ int gr_timing_span_begin(gr_ctx *ctx, gr_stream stream, const char *name, void *
 	auto *s = new gr_timing_span{name, ctx->get_event(), ctx->get_event()};
 	if (!s->start || !s->stop)
 	{
+		// one of the two could not be created: the other goes back to the pool
+		if (s->start)
+			ctx->event_pool.push_back(s->start);
+		if (s->stop)
+			ctx->event_pool.push_back(s->stop);
 		delete s;
 		return GR_OK;
 	}

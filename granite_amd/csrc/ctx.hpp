@@ -131,7 +131,14 @@ struct gr_scoped_timing
 		span.start = ctx->get_event();
 		span.stop = ctx->get_event();
 		if (!span.start || !span.stop)
+		{
+			// one of the two could not be created: the other goes back to the pool
+			if (span.start)
+				ctx->event_pool.push_back(span.start);
+			if (span.stop)
+				ctx->event_pool.push_back(span.stop);
 			return;
+		}
 		active = true;
 		(void)hipEventRecord(span.start, stream);
 	}
