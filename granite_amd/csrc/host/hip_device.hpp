@@ -180,6 +180,8 @@ public:
 	void *frame_fence(CommandBuffer::Type type) const { return staging[staging_index].fence[int(type)]; }
 	static constexpr unsigned FrameFenceRing = 4; // = StagingFrames: a frame's fences are re-recorded this many frames later
 	void record_frame_fence(CommandBuffer::Type type);
+	// Number of the frame being enqueued (from 1; advanced by next_frame_context()).
+	uint64_t get_frame_number() const { return frame_number; }
 	void next_frame_context();
 	void wait_idle();
 

@@ -1376,6 +1376,18 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 
 	static const bool sync_debug = getenv("GRANITE_SYNC_DEBUG") != nullptr;
 	const uint64_t this_frame = frame_counter - 1;
+	// The runs published under the device's frame fences stay named for EventRing frames on the assumption that the device's ring and this
+	// one advance together: one next_frame_context() per enqueued frame.  A caller that rotates the device faster only makes waits
+	// stricter (a fence re-recorded early is a later point of its stream), i.e. costs barrier packets, never correctness: say so once.
+	if (sync_debug && last_device_frame != 0 && device_.get_frame_number() != last_device_frame + 1)
+	{
+		static bool told = false;
+		if (!told)
+			fprintf(stderr, "[sync] the device advanced %llu frame contexts between two enqueued frames: published fences are re-recorded early (stricter waits)\n",
+			        (unsigned long long)(device_.get_frame_number() - last_device_frame));
+		told = true;
+	}
+	last_device_frame = device_.get_frame_number();
 	int current_pass = -1;
 	std::vector<void *> waited;
 	auto wait_for = [&](hipStream_t stream, void *event, const char *kind = "", unsigned resource = 0, int src_pass = -1, uint64_t src_frame = 0) {

@@ -529,6 +529,7 @@ private:
 	enum { EventRing = 4 };
 	std::vector<void *> pass_done_event;
 	uint64_t frame_counter = 0;
+	uint64_t last_device_frame = 0; // Device::get_frame_number() at the last enqueue (the two rings advance in lockstep)
 	struct PhysicalSync
 	{
 		void *last_write = nullptr;
