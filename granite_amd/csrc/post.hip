@@ -863,7 +863,8 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 #pragma unroll 1
 	for (int group = 0; group < TONEMAP_ROW_GROUPS; group++)
 	{
-		// a wave is one row of the block (TONEMAP_BLOCK_X = 64): the row's base addresses are scalars, the lane adds a 32-bit offset
+		// a wave is one row of the block: the row's base addresses are scalars, the lane adds a 32-bit offset
+		static_assert(TONEMAP_BLOCK_X == 64, "threadIdx.y is wave-uniform");
 		const int y = __builtin_amdgcn_readfirstlane(int(y_first) + (blockIdx.y * TONEMAP_ROW_GROUPS + group) * TONEMAP_BLOCK_Y + int(threadIdx.y));
 		if (uint32_t(y) >= y_end)
 			return;
