@@ -14,6 +14,6 @@ done
 timeout 400 bash tools/multirank_one_gpu.sh 2 --steps 5 --warmup 2 --no-cpu-baseline --sustain-seconds 0.5 > $O/multirank_2.json 2> $O/multirank_2.err; tail -c 600 $O/multirank_2.json; echo
 timeout 900 bash tools/pmc_passes.sh pmc_$TAG > $O/pmc_passes.log 2>&1; python tools/pmc_to_traffic.py gpurun_out/pmc_$TAG/summary.json $O/pmc_traffic.json ${TAG//[^0-9]/} | tail -2
 cp gpurun_out/pmc_$TAG/summary.txt $O/pmc_counters_per_kernel.txt; rm -rf gpurun_out/pmc_$TAG
-(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/kstats -o bench --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2>/dev/null)
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/kstats -o bench --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --sustain-seconds 0 > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2>/dev/null)
 find $O/kstats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv; rm -rf $O/kstats; head -6 $O/bench_kernel_stats.csv | cut -c1-140
 du -sh gpurun_out
