@@ -243,7 +243,7 @@ int gr_bloom_up_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr
                      gr_luminance_data *lum, const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1,
                      const gr_push_luminance *push_lum);
 
-/* The whole upsample chain -- luminance, upsample-2, upsample-1, upsample-0 (hdr.cpp:368-379) -- in one launch: a workgroup makes a 64 x 64
+/* The whole upsample chain -- luminance, upsample-2, upsample-1, upsample-0 (hdr.cpp:368-379) -- in one launch: a workgroup makes a 32 x 32
  * tile of upsample-0 from the patch of upsample-1 under it, that from the patch of upsample-2, that from downsample-3; all three levels are
  * written, byte for byte what gr_bloom_up_tail + gr_bloom_upsample leave.  gr_bloom_up_all_supported(): whole levels of a pyramid of
  * InputRelative sizes, upsample-0 exactly twice upsample-1 and at most 960 x 540 (a 4K frame: above, the tiles' recomputed patches cost more than the launch saved).  lum / push_lum both NULL: no
