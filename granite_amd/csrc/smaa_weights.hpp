@@ -702,7 +702,14 @@ struct SmaaWeightsBitsArgs
 // a few per cent of a frame and take different paths through the pass (horizontal / vertical / diagonal patterns), so the
 // workgroup first writes its edge pixels into a list and then walks the list with all of its lanes: full waves of edge pixels
 // instead of a few live lanes per wave.
-__global__ __launch_bounds__(FAST_BW *FAST_BH) void k_smaa_weights_bits(SmaaWeightsBitsArgs A, uint8_t *out, uint32_t out_pitch, RowSpan rows)
+// Register cap: 64 VGPRs (the kernel wants 69: two dwords go to scratch).  A workgroup is two waves per SIMD, and beside four resident
+// lighting waves of 96 registers a SIMD has 128 left: at 72 a workgroup only starts where a lighting wave has retired.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMAA_WEIGHTS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8)))
+#else
+#define SMAA_WEIGHTS_OCCUPANCY
+#endif
+__global__ __launch_bounds__(FAST_BW *FAST_BH) SMAA_WEIGHTS_OCCUPANCY void k_smaa_weights_bits(SmaaWeightsBitsArgs A, uint8_t *out, uint32_t out_pitch, RowSpan rows)
 {
 	using T = EdgeBitTiles;
 	constexpr int THREADS = FAST_BW * FAST_BH, WAVES = THREADS / 64;
