@@ -34,6 +34,8 @@ for rep in range(3):
     buf.upload(np.zeros(2 * records * 4, np.uint32))
     gr.check(fn(gr.handle, buf.ptr, records)); gr.check(gr.lib.gr_lighting(gr.handle, None, args)); gr.sync(); gr.check(fn(gr.handle, None, 0))
     both = buf.download(np.uint32).reshape(-1, 2, 4)
+    if os.environ.get('LV_STAMP_DUMP'):  # raw records for tools/lighting_residency.py (offline: wave slots over time)
+        np.savez_compressed('%s_%d.npz' % (os.environ['LV_STAMP_DUMP'], rep), records=both)
     r, marks = both[:, 0], both[:, 1]
     valid = (r[:, 0] != 0) | (r[:, 1] != 0)
     r, marks = r[valid], marks[valid]
@@ -59,11 +61,13 @@ for rep in range(3):
     walked = marks[:, 1] != 0
     if walked.any():
         total = r[walked, 2].astype(np.float64); m = marks[walked].astype(np.float64)
-        parts = [('load + decode + directional quad', m[:, 0]), ('slice window, cells, bounding sphere', m[:, 1] - m[:, 0]),
-                 ('gather + cull, all chunks', m[:, 2]), ('walks, all chunks', m[:, 3]), ('blend + store', total - m[:, 1] - m[:, 2] - m[:, 3])]
+        parts = [('loads, position, range[] requested, cells, sphere, N, V', m[:, 0]),
+                 ('window, words, material terms, records requested, directional quad', m[:, 1] - m[:, 0]),
+                 ('cull + stage, all chunks (first: wait for the records)', m[:, 2]), ('walks, all chunks', m[:, 3]),
+                 ('blend + store', total - m[:, 1] - m[:, 2] - m[:, 3])]
         emit('  shader cycles per tile by phase (tiles with lights: %d; mean %.0f cycles):' % (walked.sum(), total.mean()))
         for name, c in parts:
-            emit('    %-40s mean %6.0f  (%4.1f %%)  median %6.0f' % (name, c.mean(), 100.0 * c.mean() / total.mean(), np.median(c)))
+            emit('    %-72s mean %6.0f  (%4.1f %%)  median %6.0f' % (name, c.mean(), 100.0 * c.mean() / total.mean(), np.median(c)))
     slots = len(np.unique(r[:, 3]))
     emit('  wave slots seen (distinct XCC | HW_ID): %d; sum of tile time / (slots x span) = %.3f' % (slots, dur.sum() / (slots * span)))
 if len(sys.argv) > 1:
