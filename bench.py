@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="length of the unbracketed run after the timed region (0 = off); 6 s by default so that a 5 s utilisation sampler sees the GPU busy")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
+    ap.add_argument("--allow-replicas", action="store_true",
+                    help="N > 1: when the row-band transport (RCCL) cannot be set up, fall back to N independent replicas instead of failing "
+                         "(the line then says so in config.parallelism; it is not a scaling measurement)")
     return ap.parse_args()
 
 
@@ -327,6 +330,13 @@ def main():
                 built[0].close()
             bands = False
             fallback_reason = fallback_reason or "another rank failed to set up the row-band transport"
+            if not args.allow_replicas:
+                # N ranks that do not exchange anything are N single-GPU runs: a line from them must not pass for a scaling point
+                print(f"[bench] rank {rank}: row-band set-up failed ({fallback_reason}); --allow-replicas runs {world} independent replicas instead",
+                      file=sys.stderr)
+                dist.barrier()
+                dist.destroy_process_group()
+                raise SystemExit(3)
             built = build(False)
     else:
         built = build(False)
@@ -604,6 +614,13 @@ def main():
         "data": "synthetic",
         "config": {"workload": workload_name, "description": desc, "width": width, "height": height, "lights": num_lights,
                    "cluster_grid": list(synth.CLUSTER_RESOLUTION),
+                   # which BASELINE.json configuration this line is, in words a reader of a SCALE record needs: at N > 1 the default line
+                   # is WEAK scaling (BASELINE config 3's 3840x2160 worth of pixels per rank, one frame of N times that tiled into N row
+                   # bands), so that value(N) / (N x value(1)) is an efficiency; BASELINE config 5 (ONE 7680x4320 frame over the same N
+                   # ranks, strong scaling) is the `config5_8k` record of the same line (or `--workload config5_8k` at the top level)
+                   "baseline_config": ("config 5 (7680x4320 over %d ranks, strong scaling)" % world if (fixed_frame and bands) else
+                                       "config 3 x %d (weak scaling: %dx%d = %d frames of 3840x2160; BASELINE config 5 is in config5_8k)" % (world, width, height, world)
+                                       if bands and args.workload == "config3_4k_4096lights" else args.workload.split("_")[0].replace("config", "config ")),
                    "parallelism": ("single" if world == 1 else
                                    f"{world} row bands, RCCL all-gather of the 1/8 bloom level (in frame) and of the tonemapped bands as RGB888 (alpha is constant: 3/4 of the bytes per xGMI link; GRANITE_BENCH_GATHER_RGBA=1 sends RGBA8) "
                                    f"({'in frame' if os.environ.get('GRANITE_BENCH_GATHER', 'beside') == 'inframe' else 'beside the frame, own stream + communicator'})" if bands else

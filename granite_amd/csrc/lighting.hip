@@ -41,7 +41,7 @@ constexpr int LIGHT_TILE = 8;  // wave tile edge
 #ifndef LV_WAVES
 #define LV_WAVES 4
 #endif
-constexpr int LIGHT_WAVES = LV_WAVES; // waves per workgroup, side by side: four 8 PX x 8 tiles in a row (A/B builds: -DLV_WAVES=1 / 2)
+constexpr int LIGHT_WAVES = LV_WAVES; // waves per workgroup, side by side: four 8 PX x 8 tiles in a row (A/B builds: -DLV_WAVES=1 / 2, slower in rounds 4 and 6)
 constexpr int LIGHT_SLOT_BYTES = 64;
 
 constexpr float PI_SIC = 3.1415628f; // assets/shaders/lights/pbr.h:4-6 (sic)
@@ -69,11 +69,6 @@ constexpr float CULL_SLACK = 1e-3f;
 #define LV_STAMP_LAP_BEGIN()
 #define LV_STAMP_LAP(k)
 #endif
-
-// Scheduling ties: an empty asm that "rewrites" a loaded value and "reads" results of the arithmetic laid out in front of it.  The wait for
-// the load cannot move above the arithmetic, the arithmetic cannot sink below the wait.  No instruction is emitted.
-#define LV_TIE_V(loaded, a0, a1, a2) asm("" : "+v"(loaded) : "v"(a0), "v"(a1), "v"(a2))
-#define LV_TIE_S(loaded, a0, a1, a2, a3) asm("" : "+s"(loaded) : "v"(a0), "v"(a1), "v"(a2), "v"(a3))
 
 struct KernelArgs
 {
@@ -259,6 +254,9 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 		near_any = near_any || d2[p] < q0.w;
 	}
 	// Falloff is exactly 0 once dist * inv_radius >= 1: skip the light when no pixel of the tile is inside 1.001 r.
+#ifdef LV_NO_NEAR_EXIT
+	if (CONE)
+#endif
 	if (!__any(near_any))
 		return;
 
@@ -291,13 +289,6 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 		if (!__any(lit_any))
 			return;
 	}
-	// The cone body holds sixteen registers of light record at its widest point, the kernel's register peak; it reads the colour a
-	// second time here instead of keeping it across the cone test (the walked list holds a spot for every 40 point lights: config 3).
-	// The laundered pointer keeps the compiler from merging the two reads.
-	const f32x4 *slot_again = slot;
-	if (CONE)
-		asm("" : "+v"(slot_again));
-	const f32x4 qc = CONE ? slot_again[1] : q1;
 #pragma unroll
 	for (int p = 0; p < PX; p++)
 	{
@@ -308,7 +299,7 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 		// fp32 level when L is nearly -V, where 2 + 2 dot(V, L) would cancel.
 		const float3_ Hs = f3(fmaf(s[p].V.x, len[p], Lf[p].x), fmaf(s[p].V.y, len[p], Lf[p].y), fmaf(s[p].V.z, len[p], Lf[p].z));
 		const float hh = fmaf(Hs.z, Hs.z, fmaf(Hs.y, Hs.y, fmaf(Hs.x, Hs.x, 1e-30f))) * inv_d2[p];
-		brdf_accumulate(s[p], NdL, hh, a2, f3(qc.x, qc.y, qc.z), result[p]);
+		brdf_accumulate(s[p], NdL, hh, a2, f3(q1.x, q1.y, q1.z), result[p]);
 	}
 }
 
@@ -374,155 +365,7 @@ __device__ __forceinline__ void load_raw(const KernelArgs &a, int x0, int y, Raw
 	}
 }
 
-// Cluster words of one 64-light chunk, OR-ed over the cluster cells [cx0, cx1] x [cy0, cy1] the tile touches
-// (clusterer_bindless.h:55-67 for every lane of the wave at once).  Every address is wave-uniform: scalar loads, no vector register,
-// no vector instruction; a tile of 16 x 8 pixels touches at most 2 x 2 cells unless the cells are smaller than the tile, and those
-// (at most) four cells' words are requested back to back.
-// The cluster words and the type words were written by the cluster build, a launch earlier: to this kernel they are constants.  Read through
-// the constant address space (the same memory), a wave-uniform read is a scalar load whatever else the kernel does to memory in between.
-typedef const uint32_t __attribute__((address_space(4))) *ConstWords;
-typedef u32x2 __attribute__((aligned(4))) WordPair; // two consecutive words, 4-byte aligned: one s_load_dwordx2
-typedef const WordPair __attribute__((address_space(4))) *ConstWordPairs;
-__device__ __forceinline__ ConstWords as_constant(const uint32_t *p) { return (ConstWords)(uintptr_t)p; }
-struct CellWords
-{
-	uint64_t w[4]; // as requested, not yet combined: the OR is the first use, placed by the caller behind other work
-};
-__device__ __forceinline__ CellWords request_cell_words(const KernelArgs &a, int cx0, int cx1, int cy0, int cy1, int chunk)
-{
-	const int n32 = a.cl_num_lights_32;
-	const int w0 = chunk * 2;
-	const bool pair = w0 + 1 < n32; // false for the last chunk of a row with an odd number of words: its upper 32 lights do not exist
-	const ConstWords words = as_constant(a.bitmask);
-	CellWords r;
-	if (cx1 - cx0 <= 1 && cy1 - cy0 <= 1)
-	{
-		const ConstWords c00 = words + ((cy0 * a.cl_res_x + cx0) * n32 + w0), c10 = words + ((cy0 * a.cl_res_x + cx1) * n32 + w0);
-		const ConstWords c01 = words + ((cy1 * a.cl_res_x + cx0) * n32 + w0), c11 = words + ((cy1 * a.cl_res_x + cx1) * n32 + w0);
-		if (pair)
-		{
-			r.w[0] = __builtin_bit_cast(uint64_t, u32x2(*(ConstWordPairs)c00));
-			r.w[1] = __builtin_bit_cast(uint64_t, u32x2(*(ConstWordPairs)c10));
-			r.w[2] = __builtin_bit_cast(uint64_t, u32x2(*(ConstWordPairs)c01));
-			r.w[3] = __builtin_bit_cast(uint64_t, u32x2(*(ConstWordPairs)c11));
-		}
-		else
-			r.w[0] = *c00, r.w[1] = *c10, r.w[2] = *c01, r.w[3] = *c11;
-	}
-	else
-	{
-		uint32_t lo = 0u, hi = 0u;
-		for (int cy = cy0; cy <= cy1; cy++)
-			for (int cx = cx0; cx <= cx1; cx++)
-			{
-				const ConstWords c = words + ((cy * a.cl_res_x + cx) * n32 + w0);
-				lo |= c[0];
-				if (pair)
-					hi |= c[1];
-			}
-		r.w[0] = uint64_t(lo) | (uint64_t(hi) << 32);
-		r.w[1] = r.w[2] = r.w[3] = 0ull;
-	}
-	return r;
-}
-__device__ __forceinline__ uint64_t combine(const CellWords &r) { return (r.w[0] | r.w[1]) | (r.w[2] | r.w[3]); }
-// type_mask[] always holds GR_MAX_LIGHTS_BINDLESS / 32 words: both words of any chunk exist
-__device__ __forceinline__ uint64_t chunk_point_types(const KernelArgs &a, int chunk)
-{
-	const WordPair t = *(ConstWordPairs)(as_constant(a.type_mask) + chunk * 2);
-	return uint64_t(t.x) | (uint64_t(t.y) << 32);
-}
-
-// Bits of a chunk's 64 lights that lie inside the wave's light-index window [win_lo, win_hi] (clusterer_bindless.h:49-54, 68-77);
-// `chunk` is one of the chunks the window touches.  (Written with selects: max(a, b) - b becomes a saturating subtraction, which
-// only the vector unit has.)
-__device__ __forceinline__ uint64_t chunk_window_bits(uint32_t win_lo, uint32_t win_hi, int chunk)
-{
-	const uint32_t lo = int(win_lo >> 6u) == chunk ? (win_lo & 63u) : 0u;
-	const uint32_t hi = int(win_hi >> 6u) == chunk ? (win_hi & 63u) : 63u;
-	return (~0ull << lo) & (~0ull >> (63u - hi));
-}
-
-// One light per lane: the record as stored (colour | scale_bias, position | offset_radius, direction | inv_radius).
-struct LightRecord
-{
-	f32x4 c, pq, d;
-};
-__device__ __forceinline__ LightRecord load_light(const KernelArgs &a, int chunk, int lane)
-{
-	// lights[] always holds GR_MAX_LIGHTS_BINDLESS records (the ClustererBindlessTransforms block): the load needs no bound
-	const f32x4 *rec = reinterpret_cast<const f32x4 *>(a.lights + (uint32_t(chunk) * 64u + uint32_t(lane)));
-	return LightRecord{rec[0], rec[1], rec[2]};
-}
-
-// Sphere and cone cull of the lane's light against the tile's bounding sphere; a survivor stages its record -- with per-light
-// constants (10 / r, (1.001 r)^2, fp32 spot scale / bias) -- in the slot of its own lane.  `second`: walked with the cone body.
-__device__ __forceinline__ void cull_and_stage(const LightRecord &rec, const bool is_spot, const float3_ centre, const float tile_radius, f32x4 *const slots,
-                                               const int lane, bool &keep, bool &second)
-{
-	const f32x4 c = rec.c, pq = rec.pq, d = rec.d;
-	const float radius = CULL_RADIUS_SCALE * rcp(d.w);
-	const float3_ to_light = f3(pq.x, pq.y, pq.z) - centre;
-	const float reach = radius + tile_radius;
-	const float dist2 = dot(to_light, to_light);
-	keep = dist2 <= reach * reach;
-	// unpackHalf2x16(spot_scale_bias).  The lane is copied to a scalar first: clang (ROCm 7.2) evaluates
-	// __builtin_bit_cast on a vector-component lvalue (v.w) at the address of the whole vector, i.e. as
-	// lane .x (observed: spots shaded with colour.x as scale | bias).
-	const float sb_lane = c.w;
-	const uint32_t sb_bits = __builtin_bit_cast(uint32_t, sb_lane);
-	const float spot_scale = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits & 0xffffu)));
-	const float spot_bias = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits >> 16)));
-	if (is_spot && keep && spot_scale > 0.0f)
-	{
-		// Cone vs the tile's bounding sphere.  spot.h:44-45: the cone factor sat(cone_angle * scale + bias) is
-		// exactly 0 for cone_angle <= -bias / scale =: cos(theta).  With v = centre - light, a = dot(v, dir) and
-		// p = distance of the centre from the axis, e = p cos(theta) - a sin(theta) = |v| sin(phi - theta) is the
-		// distance of the centre from the cone's mantle line (never more than its distance from the cone), so
-		// e > tile_radius (+ margin) puts every pixel of the tile outside the cone by an angle far above fp32
-		// rounding: the light adds exactly 0 there.  (theta >= 90 degrees, cos(theta) <= 0, never culls.)
-		const float cos_t = -spot_bias * rcp(spot_scale);
-		if (cos_t > 0.0f && cos_t < 1.0f)
-		{
-			const float sin_t = __builtin_amdgcn_sqrtf(fmaf(-cos_t, cos_t, 1.0f));
-			const float along = -dot(to_light, f3(d.x, d.y, d.z)); // dot(centre - light, direction)
-			const float off_axis = __builtin_amdgcn_sqrtf(fmaxf(fmaf(-along, along, dist2), 0.0f));
-			const float e = fmaf(off_axis, cos_t, -along * sin_t);
-			keep = e <= tile_radius * 1.001f + CULL_SLACK;
-		}
-	}
-	// inv_radius > 8: the 0.1 distance floor can reach this light's smoothstep (shade_positional)
-	second = is_spot || d.w > 8.0f;
-	// A survivor stages its record in the slot of its own lane, here, where its registers are: nothing of a light
-	// lives across the ballots that follow.  The walks visit the set bits of the ballots.
-	if (keep)
-	{
-		f32x4 *dst_slot = slots + lane * (LIGHT_SLOT_BYTES / 16);
-		dst_slot[0] = f32x4{pq.x, pq.y, pq.z, radius * radius};
-		dst_slot[1] = f32x4{c.x, c.y, c.z, 10.0f * d.w};
-		if (second)
-		{
-			dst_slot[2] = is_spot ? f32x4{d.x, d.y, d.z, 0.0f} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-			dst_slot[3] = is_spot ? f32x4{spot_scale, spot_bias, 0.0f, 0.0f} : f32x4{0.0f, 1.0f, 0.0f, 0.0f};
-		}
-	}
-}
-
 // One wave, one tile of 8 PX x 8 pixels whose attachment words are in `raw`: both quads, the fog quad, the store.
-//
-// Order of the work.  A wave issues one vector instruction per ~8 cycles however independent its instructions are, and three waves that
-// are issuing saturate a SIMD's pipe; what a wave costs the launch is therefore the cycles it spends NOT issuing.  Between the attachment
-// loads and the first light walked lie three more dependent memory round trips -- range[slice], the cluster words of the window's first
-// chunk, the light records those words name -- and in front of each of them there is arithmetic that does not depend on it.  The body
-// is laid out so that every request is in flight while that arithmetic issues (round 5 ran the four trips back to back):
-//   1. position, slice                         -> range[] gather requested (vector loads, one slice per pixel)
-//   2. cells, bounding sphere, N, V, base colour (LDS table)               ... range[] arrives
-//   3. window min / max -> first chunk         -> cluster words + type words requested (scalar loads, chunk_cell_mask)
-//   4. material terms (no LDS access: scalar loads and LDS share a counter)  ... words arrive
-//   5. candidates = words & window             -> one light record per lane requested
-//   6. the directional quad, first blend                                    ... records arrive
-//   7. cull + stage + ballots, the walks; further chunks of the window (1.17 chunks per tile on config 3): next words requested before
-//      the walks, next records after them.
 template <int PX, bool AO, bool B10>
 __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x0, const int tile_y0, const int lane, const RawTile<PX, B10> &raw,
                                            f32x4 *const slots, const float *s_srgb LV_STAMP_PARAM)
@@ -531,9 +374,30 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 	const int y = tile_y0 + (lane >> 3);
 	const int W = a.hdr.w, H = a.hdr.h;
 	const bool row_inside = y >= a.row_first && y < a.row_end; // row_end <= H
-	const bool clustered = (a.flags & GR_LIGHTING_CLUSTERED_BIT) && a.cl_num_lights > 0;
 
-	// ---- 1. position reconstruction (clustering.vert:10-13, clustering.frag:37-39): clip = invVP * (ndc.xy, depth, 1),
+	bool inside[PX], active[PX];
+	f16x4 dst[PX];
+	float depth_v[PX];
+	uint32_t alb_v[PX], nrm_v[PX], mr_v[PX];
+#pragma unroll
+	for (int p = 0; p < PX; p++)
+	{
+		inside[p] = row_inside && x0 + p < W;
+		depth_v[p] = raw.depth[p];
+		alb_v[p] = raw.alb[p];
+		nrm_v[p] = raw.nrm[p];
+		mr_v[p] = PX == 2 ? (p == 0 ? raw.mr & 0xffffu : raw.mr >> 16) : raw.mr;
+		if constexpr (B10)
+		{
+			uint32_t rg, ba;
+			expand_b10g11r11(raw.em[p], rg, ba);
+			dst[p] = __builtin_bit_cast(f16x4, make_uint2(rg, ba));
+		}
+		else
+			dst[p] = __builtin_bit_cast(f16x4, make_uint2(raw.em[2 * p], raw.em[2 * p + 1]));
+	}
+
+	// ---- position reconstruction (clustering.vert:10-13, clustering.frag:37-39): clip = invVP * (ndc.xy, depth, 1),
 	// pos = clip.xyz / clip.w.  Evaluated with fused multiply-adds and a Newton-refined reciprocal; a pixel that lands
 	// in the neighbouring Z slice because of the last-bit difference sees the same lights up to ones at the very edge
 	// of their radius (falloff -> 0), cf. the conservative slice ranges of clusterer.cpp:1265-1275.  The part that does not
@@ -546,19 +410,28 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 		for (int i = 0; i < 4; i++)
 			clip_base[i] = fmaf(a.inv_vp[4 + i], ndc_y, fmaf(a.inv_vp[i], ndc_x, a.inv_vp[12 + i]));
 	}
-	bool inside[PX], active[PX];
-	bool any_active = false;
+
 	Surface s[PX];
-	uint2 z_range[PX];
+	float3_ base[PX], accum[PX];
+	bool any_active = false;
 #pragma unroll
 	for (int p = 0; p < PX; p++)
 	{
-		inside[p] = row_inside && x0 + p < W;
-		const float depth = raw.depth[p];
+		const int x = x0 + p;
+		const float depth = depth_v[p];
+		const uint32_t alb = alb_v[p], nrm = nrm_v[p], mr = mr_v[p];
 		// depth test NOT_EQUAL against the quad at z = 0 (renderer.cpp:1056-1057): reverse-Z far-plane pixels keep the
 		// emissive value (both draws are depth-rejected).
 		active[p] = inside[p] && depth != 0.0f;
 		any_active = any_active || active[p];
+
+		// ---- G-buffer decode (clustering.frag:31-35) ----
+		base[p] = f3(s_srgb[alb & 255u], s_srgb[(alb >> 8) & 255u], s_srgb[(alb >> 16) & 255u]);
+		const float3_ N = f3(float(nrm & 1023u) * (2.0f / 1023.0f) - 1.0f, float((nrm >> 10) & 1023u) * (2.0f / 1023.0f) - 1.0f,
+		                     float((nrm >> 20) & 1023u) * (2.0f / 1023.0f) - 1.0f);
+		const float metallic = float(mr & 255u) * (1.0f / 255.0f);
+		const float mat_roughness = float(mr >> 8) * (1.0f / 255.0f);
+
 		float clip[4];
 #pragma unroll
 		for (int i = 0; i < 4; i++)
@@ -566,116 +439,15 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 		const float clip_w = active[p] ? clip[3] : 1.0f;
 		float inv_w = rcp(clip_w);
 		inv_w = inv_w * fmaf(-clip_w, inv_w, 2.0f);
-		s[p].pos = f3(clip[0] * inv_w, clip[1] * inv_w, clip[2] * inv_w);
-		z_range[p] = make_uint2(0xffffffffu, 0u);
-	}
-	if (clustered)
-	{
-		// Slice lookup (clusterer_bindless.h:43-47): int(dot(pos - camera_base, camera_front) * z_scale) with the scale and the
-		// base folded into the row by the launcher (three fma; a last-bit difference moves a pixel that sits on a slice boundary
-		// into the neighbouring slice, whose lights differ from its own only by ones at the very edge of their radius: see above).
-		// Every lane reads its (clamped) slice's range: no exec-mask region around the gather, `active` picks below.
-#pragma unroll
-		for (int p = 0; p < PX; p++)
-		{
-			const float zf = fmaf(s[p].pos.z, a.cl_z_row[2], fmaf(s[p].pos.y, a.cl_z_row[1], fmaf(s[p].pos.x, a.cl_z_row[0], a.cl_z_row[3])));
-			const uint32_t z_index = uint32_t(clamp0_i32(int(zf), a.cl_z_max_index)); // -> v_med3_i32
-			z_range[p] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(a.range) + (z_index << 3u));
-		}
-	}
+		const float3_ pos = f3(clip[0] * inv_w, clip[1] * inv_w, clip[2] * inv_w);
 
-	// ---- 2. in the shadow of the gather: what needs the position and the other attachments, not the range ----
-	// Cluster cells the tile touches (clusterer_bindless.h:39-42 at the tile's first and last pixel; the per-pixel formula is
-	// monotonic, so every lane's cell lies in this rectangle).  There is no scalar float unit: lane 0 evaluates the formula for
-	// the tile's first pixel, lane 63 for its last one (its second pixel, clamped into the image), and two v_readlane per axis
-	// fetch them -- instead of four wave-uniform evaluations on the vector unit.
-	auto cell = [](int p, float inv_res, float scale, int res) {
-		return clamp0_i32(int(__fmul_rn(__fmul_rn(float(p) + 0.5f, inv_res), scale)), res - 1);
-	};
-	const int my_cx = cell(min(x0 + (lane >> 5) * (PX - 1), W - 1), a.inv_resolution[0], a.cl_xy_scale[0], a.cl_res_x);
-	const int my_cy = cell(min(y, H - 1), a.inv_resolution[1], a.cl_xy_scale[1], a.cl_res_y);
-	const int cx0 = __builtin_amdgcn_readlane(my_cx, 0), cx1 = __builtin_amdgcn_readlane(my_cx, 63);
-	const int cy0 = __builtin_amdgcn_readlane(my_cy, 0), cy1 = __builtin_amdgcn_readlane(my_cy, 63);
-
-	// Bounding sphere of the tile's surface points: centre = first lit pixel, radius = farthest lit pixel from it.
-	const uint64_t lit = __ballot(any_active);
-	const int first = lit ? __builtin_ctzll(lit) : 0;
-	const float3_ mine = PX == 2 && !active[0] ? s[PX - 1].pos : s[0].pos; // a lane in `lit` has one of them active
-	const float3_ centre = f3(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), first)),
-	                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), first)),
-	                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), first)));
-	float off2 = 0.0f;
-#pragma unroll
-	for (int p = 0; p < PX; p++)
-	{
-		const float3_ off = s[p].pos - centre;
-		const float mine2 = active[p] ? dot(off, off) : 0.0f;
-		off2 = p == 0 ? mine2 : fmaxf(off2, mine2);
-	}
-	// v_sqrt_f32 (1 ulp) is well inside the 1.0001 + CULL_SLACK margin
-	const float tile_radius =
-	    __builtin_amdgcn_sqrtf(__builtin_bit_cast(float, wave_minmax_u32<true>(__builtin_bit_cast(uint32_t, off2)))) * 1.0001f + CULL_SLACK;
-
-	// G-buffer decode (clustering.frag:31-35), view vector
-	float3_ base[PX];
-#pragma unroll
-	for (int p = 0; p < PX; p++)
-	{
-		const uint32_t alb = raw.alb[p], nrm = raw.nrm[p];
-		base[p] = f3(s_srgb[alb & 255u], s_srgb[(alb >> 8) & 255u], s_srgb[(alb >> 16) & 255u]);
-		s[p].N = f3(float(nrm & 1023u) * (2.0f / 1023.0f) - 1.0f, float((nrm >> 10) & 1023u) * (2.0f / 1023.0f) - 1.0f,
-		            float((nrm >> 20) & 1023u) * (2.0f / 1023.0f) - 1.0f);
+		s[p].pos = pos;
+		s[p].N = N;
 		const float3_ cam = f3(a.camera_pos[0], a.camera_pos[1], a.camera_pos[2]);
-		float3_ V = cam - s[p].pos;
+		float3_ V = cam - pos;
 		V = V * rsq(fmaxf(dot(V, V), 1e-30f));
 		s[p].V = V;
-		s[p].NdV = dot(s[p].N, V);
-	}
-	// The base colours have left the LDS table before step 3 requests anything: scalar loads and LDS reads share a counter and scalar
-	// loads return out of order, so an LDS value first looked at after those requests would wait for them as well.
-#pragma unroll
-	for (int p = 0; p < PX; p++)
-		asm("" : "+v"(base[p].x), "+v"(base[p].y), "+v"(base[p].z));
-	LV_STAMP_MARK(0); // position, range[] requested, cells, sphere, normals, view vectors
-
-	// ---- 3. the wave's light-index window (clusterer_bindless.h:49-54) and the first chunk's words ----
-	uint32_t win_lo = 0xffffffffu, win_hi = 0u;
-	int chunk = 0, chunk_hi = 0;
-	bool has_lights = false;
-	uint64_t candidates = 0ull, point_types = 0ull;
-	CellWords cell_words{};
-	if (clustered)
-	{
-		// Scheduling tie (no instruction): what step 2 computed is through before the wave waits for range[] -- without it the
-		// backend sinks the normals and view vectors below the wait and leaves the gather's round trip uncovered.
-		LV_TIE_V(z_range[0].x, s[0].NdV, s[PX - 1].NdV, tile_radius);
-		uint32_t lane_lo = 0xffffffffu, lane_hi = 0u;
-#pragma unroll
-		for (int p = 0; p < PX; p++)
-		{
-			lane_lo = active[p] ? min(lane_lo, z_range[p].x) : lane_lo;
-			lane_hi = active[p] ? max(lane_hi, z_range[p].y) : lane_hi;
-		}
-		wave_min_and_max_u32(lane_lo, lane_hi);
-		win_lo = lane_lo, win_hi = min(lane_hi, uint32_t(a.cl_num_lights - 1));
-		has_lights = win_lo <= win_hi;
-		// a wave without a light in range still requests chunk 0's words and records (valid addresses, nothing kept): no branch here
-		chunk = has_lights ? int(win_lo >> 6u) : 0, chunk_hi = has_lights ? int(win_hi >> 6u) : 0;
-		cell_words = request_cell_words(a, cx0, cx1, cy0, cy1, chunk);
-		point_types = chunk_point_types(a, chunk);
-	}
-
-	// ---- 4. material terms hoisted out of the light loop (pbr.h; brdf_accumulate) ----
-	// The target travels as two dwords of halves per pixel (r | g, b | a): emissive as loaded, after the directional quad the first
-	// blend's stored value (a pixel the depth test rejects keeps its emissive texel in them to the end).  The sums read them through
-	// v_fma_mix_f32 (float(half) * 1 + addend: the exact fp32 sum, one rounding), so no fp32 copy of the target lives across the walks.
-	uint32_t acc_rg[PX], acc_ba[PX];
-#pragma unroll
-	for (int p = 0; p < PX; p++)
-	{
-		const uint32_t mr = PX == 2 ? (p == 0 ? raw.mr & 0xffffu : raw.mr >> 16) : raw.mr;
-		const float metallic = float(mr & 255u) * (1.0f / 255.0f);
-		const float mat_roughness = float(mr >> 8) * (1.0f / 255.0f);
+		s[p].NdV = dot(N, V);
 		const float NoV = med3(s[p].NdV, 0.001f, 1.0f);
 		s[p].F0 = f3(fmaf(base[p].x - 0.04f, metallic, 0.04f), fmaf(base[p].y - 0.04f, metallic, 0.04f),
 		             fmaf(base[p].z - 0.04f, metallic, 0.04f));
@@ -692,169 +464,259 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 		const float kd = (1.0f - metallic) * (1.0f / PI_SIC);
 		s[p].D1 = f3(fmaf(-s[p].F0.x, base[p].x, base[p].x) * kd, fmaf(-s[p].F0.y, base[p].y, base[p].y) * kd,
 		             fmaf(-s[p].F0.z, base[p].z, base[p].z) * kd);
-		if constexpr (B10)
-			expand_b10g11r11(raw.em[p], acc_rg[p], acc_ba[p]);
-		else
-			acc_rg[p] = raw.em[2 * p], acc_ba[p] = raw.em[2 * p + 1];
-	}
 
-	// ---- 5. the first chunk's candidates: one light per lane, its record requested whether or not its bit is set (a lane without a
-	// candidate reads a record it never looks at: no exec-mask region, no zero-filled registers) ----
-	LightRecord rec{};
-	if (clustered)
-	{
-		// the material terms are through before the wave waits for the words (scalar loads return out of order: the first use waits for all)
-		LV_TIE_S(cell_words.w[0], s[0].gA, s[PX - 1].gA, s[0].D1.x, s[PX - 1].D1.x);
-		candidates = has_lights ? combine(cell_words) & chunk_window_bits(win_lo, win_hi, chunk) : 0ull;
-		rec = load_light(a, chunk, lane);
-	}
+		accum[p] = f3(float(dst[p].x), float(dst[p].y), float(dst[p].z));
 
-	// ---- 6. directional quad (directional.frag:41-65), first blend ----
-	if (a.flags & GR_LIGHTING_DIRECTIONAL_BIT)
-	{
-#pragma unroll
-		for (int p = 0; p < PX; p++)
+		// ---- directional quad (directional.frag:41-65) ----
+		if (a.flags & GR_LIGHTING_DIRECTIONAL_BIT)
 		{
 			const float3_ L = f3(a.dir_direction[0], a.dir_direction[1], a.dir_direction[2]);
-			const float3_ Hv = s[p].V + L;
-			float3_ lit_d = f3(0.0f, 0.0f, 0.0f);
-			brdf_accumulate(s[p], dot(s[p].N, L), fmaxf(dot(Hv, Hv), 1e-30f), 1.0f, f3(a.dir_color[0], a.dir_color[1], a.dir_color[2]), lit_d);
+			const float3_ Hv = V + L;
+			float3_ lit = f3(0.0f, 0.0f, 0.0f);
+			brdf_accumulate(s[p], dot(N, L), fmaxf(dot(Hv, Hv), 1e-30f), 1.0f, f3(a.dir_color[0], a.dir_color[1], a.dir_color[2]), lit);
 			// base_ambient * base_color * 0.05 (directional.frag:52-64); a scalar 0 when the fallback term is off
 			float ambient = (a.flags & GR_LIGHTING_AMBIENT_FALLBACK_BIT) ? 0.05f : 0.0f;
 			if (AO)
-				ambient *= sample_linear_r8(a.ao, (float(x0 + p) + 0.5f) * a.inv_resolution[0], (float(y) + 0.5f) * a.inv_resolution[1]);
-			lit_d = f3(fmaf(base[p].x, ambient, lit_d.x), fmaf(base[p].y, ambient, lit_d.y), fmaf(base[p].z, ambient, lit_d.z));
-			// blend ONE/ONE, attachment store rounds to fp16 (or to the packed floats, every one of which is a half)
-			const float3_ sum = f3(fma_mix_lo(acc_rg[p], 1.0f, lit_d.x), fma_mix_hi(acc_rg[p], 1.0f, lit_d.y), fma_mix_lo(acc_ba[p], 1.0f, lit_d.z));
-			f16x2 rg, b_;
+				ambient *= sample_linear_r8(a.ao, (float(x) + 0.5f) * a.inv_resolution[0], (float(y) + 0.5f) * a.inv_resolution[1]);
+			lit = f3(fmaf(base[p].x, ambient, lit.x), fmaf(base[p].y, ambient, lit.y), fmaf(base[p].z, ambient, lit.z));
+			// blend ONE/ONE, attachment store rounds to fp16 (or to the packed floats)
 			if constexpr (B10)
-				rg = f16x2{_Float16(round_to_ufloat<6>(sum.x)), _Float16(round_to_ufloat<6>(sum.y))}, b_ = f16x2{_Float16(round_to_ufloat<5>(sum.z)), _Float16(0.0f)};
+				accum[p] = f3(round_to_ufloat<6>(accum[p].x + lit.x), round_to_ufloat<6>(accum[p].y + lit.y), round_to_ufloat<5>(accum[p].z + lit.z));
 			else
-				rg = f16x2{_Float16(sum.x), _Float16(sum.y)}, b_ = f16x2{_Float16(sum.z), _Float16(0.0f)};
-			acc_rg[p] = active[p] ? __builtin_bit_cast(uint32_t, rg) : acc_rg[p];
-			acc_ba[p] = active[p] ? ((acc_ba[p] & 0xffff0000u) | (__builtin_bit_cast(uint32_t, b_) & 0xffffu)) : acc_ba[p];
+				accum[p] = f3(float(_Float16(accum[p].x + lit.x)), float(_Float16(accum[p].y + lit.y)), float(_Float16(accum[p].z + lit.z)));
 		}
 	}
-	if (clustered)
-	{
-		float tie = rec.pq.x; // the first blend is through before the wave waits for the records
-		LV_TIE_V(tie, acc_rg[0], acc_ba[0], acc_rg[PX - 1]);
-		LV_TIE_V(tie, acc_ba[PX - 1], acc_ba[0], acc_rg[0]);
-		rec.pq.x = tie;
-	}
-	LV_STAMP_MARK(1); // window, words, material terms, records requested, directional quad
 
-	// ---- 7. clustered quad (clusterer_bindless.h:29-84) ----
-	float3_ out_f[PX]; // the second blend's sums, rounded by the store
-	if (has_lights)
+	LV_STAMP_MARK(0); // G-buffer decode, material terms and the directional quad are through
+	// ---- clustered quad (clusterer_bindless.h:29-84) ----
+	f16x4 out_h[PX];
+	float3_ out_f[PX]; // B10: the sums themselves, rounded by the packed store below
+	if ((a.flags & GR_LIGHTING_CLUSTERED_BIT) && a.cl_num_lights > 0)
 	{
 		float3_ result[PX];
+		uint32_t lane_lo = 0xffffffffu, lane_hi = 0u;
 #pragma unroll
 		for (int p = 0; p < PX; p++)
-			result[p] = f3(0.0f, 0.0f, 0.0f);
-		LV_STAMP_LAP_BEGIN();
-		for (;;)
 		{
-			// ---- cull + stage: one light per lane ----
-			bool keep = false;
-			bool second = false; // walked with the cone body: spot lights, and point lights of radius < 1 / 8
-			if (__builtin_amdgcn_inverse_ballot_w64(candidates))
-				cull_and_stage(rec, !__builtin_amdgcn_inverse_ballot_w64(point_types), centre, tile_radius, slots, lane, keep, second);
-			const uint64_t kept = __ballot(keep);
-			const uint64_t seconds = __ballot(keep && second);
-			__builtin_amdgcn_wave_barrier(); // LDS is wave-private: in-order DS execution is the only ordering needed
-			// the next chunk's words travel while this chunk is walked
-			const bool more = chunk < chunk_hi;
-			if (more)
+			result[p] = f3(0.0f, 0.0f, 0.0f);
+			// Slice lookup (clusterer_bindless.h:43-47): int(dot(pos - camera_base, camera_front) * z_scale) with the scale and the
+			// base folded into the row by the launcher (three fma; a last-bit difference moves a pixel that sits on a slice boundary
+			// into the neighbouring slice, whose lights differ from its own only by ones at the very edge of their radius: see above).
+			const float zf = fmaf(s[p].pos.z, a.cl_z_row[2], fmaf(s[p].pos.y, a.cl_z_row[1], fmaf(s[p].pos.x, a.cl_z_row[0], a.cl_z_row[3])));
+			const uint32_t z_index = uint32_t(clamp0_i32(int(zf), a.cl_z_max_index)); // -> v_med3_i32
+			if (active[p])
 			{
-				candidates = combine(request_cell_words(a, cx0, cx1, cy0, cy1, chunk + 1)) & chunk_window_bits(win_lo, win_hi, chunk + 1);
-				point_types = chunk_point_types(a, chunk + 1);
+				const uint2 z_range = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(a.range) + (z_index << 3u));
+				lane_lo = min(lane_lo, z_range.x);
+				lane_hi = max(lane_hi, z_range.y);
 			}
-			LV_STAMP_LAP(2); // cull
-
-			// ---- shade: PX pixels per lane, lights broadcast from LDS; each list in index order, its body without a light-type branch ----
-			for (uint64_t todo = kept & ~seconds; todo != 0ull; todo &= todo - 1ull)
-				shade_positional<PX, false>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
-			for (uint64_t todo = seconds; todo != 0ull; todo &= todo - 1ull)
-				shade_positional<PX, true>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
-			LV_STAMP_LAP(3); // the two walks
-			__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
-			if (!more)
-				break;
-			chunk++;
-			rec = load_light(a, chunk, lane);
 		}
-		// second blend: the attachment store rounds once more
+		// The wave's light-index window.
+		wave_min_and_max_u32(lane_lo, lane_hi);
+		const uint32_t win_lo = lane_lo, win_hi = min(lane_hi, uint32_t(a.cl_num_lights - 1));
+
+		if (win_lo <= win_hi)
+		{
+			// Cluster cells the tile touches (clusterer_bindless.h:39-42 at the tile's first and last pixel; the per-pixel formula is
+			// monotonic, so every lane's cell lies in this rectangle).  There is no scalar float unit: lane 0 evaluates the formula for
+			// the tile's first pixel, lane 63 for its last one (its second pixel, clamped into the image), and two v_readlane per axis
+			// fetch them -- instead of four wave-uniform evaluations on the vector unit.
+			auto cell = [](int p, float inv_res, float scale, int res) {
+				return clamp0_i32(int(__fmul_rn(__fmul_rn(float(p) + 0.5f, inv_res), scale)), res - 1);
+			};
+			const int my_cx = cell(min(x0 + (lane >> 5) * (PX - 1), W - 1), a.inv_resolution[0], a.cl_xy_scale[0], a.cl_res_x);
+			const int my_cy = cell(min(y, H - 1), a.inv_resolution[1], a.cl_xy_scale[1], a.cl_res_y);
+			const int cx0 = __builtin_amdgcn_readlane(my_cx, 0), cx1 = __builtin_amdgcn_readlane(my_cx, 63);
+			const int cy0 = __builtin_amdgcn_readlane(my_cy, 0), cy1 = __builtin_amdgcn_readlane(my_cy, 63);
+
+			// Bounding sphere of the tile's surface points: centre = first lit pixel, radius = farthest lit pixel from it.
+			const uint64_t lit = __ballot(any_active);
+			const int first = __builtin_ctzll(lit);
+			const float3_ mine = PX == 2 && !active[0] ? s[PX - 1].pos : s[0].pos; // a lane in `lit` has one of them active
+			const float3_ centre = f3(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), first)),
+			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), first)),
+			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), first)));
+			float off2 = 0.0f;
+#pragma unroll
+			for (int p = 0; p < PX; p++)
+			{
+				const float3_ off = s[p].pos - centre;
+				const float mine2 = active[p] ? dot(off, off) : 0.0f;
+				off2 = p == 0 ? mine2 : fmaxf(off2, mine2);
+			}
+			// v_sqrt_f32 (1 ulp) is well inside the 1.0001 + CULL_SLACK margin
+			const float tile_radius =
+			    __builtin_amdgcn_sqrtf(__builtin_bit_cast(float, wave_minmax_u32<true>(__builtin_bit_cast(uint32_t, off2)))) * 1.0001f + CULL_SLACK;
+
+			LV_STAMP_MARK(1); // slice window, cells, bounding sphere
+			LV_STAMP_LAP_BEGIN();
+			const int chunk_lo = int(win_lo >> 6u), chunk_hi = int(win_hi >> 6u);
+			for (int chunk = chunk_lo; chunk <= chunk_hi; chunk++)
+			{
+				// ---- gather + cull: one light per lane ----
+				const uint32_t light_index = uint32_t(chunk) * 64u + uint32_t(lane);
+				const int my_word = chunk * 2 + (lane >> 5);
+				bool keep = false;
+				bool second = false; // walked with the cone body: spot lights, and point lights of radius < 1 / 8
+				if (index_in_range(light_index, win_lo, win_hi))
+				{
+					uint32_t word = 0u;
+					for (int cy = cy0; cy <= cy1; cy++)
+					{
+#pragma clang loop vectorize(disable) unroll(disable)
+						for (int cx = cx0; cx <= cx1; cx++)
+							word |= a.bitmask[(cy * a.cl_res_x + cx) * a.cl_num_lights_32 + my_word];
+					}
+					if ((word >> (uint32_t(lane) & 31u)) & 1u)
+					{
+						const f32x4 *rec = reinterpret_cast<const f32x4 *>(a.lights + light_index);
+						const f32x4 c = rec[0], pq = rec[1], d = rec[2]; // colour|scale_bias, position|offset_radius, direction|inv_radius
+						const float radius = CULL_RADIUS_SCALE * rcp(d.w);
+						const float3_ to_light = f3(pq.x, pq.y, pq.z) - centre;
+						const float reach = radius + tile_radius;
+						const float dist2 = dot(to_light, to_light);
+						keep = dist2 <= reach * reach;
+						const bool is_spot = ((a.type_mask[light_index >> 5] >> (light_index & 31u)) & 1u) == 0u;
+						// unpackHalf2x16(spot_scale_bias).  The lane is copied to a scalar first: clang (ROCm 7.2) evaluates
+						// __builtin_bit_cast on a vector-component lvalue (v.w) at the address of the whole vector, i.e. as
+						// lane .x (observed: spots shaded with colour.x as scale | bias).
+						const float sb_lane = c.w;
+						const uint32_t sb_bits = __builtin_bit_cast(uint32_t, sb_lane);
+						const float spot_scale = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits & 0xffffu)));
+						const float spot_bias = float(__builtin_bit_cast(_Float16, uint16_t(sb_bits >> 16)));
+						if (is_spot && keep && spot_scale > 0.0f)
+						{
+							// Cone vs the tile's bounding sphere.  spot.h:44-45: the cone factor sat(cone_angle * scale + bias) is
+							// exactly 0 for cone_angle <= -bias / scale =: cos(theta).  With v = centre - light, a = dot(v, dir) and
+							// p = distance of the centre from the axis, e = p cos(theta) - a sin(theta) = |v| sin(phi - theta) is the
+							// distance of the centre from the cone's mantle line (never more than its distance from the cone), so
+							// e > tile_radius (+ margin) puts every pixel of the tile outside the cone by an angle far above fp32
+							// rounding: the light adds exactly 0 there.  (theta >= 90 degrees, cos(theta) <= 0, never culls.)
+							const float cos_t = -spot_bias * rcp(spot_scale);
+							if (cos_t > 0.0f && cos_t < 1.0f)
+							{
+								const float sin_t = __builtin_amdgcn_sqrtf(fmaf(-cos_t, cos_t, 1.0f));
+								const float along = -dot(to_light, f3(d.x, d.y, d.z)); // dot(centre - light, direction)
+								const float off_axis = __builtin_amdgcn_sqrtf(fmaxf(fmaf(-along, along, dist2), 0.0f));
+								const float e = fmaf(off_axis, cos_t, -along * sin_t);
+								keep = e <= tile_radius * 1.001f + CULL_SLACK;
+							}
+						}
+						// inv_radius > 8: the 0.1 distance floor can reach this light's smoothstep (shade_positional)
+						second = is_spot || d.w > 8.0f;
+						// A survivor stages its record in the slot of its own lane, here, where its registers are: nothing of a light
+						// lives across the ballots below (round 4 compacted the list with mbcnt after them, which kept sixteen
+						// zero-filled registers per lane alive on every path).  The walks visit the set bits of the ballots.
+						if (keep)
+						{
+							f32x4 *dst_slot = slots + lane * (LIGHT_SLOT_BYTES / 16);
+							dst_slot[0] = f32x4{pq.x, pq.y, pq.z, radius * radius};
+							dst_slot[1] = f32x4{c.x, c.y, c.z, 10.0f * d.w};
+							if (second)
+							{
+								dst_slot[2] = is_spot ? f32x4{d.x, d.y, d.z, 0.0f} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+								dst_slot[3] = is_spot ? f32x4{spot_scale, spot_bias, 0.0f, 0.0f} : f32x4{0.0f, 1.0f, 0.0f, 0.0f};
+							}
+						}
+					}
+				}
+				const uint64_t kept = __ballot(keep);
+				const uint64_t seconds = __ballot(keep && second);
+				__builtin_amdgcn_wave_barrier(); // LDS is wave-private: in-order DS execution is the only ordering needed
+				LV_STAMP_LAP(2); // gather + cull
+
+				// ---- shade: PX pixels per lane, lights broadcast from LDS; each list in index order, its body without a light-type branch ----
+				for (uint64_t todo = kept & ~seconds; todo != 0ull; todo &= todo - 1ull)
+					shade_positional<PX, false>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
+				for (uint64_t todo = seconds; todo != 0ull; todo &= todo - 1ull)
+					shade_positional<PX, true>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
+				LV_STAMP_LAP(3); // the two walks
+				__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
+			}
+		}
+		// second blend: the attachment store rounds once more, straight into the halves that are written out
 #pragma unroll
 		for (int p = 0; p < PX; p++)
-			out_f[p] = f3(fma_mix_lo(acc_rg[p], 1.0f, result[p].x), fma_mix_hi(acc_rg[p], 1.0f, result[p].y), fma_mix_lo(acc_ba[p], 1.0f, result[p].z));
+		{
+			out_f[p] = f3(accum[p].x + result[p].x, accum[p].y + result[p].y, accum[p].z + result[p].z);
+			out_h[p].x = _Float16(out_f[p].x);
+			out_h[p].y = _Float16(out_f[p].y);
+			out_h[p].z = _Float16(out_f[p].z);
+		}
 	}
 	else
 	{
 #pragma unroll
 		for (int p = 0; p < PX; p++)
-			out_f[p] = f3(fma_mix_lo(acc_rg[p], 1.0f, 0.0f), fma_mix_hi(acc_rg[p], 1.0f, 0.0f), fma_mix_lo(acc_ba[p], 1.0f, 0.0f)); // exact
+		{
+			out_f[p] = accum[p];
+			out_h[p].x = _Float16(accum[p].x); // exact: accum holds fp16 values
+			out_h[p].y = _Float16(accum[p].y);
+			out_h[p].z = _Float16(accum[p].z);
+		}
 	}
 
 	if (!inside[0])
 		return;
-	// ---- fog quad (fog.frag:17-25, fog.h:4-8): a third blend, src * (1 - src.a) + dst * src.a on colour and alpha, onto what the
-	// second blend stored (its rounded value), rounded by the store once more.  Uniform branch: no fog, no instruction. ----
-	float out_a[PX];
+	f16x4 o[PX];
 #pragma unroll
 	for (int p = 0; p < PX; p++)
-		out_a[p] = 0.0f;
-	const bool fog = a.fog_falloff > 0.0f;
-	if (fog)
+	{
+		o[p] = dst[p];
+		if (active[p])
+		{
+			o[p].x = out_h[p].x;
+			o[p].y = out_h[p].y;
+			o[p].z = out_h[p].z;
+		}
+	}
+	// ---- fog quad (fog.frag:17-25, fog.h:4-8): a third blend, src * (1 - src.a) + dst * src.a on colour and alpha, onto what the
+	// second blend stored (its rounded value), rounded by the store once more.  Uniform branch: no fog, no instruction. ----
+	if (a.fog_falloff > 0.0f)
 	{
 #pragma unroll
 		for (int p = 0; p < PX; p++)
-		{
-			const float3_ eye = s[p].pos - f3(a.camera_pos[0], a.camera_pos[1], a.camera_pos[2]);
-			const float f = __builtin_amdgcn_exp2f(-dot(eye, eye) * a.fog_falloff), omf = 1.0f - f;
-			const float3_ lit_f = B10 ? f3(round_to_ufloat<6>(out_f[p].x), round_to_ufloat<6>(out_f[p].y), round_to_ufloat<5>(out_f[p].z))
-			                          : f3(float(_Float16(out_f[p].x)), float(_Float16(out_f[p].y)), float(_Float16(out_f[p].z)));
-			out_f[p] = f3(fmaf(lit_f.x, f, a.fog_color[0] * omf), fmaf(lit_f.y, f, a.fog_color[1] * omf), fmaf(lit_f.z, f, a.fog_color[2] * omf));
-			out_a[p] = fmaf(fma_mix_hi(acc_ba[p], 1.0f, 0.0f), f, f * omf);
-		}
+			if (active[p])
+			{
+				const float3_ eye = s[p].pos - f3(a.camera_pos[0], a.camera_pos[1], a.camera_pos[2]);
+				const float f = __builtin_amdgcn_exp2f(-dot(eye, eye) * a.fog_falloff), omf = 1.0f - f;
+				const float3_ lit = B10 ? f3(round_to_ufloat<6>(out_f[p].x), round_to_ufloat<6>(out_f[p].y), round_to_ufloat<5>(out_f[p].z))
+				                        : f3(float(o[p].x), float(o[p].y), float(o[p].z));
+				out_f[p] = f3(fmaf(lit.x, f, a.fog_color[0] * omf), fmaf(lit.y, f, a.fog_color[1] * omf), fmaf(lit.z, f, a.fog_color[2] * omf));
+				o[p].x = _Float16(out_f[p].x);
+				o[p].y = _Float16(out_f[p].y);
+				o[p].z = _Float16(out_f[p].z);
+				o[p].w = _Float16(fmaf(float(dst[p].w), f, f * omf));
+			}
 	}
 	// In place (emissive == hdr) untouched pixels need no store; a pair with one lit pixel rewrites the other's own value.
-	if (!(any_active || a.emissive.ptr != a.hdr.ptr))
-		return;
 	if constexpr (B10)
 	{
-		// an untouched pixel keeps its packed value: repacking the exact expansion is the identity (out_f of such a pixel is its emissive texel)
-		uint32_t words[PX];
-#pragma unroll
-		for (int p = 0; p < PX; p++)
+		if (any_active || a.emissive.ptr != a.hdr.ptr)
 		{
-			const float3_ kept = f3(fma_mix_lo(acc_rg[p], 1.0f, 0.0f), fma_mix_hi(acc_rg[p], 1.0f, 0.0f), fma_mix_lo(acc_ba[p], 1.0f, 0.0f));
-			words[p] = active[p] ? pack_b10g11r11(out_f[p].x, out_f[p].y, out_f[p].z) : pack_b10g11r11(kept.x, kept.y, kept.z);
+			// an untouched pixel keeps its packed value: repacking the exact expansion is the identity
+			uint32_t words[PX];
+#pragma unroll
+			for (int p = 0; p < PX; p++)
+				words[p] = active[p] ? pack_b10g11r11(out_f[p].x, out_f[p].y, out_f[p].z) : pack_b10g11r11(float(dst[p].x), float(dst[p].y), float(dst[p].z));
+			uint8_t *out = a.hdr.ptr + (uint32_t(y) * a.hdr.pitch + uint32_t(x0) * 4u);
+			if constexpr (PX == 2)
+				*reinterpret_cast<uint2 *>(out) = make_uint2(words[0], words[PX - 1]);
+			else
+				*reinterpret_cast<uint32_t *>(out) = words[0];
 		}
-		uint8_t *out = a.hdr.ptr + (uint32_t(y) * a.hdr.pitch + uint32_t(x0) * 4u);
-		if constexpr (PX == 2)
-			*reinterpret_cast<uint2 *>(out) = make_uint2(words[0], words[PX - 1]);
-		else
-			*reinterpret_cast<uint32_t *>(out) = words[0];
+		return;
 	}
-	else
+	if (any_active || a.emissive.ptr != a.hdr.ptr)
 	{
-		uint32_t o_rg[PX], o_ba[PX];
-#pragma unroll
-		for (int p = 0; p < PX; p++)
-		{
-			const f16x2 rg = f16x2{_Float16(out_f[p].x), _Float16(out_f[p].y)};
-			const f16x2 ba = f16x2{_Float16(out_f[p].z), _Float16(out_a[p])};
-			const uint32_t ba_bits = __builtin_bit_cast(uint32_t, ba);
-			o_rg[p] = active[p] ? __builtin_bit_cast(uint32_t, rg) : acc_rg[p];
-			// alpha: the emissive texel's, unless the fog quad blended it
-			o_ba[p] = active[p] ? (fog ? ba_bits : ((acc_ba[p] & 0xffff0000u) | (ba_bits & 0xffffu))) : acc_ba[p];
-		}
 		uint8_t *out = a.hdr.ptr + (uint32_t(y) * a.hdr.pitch + uint32_t(x0) * 8u);
 		if constexpr (PX == 2)
-			*reinterpret_cast<uint4 *>(out) = make_uint4(o_rg[0], o_ba[0], o_rg[PX - 1], o_ba[PX - 1]);
+		{
+			const uint2 lo = __builtin_bit_cast(uint2, o[0]), hi = __builtin_bit_cast(uint2, o[PX - 1]);
+			*reinterpret_cast<uint4 *>(out) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+		}
 		else
-			*reinterpret_cast<uint2 *>(out) = make_uint2(o_rg[0], o_ba[0]);
+			*reinterpret_cast<f16x4 *>(out) = o[0];
 	}
 }
 

@@ -225,6 +225,42 @@ def test_single_rank_rccl_exchange_is_identity():
     a.close()
 
 
+def test_single_rank_rccl_exchange_through_the_library_a_torch_process_resolves():
+    """bench.py imports torch before it creates the executor, and torch maps the librccl bundled with it (SONAME librccl.so.1): the
+    executor's dlopen("librccl.so.1") then finds THAT library already loaded, where this pytest process gets /opt/rocm's.  The same
+    one-rank exchange as above in a child process that imports torch first, so that the library the first multi-GPU bench run
+    talks to has been through a test; the child says which file it mapped."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import os, sys
+import torch  # first, as bench.py does
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np
+from granite_amd import app as gapp, synth
+from test_gpu_strips import make_app
+w, h = 256, 144
+cam = synth.Camera(w, h); gbuf = synth.make_gbuffer(cam); descs = synth.make_lights(cam, 64)
+ref = make_app(w, h, cam, gbuf, descs); ref.render_frames(2); want = ref.read_backbuffer().copy(); ref.close()
+a = make_app(w, h, cam, gbuf, descs)
+a.comm_init(gapp.Application.comm_create_unique_id(), 0, 1)
+a.render_frames(2)
+assert np.array_equal(a.read_backbuffer(), want)
+print("RCCL_VERSION", a.comm_info().get("version"))
+a.close()
+print("RCCL_MAPPED", sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l}))
+print("TORCH_LIB", os.path.join(os.path.dirname(torch.__file__), "lib"))
+"""
+    r = subprocess.run([sys.executable, "-c", child, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    mapped = [l for l in r.stdout.splitlines() if l.startswith("RCCL_MAPPED")]
+    assert mapped and "librccl" in mapped[0], r.stdout
+    print(r.stdout)  # -s shows which library a torch process resolves (profiles/ keeps the line of the round's run)
+
+
 def test_output_gather_beside_the_frame_gives_the_same_frames():
     """The tonemapped bands gathered on the device's collective stream through a second communicator (gra_comm_init_output),
     overlapping the following frames: un-synchronised runs of more frames than there are swapchain images (so that the

@@ -13,7 +13,8 @@ from oracle import oracle as orc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,width,height", [(2, 3840, 4320), (4, 7680, 4320), (8, 7680, 8640), (3, 333, 250), (8, 64, 40)])
+# (8, 7680, 4320): BASELINE config 5 as bench.py --gpus 8 tiles it (the strong-scaling record of the line)
+@pytest.mark.parametrize("world,width,height", [(2, 3840, 4320), (4, 7680, 4320), (8, 7680, 4320), (8, 7680, 8640), (3, 333, 250), (8, 64, 40)])
 def test_plan_partitions_the_frame(world, width, height):
     h_d1 = orc.level_size(width, height, 0.125)[1]
     out_rows, d1_rows = np.zeros(height, int), np.zeros(h_d1, int)
@@ -48,9 +49,11 @@ def test_weak_scaled_frames():
     assert [multigpu.weak_scaled_frame(n) for n in (1, 2, 4, 8)] == [(3840, 2160), (3840, 4320), (7680, 4320), (7680, 8640)]
 
 
-@pytest.mark.parametrize("mode,width,height", [("none", 256, 192), ("none", 200, 150), ("fxaa", 200, 150), ("smaa+taa", 256, 384),
-                                               ("smaa+taa", 200, 150), ("smaa+taa-halo", 256, 384)])
-def test_two_rank_gloo_bands_equal_single_process_frame(tmp_path, mode, width, height):
+@pytest.mark.parametrize("mode,width,height,world", [("none", 256, 192, 2), ("none", 200, 150, 2), ("fxaa", 200, 150, 2), ("smaa+taa", 256, 384, 2),
+                                                     ("smaa+taa", 200, 150, 2), ("smaa+taa-halo", 256, 384, 2),
+                                                     # four processes: an interior rank has a neighbour on both sides (the 7680x4320 frame's aspect, 1/20)
+                                                     ("none", 384, 216, 4)])
+def test_two_rank_gloo_bands_equal_single_process_frame(tmp_path, mode, width, height, world):
     """Two processes, one band each, everything a rank did not compute itself poisoned before the next stage reads it: the
     halos StripPlan keeps for the bloom pyramid, for FXAA, for SMAA Ultra's 32-step searches (the frame carries long straight
     and diagonal edges through the band boundary) and for the TAA neighbourhood must be enough, and the all-gathers (1/8
@@ -61,10 +64,10 @@ def test_two_rank_gloo_bands_equal_single_process_frame(tmp_path, mode, width, h
     worker_mode, mode = mode, mode.replace("-halo", "")
     frames = 3 if mode == "smaa+taa" else 2
     out = str(tmp_path / "rank{rank}.npz")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() % 2000)), WORLD_SIZE="2",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() % 2000)), WORLD_SIZE=str(world),
                OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "strip_worker.py"), str(width), str(height), str(frames), out, worker_mode],
-                              env=dict(env, RANK=str(r))) for r in range(2)]
+                              env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
 
@@ -84,7 +87,7 @@ def test_two_rank_gloo_bands_equal_single_process_frame(tmp_path, mode, width, h
     if mode == "smaa+taa":
         # the frame must make the weight pass search far: some weights are non-zero and the output differs from its input
         assert (orc.smaa(orc.hdr_chain(hdr, {})["tonemapped"], *load_smaa_luts(), 3)["weights"] != 0).mean() > 0.02
-    for rank in range(2):
+    for rank in range(world):
         got = np.load(out.format(rank=rank))
         for f in range(frames):
             np.testing.assert_array_equal(got["d1"][f], refs[f]["d1"], err_msg=f"rank {rank} frame {f}: 1/8 level after all-gather")
