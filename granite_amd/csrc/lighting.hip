@@ -354,13 +354,13 @@ __device__ __forceinline__ void brdf_accumulate2(const Surface2 &s, f32x2 NdL, f
 	ry = fma2(splat(cg), fma2(fma2(GD, s.F0y, s.D1y), cw, fw), ry);
 	rz = fma2(splat(cb), fma2(fma2(GD, s.F0z, s.D1z), cw, fw), rz);
 }
-template <bool CONE>
+template <bool CONE, bool EARLY_OUT = true>
 __device__ __forceinline__ void shade_positional2(const Surface2 &s, const f32x4 *slot, f32x2 &rx, f32x2 &ry, f32x2 &rz)
 {
 	const f32x4 q0 = slot[0], q1 = slot[1];
 	const f32x2 Lx = splat(q0.x) - s.px, Ly = splat(q0.y) - s.py, Lz = splat(q0.z) - s.pz; // light_pos - world_pos
 	const f32x2 d2 = fma2(Lz, Lz, fma2(Ly, Ly, fma2(Lx, Lx, splat(1e-30f))));             // > 0: no inf / nan downstream
-	if (!__any(fminf(d2.x, d2.y) < q0.w))
+	if (EARLY_OUT && !__any(fminf(d2.x, d2.y) < q0.w))
 		return;
 	const f32x2 inv_d = rsq2(d2);
 	const f32x2 len = d2 * inv_d;
@@ -714,8 +714,26 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 				// ---- shade: PX pixels per lane, lights broadcast from LDS; each list in index order, its body without a light-type branch ----
 				if constexpr (PX == 2 && LV_PACKED)
 				{
+#if LV_PACKED == 2
+					// two lights per turn: two independent chains of packed instructions in one block
+					uint64_t todo = kept & ~seconds;
+					while (__builtin_popcountll(todo) >= 2)
+					{
+						const int ia = __builtin_ctzll(todo);
+						todo &= todo - 1ull;
+						const int ib = __builtin_ctzll(todo);
+						todo &= todo - 1ull;
+						f32x2 ax = splat(0.0f), ay = splat(0.0f), az = splat(0.0f);
+						shade_positional2<false, false>(s2, slots + ia * (LIGHT_SLOT_BYTES / 16), ax, ay, az);
+						shade_positional2<false, false>(s2, slots + ib * (LIGHT_SLOT_BYTES / 16), r2x, r2y, r2z);
+						r2x += ax, r2y += ay, r2z += az;
+					}
+					if (todo)
+						shade_positional2<false>(s2, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), r2x, r2y, r2z);
+#else
 					for (uint64_t todo = kept & ~seconds; todo != 0ull; todo &= todo - 1ull)
 						shade_positional2<false>(s2, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), r2x, r2y, r2z);
+#endif
 					for (uint64_t todo = seconds; todo != 0ull; todo &= todo - 1ull)
 						shade_positional2<true>(s2, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), r2x, r2y, r2z);
 				}
