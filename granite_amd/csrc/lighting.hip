@@ -254,9 +254,6 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 		near_any = near_any || d2[p] < q0.w;
 	}
 	// Falloff is exactly 0 once dist * inv_radius >= 1: skip the light when no pixel of the tile is inside 1.001 r.
-#ifdef LV_NO_NEAR_EXIT
-	if (CONE)
-#endif
 	if (!__any(near_any))
 		return;
 
@@ -301,87 +298,6 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 		const float hh = fmaf(Hs.z, Hs.z, fmaf(Hs.y, Hs.y, fmaf(Hs.x, Hs.x, 1e-30f))) * inv_d2[p];
 		brdf_accumulate(s[p], NdL, hh, a2, f3(q1.x, q1.y, q1.z), result[p]);
 	}
-}
-
-// ---- the same walk on float2 values: component p = the lane's pixel p (A/B build -DLV_PACKED=1) --------------------------------------------
-// In the regime this kernel runs in (about one vector instruction issued per SIMD and four cycles, tools/valu_pk_chain_bench.hip) a
-// v_pk_{fma,mul,add}_f32 costs what one scalar fp32 instruction costs and does two pixels' worth.  What has no packed form -- rsq / rcp,
-// min / med3 -- stays one instruction per pixel.  Operation by operation this is shade_positional / brdf_accumulate: same products, same
-// sums, same order; the results are bit-identical.
-#ifndef LV_PACKED
-#define LV_PACKED 0
-#endif
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 rsq2(f32x2 v) { return f32x2{rsq(v.x), rsq(v.y)}; }
-__device__ __forceinline__ f32x2 rcp2(f32x2 v) { return f32x2{rcp(v.x), rcp(v.y)}; }
-__device__ __forceinline__ f32x2 sat2(f32x2 v) { return f32x2{sat(v.x), sat(v.y)}; }
-__device__ __forceinline__ f32x2 dot2(f32x2 ax, f32x2 ay, f32x2 az, f32x2 bx, f32x2 by, f32x2 bz) { return fma2(az, bz, fma2(ay, by, ax * bx)); }
-struct Surface2
-{
-	f32x2 px, py, pz, Nx, Ny, Nz, Vx, Vy, Vz, F0x, F0y, F0z, D1x, D1y, D1z;
-	f32x2 NdV, m2m1, gA, gB;
-};
-__device__ __forceinline__ Surface2 pair_surfaces(const Surface &a, const Surface &b)
-{
-	Surface2 s;
-	s.px = f32x2{a.pos.x, b.pos.x}, s.py = f32x2{a.pos.y, b.pos.y}, s.pz = f32x2{a.pos.z, b.pos.z};
-	s.Nx = f32x2{a.N.x, b.N.x}, s.Ny = f32x2{a.N.y, b.N.y}, s.Nz = f32x2{a.N.z, b.N.z};
-	s.Vx = f32x2{a.V.x, b.V.x}, s.Vy = f32x2{a.V.y, b.V.y}, s.Vz = f32x2{a.V.z, b.V.z};
-	s.F0x = f32x2{a.F0.x, b.F0.x}, s.F0y = f32x2{a.F0.y, b.F0.y}, s.F0z = f32x2{a.F0.z, b.F0.z};
-	s.D1x = f32x2{a.D1.x, b.D1.x}, s.D1y = f32x2{a.D1.y, b.D1.y}, s.D1z = f32x2{a.D1.z, b.D1.z};
-	s.NdV = f32x2{a.NdV, b.NdV}, s.m2m1 = f32x2{a.m2m1, b.m2m1}, s.gA = f32x2{a.gA, b.gA}, s.gB = f32x2{a.gB, b.gB};
-	return s;
-}
-// brdf_accumulate for both pixels
-__device__ __forceinline__ void brdf_accumulate2(const Surface2 &s, f32x2 NdL, f32x2 hh, f32x2 scale, float cr, float cg, float cb, f32x2 &rx, f32x2 &ry, f32x2 &rz)
-{
-	const f32x2 NoL = f32x2{med3(NdL.x, 0.001f, 1.0f), med3(NdL.y, 0.001f, 1.0f)};
-	const f32x2 inv_h = rsq2(hh);
-	const f32x2 mh = hh * splat(-0.5f);
-	const f32x2 omh = sat2(fma2(mh, inv_h, splat(1.001f))) - splat(0.001f); // 1 - clamp(HoV, 0.001, 1)
-	const f32x2 NoH = sat2((s.NdV + NdL) * inv_h);
-	const f32x2 omh2 = omh * omh;
-	const f32x2 f = omh2 * omh2 * omh; // pow(1 - HoV, 5)
-	const f32x2 d = fma2(NoH * NoH, s.m2m1, splat(1.0f));
-	const f32x2 g = fma2(NoL, s.gA, s.gB);
-	const f32x2 GD = rcp2(d * d * g);
-	const f32x2 w = NoL * scale;
-	const f32x2 cw = fma2(-f, w, w); // (1 - f) w
-	const f32x2 fw = f * GD * w;
-	rx = fma2(splat(cr), fma2(fma2(GD, s.F0x, s.D1x), cw, fw), rx);
-	ry = fma2(splat(cg), fma2(fma2(GD, s.F0y, s.D1y), cw, fw), ry);
-	rz = fma2(splat(cb), fma2(fma2(GD, s.F0z, s.D1z), cw, fw), rz);
-}
-template <bool CONE, bool EARLY_OUT = true>
-__device__ __forceinline__ void shade_positional2(const Surface2 &s, const f32x4 *slot, f32x2 &rx, f32x2 &ry, f32x2 &rz)
-{
-	const f32x4 q0 = slot[0], q1 = slot[1];
-	const f32x2 Lx = splat(q0.x) - s.px, Ly = splat(q0.y) - s.py, Lz = splat(q0.z) - s.pz; // light_pos - world_pos
-	const f32x2 d2 = fma2(Lz, Lz, fma2(Ly, Ly, fma2(Lx, Lx, splat(1e-30f))));             // > 0: no inf / nan downstream
-	if (EARLY_OUT && !__any(fminf(d2.x, d2.y) < q0.w))
-		return;
-	const f32x2 inv_d = rsq2(d2);
-	const f32x2 len = d2 * inv_d;
-	const f32x2 inv_d2 = inv_d * inv_d;
-	const f32x2 dist = CONE ? f32x2{fmaxf(0.1f, len.x), fmaxf(0.1f, len.y)} : len;
-	const f32x2 t = sat2(fma2(dist, splat(q1.w), splat(-9.0f)));
-	f32x2 atten = fma2(-(t * t), fma2(splat(-2.0f), t, splat(3.0f)), splat(1.0f));
-	if (CONE)
-	{
-		const f32x4 q2 = slot[2], q3 = slot[3];
-		const f32x2 cone_angle = -dot2(Lx, Ly, Lz, splat(q2.x), splat(q2.y), splat(q2.z)) * inv_d;
-		const f32x2 cone = sat2(fma2(cone_angle, splat(q3.x), splat(q3.y)));
-		atten *= cone * cone;
-		if (!__any(fmaxf(atten.x, atten.y) > 0.0f))
-			return;
-	}
-	const f32x2 a2 = atten * f32x2{fminf(inv_d2.x, 1.0f / (0.1f * 0.1f)), fminf(inv_d2.y, 1.0f / (0.1f * 0.1f))};
-	const f32x2 NdL = dot2(s.Nx, s.Ny, s.Nz, Lx, Ly, Lz) * inv_d;
-	const f32x2 Hx = fma2(s.Vx, len, Lx), Hy = fma2(s.Vy, len, Ly), Hz = fma2(s.Vz, len, Lz);
-	const f32x2 hh = fma2(Hz, Hz, fma2(Hy, Hy, fma2(Hx, Hx, splat(1e-30f)))) * inv_d2;
-	brdf_accumulate2(s, NdL, hh, a2, q1.x, q1.y, q1.z, rx, ry, rz);
 }
 
 // Forms of this walk that were built, measured slower and removed in round 4 (profiles/r04_lighting_variants_ab.txt, with the commits):
@@ -632,11 +548,6 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 			LV_STAMP_MARK(1); // slice window, cells, bounding sphere
 			LV_STAMP_LAP_BEGIN();
 			const int chunk_lo = int(win_lo >> 6u), chunk_hi = int(win_hi >> 6u);
-			// the walk's view of the lane's two pixels (LV_PACKED): component p of every float2 = pixel p
-			Surface2 s2{};
-			f32x2 r2x = splat(0.0f), r2y = splat(0.0f), r2z = splat(0.0f);
-			if constexpr (PX == 2 && LV_PACKED)
-				s2 = pair_surfaces(s[0], s[PX - 1]);
 			for (int chunk = chunk_lo; chunk <= chunk_hi; chunk++)
 			{
 				// ---- gather + cull: one light per lane ----
@@ -712,45 +623,12 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 				LV_STAMP_LAP(2); // gather + cull
 
 				// ---- shade: PX pixels per lane, lights broadcast from LDS; each list in index order, its body without a light-type branch ----
-				if constexpr (PX == 2 && LV_PACKED)
-				{
-#if LV_PACKED == 2
-					// two lights per turn: two independent chains of packed instructions in one block
-					uint64_t todo = kept & ~seconds;
-					while (__builtin_popcountll(todo) >= 2)
-					{
-						const int ia = __builtin_ctzll(todo);
-						todo &= todo - 1ull;
-						const int ib = __builtin_ctzll(todo);
-						todo &= todo - 1ull;
-						f32x2 ax = splat(0.0f), ay = splat(0.0f), az = splat(0.0f);
-						shade_positional2<false, false>(s2, slots + ia * (LIGHT_SLOT_BYTES / 16), ax, ay, az);
-						shade_positional2<false, false>(s2, slots + ib * (LIGHT_SLOT_BYTES / 16), r2x, r2y, r2z);
-						r2x += ax, r2y += ay, r2z += az;
-					}
-					if (todo)
-						shade_positional2<false>(s2, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), r2x, r2y, r2z);
-#else
-					for (uint64_t todo = kept & ~seconds; todo != 0ull; todo &= todo - 1ull)
-						shade_positional2<false>(s2, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), r2x, r2y, r2z);
-#endif
-					for (uint64_t todo = seconds; todo != 0ull; todo &= todo - 1ull)
-						shade_positional2<true>(s2, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), r2x, r2y, r2z);
-				}
-				else
-				{
-					for (uint64_t todo = kept & ~seconds; todo != 0ull; todo &= todo - 1ull)
-						shade_positional<PX, false>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
-					for (uint64_t todo = seconds; todo != 0ull; todo &= todo - 1ull)
-						shade_positional<PX, true>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
-				}
+				for (uint64_t todo = kept & ~seconds; todo != 0ull; todo &= todo - 1ull)
+					shade_positional<PX, false>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
+				for (uint64_t todo = seconds; todo != 0ull; todo &= todo - 1ull)
+					shade_positional<PX, true>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
 				LV_STAMP_LAP(3); // the two walks
 				__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
-			}
-			if constexpr (PX == 2 && LV_PACKED)
-			{
-				result[0] = f3(r2x.x, r2y.x, r2z.x);
-				result[PX - 1] = f3(r2x.y, r2y.y, r2z.y);
 			}
 		}
 		// second blend: the attachment store rounds once more, straight into the halves that are written out
