@@ -677,6 +677,20 @@ void ImageSpaceApplication::bake_render_graph()
 	if (device_holder)
 		device_holder->reset_launch_cache(); // pre-recorded launch sequences hold the old graph's pointers
 	graph.set_alias_disjoint_images(!config.disable_image_aliasing);
+	// The frame's tail (post-tonemap anti-aliasing) on its own stream: one device rendering whole frames only -- under row bands the tail's
+	// output meets the other ranks' on the collective stream, whose ordering against the frame is stated for three executor streams.
+	// GRANITE_SPLIT_TAIL=0: A/B switch for measurements (frames identical either way: tests/test_gpu_app.py).
+	{
+		static const char *env = getenv("GRANITE_SPLIT_TAIL");
+		if (env)
+		{
+			static bool told = false;
+			if (!told)
+				fprintf(stderr, "[granite-hip] note: GRANITE_SPLIT_TAIL=%s is set (results unchanged, timing differs)\n", env);
+			told = true;
+		}
+		graph.set_split_tail(config.strip_count <= 1 && !(env && env[0] == '0'));
+	}
 
 	ResourceDimensions dim;
 	dim.width = config.width;

@@ -245,11 +245,11 @@ Device::Device(int device_index) : index(device_index)
 	int least = 0, greatest = 0;
 	throw_hip(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
 	const int middle = (least + greatest) / 2;
-	int priorities[int(CommandBuffer::Type::Count)] = {greatest, middle, least}; // Generic, AsyncCompute, Front
-	if (const char *env = getenv("GRANITE_STREAM_PRIORITIES")) // experiment: three letters from {h, m, l}, e.g. "lmh"
+	int priorities[int(CommandBuffer::Type::Count)] = {greatest, middle, least, greatest}; // Generic, AsyncCompute, Front, Tail
+	if (const char *env = getenv("GRANITE_STREAM_PRIORITIES")) // experiment: a letter per stream from {h, m, l}, e.g. "lmhh"
 	{
 		fprintf(stderr, "[granite-hip] note: stream priorities overridden by GRANITE_STREAM_PRIORITIES=%s (results unchanged, timing differs)\n", env);
-		for (int i = 0; i < 3 && env[i]; i++)
+		for (int i = 0; i < int(CommandBuffer::Type::Count) && env[i]; i++)
 			priorities[i] = env[i] == 'h' ? greatest : env[i] == 'm' ? middle : least;
 	}
 	if (getenv("GRANITE_LAUNCH_GRAPHS"))

@@ -77,8 +77,9 @@ class CommandBuffer
 {
 public:
 	// Generic: graphics + compute queue of the reference; AsyncCompute: its async compute queue; Front: the executor's
-	// frame-pipelining stream (render_graph.hpp, set_hoist_independent_compute).
-	enum class Type { Generic, AsyncCompute, Front, Count };
+	// frame-pipelining stream (render_graph.hpp, set_hoist_independent_compute); Tail: what follows the last pass of a frame
+	// that hands anything to the next frame (post-tonemap anti-aliasing), so that it runs beside the next frame's back.
+	enum class Type { Generic, AsyncCompute, Front, Tail, Count };
 	CommandBuffer(Device &device_, void *stream_, Type type_) : device(device_), stream(stream_), type(type_) {}
 	Device &get_device() { return device; }
 	gr_ctx *get_context() const;

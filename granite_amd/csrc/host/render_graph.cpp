@@ -1063,6 +1063,76 @@ void RenderGraph::build_stream_assignment()
 			pass_stream[pass_index] = pass_reads_physical[pass_index].empty() ? 1 : 2;
 		uses_async_stream = uses_async_stream || pass_stream[pass_index] != 0;
 	}
+
+	// The tail: the longest run of passes at the end of the baked order that (a) stand on the generic stream, (b) write nothing the next
+	// frame reads (no image with history, nothing read before it is written within the frame: bloom's feedback, exposure) and (c) whose
+	// first pass -- and with it the whole run -- takes exactly ONE physical resource from the passes in front of it.  For the application's
+	// graphs that is post-tonemap anti-aliasing reading `tonemapped`; a frame that ends with the tonemap has no tail.  Frame N's tail then
+	// runs beside frame N + 1's back instead of in front of it (the passes of the tail depend on nothing frame N + 1 produces and
+	// produce nothing it consumes): TAA resolve N + 1 no longer queues behind SMAA N.
+	// (a frame that ends in a blit to the swapchain keeps its end on the generic stream, where the blit is)
+	if (hoist_independent_compute && split_tail && uses_async_stream && swapchain_physical_index != RenderResource::Unused)
+	{
+		std::vector<bool> carried(physical_dimensions.size(), false); // read by some pass before any pass of the frame has written it
+		{
+			std::vector<bool> written(physical_dimensions.size(), false);
+			for (unsigned pass_index : pass_stack)
+			{
+				for (unsigned r : pass_reads_physical[pass_index])
+					if (!written[r])
+						carried[r] = true;
+				for (unsigned w : pass_writes_physical[pass_index])
+					written[w] = true;
+			}
+		}
+		// the longest suffix satisfying (a) and (b)
+		size_t begin = pass_stack.size();
+		while (begin > 0)
+		{
+			const unsigned pass_index = pass_stack[begin - 1];
+			bool ok = pass_stream[pass_index] == 0 && passes[pass_index]->get_history_inputs().empty() && !passes[pass_index]->may_not_need_render_pass();
+			for (unsigned w : pass_writes_physical[pass_index])
+				ok = ok && !physical_image_has_history[w] && !carried[w] && physical_dimensions[w].buffer_info.size == 0;
+			if (!ok)
+				break;
+			begin--;
+		}
+		// (c): shrink from the front until what crosses into the run is one image, written once, by a back pass
+		for (; begin < pass_stack.size(); begin++)
+		{
+			std::vector<bool> inside(physical_dimensions.size(), false);
+			for (size_t i = begin; i < pass_stack.size(); i++)
+				for (unsigned w : pass_writes_physical[pass_stack[i]])
+					inside[w] = true;
+			std::vector<unsigned> crossing;
+			for (size_t i = begin; i < pass_stack.size(); i++)
+				for (unsigned r : pass_reads_physical[pass_stack[i]])
+					if (!inside[r] && std::find(crossing.begin(), crossing.end(), r) == crossing.end())
+						crossing.push_back(r);
+			if (crossing.size() != 1)
+				continue;
+			unsigned writers = 0;
+			bool back_writer = true;
+			for (size_t i = 0; i < begin; i++)
+				for (unsigned w : pass_writes_physical[pass_stack[i]])
+					if (w == crossing[0])
+					{
+						writers++;
+						back_writer = back_writer && pass_stream[pass_stack[i]] == 0;
+					}
+			const auto &dim = physical_dimensions[crossing[0]];
+			if (writers == 1 && back_writer && dim.buffer_info.size == 0 && !physical_image_has_history[crossing[0]] && !carried[crossing[0]] &&
+			    crossing[0] != swapchain_physical_index)
+				break;
+		}
+		// ... and something must be left in front of it on the generic stream for the run to overlap with
+		bool back_in_front = false;
+		for (size_t i = 0; i < begin && i < pass_stack.size(); i++)
+			back_in_front = back_in_front || pass_stream[pass_stack[i]] == 0;
+		if (back_in_front)
+			for (size_t i = begin; i < pass_stack.size(); i++)
+				pass_stream[pass_stack[i]] = 3;
+	}
 	physical_sync.assign(physical_dimensions.size(), {});
 	for (auto &v : physical_sync_alternate)
 		v.assign(physical_dimensions.size(), {});
@@ -1124,11 +1194,21 @@ void RenderGraph::build_stream_assignment()
 			if (itr != resource_to_index.end() && resources[itr->second]->get_physical_index() != RenderResource::Unused)
 				reader_streams[resources[itr->second]->get_physical_index()] |= 1;
 		}
+		bool has_tail = false;
 		for (unsigned pass_index : pass_stack)
-			if (front[pass_index])
+			has_tail = has_tail || pass_stream[pass_index] == 3;
+		for (unsigned pass_index : pass_stack)
+		{
+			// ... and what the back hands to the tail (`tonemapped`), for the same reason one stage further down the frame
+			const bool hands_to_tail = has_tail && pass_stream[pass_index] == 0;
+			if (front[pass_index] || hands_to_tail)
 				for (unsigned w : pass_writes_physical[pass_index])
-					if (writers[w] == 1 && (reader_streams[w] & ~uint8_t(1u << pass_stream[pass_index])) != 0)
+				{
+					const uint8_t others = reader_streams[w] & ~uint8_t(1u << pass_stream[pass_index]);
+					if (writers[w] == 1 && (front[pass_index] ? others != 0 : (others & uint8_t(1u << 3)) != 0))
 						physical_buffer_double[w] = true;
+				}
+		}
 	}
 }
 
@@ -1415,7 +1495,7 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		{
 			if (physical_sync[w].last_write && physical_sync[w].write_stream != stream_index)
 				wait_for(stream, physical_sync[w].last_write, "WAW", w, physical_sync[w].write_pass, physical_sync[w].write_frame);
-			for (int other = 0; other < 3; other++)
+			for (int other = 0; other < StreamCount; other++)
 				if (other != stream_index)
 					wait_for(stream, physical_sync[w].last_read[other], "WAR", w, physical_sync[w].read_pass[other], physical_sync[w].read_frame[other]);
 		}
@@ -1452,8 +1532,9 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 		}
 	};
 
-	static const HIP::CommandBuffer::Type stream_types[3] = {HIP::CommandBuffer::Type::Generic, HIP::CommandBuffer::Type::AsyncCompute,
-	                                                          HIP::CommandBuffer::Type::Front};
+	static const HIP::CommandBuffer::Type stream_types[StreamCount] = {HIP::CommandBuffer::Type::Generic, HIP::CommandBuffer::Type::AsyncCompute,
+	                                                                    HIP::CommandBuffer::Type::Front, HIP::CommandBuffer::Type::Tail};
+	static_assert(int(HIP::CommandBuffer::Type::Count) == StreamCount, "one hazard-tracking slot per executor stream");
 	int run_stream = -1;        // stream of the run being enqueued
 	unsigned run_slot = 0;      // index of the run within the frame (event ring row)
 	bool run_published = false; // a pass of the run published accesses under the run's event
@@ -1462,7 +1543,7 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 	// EventRing) and records it here: the fence next_frame_context() would otherwise record right behind the run's own event.
 	// Which run that is: a dry pass over the frame's passes (need_render_pass is asked once per pass and frame).
 	std::vector<char> pass_runs(pass_stack.size(), 0);
-	int last_run_of_stream[3] = {-1, -1, -1};
+	int last_run_of_stream[StreamCount] = {-1, -1, -1, -1};
 	{
 		int stream_of_run = -1, run = 0;
 		for (size_t i = 0; i < pass_stack.size(); i++)
@@ -1718,7 +1799,8 @@ std::string RenderGraph::dump_json() const
 		first = false;
 		os << "{\"name\":\"" << pass.get_name() << "\",\"queue\":" << unsigned(pass.get_queue())
 		   << ",\"physical_pass\":" << int(get_physical_pass_index(pass_index))
-		   << ",\"stream\":" << (get_pass_stream(pass_index) == 0 ? "\"generic\"" : get_pass_stream(pass_index) == 1 ? "\"async\"" : "\"front\"") << ",\"writes\":[";
+		   << ",\"stream\":" << (get_pass_stream(pass_index) == 0 ? "\"generic\"" : get_pass_stream(pass_index) == 1 ? "\"async\"" : get_pass_stream(pass_index) == 2 ? "\"front\"" : "\"tail\"")
+		   << ",\"writes\":[";
 		bool f2 = true;
 		auto emit = [&](const RenderResource *r) {
 			if (!r)

@@ -403,6 +403,8 @@ public:
 	// is double-buffered, so frame N+1's cluster build overlaps frame N's lighting and frame N+1's lighting overlaps
 	// frame N's bloom / tonemap.  Default on.
 	void set_hoist_independent_compute(bool enable) { hoist_independent_compute = enable; }
+	// The end of the frame on a stream of its own (see split_tail below).  Default on; only has an effect while frames are pipelined.
+	void set_split_tail(bool enable) { split_tail = enable; }
 	// Share one allocation between attachment images of identical geometry whose lifetimes within the frame do not
 	// overlap (build_aliases, render_graph.cpp:1548-1746).  On by default like the reference; off is for A/B tests.
 	void set_alias_disjoint_images(bool enable) { alias_disjoint_images = enable; }
@@ -410,7 +412,8 @@ public:
 	unsigned get_physical_pass_count() const { return physical_pass_count; }
 	unsigned get_physical_alias(unsigned index) const { return index < physical_aliases.size() ? physical_aliases[index] : unsigned(RenderResource::Unused); }
 	// 0 = generic stream (the back of the frame), 1 = async compute (passes the front does not wait for within a frame:
-	// explicit ASYNC_COMPUTE passes and input-free front passes such as the cluster build), 2 = the rest of the front.
+	// explicit ASYNC_COMPUTE passes and input-free front passes such as the cluster build), 2 = the rest of the front,
+	// 3 = the tail (what follows the frame's last pass with a tie to the next frame and reads one image of it).
 	unsigned get_pass_stream(unsigned pass_index) const { return pass_index < pass_stream.size() ? pass_stream[pass_index] : 0u; }
 	bool physical_buffer_is_double_buffered(unsigned index) const { return index < physical_buffer_double.size() && physical_buffer_double[index]; }
 	void bake();
@@ -518,6 +521,11 @@ private:
 	// event (RAW, WAW and WAR); the state survives across frames, which is what lets frame N+1's hoisted passes start
 	// as soon as frame N's readers of their outputs have finished.  With a single stream in use nothing is recorded.
 	bool hoist_independent_compute = true;
+	// The passes behind the last pass of the frame that leaves anything to the next frame (history, feedback) and that take ONE image from
+	// what precedes them -- post-tonemap anti-aliasing reading `tonemapped` -- run on a stream of their own: frame N's tail beside frame
+	// N + 1's resolve / bloom / tonemap (reference ordering kept: scene_viewer_application.cpp:1230-1261, smaa.cpp:95-208).  The image
+	// handed over exists in HandOverCopies rotating copies like a front-to-back resource.
+	bool split_tail = true;
 	bool uses_async_stream = false;
 	std::vector<uint8_t> pass_stream;
 	std::vector<bool> pass_needs_sync; // touches a physical resource that the other stream also touches
@@ -530,14 +538,15 @@ private:
 	std::vector<void *> pass_done_event;
 	uint64_t frame_counter = 0;
 	uint64_t last_device_frame = 0; // Device::get_frame_number() at the last enqueue (the two rings advance in lockstep)
+	enum { StreamCount = 4 }; // generic (back), async compute, front, tail: HIP::CommandBuffer::Type
 	struct PhysicalSync
 	{
 		void *last_write = nullptr;
 		int write_stream = -1;
-		void *last_read[3] = {nullptr, nullptr, nullptr};
+		void *last_read[StreamCount] = {};
 		// who recorded those events (pass index, frame), for GRANITE_SYNC_DEBUG=1 traces
-		int write_pass = -1, read_pass[3] = {-1, -1, -1};
-		uint64_t write_frame = 0, read_frame[3] = {0, 0, 0};
+		int write_pass = -1, read_pass[StreamCount] = {-1, -1, -1, -1};
+		uint64_t write_frame = 0, read_frame[StreamCount] = {};
 	};
 	std::vector<PhysicalSync> physical_sync;
 	// Buffers written by a hoisted pass exist twice and alternate per frame (like an image with history), so the

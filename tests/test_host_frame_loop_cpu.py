@@ -156,3 +156,51 @@ def test_staging_slot_is_not_reused_before_the_stream_that_read_it_is_through(tm
     for n in range(9, 13):
         assert not any(o[2] == async_event for o in frames[n]), frames[n]
         assert sum(o[0] == "Q" for o in frames[n]) == 1 and sum(o[0] == "S" for o in frames[n]) == 1, frames[n]
+
+
+TAIL_WORKER = r'''
+import json, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from granite_amd import app as gapp, synth
+w, h = 512, 288
+cam = synth.Camera(w, h)
+out = {}
+for name, kw in (("taa_smaa", dict(pre_aa=gapp.POST_AA_TAA_HIGH, post_aa=gapp.POST_AA_SMAA_ULTRA)), ("fxaa", dict(post_aa=gapp.POST_AA_FXAA)), ("plain", {}),
+                 ("taa_smaa_two_bands", dict(pre_aa=gapp.POST_AA_TAA_HIGH, post_aa=gapp.POST_AA_SMAA_ULTRA, strip_index=0, strip_count=2))):
+    a = gapp.Application(w, h, lighting=True, hdr_bloom=True, dynamic_exposure=True, compute_post=True, **kw)
+    if "pre_aa" in kw:
+        a.set_camera(np.ascontiguousarray(cam.P.T, np.float32).reshape(16), np.ascontiguousarray(cam.V.T, np.float32).reshape(16))
+    else:
+        a.set_render_parameters(cam.render_params())
+    a.set_lights(synth.make_lights(cam, 64))
+    a.upload_gbuffer(synth.make_gbuffer(cam), synth.make_motion_vectors(w, h) if "pre_aa" in kw else None)
+    if "strip_count" not in kw:
+        a.render_frames(6, sync=True)
+    g = a.graph()
+    out[name] = {"streams": {p["name"]: p["stream"] for p in g["passes"]}, "copies": {r["name"]: r["double_buffered"] for r in g["resources"]}}
+    a.close()
+print(json.dumps(out))
+'''
+
+
+def test_post_tonemap_anti_aliasing_runs_on_the_tail_stream():
+    """The end of a frame that hands nothing to the next one and takes one image from what precedes it -- SMAA / FXAA behind the tonemap --
+    is assigned to the executor's fourth stream and `tonemapped` becomes a rotating hand-over image (render_graph.cpp,
+    build_stream_assignment); a frame that ends with the tonemap has no tail; under row bands the split is off.  Six un-synchronised
+    frames run through the device-less runtime with it (no wait on an event that was never recorded: the stub aborts on one)."""
+    if not os.path.exists(STUB) or os.path.getmtime(STUB) < os.path.getmtime(os.path.join(os.path.dirname(STUB), "hip_stub.cpp")):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(STUB)])
+    env = dict(os.environ, LD_PRELOAD=STUB, HIP_STUB_EVENTS_PENDING="1")
+    env.pop("GRANITE_SPLIT_TAIL", None)
+    r = subprocess.run([sys.executable, "-c", TAIL_WORKER % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    doc = json.loads(r.stdout.strip().splitlines()[-1])
+    s = doc["taa_smaa"]["streams"]
+    assert {k for k, v in s.items() if v == "tail"} == {"smaa-edge", "smaa-weights", "smaa-blend"}, s
+    assert s["tonemap"] == "generic" and s["taa-resolve"] == "generic" and s["lighting-main"] == "front" and s["clustering-bindless"] == "async", s
+    assert doc["taa_smaa"]["copies"]["tonemapped"] is True and doc["taa_smaa"]["copies"]["HDR-main"] is True
+    f = doc["fxaa"]["streams"]
+    assert [k for k, v in f.items() if v == "tail"] == ["fxaa"] and doc["fxaa"]["copies"]["tonemapped"] is True, f
+    assert "tail" not in doc["plain"]["streams"].values() and doc["plain"]["copies"].get("tonemapped") in (False, None), doc["plain"]
+    assert "tail" not in doc["taa_smaa_two_bands"]["streams"].values(), doc["taa_smaa_two_bands"]["streams"]
