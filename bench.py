@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="length of the unbracketed run after the timed region (0 = off); 6 s by default so that a 5 s utilisation sampler sees the GPU busy")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
+    ap.add_argument("--scene", default="default", choices=["default", "depth_split", "hot_spot"],
+                    help="synthetic scene (granite_amd/synth.py): default = the scene every headline number is quoted on; depth_split = a third of the "
+                         "lighting tiles straddles a 1-7 / 30 unit depth discontinuity; hot_spot = 128 lights on 5 %% of the screen (64-94 in range per pixel)")
     ap.add_argument("--allow-replicas", action="store_true",
                     help="N > 1: when the row-band transport (RCCL) cannot be set up, fall back to N independent replicas instead of failing "
                          "(the line then says so in config.parallelism; it is not a scaling measurement)")
@@ -274,8 +277,10 @@ def main():
             name = f"{workload}_x{world}_rowbands_{width}x{height}"
             desc = f"{width}x{height} tiled into {world} row bands (one per GPU), {num_lights} clustered lights, bloom pyramid + luminance + tonemap"
         cam = synth.Camera(width, height)
-        gbuf = synth.make_gbuffer(cam)
-        descs = synth.make_lights(cam, num_lights, spot_fraction=0.25 if num_lights > 256 else 0.0)
+        gbuf = synth.make_gbuffer(cam, scene=args.scene)
+        descs = synth.make_lights(cam, num_lights, spot_fraction=0.25 if num_lights > 256 else 0.0, scene=args.scene)
+        if args.scene != "default":
+            name, desc = f"{name}_scene_{args.scene}", f"{desc}; scene {args.scene} (granite_amd/synth.py)"
         strips = dict(strip_index=rank if bands else 0, strip_count=world if bands else 1,
                       output_gather_rgba=os.environ.get("GRANITE_BENCH_GATHER_RGBA", "0") == "1")
         if workload == "config1_256_post_only":
@@ -626,7 +631,7 @@ def main():
                                    f"({'in frame' if os.environ.get('GRANITE_BENCH_GATHER', 'beside') == 'inframe' else 'beside the frame, own stream + communicator'})" if bands else
                                    f"{world} independent replicas ({'this workload is not tiled by bench.py' if args.workload in SINGLE_GPU_WORKLOADS else f'row-band set-up failed: {fallback_reason}'})"),
                    "hdr_format": ("B10G11R11_UFLOAT_PACK32 (packed-float storage, fp32 arithmetic)" if args.workload in PACKED_HDR_WORKLOADS
-                                  else "R16G16B16A16_SFLOAT (fp16 storage, fp32 arithmetic)"), "seed": synth.SEED,
+                                  else "R16G16B16A16_SFLOAT (fp16 storage, fp32 arithmetic)"), "seed": synth.SEED, "scene": args.scene,
                    "timed_region": {"config1_256_post_only": "bloom pyramid + luminance + tonemap, every frame; the HDR input is resident in HBM",
                                     "config4_4k_smaa_taa": "cluster build + per-frame light refresh + lighting + TAA resolve + bloom pyramid + luminance + "
                                                            "tonemap + SMAA (edges, weights, blend), every frame; the synthetic G-buffer is resident in HBM"}.get(

@@ -93,6 +93,7 @@ struct KernelArgs
 	uint32_t flags;
 	float fog_color[3], fog_falloff; // the fog quad behind the clustered one (renderer.cpp:1179-1196); falloff <= 0: none
 	int row_first, row_end, block_row0; // render area rows [row_first, row_end); first block row = row_first / 8
+	int list_words;                     // wide-window path: words of the cluster bitmask per span (0: off), 32 list entries of 2 B each per wave
 };
 
 struct float3_ { float x, y, z; };
@@ -224,6 +225,27 @@ __device__ __forceinline__ void wave_min_and_max_u32(uint32_t &lo, uint32_t &hi)
 #undef GR_DPP_STEP
 #undef GR_DPP_BCAST
 
+// Wave64 inclusive prefix sum: four row_shr steps scan each row of 16 lanes, row_bcast:15 adds row 0's total to row 1 and row 2's to row 3,
+// row_bcast:31 adds the total of rows 0 + 1 to rows 2 and 3.
+__device__ __forceinline__ uint32_t wave_inclusive_add_u32(uint32_t v)
+{
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, true)); // row_shr:1, lanes without a source add 0
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, true)); // row_shr:2
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, true)); // row_shr:4
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, true)); // row_shr:8
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1, 3
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2, 3
+	return v;
+}
+// The bits of the 32-bit word that starts at light index `word_first` whose index is >= `index`.
+__device__ __forceinline__ uint32_t bits_from(uint32_t index, uint32_t word_first)
+{
+	return index <= word_first ? 0xffffffffu : (index - word_first >= 32u ? 0u : 0xffffffffu << (index - word_first));
+}
+
+// The workgroup's dynamic LDS (behind the static arrays of k_lighting): the wide-window candidate lists, LIGHT_WAVES x list_words x 32 entries.
+extern __shared__ __attribute__((aligned(16))) uint8_t lv_dynamic_lds[];
+
 // One staged light = 4 x 16 B in wave-private LDS.
 //   q0: position.xyz, (1.001 r)^2        q1: colour.xyz, 10 / r
 //   q2: direction.xyz, -                 q3: spot scale, spot bias (fp32), -, -          (q2, q3 read by the second list only)
@@ -267,7 +289,7 @@ __device__ __forceinline__ void shade_positional(const Surface (&s)[PX], const f
 		inv_d2[p] = inv_d[p] * inv_d[p];
 		// 1 - smoothstep(0.9, 1.0, dist * inv_radius)
 		const float t = sat(fmaf(dist, q1.w, -9.0f));
-		atten[p] = fmaf(-(t * t), fmaf(-2.0f, t, 3.0f), 1.0f);
+		atten[p] = fmaf(t * t, fmaf(2.0f, t, -3.0f), 1.0f); // 1 - t^2 (3 - 2 t), the sign carried by the inner fma: no negation to materialise
 	}
 	if (CONE)
 	{
@@ -364,7 +386,7 @@ __device__ __forceinline__ void load_raw(const KernelArgs &a, int x0, int y, Raw
 
 // One wave, one tile of 8 PX x 8 pixels whose attachment words are in `raw`: both quads, the fog quad, the store.
 template <int PX, bool AO, bool B10>
-__device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x0, const int tile_y0, const int lane, const RawTile<PX, B10> &raw,
+__device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x0, const int tile_y0, const int wave, const int lane, const RawTile<PX, B10> &raw,
                                            f32x4 *const slots, const float *s_srgb LV_STAMP_PARAM)
 {
 	const int x0 = tile_x0 + (lane & (LIGHT_TILE - 1)) * PX;
@@ -492,6 +514,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 	{
 		float3_ result[PX];
 		uint32_t lane_lo = 0xffffffffu, lane_hi = 0u;
+		uint2 px_range[PX]; // the pixel's own light-index range, defined where active[p] (read by the wide-window path only)
 #pragma unroll
 		for (int p = 0; p < PX; p++)
 		{
@@ -504,6 +527,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 			if (active[p])
 			{
 				const uint2 z_range = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(a.range) + (z_index << 3u));
+				px_range[p] = z_range;
 				lane_lo = min(lane_lo, z_range.x);
 				lane_hi = max(lane_hi, z_range.y);
 			}
@@ -511,7 +535,30 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 		// The wave's light-index window.
 		wave_min_and_max_u32(lane_lo, lane_hi);
 		const uint32_t win_lo = lane_lo, win_hi = min(lane_hi, uint32_t(a.cl_num_lights - 1));
-
+		// A tile across a depth discontinuity (foreground against background) has a window that spans every light between the two depths,
+		// although the indices between the foreground's ranges and the background's are in no pixel's range -- the reference's per-lane
+		// cluster_mask_range (clusterer_bindless_buffers.h:17-27) removes them from every lane's mask, so they are in no subgroupOr
+		// either.  For a window of three chunks or more (the wide-window path below), with P = the smallest range end of the tile: every
+		// pixel whose range starts at or below P ends at or below Q = the largest end among them, every other pixel's range starts at
+		// or above G = the smallest start among those; the indices strictly between Q and G (if any) are trimmed from the window.
+		const bool wide = a.list_words != 0 && win_lo <= win_hi && (win_hi >> 6u) - (win_lo >> 6u) >= 2u;
+		uint32_t gap_lo = 0u, gap_hi = 0xffffffffu; // Q and G: indices i with gap_lo < i < gap_hi are in no pixel's range
+		if (wide)
+		{
+			uint32_t first_end = 0xffffffffu;
+#pragma unroll
+			for (int p = 0; p < PX; p++)
+				first_end = min(first_end, active[p] && px_range[p].x <= px_range[p].y ? px_range[p].y : 0xffffffffu);
+			first_end = wave_minmax_u32<false>(first_end);
+#pragma unroll
+			for (int p = 0; p < PX; p++)
+			{
+				const bool some = active[p] && px_range[p].x <= px_range[p].y, low = px_range[p].x <= first_end;
+				gap_lo = max(gap_lo, some && low ? px_range[p].y : 0u);
+				gap_hi = min(gap_hi, some && !low ? px_range[p].x : 0xffffffffu);
+			}
+			wave_min_and_max_u32(gap_hi, gap_lo); // gap_hi <= gap_lo + 1: an empty gap, nothing is trimmed
+		}
 		if (win_lo <= win_hi)
 		{
 			// Cluster cells the tile touches (clusterer_bindless.h:39-42 at the tile's first and last pixel; the per-pixel formula is
@@ -547,24 +594,23 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 
 			LV_STAMP_MARK(1); // slice window, cells, bounding sphere
 			LV_STAMP_LAP_BEGIN();
+			// Two sources of candidate lights, one loop around the cull and the walks:
+			//   * narrow window (one or two 64-light chunks, the usual case of a surface near the camera): a chunk per turn, lane l owns
+			//     light 64 * chunk + l and reads the word of each touched cell that holds its bit;
+			//   * wide window (a surface far from the camera: the ranges of its Z slices span the lights of a thick slab, 22 chunks at 30
+			//     units in the 4096-light scenes, of whose lights three in a hundred touch the tile's cells): the window's words are read
+			//     ONCE, lane j the j-th word of a span of `list_words` words, and their set bits are compacted in index order into a
+			//     wave-private list of light indices (counts by v_bcnt, their prefix sums by a DPP scan); a turn takes the next 64 of the
+			//     list -- one pair of memory round trips per 64 CANDIDATES instead of one per 64 indices.  The list lives in the
+			//     workgroup's dynamic LDS, which the launcher sizes anyway to cap the kernel's residency (gr_lighting).
 			const int chunk_lo = int(win_lo >> 6u), chunk_hi = int(win_hi >> 6u);
-			for (int chunk = chunk_lo; chunk <= chunk_hi; chunk++)
-			{
-				// ---- gather + cull: one light per lane ----
-				const uint32_t light_index = uint32_t(chunk) * 64u + uint32_t(lane);
-				const int my_word = chunk * 2 + (lane >> 5);
+			// One turn: up to 64 candidate lights, one per lane, culled against the tile and staged; then the walks over the survivors.
+			auto turn = [&](const uint32_t light_index, const bool candidate) __attribute__((always_inline)) {
+				// ---- cull: one light per lane ----
 				bool keep = false;
 				bool second = false; // walked with the cone body: spot lights, and point lights of radius < 1 / 8
-				if (index_in_range(light_index, win_lo, win_hi))
 				{
-					uint32_t word = 0u;
-					for (int cy = cy0; cy <= cy1; cy++)
-					{
-#pragma clang loop vectorize(disable) unroll(disable)
-						for (int cx = cx0; cx <= cx1; cx++)
-							word |= a.bitmask[(cy * a.cl_res_x + cx) * a.cl_num_lights_32 + my_word];
-					}
-					if ((word >> (uint32_t(lane) & 31u)) & 1u)
+					if (candidate)
 					{
 						const f32x4 *rec = reinterpret_cast<const f32x4 *>(a.lights + light_index);
 						const f32x4 c = rec[0], pq = rec[1], d = rec[2]; // colour|scale_bias, position|offset_radius, direction|inv_radius
@@ -628,7 +674,65 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 				for (uint64_t todo = seconds; todo != 0ull; todo &= todo - 1ull)
 					shade_positional<PX, true>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
 				LV_STAMP_LAP(3); // the two walks
-				__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
+				__builtin_amdgcn_wave_barrier(); // the slots are rewritten by the next turn
+			};
+			if (!wide)
+			{
+				for (int chunk = chunk_lo; chunk <= chunk_hi; chunk++)
+				{
+					// ---- gather: lane l looks up the bit of light 64 * chunk + l ----
+					const uint32_t light_index = uint32_t(chunk) * 64u + uint32_t(lane);
+					const int my_word = chunk * 2 + (lane >> 5);
+					bool candidate = false;
+					if (index_in_range(light_index, win_lo, win_hi))
+					{
+						uint32_t word = 0u;
+						for (int cy = cy0; cy <= cy1; cy++)
+						{
+#pragma clang loop vectorize(disable) unroll(disable)
+							for (int cx = cx0; cx <= cx1; cx++)
+								word |= a.bitmask[(cy * a.cl_res_x + cx) * a.cl_num_lights_32 + my_word];
+						}
+						candidate = ((word >> (uint32_t(lane) & 31u)) & 1u) != 0u;
+					}
+					turn(light_index, candidate);
+				}
+			}
+			else
+			{
+				uint16_t *const list = reinterpret_cast<uint16_t *>(lv_dynamic_lds) + wave * (a.list_words * 32);
+				const int word_last = int(win_hi >> 5u);
+				for (int span_word = int(win_lo >> 5u); span_word <= word_last; span_word += a.list_words)
+				{
+					// ---- gather: lane j reads word j of the span, the set bits of all words go to the list in index order ----
+					const int my_word = span_word + lane;
+					const uint32_t word_first = uint32_t(my_word) << 5u;
+					uint32_t word = 0u;
+					if (lane < a.list_words && my_word <= word_last)
+					{
+						for (int cy = cy0; cy <= cy1; cy++)
+						{
+#pragma clang loop vectorize(disable) unroll(disable)
+							for (int cx = cx0; cx <= cx1; cx++)
+								word |= a.bitmask[(cy * a.cl_res_x + cx) * a.cl_num_lights_32 + my_word];
+						}
+						// the window [win_lo, win_hi] without its gap, as bits of this word
+						word &= bits_from(win_lo, word_first) & ~bits_from(win_hi + 1u, word_first) & ~(bits_from(gap_lo + 1u, word_first) & ~bits_from(gap_hi, word_first));
+					}
+					const uint32_t count = uint32_t(__builtin_popcount(word));
+					const uint32_t upto = wave_inclusive_add_u32(count);
+					const int list_count = __builtin_amdgcn_readlane(int(upto), 63);
+					uint16_t *entry = list + (upto - count);
+					for (; word != 0u; word &= word - 1u)
+						*entry++ = uint16_t(word_first + uint32_t(__builtin_ctz(word)));
+					__builtin_amdgcn_wave_barrier();
+					for (int next = 0; next < list_count; next += 64)
+					{
+						const bool candidate = next + lane < list_count;
+						turn(candidate ? uint32_t(list[next + lane]) : 0u, candidate);
+					}
+					__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next span
+				}
 			}
 		}
 		// second blend: the attachment store rounds once more, straight into the halves that are written out
@@ -776,14 +880,16 @@ __global__ __launch_bounds__(64 * LIGHT_WAVES) LV_OCCUPANCY_ATTR void k_lighting
 #pragma unroll
 	for (int i = 0; i < 256; i += 64 * LIGHT_WAVES)
 		s_srgb[i + threadIdx.x] = a.srgb_lut[i + threadIdx.x];
-	const int wave = threadIdx.x >> 6;
+	const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)); // wave-uniform: the slot and list addresses stay scalar
 	const int lane = threadIdx.x & 63;
 	const int tile_x0 = (int(blockIdx.x) * LIGHT_WAVES + wave) * TILE_W, tile_y0 = (a.block_row0 + int(blockIdx.y)) * LIGHT_TILE;
 	LV_STAMP_SCOPE((int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * LIGHT_WAVES + wave);
 	RawTile<PX, B10> raw;
 	load_raw<PX, B10>(a, tile_x0 + (lane & (LIGHT_TILE - 1)) * PX, tile_y0 + (lane >> 3), raw);
 	__syncthreads(); // s_srgb
-	shade_tile<PX, AO, B10>(a, tile_x0, tile_y0, lane, raw, s_lights[wave], s_srgb LV_STAMP_ARG);
+	// the slot array's address stays a vector register: the walks form a light's address with one v_add (a scalar base costs a v_mov from
+	// an SGPR per ds_read, two instructions per walked light)
+	shade_tile<PX, AO, B10>(a, tile_x0, tile_y0, wave, lane, raw, s_lights[threadIdx.x >> 6], s_srgb LV_STAMP_ARG);
 }
 
 static bool check_image(const gr_image &img, uint32_t format, uint32_t bpp, uint32_t w, uint32_t h)
@@ -922,6 +1028,15 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	// must be able to start beside resident lighting workgroups instead of waiting for one to retire.
 	const size_t per_wg = ((160u - 8u) * 1024u / unsigned(max_wgs * 4 / LIGHT_WAVES)) & ~size_t(1023); // max_wgs counts four-wave workgroups
 	const size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
+	// The pad is not idle: it holds the wide-window candidate lists (shade_tile), 32 two-byte entries per word of a span and wave.
+	// 13 KiB at five workgroups per CU: spans of 52 words = 1664 light indices.  No pad (GR_LIGHTING_WGS_PER_CU=8): the chunk loop only.
+	{
+		const size_t words = pad_lds / (size_t(LIGHT_WAVES) * 32u * sizeof(uint16_t));
+		k.list_words = words >= 8 ? int(words < 64 ? words : 64) : 0;
+		static const bool narrow_only = []() { const char *env = gr_measurement_switch("GR_LIGHTING_NARROW_ONLY"); return env && atoi(env) != 0; }();
+		if (narrow_only)
+			k.list_words = 0;
+	}
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "lighting"};
 	const bool ao = (args->flags & GR_LIGHTING_AMBIENT_OCCLUSION_BIT) != 0;
 	const dim3 block(64 * LIGHT_WAVES);

@@ -112,14 +112,32 @@ def make_hdr(width: int, height: int, seed: int = SEED) -> np.ndarray:
     return _f32_to_f16_bits(rgba)
 
 
-def make_gbuffer(cam: Camera, seed: int = SEED) -> dict:
+SCENES = ("default", "depth_split", "hot_spot")
+DEPTH_SPLIT_BAR_PX, DEPTH_SPLIT_FAR_Z = 24, 30.0  # "depth_split": bars of this many pixels alternate between the default surface and a far wall
+HOT_SPOT_REGION, HOT_SPOT_LIGHTS, HOT_SPOT_RANGE = (0.39, 0.61), 128, 1.5  # "hot_spot": u and v interval of the region, lights moved into it, their range
+
+
+def surface_view_z(u, v):
+    """View-space distance of the default synthetic surface under normalised screen coordinates (u, v)."""
+    return 4.0 + 3.0 * np.sin(8.0 * np.pi * u) * np.cos(6.0 * np.pi * v)
+
+
+def make_gbuffer(cam: Camera, seed: int = SEED, scene: str = "default") -> dict:
     """G-buffer attachments in the reference's formats (application/scene_viewer_application.cpp:880-931):
-    emissive RGBA16F, albedo RGBA8_SRGB (a = ambient), normal A2B10G10R10, pbr RG8, depth D32F."""
+    emissive RGBA16F, albedo RGBA8_SRGB (a = ambient), normal A2B10G10R10, pbr RG8, depth D32F.
+
+    scene = "depth_split": every other vertical bar of DEPTH_SPLIT_BAR_PX pixels is a wall at view distance DEPTH_SPLIT_FAR_Z: a third of
+    the 16-pixel-wide lighting tiles straddles a depth discontinuity and their light-index windows span every light between the two depths
+    (the worst case of clusterer_bindless.h:49-81's subgroup min / max window).  "hot_spot" changes the lights only (make_lights)."""
+    assert scene in SCENES
     w, h = cam.width, cam.height
     r = _rng(2, seed)
     u = (np.arange(w, dtype=np.float64) + 0.5) / w
     v = (np.arange(h, dtype=np.float64) + 0.5) / h
-    view_z = 4.0 + 3.0 * np.sin(8.0 * np.pi * u)[None, :] * np.cos(6.0 * np.pi * v)[:, None]
+    view_z = surface_view_z(u[None, :], v[:, None])
+    if scene == "depth_split":
+        far = ((np.arange(w) // DEPTH_SPLIT_BAR_PX) % 2) == 1
+        view_z = np.where(far[None, :], DEPTH_SPLIT_FAR_Z + 0.25 * np.cos(6.0 * np.pi * v)[:, None], view_z)
     depth = cam.depth_from_view_distance(view_z)
     sky = r.random((h, w)) < 0.02
     depth[sky] = 0.0
@@ -143,18 +161,29 @@ def make_gbuffer(cam: Camera, seed: int = SEED) -> dict:
 
 
 def make_lights(cam: Camera, count: int, spot_fraction: float = 0.25, z_lo: float = 1.0, z_hi: float = 40.0,
-                max_range: float = 4.0, seed: int = SEED) -> np.ndarray:
+                max_range: float = 4.0, seed: int = SEED, scene: str = "default") -> np.ndarray:
     """Point + spot lights uniform (by volume) in the view-frustum slab z in [z_lo, z_hi]; colour = hue * intensity with
     intensity log-uniform 1..50; spots: inner = cos 20 deg, outer = cos 30 deg, random orientation;
-    PositionalLight::set_maximum_range(max_range)."""
+    PositionalLight::set_maximum_range(max_range).
+
+    scene = "hot_spot": the first HOT_SPOT_LIGHTS lights sit 0.3 units in front of the default surface inside the screen region
+    HOT_SPOT_REGION x HOT_SPOT_REGION (4.8 % of the screen) with range HOT_SPOT_RANGE: well over 64 lights in range per pixel there."""
+    assert scene in SCENES
     r = _rng(3, seed)
     descs = np.zeros(count, LIGHT_DESC_DTYPE)
     if count == 0:
         return descs
     d = np.cbrt(r.random(count) * (z_hi ** 3 - z_lo ** 3) + z_lo ** 3)
     t = math.tan(cam.fovy / 2.0)
-    xv = r.uniform(-1.0, 1.0, count) * d * t * cam.aspect
-    yv = r.uniform(-1.0, 1.0, count) * d * t
+    xs, ys = r.uniform(-1.0, 1.0, count), r.uniform(-1.0, 1.0, count)
+    hot = min(HOT_SPOT_LIGHTS, count) if scene == "hot_spot" else 0
+    if hot:
+        hr = _rng(7, seed)
+        hu, hv = hr.uniform(*HOT_SPOT_REGION, hot), hr.uniform(*HOT_SPOT_REGION, hot)
+        d[:hot] = surface_view_z(hu, hv) - 0.3
+        xs[:hot], ys[:hot] = 2.0 * hu - 1.0, 2.0 * hv - 1.0  # (the surface is symmetric under v -> 1 - v: the sign of the y axis does not matter)
+    xv = xs * d * t * cam.aspect
+    yv = ys * d * t
     view_pos = np.stack([xv, yv, -d, np.ones(count)], axis=1)
     world = (cam.invV @ view_pos.T).T[:, :3]
 
@@ -167,6 +196,8 @@ def make_lights(cam: Camera, count: int, spot_fraction: float = 0.25, z_lo: floa
     descs["inner_cone"] = math.cos(math.radians(20.0))
     descs["outer_cone"] = math.cos(math.radians(30.0))
     descs["cutoff_range"] = max_range
+    if hot:
+        descs["cutoff_range"][:hot] = HOT_SPOT_RANGE
 
     # orientation: -Z axis of the node = light direction
     fwd = r.normal(size=(count, 3))

@@ -8,12 +8,12 @@ from oracle import oracle as orc
 
 
 class Scene:
-    def __init__(self, w, h, num_lights, res=(128, 64, 4096), seed=synth.SEED, spot_fraction=0.25):
+    def __init__(self, w, h, num_lights, res=(128, 64, 4096), seed=synth.SEED, spot_fraction=0.25, scene="default"):
         self.w, self.h = w, h
         self.cam = synth.Camera(w, h)
         self.rp = self.cam.render_params()
-        self.gbuf = synth.make_gbuffer(self.cam, seed)
-        self.descs = synth.make_lights(self.cam, num_lights, spot_fraction, seed=seed)
+        self.gbuf = synth.make_gbuffer(self.cam, seed, scene=scene)
+        self.descs = synth.make_lights(self.cam, num_lights, spot_fraction, seed=seed, scene=scene)
         self.res = res
         self.n, self.lights, self.model, self.type_mask, self.order = orc.pack_lights(self.descs, self.rp[99:102])
         self.prm = orc.cluster_params(self.rp, res[0], res[1], res[2], self.n)

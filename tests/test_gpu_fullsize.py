@@ -155,23 +155,38 @@ def test_config3_frame_matches_oracle_at_4k():
     check_frame_against_oracle(W, H, "4K")
 
 
+@pytest.mark.parametrize("scene", ["depth_split", "hot_spot"])
+def test_worst_case_scenes_match_oracle_at_4k(scene):
+    """Two scenes the default one does not contain (granite_amd/synth.py): "depth_split" -- a third of the lighting tiles straddles a
+    depth discontinuity between 1-7 and 30 units, so their light-index windows (clusterer_bindless.h:49-81: subgroup min / max of the
+    slices' ranges) span every light in between, two dozen 64-light chunks of which most hold nothing for the tile; "hot_spot" -- 128
+    lights packed onto 5 % of the screen, 64 to 94 lights in range per pixel there, ten times the frame's average.  Same comparisons,
+    same tolerances as config 3 with one allowance for "depth_split": its wall stands 30 to 43 units from the camera, where one fp32
+    rounding of the reconstructed position is 4e-6 units, and some of its pixels have a light within 0.01 to 0.1 units of the surface.  At the
+    7 pixels of 8.3 M where kernel and oracle are more than 2 ulp apart the exact (float64) value of the shader moves by 1 to 4 fp16 ulp per
+    fp32 rounding of the position, and the kernel is the closer of the two in 8 of the 12 channels (tools/exact_pixels.py,
+    profiles/r06_depth_split_ill_conditioned_pixels.txt): at most 12 pixels may sit within 8 ulp.
+    Their times: profiles/r06_scenes_depth_split_hot_spot.txt."""
+    check_frame_against_oracle(W, H, "4K " + scene, scene=scene, ill_conditioned_pixels=12 if scene == "depth_split" else 0)
+
+
 def test_config5_frame_whole_on_one_gpu_matches_oracle_at_8k():
     """BASELINE config 5's 7680x4320 frame rendered whole by one executor (what every rank's bands must assemble to,
     tests/test_gpu_strips.py, and bench.py's bands_checked reference), against the oracle: 33 M pixels, 265 MB HDR target."""
     check_frame_against_oracle(7680, 4320, "8K")
 
 
-def check_frame_against_oracle(W, H, tag):
+def check_frame_against_oracle(W, H, tag, scene="default", ill_conditioned_pixels=0):
     """BASELINE config 3 through the executor (3840x2160, 4096 clustered point + spot lights, bloom pyramid + luminance +
     tonemap) against the oracle: cluster bitmask / ranges bit-exact, HDR-main, threshold, downsample-3, upsample-0 at the
     stated fp16 tolerances, backbuffer +-1 LSB.  Exercises what only exists at this size: the screen-order grid of 16 200 workgroups,
     32-bit offsets over 66 MB targets, 8100-block grids, the all-2:1 stencil pyramid and the fused tail."""
     from test_gpu_app import oracle_frames
     from oracle import oracle as orc
-    from util import assert_rgba16f_close, assert_rgba8_close
+    from util import assert_rgba16f_close, assert_rgba16f_close_but_for_ill_conditioned_pixels, assert_rgba8_close
     cam = synth.Camera(W, H)
-    gbuf = synth.make_gbuffer(cam)
-    descs = synth.make_lights(cam, LIGHTS)
+    gbuf = synth.make_gbuffer(cam, scene=scene)
+    descs = synth.make_lights(cam, LIGHTS, scene=scene)
     frames = 2
     ref = oracle_frames(cam, gbuf, descs, 0)  # packed lights, cluster build, lit HDR
     a = gapp.Application(W, H)
@@ -185,7 +200,10 @@ def check_frame_against_oracle(W, H, tag):
     hdr = a.read("HDR-main").copy()
     # SURVEY 8a's tolerance as written: 2 ulp fp16 + 1e-4 (measured at this size, tools/ulp_hist.py: 99.97 % of the
     # channels bit-identical, 3e-4 one ulp apart, 2 of 24.9 M further -- both below the absolute term)
-    assert_rgba16f_close(hdr, ref["hdr"], ulps=2.0, what=f"{tag} HDR-main")
+    if ill_conditioned_pixels:
+        assert_rgba16f_close_but_for_ill_conditioned_pixels(hdr, ref["hdr"], ulps=2.0, max_pixels=ill_conditioned_pixels, outer_ulps=8.0, what=f"{tag} HDR-main")
+    else:
+        assert_rgba16f_close(hdr, ref["hdr"], ulps=2.0, what=f"{tag} HDR-main")
     assert (hdr == ref["hdr"]).mean() > 0.999
     # The post chain is checked stage by stage on the DEVICE's lit HDR target (the log-luminance channel of the threshold
     # level is log2 of a value near 1 wherever the scene is near exposure: a one-ulp difference of a lit texel moves it by

@@ -96,6 +96,34 @@ def test_lighting_matches_oracle(gr, w, h, num_lights):
         assert exact > 0.95, f"only {exact:.3f} of channels bit-identical"
 
 
+@pytest.mark.parametrize("w,h", [(480, 270), (333, 77), (1280, 720)])
+def test_lighting_wide_light_index_windows_match_oracle(gr, w, h):
+    """Scene "depth_split" (granite_amd/synth.py): half of the surface is a wall 30 units from the camera, where a Z slice's light range
+    spans some 1400 indices of the 4096-light scene (22 chunks of 64), and a third of the tiles straddles the 1-7 / 30 unit discontinuity.
+    These tiles take the kernel's wide-window path (the window's cluster words read once, their set bits compacted into a list, 64 list
+    entries per turn; the gap between the foreground's and the background's ranges trimmed) -- two-pixel form at the even widths, one-pixel
+    form (16-word spans) at 333.  Against the oracle's exact per-pixel light sets, and against its unclustered sum over all lights.  The
+    allowance: tests/test_gpu_fullsize.py::test_worst_case_scenes_match_oracle_at_4k (lights within 0.1 units of a surface 30 to 43 units away)."""
+    from util import assert_rgba16f_close_but_for_ill_conditioned_pixels
+    sc = Scene(w, h, 4096, scene="depth_split")
+    ref_c = orc.cluster_build(sc.rp, sc.prm, sc.lights, sc.model, sc.type_mask, sc.n, sc.res[2])
+    dev = sc.build_clusters_gpu(gr)
+    ref = orc.lighting(sc.gbuf, sc.rp, sc.prm, sc.lights, sc.type_mask, ref_c["bitmask"], ref_c["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
+    args, imgs = sc.lighting_args(gr, dev, ALL)
+    gr.check(gr.lib.gr_lighting(gr.handle, None, args))
+    gr.sync()
+    got = imgs["hdr"].download()
+    assert_rgba16f_close_but_for_ill_conditioned_pixels(got, ref, ulps=2.0, abs_tol=1e-4, max_pixels=2, outer_ulps=8.0, what=f"depth_split {w}x{h}")
+    assert (got == ref).mean() > 0.95
+    if w == 480:
+        brute = orc.lighting(sc.gbuf, sc.rp, sc.prm, sc.lights, sc.type_mask, np.zeros(1, np.uint32), np.zeros((1, 2), np.uint32),
+                             synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION, directional=False, bruteforce=True)
+        args, imgs = sc.lighting_args(gr, dev, capi.LIGHTING_CLUSTERED_BIT)
+        gr.check(gr.lib.gr_lighting(gr.handle, None, args))
+        gr.sync()
+        assert_rgba16f_close_but_for_ill_conditioned_pixels(imgs["hdr"].download(), brute, ulps=2.0, max_pixels=2, outer_ulps=8.0, what="wide windows vs brute force")
+
+
 def test_lighting_separate_emissive_equals_aliased(gr):
     """emissive as a distinct input attachment gives bit-identical HDR to the aliased read-modify-write form and leaves
     the G-buffer untouched."""
