@@ -88,6 +88,13 @@ class PushLuminance(C.Structure):
     _fields_ = [("size", C.c_uint32 * 2), ("lerp", C.c_float), ("min_loglum", C.c_float), ("max_loglum", C.c_float)]
 
 
+class BloomPyramidArgs(C.Structure):
+    _fields_ = [("hdr", Image), ("threshold", Image), ("d0", Image), ("d1", Image), ("d2", Image), ("d3", Image), ("history", Image),
+                ("u2", Image), ("u1", Image), ("u0", Image), ("lum", C.c_void_p), ("push_threshold", PushBloomThreshold),
+                ("push_d0", PushBloomDownsample), ("push_d1", PushBloomDownsample), ("push_d2", PushBloomDownsample), ("push_d3", PushBloomDownsample),
+                ("push_u2", PushBloomUpsample), ("push_u1", PushBloomUpsample), ("push_u0", PushBloomUpsample), ("push_luminance", PushLuminance)]
+
+
 class PushTonemap(C.Structure):
     _fields_ = [("dynamic_exposure", C.c_float)]
 
@@ -261,6 +268,9 @@ def load_library() -> C.CDLL:
         "gr_bloom_down_mid": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(PushBloomDownsample), P(PushBloomDownsample), P(Rows)]),
         "gr_bloom_down_head_supported": (C.c_int, [P(Image), P(Image), P(Image), P(Image), P(PushBloomThreshold), P(PushBloomDownsample), P(PushBloomDownsample)]),
         "gr_bloom_down_head": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), vp, P(PushBloomThreshold), P(PushBloomDownsample), P(PushBloomDownsample)]),
+        "gr_bloom_pyramid_supported": (C.c_int, [P(BloomPyramidArgs)]),
+        "gr_bloom_pyramid": (C.c_int, [vp, vp, P(BloomPyramidArgs)]),
+        "gr_debug_pyramid_giveups": (C.c_int, [vp, P(C.c_uint32)]),
         "gr_bloom_up_all_supported": (C.c_int, [P(Image), P(Image), P(Image), P(Image), P(PushBloomUpsample), P(PushBloomUpsample), P(PushBloomUpsample)]),
         "gr_bloom_up_all": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), vp, P(PushBloomUpsample), P(PushBloomUpsample), P(PushBloomUpsample),
                                       P(PushLuminance)]),
@@ -496,6 +506,37 @@ class Context:
         p_lum = PushLuminance((d3.width // 2, d3.height // 2), lum_lerp, -3.0, 2.0) if lum_ptr is not None else None
         self.check(self.lib.gr_bloom_up_all(self.handle, stream, d3.desc, u2.desc, u1.desc, u0.desc, lum_ptr, p_u2, p_u1, p_u0, p_lum))
         return True
+
+    def bloom_pyramid(self, hdr: DeviceImage, levels: dict, history: DeviceImage, feedback_lerp: float, lum_ptr=None, lum_lerp: float = 0.0, stream=None,
+                      any_size: bool = False) -> bool:
+        """The whole bloom pass as ONE launch (levels: threshold, d0..d3, u2..u0 by name); False (nothing launched) when the frame does not qualify.
+        any_size: launch without asking gr_bloom_pyramid_supported (which offers the launch up to 640 x 384 frames; the launcher checks the rest itself)."""
+        def down(out, src, lerp=0.0):
+            return PushBloomDownsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height), (1.0 / src.width, 1.0 / src.height), lerp)
+
+        def up(out, src):
+            return PushBloomUpsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height), (1.0 / src.width, 1.0 / src.height))
+        l = levels
+        a = BloomPyramidArgs()
+        a.hdr, a.history = hdr.desc, history.desc
+        for name in ("threshold", "d0", "d1", "d2", "d3", "u2", "u1", "u0"):
+            setattr(a, name, l[name].desc)
+        a.lum = lum_ptr
+        a.push_threshold = PushBloomThreshold((l["threshold"].width, l["threshold"].height), (1.0 / l["threshold"].width, 1.0 / l["threshold"].height))
+        a.push_d0, a.push_d1 = down(l["d0"], l["threshold"]), down(l["d1"], l["d0"])
+        a.push_d2, a.push_d3 = down(l["d2"], l["d1"], feedback_lerp), down(l["d3"], l["d2"], feedback_lerp)
+        a.push_u2, a.push_u1, a.push_u0 = up(l["u2"], l["d3"]), up(l["u1"], l["u2"]), up(l["u0"], l["u1"])
+        if lum_ptr is not None:
+            a.push_luminance = PushLuminance((l["d3"].width // 2, l["d3"].height // 2), lum_lerp, -3.0, 2.0)
+        if not any_size and not self.lib.gr_bloom_pyramid_supported(a):
+            return False
+        self.check(self.lib.gr_bloom_pyramid(self.handle, stream, a))
+        return True
+
+    def pyramid_giveups(self) -> int:
+        n = C.c_uint32(0)
+        self.check(self.lib.gr_debug_pyramid_giveups(self.handle, C.byref(n)))
+        return int(n.value)
 
     def bloom_down_head(self, hdr: DeviceImage, threshold: DeviceImage, d0: DeviceImage, d1: DeviceImage, lum_ptr=None, stream=None) -> bool:
         """threshold, downsample-0 and downsample-1 as one launch; False (nothing launched) when the frame does not qualify."""

@@ -211,6 +211,8 @@ gr_ctx *gr_create(int device)
 	    hipMemcpy(ctx->ssr_azimuth_lut, azimuth, sizeof(azimuth), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->tonemap_srgb8_lut), sizeof(tonemap_table)) != hipSuccess ||
 	    hipMemcpy(ctx->tonemap_srgb8_lut, tonemap_table, sizeof(tonemap_table), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMalloc(reinterpret_cast<void **>(&ctx->pyramid_sync), gr_ctx::PYRAMID_SYNC_SLOTS * 4 * sizeof(uint32_t)) != hipSuccess ||
+	    hipMemset(ctx->pyramid_sync, 0, gr_ctx::PYRAMID_SYNC_SLOTS * 4 * sizeof(uint32_t)) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->srgb_decode_lut), sizeof(lut)) != hipSuccess ||
 	    hipMemcpy(ctx->srgb_decode_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->srgb_encode_lut), sizeof(encode_table)) != hipSuccess ||
@@ -235,6 +237,8 @@ void gr_destroy(gr_ctx *ctx)
 	}
 	for (auto &e : ctx->event_pool)
 		(void)hipEventDestroy(e);
+	if (ctx->pyramid_sync)
+		(void)hipFree(ctx->pyramid_sync);
 	if (ctx->srgb_decode_lut)
 		(void)hipFree(ctx->srgb_decode_lut);
 	if (ctx->srgb_encode_lut)

@@ -36,6 +36,11 @@ struct gr_ctx
 	// evaluated once on the host: the traced directions then do not depend on the device's trigonometric approximations.
 	float2 *ssr_azimuth_lut = nullptr;
 
+	// gr_bloom_pyramid (post.hip): 64 x {phase counters 0..2, give-ups}, zero-initialised, one slot per launch in rotation.
+	static constexpr unsigned PYRAMID_SYNC_SLOTS = 64;
+	uint32_t *pyramid_sync = nullptr;
+	std::atomic<unsigned> pyramid_launches{0};
+
 	// The device the context sits on.
 	int compute_units = 0;
 	bool eight_xcd_partition = false;

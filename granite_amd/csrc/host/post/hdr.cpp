@@ -224,6 +224,50 @@ bool record_pyramid_head(HIP::CommandBuffer &cmd, const FrameParameters &frame, 
 	return true;
 }
 
+// Every dispatch of the pass (hdr.cpp:354-379) as ONE launch of the C ABI when the frame qualifies (gr_bloom_pyramid_supported: what the fused
+// head, tail and upsample launches require, up to a 640 x 384 frame); returns false otherwise and records nothing.  Whole images only.
+bool record_pyramid_whole(HIP::CommandBuffer &cmd, const FrameParameters &frame, RenderGraph &graph, const RenderTextureResource &hdr_res,
+                          const RenderTextureResource &t_res, const RenderTextureResource &d0_res, const RenderTextureResource &d1_res,
+                          const RenderTextureResource &d2_res, const RenderTextureResource &d3_res, const RenderTextureResource &u2_res,
+                          const RenderTextureResource &u1_res, const RenderTextureResource &u0_res, const RenderBufferResource *lum_res)
+{
+	HIP::ImageView *history = graph.get_physical_history_texture_resource(d3_res); // null on frame 0
+	if (!history)
+		return false;
+	auto &hdr = graph.get_physical_texture_resource(hdr_res);
+	auto &t = graph.get_physical_texture_resource(t_res);
+	auto &d0 = graph.get_physical_texture_resource(d0_res);
+	auto &d1 = graph.get_physical_texture_resource(d1_res);
+	auto &d2 = graph.get_physical_texture_resource(d2_res);
+	auto &d3 = graph.get_physical_texture_resource(d3_res);
+	auto &u2 = graph.get_physical_texture_resource(u2_res);
+	auto &u1 = graph.get_physical_texture_resource(u1_res);
+	auto &u0 = graph.get_physical_texture_resource(u0_res);
+	gr_bloom_pyramid_args a = {};
+	a.hdr = hdr.get_view(), a.threshold = t.get_view(), a.d0 = d0.get_view(), a.d1 = d1.get_view(), a.d2 = d2.get_view(), a.d3 = d3.get_view();
+	a.history = history->get_view(), a.u2 = u2.get_view(), a.u1 = u1.get_view(), a.u0 = u0.get_view();
+	a.push_threshold.threads[0] = t.get_width();
+	a.push_threshold.threads[1] = t.get_height();
+	a.push_threshold.inv_output_size[0] = 1.0f / float(a.push_threshold.threads[0]);
+	a.push_threshold.inv_output_size[1] = 1.0f / float(a.push_threshold.threads[1]);
+	a.push_d0 = downsample_push(frame, d0, t), a.push_d1 = downsample_push(frame, d1, d0);
+	a.push_d2 = downsample_push(frame, d2, d1), a.push_d3 = downsample_push(frame, d3, d2);
+	a.push_u2 = upsample_push(u2, d3), a.push_u1 = upsample_push(u1, u2), a.push_u0 = upsample_push(u0, u1);
+	if (lum_res)
+	{
+		a.lum = static_cast<gr_luminance_data *>(graph.get_physical_buffer_resource(*lum_res).get_device_pointer());
+		a.push_luminance.size[0] = d3.get_width() / 2;
+		a.push_luminance.size[1] = d3.get_height() / 2;
+		a.push_luminance.lerp = float(1.0 - std::pow(0.5, frame.frame_time));
+		a.push_luminance.min_loglum = -3.0f;
+		a.push_luminance.max_loglum = 2.0f;
+	}
+	if (!gr_bloom_pyramid_supported(&a))
+		return false;
+	cmd.check(gr_bloom_pyramid(cmd.get_context(), cmd.get_stream(), &a), "bloom_pyramid");
+	return true;
+}
+
 // tonemap_build_render_pass (hdr.cpp:283-306)
 void record_tonemap(RenderPass &pass, HIP::CommandBuffer &cmd, const RenderTextureResource &hdr_res, const RenderTextureResource &bloom_res,
                     const RenderBufferResource *ubo, const HDRDynamicExposureInterface *iface, const StripPlan *strip = nullptr)
@@ -300,6 +344,8 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 				cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
 				            VK_ACCESS_2_SHADER_SAMPLED_READ_BIT);
 			};
+			if (!strip && record_pyramid_whole(cmd, frame, graph, hdr, t, d0, d1, d2, d3, u2, u1, u0, ubo))
+				return;
 			if (strip || !record_pyramid_head(cmd, frame, graph, hdr, t, d0, d1, ubo))
 			{
 				record_threshold(cmd, graph, t, hdr, ubo, strip ? &strip->threshold : nullptr);
@@ -349,7 +395,7 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 		key.add(ubo ? graph.get_physical_buffer_resource(*ubo).get_device_pointer() : nullptr);
 		key.add(frame.frame_time);
 		cmd.replayable("bloom-compute", key,
-		               {"bloom_threshold", "bloom_downsample", "bloom_down_head", "bloom_down_mid", "bloom_down_tail", "bloom_up_tail", "bloom_up_all", "luminance", "bloom_upsample"}, record);
+		               {"bloom_threshold", "bloom_downsample", "bloom_down_head", "bloom_down_mid", "bloom_down_tail", "bloom_up_tail", "bloom_up_all", "bloom_pyramid", "luminance", "bloom_upsample"}, record);
 	});
 
 	{

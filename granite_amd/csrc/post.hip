@@ -384,22 +384,29 @@ __global__ __launch_bounds__(POST_BLOCK_X *POST_BLOCK_Y) POST_VGPR_BUDGET void k
 // Summation order is fixed (deterministic across runs and ranks) but differs from the reference's tree: covered by the
 // stated fp32 tolerance on LuminanceData.
 constexpr int LUM_THREADS = 1024;
-// Called by all LUM_THREADS threads of a workgroup (thread = 0 .. LUM_THREADS - 1); wave_partial: LUM_THREADS / 64 floats of LDS.
+// Called by all NT threads of a workgroup (thread = 0 .. NT - 1); wave_partial: LUM_THREADS / 64 floats of LDS.  NT < LUM_THREADS: every thread
+// takes LUM_THREADS / NT of the 1024 strided sums, wave by wave -- the same additions in the same order, so the result does not depend on NT.
+template <int NT = LUM_THREADS>
 __device__ __forceinline__ void luminance_block(const DevImage &in, gr_luminance_data *lum, const gr_push_luminance &push, int thread,
                                                 float *wave_partial)
 {
+	static_assert(LUM_THREADS % NT == 0 && NT % 64 == 0, "whole waves of the 1024-thread order per pass");
 	const int sx = int(push.size[0]), sy = int(push.size[1]);
 	const float inv_x = 1.0f / float(sx), inv_y = 1.0f / float(sy);
 	const int total = sx * sy;
-	float sum = 0.0f;
-	for (int i = thread; i < total; i += LUM_THREADS)
+#pragma unroll 1
+	for (int first = 0; first < LUM_THREADS; first += NT)
 	{
-		const int py = i / sx, px = i - py * sx;
-		sum += sample_linear_rgba16f(in, (float(px) + 0.5f) * inv_x, (float(py) + 0.5f) * inv_y).w;
+		float sum = 0.0f;
+		for (int i = first + thread; i < total; i += LUM_THREADS)
+		{
+			const int py = i / sx, px = i - py * sx;
+			sum += sample_linear_rgba16f(in, (float(px) + 0.5f) * inv_x, (float(py) + 0.5f) * inv_y).w;
+		}
+		sum = wave_sum(sum);
+		if ((thread & 63) == 0)
+			wave_partial[(first + thread) >> 6] = sum;
 	}
-	sum = wave_sum(sum);
-	if ((thread & 63) == 0)
-		wave_partial[thread >> 6] = sum;
 	__syncthreads();
 	if (thread == 0)
 	{
@@ -477,14 +484,13 @@ __device__ __forceinline__ float4 downsample_2to1_from_patch(const TailPatch &pa
 // Two consecutive downsample levels in one launch: `lower` (level B, rows [y_first, y_end)) from `upper` (level A), which the
 // workgroup first makes from `src` -- and stores -- under its tile's taps.  Instantiated for downsample-0 / downsample-1 (from the
 // threshold level; row bands restrict level B) and for downsample-2 / downsample-3 (+ the temporal feedback).
-template <bool A_EXACT, bool B_EXACT, bool FEEDBACK>
-__global__ __launch_bounds__(256) void k_bloom_down_pair(DevImage src, DevImageRW upper, DevImageRW lower, DevImage history,
-                                                         gr_push_bloom_downsample push_a, gr_push_bloom_downsample push_b, uint32_t y_first,
-                                                         uint32_t y_end)
+// (the work of one workgroup of NT threads on tile (bx, by), s_patch: TAIL_PATCH^2 texels of LDS: the kernel below, and a phase of k_bloom_pyramid)
+template <bool A_EXACT, bool B_EXACT, bool FEEDBACK, int NT>
+__device__ __forceinline__ void down_pair_block(const int bx, const int by, const int thread, f16x4 *s_patch, const DevImage &src, const DevImageRW &upper,
+                                                const DevImageRW &lower, const DevImage &history, const gr_push_bloom_downsample &push_a,
+                                                const gr_push_bloom_downsample &push_b, uint32_t y_first, uint32_t y_end)
 {
-	post_wave_priority();
-	__shared__ f16x4 s_patch[TAIL_PATCH * TAIL_PATCH];
-	const int tile_x0 = blockIdx.x * TAIL_TILE, tile_y0 = int(y_first) + blockIdx.y * TAIL_TILE;
+	const int tile_x0 = bx * TAIL_TILE, tile_y0 = int(y_first) + by * TAIL_TILE;
 	const int tile_x1 = min(tile_x0 + TAIL_TILE, lower.w) - 1, tile_y1 = min(tile_y0 + TAIL_TILE, int(y_end)) - 1;
 	int px0, px1, py0, py1;
 	if (B_EXACT)
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(256) void k_bloom_down_pair(DevImage src, DevImageR
 	}
 	const int pw = px1 - px0 + 1, ph = py1 - py0 + 1; // <= TAIL_PATCH (checked by the launcher)
 	const int upper_w = upper.w, upper_h = upper.h;
-	for (int i = threadIdx.x; i < pw * ph; i += 256)
+	for (int i = thread; i < pw * ph; i += NT)
 	{
 		const int ly = i / pw, lx = i - ly * pw;
 		// level A exactly half of its input: the 2:1 stencil; else the nine taps of the generic kernel (odd level sizes: 1080p)
@@ -509,9 +515,9 @@ __global__ __launch_bounds__(256) void k_bloom_down_pair(DevImage src, DevImageR
 		*reinterpret_cast<f16x4 *>(upper.ptr + size_t(py0 + ly) * upper.pitch + size_t(px0 + lx) * 8u) = texel;
 	}
 	__syncthreads();
-	if (threadIdx.x >= TAIL_TILE * TAIL_TILE)
+	if (thread >= TAIL_TILE * TAIL_TILE)
 		return;
-	const int x = tile_x0 + int(threadIdx.x & (TAIL_TILE - 1)), y = tile_y0 + int(threadIdx.x / TAIL_TILE);
+	const int x = tile_x0 + int(thread & (TAIL_TILE - 1)), y = tile_y0 + int(thread / TAIL_TILE);
 	if (x >= lower.w || y > tile_y1)
 		return;
 	const TailPatch patch{s_patch, px0, py0, pw, ph};
@@ -531,6 +537,16 @@ __global__ __launch_bounds__(256) void k_bloom_down_pair(DevImage src, DevImageR
 	store_rgba16f(lower, x, y, value);
 }
 
+template <bool A_EXACT, bool B_EXACT, bool FEEDBACK>
+__global__ __launch_bounds__(256) void k_bloom_down_pair(DevImage src, DevImageRW upper, DevImageRW lower, DevImage history,
+                                                         gr_push_bloom_downsample push_a, gr_push_bloom_downsample push_b, uint32_t y_first,
+                                                         uint32_t y_end)
+{
+	post_wave_priority();
+	__shared__ f16x4 s_patch[TAIL_PATCH * TAIL_PATCH];
+	down_pair_block<A_EXACT, B_EXACT, FEEDBACK, 256>(int(blockIdx.x), int(blockIdx.y), int(threadIdx.x), s_patch, src, upper, lower, history, push_a, push_b, y_first, y_end);
+}
+
 // The head of the pyramid in one launch: threshold -> downsample-0 -> downsample-1, for frames whose chain of launches, not their
 // arithmetic, sets the pace (up to 1440p: gr_bloom_down_head_supported) and whose three levels are exactly half of their inputs.  A
 // workgroup makes an 8 x 8 tile of downsample-1; under it the <= 20 x 20 patch of downsample-0, under that the <= 44 x 44 patch of
@@ -540,14 +556,12 @@ __global__ __launch_bounds__(256) void k_bloom_down_pair(DevImage src, DevImageR
 // gr_bloom_threshold + gr_bloom_down_mid.
 constexpr int HEAD_D0_PATCH = 2 * TAIL_TILE + 4;       // 20
 constexpr int HEAD_T_PATCH = 2 * HEAD_D0_PATCH + 4;    // 44
-template <bool DYNAMIC_EXPOSURE>
-__global__ __launch_bounds__(256) void k_bloom_down_head(DevImage hdr, DevImageRW thr, DevImageRW d0, DevImageRW d1, const gr_luminance_data *lum,
-                                                         float inv_thr_w, float inv_thr_h, bool hdr_b10)
+template <bool DYNAMIC_EXPOSURE, int NT>
+__device__ __forceinline__ void down_head_block(const int bx, const int by, const int thread, f16x4 *s_thr, f16x4 *s_d0, const DevImage &hdr,
+                                                const DevImageRW &thr, const DevImageRW &d0, const DevImageRW &d1, const gr_luminance_data *lum,
+                                                float inv_thr_w, float inv_thr_h, bool hdr_b10)
 {
-	post_wave_priority();
-	__shared__ f16x4 s_thr[HEAD_T_PATCH * HEAD_T_PATCH];
-	__shared__ f16x4 s_d0[HEAD_D0_PATCH * HEAD_D0_PATCH];
-	const int tile_x0 = blockIdx.x * TAIL_TILE, tile_y0 = blockIdx.y * TAIL_TILE;
+	const int tile_x0 = bx * TAIL_TILE, tile_y0 = by * TAIL_TILE;
 	const int tile_x1 = min(tile_x0 + TAIL_TILE, d1.w) - 1, tile_y1 = min(tile_y0 + TAIL_TILE, d1.h) - 1;
 	const int px0 = clampi(2 * tile_x0 - 2, 0, d0.w - 1), px1 = clampi(2 * tile_x1 + 3, 0, d0.w - 1);
 	const int py0 = clampi(2 * tile_y0 - 2, 0, d0.h - 1), py1 = clampi(2 * tile_y1 + 3, 0, d0.h - 1);
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(256) void k_bloom_down_head(DevImage hdr, DevImageR
 	const int qy0 = clampi(2 * py0 - 2, 0, thr.h - 1), qy1 = clampi(2 * py1 + 3, 0, thr.h - 1);
 	const int pw = px1 - px0 + 1, ph = py1 - py0 + 1, qw = qx1 - qx0 + 1, qh = qy1 - qy0 + 1;
 	const float threshold = DYNAMIC_EXPOSURE ? __fmul_rn(8.0f, lum->average_linear_luminance) : 8.0f;
-	for (int i = threadIdx.x; i < qw * qh; i += 256)
+	for (int i = thread; i < qw * qh; i += NT)
 	{
 		const int ly = i / qw, lx = i - ly * qw;
 		const uint32_t x = uint32_t(qx0 + lx), y = uint32_t(qy0 + ly);
@@ -577,7 +591,7 @@ __global__ __launch_bounds__(256) void k_bloom_down_head(DevImage hdr, DevImageR
 	}
 	__syncthreads();
 	const TailPatch thr_patch{s_thr, qx0, qy0, qw, qh};
-	for (int i = threadIdx.x; i < pw * ph; i += 256)
+	for (int i = thread; i < pw * ph; i += NT)
 	{
 		const int ly = i / pw, lx = i - ly * pw;
 		const f16x4 texel = pack_rgba16f(downsample_2to1_from_patch(thr_patch, px0 + lx, py0 + ly, thr.w, thr.h));
@@ -585,13 +599,23 @@ __global__ __launch_bounds__(256) void k_bloom_down_head(DevImage hdr, DevImageR
 		*reinterpret_cast<f16x4 *>(d0.ptr + size_t(py0 + ly) * d0.pitch + size_t(px0 + lx) * 8u) = texel;
 	}
 	__syncthreads();
-	if (threadIdx.x >= TAIL_TILE * TAIL_TILE)
+	if (thread >= TAIL_TILE * TAIL_TILE)
 		return;
-	const int x = tile_x0 + int(threadIdx.x & (TAIL_TILE - 1)), y = tile_y0 + int(threadIdx.x / TAIL_TILE);
+	const int x = tile_x0 + int(thread & (TAIL_TILE - 1)), y = tile_y0 + int(thread / TAIL_TILE);
 	if (x >= d1.w || y > tile_y1)
 		return;
 	const TailPatch d0_patch{s_d0, px0, py0, pw, ph};
 	store_rgba16f(d1, x, y, downsample_2to1_from_patch(d0_patch, x, y, d0.w, d0.h));
+}
+
+template <bool DYNAMIC_EXPOSURE>
+__global__ __launch_bounds__(256) void k_bloom_down_head(DevImage hdr, DevImageRW thr, DevImageRW d0, DevImageRW d1, const gr_luminance_data *lum,
+                                                         float inv_thr_w, float inv_thr_h, bool hdr_b10)
+{
+	post_wave_priority();
+	__shared__ f16x4 s_thr[HEAD_T_PATCH * HEAD_T_PATCH];
+	__shared__ f16x4 s_d0[HEAD_D0_PATCH * HEAD_D0_PATCH];
+	down_head_block<DYNAMIC_EXPOSURE, 256>(int(blockIdx.x), int(blockIdx.y), int(threadIdx.x), s_thr, s_d0, hdr, thr, d0, d1, lum, inv_thr_w, inv_thr_h, hdr_b10);
 }
 
 // A 256-thread form (16 x 16 tiles, one wave per SIMD: finds room on a CU beside the resident lighting waves, where a 1024-thread
@@ -681,17 +705,12 @@ constexpr int UPALL_TILE = 32;               // one output per thread.  (64-wide
                                              // config 2 0.063 against 0.058 ms -- these launches are latency, not arithmetic; profiles/r04_host_lead_ab.txt)
 constexpr int UPALL_P1 = UPALL_TILE / 2 + 4; // 20
 constexpr int UPALL_P2 = 18;                 // 1:2 stencil: P1 / 2 + 4 = 14; generic taps: (P1 - 0.5) * 0.514 + 6.75 < 17
-template <bool U2_EXACT, bool U1_EXACT, bool LUMINANCE>
-__global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_all(DevImage d3, DevImageRW u2, DevImageRW u1, DevImageRW u0, gr_luminance_data *lum,
-                                                                              gr_push_bloom_upsample push2, gr_push_bloom_upsample push1,
-                                                                              gr_push_luminance push_lum)
+template <bool U2_EXACT, bool U1_EXACT, bool LUMINANCE, int NT>
+__device__ __forceinline__ void up_all_block(const int bx, const int by, const int thread, f16x4 *s_p2, f16x4 *s_p1, float *wave_partial, const DevImage &d3,
+                                             const DevImageRW &u2, const DevImageRW &u1, const DevImageRW &u0, gr_luminance_data *lum,
+                                             const gr_push_bloom_upsample &push2, const gr_push_bloom_upsample &push1, const gr_push_luminance &push_lum)
 {
-	post_wave_priority();
-	__shared__ f16x4 s_p2[UPALL_P2 * UPALL_P2];
-	__shared__ f16x4 s_p1[UPALL_P1 * UPALL_P1];
-	__shared__ float wave_partial[LUM_THREADS / 64];
-	const int thread = int(threadIdx.x);
-	const int tile_x0 = blockIdx.x * UPALL_TILE, tile_y0 = blockIdx.y * UPALL_TILE;
+	const int tile_x0 = bx * UPALL_TILE, tile_y0 = by * UPALL_TILE;
 	const int tile_x1 = min(tile_x0 + UPALL_TILE, u0.w) - 1, tile_y1 = min(tile_y0 + UPALL_TILE, u0.h) - 1;
 	// upsample-1 under the tile (1:2 stencil: k - 2 .. k + 2 for k = x / 2), upsample-2 under that
 	const int ax0 = clampi((tile_x0 >> 1) - 2, 0, u1.w - 1), ax1 = clampi((tile_x1 >> 1) + 2, 0, u1.w - 1);
@@ -708,7 +727,7 @@ __global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_all(D
 		tap_span(ay0, ay1, u1.h, u2.h, 0.875f, by0, by1);
 	}
 	const int aw = ax1 - ax0 + 1, ah = ay1 - ay0 + 1, bw = bx1 - bx0 + 1, bh = by1 - by0 + 1; // <= UPALL_P1, UPALL_P2 (the launcher checks the level sizes)
-	for (int i = thread; i < bw * bh; i += LUM_THREADS)
+	for (int i = thread; i < bw * bh; i += NT)
 	{
 		const int ly = i / bw, lx = i - ly * bw;
 		const int x = bx0 + lx, y = by0 + ly;
@@ -728,7 +747,7 @@ __global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_all(D
 		*reinterpret_cast<f16x4 *>(u2.ptr + size_t(y) * u2.pitch + size_t(x) * 8u) = texel16;
 	}
 	__syncthreads();
-	for (int i = thread; i < aw * ah; i += LUM_THREADS)
+	for (int i = thread; i < aw * ah; i += NT)
 	{
 		const int ly = i / aw, lx = i - ly * aw;
 		const int x = ax0 + lx, y = ay0 + ly;
@@ -754,7 +773,7 @@ __global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_all(D
 	}
 	__syncthreads();
 	const int tw = tile_x1 - tile_x0 + 1, th = tile_y1 - tile_y0 + 1;
-	for (int i = thread; i < UPALL_TILE * th; i += LUM_THREADS)
+	for (int i = thread; i < UPALL_TILE * th; i += NT)
 	{
 		const int ly = i / UPALL_TILE, lx = i - ly * UPALL_TILE;
 		if (lx >= tw)
@@ -763,8 +782,124 @@ __global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_all(D
 		const auto texel = [&](int tx, int ty) { return __builtin_bit_cast(u32x2, s_p1[(ty - ay0) * aw + (tx - ax0)]); };
 		store_rgba16f(u0, x, y, upsample_1to2_value(texel, u1.w, u1.h, x, y));
 	}
-	if (LUMINANCE && blockIdx.x == 0 && blockIdx.y == 0)
-		luminance_block(d3, lum, push_lum, thread, wave_partial);
+	if (LUMINANCE && bx == 0 && by == 0)
+		luminance_block<NT>(d3, lum, push_lum, thread, wave_partial);
+}
+
+template <bool U2_EXACT, bool U1_EXACT, bool LUMINANCE>
+__global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_all(DevImage d3, DevImageRW u2, DevImageRW u1, DevImageRW u0, gr_luminance_data *lum,
+                                                                              gr_push_bloom_upsample push2, gr_push_bloom_upsample push1,
+                                                                              gr_push_luminance push_lum)
+{
+	post_wave_priority();
+	__shared__ f16x4 s_p2[UPALL_P2 * UPALL_P2];
+	__shared__ f16x4 s_p1[UPALL_P1 * UPALL_P1];
+	__shared__ float wave_partial[LUM_THREADS / 64];
+	up_all_block<U2_EXACT, U1_EXACT, LUMINANCE, LUM_THREADS>(int(blockIdx.x), int(blockIdx.y), int(threadIdx.x), s_p2, s_p1, wave_partial, d3, u2, u1, u0, lum, push2,
+	                                                         push1, push_lum);
+}
+
+// ---- the whole pyramid in ONE launch (frames up to 640 x 384) ------------------------------------------------------------------------
+// For a small frame the bloom pass is a chain of launches, not arithmetic: each of down_head -> down_tail -> up_all pays a dispatch, a fill and a
+// drain of the machine for a few microseconds of work, and the host pays a runtime call for each.  k_bloom_pyramid is the three of them as three
+// block ranges ("phases") of one grid of 256-thread workgroups: [0, n0) the tiles of down_head_block, [n0, n0 + n1) those of down_pair_block
+// (downsample-2 / -3 + feedback), the rest those of up_all_block (+ the luminance reduction in its first workgroup, in the 1024-thread order).
+// A workgroup of phase k + 1 waits until ALL workgroups of phase k have published their level (one counter per phase: release add after the
+// workgroup's stores, acquire spin before its loads, agent scope).  Workgroups are dispatched in linear id order (per XCD: id mod 8) and a
+// workgroup only ever waits for lower ids, so the unfinished workgroup with the lowest id can always run: no co-residency requirement, other
+// kernels may share the machine.  (Two such launches overlapping on different streams could hold each other's slots; the executor issues them on
+// one in-order stream, and the spin is bounded: after PYRAMID_SPIN_LIMIT polls a workgroup gives up, counts itself in sync[3] and goes on --
+// gr_debug_pyramid_giveups reads the count, which every test of this launch checks to be zero.)
+// Values: every texel by the block functions the separate launches run => byte-identical levels (tests/test_gpu_post.py).
+constexpr uint32_t PYRAMID_SPIN_LIMIT = 1u << 22; // x ~0.1 us per poll
+struct PyramidArgs
+{
+	DevImage hdr, history;
+	DevImageRW thr, d0, d1, d2, d3, u2, u1, u0;
+	gr_luminance_data *lum;
+	float inv_thr_w, inv_thr_h;
+	gr_push_bloom_downsample push_d2, push_d3;
+	gr_push_bloom_upsample push_u2, push_u1;
+	gr_push_luminance push_lum;
+	uint32_t n0, n1, n2;      // workgroups per phase
+	uint32_t head_x, pair_x, up_x; // tiles per row of each phase
+	uint32_t *sync;           // {phase 0 done, phase 1 done, phase 2 done, give-ups}: zero between launches (the last workgroup clears 0..2)
+	bool hdr_b10;
+};
+
+__device__ __forceinline__ void pyramid_publish(uint32_t *counter)
+{
+	__syncthreads(); // every wave's stores have been issued and waited for (workgroup-scope release)
+	if (threadIdx.x == 0)
+		__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pyramid_wait(uint32_t *counter, uint32_t target, uint32_t *giveups)
+{
+	if (threadIdx.x == 0)
+	{
+		uint32_t polls = 0;
+		// relaxed polls (an acquire load invalidates the caches on every poll: with a hundred workgroups waiting that is a storm the other kernels
+		// on the machine pay for); the acquire is the one fence behind the barrier below
+		while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+		{
+			__builtin_amdgcn_s_sleep(8);
+			if (++polls == PYRAMID_SPIN_LIMIT)
+			{
+				__hip_atomic_fetch_add(giveups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				break;
+			}
+		}
+	}
+	__syncthreads();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // every wave's loads below see what the counter's release published
+}
+
+constexpr size_t PYRAMID_LDS_HEAD = sizeof(f16x4) * (HEAD_T_PATCH * HEAD_T_PATCH + HEAD_D0_PATCH * HEAD_D0_PATCH);
+constexpr size_t PYRAMID_LDS_UP = sizeof(f16x4) * (UPALL_P2 * UPALL_P2 + UPALL_P1 * UPALL_P1) + sizeof(float) * (LUM_THREADS / 64);
+constexpr size_t PYRAMID_LDS = PYRAMID_LDS_HEAD > PYRAMID_LDS_UP ? PYRAMID_LDS_HEAD : PYRAMID_LDS_UP;
+static_assert(PYRAMID_LDS >= sizeof(f16x4) * TAIL_PATCH * TAIL_PATCH, "the down_pair patch fits too");
+constexpr int PYRAMID_THREADS = 256;
+
+template <bool DYNAMIC_EXPOSURE, bool D2_EXACT, bool D3_EXACT, bool U2_EXACT, bool U1_EXACT>
+__global__ __launch_bounds__(PYRAMID_THREADS) void k_bloom_pyramid(PyramidArgs a)
+{
+	post_wave_priority();
+	__shared__ __attribute__((aligned(16))) uint8_t s_raw[PYRAMID_LDS];
+	const int thread = int(threadIdx.x);
+	const uint32_t block = blockIdx.x;
+	if (block < a.n0)
+	{
+		f16x4 *s_thr = reinterpret_cast<f16x4 *>(s_raw), *s_d0 = s_thr + HEAD_T_PATCH * HEAD_T_PATCH;
+		down_head_block<DYNAMIC_EXPOSURE, PYRAMID_THREADS>(int(block % a.head_x), int(block / a.head_x), thread, s_thr, s_d0, a.hdr, a.thr, a.d0, a.d1, a.lum,
+		                                                   a.inv_thr_w, a.inv_thr_h, a.hdr_b10);
+		pyramid_publish(a.sync + 0);
+	}
+	else if (block < a.n0 + a.n1)
+	{
+		const uint32_t tile = block - a.n0;
+		pyramid_wait(a.sync + 0, a.n0, a.sync + 3);
+		down_pair_block<D2_EXACT, D3_EXACT, true, PYRAMID_THREADS>(int(tile % a.pair_x), int(tile / a.pair_x), thread, reinterpret_cast<f16x4 *>(s_raw), DevImage{a.d1.ptr, a.d1.w, a.d1.h, a.d1.pitch},
+		                                                           a.d2, a.d3, a.history, a.push_d2, a.push_d3, 0u, uint32_t(a.d3.h));
+		pyramid_publish(a.sync + 1);
+	}
+	else
+	{
+		const uint32_t tile = block - a.n0 - a.n1;
+		pyramid_wait(a.sync + 1, a.n1, a.sync + 3);
+		f16x4 *s_p2 = reinterpret_cast<f16x4 *>(s_raw), *s_p1 = s_p2 + UPALL_P2 * UPALL_P2;
+		float *wave_partial = reinterpret_cast<float *>(s_p1 + UPALL_P1 * UPALL_P1);
+		up_all_block<U2_EXACT, U1_EXACT, DYNAMIC_EXPOSURE, PYRAMID_THREADS>(int(tile % a.up_x), int(tile / a.up_x), thread, s_p2, s_p1, wave_partial,
+		                                                                     DevImage{a.d3.ptr, a.d3.w, a.d3.h, a.d3.pitch}, a.u2, a.u1, a.u0, a.lum, a.push_u2, a.push_u1,
+		                                                                     a.push_lum);
+		// the last workgroup of the launch leaves the counters at zero for the next one
+		__syncthreads();
+		if (thread == 0 && __hip_atomic_fetch_add(a.sync + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == a.n2 - 1u)
+		{
+			__hip_atomic_store(a.sync + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(a.sync + 2, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
 }
 
 // ---- tonemap (tonemap.frag:30-66) -----------------------------------------------------------------------------------
@@ -838,7 +973,7 @@ __device__ __forceinline__ uint32_t tonemap_srgb8_staged(float x, const uint2 *t
 template <bool DYNAMIC_EXPOSURE, bool SRGB, bool QUARTER_BLOOM>
 __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(DevImage hdr, DevImage bloom, DevImageRW out,
                                                                               const gr_luminance_data *lum, const uint2 *encode_lut,
-                                                                              gr_push_tonemap push, uint32_t y_first, uint32_t y_end, bool hdr_b10)
+                                                                              gr_push_tonemap push, uint32_t y_first, uint32_t y_end, bool hdr_b10, int row_groups)
 {
 	post_wave_priority();
 	// *_SRGB output: the curve and the store's encode are one table lookup per channel (tonemap_srgb8_staged), staged in LDS.
@@ -861,11 +996,11 @@ __global__ __launch_bounds__(TONEMAP_BLOCK_X *TONEMAP_BLOCK_Y) void k_tonemap(De
 	const float inv_w = 1.0f / float(hdr.w), inv_h = 1.0f / float(hdr.h);
 
 #pragma unroll 1
-	for (int group = 0; group < TONEMAP_ROW_GROUPS; group++)
+	for (int group = 0; group < row_groups; group++)
 	{
 		// a wave is one row of the block: the row's base addresses are scalars, the lane adds a 32-bit offset
 		static_assert(TONEMAP_BLOCK_X == 64, "threadIdx.y is wave-uniform");
-		const int y = __builtin_amdgcn_readfirstlane(int(y_first) + (blockIdx.y * TONEMAP_ROW_GROUPS + group) * TONEMAP_BLOCK_Y + int(threadIdx.y));
+		const int y = __builtin_amdgcn_readfirstlane(int(y_first) + (blockIdx.y * row_groups + group) * TONEMAP_BLOCK_Y + int(threadIdx.y));
 		if (uint32_t(y) >= y_end)
 			return;
 		const float v = (float(y) + 0.5f) * inv_h;
@@ -1403,6 +1538,111 @@ int gr_bloom_up_all(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_
 	return GR_OK;
 }
 
+int gr_bloom_pyramid_supported(const gr_bloom_pyramid_args *a)
+{
+	static const bool allow_fusion = gr_measurement_switch("GR_NO_PYRAMID_FUSION") == nullptr; // A/B switch for measurements
+	if (!allow_fusion || !a || !a->history.ptr)
+		return 0;
+	if (!gr_bloom_down_head_supported(&a->hdr, &a->threshold, &a->d0, &a->d1, &a->push_threshold, &a->push_d0, &a->push_d1) ||
+	    !gr_bloom_tail_supported(&a->d1, &a->d2, &a->d3, &a->u2, &a->u1, &a->push_d2, &a->push_d3, &a->push_u2, &a->push_u1) ||
+	    !gr_bloom_up_all_supported(&a->d3, &a->u2, &a->u1, &a->u0, &a->push_u2, &a->push_u1, &a->push_u0))
+		return 0;
+	if (!is_rgba16f(&a->history) || a->history.width != a->d3.width || a->history.height != a->d3.height || a->history.ptr == a->d3.ptr)
+		return 0;
+	if (a->lum && (a->push_luminance.size[0] == 0 || a->push_luminance.size[1] == 0))
+		return 0;
+	// Up to a 640 x 384 frame.  A hand-over between two phases costs what agent-scope release / acquire cost on eight XCDs with an L2 each (an L2
+	// write-back per publishing workgroup, an invalidate per waiting one): measured 22 us for the 21 workgroups of a 256 x 256 frame against 8.7 +
+	// 6.5 + 5.5 us for the three launches inside their hipEvent brackets (the frame: 0.0376 against 0.047-0.052 ms, the host being what the three
+	// launches wait for), but 67 us for the 685 workgroups of a 1080p frame against 14 + 10 + 8, with the other streams' kernels slowed by the
+	// cache traffic (profiles/r06_pyramid_one_launch.txt).  (GR_PYRAMID_ANY_SIZE: wherever the three launches are offered.)
+	static const bool any_size = gr_measurement_switch("GR_PYRAMID_ANY_SIZE") != nullptr;
+	return any_size || uint64_t(a->hdr.width) * a->hdr.height <= 640ull * 384ull;
+}
+
+int gr_bloom_pyramid(gr_ctx *ctx, gr_stream stream, const gr_bloom_pyramid_args *a)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, a != nullptr);
+	// what the three launches this one stands for check (gr_bloom_down_head, gr_bloom_down_tail, gr_bloom_up_all)
+	GR_CHECK_ARG(ctx, is_hdr_target(&a->hdr) && is_rgba16f(&a->threshold) && is_rgba16f(&a->d0) && is_rgba16f(&a->d1) && is_rgba16f(&a->d2) && is_rgba16f(&a->d3) &&
+	                      is_rgba16f(&a->u2) && is_rgba16f(&a->u1) && is_rgba16f(&a->u0) && is_rgba16f(&a->history));
+	GR_CHECK_ARG(ctx, a->hdr.width == 2u * a->threshold.width && a->hdr.height == 2u * a->threshold.height && a->threshold.width == 2u * a->d0.width &&
+	                      a->threshold.height == 2u * a->d0.height && a->d0.width == 2u * a->d1.width && a->d0.height == 2u * a->d1.height);
+	GR_CHECK_ARG(ctx, a->push_threshold.threads[0] == a->threshold.width && a->push_threshold.threads[1] == a->threshold.height &&
+	                      downsample_is_exact(&a->threshold, &a->push_d0) && downsample_is_exact(&a->d0, &a->push_d1) && a->push_d0.threads[0] == a->d0.width &&
+	                      a->push_d1.threads[0] == a->d1.width);
+	GR_CHECK_ARG(ctx, (a->hdr.pitch_bytes & 15u) == 0 && (reinterpret_cast<uintptr_t>(a->hdr.ptr) & 15u) == 0);
+	GR_CHECK_ARG(ctx, a->push_d2.threads[0] == a->d2.width && a->push_d2.threads[1] == a->d2.height && a->push_d3.threads[0] == a->d3.width &&
+	                      a->push_d3.threads[1] == a->d3.height);
+	GR_CHECK_ARG(ctx, float(a->d2.width) <= 2.3f * float(a->d3.width) && float(a->d2.height) <= 2.3f * float(a->d3.height));
+	GR_CHECK_ARG(ctx, a->history.ptr != a->d3.ptr && a->history.width == a->d3.width && a->history.height == a->d3.height);
+	GR_CHECK_ARG(ctx, a->push_u0.threads[0] == a->u0.width && a->push_u0.threads[1] == a->u0.height && upsample_is_exact(&a->u1, &a->push_u0));
+	GR_CHECK_ARG(ctx, a->push_u1.threads[0] == a->u1.width && a->push_u1.threads[1] == a->u1.height && a->push_u2.threads[0] == a->u2.width &&
+	                      a->push_u2.threads[1] == a->u2.height && a->u2.width == a->d2.width && a->u2.height == a->d2.height);
+	GR_CHECK_ARG(ctx, a->u1.width <= 2 * a->u2.width && a->u1.height <= 2 * a->u2.height && 2 * a->u2.width <= a->u1.width + 1 &&
+	                      2 * a->u2.height <= a->u1.height + 1);
+	{
+		const void *levels[] = {a->hdr.ptr, a->threshold.ptr, a->d0.ptr, a->d1.ptr, a->d2.ptr, a->d3.ptr, a->u2.ptr, a->u1.ptr, a->u0.ptr, a->history.ptr};
+		for (size_t i = 0; i < sizeof(levels) / sizeof(levels[0]); i++)
+			for (size_t j = i + 1; j < sizeof(levels) / sizeof(levels[0]); j++)
+				GR_CHECK_ARG(ctx, levels[i] != levels[j]);
+	}
+	GR_CHECK_ARG(ctx, !a->lum || (a->push_luminance.size[0] != 0 && a->push_luminance.size[1] != 0));
+	if (a->d3.width == 0 || a->d3.height == 0)
+		return GR_OK;
+	PyramidArgs k{};
+	k.hdr = to_dev(&a->hdr), k.history = to_dev(&a->history);
+	k.thr = to_dev_rw(&a->threshold), k.d0 = to_dev_rw(&a->d0), k.d1 = to_dev_rw(&a->d1), k.d2 = to_dev_rw(&a->d2), k.d3 = to_dev_rw(&a->d3);
+	k.u2 = to_dev_rw(&a->u2), k.u1 = to_dev_rw(&a->u1), k.u0 = to_dev_rw(&a->u0);
+	k.lum = a->lum;
+	k.inv_thr_w = a->push_threshold.inv_output_size[0], k.inv_thr_h = a->push_threshold.inv_output_size[1];
+	k.push_d2 = a->push_d2, k.push_d3 = a->push_d3, k.push_u2 = a->push_u2, k.push_u1 = a->push_u1;
+	if (a->lum)
+		k.push_lum = a->push_luminance;
+	k.head_x = gr_div_up(a->d1.width, TAIL_TILE), k.pair_x = gr_div_up(a->d3.width, TAIL_TILE), k.up_x = gr_div_up(a->u0.width, UPALL_TILE);
+	k.n0 = k.head_x * gr_div_up(a->d1.height, TAIL_TILE);
+	k.n1 = k.pair_x * gr_div_up(a->d3.height, TAIL_TILE);
+	k.n2 = k.up_x * gr_div_up(a->u0.height, UPALL_TILE);
+	k.sync = ctx->pyramid_sync + 4u * (ctx->pyramid_launches.fetch_add(1u) % gr_ctx::PYRAMID_SYNC_SLOTS);
+	k.hdr_b10 = a->hdr.format == GR_FORMAT_B10G11R11_UFLOAT_PACK32;
+	const dim3 grid(k.n0 + k.n1 + k.n2);
+	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_pyramid"};
+	const bool d2e = downsample_is_exact(&a->d1, &a->push_d2), d3e = downsample_is_exact(&a->d2, &a->push_d3);
+	const bool u2e = upsample_is_exact(&a->d3, &a->push_u2), u1e = upsample_is_exact(&a->u2, &a->push_u1);
+	const unsigned variant = (a->lum ? 16u : 0u) | (d2e ? 8u : 0u) | (d3e ? 4u : 0u) | (u2e ? 2u : 0u) | (u1e ? 1u : 0u);
+	switch (variant)
+	{
+#define GR_PYRAMID_CASE(V)                                                                                                                     \
+	case V:                                                                                                                                    \
+		hipLaunchKernelGGL((k_bloom_pyramid<((V) & 16) != 0, ((V) & 8) != 0, ((V) & 4) != 0, ((V) & 2) != 0, ((V) & 1) != 0>), grid, dim3(PYRAMID_THREADS), 0, \
+		                   gr_to_stream(stream), k);                                                                                           \
+		break;
+		GR_PYRAMID_CASE(0) GR_PYRAMID_CASE(1) GR_PYRAMID_CASE(2) GR_PYRAMID_CASE(3) GR_PYRAMID_CASE(4) GR_PYRAMID_CASE(5) GR_PYRAMID_CASE(6) GR_PYRAMID_CASE(7)
+		GR_PYRAMID_CASE(8) GR_PYRAMID_CASE(9) GR_PYRAMID_CASE(10) GR_PYRAMID_CASE(11) GR_PYRAMID_CASE(12) GR_PYRAMID_CASE(13) GR_PYRAMID_CASE(14) GR_PYRAMID_CASE(15)
+		GR_PYRAMID_CASE(16) GR_PYRAMID_CASE(17) GR_PYRAMID_CASE(18) GR_PYRAMID_CASE(19) GR_PYRAMID_CASE(20) GR_PYRAMID_CASE(21) GR_PYRAMID_CASE(22) GR_PYRAMID_CASE(23)
+		GR_PYRAMID_CASE(24) GR_PYRAMID_CASE(25) GR_PYRAMID_CASE(26) GR_PYRAMID_CASE(27) GR_PYRAMID_CASE(28) GR_PYRAMID_CASE(29) GR_PYRAMID_CASE(30) GR_PYRAMID_CASE(31)
+#undef GR_PYRAMID_CASE
+	}
+	GR_CHECK_LAUNCH(ctx);
+	return GR_OK;
+}
+
+int gr_debug_pyramid_giveups(gr_ctx *ctx, uint32_t *count)
+{
+	if (!ctx)
+		return GR_ERR_INVALID_ARGUMENT;
+	GR_CHECK_ARG(ctx, count != nullptr);
+	uint32_t slots[gr_ctx::PYRAMID_SYNC_SLOTS * 4];
+	GR_CHECK_HIP(ctx, hipDeviceSynchronize());
+	GR_CHECK_HIP(ctx, hipMemcpy(slots, ctx->pyramid_sync, sizeof(slots), hipMemcpyDeviceToHost));
+	*count = 0;
+	for (unsigned i = 0; i < gr_ctx::PYRAMID_SYNC_SLOTS; i++)
+		*count += slots[4 * i + 3];
+	return GR_OK;
+}
+
 int gr_luminance(gr_ctx *ctx, gr_stream stream, const gr_image *in, gr_luminance_data *lum, const gr_push_luminance *push)
 {
 	if (!ctx)
@@ -1438,13 +1678,17 @@ int gr_tonemap_rows(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr
 	if (span.count() == 0)
 		return GR_OK;
 	dim3 block(TONEMAP_BLOCK_X, TONEMAP_BLOCK_Y);
-	dim3 grid(gr_div_up(hdr->width, TONEMAP_BLOCK_X * TONEMAP_PX), gr_div_up(span.count(), TONEMAP_BLOCK_Y * TONEMAP_ROW_GROUPS));
+	// A workgroup walks TONEMAP_ROW_GROUPS x 4 rows per staging of the table -- except for a frame so small that this leaves fewer than 64
+	// workgroups (256 x 256: eight, each walking its rows one after the other on one CU): there a workgroup takes four rows.
+	const unsigned columns = gr_div_up(hdr->width, TONEMAP_BLOCK_X * TONEMAP_PX);
+	const int row_groups = columns * gr_div_up(span.count(), TONEMAP_BLOCK_Y * TONEMAP_ROW_GROUPS) < 64u ? 1 : TONEMAP_ROW_GROUPS;
+	dim3 grid(columns, gr_div_up(span.count(), unsigned(TONEMAP_BLOCK_Y * row_groups)));
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "tonemap"};
 	hipStream_t s = gr_to_stream(stream);
 	const bool quarter = hdr->width == 4u * bloom->width && hdr->height == 4u * bloom->height;
 	auto launch = [&](auto kernel) {
 		hipLaunchKernelGGL(kernel, grid, block, 0, s, to_dev(hdr), to_dev(bloom), to_dev_rw(out), lum, ctx->tonemap_srgb8_lut, *push, span.first, span.end,
-		                   hdr->format == GR_FORMAT_B10G11R11_UFLOAT_PACK32);
+		                   hdr->format == GR_FORMAT_B10G11R11_UFLOAT_PACK32, row_groups);
 	};
 	if (quarter)
 	{

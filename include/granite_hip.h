@@ -254,6 +254,29 @@ int gr_bloom_up_all(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_
                     gr_luminance_data *lum, const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1,
                     const gr_push_bloom_upsample *push_u0, const gr_push_luminance *push_lum);
 
+/* The WHOLE bloom pass of a small frame -- every dispatch of bloom_build_compute (hdr.cpp:354-379): threshold, downsample-0 .. -3 (+ feedback),
+ * luminance, upsample-2 .. -0 -- in ONE launch: the work of gr_bloom_down_head, gr_bloom_down_tail and gr_bloom_up_all as three block ranges of one
+ * grid, a range starting when the one before it has published its levels (device-side counters in the context; workgroups wait for lower
+ * workgroup ids only).  Every level is written, byte for byte what the separate launches leave.  gr_bloom_pyramid_supported(): what the three
+ * launches require (whole levels of a pyramid of InputRelative sizes, threshold / downsample-0 / -1 exactly half of their inputs, upsample-0
+ * exactly twice upsample-1, a feedback history) and a frame of at most 640 x 384 pixels -- where the host's runtime calls, not the device, set
+ * the frame's pace; above, the device-side hand-overs between the ranges cost more than the launches they replace (gr_bloom_pyramid itself
+ * accepts any size the three launches accept).  lum NULL: static exposure, no luminance reduction.  Launches of this entry point on one context must not
+ * overlap in time (issue them on one stream, as the executor does); gr_debug_pyramid_giveups() synchronises the device and returns how many
+ * workgroups ever gave up waiting for a predecessor (0 unless that rule was broken). */
+typedef struct gr_bloom_pyramid_args
+{
+	gr_image hdr, threshold, d0, d1, d2, d3, history, u2, u1, u0;
+	gr_luminance_data *lum;
+	gr_push_bloom_threshold push_threshold;
+	gr_push_bloom_downsample push_d0, push_d1, push_d2, push_d3;
+	gr_push_bloom_upsample push_u2, push_u1, push_u0;
+	gr_push_luminance push_luminance;
+} gr_bloom_pyramid_args;
+int gr_bloom_pyramid_supported(const gr_bloom_pyramid_args *args);
+int gr_bloom_pyramid(gr_ctx *ctx, gr_stream stream, const gr_bloom_pyramid_args *args);
+int gr_debug_pyramid_giveups(gr_ctx *ctx, uint32_t *count);
+
 /* tonemap_build_render_pass (hdr.cpp:283-306) + tonemap.frag (full-screen quad).  out: R8G8B8A8_SRGB (linear value
  * is sRGB-encoded on store, as the attachment hardware does) or R8G8B8A8_UNORM.  lum NULL => DYNAMIC_EXPOSURE=0. */
 typedef struct gr_push_tonemap

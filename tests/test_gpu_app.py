@@ -301,8 +301,8 @@ def test_camera_motion_equals_explicit_parameters_and_keeps_the_light_prefetch()
 
 
 def test_prerecorded_launch_sequences_do_not_change_a_byte():
-    """HIP::CommandBuffer::replayable (opt-in, GRANITE_LAUNCH_GRAPHS=1): once their arguments repeat, the bloom pass's launches (five at
-    this size: threshold + downsample-0 + downsample-1 are one, gr_bloom_down_head) go out as one pre-instantiated hipGraph (the cluster build is two launches that read the frame's slot of the pinned staging
+    """HIP::CommandBuffer::replayable (opt-in, GRANITE_LAUNCH_GRAPHS=1): once their arguments repeat, the bloom pass's launches (ONE at
+    this size, gr_bloom_pyramid; three above 640 x 384) go out as one pre-instantiated hipGraph (the cluster build is two launches that read the frame's slot of the pinned staging
     ring since round 3: nothing to pre-record).  Twenty-four pipelined frames with them (a separate
     process with the variable set) equal the same frames with every kernel launched directly, byte for byte; the sequences really
     are replayed; per-kernel timing brackets switch the affected sequence back to direct launches; a moving camera never captures
@@ -338,9 +338,9 @@ np.savez({out!r}, bb=a.read_backbuffer(), hdr=a.read("HDR-main"), d3=a.read("dow
 # brackets on a kernel of the bloom sequence: that sequence is launched directly again
 k = a.kernel_context()
 before = a.launch_graph_replays()
-k.timing_set_filter("bloom_down_head"); k.timing_enable(True); k.timing_reset()
+k.timing_set_filter("bloom_pyramid"); k.timing_enable(True); k.timing_reset()
 a.render_frames(4)
-assert k.timing_query()["bloom_down_head"][0] == 4
+assert k.timing_query()["bloom_pyramid"][0] == 4
 k.timing_enable(False); k.timing_set_filter(None)
 assert a.launch_graph_replays() - before == 0, a.launch_graph_replays() - before
 a.close()

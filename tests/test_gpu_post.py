@@ -285,6 +285,64 @@ def test_fused_upsample_chain_equals_the_separate_launches(gr, w, h, dynamic):
         assert got[True][3][0] != lum0[0]
 
 
+@pytest.mark.parametrize("w,h,packed,dynamic", [(1920, 1080, False, True), (256, 256, False, True), (64, 48, False, True), (640, 360, False, False),
+                                                (1920, 1080, True, True), (328, 200, True, False), (1280, 720, False, True), (200, 136, False, True)])
+def test_whole_pyramid_in_one_launch_equals_the_separate_launches(gr, w, h, packed, dynamic):
+    """gr_bloom_pyramid (threshold, four downsamples + feedback, luminance, three upsamples as three block ranges of ONE grid, a range waiting on
+    device-side counters for the one before it) must leave the very bytes of the nine separate launches in all eight levels and in the luminance
+    buffer: the sizes of the fused-head / fused-upsample tests (256 x 256 = BASELINE config 1, partial tiles; 1080p with its odd levels on the nine
+    generic taps and 720p through the launcher directly -- gr_bloom_pyramid_supported offers the launch up to 640 x 384), both HDR formats, with and without the exposure buffer -- and run three times over the same images, as consecutive frames do
+    (the counters of a launch are left at zero by its last workgroup).  No workgroup may have given up waiting."""
+    names = ("threshold", "d0", "d1", "d2", "d3")
+    scales = dict(threshold=0.5, d0=0.25, d1=0.125, d2=0.0625, d3=0.03125, u2=0.0625, u1=0.125, u0=0.25)
+    rng = np.random.default_rng(w * 7 + h)
+    hdr_f = np.exp2(rng.uniform(-6, 6, (h, w, 4))).astype(np.float32)
+    if packed:
+        hdr = capi.DeviceImage(gr, w, h, capi.FORMAT_B10G11R11_UFLOAT_PACK32).upload(orc.pack_b10g11r11(hdr_f[..., :3]))
+    else:
+        hdr = capi.DeviceImage(gr, w, h, F16).upload(hdr_f.astype(np.float16).view(np.uint16))
+    d3_size = orc.level_size(w, h, scales["d3"])
+    history = capi.DeviceImage(gr, *d3_size, F16).upload(np.exp2(rng.uniform(-8, 2, (d3_size[1], d3_size[0], 4))).astype(np.float16).view(np.uint16))
+    lum0 = np.array([0.3, 1.7, 1.0 / 1.7], np.float32)
+    lum_lerp, feedback_lerp = orc.frame_lerps(0.01)
+    results = {}
+    for fused in (False, True):
+        l = {name: capi.DeviceImage(gr, *orc.level_size(w, h, s), F16) for name, s in scales.items()}
+        lum = capi.DeviceBuffer(gr, 12).upload(lum0) if dynamic else None
+        lum_ptr = lum.ptr if lum is not None else None
+        for frame in range(3):
+            if fused:
+                offered = gr.bloom_pyramid(hdr, l, history, feedback_lerp, lum_ptr, lum_lerp, any_size=w * h > 640 * 384)
+                assert offered, "a frame up to 640 x 384 with even half / quarter / eighth levels must qualify"
+            else:
+                gr.bloom_threshold(hdr, l["threshold"], lum_ptr)
+                for src, dst in zip(names[:-1], names[1:]):
+                    gr.bloom_downsample(l[src], l[dst], history if dst == "d3" else None, feedback_lerp)
+                if dynamic:
+                    gr.luminance(l["d3"], lum_ptr, lum_lerp)
+                gr.bloom_upsample(l["d3"], l["u2"])
+                gr.bloom_upsample(l["u2"], l["u1"])
+                gr.bloom_upsample(l["u1"], l["u0"])
+        gr.sync()
+        results[fused] = {name: img.download() for name, img in l.items()}
+        results[fused]["luminance"] = lum.download(np.float32) if dynamic else np.zeros(3, np.float32)
+    assert gr.pyramid_giveups() == 0
+    for name in results[True]:
+        np.testing.assert_array_equal(results[True][name], results[False][name], err_msg=name)
+    if dynamic:
+        assert results[True]["luminance"][0] != lum0[0]
+
+
+def test_whole_pyramid_declines_what_it_does_not_cover(gr):
+    """Frames above 640 x 384 and pyramids with an odd half / quarter / eighth level keep the separate (fused-by-parts) launches."""
+    scales = dict(threshold=0.5, d0=0.25, d1=0.125, d2=0.0625, d3=0.03125, u2=0.0625, u1=0.125, u0=0.25)
+    for w, h in ((1920, 1080), (3840, 2160), (330, 202)):
+        hdr = capi.DeviceImage(gr, w, h, F16)
+        l = {name: capi.DeviceImage(gr, *orc.level_size(w, h, s), F16) for name, s in scales.items()}
+        history = capi.DeviceImage(gr, *orc.level_size(w, h, 0.03125), F16)
+        assert not gr.bloom_pyramid(hdr, l, history, 0.1)
+
+
 def test_fused_upsample_chain_declines_what_it_does_not_cover(gr):
     """A quarter level that is not exactly twice the eighth keeps gr_bloom_up_tail + gr_bloom_upsample, and so does a frame above 4K
     (the tiles' recomputed patches cost more than the launch they save there: profiles/r05_up_fusion_by_size.txt)."""
