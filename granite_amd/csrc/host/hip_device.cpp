@@ -263,6 +263,17 @@ Device::Device(int device_index) : index(device_index)
 		throw_hip(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, priorities[i]), "hipStreamCreateWithPriority");
 		streams[i] = stream;
 	}
+	{
+		// Opt-in experiment (GRANITE_ALTERNATE_FRONT=1): a second front stream, see front_alternate.  Measured and NOT the default: two lighting
+		// launches in flight cost the 4K frame 0.199 -> 0.283-0.292 ms (profiles/r06_front_stream_alternation.txt).
+		const char *env = getenv("GRANITE_ALTERNATE_FRONT");
+		if (env && atoi(env) != 0)
+		{
+			hipStream_t stream;
+			throw_hip(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, priorities[int(CommandBuffer::Type::Front)]), "hipStreamCreateWithPriority");
+			front_alternate = stream;
+		}
+	}
 	for (auto &frame : staging)
 	{
 		throw_hip(hipHostMalloc(reinterpret_cast<void **>(&frame.base), StagingBytes, hipHostMallocDefault), "hipHostMalloc");
@@ -294,6 +305,8 @@ Device::~Device()
 	for (auto &s : streams)
 		if (s)
 			(void)hipStreamDestroy(static_cast<hipStream_t>(s));
+	if (front_alternate)
+		(void)hipStreamDestroy(static_cast<hipStream_t>(front_alternate));
 	if (collective_stream)
 		(void)hipStreamDestroy(static_cast<hipStream_t>(collective_stream));
 	if (ctx)
@@ -336,7 +349,7 @@ void Device::next_frame_context()
 	for (int i = 0; i < int(CommandBuffer::Type::Count); i++)
 		if (stream_dirty[i])
 		{
-			throw_hip(hipEventRecord(static_cast<hipEvent_t>(done.fence[i]), static_cast<hipStream_t>(streams[i])), "hipEventRecord");
+			throw_hip(hipEventRecord(static_cast<hipEvent_t>(done.fence[i]), static_cast<hipStream_t>(physical_stream(i, frame_number))), "hipEventRecord");
 			done.fence_frame[i] = frame_number;
 			stream_dirty[i] = false;
 		}
@@ -361,12 +374,21 @@ void Device::next_frame_context()
 	// the ring were waited for when their slot came round.  One hipEventQuery per stream that has been used within the ring, none
 	// for an idle stream.
 	// (frame_number is the frame about to be enqueued; "lead frames old" counts from the frame just recorded, frame_number - 1.)
+	// (The front type alternates between two streams: a record covers the frames of its own parity, so the newest old-enough record of
+	// EACH parity is waited for.)
 	for (int i = 0; i < int(CommandBuffer::Type::Count); i++)
+	{
+		const bool two_streams = i == int(CommandBuffer::Type::Front) && front_alternate != nullptr;
+		bool covered[2] = {false, !two_streams};
 		for (unsigned back = lead + 1u; back <= StagingFrames && back < frame_number; back++)
 		{
 			auto &slot = staging[(frame_number - back - 1u) % StagingFrames]; // frame f was enqueued into slot (f - 1) % StagingFrames
 			if (slot.fence_frame[i] != frame_number - back)
 				continue;
+			const unsigned parity = two_streams ? unsigned((frame_number - back) & 1u) : 0u;
+			if (covered[parity])
+				continue;
+			covered[parity] = true;
 			const auto fence = static_cast<hipEvent_t>(slot.fence[i]);
 			if (hipEventQuery(fence) != hipSuccess)
 			{
@@ -377,15 +399,17 @@ void Device::next_frame_context()
 				}
 				blocked_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 			}
-			break;
+			if (covered[0] && covered[1])
+				break;
 		}
+	}
 	staging[staging_index].offset = 0;
 }
 
 void Device::record_frame_fence(CommandBuffer::Type type)
 {
 	auto &frame = staging[staging_index];
-	throw_hip(hipEventRecord(static_cast<hipEvent_t>(frame.fence[int(type)]), static_cast<hipStream_t>(streams[int(type)])), "hipEventRecord");
+	throw_hip(hipEventRecord(static_cast<hipEvent_t>(frame.fence[int(type)]), static_cast<hipStream_t>(physical_stream(int(type), frame_number))), "hipEventRecord");
 	frame.fence_frame[int(type)] = frame_number;
 	stream_dirty[int(type)] = false;
 }
@@ -395,6 +419,8 @@ void Device::wait_idle()
 	GRANITE_SCOPED_TIMELINE_EVENT("wait-idle");
 	for (auto &s : streams)
 		throw_hip(hipStreamSynchronize(static_cast<hipStream_t>(s)), "hipStreamSynchronize");
+	if (front_alternate)
+		throw_hip(hipStreamSynchronize(static_cast<hipStream_t>(front_alternate)), "hipStreamSynchronize");
 	if (collective_stream)
 		throw_hip(hipStreamSynchronize(static_cast<hipStream_t>(collective_stream)), "hipStreamSynchronize");
 }

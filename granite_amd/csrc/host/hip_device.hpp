@@ -158,7 +158,7 @@ public:
 	gr_stream get_stream(CommandBuffer::Type type) const
 	{
 		stream_dirty[int(type)] = true;
-		return streams[int(type)];
+		return physical_stream(int(type), frame_number);
 	}
 	// A fourth in-order stream for collectives that run beside the frame (the output all-gather of row-band tiling):
 	// created on first use, drained by wait_idle() like the executor's own.
@@ -181,6 +181,13 @@ public:
 	void *frame_fence(CommandBuffer::Type type) const { return staging[staging_index].fence[int(type)]; }
 	static constexpr unsigned FrameFenceRing = 4; // = StagingFrames: a frame's fences are re-recorded this many frames later
 	void record_frame_fence(CommandBuffer::Type type);
+	bool front_alternates() const { return front_alternate != nullptr; }
+	// Whether two accesses on streams of the same type, recorded in frames a and b, were put on the same in-order stream (false only for
+	// the front type, whose stream alternates with the frame's parity).
+	bool same_stream(CommandBuffer::Type type, uint64_t frame_a, uint64_t frame_b) const
+	{
+		return physical_stream(int(type), frame_a) == physical_stream(int(type), frame_b);
+	}
 	// Number of the frame being enqueued (from 1; advanced by next_frame_context()).
 	uint64_t get_frame_number() const { return frame_number; }
 	void next_frame_context();
@@ -199,6 +206,17 @@ private:
 	int index;
 	gr_ctx *ctx = nullptr;
 	gr_stream streams[int(CommandBuffer::Type::Count)] = {};
+	// Experiment, off by default (GRANITE_ALTERNATE_FRONT=1): the front of a frame (G-buffer producer, lighting) alternates between TWO in-order
+	// streams by frame parity.  Consecutive lighting launches share no resource (HDR-main, the G-buffer targets and the cluster buffers rotate
+	// through three copies), so nothing but the stream makes launch N + 1 wait for the last workgroup of launch N.  Correct (hazards between
+	// two front passes of different parity are ordered by events, frame pacing waits for both streams: the executor's GPU tests pass with it)
+	// and 40 % slower: two lighting launches in flight take 250 us each and starve the back of the frame
+	// (profiles/r06_front_stream_alternation.txt).
+	gr_stream front_alternate = nullptr;
+	gr_stream physical_stream(int type, uint64_t frame) const
+	{
+		return type == int(CommandBuffer::Type::Front) && front_alternate && (frame & 1u) != 0 ? front_alternate : streams[type];
+	}
 	gr_stream collective_stream = nullptr;
 	struct StagingFrame
 	{

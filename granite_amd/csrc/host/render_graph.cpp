@@ -1170,7 +1170,9 @@ void RenderGraph::build_stream_assignment()
 				shared = shared || several(touched[r]);
 			for (unsigned w : pass_writes_physical[pass_index])
 				shared = shared || several(touched[w]);
-			pass_needs_sync[pass_index] = shared;
+			// The front's stream alternates with the frame's parity (HIP::Device): what two front passes of different frames share (the
+			// G-buffer targets a producer pass rewrites three frames after the lighting pass read them) is ordered by events too.
+			pass_needs_sync[pass_index] = shared || (pass_stream[pass_index] == 2 && device && device->front_alternates());
 		}
 	}
 
@@ -1487,16 +1489,22 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 			throw std::runtime_error("cross-queue dependency failed");
 	};
 	// RAW / WAW / WAR against accesses recorded on the other stream.
+	// (An access of the same stream type is ordered by the stream itself -- unless the type's stream alternates with the frame's parity, the
+	// front's, and the access was recorded in a frame of the other parity: the device says, frame numbers being the device's.)
+	const uint64_t device_frame = device_.get_frame_number();
+	auto in_order_with = [&](int stream_index, int other_index, uint64_t other_device_frame) {
+		return other_index == stream_index && device_.same_stream(HIP::CommandBuffer::Type(stream_index), device_frame, other_device_frame);
+	};
 	auto acquire = [&](hipStream_t stream, int stream_index, const std::vector<unsigned> &reads, const std::vector<unsigned> &writes) {
 		for (unsigned r : reads)
-			if (physical_sync[r].last_write && physical_sync[r].write_stream != stream_index)
+			if (physical_sync[r].last_write && !in_order_with(stream_index, physical_sync[r].write_stream, physical_sync[r].write_device_frame))
 				wait_for(stream, physical_sync[r].last_write, "RAW", r, physical_sync[r].write_pass, physical_sync[r].write_frame);
 		for (unsigned w : writes)
 		{
-			if (physical_sync[w].last_write && physical_sync[w].write_stream != stream_index)
+			if (physical_sync[w].last_write && !in_order_with(stream_index, physical_sync[w].write_stream, physical_sync[w].write_device_frame))
 				wait_for(stream, physical_sync[w].last_write, "WAW", w, physical_sync[w].write_pass, physical_sync[w].write_frame);
 			for (int other = 0; other < StreamCount; other++)
-				if (other != stream_index)
+				if (!in_order_with(stream_index, other, physical_sync[w].read_device_frame[other]))
 					wait_for(stream, physical_sync[w].last_read[other], "WAR", w, physical_sync[w].read_pass[other], physical_sync[w].read_frame[other]);
 		}
 	};
@@ -1521,6 +1529,7 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 			physical_sync[r].last_read[stream_index] = event;
 			physical_sync[r].read_pass[stream_index] = current_pass;
 			physical_sync[r].read_frame[stream_index] = this_frame;
+			physical_sync[r].read_device_frame[stream_index] = device_frame;
 		}
 		for (unsigned w : writes)
 		{
@@ -1528,7 +1537,9 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 			physical_sync[w].write_stream = stream_index;
 			physical_sync[w].write_pass = current_pass;
 			physical_sync[w].write_frame = this_frame;
-			physical_sync[w].last_read[0] = physical_sync[w].last_read[1] = physical_sync[w].last_read[2] = nullptr;
+			physical_sync[w].write_device_frame = device_frame;
+			for (auto &read : physical_sync[w].last_read)
+				read = nullptr;
 		}
 	};
 

@@ -547,6 +547,8 @@ private:
 		// who recorded those events (pass index, frame), for GRANITE_SYNC_DEBUG=1 traces
 		int write_pass = -1, read_pass[StreamCount] = {-1, -1, -1, -1};
 		uint64_t write_frame = 0, read_frame[StreamCount] = {};
+		// the device's frame number at those records: which of a type's alternating streams they went to (HIP::Device::same_stream)
+		uint64_t write_device_frame = 0, read_device_frame[StreamCount] = {};
 	};
 	std::vector<PhysicalSync> physical_sync;
 	// Buffers written by a hoisted pass exist twice and alternate per frame (like an image with history), so the

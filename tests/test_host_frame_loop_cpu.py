@@ -122,6 +122,19 @@ a.close()
         assert between[0] == "R" and all(k == "W" for k in between[1:]), between
     frame = ops[lighting[0]:lighting[1]]
     assert sum(o[0] == "R" for o in frame) == 3, [o[:2] for o in frame]
+    # The opt-in experiment GRANITE_ALTERNATE_FRONT=1 (HIP::Device: the front's stream alternates with the frame's parity; measured 40 % slower
+    # on the 4K frame, profiles/r06_front_stream_alternation.txt): consecutive lighting launches on two streams in turn, on each of them one
+    # record and waits between two launches.
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, GRANITE_ALTERNATE_FRONT="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stderr.split("=== steady")[1].split("=== end")[0].splitlines()
+    ops = [l.split(None, 2) for l in lines if l[:2] in ("L ", "R ", "W ")]
+    lighting = [i for i, o in enumerate(ops) if o[0] == "L" and "k_lighting" in o[2]]
+    streams = [ops[i][1] for i in lighting]
+    assert len(lighting) == 4 and streams[0] != streams[1] and streams[0] == streams[2] and streams[1] == streams[3], streams
+    for a_, b_ in zip(lighting, lighting[2:]):
+        between = [o[0] for o in ops[a_ + 1:b_] if o[1] == ops[a_][1]]
+        assert between.count("R") == 1 and between.count("L") == 0 and between[0] == "R" and all(k == "W" for k in between[1:]), between
 
 
 def test_staging_slot_is_not_reused_before_the_stream_that_read_it_is_through(tmp_path):
