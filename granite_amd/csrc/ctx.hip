@@ -199,13 +199,6 @@ gr_ctx *gr_create(int device)
 		volatile float phi = 2.0f * 3.1415628f * u2;
 		azimuth[i] = make_float2(cosf(phi), sinf(phi));
 	}
-	hipDeviceProp_t props{};
-	if (hipGetDeviceProperties(&props, device) == hipSuccess)
-	{
-		ctx->compute_units = props.multiProcessorCount;
-		// One MI355X in SPX mode: 8 XCDs x 32 CUs behind one agent, workgroups dealt to the XCDs in turn.
-		ctx->eight_xcd_partition = props.multiProcessorCount == 256 && strncmp(props.gcnArchName, "gfx950", 6) == 0;
-	}
 	if (encode_table_status != 0 || tonemap_table_status != 0 ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->ssr_azimuth_lut), sizeof(azimuth)) != hipSuccess ||
 	    hipMemcpy(ctx->ssr_azimuth_lut, azimuth, sizeof(azimuth), hipMemcpyHostToDevice) != hipSuccess ||

@@ -41,10 +41,6 @@ struct gr_ctx
 	uint32_t *pyramid_sync = nullptr;
 	std::atomic<unsigned> pyramid_launches{0};
 
-	// The device the context sits on.
-	int compute_units = 0;
-	bool eight_xcd_partition = false;
-
 	// SMAA lookup tables (assets/textures/smaa/{area,search}.gtx payloads), uploaded through gr_smaa_set_luts.
 	void *smaa_area = nullptr;   // 160 x 560 x 2 floats (the RG8 area texture, decoded)
 	void *smaa_search = nullptr; // 64 x 16 floats (the R8 search texture, decoded)

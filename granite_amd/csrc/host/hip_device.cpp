@@ -389,6 +389,11 @@ void Device::next_frame_context()
 			if (covered[parity])
 				continue;
 			covered[parity] = true;
+			// a record found complete (or waited for) at an earlier turn is not asked again: an intermittently used stream's last record
+			// comes round once more as it ages through the ring
+			if (slot.fence_frame[i] <= completed_frame[i][parity])
+				continue;
+			completed_frame[i][parity] = slot.fence_frame[i];
 			const auto fence = static_cast<hipEvent_t>(slot.fence[i]);
 			if (hipEventQuery(fence) != hipSuccess)
 			{

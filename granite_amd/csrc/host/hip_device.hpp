@@ -236,6 +236,7 @@ private:
 	unsigned staging_index = 0;
 	uint64_t frame_number = 1; // of the frame being enqueued (from 1); its slot is staging[staging_index] = staging[(frame_number - 1) % StagingFrames]
 	mutable bool stream_dirty[int(CommandBuffer::Type::Count)] = {};
+	uint64_t completed_frame[int(CommandBuffer::Type::Count)][2] = {}; // per stream (and parity of the front's two): the newest frame whose fence the pacing has seen complete
 	size_t allocated_bytes = 0;
 	double blocked_seconds = 0.0;
 	unsigned image_row_granularity = 1;

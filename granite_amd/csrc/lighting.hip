@@ -343,7 +343,10 @@ struct RawTile
 // every load is base SGPR pair + one VGPR offset.  PX == 2 is only launched for even widths and pitches that keep the pair of
 // texels naturally aligned: the lane's two pixels are inside or outside together and come in with one load per attachment.
 // Lanes outside the target read the texels their coordinates clamp to (no exec-mask region, no zero-filled registers): what they
-// hold is never stored, and their depth is not looked at (`inside` gates `active`).
+// hold is never stored, and their depth is not looked at (`inside` gates `active`).  The clamp is to the whole target, not to the render
+// area: a band launch (gr_rows) may read rows of the attachments it does not shade -- every attachment has the target's full height
+// (check_image in gr_lighting) -- and, with emissive aliased to the target, texels another wave or another band's launch is writing;
+// the values are dropped, so this is a benign read of a location being written (a race detector would name it).
 template <int PX, bool B10>
 __device__ __forceinline__ void load_raw(const KernelArgs &a, int x0, int y, RawTile<PX, B10> &r)
 {
@@ -960,11 +963,17 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	k.cl_num_lights_32 = args->cluster.num_lights_32;
 	k.cl_z_max_index = args->cluster.z_max_index;
 	{
+		// slice = int(dot(pos, front * zs) - dot(base, front) * zs) where the shader has dot(pos - base, front) * zs: the row is formed in
+		// double here (its entries are correctly rounded), what differs in the kernel is that the two large terms meet in the last fma instead
+		// of the subtraction coming first -- an absolute error of the slice coordinate of about |camera_base| * z_scale * 2^-23 (2e-4 of a slice
+		// at the tests' camera, 8 units from the origin with 4096 slices over 100 units; a third of a slice at 1e4 units, where fp32 world
+		// positions themselves are only good to 1e-3 units).  A pixel that changes slice by it sees lights at the edge of their range appear
+		// or vanish, with falloff -> 0 there (see shade_tile).
 		const float *front = args->cluster.camera_front, *camera = args->cluster.camera_base;
-		const float z_scale = args->cluster.z_scale;
+		const double z_scale = args->cluster.z_scale;
 		for (int i = 0; i < 3; i++)
-			k.cl_z_row[i] = front[i] * z_scale;
-		k.cl_z_row[3] = -(camera[0] * front[0] + camera[1] * front[1] + camera[2] * front[2]) * z_scale;
+			k.cl_z_row[i] = float(double(front[i]) * z_scale);
+		k.cl_z_row[3] = float(-(double(camera[0]) * front[0] + double(camera[1]) * front[1] + double(camera[2]) * front[2]) * z_scale);
 	}
 	if (clustered)
 	{
@@ -975,7 +984,7 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 		k.range = reinterpret_cast<const uint2 *>(args->range);
 	}
 	k.srgb_lut = ctx->srgb_decode_lut;
-	k.flags = args->flags;
+	k.flags = args->flags & (GR_LIGHTING_DIRECTIONAL_BIT | GR_LIGHTING_CLUSTERED_BIT | GR_LIGHTING_AMBIENT_FALLBACK_BIT | GR_LIGHTING_AMBIENT_OCCLUSION_BIT); // the shading bits; scheduling hints stay on the host
 	for (int i = 0; i < 3; i++)
 		k.fog_color[i] = args->fog_color[i];
 	k.fog_falloff = args->fog_falloff > 0.0f ? args->fog_falloff : 0.0f;

@@ -433,13 +433,13 @@ typedef struct gr_push_clustering /* renderer.cpp:1110-1121 */
 #define GR_LIGHTING_DIRECTIONAL_BIT 1u        /* draw the directional quad */
 #define GR_LIGHTING_CLUSTERED_BIT 2u          /* draw the clustered quad */
 #define GR_LIGHTING_AMBIENT_FALLBACK_BIT 4u   /* VOLUMETRIC_DIFFUSE_FALLBACK, renderer.cpp:1049-1055 */
+#define GR_LIGHTING_AMBIENT_OCCLUSION_BIT 8u  /* AMBIENT_OCCLUSION (renderer.cpp:1050-1051): `ambient_occlusion` scales the
+                                                 fallback ambient term, directional.frag:52-64.  Needs the fallback bit. */
 /* Scheduling hint, no effect on any value: register-heavy passes of other streams run beside this launch (the temporal resolve and the
  * SMAA passes of the frame before: 512-thread workgroups of 64 registers, i.e. 128 per SIMD).  The launch then leaves them a quarter of each SIMD's register
  * file -- four resident workgroups per CU instead of five.  Measured (profiles/r05_lighting_instruction_diet.txt): five are 3 % faster
  * for a lighting + bloom + tonemap frame, 5-10 % slower for the TAA High + SMAA Ultra frame. */
 #define GR_LIGHTING_SHARE_REGISTERS_BIT 16u
-#define GR_LIGHTING_AMBIENT_OCCLUSION_BIT 8u  /* AMBIENT_OCCLUSION (renderer.cpp:1050-1051): `ambient_occlusion` scales the
-                                                 fallback ambient term, directional.frag:52-64.  Needs the fallback bit. */
 
 typedef struct gr_lighting_args
 {

@@ -1,4 +1,4 @@
-"""GPU vs the frozen fixtures under tests/golden/ (no oracle call at run time)."""
+"""GPU vs the frozen fixtures under tests/golden/ (the oracle is called once, for the post chain of the executor's own lit target)."""
 import os
 
 import numpy as np
@@ -34,6 +34,18 @@ def test_executor_matches_committed_fixtures():
     np.testing.assert_array_equal(a.read("cluster-range").view(np.uint32).reshape(-1, 2), ref["range"])
     assert_rgba16f_close(a.read("HDR-main"), ref["hdr"], ulps=2.0, what="HDR-main")
     assert_rgba8_close(a.read_backbuffer(), ref["tonemapped"], 1, what="tonemapped")
+    # the hand-over from lighting to the post chain INSIDE this graph: this executor's pyramid levels against the oracle's chain
+    # evaluated on this executor's own lit target -- a wrong alias, a missing wait between lighting and threshold or the wrong copy of the
+    # rotating HDR-main would show here at 2 ulp + 1e-4, not only in the +-1 LSB of the backbuffer
+    from oracle import oracle as orc
+    state, chain = {}, None
+    own_hdr = a.read("HDR-main").copy()
+    for _ in range(FRAMES):
+        chain = orc.hdr_chain(own_hdr, state)
+    assert_rgba16f_close(a.read("threshold"), chain["threshold"], ulps=2.0, abs_tol=1e-4, what="threshold of the executor's own lit target")
+    assert_rgba16f_close(a.read("downsample-3"), chain["d3"], ulps=2.0, abs_tol=1e-4, what="downsample-3 of the executor's own lit target")
+    assert_rgba16f_close(a.read("upsample-0"), chain["u0"], ulps=2.0, abs_tol=1e-4, what="upsample-0 of the executor's own lit target")
+    np.testing.assert_allclose(a.read("average-luminance").view(np.float32)[0], chain["lum"][0], atol=2e-5)
     a.close()
     # The post chain on the fixture's own HDR target (a second executor without the lighting pass): SURVEY 8a's 2 ulp + 1e-4 on every
     # level -- nothing of the lighting tolerance is carried into it (profiles/r05_pyramid_ulp_histogram_4k.json: no channel of any level
