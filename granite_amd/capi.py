@@ -273,7 +273,7 @@ def load_library() -> C.CDLL:
         "gr_debug_pyramid_giveups": (C.c_int, [vp, P(C.c_uint32)]),
         "gr_bloom_up_all_supported": (C.c_int, [P(Image), P(Image), P(Image), P(Image), P(PushBloomUpsample), P(PushBloomUpsample), P(PushBloomUpsample)]),
         "gr_bloom_up_all": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), P(Image), vp, P(PushBloomUpsample), P(PushBloomUpsample), P(PushBloomUpsample),
-                                      P(PushLuminance)]),
+                                      P(PushLuminance), C.c_uint32]),
         "gr_bloom_up_tail": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushBloomUpsample), P(PushBloomUpsample), P(PushLuminance)]),
         "gr_tonemap": (C.c_int, [vp, vp, P(Image), P(Image), P(Image), vp, P(PushTonemap)]),
         "gr_bloom_threshold_rows": (C.c_int, [vp, vp, P(Image), P(Image), vp, P(PushBloomThreshold), P(Rows)]),
@@ -496,7 +496,8 @@ class Context:
         self.check(self.lib.gr_bloom_down_mid(self.handle, stream, threshold.desc, d0.desc, d1.desc, p_d0, p_d1, self._rows(rows)))
         return True
 
-    def bloom_up_all(self, d3: DeviceImage, u2: DeviceImage, u1: DeviceImage, u0: DeviceImage, lum_ptr=None, lum_lerp: float = 0.0, stream=None) -> bool:
+    def bloom_up_all(self, d3: DeviceImage, u2: DeviceImage, u1: DeviceImage, u0: DeviceImage, lum_ptr=None, lum_lerp: float = 0.0, stream=None,
+                     busy_frame: bool = False) -> bool:
         """luminance, upsample-2, upsample-1 and upsample-0 as one launch; False (nothing launched) when the frame does not qualify."""
         def up(out, src):
             return PushBloomUpsample((out.width, out.height), (1.0 / out.width, 1.0 / out.height), (1.0 / src.width, 1.0 / src.height))
@@ -504,7 +505,7 @@ class Context:
         if not self.lib.gr_bloom_up_all_supported(d3.desc, u2.desc, u1.desc, u0.desc, p_u2, p_u1, p_u0):
             return False
         p_lum = PushLuminance((d3.width // 2, d3.height // 2), lum_lerp, -3.0, 2.0) if lum_ptr is not None else None
-        self.check(self.lib.gr_bloom_up_all(self.handle, stream, d3.desc, u2.desc, u1.desc, u0.desc, lum_ptr, p_u2, p_u1, p_u0, p_lum))
+        self.check(self.lib.gr_bloom_up_all(self.handle, stream, d3.desc, u2.desc, u1.desc, u0.desc, lum_ptr, p_u2, p_u1, p_u0, p_lum, 1 if busy_frame else 0))
         return True
 
     def bloom_pyramid(self, hdr: DeviceImage, levels: dict, history: DeviceImage, feedback_lerp: float, lum_ptr=None, lum_lerp: float = 0.0, stream=None,

@@ -738,6 +738,12 @@ void ImageSpaceApplication::bake_render_graph()
 		bool resolved = setup_before_post_chain_antialiasing(pre_aa, graph, jitter, context, 1.0f, light_output, tagcat("depth", tag),
 		                                                     tagcat("mv", tag), "HDR-resolved", &strip_plan);
 		const std::string hdr_source = resolved ? "HDR-resolved" : light_output;
+		{
+			// the same question the lighting pass asks (heavy_neighbours): a temporal resolve in front of the bloom pass, SMAA behind the tonemap
+			const PostAAType pre = to_post_aa_type(config.pre_aa), post = to_post_aa_type(config.post_aa);
+			hdr_options.busy_frame = pre == PostAAType::TAA_Low || pre == PostAAType::TAA_Medium || pre == PostAAType::TAA_High || post == PostAAType::SMAA_Low ||
+			                         post == PostAAType::SMAA_Medium || post == PostAAType::SMAA_High || post == PostAAType::SMAA_Ultra;
+		}
 		if (config.compute_post)
 			setup_hdr_postprocess_compute(graph, frame, hdr_source, "tonemapped", hdr_options);
 		else

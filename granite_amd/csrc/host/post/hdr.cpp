@@ -128,7 +128,7 @@ gr_push_bloom_upsample upsample_push(HIP::ImageView &output, HIP::ImageView &inp
 bool record_pyramid_tail(HIP::CommandBuffer &cmd, const FrameParameters &frame, RenderGraph &graph, const RenderTextureResource &d1_res,
                          const RenderTextureResource &d2_res, const RenderTextureResource &d3_res, const RenderTextureResource &u2_res,
                          const RenderTextureResource &u1_res, const RenderBufferResource *lum_res, const RenderTextureResource *u0_res = nullptr,
-                         bool *u0_done = nullptr)
+                         bool *u0_done = nullptr, bool busy_frame = false)
 {
 	if (u0_done)
 		*u0_done = false;
@@ -167,7 +167,7 @@ bool record_pyramid_tail(HIP::CommandBuffer &cmd, const FrameParameters &frame, 
 		if (gr_bloom_up_all_supported(&d3.get_view(), &u2.get_view(), &u1.get_view(), &u0.get_view(), &push_u2, &push_u1, &push_u0))
 		{
 			cmd.check(gr_bloom_up_all(cmd.get_context(), cmd.get_stream(), &d3.get_view(), &u2.get_view(), &u1.get_view(), &u0.get_view(), lum, &push_u2,
-			                          &push_u1, &push_u0, lum ? &push_lum : nullptr),
+			                          &push_u1, &push_u0, lum ? &push_lum : nullptr, busy_frame ? GR_BLOOM_BUSY_FRAME_BIT : 0u),
 			          "bloom_up_all");
 			if (u0_done)
 				*u0_done = true;
@@ -337,7 +337,8 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 	// 1/8 level is all-gathered, everything coarser is replicated, u0 is computed where the tonemap band samples it.
 	// (A one-rank plan with an exchange installed still runs the exchange points: that is how the transport is tested.)
 	const StripPlan *plan = options.strip;
-	bloom_pass.set_build_render_pass([&graph, &frame, &t, &d0, &d1, &d2, &d3, &u0, &u1, &u2, &hdr, ubo = lum, plan](HIP::CommandBuffer &cmd) {
+	const bool busy_frame = options.busy_frame;
+	bloom_pass.set_build_render_pass([&graph, &frame, &t, &d0, &d1, &d2, &d3, &u0, &u1, &u2, &hdr, ubo = lum, plan, busy_frame](HIP::CommandBuffer &cmd) {
 		const StripPlan *strip = plan && (plan->active() || plan->exchange) ? plan : nullptr;
 		const auto record = [&]() {
 			const auto compute_to_compute = [&cmd]() {
@@ -361,7 +362,7 @@ void setup_hdr_postprocess_compute(RenderGraph &graph, const FrameParameters &fr
 				strip->exchange(cmd, graph.get_physical_texture_resource(d1), strip->d1_chunk_rows, "downsample-1");
 			compute_to_compute();
 			bool u0_done = false;
-			if (!record_pyramid_tail(cmd, frame, graph, d1, d2, d3, u2, u1, ubo, strip ? nullptr : &u0, &u0_done))
+			if (!record_pyramid_tail(cmd, frame, graph, d1, d2, d3, u2, u1, ubo, strip ? nullptr : &u0, &u0_done, busy_frame))
 			{
 				record_downsample(cmd, frame, graph, d2, d1, nullptr);
 				compute_to_compute();

@@ -21,6 +21,8 @@ struct HDROptions
 	// HIP executor extension: row-band tiling of the frame across devices (strip_plan.hpp).  nullptr or an inactive plan
 	// = the whole frame on this device.  Honoured by setup_hdr_postprocess_compute only.
 	const StripPlan *strip = nullptr;
+	// HIP executor extension, a scheduling hint (GR_BLOOM_BUSY_FRAME_BIT): other heavy passes (a temporal resolve, SMAA) share the back of the frame.
+	bool busy_frame = false;
 };
 
 // Ten separate passes (hdr.cpp:402-561).

@@ -1036,7 +1036,13 @@ int gr_lighting(gr_ctx *ctx, gr_stream stream, const gr_lighting_args *args)
 	// 8 KiB of the CU's 160 KiB stay free: back-of-frame kernels that use a little LDS (luminance, the fused pyramid tail)
 	// must be able to start beside resident lighting workgroups instead of waiting for one to retire.
 	const size_t per_wg = ((160u - 8u) * 1024u / unsigned(max_wgs * 4 / LIGHT_WAVES)) & ~size_t(1023); // max_wgs counts four-wave workgroups
-	const size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
+	size_t pad_lds = max_wgs >= 8 || per_wg <= static_lds ? 0 : per_wg - static_lds;
+	{
+		// measurement switch: the pad in KiB whatever the cap asks for (with 96 registers the two-pixel kernel cannot exceed five waves per SIMD anyway)
+		static const int pad_kib = []() { const char *env = gr_measurement_switch("GR_LIGHTING_PAD_KIB"); return env ? atoi(env) : -1; }();
+		if (pad_kib >= 0)
+			pad_lds = size_t(pad_kib) * 1024u;
+	}
 	// The pad is not idle: it holds the wide-window candidate lists (shade_tile), 32 two-byte entries per word of a span and wave.
 	// 13 KiB at five workgroups per CU: spans of 52 words = 1664 light indices.  No pad (GR_LIGHTING_WGS_PER_CU=8): the chunk loop only.
 	{

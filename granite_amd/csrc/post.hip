@@ -786,17 +786,20 @@ __device__ __forceinline__ void up_all_block(const int bx, const int by, const i
 		luminance_block<NT>(d3, lum, push_lum, thread, wave_partial);
 }
 
-template <bool U2_EXACT, bool U1_EXACT, bool LUMINANCE>
-__global__ __launch_bounds__(LUM_THREADS) POST_VGPR_BUDGET void k_bloom_up_all(DevImage d3, DevImageRW u2, DevImageRW u1, DevImageRW u0, gr_luminance_data *lum,
-                                                                              gr_push_bloom_upsample push2, gr_push_bloom_upsample push1,
-                                                                              gr_push_luminance push_lum)
+// NT = 1024: one output per thread.  NT = 256 (the same tiles, four outputs per thread): a workgroup of four waves, one per SIMD, starts wherever
+// ONE lighting workgroup has retired; the sixteen waves of the 1024-thread form need four retirements on one CU (65-88 us inside the 4K frame for
+// 14 us of work: profiles/r06_back_chain_beside_lighting.txt).
+template <bool U2_EXACT, bool U1_EXACT, bool LUMINANCE, int NT>
+__global__ __launch_bounds__(NT) POST_VGPR_BUDGET void k_bloom_up_all(DevImage d3, DevImageRW u2, DevImageRW u1, DevImageRW u0, gr_luminance_data *lum,
+                                                                     gr_push_bloom_upsample push2, gr_push_bloom_upsample push1,
+                                                                     gr_push_luminance push_lum)
 {
 	post_wave_priority();
 	__shared__ f16x4 s_p2[UPALL_P2 * UPALL_P2];
 	__shared__ f16x4 s_p1[UPALL_P1 * UPALL_P1];
 	__shared__ float wave_partial[LUM_THREADS / 64];
-	up_all_block<U2_EXACT, U1_EXACT, LUMINANCE, LUM_THREADS>(int(blockIdx.x), int(blockIdx.y), int(threadIdx.x), s_p2, s_p1, wave_partial, d3, u2, u1, u0, lum, push2,
-	                                                         push1, push_lum);
+	up_all_block<U2_EXACT, U1_EXACT, LUMINANCE, NT>(int(blockIdx.x), int(blockIdx.y), int(threadIdx.x), s_p2, s_p1, wave_partial, d3, u2, u1, u0, lum, push2, push1,
+	                                                push_lum);
 }
 
 // ---- the whole pyramid in ONE launch (frames up to 640 x 384) ------------------------------------------------------------------------
@@ -1501,7 +1504,7 @@ int gr_bloom_up_all_supported(const gr_image *d3, const gr_image *u2, const gr_i
 
 int gr_bloom_up_all(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_image *u2, const gr_image *u1, const gr_image *u0, gr_luminance_data *lum,
                     const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1, const gr_push_bloom_upsample *push_u0,
-                    const gr_push_luminance *push_lum)
+                    const gr_push_luminance *push_lum, uint32_t flags)
 {
 	if (!ctx)
 		return GR_ERR_INVALID_ARGUMENT;
@@ -1519,14 +1522,25 @@ int gr_bloom_up_all(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_
 	gr_scoped_timing timing{ctx, gr_to_stream(stream), "bloom_up_all"};
 	const gr_push_luminance no_lum = {};
 	const bool u2_exact = upsample_is_exact(d3, push_u2), u1_exact = upsample_is_exact(u2, push_u1);
-	auto launch = [&](auto kernel) {
-		hipLaunchKernelGGL(kernel, grid, dim3(LUM_THREADS), 0, gr_to_stream(stream), to_dev(d3), to_dev_rw(u2), to_dev_rw(u1), to_dev_rw(u0), lum, *push_u2,
-		                   *push_u1, push_lum ? *push_lum : no_lum);
+	// measurement switch: GR_UP_ALL_THREADS=256 / 1024 whatever the caller's hint
+	static const int forced = []() { const char *env = gr_measurement_switch("GR_UP_ALL_THREADS"); return env ? atoi(env) : 0; }();
+	const int threads = forced == 256 || forced == 1024 ? forced : ((flags & GR_BLOOM_BUSY_FRAME_BIT) ? 256 : 1024);
+	auto launch = [&](auto kernel, int nt) {
+		hipLaunchKernelGGL(kernel, grid, dim3(nt), 0, gr_to_stream(stream), to_dev(d3), to_dev_rw(u2), to_dev_rw(u1), to_dev_rw(u0), lum, *push_u2, *push_u1,
+		                   push_lum ? *push_lum : no_lum);
 	};
 	auto pick = [&](auto u2e, auto u1e) {
 		constexpr bool A = decltype(u2e)::value, B = decltype(u1e)::value;
-		if (lum) launch(k_bloom_up_all<A, B, true>);
-		else launch(k_bloom_up_all<A, B, false>);
+		if (threads == 1024)
+		{
+			if (lum) launch(k_bloom_up_all<A, B, true, LUM_THREADS>, LUM_THREADS);
+			else launch(k_bloom_up_all<A, B, false, LUM_THREADS>, LUM_THREADS);
+		}
+		else
+		{
+			if (lum) launch(k_bloom_up_all<A, B, true, 256>, 256);
+			else launch(k_bloom_up_all<A, B, false, 256>, 256);
+		}
 	};
 	using T = std::true_type;
 	using F = std::false_type;

@@ -250,9 +250,15 @@ int gr_bloom_up_tail(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr
  * dynamic exposure, no luminance reduction. */
 int gr_bloom_up_all_supported(const gr_image *d3, const gr_image *u2, const gr_image *u1, const gr_image *u0, const gr_push_bloom_upsample *push_u2,
                               const gr_push_bloom_upsample *push_u1, const gr_push_bloom_upsample *push_u0);
+/* flags: GR_BLOOM_BUSY_FRAME_BIT -- scheduling hint, no effect on any value: the rest of the frame's back (a temporal resolve, SMAA) fills the
+ * machine beside the lighting launch.  The launch then runs 256-thread workgroups (one wave per SIMD: a workgroup starts wherever one lighting
+ * workgroup has retired) instead of 1024-thread ones (which wait for four retirements on one CU and so end up in the idle time between two lighting
+ * launches: best for a frame whose back is short).  Measured (profiles/r06_back_chain_beside_lighting.txt): the launch inside the 4K frame 23
+ * against 64-68 us; the TAA + SMAA frame 0.548 against 0.558-0.573 ms, the lighting + bloom + tonemap frame 0.204 against 0.199 ms. */
+#define GR_BLOOM_BUSY_FRAME_BIT 1u
 int gr_bloom_up_all(gr_ctx *ctx, gr_stream stream, const gr_image *d3, const gr_image *u2, const gr_image *u1, const gr_image *u0,
                     gr_luminance_data *lum, const gr_push_bloom_upsample *push_u2, const gr_push_bloom_upsample *push_u1,
-                    const gr_push_bloom_upsample *push_u0, const gr_push_luminance *push_lum);
+                    const gr_push_bloom_upsample *push_u0, const gr_push_luminance *push_lum, uint32_t flags);
 
 /* The WHOLE bloom pass of a small frame -- every dispatch of bloom_build_compute (hdr.cpp:354-379): threshold, downsample-0 .. -3 (+ feedback),
  * luminance, upsample-2 .. -0 -- in ONE launch: the work of gr_bloom_down_head, gr_bloom_down_tail and gr_bloom_up_all as three block ranges of one

@@ -265,12 +265,12 @@ def test_fused_upsample_chain_equals_the_separate_launches(gr, w, h, dynamic):
     lum0 = np.array([0.25, 2.0 ** 0.25, 2.0 ** -0.25], np.float32)
     lum_lerp, _ = orc.frame_lerps(0.01)
     got = {}
-    for fused in (False, True):
+    for fused in (False, True, "busy frame"):  # "busy frame": GR_BLOOM_BUSY_FRAME_BIT, 256-thread workgroups (the luminance reduction in its 1024-thread order on 256)
         u2, u1, u0 = (capi.DeviceImage(gr, *sz[i], F16) for i in (2, 1, 0))
         lum = capi.DeviceBuffer(gr, 12).upload(lum0) if dynamic else None
         lum_ptr = lum.ptr if lum is not None else None
         if fused:
-            assert gr.bloom_up_all(d3, u2, u1, u0, lum_ptr, lum_lerp), "a pyramid of InputRelative sizes up to 1440p with an even quarter level must qualify"
+            assert gr.bloom_up_all(d3, u2, u1, u0, lum_ptr, lum_lerp, busy_frame=fused == "busy frame"), "a pyramid of InputRelative sizes up to 1440p with an even quarter level must qualify"
         else:
             if dynamic:
                 gr.luminance(d3, lum_ptr, lum_lerp)
@@ -279,8 +279,9 @@ def test_fused_upsample_chain_equals_the_separate_launches(gr, w, h, dynamic):
             gr.bloom_upsample(u1, u0)
         gr.sync()
         got[fused] = (u2.download(), u1.download(), u0.download(), lum.download(np.float32) if dynamic else np.zeros(3, np.float32))
-    for a, b, name in zip(got[True], got[False], ("upsample-2", "upsample-1", "upsample-0", "luminance")):
-        np.testing.assert_array_equal(a, b, err_msg=name)
+    for form in (True, "busy frame"):
+        for a, b, name in zip(got[form], got[False], ("upsample-2", "upsample-1", "upsample-0", "luminance")):
+            np.testing.assert_array_equal(a, b, err_msg=f"{name} ({form})")
     if dynamic:
         assert got[True][3][0] != lum0[0]
 
