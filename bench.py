@@ -566,15 +566,12 @@ def main():
                     roofline["valu_issue"] = {"frac": valu_peak_us / (1e6 * dom_avg_s),
                                               "peak": "1024 SIMD-32 x 2.4 GHz, 2 cycles per wave64 fp32 instruction",
                                               "class_histogram": entry.get("valu_class_histogram"), "counters_stale": stale}
-                    # Class-weighted issue time: the measured cost of each opcode class on this chip (profiles/r02_valu_issue_rates.txt,
-                    # cycles per wave64 instruction at the ~2.0 GHz a dense fp32 loop sustains) x the PMC class counts.
-                    hist = entry.get("valu_class_histogram") or {}
-                    if hist:
-                        cost = {"fma_f32": 2.3, "mul_f32": 2.3, "add_f32": 2.3, "transcendental_f32": 7.2, "cvt": 3.5, "int32": 2.2}
-                        cycles = sum(n * cost.get(k, 3.7) for k, n in hist.items())
-                        roofline["valu_issue"]["class_weighted_model_us"] = 1e6 * cycles / (VALU_SIMDS * 2.0e9)
-                        roofline["valu_issue"]["class_weighted_model"] = ("sum over PMC instruction classes of count x measured issue cycles (fp32 fma/mul/add 2.3, "
-                                                                         "transcendental 7.2, cvt 3.5, int 2.2, others 3.7) / 1024 SIMDs / 2.0 GHz sustained")
+                    # What the launch measures (profiles/r06_lighting_residency.txt): ONE vector instruction per SIMD and quad-cycle.  Round 5 printed a
+                    # "class-weighted model" here (every opcode class at its stand-alone cost: 118 us); the classes do not add up that way in a mixed
+                    # stream (profiles/r06_valu_mix_bench.txt), so the line now carries the rate that the occupancy sweep and the counters confirm.
+                    roofline["valu_issue"]["one_per_quad_cycle_us"] = 1e6 * valu * 4.0 / (VALU_SIMDS * 2.04e9)
+                    roofline["valu_issue"]["one_per_quad_cycle"] = ("SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.04 GHz, the shader clock measured under this load): "
+                                                                   "the launch alone on the machine takes this long; inside the frame the other streams' kernels share the same issue slots")
         except (OSError, KeyError, ValueError):
             pass
         # Config 4: what the anti-aliasing kernels fetch and write against their algorithmic bytes (tools/pmc_aa.sh -> profiles/aa_traffic.json;
