@@ -53,9 +53,11 @@ def test_store_conversion_word_for_word(gr):
     np.testing.assert_array_equal(got, want)
 
 
-@pytest.mark.parametrize("w,h,lights", [(256, 144, 300), (130, 75, 64)])
-def test_lighting_into_a_packed_target(gr, w, h, lights):
-    sc = Scene(w, h, lights)
+@pytest.mark.parametrize("w,h,lights,scene", [(256, 144, 300, "default"), (130, 75, 64, "default"), (480, 270, 4096, "depth_split"), (333, 77, 4096, "depth_split")])
+def test_lighting_into_a_packed_target(gr, w, h, lights, scene):
+    """(scene "depth_split" with 4096 lights: the B10G11R11 instantiations' wide-window path, two- and one-pixel form; the packed codes' tolerance
+    of one code covers what the RGBA16F test allows its two ill-conditioned pixels.)"""
+    sc = Scene(w, h, lights, scene=scene)
     sc.gbuf["emissive"] = orc.quantize_b10g11r11(sc.gbuf["emissive"])
     ref_c = orc.cluster_build(sc.rp, sc.prm, sc.lights, sc.model, sc.type_mask, sc.n, sc.res[2])
     dev = sc.build_clusters_gpu(gr)
