@@ -671,7 +671,7 @@ int gr_pq10_encode(gr_ctx *ctx, gr_stream stream, const gr_image *hdr, const gr_
 /* Fill with a 32-bit pattern (count dwords): attachment clears to a colour. */
 int gr_fill_u32(gr_ctx *ctx, gr_stream stream, void *dst, uint32_t value, size_t count);
 /* Executor self-test operation (no counterpart in the reference): out[i] = hash(i, salt, one dword of each of up to four
- * inputs).  Used by tests/cpp/graph_cases.cpp --execute to run random frame graphs on the three-stream executor and compare the
+ * inputs).  Used by tests/cpp/graph_cases.cpp --execute to run random frame graphs on the executor's streams and compare the
  * swapchain image with a serial run. */
 /* fp32 (r, g, b) triples -> B10G11R11_UFLOAT_PACK32 words: the attachment store conversion the lighting and TAA kernels apply
  * when their target has that format (closest finite packed value, ties to even; negative -> 0; +inf -> +inf; NaN -> NaN). */
