@@ -124,6 +124,42 @@ def test_lighting_wide_light_index_windows_match_oracle(gr, w, h):
         assert_rgba16f_close_but_for_ill_conditioned_pixels(imgs["hdr"].download(), brute, ulps=2.0, max_pixels=2, outer_ulps=8.0, what="wide windows vs brute force")
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_lighting_with_three_depth_layers_and_holes_matches_oracle(gr, seed):
+    """The window logic of the wide path under its worst inputs: every 16 x 8 tile mixes up to three depth layers (2-6, 14-16 and 30-36 units, in
+    blocks of 1 to 5 pixels, so that pixel PAIRS of one lane straddle layers too) with sky holes (pixels without a range) -- the gap between the
+    foreground's ranges and the rest is trimmed, the middle layer sits inside what a two-layer assumption would have dropped.  4096 lights, both
+    pixel-per-lane forms; against the oracle's exact per-pixel light sets."""
+    from util import assert_rgba16f_close_but_for_ill_conditioned_pixels
+    for w, h in ((320, 180), (251, 96)):
+        sc = Scene(w, h, 4096)
+        r = np.random.default_rng(seed * 100 + w)
+        layer = np.zeros((h, w), np.int32)
+        y = 0
+        while y < h:
+            bh = int(r.integers(1, 6))
+            x = 0
+            while x < w:
+                bw = int(r.integers(1, 6))
+                layer[y:y + bh, x:x + bw] = r.integers(0, 4)
+                x += bw
+            y += bh
+        view_z = np.choose(np.minimum(layer, 2), [r.uniform(2.0, 6.0, (h, w)), r.uniform(14.0, 16.0, (h, w)), r.uniform(30.0, 36.0, (h, w))])
+        depth = sc.cam.depth_from_view_distance(view_z).astype(np.float32)
+        depth[layer == 3] = 0.0  # sky
+        sc.gbuf["depth"] = depth
+        ref_c = orc.cluster_build(sc.rp, sc.prm, sc.lights, sc.model, sc.type_mask, sc.n, sc.res[2])
+        dev = sc.build_clusters_gpu(gr)
+        ref = orc.lighting(sc.gbuf, sc.rp, sc.prm, sc.lights, sc.type_mask, ref_c["bitmask"], ref_c["range"], synth.DIRECTIONAL_COLOR, synth.DIRECTIONAL_DIRECTION)
+        args, imgs = sc.lighting_args(gr, dev, ALL)
+        gr.check(gr.lib.gr_lighting(gr.handle, None, args))
+        gr.sync()
+        got = imgs["hdr"].download()
+        sky = depth == 0.0
+        np.testing.assert_array_equal(got[sky], sc.gbuf["emissive"][sky])
+        assert_rgba16f_close_but_for_ill_conditioned_pixels(got, ref, ulps=2.0, abs_tol=1e-4, max_pixels=3, outer_ulps=8.0, what=f"three layers {w}x{h} seed {seed}")
+
+
 def test_lighting_separate_emissive_equals_aliased(gr):
     """emissive as a distinct input attachment gives bit-identical HDR to the aliased read-modify-write form and leaves
     the G-buffer untouched."""
