@@ -447,8 +447,18 @@ void LightClusterer::build_cluster_bindless_gpu(HIP::CommandBuffer &cmd)
 	// as one grid (gr_cluster_front), then binning, which needs every light's cull data.  (gr_cluster_front can also read the
 	// arrays from the pinned staging ring itself and save the upload launch; measured, that form is slower: each of its 256
 	// z-range workgroups then fetches the 32 KB of slice intervals across PCIe.)
-	update_bindless_data(cmd);
-	cmd.barrier(VK_PIPELINE_STAGE_2_COPY_BIT, VK_ACCESS_TRANSFER_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
+	// Up to 512 lights (4 KB of slice intervals, 48 KB of records) gr_cluster_front reads the staged arrays itself and the upload launch is
+	// saved: such frames are paced by the host's runtime calls (config 2: eight launches a frame), not by what crosses PCIe.
+	static const uint32_t read_staged_below = []() {
+		const char *env = getenv("GRANITE_CLUSTER_READ_STAGED_MAX_LIGHTS"); // A/B switch; 0 = always upload first (round 5)
+		return env ? uint32_t(atoi(env)) : 512u;
+	}();
+	const bool read_staged = local_count <= read_staged_below;
+	if (!read_staged)
+	{
+		update_bindless_data(cmd);
+		cmd.barrier(VK_PIPELINE_STAGE_2_COPY_BIT, VK_ACCESS_TRANSFER_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
+	}
 	if ((resolution_z & 63) != 0)
 		throw std::logic_error("Cluster Z resolution must be a multiple of 64.");
 	if ((resolution_x & 7) != 0 || (resolution_y & 7) != 0)
@@ -483,6 +493,13 @@ void LightClusterer::build_cluster_bindless_gpu(HIP::CommandBuffer &cmd)
 	front.light_ranges = static_cast<uint32_t *>(bindless.light_ranges->get_device_pointer());
 	front.range_out = static_cast<uint32_t *>(bindless.range_buffer->get_device_pointer());
 	front.z_push = &z_push;
+	if (read_staged)
+	{
+		front.src_lights = cmd.stage(packed.lights.data(), local_count * sizeof(PositionalFragmentInfo));
+		front.src_models = cmd.stage(packed.model.data(), local_count * sizeof(mat_affine));
+		front.src_type_mask = cmd.stage(packed.type_mask, packed.parameters.num_lights_32 * sizeof(uint32_t));
+		front.src_ranges = cmd.stage(ranges.data(), ranges.size() * sizeof(uvec2));
+	}
 	cmd.check(gr_cluster_front(cmd.get_context(), cmd.get_stream(), &front), "cluster_front");
 	cmd.barrier(VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT, VK_ACCESS_2_SHADER_STORAGE_WRITE_BIT, VK_PIPELINE_STAGE_COMPUTE_SHADER_BIT,
 	            VK_ACCESS_2_SHADER_STORAGE_READ_BIT);
