@@ -546,6 +546,10 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 		// or above G = the smallest start among those; the indices strictly between Q and G (if any) are trimmed from the window.
 		const bool wide = a.list_words != 0 && win_lo <= win_hi && (win_hi >> 6u) - (win_lo >> 6u) >= 2u;
 		uint32_t gap_lo = 0u, gap_hi = 0xffffffffu; // Q and G: indices i with gap_lo < i < gap_hi are in no pixel's range
+		bool in_low[PX], in_high[PX];                // the pixel's range lies at or below Q / at or above G (neither: it has no range)
+#pragma unroll
+		for (int p = 0; p < PX; p++)
+			in_low[p] = in_high[p] = false;
 		if (wide)
 		{
 			uint32_t first_end = 0xffffffffu;
@@ -557,6 +561,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 			for (int p = 0; p < PX; p++)
 			{
 				const bool some = active[p] && px_range[p].x <= px_range[p].y, low = px_range[p].x <= first_end;
+				in_low[p] = some && low, in_high[p] = some && !low;
 				gap_lo = max(gap_lo, some && low ? px_range[p].y : 0u);
 				gap_hi = min(gap_hi, some && !low ? px_range[p].x : 0xffffffffu);
 			}
@@ -576,24 +581,32 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 			const int cx0 = __builtin_amdgcn_readlane(my_cx, 0), cx1 = __builtin_amdgcn_readlane(my_cx, 63);
 			const int cy0 = __builtin_amdgcn_readlane(my_cy, 0), cy1 = __builtin_amdgcn_readlane(my_cy, 63);
 
-			// Bounding sphere of the tile's surface points: centre = first lit pixel, radius = farthest lit pixel from it.
-			const uint64_t lit = __ballot(any_active);
-			const int first = __builtin_ctzll(lit);
-			const float3_ mine = PX == 2 && !active[0] ? s[PX - 1].pos : s[0].pos; // a lane in `lit` has one of them active
-			const float3_ centre = f3(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), first)),
-			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), first)),
-			                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), first)));
-			float off2 = 0.0f;
+			// Bounding sphere of a set of the tile's surface points (member[p]: a non-empty set): centre = its first pixel, radius = its
+			// farthest pixel from that.
+			auto bounding_sphere = [&](const bool (&member)[PX], float3_ &centre_out, float &radius_out) __attribute__((always_inline)) {
+				bool any_member = false;
 #pragma unroll
-			for (int p = 0; p < PX; p++)
-			{
-				const float3_ off = s[p].pos - centre;
-				const float mine2 = active[p] ? dot(off, off) : 0.0f;
-				off2 = p == 0 ? mine2 : fmaxf(off2, mine2);
-			}
-			// v_sqrt_f32 (1 ulp) is well inside the 1.0001 + CULL_SLACK margin
-			const float tile_radius =
-			    __builtin_amdgcn_sqrtf(__builtin_bit_cast(float, wave_minmax_u32<true>(__builtin_bit_cast(uint32_t, off2)))) * 1.0001f + CULL_SLACK;
+				for (int p = 0; p < PX; p++)
+					any_member = any_member || member[p];
+				const int first = __builtin_ctzll(__ballot(any_member));
+				const float3_ mine = PX == 2 && !member[0] ? s[PX - 1].pos : s[0].pos; // a lane of the ballot has one of them in the set
+				centre_out = f3(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), first)),
+				                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), first)),
+				                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), first)));
+				float off2 = 0.0f;
+#pragma unroll
+				for (int p = 0; p < PX; p++)
+				{
+					const float3_ off = s[p].pos - centre_out;
+					const float mine2 = member[p] ? dot(off, off) : 0.0f;
+					off2 = p == 0 ? mine2 : fmaxf(off2, mine2);
+				}
+				// v_sqrt_f32 (1 ulp) is well inside the 1.0001 + CULL_SLACK margin
+				radius_out = __builtin_amdgcn_sqrtf(__builtin_bit_cast(float, wave_minmax_u32<true>(__builtin_bit_cast(uint32_t, off2)))) * 1.0001f + CULL_SLACK;
+			};
+			float3_ centre;
+			float tile_radius;
+			bounding_sphere(active, centre, tile_radius); // the lit pixels of the tile
 
 			LV_STAMP_MARK(1); // slice window, cells, bounding sphere
 			LV_STAMP_LAP_BEGIN();
@@ -608,7 +621,7 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 			//     workgroup's dynamic LDS, which the launcher sizes anyway to cap the kernel's residency (gr_lighting).
 			const int chunk_lo = int(win_lo >> 6u), chunk_hi = int(win_hi >> 6u);
 			// One turn: up to 64 candidate lights, one per lane, culled against the tile and staged; then the walks over the survivors.
-			auto turn = [&](const uint32_t light_index, const bool candidate) __attribute__((always_inline)) {
+			auto turn = [&](const uint32_t light_index, const bool candidate, const float3_ &centre, const float tile_radius) __attribute__((always_inline)) {
 				// ---- cull: one light per lane ----
 				bool keep = false;
 				bool second = false; // walked with the cone body: spot lights, and point lights of radius < 1 / 8
@@ -698,11 +711,23 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 						}
 						candidate = ((word >> (uint32_t(lane) & 31u)) & 1u) != 0u;
 					}
-					turn(light_index, candidate);
+					turn(light_index, candidate, centre, tile_radius);
 				}
 			}
 			else
 			{
+				// A tile with a gap holds two groups of pixels, those whose ranges lie below it and those above (foreground and background), and
+				// ONE sphere around both is as wide as the scene is deep: no light would be culled by it.  A light of the lower part of the
+				// window is in no range of the upper group (it adds exactly 0 there, as every light outside a pixel's range does), so it is
+				// culled against the lower group's sphere alone, and the other way round.
+				const bool two_groups = gap_hi != 0xffffffffu && gap_hi > gap_lo + 1u;
+				float3_ centre_low = centre, centre_high = centre;
+				float radius_low = tile_radius, radius_high = tile_radius;
+				if (two_groups)
+				{
+					bounding_sphere(in_low, centre_low, radius_low);
+					bounding_sphere(in_high, centre_high, radius_high);
+				}
 				uint16_t *const list = reinterpret_cast<uint16_t *>(lv_dynamic_lds) + wave * (a.list_words * 32);
 				const int word_last = int(win_hi >> 5u);
 				for (int span_word = int(win_lo >> 5u); span_word <= word_last; span_word += a.list_words)
@@ -732,7 +757,11 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 					for (int next = 0; next < list_count; next += 64)
 					{
 						const bool candidate = next + lane < list_count;
-						turn(candidate ? uint32_t(list[next + lane]) : 0u, candidate);
+						const uint32_t light_index = candidate ? uint32_t(list[next + lane]) : 0u;
+						const bool upper = light_index >= gap_hi; // (without two groups both spheres are the tile's)
+						turn(light_index, candidate,
+						     f3(upper ? centre_high.x : centre_low.x, upper ? centre_high.y : centre_low.y, upper ? centre_high.z : centre_low.z),
+						     upper ? radius_high : radius_low);
 					}
 					__builtin_amdgcn_wave_barrier(); // the list is rewritten by the next span
 				}
