@@ -685,10 +685,19 @@ __device__ __forceinline__ void shade_tile(const KernelArgs &a, const int tile_x
 				LV_STAMP_LAP(2); // gather + cull
 
 				// ---- shade: PX pixels per lane, lights broadcast from LDS; each list in index order, its body without a light-type branch ----
-				for (uint64_t todo = kept & ~seconds; todo != 0ull; todo &= todo - 1ull)
-					shade_positional<PX, false>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
-				for (uint64_t todo = seconds; todo != 0ull; todo &= todo - 1ull)
-					shade_positional<PX, true>(s, slots + __builtin_ctzll(todo) * (LIGHT_SLOT_BYTES / 16), result);
+				// (the visited bit is cleared by s_bitset0_b64: one scalar instruction where `todo &= todo - 1` is three on 64 bits)
+				for (uint64_t todo = kept & ~seconds; todo != 0ull;)
+				{
+					const int bit = __builtin_ctzll(todo);
+					asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit));
+					shade_positional<PX, false>(s, slots + bit * (LIGHT_SLOT_BYTES / 16), result);
+				}
+				for (uint64_t todo = seconds; todo != 0ull;)
+				{
+					const int bit = __builtin_ctzll(todo);
+					asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit));
+					shade_positional<PX, true>(s, slots + bit * (LIGHT_SLOT_BYTES / 16), result);
+				}
 				LV_STAMP_LAP(3); // the two walks
 				__builtin_amdgcn_wave_barrier(); // the slots are rewritten by the next turn
 			};
