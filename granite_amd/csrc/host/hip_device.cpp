@@ -408,6 +408,9 @@ void Device::next_frame_context()
 				break;
 		}
 	}
+	// every stream's newest record of age lead + 1 or more has now been seen complete, and with it (the streams are in order, every stream
+	// handed out in a frame is fenced at the end of it) all work of the frames up to frame_number - (lead + 1)
+	completed_through = frame_number > lead + 1u ? frame_number - (lead + 1u) : 0u;
 	staging[staging_index].offset = 0;
 }
 

@@ -188,6 +188,9 @@ public:
 	{
 		return physical_stream(int(type), frame_a) == physical_stream(int(type), frame_b);
 	}
+	// Every launch, copy and event record the executor's streams were given in frames up to this one (device frame numbers) has completed: what
+	// frame pacing waited for on the host in next_frame_context().  An event recorded in such a frame needs neither a query nor a wait.
+	uint64_t get_completed_frame() const { return completed_through; }
 	// Number of the frame being enqueued (from 1; advanced by next_frame_context()).
 	uint64_t get_frame_number() const { return frame_number; }
 	void next_frame_context();
@@ -236,6 +239,7 @@ private:
 	unsigned staging_index = 0;
 	uint64_t frame_number = 1; // of the frame being enqueued (from 1); its slot is staging[staging_index] = staging[(frame_number - 1) % StagingFrames]
 	mutable bool stream_dirty[int(CommandBuffer::Type::Count)] = {};
+	uint64_t completed_through = 0; // see get_completed_frame()
 	uint64_t completed_frame[int(CommandBuffer::Type::Count)][2] = {}; // per stream (and parity of the front's two): the newest frame whose fence the pacing has seen complete
 	size_t allocated_bytes = 0;
 	double blocked_seconds = 0.0;

@@ -1472,8 +1472,14 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 	last_device_frame = device_.get_frame_number();
 	int current_pass = -1;
 	std::vector<void *> waited;
-	auto wait_for = [&](hipStream_t stream, void *event, const char *kind = "", unsigned resource = 0, int src_pass = -1, uint64_t src_frame = 0) {
+	const uint64_t device_completed = device_.get_completed_frame();
+	auto wait_for = [&](hipStream_t stream, void *event, const char *kind = "", unsigned resource = 0, int src_pass = -1, uint64_t src_frame = 0,
+	                    uint64_t src_device_frame = 0) {
 		if (!event || std::find(waited.begin(), waited.end(), event) != waited.end())
+			return;
+		// recorded in a frame the host has already waited for (frame pacing: three frames back with the default lead): complete, no call at all
+		// -- the write-after-read dependencies on the rotating copies' previous users are all of this kind
+		if (src_device_frame != 0 && src_device_frame <= device_completed)
 			return;
 		waited.push_back(event);
 		// The host runs one to two frames ahead of the GPU (Device::next_frame_context), so most cross-stream dependencies (anything on work of two
@@ -1498,14 +1504,15 @@ void RenderGraph::enqueue_render_passes(HIP::Device &device_, TaskComposer &comp
 	auto acquire = [&](hipStream_t stream, int stream_index, const std::vector<unsigned> &reads, const std::vector<unsigned> &writes) {
 		for (unsigned r : reads)
 			if (physical_sync[r].last_write && !in_order_with(stream_index, physical_sync[r].write_stream, physical_sync[r].write_device_frame))
-				wait_for(stream, physical_sync[r].last_write, "RAW", r, physical_sync[r].write_pass, physical_sync[r].write_frame);
+				wait_for(stream, physical_sync[r].last_write, "RAW", r, physical_sync[r].write_pass, physical_sync[r].write_frame, physical_sync[r].write_device_frame);
 		for (unsigned w : writes)
 		{
 			if (physical_sync[w].last_write && !in_order_with(stream_index, physical_sync[w].write_stream, physical_sync[w].write_device_frame))
-				wait_for(stream, physical_sync[w].last_write, "WAW", w, physical_sync[w].write_pass, physical_sync[w].write_frame);
+				wait_for(stream, physical_sync[w].last_write, "WAW", w, physical_sync[w].write_pass, physical_sync[w].write_frame, physical_sync[w].write_device_frame);
 			for (int other = 0; other < StreamCount; other++)
 				if (!in_order_with(stream_index, other, physical_sync[w].read_device_frame[other]))
-					wait_for(stream, physical_sync[w].last_read[other], "WAR", w, physical_sync[w].read_pass[other], physical_sync[w].read_frame[other]);
+					wait_for(stream, physical_sync[w].last_read[other], "WAR", w, physical_sync[w].read_pass[other], physical_sync[w].read_frame[other],
+					         physical_sync[w].read_device_frame[other]);
 		}
 	};
 	// One event per RUN of consecutive passes on the same stream (not per pass): the accesses of every pass of the run are

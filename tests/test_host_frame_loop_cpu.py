@@ -37,13 +37,14 @@ a.close()
 '''
 
 
-def run(w, h, lights, pending=False):
+def run(w, h, lights, pending=False, extra_env=None):
     if not os.path.exists(STUB) or os.path.getmtime(STUB) < os.path.getmtime(os.path.join(os.path.dirname(STUB), "hip_stub.cpp")):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(STUB)])
     env = dict(os.environ, LD_PRELOAD=STUB)
     env.pop("GRANITE_LIGHT_PREFETCH_MIN", None)  # tests/test_gpu_app.py lowers it for its own process at import: this test is about the default
     if pending:
         env["HIP_STUB_EVENTS_PENDING"] = "1"  # a recorded event never reads as complete: every cross-stream dependency takes the wait path
+    env.update(extra_env or {})
     r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT, "stub": STUB}, str(w), str(h), str(lights), "1" if pending else "0"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
@@ -85,10 +86,15 @@ def test_1080p_frame_asks_for_seven_launches_and_packs_its_lights_in_place():
 
 
 def test_every_cross_stream_wait_follows_its_record():
-    """With events that never read as complete every dependency between the three streams is a hipStreamWaitEvent: frames ahead of the
-    device must wait on the hand-over ring (WAR), the back of the frame on the front (RAW) -- and never on an event before its record."""
+    """With events that never read as complete every dependency between the streams that the host cannot rule out is a hipStreamWaitEvent --
+    and never on an event before its record.  With the default lead of two frames the host has waited for frame N - 3 before it enqueues frame N
+    (Device::get_completed_frame), so the write-after-read dependencies on the hand-over ring's previous users (three copies: frame N - 3) cost
+    no call at all and what is left are the read-after-write waits inside the frame (the back on the front, lighting on the cluster build).  With
+    a lead of three frames the host only knows frame N - 4 complete: the ring's waits are back."""
     r = run(960, 540, 300, pending=True)
-    assert r["stream_waits"] >= 3 and r["waits_before_record"] == 0, r
+    assert r["stream_waits"] >= 2 and r["waits_before_record"] == 0, r
+    longer = run(960, 540, 300, pending=True, extra_env={"GRANITE_HOST_LEAD_FRAMES": "3"})
+    assert longer["stream_waits"] >= r["stream_waits"] + 1 and longer["waits_before_record"] == 0, (r, longer)
 
 
 def test_one_record_and_only_waits_sit_between_two_lighting_launches():
