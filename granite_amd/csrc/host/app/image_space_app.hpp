@@ -144,6 +144,7 @@ private:
 	// Physical targets that already hold the current synthetic upload (an attachment the executor double-buffers has two).
 	std::unordered_set<const void *> filled_targets;
 	bool needs_fill(const HIP::Image &target) { return filled_targets.insert(target.get_device_pointer()).second; }
+	bool is_filled(const HIP::Image &target) const { return filled_targets.count(target.get_device_pointer()) != 0; }
 
 	std::vector<HIP::ImageHandle> swapchain;
 	unsigned swapchain_index = 0;
